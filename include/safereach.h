@@ -1,0 +1,149 @@
+/* safereach.h -- C-ABI of libsafereach.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the GP-dynamics inference + ellipsoid reachability hot path of
+ * befelix/safe-exploration.  The reference has NO native interface (pure Python); the Python
+ * surface it exposes is mirrored by safe_exploration_amd/ and every entry point below names the
+ * reference function(s) it replaces (paths relative to /root/reference/safe_exploration/).
+ *
+ * Conventions
+ *   - plain C, fp64, row-major; every array argument is a DEVICE pointer owned by the caller
+ *     unless marked [host]; the library owns only what hangs off its opaque handle.
+ *   - every function returns 0 on success, <0 on error (SR_E*); sr_last_error() returns a
+ *     thread-local message.  Nothing throws across the boundary.
+ *   - work is enqueued asynchronously on the hipStream_t passed as `void* stream` (NULL = default
+ *     stream).  A handle is bound to one device and is not thread-safe.
+ *   - n_out (GP outputs) == n_s for the reachability entry points; D = n_s + n_u.
+ */
+#ifndef SAFEREACH_H
+#define SAFEREACH_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sr_gp* sr_gp_t;
+
+#define SR_OK          0
+#define SR_EINVAL     -1   /* bad argument / shape                        */
+#define SR_EHIP       -2   /* HIP runtime error (no device, OOM, launch)  */
+#define SR_ENOTPD     -3   /* Cholesky breakdown: matrix not positive definite */
+#define SR_ESTATE     -4   /* call order violated (e.g. predict before factorize) */
+#define SR_EUNSUPPORTED -5 /* dimension outside compiled range (n_s<=8, n_u<=4, D<=12) */
+
+/* kernel ids for sr_prof_get() */
+#define SR_K_GRAM      0
+#define SR_K_POTRF     1
+#define SR_K_GEMM      2
+#define SR_K_KSTAR     3   /* RBF cross-covariance + mean + mean-Jacobian              */
+#define SR_K_VAR       4   /* triangular fp64-MFMA contraction |W k*|^2 (dominant)     */
+#define SR_K_FINAL     5
+#define SR_K_ELL       6   /* ellipsoid propagate/sum                                  */
+#define SR_K_COUNT     8
+
+int         sr_version(void);
+const char* sr_last_error(void);
+/* number of visible HIP devices; SR_EHIP (and *n = 0) if the runtime reports none. */
+int         sr_device_count(int* n);
+
+/* ---- model life cycle --------------------------------------------------------------------
+ * replaces: SimpleGPModel.__init__/train(opt_hyp=False)/update_model  ssm_gpy/gaussian_process.py:32-70,189-278,347-419
+ * One handle = n_out independent ARD-RBF GPs over the same N training inputs Z (N x D). */
+int sr_gp_create (sr_gp_t* h, int device, int N, int D, int n_out);
+int sr_gp_destroy(sr_gp_t h);
+
+/* Z N x D, Y N x n_out, lengthscale n_out x D, signal_var n_out, noise_var n_out (noise_var must
+ * already include every diagonal term: sigma_n^2 + noise_diag(1e-5) + GPy's 1e-8 jitter). */
+int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const double* lengthscale,
+                   const double* signal_var, const double* noise_var, void* stream);
+
+/* K_d = rbf(Z,Z) + noise I ; K_d = U^T U (blocked fp64-MFMA Cholesky) ; W = U^-T ; alpha = K^-1 y.
+ * replaces the GPy posterior the reference caches as inv_K/beta (ssm_gpy/gaussian_process.py:255-275).
+ * info [host, n_out ints]: 0, or 1-based index of the first non-positive pivot (then returns SR_ENOTPD).
+ * Synchronises the stream before returning. */
+int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
+
+/* padded leading dimension Np (multiple of 128) of the factor matrices. */
+int sr_gp_padded_n(sr_gp_t h, long* Np);
+
+/* Export / import the cached posterior state (what a broadcast receiver needs):
+ * alpha n_out x N ; Wt n_out x Np x Np = U^-1 (upper triangular, row-major, zero below the diagonal).
+ * Either pointer may be NULL.  import marks the handle as factorized. */
+int sr_gp_export(sr_gp_t h, double* alpha, double* Wt, void* stream);
+int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, void* stream);
+
+/* explicit (K + noise I)^-1 of output d, N x N -- the reference's `inv_K[d]` attribute
+ * (ssm_gpy/gaussian_process.py:258-262).  Cold path; needs factorize() on this handle. */
+int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream);
+
+/* ---- batched GP posterior ------------------------------------------------------------------
+ * replaces: SimpleGPModel.predict / predictive_gradients  ssm_gpy/gaussian_process.py:546-596
+ * (formulas: ssm_gpy/gp_models_utils_casadi.py:17-40,160-197).
+ * Xq T x D -> mu T x n_out, var T x n_out (clipped at 1e-15), jac T x n_out x D (may be NULL). */
+int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, double* var, double* jac,
+                  void* stream);
+
+/* ---- one-step reachability, batched over T queries ------------------------------------------
+ * replaces: gp_reachability.onestep_reachability  gp_reachability.py:19-156
+ *   (+ utils.compute_remainder_overapproximations utils.py:108-144,
+ *      utils_ellipsoid.ellipsoid_from_rectangle / sum_two_ellipsoids utils_ellipsoid.py:63-94,197-233)
+ * p T x n_s ; q T x n_s x n_s or NULL (point branch) ; k_ff T x n_u ; k_fb T x n_u x n_s (required
+ * iff q != NULL) ; a n_s x n_s ; b n_s x n_u ; l_mu, l_sigma n_s.
+ * -> p_out T x n_s ; q_out T x n_s x n_s ; var_out T x n_s or NULL.
+ * n_bad: device int or NULL; atomically incremented once per query whose box half-widths were not
+ * all > 0 -- the condition on which the reference raises AssertionError
+ * (utils_ellipsoid.py:226-228).  The caller zeroes it. */
+int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double* q, const double* k_ff,
+                     const double* k_fb, const double* a, const double* b, const double* l_mu,
+                     const double* l_sigma, double c_safety, double* p_out, double* q_out,
+                     double* var_out, int* n_bad, void* stream);
+
+/* ---- multi-step reachability, batched over T trajectories ------------------------------------
+ * replaces: gp_reachability.multistep_reachability  gp_reachability.py:159-212
+ * p0 T x n_s ; q0 T x n_s x n_s or NULL ; k_fb0 T x n_u x n_s or NULL (required iff q0 != NULL) ;
+ * k_ff T x H x n_u ; k_fb T x (H-1) x n_u x n_s (may be NULL when H == 1).
+ * -> p_all T x H x n_s ; q_all T x H x n_s x n_s. */
+int sr_multistep_reach(sr_gp_t h, long T, int H, const double* p0, const double* q0,
+                       const double* k_fb0, const double* k_ff, const double* k_fb, const double* a,
+                       const double* b, const double* l_mu, const double* l_sigma, double c_safety,
+                       double* p_all, double* q_all, int* n_bad, void* stream);
+
+/* ---- ellipsoid step alone (GP outputs supplied by the caller: any StateSpaceModel) -----------
+ * replaces: the algebra of gp_reachability.py:65-156 after `ssm(x, u)` returned.
+ * mu T x n_s ; var T x n_s ; jac T x n_s x (n_s+n_u) (ignored in the point branch, may be NULL). */
+int sr_ellipsoid_step(int device, long T, int n_s, int n_u, const double* p, const double* q,
+                      const double* k_ff, const double* k_fb, const double* mu, const double* var,
+                      const double* jac, const double* a, const double* b, const double* l_mu,
+                      const double* l_sigma, double c_safety, double* p_out, double* q_out,
+                      int* n_bad, void* stream);
+
+/* replaces: utils.compute_remainder_overapproximations  utils.py:108-144 (batched)
+ * q T x n_s x n_s, k_fb T x n_u x n_s -> u_mu T x n_s, u_sigma T x n_s */
+int sr_remainder_overapprox(int device, long T, int n_s, int n_u, const double* q, const double* k_fb,
+                            const double* l_mu, const double* l_sigma, double* u_mu, double* u_sigma,
+                            void* stream);
+
+/* replaces: gp_reachability.lin_ellipsoid_safety_distance  gp_reachability.py:215-250 (batched)
+ * p T x n_s, q T x n_s x n_s, h_mat m x n_s, h_vec m -> d T x m */
+int sr_safety_distance(int device, long T, int n_s, int m, const double* p, const double* q,
+                       const double* h_mat, const double* h_vec, double c_safety, double* d,
+                       void* stream);
+
+/* ---- tuning / measurement -------------------------------------------------------------------- */
+/* max queries processed per internal pass (workspace = n_out * Np * chunk * 8 B); default 65536. */
+int sr_gp_set_chunk(sr_gp_t h, long chunk);
+/* query tiles per scheduling group of the variance kernel (L2/XCD locality knob); default 16. */
+int sr_gp_set_var_group(sr_gp_t h, int group);
+/* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
+ * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.
+ * Exposed so the fp64-MFMA tile can be tested in isolation. */
+int sr_test_gemm_tn(int device, const double* A, long lda, const double* B, long ldb, double* C,
+                    long ldc, int M, int N, int K, double alpha, double beta, int mode, void* stream);
+/* per-kernel hipEvent timing inside the library (adds an event pair per launch while enabled). */
+int sr_prof_enable(sr_gp_t h, int on);
+int sr_prof_reset (sr_gp_t h);
+int sr_prof_get   (sr_gp_t h, int kernel_id, double* ms_total, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFEREACH_H */

@@ -1,0 +1,314 @@
+"""NumPy/SciPy restatement of the reference's GP-inference + ellipsoid-reachability path.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product package.
+
+Pinning status
+--------------
+* Ellipsoid / reachability algebra (``onestep_reachability`` ...): PINNED against the
+  reference's own functions, imported in the build container from /root/reference
+  (``tests/golden/make_golden.py``); fixtures in ``tests/golden/reach_*.npz``.
+* RBF kernel + posterior formulas (``rbf_kernel``, ``gp_predict``): checked against the
+  reference's in-tree restatement ``gp_models_utils_casadi._k_rbf/_unscaled_dist/gp_pred``
+  executed on numbers (casadi's 6 array functions replaced by numpy equivalents in the
+  generator script only); fixtures ``tests/golden/gp_*.npz``.
+* GPy boundary (``GPRegression`` internals: +1e-8 jitter, 1e-15 variance clip, r2>=0 clip):
+  **parity unpinned** -- GPy (unpinned in the reference's setup.py:20) is not installed and
+  no stored GPy outputs exist in the reference tree.  Those three details are restated from
+  knowledge of GPy and flagged below.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/safe_exploration/).
+"""
+import numpy as np
+import scipy.linalg as sla
+
+GPY_JITTER = 1e-8        # GPy exact_gaussian_inference adds 1e-8 to diag(K) [GPy, unverifiable here]
+GPY_VAR_CLIP = 1e-15     # GPy GP._raw_predict clips var to >=1e-15       [GPy, unverifiable here]
+
+
+# --------------------------------------------------------------------------- kernel
+def unscaled_dist_sq(x, y):
+    """r^2 = -2 x y^T + |x|^2 + |y|^2, clipped at 0.
+
+    ssm_gpy/gp_models_utils_casadi.py:160-174 (mirrors GPy stationary._unscaled_dist,
+    which additionally clips r2 at 0 before the sqrt).
+    """
+    x1sq = np.sum(x ** 2, axis=1)
+    x2sq = np.sum(y ** 2, axis=1)
+    r2 = -2.0 * x.dot(y.T) + x1sq[:, None] + x2sq[None, :]
+    return np.clip(r2, 0.0, np.inf)
+
+
+def rbf_kernel(x, y, variance, lengthscale):
+    """ARD RBF k(x,y) = variance * exp(-0.5 r^2), r = dist(x/l, y/l).
+
+    ssm_gpy/gp_models_utils_casadi.py:17-40.
+    """
+    ls = np.asarray(lengthscale, dtype=np.float64).reshape(1, -1)
+    r2 = unscaled_dist_sq(x / ls, y / ls)
+    return variance * np.exp(-0.5 * r2)
+
+
+# --------------------------------------------------------------------------- fit
+def gp_fit(Z, Y, lengthscale, signal_var, noise_var):
+    """Cache what SimpleGPModel.train(opt_hyp=False) caches: beta and inv_K per output.
+
+    ssm_gpy/gaussian_process.py:231-275: per output d a GPRegression(Z, y_d, kern_d); noise
+    fixed (noise_var here ALREADY includes the +1e-5 ``noise_diag`` of :189,252-253);
+    inv_K[d] = posterior.woodbury_inv = (K + (noise+1e-8) I)^-1, beta[:,d] = woodbury_vector.
+
+    Parameters: Z (N,D); Y (N,n_out); lengthscale (n_out,D); signal_var (n_out,); noise_var (n_out,)
+    Returns: beta (N,n_out), inv_K list of (N,N), chol list of lower factors L (K_y = L L^T)
+    """
+    Z = np.asarray(Z, np.float64)
+    Y = np.asarray(Y, np.float64)
+    N, n_out = Y.shape
+    beta = np.empty((N, n_out))
+    inv_K, chol = [], []
+    for d in range(n_out):
+        K = rbf_kernel(Z, Z, signal_var[d], lengthscale[d])
+        Ky = K + (noise_var[d] + GPY_JITTER) * np.eye(N)
+        L = sla.cholesky(Ky, lower=True)
+        Li = sla.solve_triangular(L, np.eye(N), lower=True)
+        Ki = Li.T.dot(Li)          # GPy pdinv: dpotri on the Cholesky factor
+        inv_K.append(Ki)
+        chol.append(L)
+        beta[:, d] = sla.cho_solve((L, True), Y[:, d])
+    return beta, inv_K, chol
+
+
+# --------------------------------------------------------------------------- predict
+def gp_predict(x_new, Z, beta, inv_K, lengthscale, signal_var, compute_gradients=True):
+    """Batched posterior mean / variance / mean-Jacobian, EXPLICIT-INVERSE route.
+
+    mean, var: ssm_gpy/gp_models_utils_casadi.py:177-197 (gp_pred):
+        mu = k* beta ; sigma2 = k(x,x) - sum((k* K^-1) o k*, axis=1)
+    batched shapes: ssm_gpy/gaussian_process.py:546-568 (predict) -> (T,n_out),(T,n_out)
+    jacobian: ssm_gpy/gaussian_process.py:570-596 (predictive_gradients) -> (T,n_out,D);
+        RBF closed form d mu/dx = sum_i beta_i k*_i (z_i - x)/l^2
+        (what CasADi AD of gp_pred yields, gp_models_utils_casadi.py:272-280).
+    Variance clipped at 1e-15 like GPy's _raw_predict [unverifiable here].
+    """
+    x_new = np.asarray(x_new, np.float64)
+    T, D = x_new.shape
+    n_out = beta.shape[1]
+    mu = np.empty((T, n_out))
+    var = np.empty((T, n_out))
+    jac = np.empty((T, n_out, D)) if compute_gradients else None
+    for d in range(n_out):
+        ks = rbf_kernel(x_new, Z, signal_var[d], lengthscale[d])      # (T,N)
+        mu[:, d] = ks.dot(beta[:, d])
+        var[:, d] = signal_var[d] - np.sum(ks.dot(inv_K[d]) * ks, axis=1)
+        if compute_gradients:
+            w = ks * beta[:, d][None, :]                              # (T,N)
+            l2 = np.asarray(lengthscale[d], np.float64) ** 2
+            # sum_i w_ti (z_ij - x_tj) / l_j^2
+            jac[:, d, :] = (w.dot(Z) - w.sum(axis=1)[:, None] * x_new) / l2[None, :]
+    var = np.clip(var, GPY_VAR_CLIP, np.inf)
+    if compute_gradients:
+        return mu, var, jac
+    return mu, var
+
+
+def gp_predict_chol(x_new, Z, beta, chol, lengthscale, signal_var):
+    """Second algebraic route (triangular solve against the cached factor):
+    sigma2 = k(x,x) - |L^-1 k*|^2.  Used to cross-check gp_predict."""
+    x_new = np.asarray(x_new, np.float64)
+    T = x_new.shape[0]
+    n_out = beta.shape[1]
+    mu = np.empty((T, n_out))
+    var = np.empty((T, n_out))
+    for d in range(n_out):
+        ks = rbf_kernel(x_new, Z, signal_var[d], lengthscale[d])
+        mu[:, d] = ks.dot(beta[:, d])
+        v = sla.solve_triangular(chol[d], ks.T, lower=True)
+        var[:, d] = signal_var[d] - np.sum(v * v, axis=0)
+    return mu, np.clip(var, GPY_VAR_CLIP, np.inf)
+
+
+def gp_linearize_extras(x, Z, beta, inv_K, lengthscale, signal_var):
+    """Single-query d sigma2/dx and Hessian of mu (contract
+    state_space_models.py:106-138).  RBF closed forms:
+        d sigma2/dx = -2 sum_i (K^-1 k*)_i k*_i (z_i - x)/l^2
+        d2 mu/dx2   = sum_i beta_i k*_i [ (z_i-x)(z_i-x)^T/(l^2 l^2^T) - diag(l^-2) ]
+    Returns jac_var (n_out,D), hess_mu (n_out,D,D)."""
+    x = np.asarray(x, np.float64).reshape(1, -1)
+    D = x.shape[1]
+    n_out = beta.shape[1]
+    jv = np.empty((n_out, D))
+    hm = np.empty((n_out, D, D))
+    for d in range(n_out):
+        l2 = np.asarray(lengthscale[d], np.float64) ** 2
+        ks = rbf_kernel(x, Z, signal_var[d], lengthscale[d])[0]
+        diff = (Z - x) / l2[None, :]                                  # (N,D)
+        g = inv_K[d].dot(ks)
+        jv[d] = -2.0 * (g * ks).dot(diff)
+        w = beta[:, d] * ks
+        hm[d] = np.einsum('i,ij,ik->jk', w, diff, diff) - np.diag(w.sum() / l2)
+    return jv, hm
+
+
+# --------------------------------------------------------------------------- ellipsoids
+def ellipsoid_from_rectangle(u_b):
+    """utils_ellipsoid.py:197-233: q = diag(n * u_b^2); asserts u_b > 0."""
+    u_b = np.asarray(u_b)
+    assert u_b.ndim == 1
+    assert np.all(u_b > 0)
+    return np.diag(len(u_b) * u_b ** 2)
+
+
+def sum_two_ellipsoids(p_1, q_1, p_2, q_2, c=None):
+    """utils_ellipsoid.py:63-94 (trace-optimal c when None)."""
+    if c is None:
+        c = np.sqrt(np.trace(q_1) / np.trace(q_2))
+    return p_1 + p_2, (1 + (1. / c)) * q_1 + (1 + c) * q_2
+
+
+def compute_remainder_overapproximations(q, k_fb, l_mu, l_sigma):
+    """utils.py:108-144: r^2 = max eig(Q (I + K^T K)); u_mu = l_mu r^2; u_sigma = l_sigma r.
+    The reference takes scipy.linalg.eig (complex dtype, zero imaginary part); here the real
+    part is returned."""
+    n_u, n_s = np.shape(k_fb)
+    s = np.hstack((np.eye(n_s), k_fb.T))
+    b = s.dot(s.T)
+    evals = sla.eigvals(q.dot(b))
+    r_sqr = np.max(evals.real)
+    return l_mu * r_sqr, l_sigma * np.sqrt(r_sqr)
+
+
+def lin_ellipsoid_safety_distance(p_center, q_shape, h_mat, h_vec, c_safety=1.0):
+    """gp_reachability.py:215-250."""
+    d_center = h_mat.dot(p_center)
+    d_shape = c_safety * np.sqrt(np.sum(q_shape.dot(h_mat.T) * h_mat.T, axis=0)[:, None])
+    return d_center + d_shape - h_vec
+
+
+def distance_to_center(samples, p_center, q_shape):
+    """utils_ellipsoid.py:36-60."""
+    pc = samples - p_center.T
+    return np.sum(pc * sla.solve(q_shape, pc.T).T, axis=1)
+
+
+def sample_inside_polytope(x, a, b):
+    """utils.py:38-56."""
+    c = a.dot(x.T) - b.reshape(-1, 1)
+    return np.all(c < 0, axis=0)
+
+
+# --------------------------------------------------------------------------- reachability
+def onestep_reachability_from_gp(p, q, k_ff, k_fb, mu, var, jac, l_mu, l_sigma, c_safety, a, b):
+    """One query of gp_reachability.py:19-156 given the GP outputs (mu,var (n_s,), jac (n_s,D)).
+
+    p (n_s,), q (n_s,n_s) or None, k_ff (n_u,), k_fb (n_u,n_s) or None.
+    Returns p1 (n_s,), q1 (n_s,n_s) real."""
+    n_s = p.shape[0]
+    if q is None:                                   # gp_reachability.py:65-88
+        q1 = ellipsoid_from_rectangle(c_safety * np.sqrt(var))
+        p1 = a.dot(p) + b.dot(k_ff) + mu
+        return p1, q1
+    a_mu, b_mu = jac[:, :n_s], jac[:, n_s:]         # :110-111
+    H = a + a_mu + (b_mu + b).dot(k_fb)             # :114
+    p0 = mu + a.dot(p) + b.dot(k_ff)                # :115
+    Q0 = H.dot(q).dot(H.T)                          # :117
+    ub_mean, ub_sigma = compute_remainder_overapproximations(q, k_fb, l_mu, l_sigma)  # :125
+    b_sigma_eps = c_safety * (np.sqrt(var) + ub_sigma)                                 # :127
+    Qs = ellipsoid_from_rectangle(b_sigma_eps)      # :129
+    Qm = ellipsoid_from_rectangle(ub_mean)          # :136
+    _, QL = sum_two_ellipsoids(0, Qs, 0, Qm)        # :143
+    p1, q1 = sum_two_ellipsoids(0, QL, p0, Q0)      # :148
+    return p1, q1
+
+
+def _predict_one(model, z):
+    mu, var, jac = gp_predict(z[None, :], model["Z"], model["beta"], model["inv_K"],
+                              model["lengthscale"], model["signal_var"], True)
+    return mu[0], var[0], jac[0]
+
+
+def onestep_reachability_batch(model, p, q, k_ff, k_fb, l_mu, l_sigma, c_safety=1.0, a=None, b=None):
+    """Batched (leading T axis) one-step reachability, vectorised GP + per-query ellipsoid algebra.
+
+    model: dict(Z, beta, inv_K, lengthscale, signal_var).  p (T,n_s); q (T,n_s,n_s) or None;
+    k_ff (T,n_u); k_fb (T,n_u,n_s) or None.  Returns p1 (T,n_s), q1 (T,n_s,n_s), var (T,n_s)."""
+    T, n_s = p.shape
+    n_u = k_ff.shape[1]
+    if a is None:
+        a, b = np.eye(n_s), np.zeros((n_s, n_u))
+    x = np.hstack((p, k_ff))
+    mu, var, jac = gp_predict(x, model["Z"], model["beta"], model["inv_K"],
+                              model["lengthscale"], model["signal_var"], True)
+    p1 = np.empty((T, n_s))
+    q1 = np.empty((T, n_s, n_s))
+    for t in range(T):
+        p1[t], q1[t] = onestep_reachability_from_gp(
+            p[t], None if q is None else q[t], k_ff[t], None if k_fb is None else k_fb[t],
+            mu[t], var[t], jac[t], l_mu, l_sigma, c_safety, a, b)
+    return p1, q1, var
+
+
+def multistep_reachability_batch(model, p0, k_fb, k_ff, l_mu, l_sigma, q0=None, c_safety=1.0,
+                                 a=None, b=None, k_fb_init=None):
+    """gp_reachability.py:159-212 with a leading T axis.
+    k_fb (T,H-1,n_u,n_s), k_ff (T,H,n_u), k_fb_init (T,n_u,n_s) or None (needed iff q0 given).
+    Returns p_all (T,H,n_s), q_all (T,H,n_s,n_s)."""
+    T, H, n_u = k_ff.shape
+    n_s = p0.shape[1]
+    p_all = np.empty((T, H, n_s))
+    q_all = np.empty((T, H, n_s, n_s))
+    p, q, _ = onestep_reachability_batch(model, p0, q0, k_ff[:, 0], k_fb_init, l_mu, l_sigma,
+                                         c_safety, a, b)
+    p_all[:, 0], q_all[:, 0] = p, q
+    for i in range(1, H):
+        p, q, _ = onestep_reachability_batch(model, p, q, k_ff[:, i], k_fb[:, i - 1], l_mu, l_sigma,
+                                             c_safety, a, b)
+        p_all[:, i], q_all[:, i] = p, q
+    return p_all, q_all
+
+
+# --------------------------------------------------------------------------- vectorised CPU baseline
+def onestep_reachability_vectorised(model, p, q, k_ff, k_fb, l_mu, l_sigma, c_safety, a, b):
+    """'B-vec' CPU baseline: same algebra as onestep_reachability_batch's ellipsoid
+    branch but with the per-query algebra vectorised over T (np.linalg.eigvals batched)."""
+    T, n_s = p.shape
+    x = np.hstack((p, k_ff))
+    mu, var, jac = gp_predict(x, model["Z"], model["beta"], model["inv_K"],
+                              model["lengthscale"], model["signal_var"], True)
+    a_mu, b_mu = jac[:, :, :n_s], jac[:, :, n_s:]
+    H = a[None] + a_mu + np.einsum('tiu,tuj->tij', b_mu + b[None], k_fb)
+    p0 = mu + p.dot(a.T) + k_ff.dot(b.T)
+    Q0 = np.einsum('tij,tjk,tlk->til', H, q, H)
+    B = np.eye(n_s)[None] + np.einsum('tui,tuj->tij', k_fb, k_fb)
+    r2 = np.max(np.linalg.eigvals(np.einsum('tij,tjk->tik', q, B)).real, axis=1)
+    ub_mean = l_mu[None] * r2[:, None]
+    ub_sigma = l_sigma[None] * np.sqrt(r2)[:, None]
+    ds = n_s * (c_safety * (np.sqrt(var) + ub_sigma)) ** 2
+    dm = n_s * ub_mean ** 2
+    c1 = np.sqrt(ds.sum(1) / dm.sum(1))
+    dL = (1 + 1 / c1)[:, None] * ds + (1 + c1)[:, None] * dm
+    c2 = np.sqrt(dL.sum(1) / np.trace(Q0, axis1=1, axis2=2))
+    q1 = (1 + c2)[:, None, None] * Q0
+    idx = np.arange(n_s)
+    q1[:, idx, idx] += (1 + 1 / c2)[:, None] * dL
+    return p0, q1, var
+
+
+# --------------------------------------------------------------------------- synthetic configs
+def make_synthetic(seed, N, n_s, n_u, T, noise=1e-2, sf2=1.0):
+    """Seeded synthetic problem of SURVEY.md 8(d): Z~U[-1,1], y_d = sf*(sin(2 z.w_d)+0.05 randn),
+    l~U[0.5,1.5], signal variance sf2 (1 in the survey), sn2 = noise*sf2 (+1e-5 noise_diag);
+    queries p~0.3 randn, k_ff~0.1 randn, k_fb~0.1 randn, Q = 0.01 A A^T + 0.01 I."""
+    rng = np.random.default_rng(seed)
+    D = n_s + n_u
+    Z = rng.uniform(-1, 1, (N, D))
+    Wd = rng.standard_normal((n_s, D))
+    Y = np.sqrt(sf2) * (np.sin(2.0 * Z.dot(Wd.T)) + 0.05 * rng.standard_normal((N, n_s)))
+    ls = rng.uniform(0.5, 1.5, (n_s, D))
+    sn2 = np.full(n_s, noise * sf2 + 1e-5)
+    sf2 = np.full(n_s, float(sf2))
+    p = 0.3 * rng.standard_normal((T, n_s))
+    k_ff = 0.1 * rng.standard_normal((T, n_u))
+    k_fb = 0.1 * rng.standard_normal((T, n_u, n_s))
+    A = rng.standard_normal((T, n_s, n_s))
+    Q = 0.01 * np.einsum('tij,tkj->tik', A, A) + 0.01 * np.eye(n_s)[None]
+    return dict(Z=Z, Y=Y, lengthscale=ls, signal_var=sf2, noise_var=sn2,
+                p=p, k_ff=k_ff, k_fb=k_fb, Q=Q)

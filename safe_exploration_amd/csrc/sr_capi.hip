@@ -1,0 +1,548 @@
+// sr_capi.hip -- the extern "C" boundary declared in include/safereach.h.
+// Host-side orchestration only: owns the handle, its persistent state (Z, alpha, Wt, hyper-
+// parameters) and the per-chunk workspace; enqueues the kernels of sr_factor / sr_predict /
+// sr_ellipsoid on the caller's stream.
+#include "sr_mfma_tile.h"
+#include <vector>
+#include <algorithm>
+
+static thread_local char g_err[1024] = "";
+
+void sr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct sr_gp {
+    int device, N, Np, D, n_out;
+    // persistent device state
+    double *Z, *yT, *ls, *sf2, *noise, *alpha, *Wt;
+    int have_data, factorized;
+    // per-chunk workspace (grow-only)
+    long chunk, ws_Tp;
+    int ws_nsplit;
+    double *Ks, *mu_part, *jac_part, *var_part, *mu, *var, *jac;
+    int var_group;
+    sr_prof prof;
+};
+
+static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return SR_OK;
+    SR_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return SR_OK;
+}
+static void dev_free(void* p) { if (p) (void)hipFree(p); }
+
+extern "C" int sr_version(void) { return 100; }
+extern "C" const char* sr_last_error(void) { return g_err; }
+
+extern "C" int sr_device_count(int* n) {
+    SR_CHECK(n != nullptr, SR_EINVAL, "sr_device_count: n is NULL");
+    *n = 0;
+    int c = 0;
+    SR_HIP(hipGetDeviceCount(&c));
+    *n = c;
+    SR_CHECK(c > 0, SR_EHIP, "no HIP device visible");
+    return SR_OK;
+}
+
+extern "C" int sr_gp_create(sr_gp_t* out, int device, int N, int D, int n_out) {
+    SR_CHECK(out != nullptr, SR_EINVAL, "sr_gp_create: handle pointer is NULL");
+    *out = nullptr;
+    SR_CHECK(N >= 1 && D >= 1 && n_out >= 1, SR_EINVAL, "sr_gp_create: N=%d D=%d n_out=%d", N, D, n_out);
+    SR_CHECK(D <= SR_MAX_D, SR_EUNSUPPORTED, "sr_gp_create: D=%d > %d", D, SR_MAX_D);
+    SR_CHECK(n_out <= 64, SR_EUNSUPPORTED, "sr_gp_create: n_out=%d > 64", n_out);
+    SR_HIP(hipSetDevice(device));
+    sr_gp* h = new sr_gp();
+    memset(h, 0, sizeof(*h));
+    h->device = device; h->N = N; h->D = D; h->n_out = n_out;
+    h->Np = (int)round_up(N, SR_NB);
+    h->chunk = 65536;
+    h->var_group = 16;
+    int rc = SR_OK;
+    if ((rc = dev_alloc(&h->Z, (size_t)N * D)) || (rc = dev_alloc(&h->yT, (size_t)n_out * h->Np)) ||
+        (rc = dev_alloc(&h->ls, (size_t)n_out * D)) || (rc = dev_alloc(&h->sf2, n_out)) ||
+        (rc = dev_alloc(&h->noise, n_out)) || (rc = dev_alloc(&h->alpha, (size_t)n_out * h->Np))) {
+        sr_gp_destroy(h);
+        return rc;
+    }
+    if (hipEventCreate(&h->prof.ev0) == hipSuccess && hipEventCreate(&h->prof.ev1) == hipSuccess)
+        h->prof.have_events = 1;
+    *out = h;
+    return SR_OK;
+}
+
+static void free_ws(sr_gp* h) {
+    dev_free(h->Ks); dev_free(h->mu_part); dev_free(h->jac_part); dev_free(h->var_part);
+    dev_free(h->mu); dev_free(h->var); dev_free(h->jac);
+    h->Ks = h->mu_part = h->jac_part = h->var_part = h->mu = h->var = h->jac = nullptr;
+    h->ws_Tp = 0; h->ws_nsplit = 0;
+}
+
+extern "C" int sr_gp_destroy(sr_gp_t h) {
+    if (!h) return SR_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
+    dev_free(h->alpha); dev_free(h->Wt);
+    free_ws(h);
+    if (h->prof.have_events) { (void)hipEventDestroy(h->prof.ev0); (void)hipEventDestroy(h->prof.ev1); }
+    delete h;
+    return SR_OK;
+}
+
+__global__ void sr_pack_y_kernel(const double* __restrict__ Y, double* __restrict__ yT, int N, int Np,
+                                 int n_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i < Np) yT[(long)d * Np + i] = (i < N) ? Y[(long)i * n_out + d] : 0.0;
+}
+
+extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const double* ls,
+                              const double* sf2, const double* noise, void* stream) {
+    SR_CHECK(h && Z && Y && ls && sf2 && noise, SR_EINVAL, "sr_gp_set_data: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
+    SR_HIP(hipMemcpyAsync(h->ls, ls, sizeof(double) * h->n_out * h->D, hipMemcpyDeviceToDevice, s));
+    SR_HIP(hipMemcpyAsync(h->sf2, sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToDevice, s));
+    SR_HIP(hipMemcpyAsync(h->noise, noise, sizeof(double) * h->n_out, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(sr_pack_y_kernel, dim3((h->Np + 255) / 256, h->n_out), dim3(256), 0, s, Y,
+                       h->yT, h->N, h->Np, h->n_out);
+    SR_HIP(hipGetLastError());
+    h->have_data = 1;
+    h->factorized = 0;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_padded_n(sr_gp_t h, long* Np) {
+    SR_CHECK(h && Np, SR_EINVAL, "sr_gp_padded_n: NULL argument");
+    *Np = h->Np;
+    return SR_OK;
+}
+
+static int ensure_wt(sr_gp* h) {
+    if (!h->Wt) SR_TRY(dev_alloc(&h->Wt, (size_t)h->n_out * h->Np * h->Np));
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// factorisation: K = U^T U (right-looking, block 128), W = U^-T (blocked forward substitution),
+// Wt = W^T, alpha = Wt (W y)
+// ---------------------------------------------------------------------------------------------
+extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_factorize: NULL handle");
+    SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    SR_TRY(ensure_wt(h));
+    const int Np = h->Np, nb = Np / SR_NB;
+    const size_t NN = (size_t)Np * Np;
+    double *U = nullptr, *W = nullptr, *tmp = nullptr, *v = nullptr;
+    int* info_dev = nullptr;
+    std::vector<double> sf2(h->n_out), noise(h->n_out);
+    int rc = SR_OK;
+    auto cleanup = [&]() { dev_free(U); dev_free(W); dev_free(tmp); dev_free(v); dev_free(info_dev); };
+#define SR_F(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(); return rc; } } while (0)
+#define SR_FH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); return SR_EHIP; } } while (0)
+    SR_F(dev_alloc(&U, NN));
+    SR_F(dev_alloc(&W, NN));
+    SR_F(dev_alloc(&tmp, (size_t)SR_NB * Np));
+    SR_F(dev_alloc(&v, (size_t)Np));
+    SR_F(dev_alloc(&info_dev, (size_t)h->n_out));
+    SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s));
+    SR_FH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s));
+    SR_FH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s));
+    SR_FH(hipStreamSynchronize(s));
+
+    for (int d = 0; d < h->n_out; ++d) {
+        double* Wt = h->Wt + (size_t)d * NN;
+        SR_FH(hipMemsetAsync(W, 0, NN * sizeof(double), s));
+        SR_FH(hipMemsetAsync(Wt, 0, NN * sizeof(double), s));
+        {
+            sr_prof_scope ps(&h->prof, SR_K_GRAM, s);
+            SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, s));
+        }
+        // --- Cholesky, block row kb
+        for (int kb = 0; kb < nb; ++kb) {
+            const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
+            {
+                sr_prof_scope ps(&h->prof, SR_K_POTRF, s);
+                SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, s));
+            }
+            const int ncols = Np - (kb + 1) * SR_NB;
+            if (ncols > 0) {
+                double* Urow = U + dg + SR_NB;                    // U[kb rows][cols right of the block]
+                sr_prof_scope ps(&h->prof, SR_K_GEMM, s);
+                // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major) -- in place
+                SR_F(sr_launch_gemm_tn(Wt + dg, Np, Urow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, s));
+                // trailing update A_ij -= U_k,i^T U_k,j  (upper block triangle)
+                SR_F(sr_launch_gemm_tn(Urow, Np, Urow, Np, U + dg + (size_t)SR_NB * Np + SR_NB, Np,
+                                       ncols, ncols, SR_NB, -1.0, 1.0, 1, s));
+            }
+        }
+        // --- W = U^-T by block rows: W_i,0:i = -U_ii^-T (sum_{k<i} U_k,i^T W_k,0:i)
+        for (int i = 1; i < nb; ++i) {
+            sr_prof_scope ps(&h->prof, SR_K_GEMM, s);
+            const int ncol = i * SR_NB;
+            SR_F(sr_launch_gemm_tn(U + (size_t)i * SR_NB, Np, W, Np, tmp, Np, SR_NB, ncol, ncol, 1.0, 0.0, 2, s));
+            const size_t dg = (size_t)i * SR_NB * Np + (size_t)i * SR_NB;
+            SR_F(sr_launch_gemm_tn(Wt + dg, Np, tmp, Np, W + (size_t)i * SR_NB * Np, Np, SR_NB, ncol,
+                                   SR_NB, -1.0, 0.0, 0, s));
+        }
+        SR_F(sr_launch_transpose(W, Wt, Np, s));
+        // alpha = Wt (W y)
+        SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d * Np, v, Np, 1, s));
+        SR_F(sr_launch_trmv(Wt, Np, v, h->alpha + (size_t)d * Np, Np, 0, s));
+    }
+    std::vector<int> info_h(h->n_out, 0);
+    SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s));
+    SR_FH(hipStreamSynchronize(s));
+    cleanup();
+#undef SR_F
+#undef SR_FH
+    int bad = 0;
+    for (int d = 0; d < h->n_out; ++d) {
+        if (info) info[d] = info_h[d];
+        if (info_h[d] != 0 && !bad) bad = d + 1;
+    }
+    if (bad) {
+        h->factorized = 0;
+        sr_set_error("Cholesky breakdown: output %d, pivot %d not positive", bad - 1, info_h[bad - 1]);
+        return SR_ENOTPD;
+    }
+    h->factorized = 1;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_export(sr_gp_t h, double* alpha, double* Wt, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_export: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_export: model not factorized");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    if (alpha)
+        SR_HIP(hipMemcpy2DAsync(alpha, sizeof(double) * h->N, h->alpha, sizeof(double) * h->Np,
+                                sizeof(double) * h->N, h->n_out, hipMemcpyDeviceToDevice, s));
+    if (Wt)
+        SR_HIP(hipMemcpyAsync(Wt, h->Wt, sizeof(double) * h->n_out * h->Np * h->Np,
+                              hipMemcpyDeviceToDevice, s));
+    return SR_OK;
+}
+
+extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_import: NULL handle");
+    SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_import: call sr_gp_set_data first (Z and hyper-parameters)");
+    SR_CHECK(alpha && Wt, SR_EINVAL, "sr_gp_import: alpha and Wt are both required");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    SR_TRY(ensure_wt(h));
+    SR_HIP(hipMemsetAsync(h->alpha, 0, sizeof(double) * h->n_out * h->Np, s));
+    SR_HIP(hipMemcpy2DAsync(h->alpha, sizeof(double) * h->Np, alpha, sizeof(double) * h->N,
+                            sizeof(double) * h->N, h->n_out, hipMemcpyDeviceToDevice, s));
+    SR_HIP(hipMemcpyAsync(h->Wt, Wt, sizeof(double) * h->n_out * h->Np * h->Np,
+                          hipMemcpyDeviceToDevice, s));
+    h->factorized = 1;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream) {
+    SR_CHECK(h && inv_k, SR_EINVAL, "sr_gp_inv_k: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_inv_k: model not factorized");
+    SR_CHECK(d >= 0 && d < h->n_out, SR_EINVAL, "sr_gp_inv_k: d=%d out of range", d);
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    const int Np = h->Np;
+    const size_t NN = (size_t)Np * Np;
+    double *W = nullptr, *out = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&W, NN)) || (rc = dev_alloc(&out, NN))) { dev_free(W); dev_free(out); return rc; }
+    // K^-1 = U^-1 U^-T = sum_k W[k][i] W[k][j]  (W = Wt^T, k-major)
+    rc = sr_launch_transpose(h->Wt + (size_t)d * NN, W, Np, s);
+    if (rc == SR_OK) rc = sr_launch_gemm_tn(W, Np, W, Np, out, Np, Np, Np, Np, 1.0, 0.0, 0, s);
+    hipError_t e = hipSuccess;
+    if (rc == SR_OK)
+        e = hipMemcpy2DAsync(inv_k, sizeof(double) * h->N, out, sizeof(double) * Np,
+                             sizeof(double) * h->N, h->N, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(W); dev_free(out);
+    if (rc != SR_OK) return rc;
+    SR_HIP(e);
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace + the three-kernel GP pass over one chunk
+// ---------------------------------------------------------------------------------------------
+static int pick_nsplit(const sr_gp* h, long Tp) {
+    const long blocks = ((Tp + 255) / 256) * h->n_out;
+    long ns = (768 + blocks - 1) / blocks;
+    const long maxs = h->Np / SR_NB;
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
+    if (Tp <= h->ws_Tp && nsplit <= h->ws_nsplit) return SR_OK;
+    const long nTp = std::max(Tp, h->ws_Tp);
+    const int nsp = std::max(nsplit, h->ws_nsplit);
+    (void)hipDeviceSynchronize();
+    free_ws(h);
+    const int nrb = h->Np / SR_NB;
+    int rc;
+    if ((rc = dev_alloc(&h->Ks, (size_t)h->n_out * h->Np * nTp)) ||
+        (rc = dev_alloc(&h->mu_part, (size_t)nsp * h->n_out * nTp)) ||
+        (rc = dev_alloc(&h->jac_part, (size_t)nsp * h->n_out * h->D * nTp)) ||
+        (rc = dev_alloc(&h->var_part, (size_t)h->n_out * nrb * nTp)) ||
+        (rc = dev_alloc(&h->mu, (size_t)h->n_out * nTp)) ||
+        (rc = dev_alloc(&h->var, (size_t)h->n_out * nTp)) ||
+        (rc = dev_alloc(&h->jac, (size_t)h->n_out * h->D * nTp))) {
+        free_ws(h);
+        return rc;
+    }
+    h->ws_Tp = nTp;
+    h->ws_nsplit = nsp;
+    return SR_OK;
+}
+
+// GP posterior of Tc queries x = [xa | xb] into (mu, var, jac) in API layout (jac may be NULL).
+static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb,
+                   int nb, double* mu, double* var, double* jac, hipStream_t s) {
+    const long Tp = round_up(Tc, srt::BN);
+    const int nsplit = pick_nsplit(h, Tp);
+    SR_TRY(ensure_ws(h, Tp, nsplit));
+    sr_kstar_args ka;
+    ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.xa = xa; ka.lda = lda; ka.na = na; ka.xb = xb; ka.ldb = ldb; ka.nb = nb;
+    ka.Ks = h->Ks; ka.mu_part = h->mu_part; ka.jac_part = h->jac_part;
+    ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = nsplit;
+    ka.T = Tc; ka.Tp = Tp;
+    {
+        sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
+        SR_TRY(sr_launch_kstar(ka, s));
+    }
+    {
+        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+        SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->Np, Tp, h->n_out, h->var_group, s));
+    }
+    sr_final_args fa;
+    fa.mu_part = h->mu_part; fa.jac_part = h->jac_part; fa.var_part = h->var_part; fa.sf2 = h->sf2;
+    fa.ls = h->ls; fa.mu = mu; fa.var = var; fa.jac = jac;
+    fa.n_out = h->n_out; fa.D = h->D; fa.nsplit = nsplit; fa.nrb = h->Np / SR_NB; fa.T = Tc; fa.Tp = Tp;
+    {
+        sr_prof_scope ps(&h->prof, SR_K_FINAL, s);
+        SR_TRY(sr_launch_finalize(fa, s));
+    }
+    return SR_OK;
+}
+
+extern "C" int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, double* var,
+                             double* jac, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_predict: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_predict: model not factorized");
+    SR_CHECK(T >= 0, SR_EINVAL, "sr_gp_predict: T=%ld", T);
+    if (T == 0) return SR_OK;
+    SR_CHECK(Xq && mu && var, SR_EINVAL, "sr_gp_predict: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    for (long t0 = 0; t0 < T; t0 += h->chunk) {
+        const long Tc = std::min(h->chunk, T - t0);
+        SR_TRY(gp_pass(h, Tc, Xq + t0 * h->D, h->D, h->D, nullptr, 0, 0, mu + t0 * h->n_out,
+                       var + t0 * h->n_out, jac ? jac + t0 * h->n_out * h->D : nullptr, s));
+    }
+    return SR_OK;
+}
+
+static int check_reach_dims(const sr_gp* h, int* n_s, int* n_u) {
+    *n_s = h->n_out;
+    *n_u = h->D - h->n_out;
+    SR_CHECK(*n_u >= 1, SR_EINVAL, "reachability needs D = n_s + n_u with n_u >= 1 (D=%d, n_out=%d)",
+             h->D, h->n_out);
+    SR_CHECK(*n_s <= SR_MAX_NS && *n_u <= SR_MAX_NU, SR_EUNSUPPORTED,
+             "reachability supports n_s <= %d, n_u <= %d (got %d, %d)", SR_MAX_NS, SR_MAX_NU, *n_s, *n_u);
+    return SR_OK;
+}
+
+extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double* q,
+                                const double* k_ff, const double* k_fb, const double* a,
+                                const double* b, const double* l_mu, const double* l_sigma,
+                                double c_safety, double* p_out, double* q_out, double* var_out,
+                                int* n_bad, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_onestep_reach: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_onestep_reach: model not factorized");
+    SR_CHECK(T >= 0, SR_EINVAL, "sr_onestep_reach: T=%ld", T);
+    if (T == 0) return SR_OK;
+    SR_CHECK(p && k_ff && a && b && l_mu && l_sigma && p_out && q_out, SR_EINVAL,
+             "sr_onestep_reach: NULL argument");
+    SR_CHECK(q == nullptr || k_fb != nullptr, SR_EINVAL, "sr_onestep_reach: k_fb required with q");
+    int n_s, n_u;
+    SR_TRY(check_reach_dims(h, &n_s, &n_u));
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    for (long t0 = 0; t0 < T; t0 += h->chunk) {
+        const long Tc = std::min(h->chunk, T - t0);
+        double* var_dst = var_out ? var_out + t0 * n_s : nullptr;
+        // gp_pass may (re)allocate the workspace: resolve internal pointers after it
+        SR_TRY(ensure_ws(h, round_up(Tc, srt::BN), pick_nsplit(h, round_up(Tc, srt::BN))));
+        if (!var_dst) var_dst = h->var;
+        SR_TRY(gp_pass(h, Tc, p + t0 * n_s, n_s, n_s, k_ff + t0 * n_u, n_u, n_u, h->mu, var_dst,
+                       h->jac, s));
+        sr_ell_args ea;
+        ea.T = Tc; ea.n_s = n_s; ea.n_u = n_u;
+        ea.p = p + t0 * n_s; ea.ldp = n_s;
+        ea.q = q ? q + t0 * n_s * n_s : nullptr; ea.ldq = (long)n_s * n_s;
+        ea.k_ff = k_ff + t0 * n_u; ea.ldkff = n_u;
+        ea.k_fb = k_fb ? k_fb + t0 * n_u * n_s : nullptr; ea.ldkfb = (long)n_u * n_s;
+        ea.mu = h->mu; ea.var = var_dst; ea.jac = h->jac;
+        ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
+        ea.p_out = p_out + t0 * n_s; ea.ldpo = n_s;
+        ea.q_out = q_out + t0 * n_s * n_s; ea.ldqo = (long)n_s * n_s;
+        ea.n_bad = n_bad;
+        sr_prof_scope ps(&h->prof, SR_K_ELL, s);
+        SR_TRY(sr_launch_ellipsoid(ea, s));
+    }
+    return SR_OK;
+}
+
+extern "C" int sr_multistep_reach(sr_gp_t h, long T, int H, const double* p0, const double* q0,
+                                  const double* k_fb0, const double* k_ff, const double* k_fb,
+                                  const double* a, const double* b, const double* l_mu,
+                                  const double* l_sigma, double c_safety, double* p_all,
+                                  double* q_all, int* n_bad, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_multistep_reach: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_multistep_reach: model not factorized");
+    SR_CHECK(T >= 0 && H >= 1, SR_EINVAL, "sr_multistep_reach: T=%ld H=%d", T, H);
+    if (T == 0) return SR_OK;
+    SR_CHECK(p0 && k_ff && a && b && l_mu && l_sigma && p_all && q_all, SR_EINVAL,
+             "sr_multistep_reach: NULL argument");
+    SR_CHECK(H == 1 || k_fb != nullptr, SR_EINVAL, "sr_multistep_reach: k_fb required for H > 1");
+    SR_CHECK(q0 == nullptr || k_fb0 != nullptr, SR_EINVAL, "sr_multistep_reach: k_fb0 required with q0");
+    int n_s, n_u;
+    SR_TRY(check_reach_dims(h, &n_s, &n_u));
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
+    for (long t0 = 0; t0 < T; t0 += h->chunk) {
+        const long Tc = std::min(h->chunk, T - t0);
+        SR_TRY(ensure_ws(h, round_up(Tc, srt::BN), pick_nsplit(h, round_up(Tc, srt::BN))));
+        for (int i = 0; i < H; ++i) {
+            // inputs of step i (gp_reachability.py:195-210)
+            const double* p_in; long ldp; const double* q_in; long ldq; const double* kfb_in; long ldkfb;
+            if (i == 0) {
+                p_in = p0 + t0 * n_s; ldp = n_s;
+                q_in = q0 ? q0 + t0 * nss : nullptr; ldq = nss;
+                kfb_in = k_fb0 ? k_fb0 + t0 * nus : nullptr; ldkfb = nus;
+            } else {
+                p_in = p_all + (t0 * H + (i - 1)) * n_s; ldp = (long)H * n_s;
+                q_in = q_all + (t0 * H + (i - 1)) * nss; ldq = (long)H * nss;
+                kfb_in = k_fb + (t0 * (H - 1) + (i - 1)) * nus; ldkfb = (long)(H - 1) * nus;
+            }
+            const double* kff_in = k_ff + (t0 * H + i) * n_u;
+            const long ldkff = (long)H * n_u;
+            SR_TRY(gp_pass(h, Tc, p_in, ldp, n_s, kff_in, ldkff, n_u, h->mu, h->var, h->jac, s));
+            sr_ell_args ea;
+            ea.T = Tc; ea.n_s = n_s; ea.n_u = n_u;
+            ea.p = p_in; ea.ldp = ldp; ea.q = q_in; ea.ldq = ldq;
+            ea.k_ff = kff_in; ea.ldkff = ldkff; ea.k_fb = kfb_in; ea.ldkfb = ldkfb;
+            ea.mu = h->mu; ea.var = h->var; ea.jac = h->jac;
+            ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
+            ea.p_out = p_all + (t0 * H + i) * n_s; ea.ldpo = (long)H * n_s;
+            ea.q_out = q_all + (t0 * H + i) * nss; ea.ldqo = (long)H * nss;
+            ea.n_bad = n_bad;
+            sr_prof_scope ps(&h->prof, SR_K_ELL, s);
+            SR_TRY(sr_launch_ellipsoid(ea, s));
+        }
+    }
+    return SR_OK;
+}
+
+extern "C" int sr_ellipsoid_step(int device, long T, int n_s, int n_u, const double* p,
+                                 const double* q, const double* k_ff, const double* k_fb,
+                                 const double* mu, const double* var, const double* jac,
+                                 const double* a, const double* b, const double* l_mu,
+                                 const double* l_sigma, double c_safety, double* p_out,
+                                 double* q_out, int* n_bad, void* stream) {
+    SR_CHECK(T >= 0, SR_EINVAL, "sr_ellipsoid_step: T=%ld", T);
+    if (T == 0) return SR_OK;
+    SR_CHECK(p && k_ff && mu && var && a && b && l_mu && l_sigma && p_out && q_out, SR_EINVAL,
+             "sr_ellipsoid_step: NULL argument");
+    SR_CHECK(q == nullptr || (k_fb != nullptr && jac != nullptr), SR_EINVAL,
+             "sr_ellipsoid_step: k_fb and jac required with q");
+    SR_HIP(hipSetDevice(device));
+    sr_ell_args ea;
+    ea.T = T; ea.n_s = n_s; ea.n_u = n_u;
+    ea.p = p; ea.ldp = n_s; ea.q = q; ea.ldq = (long)n_s * n_s;
+    ea.k_ff = k_ff; ea.ldkff = n_u; ea.k_fb = k_fb; ea.ldkfb = (long)n_u * n_s;
+    ea.mu = mu; ea.var = var; ea.jac = jac;
+    ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
+    ea.p_out = p_out; ea.ldpo = n_s; ea.q_out = q_out; ea.ldqo = (long)n_s * n_s;
+    ea.n_bad = n_bad;
+    return sr_launch_ellipsoid(ea, (hipStream_t)stream);
+}
+
+extern "C" int sr_remainder_overapprox(int device, long T, int n_s, int n_u, const double* q,
+                                       const double* k_fb, const double* l_mu, const double* l_sigma,
+                                       double* u_mu, double* u_sigma, void* stream) {
+    SR_CHECK(T >= 0, SR_EINVAL, "sr_remainder_overapprox: T=%ld", T);
+    if (T == 0) return SR_OK;
+    SR_CHECK(q && k_fb && l_mu && l_sigma && u_mu && u_sigma, SR_EINVAL,
+             "sr_remainder_overapprox: NULL argument");
+    SR_HIP(hipSetDevice(device));
+    return sr_launch_remainder(T, n_s, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, (hipStream_t)stream);
+}
+
+extern "C" int sr_safety_distance(int device, long T, int n_s, int m, const double* p,
+                                  const double* q, const double* h_mat, const double* h_vec,
+                                  double c_safety, double* d, void* stream) {
+    SR_CHECK(T >= 0 && n_s >= 1 && m >= 1, SR_EINVAL, "sr_safety_distance: T=%ld n_s=%d m=%d", T, n_s, m);
+    if (T == 0) return SR_OK;
+    SR_CHECK(p && q && h_mat && h_vec && d, SR_EINVAL, "sr_safety_distance: NULL argument");
+    SR_HIP(hipSetDevice(device));
+    return sr_launch_safety(T, n_s, m, p, q, h_mat, h_vec, c_safety, d, (hipStream_t)stream);
+}
+
+extern "C" int sr_gp_set_chunk(sr_gp_t h, long chunk) {
+    SR_CHECK(h != nullptr && chunk >= 1, SR_EINVAL, "sr_gp_set_chunk: bad argument");
+    h->chunk = chunk;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_set_var_group(sr_gp_t h, int group) {
+    SR_CHECK(h != nullptr && group >= 1, SR_EINVAL, "sr_gp_set_var_group: bad argument");
+    h->var_group = group;
+    return SR_OK;
+}
+
+extern "C" int sr_test_gemm_tn(int device, const double* A, long lda, const double* B, long ldb,
+                               double* C, long ldc, int M, int N, int K, double alpha, double beta,
+                               int mode, void* stream) {
+    SR_CHECK(A && B && C, SR_EINVAL, "sr_test_gemm_tn: NULL argument");
+    SR_HIP(hipSetDevice(device));
+    return sr_launch_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, mode, (hipStream_t)stream);
+}
+
+extern "C" int sr_prof_enable(sr_gp_t h, int on) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_prof_enable: NULL handle");
+    SR_CHECK(!on || h->prof.have_events, SR_EHIP, "sr_prof_enable: events unavailable");
+    h->prof.enabled = on ? 1 : 0;
+    return SR_OK;
+}
+extern "C" int sr_prof_reset(sr_gp_t h) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_prof_reset: NULL handle");
+    for (int i = 0; i < SR_K_COUNT; ++i) { h->prof.ms[i] = 0.0; h->prof.launches[i] = 0; }
+    return SR_OK;
+}
+extern "C" int sr_prof_get(sr_gp_t h, int kernel_id, double* ms_total, long* launches) {
+    SR_CHECK(h != nullptr && kernel_id >= 0 && kernel_id < SR_K_COUNT, SR_EINVAL,
+             "sr_prof_get: bad argument");
+    if (ms_total) *ms_total = h->prof.ms[kernel_id];
+    if (launches) *launches = h->prof.launches[kernel_id];
+    return SR_OK;
+}

@@ -1,0 +1,128 @@
+// sr_common.h -- shared declarations for libsafereach (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include "../../include/safereach.h"
+
+#define SR_NB 128          // factor block size == GEMM tile edge; Np is a multiple of it
+#define SR_MAX_NS 8
+#define SR_MAX_NU 4
+#define SR_MAX_D 12
+#define SR_VAR_CLIP 1e-15  // GPy GP._raw_predict clips the predictive variance here
+
+void sr_set_error(const char* fmt, ...);
+
+#define SR_HIP(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return SR_EHIP;                                                           \
+        }                                                                             \
+    } while (0)
+
+#define SR_CHECK(cond, code, ...)                                                     \
+    do {                                                                              \
+        if (!(cond)) { sr_set_error(__VA_ARGS__); return (code); }                    \
+    } while (0)
+
+#define SR_TRY(expr)                                                                  \
+    do { int rc_ = (expr); if (rc_ != SR_OK) return rc_; } while (0)
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+struct sr_prof {
+    int enabled;
+    double ms[SR_K_COUNT];
+    long launches[SR_K_COUNT];
+    hipEvent_t ev0, ev1;
+    int have_events;
+};
+
+// Optional per-launch timing: records an event pair on `stream` around one launch and
+// accumulates the elapsed time.  Only used while sr_prof_enable(h, 1).
+struct sr_prof_scope {
+    sr_prof* p; int id; hipStream_t s;
+    sr_prof_scope(sr_prof* p_, int id_, hipStream_t s_) : p(p_), id(id_), s(s_) {
+        if (p && p->enabled) (void)hipEventRecord(p->ev0, s);
+    }
+    ~sr_prof_scope() {
+        if (p && p->enabled) {
+            (void)hipEventRecord(p->ev1, s);
+            (void)hipEventSynchronize(p->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, p->ev0, p->ev1);
+            p->ms[id] += ms;
+            p->launches[id] += 1;
+        }
+    }
+};
+
+// ---- launchers implemented in the .hip files ---------------------------------------------------
+// C[m][n] (op)= alpha * sum_k A[k][m] * B[k][n]; A: K x M (lda), B: K x N (ldb), C: M x N (ldc).
+// M, N multiples of 128; K multiple of 16.
+//   mode 0: all tiles.  mode 1: only tiles with n0 >= m0 (upper block triangle).
+//   mode 2: B block-lower-triangular (B[k][n] == 0 for k < n0): per tile k starts at n0.
+int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s);
+
+int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, double* K, int N,
+                   int Np, int D, hipStream_t s);
+// factor the diagonal block kb of the Np x Np matrix A (upper), write U_kk in place, U_kk^-1 to
+// wt_diag (into Wt's diagonal block) and U_kk^-T to w_diag (into W's diagonal block).
+int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
+                         int kb, int* info_dev, hipStream_t s);
+int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s);
+// y[r] = sum_c M[r][c] x[c], c in [0..r] (lower=1) or [r..n) (lower=0)
+int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
+                   hipStream_t s);
+int sr_launch_fill(double* p, size_t n, double v, hipStream_t s);
+
+struct sr_kstar_args {
+    const double* Z;        // N x D
+    const double* alpha;    // n_out x Np
+    const double* ls;       // n_out x D
+    const double* sf2;      // n_out
+    const double* xa; long lda; int na;   // query part a: T x na (row stride lda)
+    const double* xb; long ldb; int nb;   // query part b: T x nb (row stride ldb), na+nb == D
+    double* Ks;             // n_out x Np x Tp
+    double* mu_part;        // nsplit x n_out x Tp
+    double* jac_part;       // nsplit x n_out x D x Tp
+    int N, Np, D, n_out, nsplit;
+    long T, Tp;
+};
+int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
+
+// part[d][rb][t] = sum_{i in row block rb} ( sum_k Wt[d][k][i] Ks[d][k][t] )^2
+int sr_launch_var(const double* Wt, const double* Ks, double* part, int Np, long Tp, int n_out,
+                  int group, hipStream_t s);
+
+struct sr_final_args {
+    const double* mu_part; const double* jac_part; const double* var_part; const double* sf2;
+    const double* ls;
+    double* mu; double* var; double* jac;   // T x n_out, T x n_out, T x n_out x D (jac may be NULL)
+    int n_out, D, nsplit, nrb; long T, Tp;
+};
+int sr_launch_finalize(const sr_final_args& a, hipStream_t s);
+
+struct sr_ell_args {
+    long T; int n_s, n_u;
+    const double* p; long ldp;        // T x n_s, row stride ldp
+    const double* q; long ldq;        // T x n_s*n_s or NULL
+    const double* k_ff; long ldkff;   // T x n_u
+    const double* k_fb; long ldkfb;   // T x n_u*n_s or NULL
+    const double* mu; const double* var; const double* jac;   // dense T x n_s, T x n_s, T x n_s x D
+    const double* a; const double* b; const double* l_mu; const double* l_sigma;
+    double c_safety;
+    double* p_out; long ldpo;         // T x n_s
+    double* q_out; long ldqo;         // T x n_s*n_s
+    int* n_bad;                       // device counter (nullable): queries whose box bounds were not > 0
+};
+int sr_launch_ellipsoid(const sr_ell_args& a, hipStream_t s);
+int sr_launch_remainder(long T, int n_s, int n_u, const double* q, const double* k_fb,
+                        const double* l_mu, const double* l_sigma, double* u_mu, double* u_sigma,
+                        hipStream_t s);
+int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, const double* h_mat,
+                     const double* h_vec, double c, double* d, hipStream_t s);

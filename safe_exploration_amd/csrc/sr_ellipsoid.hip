@@ -1,0 +1,384 @@
+// sr_ellipsoid.hip -- per-query Jacobian-linearised ellipsoid propagate / sum.
+//
+// One thread per query; everything lives in registers (n_s <= 8, n_u <= 4 are template parameters
+// so every small-matrix index is a compile-time constant).
+//
+// replaces the algebra of
+//   /root/reference/safe_exploration/gp_reachability.py:65-88   (point branch)
+//   /root/reference/safe_exploration/gp_reachability.py:89-156  (ellipsoid branch)
+//   /root/reference/safe_exploration/utils.py:108-144           (compute_remainder_overapproximations)
+//   /root/reference/safe_exploration/utils_ellipsoid.py:63-94, 197-233
+//   /root/reference/safe_exploration/gp_reachability.py:215-250 (lin_ellipsoid_safety_distance)
+#include "sr_common.h"
+
+// largest eigenvalue of Q * B, Q symmetric PSD, B = I + K^T K SPD.
+// eig(Q B) == eig(L^T Q L) with B = L L^T (similarity by L^T); the latter is symmetric, so a cyclic
+// Jacobi iteration gives all eigenvalues to full fp64 accuracy.  The reference calls
+// scipy.linalg.eig on the non-symmetric product and keeps np.max (utils.py:133-134).
+template <int NS, int NU>
+__device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
+                                                   const double (&kfb)[NU][NS]) {
+    double B[NS][NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) s = fma(kfb[u][i], kfb[u][j], s);
+            B[i][j] = s;
+        }
+    if (NS == 1) return q[0][0] * B[0][0];
+    // lower Cholesky of B
+    double L[NS][NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        double s = B[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        const double ljj = sqrt(s);
+        L[j][j] = ljj;
+        const double inv = 1.0 / ljj;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (i > j) {
+                double v = B[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+                L[i][j] = v * inv;
+            } else if (i < j) {
+                L[i][j] = 0.0;
+            }
+        }
+    }
+    // M = L^T Q L
+    double QL[NS][NS], M[NS][NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if (k >= j) s = fma(q[i][k], L[k][j], s);
+            QL[i][j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if (k >= i) s = fma(L[k][i], QL[k][j], s);
+            M[i][j] = s;
+        }
+    // symmetrise (Q is symmetric by contract; removes rounding asymmetry)
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (j > i) { const double m = 0.5 * (M[i][j] + M[j][i]); M[i][j] = m; M[j][i] = m; }
+    if (NS == 2) {
+        const double tr = M[0][0] + M[1][1];
+        const double df = M[0][0] - M[1][1];
+        return 0.5 * (tr + sqrt(fma(df, df, 4.0 * M[0][1] * M[0][1])));
+    }
+    // cyclic Jacobi (eigenvalues only)
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            dia = fma(M[i][i], M[i][i], dia);
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+                if (j > i) off = fma(M[i][j], M[i][j], off);
+        }
+        if (off <= 1e-34 * dia || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+#pragma unroll
+            for (int r = 0; r < NS; ++r) {
+                if (r > p) {
+                    const double apr = M[p][r];
+                    if (apr != 0.0) {
+                        const double theta = (M[r][r] - M[p][p]) / (2.0 * apr);
+                        const double tt = ((theta >= 0.0) ? 1.0 : -1.0) /
+                                          (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+                        const double c = 1.0 / sqrt(fma(tt, tt, 1.0));
+                        const double s = tt * c;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {   // columns p, r
+                            const double mkp = M[k][p], mkr = M[k][r];
+                            M[k][p] = c * mkp - s * mkr;
+                            M[k][r] = s * mkp + c * mkr;
+                        }
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {   // rows p, r
+                            const double mpk = M[p][k], mrk = M[r][k];
+                            M[p][k] = c * mpk - s * mrk;
+                            M[r][k] = s * mpk + c * mrk;
+                        }
+                    }
+                }
+            }
+    }
+    double lam = M[0][0];
+#pragma unroll
+    for (int i = 1; i < NS; ++i) lam = fmax(lam, M[i][i]);
+    return lam;
+}
+
+template <int NS, int NU>
+__global__ __launch_bounds__(256) void sr_ellipsoid_kernel(sr_ell_args a) {
+    int* n_bad = a.n_bad;
+    constexpr int D = NS + NU;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.T) return;
+
+    double p[NS], u[NU], mu[NS], var[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        p[i] = a.p[t * a.ldp + i];
+        mu[i] = a.mu[t * NS + i];
+        var[i] = a.var[t * NS + i];
+    }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) u[k] = a.k_ff[t * a.ldkff + k];
+
+    // p_lin = a p + b u + mu        (gp_reachability.py:82-83 / :115)
+    double p1[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double s = mu[i];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) s = fma(a.a[i * NS + j], p[j], s);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) s = fma(a.b[i * NU + k], u[k], s);
+        p1[i] = s;
+        a.p_out[t * a.ldpo + i] = s;
+    }
+    double* qo = a.q_out + t * a.ldqo;
+    bool bad = false;
+
+    if (a.q == nullptr) {
+        // point branch: Q1 = diag(n_s (c sqrt(var))^2)     (gp_reachability.py:78-80)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const double ub = a.c_safety * sqrt(var[i]);
+            bad |= !(ub > 0.0);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) qo[i * NS + j] = (i == j) ? NS * ub * ub : 0.0;
+        }
+        if (bad && n_bad) atomicAdd(n_bad, 1);
+        return;
+    }
+
+    double q[NS][NS], kfb[NU][NS], H[NS][NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) q[i][j] = a.q[t * a.ldq + i * NS + j];
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) kfb[k][j] = a.k_fb[t * a.ldkfb + k * NS + j];
+
+    // H = a + a_mu + (b_mu + b) k_fb                          (gp_reachability.py:110-114)
+    const double* jac = a.jac + t * NS * D;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double bm[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) bm[k] = jac[i * D + NS + k] + a.b[i * NU + k];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double s = a.a[i * NS + j] + jac[i * D + j];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) s = fma(bm[k], kfb[k][j], s);
+            H[i][j] = s;
+        }
+    }
+    // Q0 = H Q H^T                                            (:117)
+    double HQ[NS][NS], Q0[NS][NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s = fma(H[i][k], q[k][j], s);
+            HQ[i][j] = s;
+        }
+    double trQ0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s = fma(HQ[i][k], H[j][k], s);
+            Q0[i][j] = s;
+            if (i == j) trQ0 += s;
+        }
+    // remainder boxes                                          (:125-137, utils.py:129-142)
+    const double r2 = sr_lambda_max_qb<NS, NU>(q, kfb);
+    const double r1 = sqrt(r2);
+    double dL[NS], dM[NS];
+    double trS = 0.0, trM = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double ub_mu = a.l_mu[i] * r2;
+        const double ub_sg = a.c_safety * (sqrt(var[i]) + a.l_sigma[i] * r1);
+        bad |= !(ub_mu > 0.0) || !(ub_sg > 0.0);
+        const double ds = NS * ub_sg * ub_sg;
+        const double dm = NS * ub_mu * ub_mu;
+        trS += ds;
+        trM += dm;
+        dL[i] = ds;
+        dM[i] = dm;
+    }
+    // trace-optimal sums                                        (:143-148, utils_ellipsoid.py:88-92)
+    const double c1 = sqrt(trS / trM);
+    double trL = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        dL[i] = (1.0 + 1.0 / c1) * dL[i] + (1.0 + c1) * dM[i];
+        trL += dL[i];
+    }
+    const double c2 = sqrt(trL / trQ0);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            double v = (1.0 + c2) * Q0[i][j];
+            if (i == j) v += (1.0 + 1.0 / c2) * dL[i];
+            qo[i * NS + j] = v;
+        }
+    if (bad && n_bad) atomicAdd(n_bad, 1);
+    (void)p1;
+}
+
+template <int NS, int NU>
+__global__ __launch_bounds__(256) void sr_remainder_kernel(long T, const double* __restrict__ qg,
+                                                           const double* __restrict__ kg,
+                                                           const double* __restrict__ l_mu,
+                                                           const double* __restrict__ l_sigma,
+                                                           double* __restrict__ u_mu,
+                                                           double* __restrict__ u_sigma) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    double q[NS][NS], kfb[NU][NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) q[i][j] = qg[(t * NS + i) * NS + j];
+#pragma unroll
+    for (int k = 0; k < NU; ++k)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) kfb[k][j] = kg[(t * NU + k) * NS + j];
+    const double r2 = sr_lambda_max_qb<NS, NU>(q, kfb);
+    const double r1 = sqrt(r2);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        u_mu[t * NS + i] = l_mu[i] * r2;
+        u_sigma[t * NS + i] = l_sigma[i] * r1;
+    }
+}
+
+// d[t][m] = h_m . p + c sqrt(h_m Q h_m^T) - h_vec[m]           (gp_reachability.py:245-248)
+__global__ __launch_bounds__(256) void sr_safety_kernel(long T, int n_s, int m,
+                                                        const double* __restrict__ p,
+                                                        const double* __restrict__ q,
+                                                        const double* __restrict__ h_mat,
+                                                        const double* __restrict__ h_vec, double c,
+                                                        double* __restrict__ d) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const double* pt = p + t * n_s;
+    const double* qt = q + t * n_s * n_s;
+    for (int r = 0; r < m; ++r) {
+        const double* h = h_mat + r * n_s;
+        double dc = 0.0, quad = 0.0;
+        for (int i = 0; i < n_s; ++i) {
+            dc = fma(h[i], pt[i], dc);
+            double s = 0.0;
+            for (int j = 0; j < n_s; ++j) s = fma(qt[i * n_s + j], h[j], s);
+            quad = fma(s, h[i], quad);
+        }
+        d[t * m + r] = dc + c * sqrt(quad) - h_vec[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch on (n_s, n_u)
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+static int launch_ell_ns(const sr_ell_args& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.T + 255) / 256));
+    switch (a.n_u) {
+        case 1: hipLaunchKernelGGL((sr_ellipsoid_kernel<NS, 1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((sr_ellipsoid_kernel<NS, 2>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((sr_ellipsoid_kernel<NS, 3>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((sr_ellipsoid_kernel<NS, 4>), grid, dim3(256), 0, s, a); break;
+        default: sr_set_error("ellipsoid: n_u=%d outside 1..%d", a.n_u, SR_MAX_NU); return SR_EUNSUPPORTED;
+    }
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_launch_ellipsoid(const sr_ell_args& a, hipStream_t s) {
+    if (a.T <= 0) return SR_OK;
+    switch (a.n_s) {
+        case 1: return launch_ell_ns<1>(a, s);
+        case 2: return launch_ell_ns<2>(a, s);
+        case 3: return launch_ell_ns<3>(a, s);
+        case 4: return launch_ell_ns<4>(a, s);
+        case 5: return launch_ell_ns<5>(a, s);
+        case 6: return launch_ell_ns<6>(a, s);
+        case 7: return launch_ell_ns<7>(a, s);
+        case 8: return launch_ell_ns<8>(a, s);
+        default: sr_set_error("ellipsoid: n_s=%d outside 1..%d", a.n_s, SR_MAX_NS); return SR_EUNSUPPORTED;
+    }
+}
+
+template <int NS>
+static int launch_rem_ns(long T, int n_u, const double* q, const double* k, const double* lm,
+                         const double* lsg, double* um, double* us, hipStream_t s) {
+    dim3 grid((unsigned)((T + 255) / 256));
+    switch (n_u) {
+        case 1: hipLaunchKernelGGL((sr_remainder_kernel<NS, 1>), grid, dim3(256), 0, s, T, q, k, lm, lsg, um, us); break;
+        case 2: hipLaunchKernelGGL((sr_remainder_kernel<NS, 2>), grid, dim3(256), 0, s, T, q, k, lm, lsg, um, us); break;
+        case 3: hipLaunchKernelGGL((sr_remainder_kernel<NS, 3>), grid, dim3(256), 0, s, T, q, k, lm, lsg, um, us); break;
+        case 4: hipLaunchKernelGGL((sr_remainder_kernel<NS, 4>), grid, dim3(256), 0, s, T, q, k, lm, lsg, um, us); break;
+        default: sr_set_error("remainder: n_u=%d outside 1..%d", n_u, SR_MAX_NU); return SR_EUNSUPPORTED;
+    }
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_launch_remainder(long T, int n_s, int n_u, const double* q, const double* k_fb,
+                        const double* l_mu, const double* l_sigma, double* u_mu, double* u_sigma,
+                        hipStream_t s) {
+    if (T <= 0) return SR_OK;
+    switch (n_s) {
+        case 1: return launch_rem_ns<1>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        case 2: return launch_rem_ns<2>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        case 3: return launch_rem_ns<3>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        case 4: return launch_rem_ns<4>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        case 5: return launch_rem_ns<5>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        case 6: return launch_rem_ns<6>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        case 7: return launch_rem_ns<7>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        case 8: return launch_rem_ns<8>(T, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, s);
+        default: sr_set_error("remainder: n_s=%d outside 1..%d", n_s, SR_MAX_NS); return SR_EUNSUPPORTED;
+    }
+}
+
+int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, const double* h_mat,
+                     const double* h_vec, double c, double* d, hipStream_t s) {
+    if (T <= 0) return SR_OK;
+    hipLaunchKernelGGL(sr_safety_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, T, n_s,
+                       m, p, q, h_mat, h_vec, c, d);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}

@@ -1,0 +1,233 @@
+// sr_factor.hip -- model-update path: Gram matrix, blocked fp64-MFMA Cholesky
+// K = U^T U, explicit triangular inverse W = U^-T by blocked forward substitution, helpers.
+//
+// replaces (numerically) what GPy computes for SimpleGPModel.train / update_model:
+//   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:238-275, 398-419
+#include "sr_mfma_tile.h"
+
+// ------------------------------------------------------------------------------------------------
+// generic TN GEMM on the fp64 matrix cores
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void sr_gemm_tn_kernel(
+    const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* C,
+    long ldc, int K, double alpha, double beta, int mode) {
+    __shared__ double smem[srt::SMEM_DOUBLES];
+    const int m0 = blockIdx.y * srt::BM;
+    const int n0 = blockIdx.x * srt::BN;
+    if (mode == 1 && n0 < m0) return;
+    const int k_beg = (mode == 2) ? n0 : 0;
+
+    srt::Acc acc;
+    acc.zero();
+    srt::mainloop_tn(A + m0, lda, B + n0, ldb, k_beg, K, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = m0 + srt::acc_row(wm, mi, lane, r);
+                const long col = n0 + srt::acc_col(wn, ni, lane);
+                double* c = C + row * ldc + col;
+                double v = alpha * acc.v[mi][ni][r];
+                if (beta != 0.0) v += beta * (*c);
+                *c = v;
+            }
+}
+
+int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s) {
+    SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && M > 0 && N > 0, SR_EINVAL,
+             "gemm_tn: M=%d N=%d K=%d must be tile multiples", M, N, K);
+    dim3 grid(N / srt::BN, M / srt::BM);
+    hipLaunchKernelGGL(sr_gemm_tn_kernel, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
+                       beta, mode);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gram matrix K[i][j] = sf2 exp(-0.5 |(z_i - z_j)/l|^2) + noise (i==j); identity on the padding.
+// (kernel spec: ssm_gpy/gp_models_utils_casadi.py:17-40; noise on the diagonal:
+//  ssm_gpy/gaussian_process.py:252-253)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__ Z,
+                                                      const double* __restrict__ ls, double sf2,
+                                                      double noise, double* __restrict__ K, int N,
+                                                      int Np, int D) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Np) return;
+    double v;
+    if (i >= N || j >= N) {
+        v = (i == j) ? 1.0 : 0.0;
+    } else {
+        double r2 = 0.0;
+        for (int c = 0; c < D; ++c) {
+            const double t = (Z[(long)i * D + c] - Z[(long)j * D + c]) / ls[c];
+            r2 += t * t;
+        }
+        v = sf2 * exp(-0.5 * r2);
+        if (i == j) v = sf2 + noise;
+    }
+    K[(long)i * Np + j] = v;
+}
+
+int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, double* K, int N,
+                   int Np, int D, hipStream_t s) {
+    dim3 grid((Np + 255) / 256, Np);
+    hipLaunchKernelGGL(sr_gram_kernel, grid, dim3(256), 0, s, Z, ls, sf2, noise, K, N, Np, D);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Diagonal block: A_kk = U_kk^T U_kk (upper Cholesky) and in-place inverse of U_kk, all in LDS.
+// One workgroup; 128 x 129 doubles of LDS (132 KiB of the CU's 160 KiB).
+// ------------------------------------------------------------------------------------------------
+#define SR_PD_LD 129
+__global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long lda,
+                                                               double* wt_diag, double* w_diag,
+                                                               long ldw, int kb, int* info) {
+    __shared__ double S[SR_NB * SR_PD_LD];
+    __shared__ double dg[SR_NB];
+    __shared__ double tmp[SR_NB];
+    __shared__ int fail;
+    const int tid = threadIdx.x;
+    const long k0 = (long)kb * SR_NB;
+    if (tid == 0) fail = 0;
+    for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        S[r * SR_PD_LD + c] = (c >= r) ? A[(k0 + r) * lda + k0 + c] : 0.0;
+    }
+    __syncthreads();
+
+    // right-looking upper Cholesky, S[j][j] keeps the pivot d_j until the end (sqrt kept in dg)
+    const int c_own = tid & 127, half = tid >> 7;
+    for (int j = 0; j < SR_NB; ++j) {
+        const double d = S[j * SR_PD_LD + j];
+        if (!(d > 0.0)) {                       // also catches NaN; uniform across the workgroup
+            if (tid == 0) fail = j + 1;
+            break;
+        }
+        const double sd = sqrt(d);
+        const double inv = 1.0 / sd;
+        if (tid == 0) dg[j] = sd;
+        if (tid < SR_NB && tid > j) S[j * SR_PD_LD + tid] *= inv;
+        __syncthreads();
+        if (c_own > j) {
+            const double ujc = S[j * SR_PD_LD + c_own];
+            for (int r = j + 1 + half; r <= c_own; r += 2)
+                S[r * SR_PD_LD + c_own] -= S[j * SR_PD_LD + r] * ujc;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (fail) {
+        if (tid == 0 && *info == 0) *info = (int)k0 + fail;
+        // keep downstream kernels finite: identity block
+        for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+            const int r = idx >> 7, c = idx & 127;
+            const double v = (r == c) ? 1.0 : 0.0;
+            A[(k0 + r) * lda + k0 + c] = v;
+            wt_diag[(long)r * ldw + c] = v;
+            w_diag[(long)r * ldw + c] = v;
+        }
+        return;
+    }
+    if (tid < SR_NB) S[tid * SR_PD_LD + tid] = dg[tid];
+    __syncthreads();
+    for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        A[(k0 + r) * lda + k0 + c] = S[r * SR_PD_LD + c];   // strict lower part is zero in S
+    }
+    __syncthreads();
+
+    // in-place inverse of the upper-triangular block, column by column
+    for (int j = 0; j < SR_NB; ++j) {
+        if (tid < j) tmp[tid] = S[tid * SR_PD_LD + j];
+        __syncthreads();
+        const double invjj = 1.0 / S[j * SR_PD_LD + j];
+        __syncthreads();
+        if (tid < j) {
+            double s = 0.0;
+            for (int k = tid; k < j; ++k) s += S[tid * SR_PD_LD + k] * tmp[k];
+            S[tid * SR_PD_LD + j] = -s * invjj;
+        } else if (tid == j) {
+            S[j * SR_PD_LD + j] = invjj;
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        wt_diag[(long)r * ldw + c] = S[r * SR_PD_LD + c];    // U_kk^-1   (upper)
+        w_diag[(long)r * ldw + c] = S[c * SR_PD_LD + r];     // U_kk^-T   (lower)
+    }
+}
+
+int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw, int kb,
+                         int* info_dev, hipStream_t s) {
+    hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(256), 0, s, A, lda, wt_diag, w_diag, ldw,
+                       kb, info_dev);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_transpose_kernel(const double* __restrict__ src,
+                                                           double* __restrict__ dst, int n) {
+    __shared__ double t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) t[r][tx] = src[(long)(by + r) * n + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) dst[(long)(bx + r) * n + by + tx] = t[tx][r];
+}
+
+int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s) {
+    SR_CHECK(n % 32 == 0, SR_EINVAL, "transpose: n=%d not a multiple of 32", n);
+    hipLaunchKernelGGL(sr_transpose_kernel, dim3(n / 32, n / 32), dim3(256), 0, s, src, dst, n);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// one wavefront per row; shuffle reduction
+__global__ __launch_bounds__(256) void sr_trmv_kernel(const double* __restrict__ M, long ld,
+                                                      const double* __restrict__ x,
+                                                      double* __restrict__ y, int n, int lower) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int c0 = lower ? 0 : row, c1 = lower ? row + 1 : n;
+    double s = 0.0;
+    for (int c = c0 + lane; c < c1; c += 64) s += M[(long)row * ld + c] * x[c];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) y[row] = s;
+}
+
+int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(sr_trmv_kernel, dim3((n + 3) / 4), dim3(256), 0, s, M, ld, x, y, n, lower);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+__global__ __launch_bounds__(256) void sr_fill_kernel(double* p, size_t n, double v) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+int sr_launch_fill(double* p, size_t n, double v, hipStream_t s) {
+    if (n == 0) return SR_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sr_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}

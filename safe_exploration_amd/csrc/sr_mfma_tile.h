@@ -1,0 +1,128 @@
+// sr_mfma_tile.h -- fp64 MFMA "TN" tile main loop for gfx950 (v_mfma_f64_16x16x4_f64).
+//
+//   acc[m][n] += sum_{k in [k_beg, k_end)} A[k][m] * B[k][n]
+//
+// Both operands are k-major (row k holds contiguous m resp. n), which is how this library stores
+// every matrix it multiplies (U, W, Wt, K*): a BK x 128 tile is BK fully coalesced 1 KiB rows and
+// lands in LDS unchanged; MFMA fragments are then read with conflict-free ds_read_b64
+// (row stride 144 doubles = 288 dwords == 32 mod 64 -> the two k-rows a 32-lane group touches sit on
+// opposite bank halves).
+//
+// Workgroup: 256 threads = 4 wavefronts (2 x 2), each wavefront owns a 64 x 64 sub-tile
+// = 4 x 4 MFMA tiles of 16 x 16 (64 accumulator doubles / lane).  Global->LDS is register-staged and
+// double-buffered: the loads for k-tile t+1 are issued before the MFMAs of k-tile t.
+#pragma once
+#include "sr_common.h"
+
+namespace srt {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = 144;                     // padded LDS row (doubles)
+constexpr int STAGE = BK * LDT;              // doubles per operand per stage
+constexpr int SMEM_DOUBLES = 4 * STAGE;      // A,B x 2 stages  (73,728 B)
+
+struct Acc {
+    d4_t v[4][4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+};
+
+// element (mi, ni, r) of the accumulator is C[row][col] with
+//   row = wm*64 + mi*16 + (lane>>4) + 4*r ,  col = wn*64 + ni*16 + (lane&15)
+__device__ __forceinline__ int acc_row(int wm, int mi, int lane, int r) {
+    return wm * 64 + mi * 16 + (lane >> 4) + 4 * r;
+}
+__device__ __forceinline__ int acc_col(int wn, int ni, int lane) {
+    return wn * 64 + ni * 16 + (lane & 15);
+}
+
+// A points at A[0][m0], B at B[0][n0] (row strides lda/ldb in doubles); k range [k_beg, k_end),
+// both multiples of BK.  smem: SMEM_DOUBLES doubles.  All 256 threads must call.
+__device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long lda,
+                                            const double* __restrict__ B, long ldb,
+                                            int k_beg, int k_end, double* smem, Acc& acc) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    double* As = smem;                 // [2][BK][LDT]
+    double* Bs = smem + 2 * STAGE;     // [2][BK][LDT]
+
+    // staging map: 16 rows x 64 double2 per operand; thread handles 4 double2 per operand
+    // e = tid + j*256 -> row = e >> 6 (one wavefront == one 1 KiB row), c2 = e & 63
+    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const int c2 = tid & 63;
+    const int r0 = tid >> 6;           // rows r0, r0+4, r0+8, r0+12
+    const double* ga = A + (long)r0 * lda + 2 * c2;
+    const double* gb = B + (long)r0 * ldb + 2 * c2;
+    const int so = r0 * LDT + 2 * c2;  // LDS offset of row r0 inside a stage
+
+#define SRT_GLOAD(k0)                                                                   \
+    do {                                                                                \
+        const double* pa_ = ga + (long)(k0) * lda;                                      \
+        const double* pb_ = gb + (long)(k0) * ldb;                                      \
+        ra0 = *reinterpret_cast<const double2*>(pa_);                                   \
+        ra1 = *reinterpret_cast<const double2*>(pa_ + 4 * lda);                         \
+        ra2 = *reinterpret_cast<const double2*>(pa_ + 8 * lda);                         \
+        ra3 = *reinterpret_cast<const double2*>(pa_ + 12 * lda);                        \
+        rb0 = *reinterpret_cast<const double2*>(pb_);                                   \
+        rb1 = *reinterpret_cast<const double2*>(pb_ + 4 * ldb);                         \
+        rb2 = *reinterpret_cast<const double2*>(pb_ + 8 * ldb);                         \
+        rb3 = *reinterpret_cast<const double2*>(pb_ + 12 * ldb);                        \
+    } while (0)
+#define SRT_SSTORE(buf)                                                                 \
+    do {                                                                                \
+        double* sa_ = As + (buf) * STAGE + so;                                          \
+        double* sb_ = Bs + (buf) * STAGE + so;                                          \
+        *reinterpret_cast<double2*>(sa_) = ra0;                                         \
+        *reinterpret_cast<double2*>(sa_ + 4 * LDT) = ra1;                               \
+        *reinterpret_cast<double2*>(sa_ + 8 * LDT) = ra2;                               \
+        *reinterpret_cast<double2*>(sa_ + 12 * LDT) = ra3;                              \
+        *reinterpret_cast<double2*>(sb_) = rb0;                                         \
+        *reinterpret_cast<double2*>(sb_ + 4 * LDT) = rb1;                               \
+        *reinterpret_cast<double2*>(sb_ + 8 * LDT) = rb2;                               \
+        *reinterpret_cast<double2*>(sb_ + 12 * LDT) = rb3;                              \
+    } while (0)
+
+    if (k_beg >= k_end) return;
+    SRT_GLOAD(k_beg);
+    SRT_SSTORE(0);
+    __syncthreads();
+
+    const int fa = (lane >> 4) * LDT + wm * 64 + (lane & 15);   // fragment offsets inside a stage
+    const int fb = (lane >> 4) * LDT + wn * 64 + (lane & 15);
+
+    int buf = 0;
+    for (int k0 = k_beg; k0 < k_end; k0 += BK) {
+        const bool more = (k0 + BK) < k_end;
+        if (more) SRT_GLOAD(k0 + BK);
+        const double* as = As + buf * STAGE + fa;
+        const double* bs = Bs + buf * STAGE + fb;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = as[kk * 4 * LDT + i * 16];
+                bf[i] = bs[kk * 4 * LDT + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0);
+        }
+        if (more) SRT_SSTORE(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef SRT_GLOAD
+#undef SRT_SSTORE
+}
+
+}  // namespace srt

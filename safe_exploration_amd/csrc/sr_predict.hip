@@ -1,0 +1,209 @@
+// sr_predict.hip -- batched GP posterior: the per-control-step inference kernels.
+//
+//   K1 sr_kstar_kernel : RBF cross-covariance K*(Z, Xq) written once to HBM (k-major, queries
+//                        contiguous) fused with mu = k* alpha and d mu/dx      [VALU/exp bound]
+//   K2 sr_var_kernel   : |W k*|^2 = column norms of the block-triangular product Wt^T K*, on the
+//                        fp64 matrix cores, never storing the product          [MFMA bound, dominant]
+//   K3 sr_finalize     : var = sf2 - sum_rb part, clip 1e-15, transpose to the API layout
+//
+// formulas: /root/reference/safe_exploration/ssm_gpy/gp_models_utils_casadi.py:17-40,160-197
+// shapes:   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:546-596
+#include "sr_mfma_tile.h"
+
+// ------------------------------------------------------------------------------------------------
+// K1: one thread per (query, output); training inputs staged through LDS in tiles of 256 rows,
+// pre-scaled by 1/lengthscale so a pair costs D sub + D fma + exp; all lanes read the same LDS
+// address (broadcast).  K* stores: 64 consecutive queries per wavefront = 512 B contiguous.
+// ------------------------------------------------------------------------------------------------
+#define SR_ZT 256
+template <int DT>
+__global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
+    __shared__ double zs[SR_ZT * DT];
+    __shared__ double al[SR_ZT];
+    const int d = blockIdx.y, sp = blockIdx.z;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < a.T;
+    const bool inpad = t < a.Tp;
+
+    double inv_l[DT], xs[DT], g[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        inv_l[j] = (j < a.D) ? 1.0 / a.ls[d * a.D + j] : 0.0;
+        double x = 0.0;
+        if (live && j < a.D)
+            x = (j < a.na) ? a.xa[t * a.lda + j] : a.xb[t * a.ldb + (j - a.na)];
+        xs[j] = x * inv_l[j];
+        g[j] = 0.0;
+    }
+    const double sf2 = a.sf2[d];
+    double mu = 0.0;
+
+    const int rows_per = (a.Np + a.nsplit - 1) / a.nsplit;
+    const int i_beg = sp * rows_per;
+    const int i_end = min(a.Np, i_beg + rows_per);
+    double* ks_col = a.Ks + (long)d * a.Np * a.Tp + t;
+
+    for (int i0 = i_beg; i0 < i_end; i0 += SR_ZT) {
+        const int nrow = min(SR_ZT, i_end - i0);
+        __syncthreads();
+        {
+            const int r = threadIdx.x;
+            const int i = i0 + r;
+            const bool ok = (r < nrow) && (i < a.N);
+#pragma unroll
+            for (int j = 0; j < DT; ++j)
+                zs[r * DT + j] = (ok && j < a.D) ? a.Z[(long)i * a.D + j] * inv_l[j] : 0.0;
+            al[r] = ok ? a.alpha[(long)d * a.Np + i] : 0.0;
+        }
+        __syncthreads();
+        const int nvalid = max(0, min(nrow, a.N - i0));
+        if (inpad) {
+            for (int r = 0; r < nvalid; ++r) {
+                double diff[DT];
+                double r2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    diff[j] = xs[j] - zs[r * DT + j];
+                    r2 = fma(diff[j], diff[j], r2);
+                }
+                const double k = live ? sf2 * exp(-0.5 * r2) : 0.0;
+                ks_col[(long)(i0 + r) * a.Tp] = k;
+                const double w = k * al[r];
+                mu += w;
+#pragma unroll
+                for (int j = 0; j < DT; ++j) g[j] = fma(-w, diff[j], g[j]);
+            }
+            for (int r = nvalid; r < nrow; ++r) ks_col[(long)(i0 + r) * a.Tp] = 0.0;
+        }
+    }
+    if (inpad) {
+        a.mu_part[((long)sp * a.n_out + d) * a.Tp + t] = mu;
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+            if (j < a.D)
+                a.jac_part[(((long)sp * a.n_out + d) * a.D + j) * a.Tp + t] = g[j] * inv_l[j];
+    }
+}
+
+int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.Tp + 255) / 256), a.n_out, a.nsplit);
+#define SR_KSTAR_CASE(DT) \
+    hipLaunchKernelGGL(sr_kstar_kernel<DT>, grid, dim3(256), 0, s, a)
+    if (a.D <= 3) SR_KSTAR_CASE(3);
+    else if (a.D <= 5) SR_KSTAR_CASE(5);
+    else if (a.D <= 8) SR_KSTAR_CASE(8);
+    else if (a.D <= 12) SR_KSTAR_CASE(12);
+    else { sr_set_error("kstar: D=%d > %d", a.D, SR_MAX_D); return SR_EUNSUPPORTED; }
+#undef SR_KSTAR_CASE
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: for row block rb (128 rows of V = W K*) and query tile x (128 queries):
+//        V[i][t] = sum_{k <= i} Wt[k][i] * Ks[k][t]     (Wt = U^-1, upper triangular, k-major)
+//        part[rb][t] = sum_{i in rb} V[i][t]^2
+// K range is [0, (rb+1)*128): the block-triangular structure halves the flops of a dense product.
+// Work items are ordered heavy-first (rb descending) inside groups of `group` query tiles; blocks
+// b, b+8, ... share an XCD (dispatch is round-robin over the 8 XCDs), so with the query-tile index
+// fastest each XCD's L2 sees group/8 query tiles x all row blocks: W tiles are shared between the
+// query tiles, K* tiles between the row blocks.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict__ Wt,
+                                                        const double* __restrict__ Ks,
+                                                        double* __restrict__ part, int Np, long Tp,
+                                                        int nrb, int ntq, int group) {
+    __shared__ double smem[srt::SMEM_DOUBLES];
+    const long per_d = (long)nrb * ntq;
+    const int ngrp = (ntq + group - 1) / group;
+    const long per_d_padded = (long)ngrp * nrb * group;
+    const long b = blockIdx.x;
+    const int d = (int)(b / per_d_padded);
+    long rem = b % per_d_padded;
+    const int xg = (int)(rem / ((long)nrb * group));
+    rem = rem % ((long)nrb * group);
+    const int rb = nrb - 1 - (int)(rem / group);
+    const int x = xg * group + (int)(rem % group);
+    if (x >= ntq) return;
+    (void)per_d;
+
+    const double* A = Wt + (long)d * Np * Np + (long)rb * srt::BM;
+    const double* B = Ks + (long)d * Np * Tp + (long)x * srt::BN;
+
+    srt::Acc acc;
+    acc.zero();
+    srt::mainloop_tn(A, Np, B, Tp, 0, (rb + 1) * srt::BM, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    double s[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        double v = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v = fma(acc.v[mi][ni][r], acc.v[mi][ni][r], v);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        s[ni] = v;
+    }
+    // mainloop_tn ended with a barrier: smem is free.  red[wm][128]
+    double* red = smem;
+    if (lane < 16) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) red[wm * 128 + wn * 64 + ni * 16 + lane] = s[ni];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const double v = red[threadIdx.x] + red[128 + threadIdx.x];
+        part[((long)d * nrb + rb) * Tp + (long)x * srt::BN + threadIdx.x] = v;
+    }
+}
+
+int sr_launch_var(const double* Wt, const double* Ks, double* part, int Np, long Tp, int n_out,
+                  int group, hipStream_t s) {
+    const int nrb = Np / srt::BM;
+    const int ntq = (int)(Tp / srt::BN);
+    if (group < 1) group = 1;
+    if (group > ntq) group = ntq;
+    const int ngrp = (ntq + group - 1) / group;
+    const long blocks = (long)n_out * ngrp * nrb * group;
+    SR_CHECK(blocks < 2147483647L, SR_EINVAL, "var: grid too large (%ld blocks)", blocks);
+    hipLaunchKernelGGL(sr_var_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
+                       nrb, ntq, group);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: reduce partials, clip, write API layout (T x n_out [x D]).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_finalize_kernel(sr_final_args a) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int d = blockIdx.y;
+    if (t >= a.T) return;
+    double m = 0.0;
+    for (int s = 0; s < a.nsplit; ++s) m += a.mu_part[((long)s * a.n_out + d) * a.Tp + t];
+    double q = 0.0;
+    for (int rb = 0; rb < a.nrb; ++rb) q += a.var_part[((long)d * a.nrb + rb) * a.Tp + t];
+    double v = a.sf2[d] - q;
+    if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+    a.mu[t * a.n_out + d] = m;
+    a.var[t * a.n_out + d] = v;
+    if (a.jac) {
+        for (int j = 0; j < a.D; ++j) {
+            double gj = 0.0;
+            for (int s = 0; s < a.nsplit; ++s)
+                gj += a.jac_part[(((long)s * a.n_out + d) * a.D + j) * a.Tp + t];
+            a.jac[(t * a.n_out + d) * a.D + j] = gj;
+        }
+    }
+}
+
+int sr_launch_finalize(const sr_final_args& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.T + 255) / 256), a.n_out);
+    hipLaunchKernelGGL(sr_finalize_kernel, grid, dim3(256), 0, s, a);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}

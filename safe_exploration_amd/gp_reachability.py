@@ -1,0 +1,236 @@
+"""Ellipsoidal one-step / multi-step reachability on MI355X.
+
+Same function names, positional orders and return conventions as
+/root/reference/safe_exploration/gp_reachability.py:19-250; the ``*_batch`` variants carry a
+leading T axis (T query states / T candidate trajectories) and are what the benchmark measures.
+All arithmetic happens in the HIP kernels behind include/safereach.h:
+
+  * ssm is a HIP ``SimpleGPModel``  -> sr_onestep_reach / sr_multistep_reach (GP + ellipsoid fused
+    on the device, nothing returns to the host between the kernels),
+  * any other StateSpaceModel     -> its ``ssm(x, u)`` is called on the host exactly like the
+    reference does (gp_reachability.py:74,101) and the ellipsoid algebra runs in sr_ellipsoid_step.
+"""
+import numpy as np
+
+from . import _buffers as B
+from ._lib import lib, check
+from .ssm_hip.gaussian_process import SimpleGPModel
+from .utils import print_ellipsoid
+
+
+def _lin_model(a, b, n_s, n_u):
+    if a is None:                      # gp_reachability.py:61-63
+        a = np.eye(n_s)
+        b = np.zeros((n_s, n_u))
+    return np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+
+
+def _raise_if_bad(n_bad):
+    if n_bad is not None and int(n_bad.item()) > 0:
+        # the reference asserts inside ellipsoid_from_rectangle (utils_ellipsoid.py:226-228)
+        raise AssertionError("all elements of u_b need to be greater than zero! "
+                             "({} query state(s) affected)".format(int(n_bad.item())))
+
+
+def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None, k_fb=None,
+                               c_safety=1., a=None, b=None, check_bounds=False, return_var=False):
+    """Batched ``onestep_reachability``.
+
+    p_center (T,n_s); k_ff (T,n_u); q_shape (T,n_s,n_s) or None; k_fb (T,n_u,n_s) or None.
+    numpy in -> numpy out, torch (device) in -> torch out.  Requires a HIP ``SimpleGPModel``.
+    Returns p_new (T,n_s), q_new (T,n_s,n_s) [, var (T,n_s)].
+    """
+    if not isinstance(ssm, SimpleGPModel):
+        raise TypeError("onestep_reachability_batch needs the HIP SimpleGPModel")
+    as_t = B.is_tensor(p_center)
+    hd = ssm._handle
+    ssm._need_trained()
+    dev = hd.device
+    n_s, n_u = hd.n_out, hd.D - hd.n_out
+    p = B.as_dev(p_center, dev)
+    T = p.shape[0]
+    if p.dim() != 2 or p.shape[1] != n_s:
+        raise ValueError("p_center must be (T, {})".format(n_s))
+    kff = B.as_dev(k_ff, dev, (T, n_u))
+    q = B.as_dev(q_shape, dev, (T, n_s, n_s)) if q_shape is not None else None
+    if q is not None and k_fb is None:
+        raise ValueError("k_fb is required when q_shape is given")
+    kfb = B.as_dev(k_fb, dev, (T, n_u, n_s)) if (k_fb is not None and q is not None) else None
+    a, b = _lin_model(a, b, n_s, n_u)
+    ta, tb = B.as_dev(a, dev, (n_s, n_s)), B.as_dev(b, dev, (n_s, n_u))
+    tlm, tls = B.as_dev(np.reshape(l_mu, (-1,)), dev, (n_s,)), B.as_dev(np.reshape(l_sigma, (-1,)), dev, (n_s,))
+    p_out = B.empty((T, n_s), dev)
+    q_out = B.empty((T, n_s, n_s), dev)
+    var = B.empty((T, n_s), dev) if return_var else None
+    n_bad = B.zeros_i32(1, dev) if check_bounds else None
+    check(lib.sr_onestep_reach(hd.h, T, B.ptr(p), B.ptr(q), B.ptr(kff), B.ptr(kfb), B.ptr(ta),
+                               B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety), B.ptr(p_out),
+                               B.ptr(q_out), B.ptr(var), B.ptr(n_bad), B.stream_ptr(dev)))
+    _raise_if_bad(n_bad)
+    outs = (p_out, q_out, var) if return_var else (p_out, q_out)
+    return outs if as_t else tuple(B.to_numpy(o) for o in outs)
+
+
+def ellipsoid_step_batch(p_center, k_ff, mu, var, jac, l_mu, l_sigma, q_shape=None, k_fb=None,
+                         c_safety=1., a=None, b=None, check_bounds=False, device=None):
+    """The ellipsoid algebra of gp_reachability.py:65-156 for T queries whose GP outputs
+    (mu (T,n_s), var (T,n_s), jac (T,n_s,n_s+n_u)) are supplied by the caller."""
+    as_t = B.is_tensor(p_center)
+    dev = B.resolve_device(p_center.device if as_t else device)
+    p = B.as_dev(p_center, dev)
+    T, n_s = p.shape
+    kff = B.as_dev(k_ff, dev).reshape(T, -1)
+    n_u = kff.shape[1]
+    tmu, tvar = B.as_dev(mu, dev, (T, n_s)), B.as_dev(var, dev, (T, n_s))
+    q = B.as_dev(q_shape, dev, (T, n_s, n_s)) if q_shape is not None else None
+    if q is not None and (k_fb is None or jac is None):
+        raise ValueError("k_fb and jac are required when q_shape is given")
+    kfb = B.as_dev(k_fb, dev, (T, n_u, n_s)) if q is not None else None
+    tjac = B.as_dev(jac, dev, (T, n_s, n_s + n_u)) if (jac is not None and q is not None) else None
+    a, b = _lin_model(a, b, n_s, n_u)
+    ta, tb = B.as_dev(a, dev, (n_s, n_s)), B.as_dev(b, dev, (n_s, n_u))
+    tlm, tls = B.as_dev(np.reshape(l_mu, (-1,)), dev, (n_s,)), B.as_dev(np.reshape(l_sigma, (-1,)), dev, (n_s,))
+    p_out = B.empty((T, n_s), dev)
+    q_out = B.empty((T, n_s, n_s), dev)
+    n_bad = B.zeros_i32(1, dev) if check_bounds else None
+    check(lib.sr_ellipsoid_step(dev.index, T, n_s, n_u, B.ptr(p), B.ptr(q), B.ptr(kff), B.ptr(kfb),
+                                B.ptr(tmu), B.ptr(tvar), B.ptr(tjac), B.ptr(ta), B.ptr(tb),
+                                B.ptr(tlm), B.ptr(tls), float(c_safety), B.ptr(p_out), B.ptr(q_out),
+                                B.ptr(n_bad), B.stream_ptr(dev)))
+    _raise_if_bad(n_bad)
+    return (p_out, q_out) if as_t else (B.to_numpy(p_out), B.to_numpy(q_out))
+
+
+def onestep_reachability(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None, k_fb=None,
+                         c_safety=1., verbose=1, a=None, b=None):
+    """Overapproximate the reachable set of states under the affine control law u = K(x-p) + k.
+
+    Single-query semantics and argument order of gp_reachability.py:19-156.
+    p_center (n_s,1); k_ff (n_u,1); q_shape (n_s,n_s) or None; k_fb (n_u,n_s) or None.
+    Returns p_new (n_s,1), q_new (n_s,n_s).
+    """
+    p_center = np.asarray(p_center, dtype=np.float64)
+    k_ff = np.asarray(k_ff, dtype=np.float64)
+    n_s = np.shape(p_center)[0]
+    n_u = np.shape(k_ff)[0]
+    if verbose > 0:
+        if q_shape is not None:
+            print_ellipsoid(p_center, q_shape, text="initial uncertainty ellipsoid")
+        print("\nApplying action:")
+        print(k_ff)
+    q_b = None if q_shape is None else np.asarray(q_shape, dtype=np.float64)[None]
+    kfb_b = None if (k_fb is None or q_shape is None) else np.asarray(k_fb, dtype=np.float64)[None]
+    if isinstance(ssm, SimpleGPModel):
+        p1, q1 = onestep_reachability_batch(p_center.T, ssm, k_ff.T, l_mu, l_sigma, q_b, kfb_b,
+                                            c_safety, a, b, check_bounds=True)
+    else:
+        out = ssm(p_center.T, k_ff.T)                  # (mu n x 1, sigma n x 1, jac n x D)
+        mu_0, sigm_0 = np.array(out[0], dtype=np.float64), np.array(out[1], dtype=np.float64)
+        jac_mu = np.array(out[2], dtype=np.float64)[None] if q_shape is not None else None
+        p1, q1 = ellipsoid_step_batch(p_center.T, k_ff.T, mu_0.reshape(1, n_s), sigm_0.reshape(1, n_s),
+                                      jac_mu, l_mu, l_sigma, q_b, kfb_b, c_safety, a, b,
+                                      check_bounds=True)
+    p_1, q_1 = p1.reshape(n_s, 1), q1[0]
+    if verbose > 0:
+        print_ellipsoid(p_1, q_1, text="accumulated uncertainty current step")
+    return p_1, q_1
+
+
+def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_safety=1., a=None,
+                                 b=None, k_fb_init=None, check_bounds=False):
+    """Batched ``multistep_reachability``: T independent trajectories, H sequential steps each.
+
+    p_0 (T,n_s); k_fb (T,H-1,n_u,n_s); k_ff (T,H,n_u); q_0 (T,n_s,n_s) or None;
+    k_fb_init (T,n_u,n_s) (needed iff q_0 is given).  Returns p_all (T,H,n_s), q_all (T,H,n_s,n_s).
+    """
+    if not isinstance(gp, SimpleGPModel):
+        raise TypeError("multistep_reachability_batch needs the HIP SimpleGPModel")
+    gp._need_trained()
+    as_t = B.is_tensor(p_0)
+    hd = gp._handle
+    dev = hd.device
+    n_s, n_u = hd.n_out, hd.D - hd.n_out
+    p0 = B.as_dev(p_0, dev)
+    T = p0.shape[0]
+    kff = B.as_dev(k_ff, dev)
+    if kff.dim() != 3 or kff.shape[0] != T or kff.shape[2] != n_u:
+        raise ValueError("k_ff must be (T, H, {})".format(n_u))
+    H = kff.shape[1]
+    kfb = B.as_dev(k_fb, dev, (T, H - 1, n_u, n_s)) if H > 1 else None
+    q0 = B.as_dev(q_0, dev, (T, n_s, n_s)) if q_0 is not None else None
+    if q0 is not None and k_fb_init is None:
+        raise ValueError("k_fb_init is required when q_0 is given")
+    kfb0 = B.as_dev(k_fb_init, dev, (T, n_u, n_s)) if q0 is not None else None
+    a, b = _lin_model(a, b, n_s, n_u)
+    ta, tb = B.as_dev(a, dev, (n_s, n_s)), B.as_dev(b, dev, (n_s, n_u))
+    tlm, tls = B.as_dev(np.reshape(L_mu, (-1,)), dev, (n_s,)), B.as_dev(np.reshape(L_sigm, (-1,)), dev, (n_s,))
+    p_all = B.empty((T, H, n_s), dev)
+    q_all = B.empty((T, H, n_s, n_s), dev)
+    n_bad = B.zeros_i32(1, dev) if check_bounds else None
+    check(lib.sr_multistep_reach(hd.h, T, H, B.ptr(p0), B.ptr(q0), B.ptr(kfb0), B.ptr(kff), B.ptr(kfb),
+                                 B.ptr(ta), B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety),
+                                 B.ptr(p_all), B.ptr(q_all), B.ptr(n_bad), B.stream_ptr(dev)))
+    _raise_if_bad(n_bad)
+    return (p_all, q_all) if as_t else (B.to_numpy(p_all), B.to_numpy(q_all))
+
+
+def multistep_reachability(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_safety=1., verbose=1,
+                           a=None, b=None, k_fb_init=None):
+    """Ellipsoidal overapproximation after n actions (gp_reachability.py:159-212).
+
+    p_0 (n_s,1); k_fb (n-1,n_u,n_s); k_ff (n,n_u).  Returns p_new (n_s,1), q_new (n_s,n_s),
+    p_all (n,n_s), q_all (n,n_s,n_s).
+    """
+    k_fb = np.asarray(k_fb, dtype=np.float64)
+    k_ff = np.asarray(k_ff, dtype=np.float64)
+    n_, n_u, n_s = np.shape(k_fb)
+    n = n_ + 1
+    if isinstance(gp, SimpleGPModel):
+        q0 = None if q_0 is None else np.asarray(q_0, dtype=np.float64)[None]
+        kfb0 = None if (k_fb_init is None or q_0 is None) else np.asarray(k_fb_init, dtype=np.float64)[None]
+        p_all, q_all = multistep_reachability_batch(np.asarray(p_0, dtype=np.float64).reshape(1, n_s), gp,
+                                                    k_fb[None], k_ff[None], L_mu, L_sigm, q0, c_safety,
+                                                    a, b, kfb0, check_bounds=True)
+        p_all, q_all = p_all[0], q_all[0]
+    else:
+        p_all = np.empty((n, n_s))
+        q_all = np.empty((n, n_s, n_s))
+        p_new, q_new = onestep_reachability(p_0, gp, k_ff[0, :, None], L_mu, L_sigm, q_0, k_fb_init,
+                                            c_safety, verbose, a, b)
+        p_all[0], q_all[0] = p_new.T, q_new
+        for i in range(1, n):
+            p_new, q_new = onestep_reachability(p_new, gp, k_ff[i, :, None], L_mu, L_sigm, q_new,
+                                                k_fb[i - 1], c_safety, verbose, a, b)
+            p_all[i], q_all[i] = p_new.T, q_new
+    return p_all[-1][:, None].copy(), q_all[-1].copy(), p_all, q_all
+
+
+def lin_ellipsoid_safety_distance_batch(p_center, q_shape, h_mat, h_vec, c_safety=1.0, device=None):
+    """d (T,m) = h_mat p + c sqrt(diag(h_mat Q h_mat^T)) - h_vec for T ellipsoids."""
+    as_t = B.is_tensor(p_center)
+    dev = B.resolve_device(p_center.device if as_t else device)
+    p = B.as_dev(p_center, dev)
+    T, n_s = p.shape
+    q = B.as_dev(q_shape, dev, (T, n_s, n_s))
+    hm = B.as_dev(h_mat, dev)
+    m = hm.shape[0]
+    if hm.dim() != 2 or hm.shape[1] != n_s:
+        raise ValueError("h_mat must be (m, {})".format(n_s))
+    hv = B.as_dev(np.reshape(B.to_numpy(h_vec) if B.is_tensor(h_vec) else h_vec, (-1,)), dev, (m,))
+    d = B.empty((T, m), dev)
+    check(lib.sr_safety_distance(dev.index, T, n_s, m, B.ptr(p), B.ptr(q), B.ptr(hm), B.ptr(hv),
+                                 float(c_safety), B.ptr(d), B.stream_ptr(dev)))
+    return d if as_t else B.to_numpy(d)
+
+
+def lin_ellipsoid_safety_distance(p_center, q_shape, h_mat, h_vec, c_safety=1.0):
+    """Distance between ellipsoid E(p,Q) and polytope h_mat x <= h_vec (gp_reachability.py:215-250).
+    d < 0 (element-wise) <=> the ellipsoid is inside the polytope.  Returns (m,1)."""
+    m, n_s = np.shape(h_mat)
+    assert np.shape(p_center) == (n_s, 1), "p_center has to have shape n_s x 1"
+    assert np.shape(q_shape) == (n_s, n_s), "q_shape has to have shape n_s x n_s"
+    assert np.shape(h_vec) == (m, 1), "q_shape has to have shape m x 1"
+    d = lin_ellipsoid_safety_distance_batch(np.asarray(p_center, dtype=np.float64).reshape(1, n_s),
+                                            np.asarray(q_shape, dtype=np.float64)[None], h_mat, h_vec,
+                                            c_safety)
+    return d.reshape(m, 1)

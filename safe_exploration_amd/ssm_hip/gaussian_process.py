@@ -1,0 +1,387 @@
+"""``SimpleGPModel``: one independent ARD-RBF GP per output dimension, evaluated on MI355X.
+
+Mirrors the public surface of the reference class
+/root/reference/safe_exploration/ssm_gpy/gaussian_process.py:15-634 (constructor signature,
+``train`` / ``update_model`` / ``predict`` / ``predictive_gradients`` / ``__call__`` /
+``to_dict`` / ``from_dict`` and the cached attributes ``z, beta, inv_K, hyp, kern_types, x_train,
+y_train, gp_trained``), but none of its implementation: GPy is replaced by the C-ABI in
+include/safereach.h (Gram + blocked fp64-MFMA Cholesky at model-update time; fused RBF
+cross-covariance / triangular contraction kernels at prediction time).
+
+Not on the hot path and therefore not provided: hyper-parameter optimisation (``opt_hyp=True``),
+sparse GP, ``sample_from_gp``, ``information_gain``, non-RBF kernels (ranked "next").
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+
+from .. import _buffers as B
+from .._lib import lib, check
+from ..state_space_models import StateSpaceModel
+
+GPY_JITTER = 1e-8   # GPy's exact inference adds this to diag(K) (from knowledge of GPy; unverifiable here)
+
+
+class _Handle(object):
+    """Owns one sr_gp_t; shared between deep copies of a model (state_space_models.py:166 deep-copies
+    the SSM when handing it to CasADi -- the device state is immutable between updates)."""
+
+    def __init__(self, device, N, D, n_out):
+        self.device = device
+        self.h = ctypes.c_void_p()
+        check(lib.sr_gp_create(ctypes.byref(self.h), device.index, N, D, n_out))
+        self.N, self.D, self.n_out = N, D, n_out
+        npad = ctypes.c_long(0)
+        check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
+        self.Np = npad.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib.sr_gp_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class SimpleGPModel(StateSpaceModel):
+    """GP dynamics model x_{t+1} - prior(x_t,u_t) ~ GP, one output per state dimension.
+
+    Parameters follow ssm_gpy/gaussian_process.py:32-33.  ``hyp`` is a list (one dict per output)
+    with the reference's keys ``"lengthscale"`` (D,) and ``"variance"``; the Gaussian noise
+    variance may be given as ``"noise_variance"`` (GPy's GPRegression default 1.0 otherwise).
+    ``device`` (extension) selects the GPU.
+    """
+
+    def __init__(self, n_s_out, n_s_in, n_u, X=None, y=None, m=None, kern_types=None, hyp=None,
+                 train=False, Z=None, device=None):
+        self.n_s_out = n_s_out
+        self.n_s_in = n_s_in
+        self.n_u = n_u
+        self.gp_trained = False
+        self.m = m
+        self.Z = Z
+        self.z = None
+        self.x_train = None
+        self.y_train = None
+        self._beta = None
+        self._inv_K = None
+        self._handle = None
+        self._device_arg = device
+        self.do_sparse_gp = False
+        self.z_fixed = Z is not None
+        self._init_kernel_function(kern_types, hyp)
+        if X is None or y is None:
+            train = False
+        super(SimpleGPModel, self).__init__(n_s_out, n_u)
+        if train:
+            self.train(X, y, m, Z=Z)
+
+    # ------------------------------------------------------------------ construction helpers
+    def _init_kernel_function(self, kern_types=None, hyp=None):
+        """Kernel bookkeeping (ssm_gpy/gaussian_process.py:421-489).  Only "rbf" is on the hot path."""
+        D = self.n_s_in + self.n_u
+        if kern_types is None:
+            kern_types = ["rbf"] * self.n_s_out
+        if hyp is None:
+            hyp = [None] * self.n_s_out
+        if len(kern_types) != self.n_s_out or len(hyp) != self.n_s_out:
+            raise ValueError("kern_types / hyp need one entry per output dimension")
+        hyp_out = []
+        self._noise = np.empty(self.n_s_out)
+        for i in range(self.n_s_out):
+            if kern_types[i] != "rbf":
+                if kern_types[i] in ("mat52", "lin_rbf", "lin_mat52"):
+                    raise NotImplementedError("kernel type '{}' is not on the MI355X hot path yet "
+                                              "(north_star: RBF)".format(kern_types[i]))
+                raise ValueError("kernel type '{}' not supported".format(kern_types[i]))
+            h = dict(hyp[i]) if hyp[i] is not None else {}
+            ls = np.reshape(np.asarray(h.get("lengthscale", np.ones(D)), dtype=np.float64), (-1,))
+            if ls.size == 1:
+                ls = np.full(D, float(ls[0]))
+            if ls.size != D:
+                raise ValueError("lengthscale needs {} entries".format(D))
+            var = float(np.asarray(h.get("variance", 1.0)).reshape(-1)[0])
+            self._noise[i] = float(np.asarray(h.get("noise_variance", 1.0)).reshape(-1)[0])
+            hyp_out.append({"lengthscale": ls, "variance": var})
+        self.kern_types = list(kern_types)
+        self.hyp = hyp_out
+
+    @classmethod
+    def from_dict(cls, gp_dict):
+        """ssm_gpy/gaussian_process.py:72-133 (same keys)."""
+        x = y = None
+        data_available = False
+        if gp_dict.get("data_path") is not None:
+            data = np.load(gp_dict["data_path"])
+            x, y = data["S"], data["y"]
+            data_available = True
+        elif "x" in gp_dict and "y" in gp_dict:
+            x, y = gp_dict["x"], gp_dict["y"]
+            data_available = True
+        else:
+            warnings.warn("GP needs a data_path or the data itself (keys 'x' and 'y'); "
+                          "instantiating without training")
+        if "prior_model" in gp_dict and data_available:
+            y = y - gp_dict["prior_model"](x)
+        train = bool(gp_dict.get("train", False)) and data_available
+        return cls(gp_dict["n_s_out"], gp_dict["n_s_in"], gp_dict["n_u"], x, y, gp_dict.get("m"),
+                   gp_dict.get("kern_types"), gp_dict.get("hyp"), train, gp_dict.get("Z"),
+                   device=gp_dict.get("device"))
+
+    def to_dict(self):
+        """ssm_gpy/gaussian_process.py:177-187 (same keys)."""
+        return {"x": self.x_train, "y": self.y_train, "kern_types": self.kern_types,
+                "hyp": self.hyp, "beta": self.beta, "inv_K": self.inv_K}
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = v          # arrays are replaced, never mutated, on update
+        return new
+
+    # ------------------------------------------------------------------ training
+    def _select_subset(self, X, y, m, Z, choose_data):
+        n_data = X.shape[0]
+        if m is None or n_data < m:
+            if m is not None:
+                warnings.warn("The desired number of datapoints is not available. Dataset consist "
+                              "of {} Datapoints!".format(n_data))
+            return X, y
+        if choose_data:
+            raise NotImplementedError("max-variance data selection (choose_data=True, "
+                                      "ssm_gpy/gaussian_process.py:280-345) is training-time logic "
+                                      "outside the hot path; pass choose_data=False or m=None")
+        idx = np.random.choice(n_data, size=m, replace=False)
+        return X[idx, :], y[idx, :]
+
+    def train(self, X, y, m=None, opt_hyp=True, noise_diag=1e-5, Z=None, choose_data=True):
+        """Condition the GPs on data (ssm_gpy/gaussian_process.py:189-278).
+
+        ``opt_hyp=True`` (marginal-likelihood optimisation inside GPy) is outside the hot path:
+        construct the model with fixed ``hyp`` and call with ``opt_hyp=False``."""
+        if opt_hyp:
+            raise NotImplementedError("hyper-parameter optimisation is not part of the MI355X hot "
+                                      "path; pass hyp=... and opt_hyp=False")
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        if X.ndim != 2 or y.ndim != 2 or X.shape[0] != y.shape[0]:
+            raise ValueError("X must be (N, n_s_in+n_u) and y (N, n_s_out)")
+        if X.shape[1] != self.n_s_in + self.n_u or y.shape[1] != self.n_s_out:
+            raise ValueError("X must be (N, n_s_in+n_u) and y (N, n_s_out)")
+        Zs, yz = self._select_subset(X, y, m, Z, choose_data)
+        self._fit(Zs, yz, noise_diag)
+        self.z = self.Z if self.z_fixed else Zs
+        self.x_train = X
+        self.y_train = y
+        self.gp_trained = True
+
+    def update_model(self, x, y, opt_hyp=False, replace_old=True, noise_diag=1e-5, choose_data=True):
+        """ssm_gpy/gaussian_process.py:347-419."""
+        x = np.asarray(x, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        if not replace_old and self.x_train is not None:
+            x = np.vstack((self.x_train, x))
+            y = np.vstack((self.y_train, y))
+        self.train(x, y, self.m, opt_hyp=opt_hyp, noise_diag=noise_diag, Z=self.Z,
+                   choose_data=choose_data)
+
+    def _fit(self, Z, Y, noise_diag):
+        dev = B.resolve_device(self._device_arg)
+        N, D = Z.shape
+        handle = _Handle(dev, N, D, self.n_s_out)
+        ls = np.stack([h["lengthscale"] for h in self.hyp])
+        sf2 = np.array([h["variance"] for h in self.hyp])
+        # diagonal term: sigma_n^2 + noise_diag (gaussian_process.py:252-253) + GPy's internal jitter
+        noise = self._noise + float(noise_diag) + GPY_JITTER
+        s = B.stream_ptr(dev)
+        tz, ty, tl, tf, tn = (B.as_dev(a, dev) for a in (Z, Y, ls, sf2, noise))
+        check(lib.sr_gp_set_data(handle.h, B.ptr(tz), B.ptr(ty), B.ptr(tl), B.ptr(tf), B.ptr(tn), s))
+        info = (ctypes.c_int * self.n_s_out)()
+        check(lib.sr_gp_factorize(handle.h, s, info))
+        self._handle = handle
+        self._beta = None
+        self._inv_K = None
+
+    # ------------------------------------------------------------------ cached posterior state
+    def _need_trained(self):
+        if not self.gp_trained or self._handle is None:
+            raise RuntimeError("SimpleGPModel: call train()/update_model() before predicting")
+
+    @property
+    def device(self):
+        self._need_trained()
+        return self._handle.device
+
+    @property
+    def beta(self):
+        """(N, n_s_out) = K_y^-1 y  (``woodbury_vector``; gaussian_process.py:264)."""
+        if self._handle is None:
+            return None
+        if self._beta is None:
+            hd = self._handle
+            t = B.empty((hd.n_out, hd.N), hd.device)
+            check(lib.sr_gp_export(hd.h, B.ptr(t), None, B.stream_ptr(hd.device)))
+            self._beta = B.to_numpy(t).T.copy()
+        return self._beta
+
+    @property
+    def inv_K(self):
+        """list of (N, N) explicit inverses (``woodbury_inv``; gaussian_process.py:262).  Cold path."""
+        if self._handle is None:
+            return None
+        if self._inv_K is None:
+            hd = self._handle
+            out = []
+            for d in range(hd.n_out):
+                t = B.empty((hd.N, hd.N), hd.device)
+                check(lib.sr_gp_inv_k(hd.h, d, B.ptr(t), B.stream_ptr(hd.device)))
+                out.append(B.to_numpy(t))
+            self._inv_K = out
+        return self._inv_K
+
+    def export_state(self):
+        """(alpha (n_out,N), Wt (n_out,Np,Np)) device tensors -- what a broadcast receiver imports."""
+        self._need_trained()
+        hd = self._handle
+        alpha = B.empty((hd.n_out, hd.N), hd.device)
+        wt = B.empty((hd.n_out, hd.Np, hd.Np), hd.device)
+        check(lib.sr_gp_export(hd.h, B.ptr(alpha), B.ptr(wt), B.stream_ptr(hd.device)))
+        return alpha, wt
+
+    def import_state(self, Z, Y, alpha, wt, noise_diag=1e-5):
+        """Adopt a posterior factorised elsewhere (rank-0 broadcast): no factorisation here."""
+        dev = B.resolve_device(self._device_arg)
+        Z = np.asarray(Z, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64)
+        N, D = Z.shape
+        handle = _Handle(dev, N, D, self.n_s_out)
+        ls = np.stack([h["lengthscale"] for h in self.hyp])
+        sf2 = np.array([h["variance"] for h in self.hyp])
+        noise = self._noise + float(noise_diag) + GPY_JITTER
+        s = B.stream_ptr(dev)
+        tz, ty, tl, tf, tn = (B.as_dev(a, dev) for a in (Z, Y, ls, sf2, noise))
+        check(lib.sr_gp_set_data(handle.h, B.ptr(tz), B.ptr(ty), B.ptr(tl), B.ptr(tf), B.ptr(tn), s))
+        ta = B.as_dev(alpha, dev, (self.n_s_out, N))
+        tw = B.as_dev(wt, dev, (self.n_s_out, handle.Np, handle.Np))
+        check(lib.sr_gp_import(handle.h, B.ptr(ta), B.ptr(tw), s))
+        torch.cuda.current_stream(dev).synchronize()
+        self._handle = handle
+        self._beta = None
+        self._inv_K = None
+        self.z = Z
+        self.x_train = Z
+        self.y_train = Y
+        self.gp_trained = True
+
+    # ------------------------------------------------------------------ prediction
+    def predict_device(self, x_new, compute_gradients=False):
+        """Batched posterior on device tensors: x_new (T, D) -> mu (T,n), var (T,n)[, jac (T,n,D)]."""
+        self._need_trained()
+        hd = self._handle
+        x = B.as_dev(x_new, hd.device)
+        if x.dim() != 2 or x.shape[1] != hd.D:
+            raise ValueError("x_new must be (T, {})".format(hd.D))
+        T = x.shape[0]
+        mu = B.empty((T, hd.n_out), hd.device)
+        var = B.empty((T, hd.n_out), hd.device)
+        jac = B.empty((T, hd.n_out, hd.D), hd.device) if compute_gradients else None
+        check(lib.sr_gp_predict(hd.h, B.ptr(x), T, B.ptr(mu), B.ptr(var), B.ptr(jac),
+                                B.stream_ptr(hd.device)))
+        return (mu, var, jac) if compute_gradients else (mu, var)
+
+    def predict(self, *args, **kwargs):
+        """Predictive mean and variance for a set of test inputs.
+
+        Accepts both historical call shapes of the reference:
+          * ``predict(x_new (T,D), quantiles=None, compute_gradients=False)``
+            -> (T,n_s), (T,n_s)[, (T,n_s,D)]                   gaussian_process.py:546-568
+          * ``predict(states (N,n), actions (N,m), jacobians=False, full_cov=False)``
+            -> mean (N,n), var (N,n)[, jac_mean (N,n,n+m)]     state_space_models.py:74-104
+        """
+        two = (len(args) >= 2 and hasattr(args[1], "shape") and np.ndim(args[1]) == 2) or "actions" in kwargs
+        if two:
+            states = args[0] if args else kwargs.pop("states")
+            actions = args[1] if len(args) > 1 else kwargs.pop("actions")
+            jacobians = args[2] if len(args) > 2 else kwargs.pop("jacobians", False)
+            full_cov = args[3] if len(args) > 3 else kwargs.pop("full_cov", False)
+            if full_cov:
+                raise NotImplementedError("full covariance is not supported")
+            as_t = B.is_tensor(states)
+            if as_t:
+                x_new = torch.cat((states, actions), dim=1)
+            else:
+                x_new = np.hstack((np.asarray(states, dtype=np.float64),
+                                   np.asarray(actions, dtype=np.float64)))
+            out = self.predict_device(x_new, bool(jacobians))
+            return out if as_t else tuple(B.to_numpy(o) for o in out)
+        x_new = args[0] if args else kwargs.pop("x_new")
+        quantiles = args[1] if len(args) > 1 else kwargs.pop("quantiles", None)
+        compute_gradients = args[2] if len(args) > 2 else kwargs.pop("compute_gradients", False)
+        if quantiles is not None:
+            raise NotImplementedError()
+        out = self.predict_device(x_new, bool(compute_gradients))
+        return out if B.is_tensor(x_new) else tuple(B.to_numpy(o) for o in out)
+
+    def predictive_gradients(self, x_new, grad_sigma=False):
+        """(T, n_s, D) gradients of the predictive mean (gaussian_process.py:570-596)."""
+        if grad_sigma:
+            raise NotImplementedError("Gradient of sigma not implemented")
+        out = self.predict_device(x_new, True)[2]
+        return out if B.is_tensor(x_new) else B.to_numpy(out)
+
+    def __call__(self, states, actions):
+        """Single-query evaluation used by onestep_reachability (gaussian_process.py:135-144):
+        returns exactly (mu (n,1), sigma (n,1), jac (n,D))."""
+        states = np.asarray(states, dtype=np.float64)
+        actions = np.asarray(actions, dtype=np.float64)
+        N, _ = np.shape(states)
+        if N > 1:
+            raise NotImplementedError("Currently do not support multiple state-action pairs to "
+                                      "evaluate on.")
+        mu, var, jac = self.predict_device(np.hstack((states, actions)), True)
+        return B.to_numpy(mu).T, B.to_numpy(var).T, B.to_numpy(jac)[0]
+
+    def linearize_predict(self, states, actions, jacobians=False, full_cov=False):
+        """Contract of state_space_models.py:106-138 for a single query:
+        (mu (n,1), var (n,1), jac_mu (n,D)).  ``jacobians=True`` (d var/dx, Hessian of mu) belongs
+        to the T=1 CasADi latency path, ranked "next"."""
+        if full_cov:
+            raise NotImplementedError("full covariance is not supported")
+        if jacobians:
+            raise NotImplementedError("second-order outputs of linearize_predict are not on the "
+                                      "batched hot path (ranked 'next')")
+        return self.__call__(states, actions)
+
+    def sample_from_gp(self, inp, size=10):
+        raise NotImplementedError("posterior sampling is outside the MI355X hot path")
+
+    def information_gain(self, x=None):
+        raise NotImplementedError("information gain is outside the MI355X hot path")
+
+    # ------------------------------------------------------------------ measurement hooks
+    def set_chunk(self, chunk):
+        self._need_trained()
+        check(lib.sr_gp_set_chunk(self._handle.h, int(chunk)))
+
+    def set_var_group(self, group):
+        self._need_trained()
+        check(lib.sr_gp_set_var_group(self._handle.h, int(group)))
+
+    def prof_enable(self, on=True):
+        self._need_trained()
+        check(lib.sr_prof_enable(self._handle.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._need_trained()
+        check(lib.sr_prof_reset(self._handle.h))
+
+    def prof_get(self, kernel_id):
+        self._need_trained()
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_long(0)
+        check(lib.sr_prof_get(self._handle.h, kernel_id, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+What is executed from the reference (imported, never copied):
+  * safe_exploration.utils_ellipsoid      (as-is)
+  * safe_exploration.utils                (compute_remainder_overapproximations, sample_inside_polytope)
+  * safe_exploration.gp_reachability      (onestep_reachability, multistep_reachability,
+                                           lin_ellipsoid_safety_distance)
+  * safe_exploration/ssm_gpy/gp_models_utils_casadi.py  (_k_rbf, _unscaled_dist, gp_pred), loaded by
+    file path because the sub-package __init__ imports GPy.
+
+casadi is not installed.  utils.py needs the *name* ``casadi.reshape`` at import; the
+gp_models_utils_casadi formulas call six casadi array functions (mtimes, exp, sum2, repmat, sqrt,
+SX(n)).  A throw-away numpy-backed module named ``casadi`` is written to a temp dir for THIS script
+only so that those reference formulas can be evaluated on numbers.  GPy itself is absent, so the GPy
+boundary stays unpinned (see oracle/oracle_np.py header).
+
+The GP posterior state (beta, inv_K) fed to the reference formulas comes from oracle.gp_fit; the
+(mu, var, jac) fed to the reference reachability functions come from oracle.gp_predict and are stored
+in the fixtures so the ellipsoid kernel can be tested in isolation from the GP kernels.
+"""
+import importlib.util
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+CASADI_SHIM = '''
+import numpy as _np
+def reshape(a, s): return _np.reshape(a, s, order="F")
+def mtimes(a, b): return _np.dot(a, b)
+def exp(a): return _np.exp(a)
+def sqrt(a): return _np.sqrt(a)
+def sum2(a): return _np.sum(a, axis=1, keepdims=True)
+def repmat(a, n, m=1): return _np.tile(_np.atleast_2d(a), (n, m))
+def vertcat(*a): return _np.vstack([x for x in a if _np.size(x)])
+def horzcat(*a): return _np.hstack([x for x in a if _np.size(x)])
+class SX(object):
+    def __new__(cls, *a):
+        return _np.zeros((1, 1)) if len(a) < 2 else _np.zeros(a)
+class Function(object):
+    def __init__(self, *a, **k): raise NotImplementedError("numeric shim only")
+'''
+
+
+def _import_reference():
+    shim_dir = tempfile.mkdtemp(prefix="casadi_shim_")
+    with open(os.path.join(shim_dir, "casadi.py"), "w") as f:
+        f.write(CASADI_SHIM)
+    sys.path.insert(0, shim_dir)
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    warnings.simplefilter("ignore")
+    from safe_exploration import utils_ellipsoid, utils, gp_reachability
+    spec = importlib.util.spec_from_file_location(
+        "ref_gp_models_utils_casadi",
+        os.path.join(REF, "safe_exploration/ssm_gpy/gp_models_utils_casadi.py"))
+    gpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gpu)
+    return utils_ellipsoid, utils, gp_reachability, gpu
+
+
+def _save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, {k: np.shape(v) for k, v in arrs.items()})
+
+
+def main():
+    ue, ut, gr, gpu = _import_reference()
+    from oracle import oracle_np as orc
+
+    # ------------------------------------------------------------------ 1. utils_ellipsoid
+    rng = np.random.default_rng(11)
+    out = {}
+    for n in (2, 3, 4, 8):
+        ub = rng.uniform(0.05, 0.5, n)
+        out["rect_ub_%d" % n] = ub
+        out["rect_q_%d" % n] = ue.ellipsoid_from_rectangle(ub)
+        A1, A2 = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+        q1, q2 = A1.dot(A1.T) + 0.1 * np.eye(n), A2.dot(A2.T) + 0.2 * np.eye(n)
+        p1, p2 = rng.standard_normal((n, 1)), rng.standard_normal((n, 1))
+        ps, qs = ue.sum_two_ellipsoids(p1, q1, p2, q2)
+        pc, qc = ue.sum_two_ellipsoids(p1, q1, p2, q2, c=0.7)
+        out.update({"sum_p1_%d" % n: p1, "sum_q1_%d" % n: q1, "sum_p2_%d" % n: p2,
+                    "sum_q2_%d" % n: q2, "sum_p_%d" % n: ps, "sum_q_%d" % n: qs,
+                    "sumc_q_%d" % n: qc})
+        # sum_ellipsoids with direction l, 3 and 4 ellipsoids
+        for k in (3, 4):
+            pp = rng.standard_normal((k, n))
+            qq = np.empty((k, n, n))
+            for i in range(k):
+                B = rng.standard_normal((n, n))
+                qq[i] = B.dot(B.T) + 0.1 * np.eye(n)
+            l = rng.standard_normal((n, 1))
+            pn, qn = ue.sum_ellipsoids(pp, qq, l)
+            out.update({"msum_p_in_%d_%d" % (k, n): pp, "msum_q_in_%d_%d" % (k, n): qq,
+                        "msum_l_%d_%d" % (k, n): l, "msum_p_%d_%d" % (k, n): pn,
+                        "msum_q_%d_%d" % (k, n): qn})
+        S = rng.standard_normal((7, n))
+        out["dist_s_%d" % n] = S
+        out["dist_d_%d" % n] = ue.distance_to_center(S, p1, q1)
+        out["inside_%d" % n] = ue.sample_inside_ellipsoid(S, p1, q1, c=3.0)
+    # known answers quoted by the reference tests / __main__
+    out["known_rect"] = ue.ellipsoid_from_rectangle([0.1, 0.2, 0.3])          # diag(.03,.12,.27)
+    out["known_dist"] = ue.distance_to_center(np.array([[1 + np.sqrt(2), 1.0]]),
+                                              np.array([[1.0], [1.0]]), 4 * np.eye(2) / 2)
+    _save("ellipsoid.npz", **out)
+
+    # ------------------------------------------------------------------ 2. remainder over-approximation
+    out = {}
+    for tag, (n_s, n_u) in zip("1234", [(2, 1), (3, 2), (5, 4), (8, 3)]):
+        np.random.seed(0)                     # the reference test's own recipe (test_utils_casadi.py:99-120)
+        x_0 = np.random.rand(n_s, n_s)
+        q = np.dot(x_0, x_0.T) + 0.1 * np.eye(n_s)
+        k_fb = np.random.randn(n_u, n_s)
+        l_mu = np.array([.1] * n_s)
+        l_sigma = np.array([.1] * n_s)
+        u_mu, u_sigma = ut.compute_remainder_overapproximations(q, k_fb, l_mu, l_sigma)
+        assert np.all(np.imag(u_mu) == 0) and np.all(np.imag(u_sigma) == 0)
+        out.update({"q_" + tag: q, "k_fb_" + tag: k_fb, "l_mu_" + tag: l_mu, "l_sigma_" + tag: l_sigma,
+                    "u_mu_" + tag: np.real(u_mu), "u_sigma_" + tag: np.real(u_sigma)})
+        u0m, u0s = ut.compute_remainder_overapproximations(q, np.zeros((n_u, n_s)), l_mu, l_sigma)
+        out["u_mu_k0_" + tag] = np.real(u0m)
+        out["u_sigma_k0_" + tag] = np.real(u0s)
+    # polytope known answer (test_utils.py:12-29)
+    x = np.array([[0.1, 0.15], [0.0, 0.0], [.5, .15]])
+    a = np.vstack((np.eye(2), -np.eye(2), -np.eye(2)))
+    b = np.array([.4, .2, .3, .2, .3, .2])[:, None]
+    out.update({"poly_x": x, "poly_a": a, "poly_b": b, "poly_res": ut.sample_inside_polytope(x, a, b)})
+    _save("remainder.npz", **out)
+
+    # ------------------------------------------------------------------ 3. GP formulas vs reference gp_pred
+    def gp_case(name, seed, N, n_s, n_u, T):
+        syn = orc.make_synthetic(seed, N, n_s, n_u, T)
+        beta, inv_K, chol = orc.gp_fit(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"],
+                                       syn["noise_var"])
+        x_new = np.hstack((syn["p"], syn["k_ff"]))
+        mu, var, jac = orc.gp_predict(x_new, syn["Z"], beta, inv_K, syn["lengthscale"],
+                                      syn["signal_var"], True)
+        ref_mu = np.empty_like(mu)
+        ref_var = np.empty_like(var)
+        ref_K = []
+        for d in range(n_s):
+            hyp = {"lengthscale": syn["lengthscale"][d], "variance": syn["signal_var"][d]}
+            kern = gpu._get_kernel_function("rbf", hyp)
+            ref_K.append(np.asarray(kern(x_new, y=syn["Z"])))
+            for t in range(T):       # gp_pred is used single-query by the reference (N==1 assert, :164)
+                m_t, s_t = gpu.gp_pred(x_new[t:t + 1], kern, beta[:, d:d + 1], syn["Z"], inv_K[d], True)
+                ref_mu[t, d] = np.asarray(m_t).item()
+                ref_var[t, d] = np.asarray(s_t).item()
+        # oracle == reference's formulas on numbers (before the GPy-style 1e-15 clip, which never binds here)
+        assert np.allclose(ref_mu, mu, rtol=1e-12, atol=1e-13), np.abs(ref_mu - mu).max()
+        assert np.allclose(ref_var, var, rtol=0, atol=1e-12), np.abs(ref_var - var).max()
+        for d in range(n_s):
+            assert np.allclose(ref_K[d], orc.rbf_kernel(x_new, syn["Z"], syn["signal_var"][d],
+                                                        syn["lengthscale"][d]), rtol=1e-13, atol=0)
+        jv, hm = orc.gp_linearize_extras(x_new[0], syn["Z"], beta, inv_K, syn["lengthscale"],
+                                         syn["signal_var"])
+        _save(name, Z=syn["Z"], Y=syn["Y"], lengthscale=syn["lengthscale"],
+              signal_var=syn["signal_var"], noise_var=syn["noise_var"], x_new=x_new, beta=beta,
+              mu=mu, var=var, jac=jac, ref_mu=ref_mu, ref_var=ref_var, ref_kstar0=ref_K[0],
+              jac_var0=jv, hess_mu0=hm)
+        return syn, beta, inv_K
+
+    gp_case("gp_pend.npz", 101, 60, 2, 1, 33)
+    gp_case("gp_cart.npz", 102, 90, 4, 1, 20)
+
+    # ------------------------------------------------------------------ 4. reachability through the reference
+    def reach_case(name, seed, N, n_s, n_u, T, H, l_mu, l_sigma, c_safety, a_scale=1.0, sf2=1.0):
+        syn = orc.make_synthetic(seed, N, n_s, n_u, T, sf2=sf2)
+        beta, inv_K, _ = orc.gp_fit(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"],
+                                    syn["noise_var"])
+        model = dict(Z=syn["Z"], beta=beta, inv_K=inv_K, lengthscale=syn["lengthscale"],
+                     signal_var=syn["signal_var"])
+        rng = np.random.default_rng(seed + 1000)
+        a_lin = a_scale * np.eye(n_s) + 0.05 * rng.standard_normal((n_s, n_s))
+        b_lin = 0.1 * rng.standard_normal((n_s, n_u))
+
+        def ssm(states, actions):              # 3-tuple contract of SimpleGPModel.__call__ (A5)
+            z = np.hstack((np.asarray(states), np.asarray(actions)))[0]
+            mu, var, jac = orc._predict_one(model, z)
+            return mu[:, None], var[:, None], jac
+
+        x = np.hstack((syn["p"], syn["k_ff"]))
+        mu, var, jac = orc.gp_predict(x, syn["Z"], beta, inv_K, syn["lengthscale"],
+                                      syn["signal_var"], True)
+        res = {k: syn[k] for k in ("Z", "Y", "lengthscale", "signal_var", "noise_var", "p", "k_ff",
+                                   "k_fb", "Q")}
+        res.update(mu=mu, var=var, jac=jac, l_mu=l_mu, l_sigma=l_sigma, c_safety=c_safety,
+                   a_lin=a_lin, b_lin=b_lin)
+        for tag, (aa, bb) in {"id": (None, None), "lin": (a_lin, b_lin)}.items():
+            p1_pt = np.empty((T, n_s)); q1_pt = np.empty((T, n_s, n_s))
+            p1_el = np.empty((T, n_s)); q1_el = np.empty((T, n_s, n_s))
+            for t in range(T):
+                pp, qq = gr.onestep_reachability(syn["p"][t][:, None], ssm, syn["k_ff"][t][:, None],
+                                                 l_mu, l_sigma, None, None, c_safety, 0, aa, bb)
+                p1_pt[t], q1_pt[t] = pp[:, 0], qq
+                pp, qq = gr.onestep_reachability(syn["p"][t][:, None], ssm, syn["k_ff"][t][:, None],
+                                                 l_mu, l_sigma, syn["Q"][t], syn["k_fb"][t], c_safety,
+                                                 0, aa, bb)
+                assert np.all(np.imag(qq) == 0)
+                p1_el[t], q1_el[t] = pp[:, 0], np.real(qq)
+            res.update({"p1_point_" + tag: p1_pt, "q1_point_" + tag: q1_pt,
+                        "p1_ell_" + tag: p1_el, "q1_ell_" + tag: q1_el})
+        # multistep chains (workload generator of uncertainty_propagation_runner.py:32-33)
+        Tm = min(T, 6)
+        k_fb_m = 0.1 * rng.standard_normal((Tm, H - 1, n_u, n_s))
+        k_ff_m = 0.1 * rng.standard_normal((Tm, H, n_u))
+        p0_m = 0.1 * rng.standard_normal((Tm, n_s))
+        p_all = np.empty((Tm, H, n_s)); q_all = np.empty((Tm, H, n_s, n_s))
+        p_all_q0 = np.empty((Tm, H, n_s)); q_all_q0 = np.empty((Tm, H, n_s, n_s))
+        for t in range(Tm):
+            _, _, pa, qa = gr.multistep_reachability(p0_m[t][:, None], ssm, k_fb_m[t], k_ff_m[t], l_mu,
+                                                     l_sigma, None, c_safety, 0, a_lin, b_lin, None)
+            p_all[t], q_all[t] = pa, qa
+            _, _, pa, qa = gr.multistep_reachability(p0_m[t][:, None], ssm, k_fb_m[t], k_ff_m[t], l_mu,
+                                                     l_sigma, syn["Q"][t], c_safety, 0, a_lin, b_lin,
+                                                     syn["k_fb"][t])
+            p_all_q0[t], q_all_q0[t] = pa, qa
+        assert np.all(np.isfinite(q_all)) and np.all(np.isfinite(q_all_q0)), "chain diverged"
+        print(name, "max |q| along chain", np.abs(q_all).max(), np.abs(q_all_q0).max())
+        res.update(ms_k_fb=k_fb_m, ms_k_ff=k_ff_m, ms_p0=p0_m, ms_p_all=p_all, ms_q_all=q_all,
+                   ms_p_all_q0=p_all_q0, ms_q_all_q0=q_all_q0)
+        # safety distance on the ellipsoid-branch results
+        h_mat = np.vstack((np.eye(n_s), -np.eye(n_s)))
+        h_vec = np.ones((2 * n_s, 1))
+        d = np.empty((T, 2 * n_s))
+        for t in range(T):
+            d[t] = gr.lin_ellipsoid_safety_distance(res["p1_ell_id"][t][:, None], res["q1_ell_id"][t],
+                                                    h_mat, h_vec, c_safety)[:, 0]
+        res.update(h_mat=h_mat, h_vec=h_vec, d_safety=d)
+        _save(name, **res)
+
+    reach_case("reach_pend.npz", 201, 60, 2, 1, 24, 15, np.array([0.05, 0.02]), np.array([0.05, 0.02]), 2.0, a_scale=0.8, sf2=0.01)
+    reach_case("reach_cart.npz", 202, 90, 4, 1, 16, 15, np.array([0.05] * 4), np.array([0.05] * 4), 2.0, a_scale=0.5, sf2=0.01)
+    reach_case("reach_n3u2.npz", 203, 40, 3, 2, 8, 3, np.array([0.01] * 3), np.array([0.02] * 3), 1.5)
+
+    # ------------------------------------------------------------------ 5. worked anchor of SURVEY 8c
+    p = np.array([[0.1], [-0.2]]); Q = 0.2 * np.array([[.5, .2], [.2, .65]])
+    k_ff = np.array([[0.3]]); k_fb = np.array([[0.4, -0.1]])
+    mu = np.array([[0.05], [-0.02]]); s2 = np.array([[0.01], [0.04]])
+    J = np.array([[0.1, 0.2, 0.3], [-0.1, 0.05, 0.2]])
+    l = np.array([0.05, 0.02])
+    const = lambda s, a: (mu, s2, J)
+    a2 = np.array([[1, 0.05], [0, 0.98]]); b2 = np.array([[0.], [0.1]])
+    pp, qp = gr.onestep_reachability(p, const, k_ff, l, l, None, None, 2.0, 0)
+    pe, qe = gr.onestep_reachability(p, const, k_ff, l, l, Q, k_fb, 2.0, 0)
+    pl, ql = gr.onestep_reachability(p, const, k_ff, l, l, Q, k_fb, 2.0, 0, a2, b2)
+    h = np.vstack((np.eye(2), -np.eye(2)))
+    dd = gr.lin_ellipsoid_safety_distance(pe, np.real(qe), h, np.ones((4, 1)), 1.0)
+    _save("anchor.npz", p=p, Q=Q, k_ff=k_ff, k_fb=k_fb, mu=mu, var=s2, jac=J, l=l, a2=a2, b2=b2,
+          p_point=pp, q_point=qp, p_ell=pe, q_ell=np.real(qe), p_lin=pl, q_lin=np.real(ql),
+          d_safety=dd, dist=ue.distance_to_center(np.array([[0.2, 0.0]]), pe, np.real(qe)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,289 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs the CPU oracle and the committed golden
+fixtures.  Tolerances are the ones stated in SURVEY.md 8(d):
+    mu, jac : rtol 1e-10, atol 1e-12 * sigma_f * |alpha|_1
+    var     : atol 1e-9 * sigma_f^2
+    p1      : as mu ;  Q1 : rtol 1e-8
+    ellipsoid algebra alone (identical mu/var/jac fed): rtol 1e-12
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from _helpers import hip_model, oracle_model, mu_atol
+from oracle import oracle_np as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(lib_built):
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+
+
+# ------------------------------------------------------------------ MFMA tile in isolation
+@pytest.mark.parametrize("M,N,K,mode", [(128, 128, 16, 0), (256, 384, 128, 0), (384, 384, 64, 1),
+                                        (128, 512, 512, 2)])
+def test_gemm_tn_matches_numpy(M, N, K, mode):
+    import torch
+    from safe_exploration_amd import _buffers as B
+    from safe_exploration_amd._lib import lib, check
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M))          # asymmetric, transpose-detecting
+    Bm = rng.standard_normal((K, N))
+    C0 = rng.standard_normal((M, N))
+    if mode == 2:                            # B block-lower-triangular: B[k][n] = 0 for k < n0
+        for n0 in range(0, N, 128):
+            Bm[:n0, n0:n0 + 128] = 0.0
+    dev = torch.device("cuda", 0)
+    tA, tB, tC = B.as_dev(A, dev), B.as_dev(Bm, dev), B.as_dev(C0.copy(), dev)
+    check(lib.sr_test_gemm_tn(0, B.ptr(tA), M, B.ptr(tB), N, B.ptr(tC), N, M, N, K, -0.5, 2.0, mode,
+                              B.stream_ptr(dev)))
+    got = B.to_numpy(tC)
+    ref = -0.5 * A.T.dot(Bm) + 2.0 * C0
+    if mode == 1:
+        for m0 in range(0, M, 128):
+            for n0 in range(0, N, 128):
+                if n0 < m0:
+                    ref[m0:m0 + 128, n0:n0 + 128] = C0[m0:m0 + 128, n0:n0 + 128]
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ GP fit + predict
+@pytest.mark.parametrize("name,n_s,n_u", [("gp_pend.npz", 2, 1), ("gp_cart.npz", 4, 1)])
+def test_predict_matches_golden_and_oracle(name, n_s, n_u):
+    g = load_golden(name)
+    gp = hip_model(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"], n_s, n_u)
+    om = oracle_model(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"])
+    at = mu_atol(om)
+    sf2 = float(np.max(g["signal_var"]))
+    # cached posterior state
+    np.testing.assert_allclose(gp.beta, g["beta"], rtol=1e-8, atol=1e-9 * np.abs(g["beta"]).max())
+    for d in range(n_s):
+        np.testing.assert_allclose(gp.inv_K[d], om["inv_K"][d], rtol=1e-7,
+                                   atol=1e-9 * np.abs(om["inv_K"][d]).max())
+    mu, var, jac = gp.predict(g["x_new"], None, True)
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-10, atol=max(at, 1e-12))
+    np.testing.assert_allclose(jac, g["jac"], rtol=1e-10, atol=max(10 * at, 1e-11))
+    np.testing.assert_allclose(var, g["var"], rtol=0, atol=1e-9 * sf2)
+    # the fixture values produced by the reference's own gp_pred formulas
+    np.testing.assert_allclose(mu, g["ref_mu"], rtol=1e-10, atol=max(at, 1e-12))
+    np.testing.assert_allclose(var, g["ref_var"], rtol=0, atol=1e-9 * sf2)
+    # both call shapes + the single-query 3-tuple
+    mu2, var2 = gp.predict(g["x_new"][:, :n_s], g["x_new"][:, n_s:])
+    np.testing.assert_array_equal(mu2, mu)
+    np.testing.assert_array_equal(var2, var)
+    m1, s1, j1 = gp(g["x_new"][3:4, :n_s], g["x_new"][3:4, n_s:])
+    assert m1.shape == (n_s, 1) and s1.shape == (n_s, 1) and j1.shape == (n_s, n_s + n_u)
+    np.testing.assert_allclose(m1[:, 0], g["mu"][3], rtol=1e-10, atol=max(at, 1e-12))
+    np.testing.assert_allclose(j1, g["jac"][3], rtol=1e-10, atol=max(10 * at, 1e-11))
+    with pytest.raises(NotImplementedError):
+        gp(g["x_new"][:2, :n_s], g["x_new"][:2, n_s:])
+
+
+@pytest.mark.parametrize("N,n_s,n_u,T", [(1, 2, 1, 5), (2, 2, 1, 3), (127, 2, 1, 130), (129, 4, 1, 257),
+                                         (300, 3, 2, 1), (700, 2, 1, 1000)])
+def test_predict_ragged_sizes(N, n_s, n_u, T):
+    """padding edges: N around the 128 block, T around the 128/256 tiles, T = 1, N = 1."""
+    syn = orc.make_synthetic(7 * N + T, N, n_s, n_u, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    mu, var, jac = gp.predict(x, None, True)
+    rmu, rvar, rjac = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"],
+                                     om["signal_var"], True)
+    at = max(mu_atol(om), 1e-12)
+    np.testing.assert_allclose(mu, rmu, rtol=1e-9, atol=at)
+    np.testing.assert_allclose(jac, rjac, rtol=1e-9, atol=10 * at)
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-9)
+    # second algebraic route of the oracle agrees too
+    _, cvar = orc.gp_predict_chol(x, om["Z"], om["beta"], om["chol"], om["lengthscale"], om["signal_var"])
+    np.testing.assert_allclose(var, cvar, rtol=0, atol=1e-9)
+
+
+def test_predict_empty_batch():
+    syn = orc.make_synthetic(5, 40, 2, 1, 4)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    mu, var = gp.predict(np.empty((0, 3)))
+    assert mu.shape == (0, 2) and var.shape == (0, 2)
+
+
+def test_interpolation_property():
+    """mu(z_i) -> y_i and var(z_i) -> O(noise) as noise -> 0."""
+    rng = np.random.default_rng(3)
+    Z = rng.uniform(-1, 1, (50, 3))
+    Y = np.sin(Z.dot(rng.standard_normal((3, 2))))
+    ls = np.full((2, 3), 0.7)
+    gp = hip_model(Z, Y, ls, np.ones(2), np.full(2, 1e-6 + 1e-5), 2, 1)
+    mu, var = gp.predict(Z)
+    assert np.abs(mu - Y).max() < 1e-3
+    assert var.max() < 1e-4 and var.min() > 0
+
+
+def test_not_positive_definite_is_reported():
+    Z = np.zeros((4, 3))                       # identical points, ~zero noise -> singular K
+    from safe_exploration_amd import SimpleGPModel
+    gp = SimpleGPModel(2, 2, 1, hyp=[{"lengthscale": np.ones(3), "variance": 1.0,
+                                      "noise_variance": -1e-5 - 1e-8 - 1e-3}] * 2)
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.train(Z, np.zeros((4, 2)), opt_hyp=False)
+
+
+# ------------------------------------------------------------------ ellipsoid kernel in isolation
+@pytest.mark.parametrize("name", ["reach_pend.npz", "reach_cart.npz", "reach_n3u2.npz"])
+def test_ellipsoid_step_vs_reference_golden(name):
+    """identical (mu,var,jac) fed -> pure small-matrix algebra, rtol 1e-12 vs the REFERENCE's output."""
+    from safe_exploration_amd import gp_reachability as reach
+    g = load_golden(name)
+    for tag, a, b in (("id", None, None), ("lin", g["a_lin"], g["b_lin"])):
+        p1, q1 = reach.ellipsoid_step_batch(g["p"], g["k_ff"], g["mu"], g["var"], g["jac"], g["l_mu"],
+                                            g["l_sigma"], None, None, float(g["c_safety"]), a, b,
+                                            check_bounds=True)
+        np.testing.assert_allclose(p1, g["p1_point_" + tag], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(q1, g["q1_point_" + tag], rtol=1e-12, atol=1e-16)
+        p1, q1 = reach.ellipsoid_step_batch(g["p"], g["k_ff"], g["mu"], g["var"], g["jac"], g["l_mu"],
+                                            g["l_sigma"], g["Q"], g["k_fb"], float(g["c_safety"]), a, b,
+                                            check_bounds=True)
+        np.testing.assert_allclose(p1, g["p1_ell_" + tag], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(q1, g["q1_ell_" + tag], rtol=1e-12, atol=1e-15)
+
+
+def test_anchor_known_answers():
+    """SURVEY 8c worked anchor (values produced by the imported reference functions)."""
+    from safe_exploration_amd import gp_reachability as reach
+    g = load_golden("anchor.npz")
+    const = lambda s, a: (g["mu"], g["var"], g["jac"])      # a non-HIP StateSpaceModel stand-in
+    l = g["l"]
+    pp, qp = reach.onestep_reachability(g["p"], const, g["k_ff"], l, l, None, None, 2.0, 0)
+    np.testing.assert_allclose(pp, g["p_point"], rtol=1e-13)
+    np.testing.assert_allclose(qp, np.diag([0.08, 0.32]), rtol=1e-13)      # hand check n_s (c sigma)^2
+    pe, qe = reach.onestep_reachability(g["p"], const, g["k_ff"], l, l, g["Q"], g["k_fb"], 2.0, 0)
+    np.testing.assert_allclose(pe, g["p_ell"], rtol=1e-13)
+    np.testing.assert_allclose(qe, g["q_ell"], rtol=1e-12)
+    np.testing.assert_allclose(qe, [[0.605462201964151, 0.158620529130949],
+                                    [0.158620529130949, 0.943186225924461]], rtol=1e-12)
+    pl, ql = reach.onestep_reachability(g["p"], const, g["k_ff"], l, l, g["Q"], g["k_fb"], 2.0, 0,
+                                        g["a2"], g["b2"])
+    np.testing.assert_allclose(pl, g["p_lin"], rtol=1e-13)
+    np.testing.assert_allclose(ql, g["q_lin"], rtol=1e-12)
+    h = np.vstack((np.eye(2), -np.eye(2)))
+    d = reach.lin_ellipsoid_safety_distance(pe, qe, h, np.ones((4, 1)), 1.0)
+    np.testing.assert_allclose(d, g["d_safety"], rtol=1e-12)
+    # demo known answer of the reference: p=0, Q=I/4, H=[e1;-e1], h=.5 -> d = 0
+    d0 = reach.lin_ellipsoid_safety_distance(np.zeros((3, 1)), 0.25 * np.eye(3),
+                                             np.array([[1., 0, 0], [-1., 0, 0]]), 0.5 * np.ones((2, 1)))
+    np.testing.assert_allclose(d0, 0.0, atol=1e-15)
+
+
+def test_remainder_golden():
+    from safe_exploration_amd import utils
+    g = load_golden("remainder.npz")
+    for tag in "1234":
+        um, us = utils.compute_remainder_overapproximations(g["q_" + tag], g["k_fb_" + tag],
+                                                            g["l_mu_" + tag], g["l_sigma_" + tag])
+        np.testing.assert_allclose(um, g["u_mu_" + tag], rtol=1e-12)
+        np.testing.assert_allclose(us, g["u_sigma_" + tag], rtol=1e-12)
+        um, us = utils.compute_remainder_overapproximations(g["q_" + tag], 0 * g["k_fb_" + tag],
+                                                            g["l_mu_" + tag], g["l_sigma_" + tag])
+        np.testing.assert_allclose(um, g["u_mu_k0_" + tag], rtol=1e-12)
+        # k_fb = 0 => r^2 = lambda_max(Q)
+        np.testing.assert_allclose(um, g["l_mu_" + tag] * np.linalg.eigvalsh(g["q_" + tag])[-1], rtol=1e-12)
+
+
+def test_bad_box_raises_like_reference():
+    from safe_exploration_amd import gp_reachability as reach
+    g = load_golden("anchor.npz")
+    const = lambda s, a: (g["mu"], g["var"], g["jac"])
+    with pytest.raises(AssertionError):       # l_mu = 0 -> zero-width box (utils_ellipsoid.py:227)
+        reach.onestep_reachability(g["p"], const, g["k_ff"], 0 * g["l"], g["l"], g["Q"], g["k_fb"], 2.0, 0)
+
+
+# ------------------------------------------------------------------ fused GP + ellipsoid
+@pytest.mark.parametrize("name,n_s,n_u", [("reach_pend.npz", 2, 1), ("reach_cart.npz", 4, 1),
+                                          ("reach_n3u2.npz", 3, 2)])
+def test_onestep_and_multistep_vs_reference_golden(name, n_s, n_u):
+    from safe_exploration_amd import gp_reachability as reach
+    g = load_golden(name)
+    gp = hip_model(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"], n_s, n_u)
+    c = float(g["c_safety"])
+    for tag, a, b in (("id", None, None), ("lin", g["a_lin"], g["b_lin"])):
+        p1, q1 = reach.onestep_reachability_batch(g["p"], gp, g["k_ff"], g["l_mu"], g["l_sigma"], None,
+                                                  None, c, a, b, check_bounds=True)
+        np.testing.assert_allclose(p1, g["p1_point_" + tag], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(q1, g["q1_point_" + tag], rtol=1e-8, atol=1e-14)
+        p1, q1, var = reach.onestep_reachability_batch(g["p"], gp, g["k_ff"], g["l_mu"], g["l_sigma"],
+                                                       g["Q"], g["k_fb"], c, a, b, check_bounds=True,
+                                                       return_var=True)
+        np.testing.assert_allclose(p1, g["p1_ell_" + tag], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(q1, g["q1_ell_" + tag], rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(var, g["var"], rtol=0, atol=1e-9 * float(np.max(g["signal_var"])))
+    # single-query API with the reference's shapes
+    p_1, q_1 = reach.onestep_reachability(g["p"][0][:, None], gp, g["k_ff"][0][:, None], g["l_mu"],
+                                          g["l_sigma"], g["Q"][0], g["k_fb"][0], c, 0)
+    assert p_1.shape == (n_s, 1) and q_1.shape == (n_s, n_s)
+    np.testing.assert_allclose(q_1, g["q1_ell_id"][0], rtol=1e-8)
+    # multi-step chains (errors compound over H steps)
+    pa, qa = reach.multistep_reachability_batch(g["ms_p0"], gp, g["ms_k_fb"], g["ms_k_ff"], g["l_mu"],
+                                                g["l_sigma"], None, c, g["a_lin"], g["b_lin"], None)
+    np.testing.assert_allclose(pa, g["ms_p_all"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(qa, g["ms_q_all"], rtol=1e-6, atol=1e-12)
+    Tm = g["ms_p0"].shape[0]
+    pa, qa = reach.multistep_reachability_batch(g["ms_p0"], gp, g["ms_k_fb"], g["ms_k_ff"], g["l_mu"],
+                                                g["l_sigma"], g["Q"][:Tm], c, g["a_lin"], g["b_lin"],
+                                                g["k_fb"][:Tm])
+    np.testing.assert_allclose(pa, g["ms_p_all_q0"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(qa, g["ms_q_all_q0"], rtol=1e-6, atol=1e-12)
+    # single-trajectory API: (p_new, q_new, p_all, q_all) like gp_reachability.py:212
+    pn, qn, p_all, q_all = reach.multistep_reachability(g["ms_p0"][0][:, None], gp, g["ms_k_fb"][0],
+                                                        g["ms_k_ff"][0], g["l_mu"], g["l_sigma"], None,
+                                                        c, 0, g["a_lin"], g["b_lin"], None)
+    np.testing.assert_allclose(p_all, g["ms_p_all"][0], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(qn, g["ms_q_all"][0][-1], rtol=1e-6)
+    assert pn.shape == (n_s, 1)
+    # safety distance on the results
+    d = reach.lin_ellipsoid_safety_distance_batch(g["p1_ell_id"], g["q1_ell_id"], g["h_mat"], g["h_vec"], c)
+    np.testing.assert_allclose(d, g["d_safety"], rtol=1e-12, atol=1e-14)
+
+
+def test_chunking_is_invisible():
+    """results do not depend on the internal chunk size (ragged last chunk included)."""
+    from safe_exploration_amd import gp_reachability as reach
+    syn = orc.make_synthetic(77, 200, 2, 1, 1000)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    l = np.array([0.05, 0.02])
+    ref = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0)
+    gp.set_chunk(384)
+    got = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0)
+    np.testing.assert_allclose(got[0], ref[0], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-12, atol=1e-16)
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] size (N=2000, T=65536): size-independent properties.
+    (i) a 4096-query sample agrees with the oracle, (ii) permuting the queries permutes the outputs
+    bit-exactly, (iii) Q1 symmetric positive definite, (iv) Q1 is monotone in c_safety."""
+    from safe_exploration_amd import gp_reachability as reach
+    N, T = 2000, 65536
+    syn = orc.make_synthetic(2, N, 2, 1, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    l = np.array([0.05, 0.02])
+    p1, q1, var = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"],
+                                                   2.0, return_var=True)
+    assert np.all(np.isfinite(q1))
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    idx = np.random.default_rng(0).choice(T, 4096, replace=False)
+    rp, rq, rvar = orc.onestep_reachability_vectorised(om, syn["p"][idx], syn["Q"][idx], syn["k_ff"][idx],
+                                                       syn["k_fb"][idx], l, l, 2.0, np.eye(2), np.zeros((2, 1)))
+    np.testing.assert_allclose(p1[idx], rp, rtol=1e-9, atol=max(mu_atol(om), 1e-12))
+    np.testing.assert_allclose(var[idx], rvar, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(q1[idx], rq, rtol=1e-8, atol=1e-12)
+    perm = np.random.default_rng(1).permutation(T)
+    p1p, q1p = reach.onestep_reachability_batch(syn["p"][perm], gp, syn["k_ff"][perm], l, l, syn["Q"][perm],
+                                                syn["k_fb"][perm], 2.0)
+    np.testing.assert_array_equal(p1p, p1[perm])
+    np.testing.assert_array_equal(q1p, q1[perm])
+    np.testing.assert_allclose(q1, np.swapaxes(q1, 1, 2), rtol=1e-13, atol=0)
+    assert np.linalg.eigvalsh(q1).min() > 0
+    _, q1c = reach.onestep_reachability_batch(syn["p"][:2048], gp, syn["k_ff"][:2048], l, l, syn["Q"][:2048],
+                                              syn["k_fb"][:2048], 3.0)
+    assert np.all(np.trace(q1c, axis1=1, axis2=2) > np.trace(q1[:2048], axis1=1, axis2=2))
