@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- one-step reachability throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2p|c2|c3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the hot path over one batch of T synthetic query states per GPU:
+GP posterior (mu, var, d mu/dx at z=[p;k_ff]) + ellipsoid branch of onestep_reachability, through
+the C-ABI (sr_onestep_reach).  Inputs are resident in HBM before the timed region.  Default
+workload "c2p" is the configuration the metric is quoted on: pendulum (n_s=2, n_u=1), N=5000
+training points, T=65536 query states per GPU per step, fp64 (SURVEY.md 8(d) row C2').
+
+Multi-GPU: weak scaling, one process per GPU, the query batch is sharded; rank 0 factorises and
+broadcasts the training set + cached posterior (alpha, U^-1) ONCE over RCCL; no data-path collective.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel sr_var_kernel, fp64 MFMA bound, timed
+live with hipEvents on the launch stream) and `cpu_baseline` (oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "one-step reachability evals/sec (batched query states), N=5k train pts"
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (v_mfma_f64_16x16x4_f64) dense peak, vendor spec
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (description, seed, N, n_s, n_u, T per GPU, H)
+    "c2p": ("C2' pendulum n_s=2 n_u=1 D=3, N=5000 train pts, T=65536 query states/GPU/step, "
+            "one-step ellipsoid branch, fp64", 5, 5000, 2, 1, 65536, 1),
+    "c2": ("C2 pendulum n_s=2 n_u=1 D=3, N=2000 train pts, T=65536 query states/GPU/step, "
+           "one-step ellipsoid branch, fp64", 2, 2000, 2, 1, 65536, 1),
+    "c3": ("C3 cart-pole n_s=4 n_u=1 D=5, N=5000 train pts, T=65536 rollouts/GPU/step, H=15 multi-step "
+           "(evals = T*H), fp64", 3, 5000, 4, 1, 65536, 15),
+}
+L_CONST = {2: np.array([0.05, 0.02]), 4: np.array([0.05] * 4)}   # environments.py:317-318, 702-704
+C_SAFETY = 2.0                                                     # defaultconfig_exploration.py:35
+
+
+def cpu_baseline(prob, l_mu, l_sigma, budget_s=12.0):
+    """Oracle ('port' of the reference route: explicit-inverse variance, vectorised over the sample)
+    timed on this box's host cores.  The model fit is excluded (as for the GPU), the sample is bounded."""
+    from oracle import oracle_np as orc
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    n_s = len(prob["signal_var"])
+    noise = prob["noise_var"] + 1e-5
+    t0 = time.time()
+    beta, inv_K, _ = orc.gp_fit(prob["Z"], prob["Y"], prob["lengthscale"], prob["signal_var"], noise)
+    fit_s = time.time() - t0
+    model = dict(Z=prob["Z"], beta=beta, inv_K=inv_K, lengthscale=prob["lengthscale"],
+                 signal_var=prob["signal_var"])
+    a, b = np.eye(n_s), np.zeros((n_s, prob["k_ff"].shape[1]))
+    Ts, done, spent = 256, 0, 0.0
+    while True:
+        sl = slice(0, Ts)
+        t0 = time.time()
+        orc.onestep_reachability_vectorised(model, prob["p"][sl], prob["Q"][sl], prob["k_ff"][sl],
+                                            prob["k_fb"][sl], l_mu, l_sigma, C_SAFETY, a, b)
+        dt = time.time() - t0
+        done, spent = Ts, dt
+        if dt > budget_s / 3 or Ts * 2 > prob["p"].shape[0]:
+            break
+        Ts *= 2
+    return {"value": done / spent, "unit": "evals/s", "cores": int(thr), "kind": "port",
+            "sample": "first %d of the same T query states, N=%d; vectorised NumPy/SciPy oracle "
+                      "(explicit inv_K route of the reference), %.1f s timed; model fit (%.1f s) excluded"
+                      % (done, prob["Z"].shape[0], spent, fit_s)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2p", choices=sorted(WORKLOADS))
+    ap.add_argument("--queries", type=int, default=0, help="override T per GPU")
+    ap.add_argument("--var-group", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload, parallel
+    from safe_exploration_amd import _lib, _buffers as B
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    desc, seed, N, n_s, n_u, T, H = WORKLOADS[args.workload]
+    if args.queries:
+        T = args.queries
+    prob = workload.make_problem(seed, N, n_s, n_u, T)     # model part identical on every rank
+    l_mu = l_sigma = L_CONST[n_s]
+
+    # ---- model: rank 0 factorises, the others receive alpha / U^-1 over RCCL --------------------
+    t0 = time.time()
+    gp = None
+    if rank == 0:
+        gp = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device=dev)
+        gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+        torch.cuda.synchronize(dev)
+    fit_s = time.time() - t0
+    bcast_s = 0.0
+    if world > 1:
+        dist.barrier()
+        t0 = time.time()
+        gp = parallel.replicate_model(gp, prob, src=0)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        bcast_s = time.time() - t0
+    if args.var_group:
+        gp.set_var_group(args.var_group)
+
+    # ---- this rank's shard of the (world * T) query states, resident in HBM ------------------------
+    q = workload.make_queries(seed + 7919 + 104729 * rank, n_s, n_u, T) if rank else prob
+    tp, tq, tkff, tkfb = (B.as_dev(q[k], dev) for k in ("p", "Q", "k_ff", "k_fb"))
+    if H > 1:
+        roll = workload.random_rollout_controls(seed + 31 * rank, T, H, n_s, n_u)
+        tp0, tkffH, tkfbH = (B.as_dev(roll[k], dev) for k in ("p0", "k_ff", "k_fb"))
+
+    def step():
+        if H == 1:
+            return reach.onestep_reachability_batch(tp, gp, tkff, l_mu, l_sigma, tq, tkfb, C_SAFETY)
+        return reach.multistep_reachability_batch(tp0, gp, tkfbH, tkffH, l_mu, l_sigma, None, C_SAFETY)
+
+    for _ in range(args.warmup):
+        step()
+    gp.prof_reset()
+    gp.prof_enable(True)                 # event pairs on the launch stream, resolved after the region
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gp.prof_enable(False)
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    assert bool(torch.isfinite(out[1]).all()), "non-finite result in the timed region"
+
+    if rank == 0:
+        evals = float(world) * T * H * args.steps
+        var_ms, var_n = gp.prof_get(_lib.K_VAR)
+        ks_ms, ks_n = gp.prof_get(_lib.K_KSTAR)
+        ell_ms, ell_n = gp.prof_get(_lib.K_ELL)
+        fin_ms, fin_n = gp.prof_get(_lib.K_FINAL)
+        # algorithmic flops of one sr_var_kernel launch: n_out * N^2 * T  (N^2/2 MACs per query and
+        # output through the triangular factor) -- true N, not the padded one
+        Tc = min(T, 65536)
+        flops_launch = float(n_s) * N * N * Tc
+        avg_ms = var_ms / max(var_n, 1)
+        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("sr_var_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": METRIC, "value": evals / elapsed, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": desc, "N": N, "queries_per_gpu_per_step": T, "horizon": H,
+                       "n_s": n_s, "n_u": n_u,
+                       "parallelism": "query-shard x%d, one-time RCCL broadcast of Z/alpha/U^-1, no "
+                                      "data-path collective" % world,
+                       "model_fit_s": round(fit_s, 3), "broadcast_s": round(bcast_s, 3)},
+            "roofline": {"kernel": "sr_var_kernel", "bound": "mfma", "achieved": achieved,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "flops_per_launch": flops_launch, "avg_launch_ms": avg_ms,
+                         "launches": var_n},
+            "kernel_ms_per_step": {"sr_kstar_kernel": ks_ms / args.steps, "sr_var_kernel": var_ms / args.steps,
+                                   "sr_finalize_kernel": fin_ms / args.steps,
+                                   "sr_ellipsoid_kernel": ell_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(prob, l_mu, l_sigma)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,9 @@ import ctypes
 import os
 
 import numpy as np
+import torch  # noqa: F401  MUST precede CDLL below: PyTorch-ROCm bundles its own libamdhip64.so.7;
+#               loading it first makes libsafereach.so bind to that same runtime (one HIP runtime
+#               per process -- two of them cannot both own the device).
 
 from ._build import LIB_PATH
 

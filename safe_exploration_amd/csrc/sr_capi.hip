@@ -16,15 +16,17 @@ void sr_set_error(const char* fmt, ...) {
 }
 
 struct sr_gp {
-    int device, N, Np, D, n_out;
+    int device = 0, N = 0, Np = 0, D = 0, n_out = 0;
     // persistent device state
-    double *Z, *yT, *ls, *sf2, *noise, *alpha, *Wt;
-    int have_data, factorized;
+    double *Z = nullptr, *yT = nullptr, *ls = nullptr, *sf2 = nullptr, *noise = nullptr,
+           *alpha = nullptr, *Wt = nullptr;
+    int have_data = 0, factorized = 0;
     // per-chunk workspace (grow-only)
-    long chunk, ws_Tp;
-    int ws_nsplit;
-    double *Ks, *mu_part, *jac_part, *var_part, *mu, *var, *jac;
-    int var_group;
+    long chunk = 65536, ws_Tp = 0;
+    int ws_nsplit = 0;
+    double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
+           *mu = nullptr, *var = nullptr, *jac = nullptr;
+    int var_group = 16;
     sr_prof prof;
 };
 
@@ -60,11 +62,8 @@ extern "C" int sr_gp_create(sr_gp_t* out, int device, int N, int D, int n_out) {
     SR_CHECK(n_out <= 64, SR_EUNSUPPORTED, "sr_gp_create: n_out=%d > 64", n_out);
     SR_HIP(hipSetDevice(device));
     sr_gp* h = new sr_gp();
-    memset(h, 0, sizeof(*h));
     h->device = device; h->N = N; h->D = D; h->n_out = n_out;
     h->Np = (int)round_up(N, SR_NB);
-    h->chunk = 65536;
-    h->var_group = 16;
     int rc = SR_OK;
     if ((rc = dev_alloc(&h->Z, (size_t)N * D)) || (rc = dev_alloc(&h->yT, (size_t)n_out * h->Np)) ||
         (rc = dev_alloc(&h->ls, (size_t)n_out * D)) || (rc = dev_alloc(&h->sf2, n_out)) ||
@@ -72,8 +71,6 @@ extern "C" int sr_gp_create(sr_gp_t* out, int device, int N, int D, int n_out) {
         sr_gp_destroy(h);
         return rc;
     }
-    if (hipEventCreate(&h->prof.ev0) == hipSuccess && hipEventCreate(&h->prof.ev1) == hipSuccess)
-        h->prof.have_events = 1;
     *out = h;
     return SR_OK;
 }
@@ -92,7 +89,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt);
     free_ws(h);
-    if (h->prof.have_events) { (void)hipEventDestroy(h->prof.ev0); (void)hipEventDestroy(h->prof.ev1); }
+    h->prof.destroy();
     delete h;
     return SR_OK;
 }
@@ -530,18 +527,23 @@ extern "C" int sr_test_gemm_tn(int device, const double* A, long lda, const doub
 
 extern "C" int sr_prof_enable(sr_gp_t h, int on) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_prof_enable: NULL handle");
-    SR_CHECK(!on || h->prof.have_events, SR_EHIP, "sr_prof_enable: events unavailable");
+    SR_HIP(hipSetDevice(h->device));
+    if (!on) h->prof.resolve();
     h->prof.enabled = on ? 1 : 0;
     return SR_OK;
 }
 extern "C" int sr_prof_reset(sr_gp_t h) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_prof_reset: NULL handle");
+    SR_HIP(hipSetDevice(h->device));
+    h->prof.resolve();
     for (int i = 0; i < SR_K_COUNT; ++i) { h->prof.ms[i] = 0.0; h->prof.launches[i] = 0; }
     return SR_OK;
 }
 extern "C" int sr_prof_get(sr_gp_t h, int kernel_id, double* ms_total, long* launches) {
     SR_CHECK(h != nullptr && kernel_id >= 0 && kernel_id < SR_K_COUNT, SR_EINVAL,
              "sr_prof_get: bad argument");
+    SR_HIP(hipSetDevice(h->device));
+    h->prof.resolve();
     if (ms_total) *ms_total = h->prof.ms[kernel_id];
     if (launches) *launches = h->prof.launches[kernel_id];
     return SR_OK;

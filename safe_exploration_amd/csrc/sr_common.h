@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <vector>
 #include "../../include/safereach.h"
 
 #define SR_NB 128          // factor block size == GEMM tile edge; Np is a multiple of it
@@ -33,31 +34,60 @@ void sr_set_error(const char* fmt, ...);
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+struct sr_prof_rec { int id; hipEvent_t e0, e1; };
 struct sr_prof {
-    int enabled;
-    double ms[SR_K_COUNT];
-    long launches[SR_K_COUNT];
-    hipEvent_t ev0, ev1;
-    int have_events;
+    int enabled = 0;
+    double ms[SR_K_COUNT] = {0};
+    long launches[SR_K_COUNT] = {0};
+    std::vector<hipEvent_t> pool;        // recycled events
+    std::vector<sr_prof_rec> pending;    // recorded, not yet resolved
+    hipEvent_t take() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    // wait for every recorded pair and fold the elapsed times into ms[] / launches[]
+    void resolve() {
+        for (auto& r : pending) {
+            float t = 0.f;
+            if (r.e0 && r.e1 && hipEventSynchronize(r.e1) == hipSuccess &&
+                hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+                ms[r.id] += t;
+                launches[r.id] += 1;
+            }
+            if (r.e0) pool.push_back(r.e0);
+            if (r.e1) pool.push_back(r.e1);
+        }
+        pending.clear();
+    }
+    void destroy() {
+        resolve();
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
 };
 
-// Optional per-launch timing: records an event pair on `stream` around one launch and
-// accumulates the elapsed time.  Only used while sr_prof_enable(h, 1).
+// Optional per-launch timing: a hipEvent pair recorded on the launch stream around one kernel.
+// Nothing synchronises at launch time; pairs are resolved lazily by sr_prof_get / sr_prof_reset.
 struct sr_prof_scope {
-    sr_prof* p; int id; hipStream_t s;
-    sr_prof_scope(sr_prof* p_, int id_, hipStream_t s_) : p(p_), id(id_), s(s_) {
-        if (p && p->enabled) (void)hipEventRecord(p->ev0, s);
+    sr_prof* p; sr_prof_rec r;
+    sr_prof_scope(sr_prof* p_, int id_, hipStream_t s_) : p(p_), s(s_) {
+        r.id = id_; r.e0 = r.e1 = nullptr;
+        if (p && p->enabled) {
+            if (p->pending.size() >= 8192) p->resolve();
+            r.e0 = p->take();
+            if (r.e0) (void)hipEventRecord(r.e0, s);
+        }
     }
     ~sr_prof_scope() {
         if (p && p->enabled) {
-            (void)hipEventRecord(p->ev1, s);
-            (void)hipEventSynchronize(p->ev1);
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, p->ev0, p->ev1);
-            p->ms[id] += ms;
-            p->launches[id] += 1;
+            r.e1 = p->take();
+            if (r.e1) (void)hipEventRecord(r.e1, s);
+            p->pending.push_back(r);
         }
     }
+    hipStream_t s;
 };
 
 // ---- launchers implemented in the .hip files ---------------------------------------------------

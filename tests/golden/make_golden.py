@@ -187,14 +187,23 @@ def main():
         a_lin = a_scale * np.eye(n_s) + 0.05 * rng.standard_normal((n_s, n_s))
         b_lin = 0.1 * rng.standard_normal((n_s, n_u))
 
-        def ssm(states, actions):              # 3-tuple contract of SimpleGPModel.__call__ (A5)
-            z = np.hstack((np.asarray(states), np.asarray(actions)))[0]
-            mu, var, jac = orc._predict_one(model, z)
-            return mu[:, None], var[:, None], jac
-
+        # GP outputs per query, computed ONCE and replayed to the reference bit-for-bit (a batched and a
+        # single-row BLAS call differ in the last bits of the cancelling variance)
         x = np.hstack((syn["p"], syn["k_ff"]))
-        mu, var, jac = orc.gp_predict(x, syn["Z"], beta, inv_K, syn["lengthscale"],
-                                      syn["signal_var"], True)
+        mu = np.empty((T, n_s)); var = np.empty((T, n_s)); jac = np.empty((T, n_s, n_s + n_u))
+        cache = {}
+        for t in range(T):
+            mu[t], var[t], jac[t] = orc._predict_one(model, x[t])
+            cache[x[t].tobytes()] = t
+
+        def ssm(states, actions):              # 3-tuple contract of SimpleGPModel.__call__ (A5)
+            z = np.ascontiguousarray(np.hstack((np.asarray(states), np.asarray(actions)))[0])
+            t = cache.get(z.tobytes())
+            if t is not None:
+                return mu[t][:, None].copy(), var[t][:, None].copy(), jac[t].copy()
+            m, v, j = orc._predict_one(model, z)
+            return m[:, None], v[:, None], j
+
         res = {k: syn[k] for k in ("Z", "Y", "lengthscale", "signal_var", "noise_var", "p", "k_ff",
                                    "k_fb", "Q")}
         res.update(mu=mu, var=var, jac=jac, l_mu=l_mu, l_sigma=l_sigma, c_safety=c_safety,

@@ -282,7 +282,7 @@ def test_full_size_properties():
                                                 syn["k_fb"][perm], 2.0)
     np.testing.assert_array_equal(p1p, p1[perm])
     np.testing.assert_array_equal(q1p, q1[perm])
-    np.testing.assert_allclose(q1, np.swapaxes(q1, 1, 2), rtol=1e-13, atol=0)
+    np.testing.assert_allclose(q1, np.swapaxes(q1, 1, 2), rtol=1e-12, atol=1e-15)
     assert np.linalg.eigvalsh(q1).min() > 0
     _, q1c = reach.onestep_reachability_batch(syn["p"][:2048], gp, syn["k_ff"][:2048], l, l, syn["Q"][:2048],
                                               syn["k_fb"][:2048], 3.0)
