@@ -1,0 +1,147 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the
+Python mirror keeps the reference's surface and error behaviour, host helpers match the golden
+vectors, and nothing in the product package routes through the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, ROOT
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    from safe_exploration_amd import _lib
+    header = open(os.path.join(ROOT, "include", "safereach.h")).read()
+    declared = set(re.findall(r"\b(sr_[a-z_0-9]+)\s*\(", header))
+    declared -= {"sr_gp"}
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(_lib.lib, name), "libsafereach.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "no ctypes signature for %s" % name
+    assert set(_lib.SIGNATURES) == declared
+    assert _lib.lib.sr_version() >= 100
+
+
+def test_no_gpu_fails_loudly(lib_built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, _lib
+    assert _lib.device_count() == 0
+    gp = SimpleGPModel(2, 2, 1)
+    with pytest.raises(RuntimeError):
+        gp.train(np.zeros((4, 3)), np.zeros((4, 2)), opt_hyp=False)
+    with pytest.raises(RuntimeError):
+        gp.predict(np.zeros((1, 3)))
+    with pytest.raises(RuntimeError):
+        reach.ellipsoid_step_batch(np.zeros((1, 2)), np.zeros((1, 1)), np.zeros((1, 2)), np.ones((1, 2)),
+                                   None, np.ones(2), np.ones(2))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "safe_exploration_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), "%s mentions the oracle" % f
+    for f in ("bench.py",):
+        src = open(os.path.join(ROOT, f)).read()
+        assert src.count("from oracle") == 1      # only inside cpu_baseline()
+
+
+def test_simple_gp_model_surface(lib_built):
+    from safe_exploration_amd import SimpleGPModel, StateSpaceModel
+    gp = SimpleGPModel(2, 2, 1)
+    assert isinstance(gp, StateSpaceModel)
+    assert (gp.n_s_out, gp.n_s_in, gp.n_u, gp.num_states, gp.num_actions) == (2, 2, 1, 2, 1)
+    assert gp.has_jacobian and not gp.has_reverse and not gp.gp_trained
+    assert gp.kern_types == ["rbf", "rbf"] and gp.beta is None and gp.inv_K is None
+    assert set(gp.hyp[0]) == {"lengthscale", "variance"} and gp.hyp[0]["lengthscale"].shape == (3,)
+    with pytest.raises(ValueError):
+        SimpleGPModel(2, 2, 1, kern_types=["rbf", "nope"])
+    with pytest.raises(NotImplementedError):
+        SimpleGPModel(2, 2, 1, kern_types=["rbf", "lin_mat52"])
+    with pytest.raises(NotImplementedError):                  # opt_hyp=True is outside the hot path
+        gp.train(np.zeros((4, 3)), np.zeros((4, 2)))
+    with pytest.raises(ValueError):
+        gp.train(np.zeros((4, 2)), np.zeros((4, 2)), opt_hyp=False)
+    with pytest.raises(RuntimeError):
+        gp.predict_device(np.zeros((1, 3)))
+    d = gp.to_dict()
+    assert set(d) == {"x", "y", "kern_types", "hyp", "beta", "inv_K"}
+    g2 = SimpleGPModel.from_dict({"n_s_in": 2, "n_s_out": 2, "n_u": 1, "x": np.zeros((3, 3)),
+                                  "y": np.zeros((3, 2)), "train": False})
+    assert not g2.gp_trained
+    import copy
+    g3 = copy.deepcopy(gp)
+    assert g3 is not gp and g3.hyp is gp.hyp
+
+
+def test_state_space_model_abstract_surface():
+    from safe_exploration_amd import StateSpaceModel
+    ssm = StateSpaceModel(3, 2)
+    for call in (lambda: ssm.predict(None, None), lambda: ssm(None, None),
+                 lambda: ssm.linearize_predict(None, None), lambda: ssm.get_reverse(None),
+                 lambda: ssm.get_linearize_reverse(None), lambda: ssm.update_model(None, None)):
+        with pytest.raises(NotImplementedError):
+            call()
+    with pytest.raises(ImportError):       # casadi is an optional dependency of the caller
+        ssm.get_forward_model_casadi()
+
+
+def test_utils_ellipsoid_host_helpers_vs_reference_golden():
+    from safe_exploration_amd import utils_ellipsoid as ue
+    g = load_golden("ellipsoid.npz")
+    for n in (2, 3, 4, 8):
+        np.testing.assert_allclose(ue.ellipsoid_from_rectangle(g["rect_ub_%d" % n]), g["rect_q_%d" % n], rtol=1e-15)
+        p, q = ue.sum_two_ellipsoids(g["sum_p1_%d" % n], g["sum_q1_%d" % n], g["sum_p2_%d" % n], g["sum_q2_%d" % n])
+        np.testing.assert_allclose(q, g["sum_q_%d" % n], rtol=1e-14)
+        np.testing.assert_allclose(p, g["sum_p_%d" % n], rtol=1e-15)
+        for k in (3, 4):
+            pn, qn = ue.sum_ellipsoids(g["msum_p_in_%d_%d" % (k, n)], g["msum_q_in_%d_%d" % (k, n)],
+                                       g["msum_l_%d_%d" % (k, n)])
+            np.testing.assert_allclose(pn, g["msum_p_%d_%d" % (k, n)], rtol=1e-14)
+            np.testing.assert_allclose(qn, g["msum_q_%d_%d" % (k, n)], rtol=1e-13)
+        d = ue.distance_to_center(g["dist_s_%d" % n], g["sum_p1_%d" % n], g["sum_q1_%d" % n])
+        np.testing.assert_allclose(d, g["dist_d_%d" % n], rtol=1e-12)
+        assert list(ue.sample_inside_ellipsoid(g["dist_s_%d" % n], g["sum_p1_%d" % n], g["sum_q1_%d" % n], 3.0)) \
+            == list(g["inside_%d" % n])
+    # the reference test's geometric property: box corners lie on the ellipsoid (test_utils_ellipsoid.py:13-25)
+    ub = np.array([0.1, 0.2, 0.3])
+    q = ue.ellipsoid_from_rectangle(ub)
+    corners = np.array([[sx * ub[0], sy * ub[1], sz * ub[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    np.testing.assert_allclose(ue.distance_to_center(corners, np.zeros((3, 1)), q), 1.0, rtol=1e-12)
+    with pytest.raises(AssertionError):
+        ue.ellipsoid_from_rectangle(np.array([0.1, 0.0]))
+    with pytest.raises(AssertionError):
+        ue.sum_ellipsoids(np.zeros((1, 2)), np.eye(2)[None])
+
+
+def test_utils_host_helpers():
+    from safe_exploration_amd import utils
+    g = load_golden("remainder.npz")
+    assert list(utils.sample_inside_polytope(g["poly_x"], g["poly_a"], g["poly_b"])) == [True, True, False]
+    k_fb, p, x, k_ff = np.array([[1.0, 2.0]]), np.array([[0.1], [0.2]]), np.array([[0.3], [0.1]]), np.array([[0.5]])
+    np.testing.assert_allclose(utils.feedback_ctrl(x, k_ff, k_fb, p), [[0.5]])
+    assert utils.feedback_ctrl(x, k_ff) is k_ff
+    assert utils.array_of_vec_to_array_of_mat(np.arange(12.0).reshape(2, 6), 2, 3).shape == (2, 2, 3)
+
+
+def test_safety_distance_shape_asserts(lib_built):
+    from safe_exploration_amd import gp_reachability as reach
+    with pytest.raises(AssertionError):
+        reach.lin_ellipsoid_safety_distance(np.zeros((2,)), np.eye(2), np.eye(2), np.ones((2, 1)))
+    with pytest.raises(AssertionError):
+        reach.lin_ellipsoid_safety_distance(np.zeros((2, 1)), np.eye(3), np.eye(2), np.ones((2, 1)))
+
+
+def test_workload_generator_shapes():
+    from safe_exploration_amd import workload
+    prob = workload.make_problem(1, 50, 2, 1, 16)
+    assert prob["Z"].shape == (50, 3) and prob["Q"].shape == (16, 2, 2)
+    assert np.all(np.linalg.eigvalsh(prob["Q"]) > 0)
+    r = workload.random_rollout_controls(3, 8, 15, 4, 1)
+    assert r["k_fb"].shape == (8, 14, 1, 4) and r["k_ff"].shape == (8, 15, 1) and r["p0"].shape == (8, 4)
+    assert abs(np.std(r["k_fb"]) - 0.1) < 0.02       # uncertainty_propagation_runner.py:32-33

@@ -1,0 +1,158 @@
+"""CPU tests: the oracle (oracle/oracle_np.py) against every golden vector generated from the
+reference itself (tests/golden/make_golden.py), plus independent cross-checks of the GP formulas."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import oracle_np as orc
+
+
+def _model(g):
+    beta, inv_K, chol = orc.gp_fit(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"])
+    return dict(Z=g["Z"], beta=beta, inv_K=inv_K, chol=chol, lengthscale=g["lengthscale"],
+                signal_var=g["signal_var"])
+
+
+def test_ellipsoid_helpers_vs_reference():
+    g = load_golden("ellipsoid.npz")
+    for n in (2, 3, 4, 8):
+        np.testing.assert_allclose(orc.ellipsoid_from_rectangle(g["rect_ub_%d" % n]), g["rect_q_%d" % n], rtol=1e-15)
+        p, q = orc.sum_two_ellipsoids(g["sum_p1_%d" % n], g["sum_q1_%d" % n], g["sum_p2_%d" % n], g["sum_q2_%d" % n])
+        np.testing.assert_allclose(p, g["sum_p_%d" % n], rtol=1e-15)
+        np.testing.assert_allclose(q, g["sum_q_%d" % n], rtol=1e-14)
+        _, qc = orc.sum_two_ellipsoids(g["sum_p1_%d" % n], g["sum_q1_%d" % n], g["sum_p2_%d" % n],
+                                       g["sum_q2_%d" % n], c=0.7)
+        np.testing.assert_allclose(qc, g["sumc_q_%d" % n], rtol=1e-14)
+        d = orc.distance_to_center(g["dist_s_%d" % n], g["sum_p1_%d" % n], g["sum_q1_%d" % n])
+        np.testing.assert_allclose(d, g["dist_d_%d" % n], rtol=1e-12)
+    np.testing.assert_allclose(np.diag(g["known_rect"]), [0.03, 0.12, 0.27], rtol=1e-14)
+    np.testing.assert_allclose(g["known_dist"], 1.0, rtol=1e-14)
+
+
+def test_remainder_vs_reference():
+    g = load_golden("remainder.npz")
+    for tag in "1234":
+        um, us = orc.compute_remainder_overapproximations(g["q_" + tag], g["k_fb_" + tag],
+                                                          g["l_mu_" + tag], g["l_sigma_" + tag])
+        np.testing.assert_allclose(um, g["u_mu_" + tag], rtol=1e-13)
+        np.testing.assert_allclose(us, g["u_sigma_" + tag], rtol=1e-13)
+    assert list(orc.sample_inside_polytope(g["poly_x"], g["poly_a"], g["poly_b"])) == [True, True, False]
+    assert list(g["poly_res"]) == [True, True, False]
+
+
+@pytest.mark.parametrize("name", ["gp_pend.npz", "gp_cart.npz"])
+def test_gp_formulas_vs_reference_gp_pred(name):
+    """fixtures hold the outputs of the reference's own _k_rbf/gp_pred evaluated on numbers."""
+    g = load_golden(name)
+    m = _model(g)
+    np.testing.assert_allclose(m["beta"], g["beta"], rtol=1e-9, atol=1e-12)
+    mu, var, jac = orc.gp_predict(g["x_new"], m["Z"], m["beta"], m["inv_K"], m["lengthscale"], m["signal_var"])
+    np.testing.assert_allclose(mu, g["ref_mu"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(var, g["ref_var"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(orc.rbf_kernel(g["x_new"], m["Z"], g["signal_var"][0], g["lengthscale"][0]),
+                               g["ref_kstar0"], rtol=1e-13)
+    # explicit-inverse route == Cholesky route
+    mu2, var2 = orc.gp_predict_chol(g["x_new"], m["Z"], m["beta"], m["chol"], m["lengthscale"], m["signal_var"])
+    np.testing.assert_allclose(mu2, mu, rtol=1e-13)
+    np.testing.assert_allclose(var2, var, rtol=0, atol=1e-10 * float(np.max(g["signal_var"])))
+
+
+def test_gp_derivatives_vs_torch_autograd():
+    """analytic d mu/dx, d var/dx, Hessian of mu vs torch-fp64 autograd."""
+    g = load_golden("gp_pend.npz")
+    m = _model(g)
+    Z = torch.from_numpy(g["Z"])
+
+    def post(x, d):
+        ls = torch.from_numpy(g["lengthscale"][d])
+        r2 = (((x[None, :] - Z) / ls) ** 2).sum(1)
+        ks = g["signal_var"][d] * torch.exp(-0.5 * r2)
+        mu = ks @ torch.from_numpy(m["beta"][:, d])
+        var = g["signal_var"][d] - ks @ torch.from_numpy(m["inv_K"][d]) @ ks
+        return mu, var
+
+    x0 = g["x_new"][0]
+    _, _, jac = orc.gp_predict(x0[None], m["Z"], m["beta"], m["inv_K"], m["lengthscale"], m["signal_var"])
+    jv, hm = orc.gp_linearize_extras(x0, m["Z"], m["beta"], m["inv_K"], m["lengthscale"], m["signal_var"])
+    for d in range(2):
+        x = torch.from_numpy(x0.copy()).requires_grad_(True)
+        mu, var = post(x, d)
+        gmu, = torch.autograd.grad(mu, x, create_graph=True)
+        gvar, = torch.autograd.grad(var, x, retain_graph=True)
+        H = torch.stack([torch.autograd.grad(gmu[j], x, retain_graph=True)[0] for j in range(3)])
+        np.testing.assert_allclose(jac[0, d], gmu.detach().numpy(), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(jv[d], gvar.numpy(), rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(hm[d], H.numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(jv, g["jac_var0"], rtol=1e-9, atol=1e-14)
+
+
+def test_hand_cases_n1_n2():
+    """N=1: mu = k y/(sf2+sn2), var = sf2 - k^2/(sf2+sn2)."""
+    Z = np.array([[0.2, -0.1, 0.4]])
+    Y = np.array([[0.7, -0.3]])
+    ls = np.array([[0.5, 1.0, 2.0], [1.0, 1.0, 1.0]])
+    sf2, sn2 = np.array([1.3, 0.6]), np.array([0.01, 0.02])
+    beta, inv_K, _ = orc.gp_fit(Z, Y, ls, sf2, sn2)
+    x = np.array([[0.0, 0.3, 0.1]])
+    mu, var, jac = orc.gp_predict(x, Z, beta, inv_K, ls, sf2)
+    for d in range(2):
+        k = sf2[d] * np.exp(-0.5 * np.sum(((x - Z) / ls[d]) ** 2))
+        den = sf2[d] + sn2[d] + orc.GPY_JITTER
+        np.testing.assert_allclose(mu[0, d], k * Y[0, d] / den, rtol=1e-13)
+        np.testing.assert_allclose(var[0, d], sf2[d] - k * k / den, rtol=1e-12)
+        np.testing.assert_allclose(jac[0, d], k * Y[0, d] / den * (Z[0] - x[0]) / ls[d] ** 2, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["reach_pend.npz", "reach_cart.npz", "reach_n3u2.npz"])
+def test_reachability_vs_reference(name):
+    """the oracle's ellipsoid algebra == the imported reference functions, same (mu,var,jac) fed."""
+    g = load_golden(name)
+    T, n_s = g["p"].shape
+    n_u = g["k_ff"].shape[1]
+    c = float(g["c_safety"])
+    for tag, a, b in (("id", np.eye(n_s), np.zeros((n_s, n_u))), ("lin", g["a_lin"], g["b_lin"])):
+        for t in range(T):
+            p1, q1 = orc.onestep_reachability_from_gp(g["p"][t], None, g["k_ff"][t], None, g["mu"][t],
+                                                      g["var"][t], g["jac"][t], g["l_mu"], g["l_sigma"], c, a, b)
+            np.testing.assert_allclose(p1, g["p1_point_" + tag][t], rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(q1, g["q1_point_" + tag][t], rtol=1e-13)
+            p1, q1 = orc.onestep_reachability_from_gp(g["p"][t], g["Q"][t], g["k_ff"][t], g["k_fb"][t],
+                                                      g["mu"][t], g["var"][t], g["jac"][t], g["l_mu"],
+                                                      g["l_sigma"], c, a, b)
+            np.testing.assert_allclose(p1, g["p1_ell_" + tag][t], rtol=1e-13, atol=1e-15)
+            np.testing.assert_allclose(q1, g["q1_ell_" + tag][t], rtol=1e-12, atol=1e-16)
+    # full chain through the oracle's own GP (what the reference was driven with)
+    m = _model(g)
+    pa, qa = orc.multistep_reachability_batch(m, g["ms_p0"], g["ms_k_fb"], g["ms_k_ff"], g["l_mu"], g["l_sigma"],
+                                              None, c, g["a_lin"], g["b_lin"], None)
+    np.testing.assert_allclose(pa, g["ms_p_all"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(qa, g["ms_q_all"], rtol=1e-7, atol=1e-13)
+    Tm = g["ms_p0"].shape[0]
+    pa, qa = orc.multistep_reachability_batch(m, g["ms_p0"], g["ms_k_fb"], g["ms_k_ff"], g["l_mu"], g["l_sigma"],
+                                              g["Q"][:Tm], c, g["a_lin"], g["b_lin"], g["k_fb"][:Tm])
+    np.testing.assert_allclose(qa, g["ms_q_all_q0"], rtol=1e-7, atol=1e-13)
+    for t in range(T):
+        d = orc.lin_ellipsoid_safety_distance(g["p1_ell_id"][t][:, None], g["q1_ell_id"][t], g["h_mat"],
+                                              g["h_vec"], c)
+        np.testing.assert_allclose(d[:, 0], g["d_safety"][t], rtol=1e-13, atol=1e-15)
+    # vectorised CPU baseline == per-query algebra
+    vp, vq, _ = orc.onestep_reachability_vectorised(m, g["p"], g["Q"], g["k_ff"], g["k_fb"], g["l_mu"],
+                                                    g["l_sigma"], c, g["a_lin"], g["b_lin"])
+    np.testing.assert_allclose(vq, g["q1_ell_lin"], rtol=1e-8, atol=1e-14)
+
+
+def test_anchor_numbers_of_the_survey():
+    g = load_golden("anchor.npz")
+    np.testing.assert_allclose(g["q_point"], np.diag([0.08, 0.32]), rtol=1e-14)
+    np.testing.assert_allclose(g["q_ell"], [[0.605462201964151, 0.158620529130949],
+                                            [0.158620529130949, 0.943186225924461]], rtol=1e-13)
+    np.testing.assert_allclose(g["q_lin"], [[0.621617596208348, 0.17970909212829],
+                                            [0.17970909212829, 0.933205766585243]], rtol=1e-13)
+    np.testing.assert_allclose(g["dist"], 0.051607478675549, rtol=1e-12)
+    a, b = np.eye(2), np.zeros((2, 1))
+    p1, q1 = orc.onestep_reachability_from_gp(g["p"][:, 0], g["Q"], g["k_ff"][:, 0], g["k_fb"], g["mu"][:, 0],
+                                              g["var"][:, 0], g["jac"], g["l"], g["l"], 2.0, a, b)
+    np.testing.assert_allclose(q1, g["q_ell"], rtol=1e-13)
+    um, us = orc.compute_remainder_overapproximations(g["Q"], g["k_fb"], g["l"], g["l"])
+    np.testing.assert_allclose(um, [0.0080762036885, 0.0032304814754], rtol=1e-10)
