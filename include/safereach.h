@@ -62,7 +62,8 @@ int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const double* le
  * Synchronises the stream before returning. */
 int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
 
-/* padded leading dimension Np (multiple of 128) of the factor matrices. */
+/* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and
+ * columns are at the FRONT (identity block): training point i has padded index i + (Np - N). */
 int sr_gp_padded_n(sr_gp_t h, long* Np);
 
 /* Export / import the cached posterior state (what a broadcast receiver needs):
@@ -131,7 +132,7 @@ int sr_safety_distance(int device, long T, int n_s, int m, const double* p, cons
 /* ---- tuning / measurement -------------------------------------------------------------------- */
 /* max queries processed per internal pass (workspace = n_out * Np * chunk * 8 B); default 65536. */
 int sr_gp_set_chunk(sr_gp_t h, long chunk);
-/* query tiles per scheduling group of the variance kernel (L2/XCD locality knob); default 16. */
+/* query tiles per scheduling group of the variance kernel (L2/XCD locality knob); default 32. */
 int sr_gp_set_var_group(sr_gp_t h, int group);
 /* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
  * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.

@@ -26,7 +26,7 @@ struct sr_gp {
     int ws_nsplit = 0;
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr;
-    int var_group = 16;
+    int var_group = 32;
     sr_prof prof;
 };
 
@@ -98,7 +98,8 @@ __global__ void sr_pack_y_kernel(const double* __restrict__ Y, double* __restric
                                  int n_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int d = blockIdx.y;
-    if (i < Np) yT[(long)d * Np + i] = (i < N) ? Y[(long)i * n_out + d] : 0.0;
+    const int off = Np - N;                   // front padding
+    if (i < Np) yT[(long)d * Np + i] = (i >= off) ? Y[(long)(i - off) * n_out + d] : 0.0;
 }
 
 extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const double* ls,
@@ -207,6 +208,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
 #undef SR_FH
     int bad = 0;
     for (int d = 0; d < h->n_out; ++d) {
+        if (info_h[d] > 0) info_h[d] = std::max(1, info_h[d] - (h->Np - h->N));   // padded -> training index
         if (info) info[d] = info_h[d];
         if (info_h[d] != 0 && !bad) bad = d + 1;
     }
@@ -225,8 +227,9 @@ extern "C" int sr_gp_export(sr_gp_t h, double* alpha, double* Wt, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
     if (alpha)
-        SR_HIP(hipMemcpy2DAsync(alpha, sizeof(double) * h->N, h->alpha, sizeof(double) * h->Np,
-                                sizeof(double) * h->N, h->n_out, hipMemcpyDeviceToDevice, s));
+        SR_HIP(hipMemcpy2DAsync(alpha, sizeof(double) * h->N, h->alpha + (h->Np - h->N),
+                                sizeof(double) * h->Np, sizeof(double) * h->N, h->n_out,
+                                hipMemcpyDeviceToDevice, s));
     if (Wt)
         SR_HIP(hipMemcpyAsync(Wt, h->Wt, sizeof(double) * h->n_out * h->Np * h->Np,
                               hipMemcpyDeviceToDevice, s));
@@ -241,8 +244,9 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
     SR_HIP(hipSetDevice(h->device));
     SR_TRY(ensure_wt(h));
     SR_HIP(hipMemsetAsync(h->alpha, 0, sizeof(double) * h->n_out * h->Np, s));
-    SR_HIP(hipMemcpy2DAsync(h->alpha, sizeof(double) * h->Np, alpha, sizeof(double) * h->N,
-                            sizeof(double) * h->N, h->n_out, hipMemcpyDeviceToDevice, s));
+    SR_HIP(hipMemcpy2DAsync(h->alpha + (h->Np - h->N), sizeof(double) * h->Np, alpha,
+                            sizeof(double) * h->N, sizeof(double) * h->N, h->n_out,
+                            hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->Wt, Wt, sizeof(double) * h->n_out * h->Np * h->Np,
                           hipMemcpyDeviceToDevice, s));
     h->factorized = 1;
@@ -265,8 +269,8 @@ extern "C" int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream) {
     if (rc == SR_OK) rc = sr_launch_gemm_tn(W, Np, W, Np, out, Np, Np, Np, Np, 1.0, 0.0, 0, s);
     hipError_t e = hipSuccess;
     if (rc == SR_OK)
-        e = hipMemcpy2DAsync(inv_k, sizeof(double) * h->N, out, sizeof(double) * Np,
-                             sizeof(double) * h->N, h->N, hipMemcpyDeviceToDevice, s);
+        e = hipMemcpy2DAsync(inv_k, sizeof(double) * h->N, out + (size_t)(Np - h->N) * Np + (Np - h->N),
+                             sizeof(double) * Np, sizeof(double) * h->N, h->N, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     dev_free(W); dev_free(out);
     if (rc != SR_OK) return rc;
@@ -327,7 +331,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     }
     {
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->Np, Tp, h->n_out, h->var_group, s));
+        SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, s));
     }
     sr_final_args fa;
     fa.mu_part = h->mu_part; fa.jac_part = h->jac_part; fa.var_part = h->var_part; fa.sf2 = h->sf2;

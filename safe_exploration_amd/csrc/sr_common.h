@@ -98,6 +98,8 @@ struct sr_prof_scope {
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                       int M, int N, int K, double alpha, double beta, int mode, hipStream_t s);
 
+// padded index space: the Np - N padding rows/cols sit at the FRONT (identity), training point i lives
+// at padded index i + (Np - N); the contraction kernels simply start at k = 16*floor((Np-N)/16).
 int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, double* K, int N,
                    int Np, int D, hipStream_t s);
 // factor the diagonal block kb of the Np x Np matrix A (upper), write U_kk in place, U_kk^-1 to
@@ -126,7 +128,7 @@ struct sr_kstar_args {
 int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 
 // part[d][rb][t] = sum_{i in row block rb} ( sum_k Wt[d][k][i] Ks[d][k][t] )^2
-int sr_launch_var(const double* Wt, const double* Ks, double* part, int Np, long Tp, int n_out,
+int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                   int group, hipStream_t s);
 
 struct sr_final_args {

@@ -61,13 +61,15 @@ __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= Np) return;
+    const int off = Np - N;                  // front padding
     double v;
-    if (i >= N || j >= N) {
+    if (i < off || j < off) {
         v = (i == j) ? 1.0 : 0.0;
     } else {
+        const int zi = i - off, zj = j - off;
         double r2 = 0.0;
         for (int c = 0; c < D; ++c) {
-            const double t = (Z[(long)i * D + c] - Z[(long)j * D + c]) / ls[c];
+            const double t = (Z[(long)zi * D + c] - Z[(long)zj * D + c]) / ls[c];
             r2 += t * t;
         }
         v = sf2 * exp(-0.5 * r2);

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
     const double sf2 = a.sf2[d];
     double mu = 0.0;
 
+    const int off = a.Np - a.N;
     const int rows_per = (a.Np + a.nsplit - 1) / a.nsplit;
     const int i_beg = sp * rows_per;
     const int i_end = min(a.Np, i_beg + rows_per);
@@ -48,17 +49,18 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
         __syncthreads();
         {
             const int r = threadIdx.x;
-            const int i = i0 + r;
-            const bool ok = (r < nrow) && (i < a.N);
+            const int i = i0 + r - off;       // training index (front padding)
+            const bool ok = (r < nrow) && (i >= 0);
 #pragma unroll
             for (int j = 0; j < DT; ++j)
                 zs[r * DT + j] = (ok && j < a.D) ? a.Z[(long)i * a.D + j] * inv_l[j] : 0.0;
-            al[r] = ok ? a.alpha[(long)d * a.Np + i] : 0.0;
+            al[r] = ok ? a.alpha[(long)d * a.Np + i0 + r] : 0.0;
         }
         __syncthreads();
-        const int nvalid = max(0, min(nrow, a.N - i0));
+        const int rpad = min(nrow, max(0, off - i0));     // leading padding rows of this tile
         if (inpad) {
-            for (int r = 0; r < nvalid; ++r) {
+            for (int r = 0; r < rpad; ++r) ks_col[(long)(i0 + r) * a.Tp] = 0.0;
+            for (int r = rpad; r < nrow; ++r) {
                 double diff[DT];
                 double r2 = 0.0;
 #pragma unroll
@@ -73,7 +75,6 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
 #pragma unroll
                 for (int j = 0; j < DT; ++j) g[j] = fma(-w, diff[j], g[j]);
             }
-            for (int r = nvalid; r < nrow; ++r) ks_col[(long)(i0 + r) * a.Tp] = 0.0;
         }
     }
     if (inpad) {
@@ -112,7 +113,7 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s) {
 __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict__ Wt,
                                                         const double* __restrict__ Ks,
                                                         double* __restrict__ part, int Np, long Tp,
-                                                        int nrb, int ntq, int group) {
+                                                        int nrb, int ntq, int group, int k_beg) {
     __shared__ double smem[srt::SMEM_DOUBLES];
     const long per_d = (long)nrb * ntq;
     const int ngrp = (ntq + group - 1) / group;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
 
     srt::Acc acc;
     acc.zero();
-    srt::mainloop_tn(A, Np, B, Tp, 0, (rb + 1) * srt::BM, smem, acc);
+    srt::mainloop_tn(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
     }
 }
 
-int sr_launch_var(const double* Wt, const double* Ks, double* part, int Np, long Tp, int n_out,
+int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                   int group, hipStream_t s) {
+    const int k_beg = ((Np - N) / srt::BK) * srt::BK;     // rows k < Np-N are padding: K* is zero there
     const int nrb = Np / srt::BM;
     const int ntq = (int)(Tp / srt::BN);
     if (group < 1) group = 1;
@@ -171,7 +173,7 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int Np, long
     const long blocks = (long)n_out * ngrp * nrb * group;
     SR_CHECK(blocks < 2147483647L, SR_EINVAL, "var: grid too large (%ld blocks)", blocks);
     hipLaunchKernelGGL(sr_var_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
-                       nrb, ntq, group);
+                       nrb, ntq, group, k_beg);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
