@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--workload", default="c2p", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=0, help="override T per GPU")
     ap.add_argument("--var-group", type=int, default=0)
+    ap.add_argument("--var-variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -133,6 +134,8 @@ def main():
         bcast_s = time.time() - t0
     if args.var_group:
         gp.set_var_group(args.var_group)
+    if args.var_variant >= 0:
+        gp.set_var_variant(args.var_variant)
 
     # ---- this rank's shard of the (world * T) query states, resident in HBM ------------------------
     q = workload.make_queries(seed + 7919 + 104729 * rank, n_s, n_u, T) if rank else prob

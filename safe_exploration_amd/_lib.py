@@ -57,6 +57,7 @@ SIGNATURES = {
     "sr_safety_distance": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _D, _P, _P]),
     "sr_gp_set_chunk": (_I, [_H, _L]),
     "sr_gp_set_var_group": (_I, [_H, _I]),
+    "sr_gp_set_var_variant": (_I, [_H, _I]),
     "sr_test_gemm_tn": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_prof_enable": (_I, [_H, _I]),
     "sr_prof_reset": (_I, [_H]),

@@ -27,6 +27,7 @@ struct sr_gp {
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr;
     int var_group = 32;
+    int var_variant = 1;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles (default)
     sr_prof prof;
 };
 
@@ -331,7 +332,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     }
     {
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, s));
+        SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, h->var_variant, s));
     }
     sr_final_args fa;
     fa.mu_part = h->mu_part; fa.jac_part = h->jac_part; fa.var_part = h->var_part; fa.sf2 = h->sf2;
@@ -518,6 +519,12 @@ extern "C" int sr_gp_set_chunk(sr_gp_t h, long chunk) {
 extern "C" int sr_gp_set_var_group(sr_gp_t h, int group) {
     SR_CHECK(h != nullptr && group >= 1, SR_EINVAL, "sr_gp_set_var_group: bad argument");
     h->var_group = group;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_set_var_variant(sr_gp_t h, int variant) {
+    SR_CHECK(h != nullptr && (variant == 0 || variant == 1), SR_EINVAL, "sr_gp_set_var_variant: bad argument");
+    h->var_variant = variant;
     return SR_OK;
 }
 

@@ -129,7 +129,7 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 
 // part[d][rb][t] = sum_{i in row block rb} ( sum_k Wt[d][k][i] Ks[d][k][t] )^2
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
-                  int group, hipStream_t s);
+                  int group, int variant, hipStream_t s);
 
 struct sr_final_args {
     const double* mu_part; const double* jac_part; const double* var_part; const double* sf2;

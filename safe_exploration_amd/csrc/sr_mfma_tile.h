@@ -125,4 +125,69 @@ __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long l
 #undef SRT_SSTORE
 }
 
+// Same contract as mainloop_tn, but global->LDS goes through the LDS-DMA path
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass).  Each wavefront-instruction moves one
+// 1 KiB tile row (lane-linear destination == our row layout; the padding sits between rows).
+// Two LDS stages; the barrier at the top of a k-step carries the vmcnt(0) that retires the DMA of the
+// tile about to be read, and frees the other stage for the next DMA.
+#define SRT_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SRT_AS3(p) ((__attribute__((address_space(3))) void*)(p))
+template <int BKT>
+__device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, long lda,
+                                                 const double* __restrict__ B, long ldb,
+                                                 int k_beg, int k_end, double* smem, Acc& acc) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    double* As = smem;
+    constexpr int STG = BKT * LDT;             // doubles per operand per stage
+    double* Bs = smem + 2 * STG;
+    if (k_beg >= k_end) return;
+
+    const double* ga = A + (long)wave * lda + 2 * lane;   // rows wave, wave+4, wave+8, wave+12
+    const double* gb = B + (long)wave * ldb + 2 * lane;
+    const int srow = wave * LDT;
+
+#define SRT_DMA(k0, buf)                                                                             \
+    do {                                                                                             \
+        const double* pa_ = ga + (long)(k0) * lda;                                                   \
+        const double* pb_ = gb + (long)(k0) * ldb;                                                   \
+        double* sa_ = As + (buf) * STG + srow;                                                       \
+        double* sb_ = Bs + (buf) * STG + srow;                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < BKT / 4; ++j_) {                                     \
+            __builtin_amdgcn_global_load_lds(SRT_AS1(pa_ + 4 * j_ * lda), SRT_AS3(sa_ + 4 * j_ * LDT), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds(SRT_AS1(pb_ + 4 * j_ * ldb), SRT_AS3(sb_ + 4 * j_ * LDT), 16, 0, 0); \
+        }                                                                                            \
+    } while (0)
+
+    SRT_DMA(k_beg, 0);
+    const int fa = (lane >> 4) * LDT + wm * 64 + (lane & 15);
+    const int fb = (lane >> 4) * LDT + wn * 64 + (lane & 15);
+    int buf = 0;
+    for (int k0 = k_beg; k0 < k_end; k0 += BKT) {
+        __syncthreads();                       // vmcnt(0) + s_barrier: tile k0 landed, other stage is free
+        if (k0 + BKT < k_end) SRT_DMA(k0 + BKT, buf ^ 1);
+        const double* as = As + buf * STG + fa;
+        const double* bs = Bs + buf * STG + fb;
+#pragma unroll
+        for (int kk = 0; kk < BKT / 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = as[kk * 4 * LDT + i * 16];
+                bf[i] = bs[kk * 4 * LDT + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    __syncthreads();                           // callers reuse smem after the main loop
+#undef SRT_DMA
+}
+
 }  // namespace srt

@@ -110,6 +110,7 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s) {
 // fastest each XCD's L2 sees group/8 query tiles x all row blocks: W tiles are shared between the
 // query tiles, K* tiles between the row blocks.
 // ------------------------------------------------------------------------------------------------
+template <int VARIANT>
 __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict__ Wt,
                                                         const double* __restrict__ Ks,
                                                         double* __restrict__ part, int Np, long Tp,
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
 
     srt::Acc acc;
     acc.zero();
-    srt::mainloop_tn(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+    if (VARIANT == 1) srt::mainloop_tn_glds<16>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+    else srt::mainloop_tn(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
 }
 
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
-                  int group, hipStream_t s) {
+                  int group, int variant, hipStream_t s) {
     const int k_beg = ((Np - N) / srt::BK) * srt::BK;     // rows k < Np-N are padding: K* is zero there
     const int nrb = Np / srt::BM;
     const int ntq = (int)(Tp / srt::BN);
@@ -172,8 +174,12 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
     const int ngrp = (ntq + group - 1) / group;
     const long blocks = (long)n_out * ngrp * nrb * group;
     SR_CHECK(blocks < 2147483647L, SR_EINVAL, "var: grid too large (%ld blocks)", blocks);
-    hipLaunchKernelGGL(sr_var_kernel, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
-                       nrb, ntq, group, k_beg);
+    if (variant == 1)
+        hipLaunchKernelGGL(sr_var_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
+                           nrb, ntq, group, k_beg);
+    else
+        hipLaunchKernelGGL(sr_var_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
+                           nrb, ntq, group, k_beg);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

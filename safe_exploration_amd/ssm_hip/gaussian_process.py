@@ -371,6 +371,10 @@ class SimpleGPModel(StateSpaceModel):
         self._need_trained()
         check(lib.sr_gp_set_var_group(self._handle.h, int(group)))
 
+    def set_var_variant(self, variant):
+        self._need_trained()
+        check(lib.sr_gp_set_var_variant(self._handle.h, int(variant)))
+
     def prof_enable(self, on=True):
         self._need_trained()
         check(lib.sr_prof_enable(self._handle.h, 1 if on else 0))

@@ -287,3 +287,20 @@ def test_full_size_properties():
     _, q1c = reach.onestep_reachability_batch(syn["p"][:2048], gp, syn["k_ff"][:2048], l, l, syn["Q"][:2048],
                                               syn["k_fb"][:2048], 3.0)
     assert np.all(np.trace(q1c, axis1=1, axis2=2) > np.trace(q1[:2048], axis1=1, axis2=2))
+
+
+def test_var_kernel_variants_agree_bitwise():
+    """register-staged and LDS-DMA tile staging are the same arithmetic in the same order."""
+    syn = orc.make_synthetic(91, 700, 2, 1, 3000)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    gp.set_var_variant(0)
+    mu0, var0 = gp.predict(x)
+    for variant in (1,):
+        gp.set_var_variant(variant)
+        mu1, var1 = gp.predict(x)
+        np.testing.assert_array_equal(var0, var1)
+        np.testing.assert_array_equal(mu0, mu1)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
+    np.testing.assert_allclose(var1, rvar, rtol=0, atol=1e-9)
