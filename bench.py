@@ -34,13 +34,15 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (v_mfma_f64_16x16x4_f64) d
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (description, seed, N, n_s, n_u, T per GPU, H)
+    # name: (description, seed, N, n_s, n_u, T per GPU, H, signal variance, prior a = a_scale * I)
     "c2p": ("C2' pendulum n_s=2 n_u=1 D=3, N=5000 train pts, T=65536 query states/GPU/step, "
-            "one-step ellipsoid branch, fp64", 5, 5000, 2, 1, 65536, 1),
+            "one-step ellipsoid branch, fp64", 5, 5000, 2, 1, 65536, 1, 1.0, 1.0),
     "c2": ("C2 pendulum n_s=2 n_u=1 D=3, N=2000 train pts, T=65536 query states/GPU/step, "
-           "one-step ellipsoid branch, fp64", 2, 2000, 2, 1, 65536, 1),
+           "one-step ellipsoid branch, fp64", 2, 2000, 2, 1, 65536, 1, 1.0, 1.0),
+    # the 15-step chain is only numerically meaningful for a contracting prior model and a GP that
+    # models a small residual (sigma_f^2 = 0.01, a = 0.5 I), as in the golden chain fixtures
     "c3": ("C3 cart-pole n_s=4 n_u=1 D=5, N=5000 train pts, T=65536 rollouts/GPU/step, H=15 multi-step "
-           "(evals = T*H), fp64", 3, 5000, 4, 1, 65536, 15),
+           "(evals = T*H), sigma_f^2=0.01, prior a=0.5 I, fp64", 3, 5000, 4, 1, 65536, 15, 0.01, 0.5),
 }
 L_CONST = {2: np.array([0.05, 0.02]), 4: np.array([0.05] * 4)}   # environments.py:317-318, 702-704
 C_SAFETY = 2.0                                                     # defaultconfig_exploration.py:35
@@ -110,10 +112,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    desc, seed, N, n_s, n_u, T, H = WORKLOADS[args.workload]
+    desc, seed, N, n_s, n_u, T, H, sf2, a_scale = WORKLOADS[args.workload]
     if args.queries:
         T = args.queries
-    prob = workload.make_problem(seed, N, n_s, n_u, T)     # model part identical on every rank
+    prob = workload.make_problem(seed, N, n_s, n_u, T, sf2=sf2)     # model part identical on every rank
+    a_lin, b_lin = a_scale * np.eye(n_s), np.zeros((n_s, n_u))
     l_mu = l_sigma = L_CONST[n_s]
 
     # ---- model: rank 0 factorises, the others receive alpha / U^-1 over RCCL --------------------
@@ -146,8 +149,8 @@ def main():
 
     def step():
         if H == 1:
-            return reach.onestep_reachability_batch(tp, gp, tkff, l_mu, l_sigma, tq, tkfb, C_SAFETY)
-        return reach.multistep_reachability_batch(tp0, gp, tkfbH, tkffH, l_mu, l_sigma, None, C_SAFETY)
+            return reach.onestep_reachability_batch(tp, gp, tkff, l_mu, l_sigma, tq, tkfb, C_SAFETY, a_lin, b_lin)
+        return reach.multistep_reachability_batch(tp0, gp, tkfbH, tkffH, l_mu, l_sigma, None, C_SAFETY, a_lin, b_lin)
 
     for _ in range(args.warmup):
         step()

@@ -83,6 +83,13 @@ int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream);
 int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, double* var, double* jac,
                   void* stream);
 
+/* ---- single query with second-order outputs (the CasADi Jacobian callback) ------------------------
+ * replaces: linearize_predict(states 1xn, actions 1xm, jacobians=True)  state_space_models.py:106-138,
+ *           consumed at :402-415; reference implementation ssm_pytorch/gaussian_process.py:333-385.
+ * x D -> mu n_out, var n_out, jac_mu n_out x D, jac_var n_out x D (d var/dx), hess_mu n_out x D x D. */
+int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* var, double* jac_mu,
+                    double* jac_var, double* hess_mu, void* stream);
+
 /* ---- one-step reachability, batched over T queries ------------------------------------------
  * replaces: gp_reachability.onestep_reachability  gp_reachability.py:19-156
  *   (+ utils.compute_remainder_overapproximations utils.py:108-144,

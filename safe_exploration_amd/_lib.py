@@ -49,6 +49,7 @@ SIGNATURES = {
     "sr_gp_import": (_I, [_H, _P, _P, _P]),
     "sr_gp_inv_k": (_I, [_H, _I, _P, _P]),
     "sr_gp_predict": (_I, [_H, _P, _L, _P, _P, _P, _P]),
+    "sr_gp_linearize": (_I, [_H, _P, _P, _P, _P, _P, _P, _P]),
     "sr_onestep_reach": (_I, [_H, _L, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P]),
     "sr_multistep_reach": (_I, [_H, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P]),
     "sr_ellipsoid_step": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P,

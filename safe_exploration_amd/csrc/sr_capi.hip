@@ -26,6 +26,7 @@ struct sr_gp {
     int ws_nsplit = 0;
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr;
+    double *lin_v = nullptr, *lin_g = nullptr;     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 32;
     int var_variant = 1;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles (default)
     sr_prof prof;
@@ -88,7 +89,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
-    dev_free(h->alpha); dev_free(h->Wt);
+    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->lin_v); dev_free(h->lin_g);
     free_ws(h);
     h->prof.destroy();
     delete h;
@@ -360,6 +361,31 @@ extern "C" int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, do
                        var + t0 * h->n_out, jac ? jac + t0 * h->n_out * h->D : nullptr, s));
     }
     return SR_OK;
+}
+
+extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* var, double* jac_mu,
+                               double* jac_var, double* hess_mu, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_linearize: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_linearize: model not factorized");
+    SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    if (!h->lin_v) SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np));
+    if (!h->lin_g) SR_TRY(dev_alloc(&h->lin_g, (size_t)h->n_out * h->Np));
+    SR_TRY(gp_pass(h, 1, x, h->D, h->D, nullptr, 0, 0, mu, var, jac_mu, s));    // leaves K*(:,0) in the workspace
+    const long Tp = srt::BN;
+    for (int d = 0; d < h->n_out; ++d) {
+        const double* Wt = h->Wt + (size_t)d * h->Np * h->Np;
+        const double* ks = h->Ks + (size_t)d * h->Np * Tp;
+        SR_TRY(sr_launch_trmv_t(Wt, h->Np, ks, Tp, h->lin_v + (size_t)d * h->Np, h->Np, s));      // v = U^-T k*
+        SR_TRY(sr_launch_trmv(Wt, h->Np, h->lin_v + (size_t)d * h->Np, h->lin_g + (size_t)d * h->Np,
+                              h->Np, 0, s));                                                       // g = U^-1 v
+    }
+    sr_lin_args la;
+    la.Z = h->Z; la.alpha = h->alpha; la.ls = h->ls; la.Ks = h->Ks; la.g = h->lin_g; la.x = x;
+    la.jac_var = jac_var; la.hess_mu = hess_mu;
+    la.N = h->N; la.Np = h->Np; la.D = h->D; la.n_out = h->n_out; la.Tp = Tp;
+    return sr_launch_linearize(la, s);
 }
 
 static int check_reach_dims(const sr_gp* h, int* n_s, int* n_u) {

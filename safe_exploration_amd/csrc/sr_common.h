@@ -158,3 +158,13 @@ int sr_launch_remainder(long T, int n_s, int n_u, const double* q, const double*
                         hipStream_t s);
 int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, const double* h_mat,
                      const double* h_vec, double c, double* d, hipStream_t s);
+
+// ---- single-query second-order outputs (sr_linearize.hip) --------------------------------------
+struct sr_lin_args {
+    const double* Z; const double* alpha; const double* ls; const double* Ks; const double* g;
+    const double* x;                 // D query coordinates
+    double* jac_var; double* hess_mu;   // n_out x D, n_out x D x D
+    int N, Np, D, n_out; long Tp;
+};
+int sr_launch_trmv_t(const double* M, long ld, const double* x, long xs, double* y, int n, hipStream_t s);
+int sr_launch_linearize(const sr_lin_args& a, hipStream_t s);

@@ -1,0 +1,112 @@
+// sr_linearize.hip -- second-order outputs of the single-query CasADi boundary:
+// d var/dx and the Hessian of mu, the extra outputs of linearize_predict(..., jacobians=True)
+//   contract: /root/reference/safe_exploration/state_space_models.py:106-138, consumed at :402-415
+//   reference implementation (fp32, autograd): ssm_pytorch/gaussian_process.py:333-385
+// RBF closed forms (g = K_y^-1 k* = U^-1 (U^-T k*)):
+//   d var/dx_j      = -2 sum_i g_i k*_i (z_ij - x_j) / l_j^2
+//   d2 mu/dx_j dx_k = sum_i alpha_i k*_i [ (z_ij-x_j)(z_ik-x_k)/(l_j^2 l_k^2) - delta_jk / l_j^2 ]
+// Latency path (T = 1): three small launches per output, HBM-bound on the 2 x N^2/2 factor reads.
+#include "sr_common.h"
+
+// y[i] = sum_{k <= i} M[k][i] * x[k * xs]   (M upper triangular, row-major): v = U^-T k*
+__global__ __launch_bounds__(256) void sr_trmv_t_kernel(const double* __restrict__ M, long ld,
+                                                        const double* __restrict__ x, long xs,
+                                                        double* __restrict__ y, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 1 <= i; k += 2) {
+        s0 = fma(M[(long)k * ld + i], x[(long)k * xs], s0);
+        s1 = fma(M[(long)(k + 1) * ld + i], x[(long)(k + 1) * xs], s1);
+    }
+    if (k <= i) s0 = fma(M[(long)k * ld + i], x[(long)k * xs], s0);
+    y[i] = s0 + s1;
+}
+
+int sr_launch_trmv_t(const double* M, long ld, const double* x, long xs, double* y, int n,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(sr_trmv_t_kernel, dim3((n + 255) / 256), dim3(256), 0, s, M, ld, x, xs, y, n);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void sr_linearize_kernel(sr_lin_args a) {
+    constexpr int NH = DT * (DT + 1) / 2;
+    constexpr int NACC = DT + NH + 1;
+    __shared__ double red[4][NACC];
+    const int d = blockIdx.x;
+    const int off = a.Np - a.N;
+    const double* ks = a.Ks + (long)d * a.Np * a.Tp;       // column t = 0, stride Tp
+    const double* g = a.g + (long)d * a.Np;
+    const double* al = a.alpha + (long)d * a.Np;
+    double il2[DT], x[DT], acc[NACC];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        const double l = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
+        il2[j] = (j < a.D) ? 1.0 / (l * l) : 0.0;
+        x[j] = (j < a.D) ? a.x[j] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
+    for (int i = threadIdx.x; i < a.N; i += 256) {
+        const double k = ks[(long)(i + off) * a.Tp];
+        const double gk = g[i + off] * k;
+        const double w = al[i + off] * k;
+        double df[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) df[j] = (j < a.D) ? (a.Z[(long)i * a.D + j] - x[j]) * il2[j] : 0.0;
+        int q = DT;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            acc[j] = fma(gk, df[j], acc[j]);
+#pragma unroll
+            for (int c = 0; c < DT; ++c)
+                if (c >= j) { acc[q] = fma(w * df[j], df[c], acc[q]); ++q; }
+        }
+        acc[NACC - 1] += w;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) {
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot[NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) tot[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+        int q = DT;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            if (j < a.D) a.jac_var[d * a.D + j] = -2.0 * tot[j];
+#pragma unroll
+            for (int c = 0; c < DT; ++c)
+                if (c >= j) {
+                    if (j < a.D && c < a.D) {
+                        double hv = tot[q];
+                        if (c == j) hv -= tot[NACC - 1] * il2[j];
+                        a.hess_mu[((long)d * a.D + j) * a.D + c] = hv;
+                        a.hess_mu[((long)d * a.D + c) * a.D + j] = hv;
+                    }
+                    ++q;
+                }
+        }
+    }
+}
+
+int sr_launch_linearize(const sr_lin_args& a, hipStream_t s) {
+    dim3 grid(a.n_out);
+#define SR_LIN_CASE(DT) hipLaunchKernelGGL(sr_linearize_kernel<DT>, grid, dim3(256), 0, s, a)
+    if (a.D <= 3) SR_LIN_CASE(3);
+    else if (a.D <= 5) SR_LIN_CASE(5);
+    else if (a.D <= 8) SR_LIN_CASE(8);
+    else if (a.D <= 12) SR_LIN_CASE(12);
+    else { sr_set_error("linearize: D=%d > %d", a.D, SR_MAX_D); return SR_EUNSUPPORTED; }
+#undef SR_LIN_CASE
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}

@@ -300,7 +300,7 @@ class SimpleGPModel(StateSpaceModel):
           * ``predict(x_new (T,D), quantiles=None, compute_gradients=False)``
             -> (T,n_s), (T,n_s)[, (T,n_s,D)]                   gaussian_process.py:546-568
           * ``predict(states (N,n), actions (N,m), jacobians=False, full_cov=False)``
-            -> mean (N,n), var (N,n)[, jac_mean (N,n,n+m)]     state_space_models.py:74-104
+            -> mean (N,n), var (N,n)[, jac_mean (N,n,n+m), jac_var (N,n,n+m)]   state_space_models.py:74-104
         """
         two = (len(args) >= 2 and hasattr(args[1], "shape") and np.ndim(args[1]) == 2) or "actions" in kwargs
         if two:
@@ -310,6 +310,8 @@ class SimpleGPModel(StateSpaceModel):
             full_cov = args[3] if len(args) > 3 else kwargs.pop("full_cov", False)
             if full_cov:
                 raise NotImplementedError("full covariance is not supported")
+            if jacobians:
+                return self.predict_with_jacobians(states, actions)
             as_t = B.is_tensor(states)
             if as_t:
                 x_new = torch.cat((states, actions), dim=1)
@@ -345,16 +347,82 @@ class SimpleGPModel(StateSpaceModel):
         mu, var, jac = self.predict_device(np.hstack((states, actions)), True)
         return B.to_numpy(mu).T, B.to_numpy(var).T, B.to_numpy(jac)[0]
 
+    def linearize_device(self, x):
+        """Single query x (D,) -> device tensors (mu (n,), var (n,), jac_mu (n,D), jac_var (n,D),
+        hess_mu (n,D,D)) through sr_gp_linearize."""
+        self._need_trained()
+        hd = self._handle
+        tx = B.as_dev(x, hd.device).reshape(-1)
+        if tx.numel() != hd.D:
+            raise ValueError("x must have {} entries".format(hd.D))
+        mu, var = B.empty((hd.n_out,), hd.device), B.empty((hd.n_out,), hd.device)
+        jm, jv = B.empty((hd.n_out, hd.D), hd.device), B.empty((hd.n_out, hd.D), hd.device)
+        hm = B.empty((hd.n_out, hd.D, hd.D), hd.device)
+        check(lib.sr_gp_linearize(hd.h, B.ptr(tx), B.ptr(mu), B.ptr(var), B.ptr(jm), B.ptr(jv), B.ptr(hm),
+                                  B.stream_ptr(hd.device)))
+        return mu, var, jm, jv, hm
+
     def linearize_predict(self, states, actions, jacobians=False, full_cov=False):
-        """Contract of state_space_models.py:106-138 for a single query:
-        (mu (n,1), var (n,1), jac_mu (n,D)).  ``jacobians=True`` (d var/dx, Hessian of mu) belongs
-        to the T=1 CasADi latency path, ranked "next"."""
+        """Contract of state_space_models.py:106-138 for a single query (what CasadiSSMEvaluator calls,
+        :297-303 and :402-415):
+          jacobians=False -> (mu (n,1), var (n,1), jac_mu (n,D))
+          jacobians=True  -> (mu (n,1), var (n,1), jac_mu (n,D), jac_var (n,D), hess_mu (n,D,D))
+        The outputs are cached for ``get_linearize_reverse``."""
         if full_cov:
             raise NotImplementedError("full covariance is not supported")
-        if jacobians:
-            raise NotImplementedError("second-order outputs of linearize_predict are not on the "
-                                      "batched hot path (ranked 'next')")
-        return self.__call__(states, actions)
+        states = np.asarray(states, dtype=np.float64)
+        actions = np.asarray(actions, dtype=np.float64)
+        N, _ = np.shape(states)
+        if not jacobians:
+            return self.__call__(states, actions)
+        if N > 1:
+            raise NotImplementedError("'linearize_predict' currently only allows for single inputs, "
+                                      "i.e. (1 x n) arrays, when computing jacobians.")
+        mu, var, jm, jv, hm = (B.to_numpy(t) for t in self.linearize_device(np.hstack((states, actions))[0]))
+        self._linearize_forward_cache = (jm, jv, hm)
+        return mu[:, None], var[:, None], jm, jv, hm
+
+    def predict_with_jacobians(self, states, actions):
+        """Base-class ``predict(states, actions, jacobians=True)`` (state_space_models.py:74-104):
+        (mean (N,n), var (N,n), jac_mean (N,n,D), jac_var (N,n,D)).  d var/dx needs K_y^-1 k* per
+        query, so this is the latency path looped over the N queries."""
+        x = np.hstack((np.asarray(states, dtype=np.float64), np.asarray(actions, dtype=np.float64)))
+        N = x.shape[0]
+        hd = self._handle
+        self._need_trained()
+        mean, var = np.empty((N, hd.n_out)), np.empty((N, hd.n_out))
+        jm, jv = np.empty((N, hd.n_out, hd.D)), np.empty((N, hd.n_out, hd.D))
+        for t in range(N):
+            o = [B.to_numpy(v) for v in self.linearize_device(x[t])]
+            mean[t], var[t], jm[t], jv[t] = o[0], o[1], o[2], o[3]
+        if N == 1:
+            self._forward_cache = (jm[0], jv[0])
+        return mean, var, jm, jv
+
+    def get_reverse(self, seed):
+        """v^T J for the stacked outputs [mu; var] of the last single-query
+        ``predict(states, actions, jacobians=True)`` (state_space_models.py:168-179);
+        returns (grad_state (n,), grad_action (m,))."""
+        if self._forward_cache is None:
+            raise RuntimeError("get_reverse needs a preceding single-query predict(..., jacobians=True)")
+        jm, jv = self._forward_cache
+        n = self.n_s_out
+        seed = np.asarray(seed, dtype=np.float64).reshape(-1)
+        grad = seed[:n].dot(jm) + seed[n:2 * n].dot(jv)
+        return grad[:self.n_s_in], grad[self.n_s_in:]
+
+    def get_linearize_reverse(self, seed):
+        """v^T J for the stacked outputs [mu; var; vec(jac_mu)] of the last
+        ``linearize_predict(..., jacobians=True)`` (state_space_models.py:181-192; seed length
+        2n + n(n+m), jac_mu flattened row-major like ssm_pytorch/gaussian_process.py:372);
+        returns (grad_state (n,1), grad_action (m,1))."""
+        if self._linearize_forward_cache is None:
+            raise RuntimeError("get_linearize_reverse needs a preceding linearize_predict(..., jacobians=True)")
+        jm, jv, hm = self._linearize_forward_cache
+        n, D = jm.shape
+        seed = np.asarray(seed, dtype=np.float64).reshape(-1)
+        grad = seed[:n].dot(jm) + seed[n:2 * n].dot(jv) + np.einsum('ij,ijk->k', seed[2 * n:].reshape(n, D), hm)
+        return grad[:self.n_s_in, None], grad[self.n_s_in:, None]
 
     def sample_from_gp(self, inp, size=10):
         raise NotImplementedError("posterior sampling is outside the MI355X hot path")

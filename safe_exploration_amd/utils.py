@@ -53,6 +53,12 @@ def array_of_vec_to_array_of_mat(array_of_vec, n, m):
     return np.reshape(array_of_vec, (-1, n, m))
 
 
+def reshape_derivatives_3d_to_2d(derivative_3d):
+    """(r, s, n_in) derivative tensor -> (r*s, n_in), the layout CasADi callbacks need (utils.py:357-380)."""
+    r, s, n_in = np.shape(derivative_3d)
+    return np.reshape(derivative_3d, (r * s, n_in))
+
+
 def print_ellipsoid(p_center, q_shape, text="ellipsoid", visualize=False):
     print("\n")
     print("===== {} =====".format(text))

@@ -145,3 +145,10 @@ def test_workload_generator_shapes():
     r = workload.random_rollout_controls(3, 8, 15, 4, 1)
     assert r["k_fb"].shape == (8, 14, 1, 4) and r["k_ff"].shape == (8, 15, 1) and r["p0"].shape == (8, 4)
     assert abs(np.std(r["k_fb"]) - 0.1) < 0.02       # uncertainty_propagation_runner.py:32-33
+
+
+def test_reshape_derivatives():
+    from safe_exploration_amd import utils
+    d3 = np.arange(2 * 3 * 4, dtype=float).reshape(2, 3, 4)
+    d2 = utils.reshape_derivatives_3d_to_2d(d3)
+    assert d2.shape == (6, 4) and d2[4, 1] == d3[1, 1, 1]
