@@ -38,6 +38,7 @@ typedef struct sr_gp* sr_gp_t;
 #define SR_K_VAR       4   /* triangular fp64-MFMA contraction |W k*|^2 (dominant)     */
 #define SR_K_FINAL     5
 #define SR_K_ELL       6   /* ellipsoid propagate/sum                                  */
+#define SR_K_TRINV     7   /* GEMMs of the blocked triangular inversion W = U^-T            */
 #define SR_K_COUNT     8
 
 int         sr_version(void);

@@ -144,17 +144,16 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_TRY(ensure_wt(h));
     const int Np = h->Np, nb = Np / SR_NB;
     const size_t NN = (size_t)Np * Np;
-    double *U = nullptr, *W = nullptr, *tmp = nullptr, *v = nullptr;
+    double *U = nullptr, *W = nullptr, *v = nullptr;
     int* info_dev = nullptr;
     std::vector<double> sf2(h->n_out), noise(h->n_out);
     int rc = SR_OK;
-    auto cleanup = [&]() { dev_free(U); dev_free(W); dev_free(tmp); dev_free(v); dev_free(info_dev); };
+    auto cleanup = [&]() { dev_free(U); dev_free(W); dev_free(v); dev_free(info_dev); };
 #define SR_F(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(); return rc; } } while (0)
 #define SR_FH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); return SR_EHIP; } } while (0)
     SR_F(dev_alloc(&U, NN));
     SR_F(dev_alloc(&W, NN));
-    SR_F(dev_alloc(&tmp, (size_t)SR_NB * Np));
     SR_F(dev_alloc(&v, (size_t)Np));
     SR_F(dev_alloc(&info_dev, (size_t)h->n_out));
     SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s));
@@ -170,34 +169,72 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             sr_prof_scope ps(&h->prof, SR_K_GRAM, s);
             SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, s));
         }
-        // --- Cholesky, block row kb
-        for (int kb = 0; kb < nb; ++kb) {
-            const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
-            {
-                sr_prof_scope ps(&h->prof, SR_K_POTRF, s);
-                SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, s));
+        // --- Cholesky K = U^T U, right-looking, two-level blocking: 128-row blocks inside panels of
+        // SR_PANEL blocks.  Inside a panel a factored block row updates only the panel's remaining
+        // rows; everything below the panel is updated once per panel with K = SR_PANEL*128, which
+        // divides the read-modify-write traffic of the trailing matrix by SR_PANEL.
+        for (int p0 = 0; p0 < nb; p0 += SR_PANEL) {
+            const int p1 = std::min(nb, p0 + SR_PANEL);
+            for (int kb = p0; kb < p1; ++kb) {
+                const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_POTRF, s);
+                    SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, s));
+                }
+                const int ncols = Np - (kb + 1) * SR_NB;
+                if (ncols > 0) {
+                    double* Urow = U + dg + SR_NB;                // U[kb rows][cols right of the block]
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, s);
+                    // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major) -- in place
+                    SR_F(sr_launch_gemm_tn(Wt + dg, Np, Urow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, s));
+                    const int mrows = (p1 - kb - 1) * SR_NB;      // remaining rows of this panel
+                    if (mrows > 0)
+                        SR_F(sr_launch_gemm_tn(Urow, Np, Urow, Np, U + dg + (size_t)SR_NB * Np + SR_NB, Np,
+                                               mrows, ncols, SR_NB, -1.0, 1.0, 1, s));
+                }
             }
-            const int ncols = Np - (kb + 1) * SR_NB;
-            if (ncols > 0) {
-                double* Urow = U + dg + SR_NB;                    // U[kb rows][cols right of the block]
+            const int rest = Np - p1 * SR_NB;
+            if (rest > 0) {
                 sr_prof_scope ps(&h->prof, SR_K_GEMM, s);
-                // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major) -- in place
-                SR_F(sr_launch_gemm_tn(Wt + dg, Np, Urow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, s));
-                // trailing update A_ij -= U_k,i^T U_k,j  (upper block triangle)
-                SR_F(sr_launch_gemm_tn(Urow, Np, Urow, Np, U + dg + (size_t)SR_NB * Np + SR_NB, Np,
-                                       ncols, ncols, SR_NB, -1.0, 1.0, 1, s));
+                const double* Upan = U + (size_t)p0 * SR_NB * Np + (size_t)p1 * SR_NB;
+                SR_F(sr_launch_gemm_tn(Upan, Np, Upan, Np, U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB, Np,
+                                       rest, rest, (p1 - p0) * SR_NB, -1.0, 1.0, 1, s));
             }
         }
-        // --- W = U^-T by block rows: W_i,0:i = -U_ii^-T (sum_{k<i} U_k,i^T W_k,0:i)
-        for (int i = 1; i < nb; ++i) {
-            sr_prof_scope ps(&h->prof, SR_K_GEMM, s);
-            const int ncol = i * SR_NB;
-            SR_F(sr_launch_gemm_tn(U + (size_t)i * SR_NB, Np, W, Np, tmp, Np, SR_NB, ncol, ncol, 1.0, 0.0, 2, s));
-            const size_t dg = (size_t)i * SR_NB * Np + (size_t)i * SR_NB;
-            SR_F(sr_launch_gemm_tn(Wt + dg, Np, tmp, Np, W + (size_t)i * SR_NB * Np, Np, SR_NB, ncol,
-                                   SR_NB, -1.0, 0.0, 0, s));
+        // --- W = U^-T (lower) and Wt = U^-1 (upper) by recursive halving of the block range:
+        //   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22],  L21 = U12^T.
+        // Both products are TN GEMMs over large ranges (good occupancy at every level above the leaves):
+        //   Y   = U12^T W11      (A = U12 k-major, B = W11 block-lower-triangular, mode 2)  -> parked in the
+        //                         unused strict lower triangle of U, exactly where W21 will live in W
+        //   W21 = -Wt22^T Y      (A = Wt22 = U22^-1 upper-triangular, mode 3)
+        //   Wt12 = W21^T         (keeps U^-1 complete for the next level)
+        // The diagonal blocks of W / Wt were written by sr_potrf_diag_kernel.
+        {
+            struct Rng { int lo, hi; bool expanded; };
+            std::vector<Rng> stack;
+            stack.push_back({0, nb, false});
+            while (!stack.empty()) {
+                Rng r = stack.back();
+                stack.pop_back();
+                if (r.hi - r.lo <= 1) continue;
+                const int mid = (r.lo + r.hi) / 2;
+                if (!r.expanded) {
+                    stack.push_back({r.lo, r.hi, true});       // combine after both halves
+                    stack.push_back({r.lo, mid, false});
+                    stack.push_back({mid, r.hi, false});
+                    continue;
+                }
+                const int n1 = (mid - r.lo) * SR_NB, n2 = (r.hi - mid) * SR_NB;
+                const size_t o11 = (size_t)r.lo * SR_NB * Np + (size_t)r.lo * SR_NB;
+                const size_t o12 = (size_t)r.lo * SR_NB * Np + (size_t)mid * SR_NB;
+                const size_t o21 = (size_t)mid * SR_NB * Np + (size_t)r.lo * SR_NB;
+                const size_t o22 = (size_t)mid * SR_NB * Np + (size_t)mid * SR_NB;
+                sr_prof_scope ps(&h->prof, SR_K_TRINV, s);
+                SR_F(sr_launch_gemm_tn(U + o12, Np, W + o11, Np, U + o21, Np, n2, n1, n1, 1.0, 0.0, 2, s));
+                SR_F(sr_launch_gemm_tn(Wt + o22, Np, U + o21, Np, W + o21, Np, n2, n1, n2, -1.0, 0.0, 3, s));
+                SR_F(sr_launch_transpose_rect(W + o21, Np, Wt + o12, Np, n2, n1, s));
+            }
         }
-        SR_F(sr_launch_transpose(W, Wt, Np, s));
         // alpha = Wt (W y)
         SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d * Np, v, Np, 1, s));
         SR_F(sr_launch_trmv(Wt, Np, v, h->alpha + (size_t)d * Np, Np, 0, s));

@@ -8,6 +8,7 @@
 #include "../../include/safereach.h"
 
 #define SR_NB 128          // factor block size == GEMM tile edge; Np is a multiple of it
+#define SR_PANEL 4         // factor blocks per Cholesky panel (deferred trailing update with K = 512)
 #define SR_MAX_NS 8
 #define SR_MAX_NU 4
 #define SR_MAX_D 12
@@ -95,6 +96,7 @@ struct sr_prof_scope {
 // M, N multiples of 128; K multiple of 16.
 //   mode 0: all tiles.  mode 1: only tiles with n0 >= m0 (upper block triangle).
 //   mode 2: B block-lower-triangular (B[k][n] == 0 for k < n0): per tile k starts at n0.
+//   mode 3: A block-upper-triangular (A[k][m] == 0 for k >= m0 + 128): per tile k ends at m0 + 128.
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                       int M, int N, int K, double alpha, double beta, int mode, hipStream_t s);
 
@@ -107,6 +109,8 @@ int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, 
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
                          int kb, int* info_dev, hipStream_t s);
 int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s);
+int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd, int rows, int cols,
+                             hipStream_t s);
 // y[r] = sum_c M[r][c] x[c], c in [0..r] (lower=1) or [r..n) (lower=0)
 int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
                    hipStream_t s);

@@ -16,10 +16,11 @@ __global__ __launch_bounds__(256, 2) void sr_gemm_tn_kernel(
     const int n0 = blockIdx.x * srt::BN;
     if (mode == 1 && n0 < m0) return;
     const int k_beg = (mode == 2) ? n0 : 0;
+    const int k_end = (mode == 3) ? min(K, m0 + srt::BM) : K;
 
     srt::Acc acc;
     acc.zero();
-    srt::mainloop_tn(A + m0, lda, B + n0, ldb, k_beg, K, smem, acc);
+    srt::mainloop_tn(A + m0, lda, B + n0, ldb, k_beg, k_end, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -122,8 +123,21 @@ __global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long l
         __syncthreads();
         if (c_own > j) {
             const double ujc = S[j * SR_PD_LD + c_own];
-            for (int r = j + 1 + half; r <= c_own; r += 2)
-                S[r * SR_PD_LD + c_own] -= S[j * SR_PD_LD + r] * ujc;
+            int r = j + 1 + half;
+            // 4 independent read-modify-writes in flight (the LDS round trips do not alias: row j is
+            // read-only here, rows r > j are written by exactly one thread each)
+            for (; r + 6 <= c_own; r += 8) {
+                const double a0 = S[j * SR_PD_LD + r], a1 = S[j * SR_PD_LD + r + 2];
+                const double a2 = S[j * SR_PD_LD + r + 4], a3 = S[j * SR_PD_LD + r + 6];
+                double* p0 = &S[r * SR_PD_LD + c_own];
+                const double b0 = p0[0], b1 = p0[2 * SR_PD_LD], b2 = p0[4 * SR_PD_LD], b3 = p0[6 * SR_PD_LD];
+                p0[0] = fma(-a0, ujc, b0);
+                p0[2 * SR_PD_LD] = fma(-a1, ujc, b1);
+                p0[4 * SR_PD_LD] = fma(-a2, ujc, b2);
+                p0[6 * SR_PD_LD] = fma(-a3, ujc, b3);
+            }
+            for (; r <= c_own; r += 2)
+                S[r * SR_PD_LD + c_own] = fma(-S[j * SR_PD_LD + r], ujc, S[r * SR_PD_LD + c_own]);
         }
         __syncthreads();
     }
@@ -155,8 +169,16 @@ __global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long l
         const double invjj = 1.0 / S[j * SR_PD_LD + j];
         __syncthreads();
         if (tid < j) {
-            double s = 0.0;
-            for (int k = tid; k < j; ++k) s += S[tid * SR_PD_LD + k] * tmp[k];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = tid;
+            for (; k + 3 < j; k += 4) {
+                s0 = fma(S[tid * SR_PD_LD + k], tmp[k], s0);
+                s1 = fma(S[tid * SR_PD_LD + k + 1], tmp[k + 1], s1);
+                s2 = fma(S[tid * SR_PD_LD + k + 2], tmp[k + 2], s2);
+                s3 = fma(S[tid * SR_PD_LD + k + 3], tmp[k + 3], s3);
+            }
+            for (; k < j; ++k) s0 = fma(S[tid * SR_PD_LD + k], tmp[k], s0);
+            const double s = (s0 + s1) + (s2 + s3);
             S[tid * SR_PD_LD + j] = -s * invjj;
         } else if (tid == j) {
             S[j * SR_PD_LD + j] = invjj;
@@ -181,21 +203,28 @@ int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, l
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sr_transpose_kernel(const double* __restrict__ src,
-                                                           double* __restrict__ dst, int n) {
+// dst[c][r] = src[r][c] for an (rows x cols) block; rows, cols multiples of 32
+__global__ __launch_bounds__(256) void sr_transpose_kernel(const double* __restrict__ src, long lds_,
+                                                           double* __restrict__ dst, long ldd) {
     __shared__ double t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int r = ty; r < 32; r += 8) t[r][tx] = src[(long)(by + r) * n + bx + tx];
+    for (int r = ty; r < 32; r += 8) t[r][tx] = src[(long)(by + r) * lds_ + bx + tx];
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) dst[(long)(bx + r) * n + by + tx] = t[tx][r];
+    for (int r = ty; r < 32; r += 8) dst[(long)(bx + r) * ldd + by + tx] = t[tx][r];
+}
+
+int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd, int rows, int cols,
+                             hipStream_t s) {
+    SR_CHECK(rows % 32 == 0 && cols % 32 == 0 && rows > 0 && cols > 0, SR_EINVAL,
+             "transpose: %d x %d not multiples of 32", rows, cols);
+    hipLaunchKernelGGL(sr_transpose_kernel, dim3(cols / 32, rows / 32), dim3(256), 0, s, src, lds_, dst, ldd);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
 }
 
 int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s) {
-    SR_CHECK(n % 32 == 0, SR_EINVAL, "transpose: n=%d not a multiple of 32", n);
-    hipLaunchKernelGGL(sr_transpose_kernel, dim3(n / 32, n / 32), dim3(256), 0, s, src, dst, n);
-    SR_HIP(hipGetLastError());
-    return SR_OK;
+    return sr_launch_transpose_rect(src, n, dst, n, n, n, s);
 }
 
 // one wavefront per row; shuffle reduction
