@@ -145,6 +145,9 @@ int sr_gp_set_var_group(sr_gp_t h, int group);
 /* tile staging of the variance kernel: 0 = register-staged (global->VGPR->LDS), 1 = LDS-DMA
  * (global_load_lds_dwordx4, default).  Same results bit for bit; a measurement knob. */
 int sr_gp_set_var_variant(sr_gp_t h, int variant);
+/* batches of <= 16 queries take an HBM-bound streaming path (U^-1 read once) instead of the MFMA
+ * tiles; on by default, switchable for A/B measurement.  Results agree to rounding. */
+int sr_gp_set_small_path(sr_gp_t h, int on);
 /* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
  * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.
  * Exposed so the fp64-MFMA tile can be tested in isolation. */

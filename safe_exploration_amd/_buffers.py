@@ -39,6 +39,25 @@ def as_dev(x, device, shape=None):
     return t.contiguous()
 
 
+_CONST_CACHE = {}
+
+
+def const_dev(x, device, shape):
+    """Small constant host array (model matrices a/b, Lipschitz vectors) -> device tensor, memoised on
+    its bytes so that repeated calls of the per-step entry points do not pay an H2D copy each."""
+    if isinstance(x, torch.Tensor):
+        return as_dev(x, device, shape)
+    arr = np.ascontiguousarray(np.asarray(x, dtype=np.float64)).reshape(shape)
+    key = (arr.tobytes(), tuple(shape), str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 256:
+            _CONST_CACHE.clear()
+        t = torch.from_numpy(arr.copy()).to(device)
+        _CONST_CACHE[key] = t
+    return t
+
+
 def empty(shape, device):
     return torch.empty(shape, dtype=torch.float64, device=device)
 

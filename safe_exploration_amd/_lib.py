@@ -59,6 +59,7 @@ SIGNATURES = {
     "sr_gp_set_chunk": (_I, [_H, _L]),
     "sr_gp_set_var_group": (_I, [_H, _I]),
     "sr_gp_set_var_variant": (_I, [_H, _I]),
+    "sr_gp_set_small_path": (_I, [_H, _I]),
     "sr_test_gemm_tn": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_prof_enable": (_I, [_H, _I]),
     "sr_prof_reset": (_I, [_H]),

@@ -26,8 +26,9 @@ struct sr_gp {
     int ws_nsplit = 0;
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr;
-    double *lin_v = nullptr, *lin_g = nullptr;     // 2 x (n_out x Np) scratch of sr_gp_linearize
+    double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 32;
+    int small_path = 1;      // T <= 16: HBM-bound streaming kernels instead of the MFMA tiles
     int var_variant = 1;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles (default)
     sr_prof prof;
 };
@@ -89,7 +90,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
-    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->lin_v); dev_free(h->lin_g);
+    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp);
     free_ws(h);
     h->prof.destroy();
     delete h;
@@ -368,14 +369,21 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
         SR_TRY(sr_launch_kstar(ka, s));
     }
-    {
+    int nrb = h->Np / SR_NB;
+    if (Tc <= SR_SMALL_T && h->small_path) {
+        // latency regime: stream U^-1 once (HBM-bound) instead of the MFMA tiles
+        if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
+        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+        SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, s));
+        nrb = (h->Np + 255) / 256;
+    } else {
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, h->var_variant, s));
     }
     sr_final_args fa;
     fa.mu_part = h->mu_part; fa.jac_part = h->jac_part; fa.var_part = h->var_part; fa.sf2 = h->sf2;
     fa.ls = h->ls; fa.mu = mu; fa.var = var; fa.jac = jac;
-    fa.n_out = h->n_out; fa.D = h->D; fa.nsplit = nsplit; fa.nrb = h->Np / SR_NB; fa.T = Tc; fa.Tp = Tp;
+    fa.n_out = h->n_out; fa.D = h->D; fa.nsplit = nsplit; fa.nrb = nrb; fa.T = Tc; fa.Tp = Tp;
     {
         sr_prof_scope ps(&h->prof, SR_K_FINAL, s);
         SR_TRY(sr_launch_finalize(fa, s));
@@ -411,10 +419,13 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     if (!h->lin_g) SR_TRY(dev_alloc(&h->lin_g, (size_t)h->n_out * h->Np));
     SR_TRY(gp_pass(h, 1, x, h->D, h->D, nullptr, 0, 0, mu, var, jac_mu, s));    // leaves K*(:,0) in the workspace
     const long Tp = srt::BN;
+    if (h->small_path)       // v = U^-T k* is what the streaming variance pass just accumulated
+        SR_TRY(sr_launch_var_small_gather(h->small_vp, h->lin_v, h->Np, h->n_out, 0, s));
     for (int d = 0; d < h->n_out; ++d) {
         const double* Wt = h->Wt + (size_t)d * h->Np * h->Np;
         const double* ks = h->Ks + (size_t)d * h->Np * Tp;
-        SR_TRY(sr_launch_trmv_t(Wt, h->Np, ks, Tp, h->lin_v + (size_t)d * h->Np, h->Np, s));      // v = U^-T k*
+        if (!h->small_path)
+            SR_TRY(sr_launch_trmv_t(Wt, h->Np, ks, Tp, h->lin_v + (size_t)d * h->Np, h->Np, s));  // v = U^-T k*
         SR_TRY(sr_launch_trmv(Wt, h->Np, h->lin_v + (size_t)d * h->Np, h->lin_g + (size_t)d * h->Np,
                               h->Np, 0, s));                                                       // g = U^-1 v
     }
@@ -582,6 +593,12 @@ extern "C" int sr_gp_set_chunk(sr_gp_t h, long chunk) {
 extern "C" int sr_gp_set_var_group(sr_gp_t h, int group) {
     SR_CHECK(h != nullptr && group >= 1, SR_EINVAL, "sr_gp_set_var_group: bad argument");
     h->var_group = group;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_small_path: NULL handle");
+    h->small_path = on ? 1 : 0;
     return SR_OK;
 }
 

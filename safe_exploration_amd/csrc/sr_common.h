@@ -135,6 +135,14 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                   int group, int variant, hipStream_t s);
 
+// small-batch (T <= 16) variance path: U^-1 streamed once at HBM rate (sr_predict.hip, K2s)
+#define SR_SMALL_T 16
+long sr_var_small_ws(int Np, int n_out);
+int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
+                        long Tp, int n_out, hipStream_t s);
+
+int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, hipStream_t s);
+
 struct sr_final_args {
     const double* mu_part; const double* jac_part; const double* var_part; const double* sf2;
     const double* ls;

@@ -184,6 +184,120 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
     return SR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K2s: small-batch variance (T <= SR_TS queries, the CasADi/IPOPT callback regime).  With one query
+// tile the MFMA kernel is serialised on its longest row block; here U^-1 is streamed exactly once at
+// HBM rate instead: thread = one column i of Wt, workgroup = 256 columns x 128 k-rows, K* rows
+// broadcast from LDS.  HBM-bound: n_out * Np^2/2 * 8 bytes per call (">= 25 us per eval").
+//   pass 1: Vp[chunk][t][i] = sum_{k in chunk, k <= i} Wt[k][i] K*[k][t]
+//   pass 2: part[cb][t]     = sum_{i in column block cb} (sum_chunks Vp)^2     (layout of sr_finalize)
+// ------------------------------------------------------------------------------------------------
+#define SR_TS 16
+__global__ __launch_bounds__(256) void sr_var_small_partial_kernel(const double* __restrict__ Wt,
+                                                                   const double* __restrict__ Ks,
+                                                                   double* __restrict__ Vp, int Np,
+                                                                   long Tp, int npairs, int k_lo) {
+    __shared__ double ks[128][SR_TS];
+    const int d = blockIdx.y;
+    const int p = blockIdx.x;                       // pair index: column block cb, k-chunk j <= 2 cb + 1
+    int cb = (int)((sqrt(4.0 * p + 1.0) - 1.0) * 0.5);
+    while ((cb + 1) * (cb + 2) <= p) ++cb;
+    while (cb * (cb + 1) > p) --cb;
+    const int j = p - cb * (cb + 1);
+    const int k0 = j * 128;
+    const int i = cb * 256 + threadIdx.x;
+    const double* ksrc = Ks + (long)d * Np * Tp + (long)k0 * Tp;
+    for (int e = threadIdx.x; e < 128 * SR_TS; e += 256) {
+        const int r = e / SR_TS, t = e % SR_TS;
+        ks[r][t] = (k0 + r < Np) ? ksrc[(long)r * Tp + t] : 0.0;
+    }
+    __syncthreads();
+    double acc[SR_TS];
+#pragma unroll
+    for (int t = 0; t < SR_TS; ++t) acc[t] = 0.0;
+    const double* w = Wt + (long)d * Np * Np + (long)k0 * Np + i;
+    const int kmax = (i < Np) ? min(127, i - k0) : -1;   // rows k0 .. k0 + kmax have k <= i
+    const int kbeg = max(0, k_lo - k0);             // leading padding rows carry K* == 0
+#pragma unroll 4
+    for (int r = kbeg; r <= kmax; ++r) {
+        const double wv = w[(long)r * Np];
+#pragma unroll
+        for (int t = 0; t < SR_TS; ++t) acc[t] = fma(wv, ks[r][t], acc[t]);
+    }
+    double* out = Vp + ((long)d * npairs + p) * SR_TS * 256;
+#pragma unroll
+    for (int t = 0; t < SR_TS; ++t) out[t * 256 + threadIdx.x] = acc[t];
+}
+
+__global__ __launch_bounds__(256) void sr_var_small_reduce_kernel(const double* __restrict__ Vp,
+                                                                  double* __restrict__ part, long Tp,
+                                                                  int npairs, int ncb) {
+    __shared__ double red[4][SR_TS];
+    const int cb = blockIdx.x, d = blockIdx.y;
+    const int p0 = cb * (cb + 1), nch = 2 * cb + 2;
+    double v[SR_TS];
+#pragma unroll
+    for (int t = 0; t < SR_TS; ++t) v[t] = 0.0;
+    for (int j = 0; j < nch; ++j) {
+        const double* src = Vp + ((long)d * npairs + p0 + j) * SR_TS * 256 + threadIdx.x;
+#pragma unroll
+        for (int t = 0; t < SR_TS; ++t) v[t] += src[t * 256];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < SR_TS; ++t) {
+        double q = v[t] * v[t];
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        if (lane == 0) red[wave][t] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < SR_TS)
+        part[((long)d * ncb + cb) * Tp + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// v[d][i] = sum_chunks Vp[..][t][i]  (= (U^-T k*_t)[i]) -- reused by sr_gp_linearize
+__global__ __launch_bounds__(256) void sr_var_small_gather_kernel(const double* __restrict__ Vp,
+                                                                  double* __restrict__ v, int Np, int npairs,
+                                                                  int t) {
+    const int cb = blockIdx.x, d = blockIdx.y;
+    const int i = cb * 256 + threadIdx.x;
+    if (i >= Np) return;
+    const int p0 = cb * (cb + 1), nch = 2 * cb + 2;
+    double acc = 0.0;
+    for (int j = 0; j < nch; ++j) acc += Vp[(((long)d * npairs + p0 + j) * SR_TS + t) * 256 + threadIdx.x];
+    v[(long)d * Np + i] = acc;
+}
+
+int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, hipStream_t s) {
+    const int ncb = (Np + 255) / 256;
+    hipLaunchKernelGGL(sr_var_small_gather_kernel, dim3(ncb, n_out), dim3(256), 0, s, Vp, v, Np,
+                       ncb * (ncb + 1), t);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// workspace need of the small path: n_out * npairs * SR_TS * 256 doubles for Vp
+long sr_var_small_ws(int Np, int n_out) {
+    const int ncb = (Np + 255) / 256;
+    return (long)n_out * ncb * (ncb + 1) * SR_TS * 256;
+}
+
+int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
+                        long Tp, int n_out, hipStream_t s) {
+    const int ncb = (Np + 255) / 256;              // Np is a multiple of 128: the last block may be half empty
+    const int npairs = ncb * (ncb + 1);
+    const int k_lo = Np - N;
+    hipLaunchKernelGGL(sr_var_small_partial_kernel, dim3(npairs, n_out), dim3(256), 0, s, Wt, Ks, Vp, Np,
+                       Tp, npairs, k_lo);
+    SR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sr_var_small_reduce_kernel, dim3(ncb, n_out), dim3(256), 0, s, Vp, part, Tp, npairs,
+                       ncb);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: reduce partials, clip, write API layout (T x n_out [x D]).
 // ------------------------------------------------------------------------------------------------

@@ -57,8 +57,8 @@ def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None,
         raise ValueError("k_fb is required when q_shape is given")
     kfb = B.as_dev(k_fb, dev, (T, n_u, n_s)) if (k_fb is not None and q is not None) else None
     a, b = _lin_model(a, b, n_s, n_u)
-    ta, tb = B.as_dev(a, dev, (n_s, n_s)), B.as_dev(b, dev, (n_s, n_u))
-    tlm, tls = B.as_dev(np.reshape(l_mu, (-1,)), dev, (n_s,)), B.as_dev(np.reshape(l_sigma, (-1,)), dev, (n_s,))
+    ta, tb = B.const_dev(a, dev, (n_s, n_s)), B.const_dev(b, dev, (n_s, n_u))
+    tlm, tls = B.const_dev(l_mu, dev, (n_s,)), B.const_dev(l_sigma, dev, (n_s,))
     p_out = B.empty((T, n_s), dev)
     q_out = B.empty((T, n_s, n_s), dev)
     var = B.empty((T, n_s), dev) if return_var else None
@@ -88,8 +88,8 @@ def ellipsoid_step_batch(p_center, k_ff, mu, var, jac, l_mu, l_sigma, q_shape=No
     kfb = B.as_dev(k_fb, dev, (T, n_u, n_s)) if q is not None else None
     tjac = B.as_dev(jac, dev, (T, n_s, n_s + n_u)) if (jac is not None and q is not None) else None
     a, b = _lin_model(a, b, n_s, n_u)
-    ta, tb = B.as_dev(a, dev, (n_s, n_s)), B.as_dev(b, dev, (n_s, n_u))
-    tlm, tls = B.as_dev(np.reshape(l_mu, (-1,)), dev, (n_s,)), B.as_dev(np.reshape(l_sigma, (-1,)), dev, (n_s,))
+    ta, tb = B.const_dev(a, dev, (n_s, n_s)), B.const_dev(b, dev, (n_s, n_u))
+    tlm, tls = B.const_dev(l_mu, dev, (n_s,)), B.const_dev(l_sigma, dev, (n_s,))
     p_out = B.empty((T, n_s), dev)
     q_out = B.empty((T, n_s, n_s), dev)
     n_bad = B.zeros_i32(1, dev) if check_bounds else None
@@ -162,8 +162,8 @@ def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_
         raise ValueError("k_fb_init is required when q_0 is given")
     kfb0 = B.as_dev(k_fb_init, dev, (T, n_u, n_s)) if q0 is not None else None
     a, b = _lin_model(a, b, n_s, n_u)
-    ta, tb = B.as_dev(a, dev, (n_s, n_s)), B.as_dev(b, dev, (n_s, n_u))
-    tlm, tls = B.as_dev(np.reshape(L_mu, (-1,)), dev, (n_s,)), B.as_dev(np.reshape(L_sigm, (-1,)), dev, (n_s,))
+    ta, tb = B.const_dev(a, dev, (n_s, n_s)), B.const_dev(b, dev, (n_s, n_u))
+    tlm, tls = B.const_dev(L_mu, dev, (n_s,)), B.const_dev(L_sigm, dev, (n_s,))
     p_all = B.empty((T, H, n_s), dev)
     q_all = B.empty((T, H, n_s, n_s), dev)
     n_bad = B.zeros_i32(1, dev) if check_bounds else None

@@ -443,6 +443,10 @@ class SimpleGPModel(StateSpaceModel):
         self._need_trained()
         check(lib.sr_gp_set_var_variant(self._handle.h, int(variant)))
 
+    def set_small_path(self, on):
+        self._need_trained()
+        check(lib.sr_gp_set_small_path(self._handle.h, 1 if on else 0))
+
     def prof_enable(self, on=True):
         self._need_trained()
         check(lib.sr_prof_enable(self._handle.h, 1 if on else 0))

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Latency of the small-batch entry points (the regime the CasADi/IPOPT loop drives): wall time per
+call of predict / onestep / linearize for T in {1, 16, 128, 1024} at N in {200, 5000}."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload, _buffers as B  # noqa: E402
+
+
+def timeit(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+def main():
+    out = {}
+    for N in (200, 5000):
+        prob = workload.make_problem(9, N, 2, 1, 1024, sf2=0.01)
+        gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob), device="cuda:0")
+        gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+        dev = gp.device
+        l = np.array([0.05, 0.02])
+        for T in (1, 16, 128, 1024):
+            x = B.as_dev(np.hstack((prob["p"][:T], prob["k_ff"][:T])), dev)
+            tp, tq, tkff, tkfb = (B.as_dev(prob[k][:T], dev) for k in ("p", "Q", "k_ff", "k_fb"))
+            out["N%d_T%d_predict_us" % (N, T)] = round(timeit(lambda: gp.predict_device(x, True)), 1)
+            out["N%d_T%d_onestep_us" % (N, T)] = round(
+                timeit(lambda: reach.onestep_reachability_batch(tp, gp, tkff, l, l, tq, tkfb, 2.0)), 1)
+        x1 = B.as_dev(np.hstack((prob["p"][0], prob["k_ff"][0])), dev)
+        out["N%d_linearize_us" % N] = round(timeit(lambda: gp.linearize_device(x1)), 1)
+        out["N%d_call_numpy_us" % N] = round(timeit(lambda: gp(prob["p"][:1], prob["k_ff"][:1])), 1)
+        roll = workload.random_rollout_controls(3, 256, 15, 2, 1)
+        tr = {k: B.as_dev(v, dev) for k, v in roll.items()}
+        a = 0.8 * np.eye(2)
+        out["N%d_multistep_T256_H15_us" % N] = round(timeit(
+            lambda: reach.multistep_reachability_batch(tr["p0"], gp, tr["k_fb"], tr["k_ff"], l, l, None, 2.0, a,
+                                                       np.zeros((2, 1))), 20), 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

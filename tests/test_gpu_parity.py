@@ -387,3 +387,21 @@ def test_many_chunks_million_queries():
     np.testing.assert_allclose(q1[0], ref_q, rtol=1e-10, atol=1e-13)
     np.testing.assert_array_equal(q1[reps - 1], q1[0])         # every replica of the block is identical
     np.testing.assert_array_equal(q1[reps // 2], q1[0])
+
+
+@pytest.mark.parametrize("N,T", [(100, 1), (300, 16), (700, 7), (1300, 1), (257, 16)])
+def test_small_batch_streaming_path_matches_mfma_path(N, T):
+    """T <= 16 uses the HBM-bound streaming kernels; it must agree with the MFMA tiles and the oracle
+    (Np both an even and an odd multiple of 128)."""
+    syn = orc.make_synthetic(3 * N + T, N, 2, 1, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    gp.set_small_path(True)
+    mu_s, var_s = gp.predict(x)
+    gp.set_small_path(False)
+    mu_m, var_m = gp.predict(x)
+    np.testing.assert_array_equal(mu_s, mu_m)
+    np.testing.assert_allclose(var_s, var_m, rtol=0, atol=1e-12)
+    _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
+    np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
