@@ -26,7 +26,9 @@ struct sr_gp {
     int ws_nsplit = 0;
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr;
-    double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch     // 2 x (n_out x Np) scratch of sr_gp_linearize
+    double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch
+    double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
+    double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 32;
     int small_path = 1;      // T <= 16: HBM-bound streaming kernels instead of the MFMA tiles
     int var_variant = 1;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles (default)
@@ -90,7 +92,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
-    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp);
+    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     free_ws(h);
     h->prof.destroy();
     delete h;
@@ -370,18 +372,34 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         SR_TRY(sr_launch_kstar(ka, s));
     }
     int nrb = h->Np / SR_NB;
+    const double* var_part = h->var_part;
     if (Tc <= SR_SMALL_T && h->small_path) {
         // latency regime: stream U^-1 once (HBM-bound) instead of the MFMA tiles
         if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, s));
         nrb = (h->Np + 255) / 256;
+    } else if (h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) {
+        // few query tiles: split the K range so that no workgroup serialises a whole row block
+        const long need = sr_var_splitk_ws(h->Np, Tp, h->n_out);
+        if (need > h->splitk_cap) {
+            (void)hipStreamSynchronize(s);
+            dev_free(h->splitk_vt);
+            h->splitk_vt = nullptr; h->splitk_cap = 0;
+            SR_TRY(dev_alloc(&h->splitk_vt, (size_t)need));
+            h->splitk_cap = need;
+        }
+        if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));  // wgs <= 1024
+        var_part = h->splitk_part;
+        nrb = 4 * (h->Np / SR_NB);
+        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+        SR_TRY(sr_launch_var_splitk(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else {
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, h->var_variant, s));
     }
     sr_final_args fa;
-    fa.mu_part = h->mu_part; fa.jac_part = h->jac_part; fa.var_part = h->var_part; fa.sf2 = h->sf2;
+    fa.mu_part = h->mu_part; fa.jac_part = h->jac_part; fa.var_part = var_part; fa.sf2 = h->sf2;
     fa.ls = h->ls; fa.mu = mu; fa.var = var; fa.jac = jac;
     fa.n_out = h->n_out; fa.D = h->D; fa.nsplit = nsplit; fa.nrb = nrb; fa.T = Tc; fa.Tp = Tp;
     {

@@ -135,6 +135,12 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                   int group, int variant, hipStream_t s);
 
+// split-K form of the variance kernel for few query tiles (sr_predict.hip, K2k)
+long sr_var_splitk_ws(int Np, long Tp, int n_out);
+bool sr_var_splitk_wanted(int Np, long Tp, int n_out);
+int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,
+                         long Tp, int n_out, hipStream_t s);
+
 // small-batch (T <= 16) variance path: U^-1 streamed once at HBM rate (sr_predict.hip, K2s)
 #define SR_SMALL_T 16
 long sr_var_small_ws(int Np, int n_out);

@@ -186,6 +186,108 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
 
 
 // ------------------------------------------------------------------------------------------------
+// K2k: split-K form of K2 for FEW query tiles (16 < T <~ 1500 at N = 5000: batches of candidate
+// rollouts).  With so few tiles the plain kernel is serialised on its longest row block (40 k-blocks);
+// here every (row block, query tile) is cut into chunks of 8 k-blocks that run as independent
+// workgroups and store their 128 x 128 partial product; a second pass adds the chunks, squares and
+// reduces over the rows.  Same MFMA tile, same arithmetic per chunk.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void sr_var_splitk_kernel(const double* __restrict__ Wt,
+                                                               const double* __restrict__ Ks,
+                                                               double* __restrict__ Vt, int Np, long Tp,
+                                                               int nrb, int ntq, int maxch, int k_beg,
+                                                               int kcb) {
+    __shared__ double smem[srt::SMEM_DOUBLES];
+    const int x = blockIdx.x, rb = blockIdx.y;
+    const int d = blockIdx.z / maxch, ch = blockIdx.z % maxch;
+    const int k0 = max(k_beg, ch * kcb * srt::BM);
+    const int k1 = min((rb + 1) * srt::BM, (ch + 1) * kcb * srt::BM);
+    if (k0 >= k1) return;
+    const double* A = Wt + (long)d * Np * Np + (long)rb * srt::BM;
+    const double* B = Ks + (long)d * Np * Tp + (long)x * srt::BN;
+    srt::Acc acc;
+    acc.zero();
+    srt::mainloop_tn_glds<16>(A, Np, B, Tp, k0, k1, smem, acc);
+    double* out = Vt + ((((long)d * nrb + rb) * ntq + x) * maxch + ch) * (srt::BM * srt::BN);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[srt::acc_row(wm, mi, lane, r) * srt::BN + srt::acc_col(wn, ni, lane)] = acc.v[mi][ni][r];
+}
+
+__global__ __launch_bounds__(256) void sr_var_splitk_reduce_kernel(const double* __restrict__ Vt,
+                                                                   double* __restrict__ part, long Tp,
+                                                                   int nrb, int ntq, int maxch, int k_beg,
+                                                                   int kcb) {
+    // one workgroup = 32 rows of one partial tile: 4 workgroups per (row block, query tile)
+    __shared__ double red[128];
+    const int x = blockIdx.x >> 2, q = blockIdx.x & 3, rb = blockIdx.y, d = blockIdx.z;
+    const int n = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int ch0 = k_beg / (kcb * srt::BM);                    // chunks below k_beg were never written
+    const int nch = (rb + 1 + kcb - 1) / kcb;
+    const double* base = Vt + (((long)d * nrb + rb) * ntq + x) * maxch * (srt::BM * srt::BN) +
+                         (q * 32 + half * 16) * srt::BN + n;
+    double v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = 0.0;
+    for (int c = ch0; c < nch; ++c) {
+        const double* src = base + (long)c * (srt::BM * srt::BN);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] += src[m * srt::BN];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s = fma(v[m], v[m], s);
+    if (half == 1) red[n] = s;
+    __syncthreads();
+    if (half == 0) part[((long)d * (4 * nrb) + rb * 4 + q) * Tp + (long)x * srt::BN + n] = s + red[n];
+}
+
+// k-blocks per chunk: 4 when all chunk workgroups of that size are co-resident (2 per CU), else 8
+// (measured at N = 5000: T=128 -> 4 is 30 % faster, T=256 -> 8 is 12 % faster)
+static int splitk_kcb(int Np, long Tp, int n_out) {
+    const long nrb = Np / srt::BM;
+    long wg4 = 0;
+    for (long rb = 0; rb < nrb; ++rb) wg4 += (rb + 4) / 4;
+    wg4 *= (Tp / srt::BN) * n_out;
+    return wg4 <= 512 ? 4 : 8;
+}
+
+long sr_var_splitk_ws(int Np, long Tp, int n_out) {
+    const int nrb = Np / srt::BM;
+    const int kcb = splitk_kcb(Np, Tp, n_out);
+    const int maxch = (nrb + kcb - 1) / kcb;
+    return (long)n_out * nrb * (Tp / srt::BN) * maxch * srt::BM * srt::BN;
+}
+
+// profitable when the plain kernel cannot fill the chip and there is a K range to split
+bool sr_var_splitk_wanted(int Np, long Tp, int n_out) {
+    const int nrb = Np / srt::BM;
+    const long wgs = (long)nrb * (Tp / srt::BN) * n_out;
+    return nrb > 8 && wgs <= 1024;
+}
+
+int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,
+                         long Tp, int n_out, hipStream_t s) {
+    const int k_beg = ((Np - N) / srt::BK) * srt::BK;
+    const int nrb = Np / srt::BM, ntq = (int)(Tp / srt::BN);
+    const int kcb = splitk_kcb(Np, Tp, n_out);
+    const int maxch = (nrb + kcb - 1) / kcb;
+    hipLaunchKernelGGL(sr_var_splitk_kernel, dim3(ntq, nrb, n_out * maxch), dim3(256), 0, s, Wt, Ks, Vt, Np,
+                       Tp, nrb, ntq, maxch, k_beg, kcb);
+    SR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sr_var_splitk_reduce_kernel, dim3(ntq * 4, nrb, n_out), dim3(256), 0, s, Vt, part, Tp,
+                       nrb, ntq, maxch, k_beg, kcb);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2s: small-batch variance (T <= SR_TS queries, the CasADi/IPOPT callback regime).  With one query
 // tile the MFMA kernel is serialised on its longest row block; here U^-1 is streamed exactly once at
 // HBM rate instead: thread = one column i of Wt, workgroup = 256 columns x 128 k-rows, K* rows

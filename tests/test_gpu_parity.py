@@ -405,3 +405,20 @@ def test_small_batch_streaming_path_matches_mfma_path(N, T):
     np.testing.assert_allclose(var_s, var_m, rtol=0, atol=1e-12)
     _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
     np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,T", [(1300, 17), (1300, 300), (2500, 129)])
+def test_splitk_path_matches_plain_path(N, T):
+    """few query tiles + more than 8 row blocks -> split-K kernels; must agree with the plain tiles."""
+    syn = orc.make_synthetic(N + T, N, 2, 1, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    gp.set_small_path(True)
+    mu_s, var_s = gp.predict(x)
+    gp.set_small_path(False)
+    mu_m, var_m = gp.predict(x)
+    np.testing.assert_array_equal(mu_s, mu_m)
+    np.testing.assert_allclose(var_s, var_m, rtol=0, atol=1e-12)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
+    np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
