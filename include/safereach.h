@@ -57,6 +57,15 @@ int sr_gp_destroy(sr_gp_t h);
 int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const double* lengthscale,
                    const double* signal_var, const double* noise_var, void* stream);
 
+/* Same, for the general kernel family of the reference's non-RBF kernel types
+ * (ssm_gpy/gp_models_utils_casadi.py:43-157: mat52, lin_rbf, lin_mat52):
+ *   k(x,y) = (c0 + sum_j a_j x_j y_j) * v * kappa(r) + sum_j b_j x_j y_j,  r^2 = sum_j ((x_j - y_j) s_j)^2
+ *   kappa(r) = exp(-r^2/2) (0) | (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r) (1)
+ * kparams [device]: n_out x (3 + 3 D) doubles, per output [kappa, v, c0, s_1..s_D, a_1..a_D, b_1..b_D]
+ * (s_j = 1/lengthscale_j on the dimensions the stationary factor acts on, 0 elsewhere). */
+int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* Y, const double* kparams,
+                           const double* noise_var, void* stream);
+
 /* K_d = rbf(Z,Z) + noise I ; K_d = U^T U (blocked fp64-MFMA Cholesky) ; W = U^-T ; alpha = K^-1 y.
  * replaces the GPy posterior the reference caches as inv_K/beta (ssm_gpy/gaussian_process.py:255-275).
  * info [host, n_out ints]: 0, or 1-based index of the first non-positive pivot (then returns SR_ENOTPD).

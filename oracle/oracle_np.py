@@ -312,3 +312,102 @@ def make_synthetic(seed, N, n_s, n_u, T, noise=1e-2, sf2=1.0):
     Q = 0.01 * np.einsum('tij,tkj->tik', A, A) + 0.01 * np.eye(n_s)[None]
     return dict(Z=Z, Y=Y, lengthscale=ls, signal_var=sf2, noise_var=sn2,
                 p=p, k_ff=k_ff, k_fb=k_fb, Q=Q)
+
+
+# --------------------------------------------------------------------------- non-RBF kernel types
+SQRT5 = np.sqrt(5.0)
+
+
+def mat52_kernel(x, y, variance, lengthscale):
+    """ssm_gpy/gp_models_utils_casadi.py:43-69: variance (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r)."""
+    ls = np.asarray(lengthscale, dtype=np.float64).reshape(-1) * np.ones(x.shape[1])
+    r = np.sqrt(unscaled_dist_sq(x / ls[None, :], y / ls[None, :]))
+    return variance * (1.0 + SQRT5 * r + 5.0 / 3.0 * r ** 2) * np.exp(-SQRT5 * r)
+
+
+def lin_kernel(x, y, variances):
+    """ssm_gpy/gp_models_utils_casadi.py:131-157: (x sqrt(v)) (y sqrt(v))^T."""
+    v = np.asarray(variances, dtype=np.float64).reshape(-1) * np.ones(x.shape[1])
+    return (x * np.sqrt(v)[None, :]).dot((y * np.sqrt(v)[None, :]).T)
+
+
+def kernel_matrix(kern_type, hyp, x, y):
+    """K(x, y) for the reference's kernel identifiers (gp_models_utils_casadi.py:200-231).  The
+    lin_* types act with their product part on input dimension 1 only (:83-84, :113-114)."""
+    if kern_type == "rbf":
+        return rbf_kernel(x, y, hyp["variance"], hyp["lengthscale"])
+    if kern_type == "mat52":
+        return mat52_kernel(x, y, hyp["variance"], hyp["lengthscale"])
+    x1, y1 = x[:, 1:2], y[:, 1:2]
+    k_lin = lin_kernel(x, y, hyp["linear.variances"])
+    k_prod_lin = lin_kernel(x1, y1, hyp["prod.linear.variances"])
+    if kern_type == "lin_rbf":
+        return k_prod_lin * rbf_kernel(x1, y1, hyp["prod.rbf.variance"], hyp["prod.rbf.lengthscale"]) + k_lin
+    if kern_type == "lin_mat52":
+        return k_prod_lin * mat52_kernel(x1, y1, hyp["prod.mat52.variance"], hyp["prod.mat52.lengthscale"]) + k_lin
+    raise ValueError("Unknown kernel {}".format(kern_type))
+
+
+def kernel_diag(kern_type, hyp, x):
+    """k(x_t, x_t) (the diag_only branches of gp_models_utils_casadi.py)."""
+    if kern_type in ("rbf", "mat52"):
+        return np.full(x.shape[0], float(hyp["variance"]))
+    vp = np.asarray(hyp["prod.linear.variances"], dtype=np.float64).reshape(-1)[0]
+    vl = np.asarray(hyp["linear.variances"], dtype=np.float64).reshape(-1) * np.ones(x.shape[1])
+    var = hyp["prod.rbf.variance"] if kern_type == "lin_rbf" else hyp["prod.mat52.variance"]
+    return vp * x[:, 1] ** 2 * float(var) + (x ** 2).dot(vl)
+
+
+def gp_fit_k(Z, Y, kern_types, hyp, noise_var):
+    """gp_fit for arbitrary kernel identifiers (one per output)."""
+    N, n_out = Y.shape
+    beta = np.empty((N, n_out))
+    inv_K = []
+    for d in range(n_out):
+        Ky = kernel_matrix(kern_types[d], hyp[d], Z, Z) + (noise_var[d] + GPY_JITTER) * np.eye(N)
+        L = sla.cholesky(Ky, lower=True)
+        Li = sla.solve_triangular(L, np.eye(N), lower=True)
+        inv_K.append(Li.T.dot(Li))
+        beta[:, d] = sla.cho_solve((L, True), Y[:, d])
+    return beta, inv_K
+
+
+def gp_predict_k(x_new, Z, beta, inv_K, kern_types, hyp):
+    """mean / variance for arbitrary kernel identifiers, formulas of gp_pred
+    (gp_models_utils_casadi.py:177-197).  Returns mu (T,n_out), var (T,n_out)."""
+    T = x_new.shape[0]
+    n_out = beta.shape[1]
+    mu = np.empty((T, n_out))
+    var = np.empty((T, n_out))
+    for d in range(n_out):
+        ks = kernel_matrix(kern_types[d], hyp[d], x_new, Z)
+        mu[:, d] = ks.dot(beta[:, d])
+        var[:, d] = kernel_diag(kern_types[d], hyp[d], x_new) - np.sum(ks.dot(inv_K[d]) * ks, axis=1)
+    return mu, np.clip(var, GPY_VAR_CLIP, np.inf)
+
+
+def gp_mean_jacobian_fd(x_new, Z, beta, kern_types, hyp, eps=1e-6):
+    """central-difference d mu/dx (T,n_out,D): an algebra-free check of the analytic Jacobians."""
+    T, D = x_new.shape
+    n_out = beta.shape[1]
+    jac = np.empty((T, n_out, D))
+    for j in range(D):
+        e = np.zeros(D)
+        e[j] = eps
+        for d in range(n_out):
+            kp = kernel_matrix(kern_types[d], hyp[d], x_new + e, Z)
+            km = kernel_matrix(kern_types[d], hyp[d], x_new - e, Z)
+            jac[:, d, j] = (kp - km).dot(beta[:, d]) / (2 * eps)
+    return jac
+
+
+def make_hyp(kern_type, rng, D):
+    """random hyper-parameters with the key names of SimpleGPModel._create_hyp_dict
+    (ssm_gpy/gaussian_process.py:491-544)."""
+    if kern_type in ("rbf", "mat52"):
+        return {"lengthscale": rng.uniform(0.5, 1.5, D), "variance": float(rng.uniform(0.5, 1.5))}
+    st = "rbf" if kern_type == "lin_rbf" else "mat52"
+    return {"prod.%s.lengthscale" % st: np.array([rng.uniform(0.5, 1.5)]),
+            "prod.%s.variance" % st: float(rng.uniform(0.5, 1.5)),
+            "prod.linear.variances": np.array([rng.uniform(0.5, 1.5)]),
+            "linear.variances": rng.uniform(0.2, 1.0, D)}

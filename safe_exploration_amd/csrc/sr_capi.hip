@@ -20,12 +20,14 @@ struct sr_gp {
     // persistent device state
     double *Z = nullptr, *yT = nullptr, *ls = nullptr, *sf2 = nullptr, *noise = nullptr,
            *alpha = nullptr, *Wt = nullptr;
+    double* kp = nullptr;     // general kernel family: n_out x SR_KP(D) packed parameters (else NULL)
+    int general = 0;
     int have_data = 0, factorized = 0;
     // per-chunk workspace (grow-only)
     long chunk = 65536, ws_Tp = 0;
     int ws_nsplit = 0;
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
-           *mu = nullptr, *var = nullptr, *jac = nullptr;
+           *mu = nullptr, *var = nullptr, *jac = nullptr, *kxx = nullptr;
     double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
@@ -82,8 +84,8 @@ extern "C" int sr_gp_create(sr_gp_t* out, int device, int N, int D, int n_out) {
 
 static void free_ws(sr_gp* h) {
     dev_free(h->Ks); dev_free(h->mu_part); dev_free(h->jac_part); dev_free(h->var_part);
-    dev_free(h->mu); dev_free(h->var); dev_free(h->jac);
-    h->Ks = h->mu_part = h->jac_part = h->var_part = h->mu = h->var = h->jac = nullptr;
+    dev_free(h->mu); dev_free(h->var); dev_free(h->jac); dev_free(h->kxx);
+    h->Ks = h->mu_part = h->jac_part = h->var_part = h->mu = h->var = h->jac = h->kxx = nullptr;
     h->ws_Tp = 0; h->ws_nsplit = 0;
 }
 
@@ -92,7 +94,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
-    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
+    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     free_ws(h);
     h->prof.destroy();
     delete h;
@@ -119,6 +121,25 @@ extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const
     hipLaunchKernelGGL(sr_pack_y_kernel, dim3((h->Np + 255) / 256, h->n_out), dim3(256), 0, s, Y,
                        h->yT, h->N, h->Np, h->n_out);
     SR_HIP(hipGetLastError());
+    h->general = 0;
+    h->have_data = 1;
+    h->factorized = 0;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* Y, const double* kparams,
+                                      const double* noise, void* stream) {
+    SR_CHECK(h && Z && Y && kparams && noise, SR_EINVAL, "sr_gp_set_data_general: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    if (!h->kp) SR_TRY(dev_alloc(&h->kp, (size_t)h->n_out * SR_KP(h->D)));
+    SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
+    SR_HIP(hipMemcpyAsync(h->kp, kparams, sizeof(double) * h->n_out * SR_KP(h->D), hipMemcpyDeviceToDevice, s));
+    SR_HIP(hipMemcpyAsync(h->noise, noise, sizeof(double) * h->n_out, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(sr_pack_y_kernel, dim3((h->Np + 255) / 256, h->n_out), dim3(256), 0, s, Y,
+                       h->yT, h->N, h->Np, h->n_out);
+    SR_HIP(hipGetLastError());
+    h->general = 1;
     h->have_data = 1;
     h->factorized = 0;
     return SR_OK;
@@ -170,7 +191,10 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         SR_FH(hipMemsetAsync(Wt, 0, NN * sizeof(double), s));
         {
             sr_prof_scope ps(&h->prof, SR_K_GRAM, s);
-            SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, s));
+            if (h->general)
+                SR_F(sr_launch_gram_general(h->Z, h->kp + (size_t)d * SR_KP(h->D), noise[d], U, h->N, Np, h->D, s));
+            else
+                SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, s));
         }
         // --- Cholesky K = U^T U, right-looking, two-level blocking: 128-row blocks inside panels of
         // SR_PANEL blocks.  Inside a panel a factored block row updates only the panel's remaining
@@ -346,7 +370,8 @@ static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
         (rc = dev_alloc(&h->var_part, (size_t)h->n_out * nrb * nTp)) ||
         (rc = dev_alloc(&h->mu, (size_t)h->n_out * nTp)) ||
         (rc = dev_alloc(&h->var, (size_t)h->n_out * nTp)) ||
-        (rc = dev_alloc(&h->jac, (size_t)h->n_out * h->D * nTp))) {
+        (rc = dev_alloc(&h->jac, (size_t)h->n_out * h->D * nTp)) ||
+        (rc = dev_alloc(&h->kxx, (size_t)h->n_out * nTp))) {
         free_ws(h);
         return rc;
     }
@@ -363,6 +388,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     SR_TRY(ensure_ws(h, Tp, nsplit));
     sr_kstar_args ka;
     ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.kp = h->general ? h->kp : nullptr; ka.kxx = h->kxx;
     ka.xa = xa; ka.lda = lda; ka.na = na; ka.xb = xb; ka.ldb = ldb; ka.nb = nb;
     ka.Ks = h->Ks; ka.mu_part = h->mu_part; ka.jac_part = h->jac_part;
     ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = nsplit;
@@ -400,7 +426,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     }
     sr_final_args fa;
     fa.mu_part = h->mu_part; fa.jac_part = h->jac_part; fa.var_part = var_part; fa.sf2 = h->sf2;
-    fa.ls = h->ls; fa.mu = mu; fa.var = var; fa.jac = jac;
+    fa.ls = h->ls; fa.kxx = h->general ? h->kxx : nullptr; fa.mu = mu; fa.var = var; fa.jac = jac;
     fa.n_out = h->n_out; fa.D = h->D; fa.nsplit = nsplit; fa.nrb = nrb; fa.T = Tc; fa.Tp = Tp;
     {
         sr_prof_scope ps(&h->prof, SR_K_FINAL, s);
@@ -431,6 +457,7 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_linearize: NULL handle");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_linearize: model not factorized");
     SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
+    SR_CHECK(!h->general, SR_EUNSUPPORTED, "sr_gp_linearize: second-order outputs are implemented for ARD-RBF only");
     hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
     if (!h->lin_v) SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np));

@@ -116,6 +116,14 @@ int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, 
                    hipStream_t s);
 int sr_launch_fill(double* p, size_t n, double v, hipStream_t s);
 
+// General kernel family (formulas ssm_gpy/gp_models_utils_casadi.py:17-157):
+//   k(x,y) = (c0 + sum_j a_j x_j y_j) * v * kappa(r) + sum_j b_j x_j y_j ,  r^2 = sum_j ((x_j-y_j) s_j)^2
+//   kappa = exp(-r^2/2) (RBF, 0) or (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r) (Matern-5/2, 1)
+// packed per output as SR_KP(D) doubles: [kappa, v, c0, s[D], a[D], b[D]]
+#define SR_KP(D) (3 + 3 * (D))
+int sr_launch_gram_general(const double* Z, const double* kp, double noise, double* K, int N, int Np,
+                           int D, hipStream_t s);
+
 struct sr_kstar_args {
     const double* Z;        // N x D
     const double* alpha;    // n_out x Np
@@ -123,6 +131,8 @@ struct sr_kstar_args {
     const double* sf2;      // n_out
     const double* xa; long lda; int na;   // query part a: T x na (row stride lda)
     const double* xb; long ldb; int nb;   // query part b: T x nb (row stride ldb), na+nb == D
+    const double* kp;       // general kernels: n_out x SR_KP(D) packed parameters, else NULL (ARD-RBF fast path)
+    double* kxx;            // general kernels: prior variance k(x_t, x_t), n_out x Tp
     double* Ks;             // n_out x Np x Tp
     double* mu_part;        // nsplit x n_out x Tp
     double* jac_part;       // nsplit x n_out x D x Tp
@@ -151,7 +161,7 @@ int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, i
 
 struct sr_final_args {
     const double* mu_part; const double* jac_part; const double* var_part; const double* sf2;
-    const double* ls;
+    const double* ls; const double* kxx;    // kxx != NULL: per-query prior variance instead of sf2
     double* mu; double* var; double* jac;   // T x n_out, T x n_out, T x n_out x D (jac may be NULL)
     int n_out, D, nsplit, nrb; long T, Tp;
 };

@@ -87,6 +87,50 @@ int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, 
     return SR_OK;
 }
 
+// general kernel family (see sr_common.h); diagonal = k(z_i, z_i) + noise
+__device__ __forceinline__ double sr_kappa(int kind, double r2) {
+    if (kind == 0) return exp(-0.5 * r2);
+    const double r = sqrt(r2);
+    return (1.0 + 2.23606797749978969641 * r + (5.0 / 3.0) * r2) * exp(-2.23606797749978969641 * r);
+}
+
+__global__ __launch_bounds__(256) void sr_gram_general_kernel(const double* __restrict__ Z,
+                                                              const double* __restrict__ kp, double noise,
+                                                              double* __restrict__ K, int N, int Np, int D) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Np) return;
+    const int off = Np - N;
+    double v;
+    if (i < off || j < off) {
+        v = (i == j) ? 1.0 : 0.0;
+    } else {
+        const double* zi = Z + (long)(i - off) * D;
+        const double* zj = Z + (long)(j - off) * D;
+        const int kind = (int)kp[0];
+        const double var = kp[1], c0 = kp[2];
+        const double *sv = kp + 3, *av = kp + 3 + D, *bv = kp + 3 + 2 * D;
+        double r2 = 0.0, la = 0.0, lb = 0.0;
+        for (int c = 0; c < D; ++c) {
+            const double t = (zi[c] - zj[c]) * sv[c];
+            r2 = fma(t, t, r2);
+            la = fma(av[c] * zi[c], zj[c], la);
+            lb = fma(bv[c] * zi[c], zj[c], lb);
+        }
+        v = (c0 + la) * var * sr_kappa(kind, (i == j) ? 0.0 : r2) + lb;
+        if (i == j) v += noise;
+    }
+    K[(long)i * Np + j] = v;
+}
+
+int sr_launch_gram_general(const double* Z, const double* kp, double noise, double* K, int N, int Np,
+                           int D, hipStream_t s) {
+    dim3 grid((Np + 255) / 256, Np);
+    hipLaunchKernelGGL(sr_gram_general_kernel, grid, dim3(256), 0, s, Z, kp, noise, K, N, Np, D);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Diagonal block: A_kk = U_kk^T U_kk (upper Cholesky) and in-place inverse of U_kk, all in LDS.
 // One workgroup; 128 x 129 doubles of LDS (132 KiB of the CU's 160 KiB).

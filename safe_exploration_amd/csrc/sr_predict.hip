@@ -86,8 +86,116 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
     }
 }
 
+// K1g: the same pass for the general kernel family of sr_common.h (Matern-5/2, linear x stationary +
+// linear).  Inputs stay unscaled in LDS because the linear parts need x_j z_j; per pair
+//   k = (c0 + sum a_j x_j z_j) v kappa(r) + sum b_j x_j z_j
+//   dk/dx_j = a_j z_j v kappa + (c0 + ...) v g (x_j - z_j) s_j^2 + b_j z_j ,  g = kappa'(r)/r
+// and the prior variance k(x,x) = (c0 + sum a_j x_j^2) v + sum b_j x_j^2 is emitted per query.
+template <int DT>
+__global__ __launch_bounds__(256) void sr_kstar_general_kernel(sr_kstar_args a) {
+    __shared__ double zs[SR_ZT * DT];
+    __shared__ double al[SR_ZT];
+    const int d = blockIdx.y, sp = blockIdx.z;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < a.T;
+    const bool inpad = t < a.Tp;
+    const double* kp = a.kp + (long)d * SR_KP(a.D);
+    const int kind = (int)kp[0];
+    const double var = kp[1], c0 = kp[2];
+    double s2[DT], ax[DT], bx[DT], av[DT], bv[DT], x[DT], g[DT];
+    double kxx = c0 * var;
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        const double sj = (j < a.D) ? kp[3 + j] : 0.0;
+        av[j] = (j < a.D) ? kp[3 + a.D + j] : 0.0;
+        bv[j] = (j < a.D) ? kp[3 + 2 * a.D + j] : 0.0;
+        double xv = 0.0;
+        if (live && j < a.D) xv = (j < a.na) ? a.xa[t * a.lda + j] : a.xb[t * a.ldb + (j - a.na)];
+        x[j] = xv;
+        s2[j] = sj * sj;
+        ax[j] = av[j] * xv;
+        bx[j] = bv[j] * xv;
+        kxx = fma(ax[j] * var + bx[j], xv, kxx);
+        g[j] = 0.0;
+    }
+    double mu = 0.0;
+    const int off = a.Np - a.N;
+    const int rows_per = (a.Np + a.nsplit - 1) / a.nsplit;
+    const int i_beg = sp * rows_per;
+    const int i_end = min(a.Np, i_beg + rows_per);
+    double* ks_col = a.Ks + (long)d * a.Np * a.Tp + t;
+    for (int i0 = i_beg; i0 < i_end; i0 += SR_ZT) {
+        const int nrow = min(SR_ZT, i_end - i0);
+        __syncthreads();
+        {
+            const int r = threadIdx.x;
+            const int i = i0 + r - off;
+            const bool ok = (r < nrow) && (i >= 0);
+#pragma unroll
+            for (int j = 0; j < DT; ++j) zs[r * DT + j] = (ok && j < a.D) ? a.Z[(long)i * a.D + j] : 0.0;
+            al[r] = ok ? a.alpha[(long)d * a.Np + i0 + r] : 0.0;
+        }
+        __syncthreads();
+        const int rpad = min(nrow, max(0, off - i0));
+        if (inpad) {
+            for (int r = 0; r < rpad; ++r) ks_col[(long)(i0 + r) * a.Tp] = 0.0;
+            for (int r = rpad; r < nrow; ++r) {
+                double diff[DT];
+                double r2 = 0.0, la = 0.0, lb = 0.0;
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    const double z = zs[r * DT + j];
+                    diff[j] = x[j] - z;
+                    r2 = fma(diff[j] * s2[j], diff[j], r2);
+                    la = fma(ax[j], z, la);
+                    lb = fma(bx[j], z, lb);
+                }
+                double kap, gk;              // kappa and kappa'(r)/r
+                if (kind == 0) {
+                    kap = exp(-0.5 * r2);
+                    gk = -kap;
+                } else {
+                    const double rr = sqrt(r2);
+                    const double e = exp(-2.23606797749978969641 * rr);
+                    kap = (1.0 + 2.23606797749978969641 * rr + (5.0 / 3.0) * r2) * e;
+                    gk = -(5.0 / 3.0) * (1.0 + 2.23606797749978969641 * rr) * e;
+                }
+                const double pre = (c0 + la) * var;
+                const double k = live ? fma(pre, kap, lb) : 0.0;
+                ks_col[(long)(i0 + r) * a.Tp] = k;
+                const double w = live ? al[r] : 0.0;
+                mu = fma(w, k, mu);
+                const double wk = w * var * kap, wg = w * pre * gk;
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    const double z = zs[r * DT + j];
+                    g[j] = fma(wk * av[j] + w * bv[j], z, fma(wg * s2[j], diff[j], g[j]));
+                }
+            }
+        }
+    }
+    if (inpad) {
+        a.mu_part[((long)sp * a.n_out + d) * a.Tp + t] = mu;
+        if (sp == 0) a.kxx[(long)d * a.Tp + t] = kxx;
+#pragma unroll
+        for (int j = 0; j < DT; ++j)
+            if (j < a.D) a.jac_part[(((long)sp * a.n_out + d) * a.D + j) * a.Tp + t] = g[j];
+    }
+}
+
 int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s) {
     dim3 grid((unsigned)((a.Tp + 255) / 256), a.n_out, a.nsplit);
+    if (a.kp) {
+#define SR_KSTARG_CASE(DT) hipLaunchKernelGGL(sr_kstar_general_kernel<DT>, grid, dim3(256), 0, s, a)
+        if (a.D <= 3) SR_KSTARG_CASE(3);
+        else if (a.D <= 5) SR_KSTARG_CASE(5);
+        else if (a.D <= 8) SR_KSTARG_CASE(8);
+        else if (a.D <= 12) SR_KSTARG_CASE(12);
+        else { sr_set_error("kstar: D=%d > %d", a.D, SR_MAX_D); return SR_EUNSUPPORTED; }
+#undef SR_KSTARG_CASE
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
 #define SR_KSTAR_CASE(DT) \
     hipLaunchKernelGGL(sr_kstar_kernel<DT>, grid, dim3(256), 0, s, a)
     if (a.D <= 3) SR_KSTAR_CASE(3);
@@ -411,7 +519,7 @@ __global__ __launch_bounds__(256) void sr_finalize_kernel(sr_final_args a) {
     for (int s = 0; s < a.nsplit; ++s) m += a.mu_part[((long)s * a.n_out + d) * a.Tp + t];
     double q = 0.0;
     for (int rb = 0; rb < a.nrb; ++rb) q += a.var_part[((long)d * a.nrb + rb) * a.Tp + t];
-    double v = a.sf2[d] - q;
+    double v = (a.kxx ? a.kxx[(long)d * a.Tp + t] : a.sf2[d]) - q;
     if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
     a.mu[t * a.n_out + d] = m;
     a.var[t * a.n_out + d] = v;

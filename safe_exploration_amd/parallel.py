@@ -59,7 +59,8 @@ def replicate_model(gp, prob, src=0):
     got = broadcast_tensors(payload, src=src, device=dev)
     if rank == src:
         return gp
-    local = SimpleGPModel(n_s, n_s, D - n_s, kern_types=["rbf"] * n_s, hyp=hyp_list(prob), device=dev)
+    local = SimpleGPModel(n_s, n_s, D - n_s, kern_types=prob.get("kern_types", ["rbf"] * n_s),
+                          hyp=prob.get("hyp", None) or hyp_list(prob), device=dev)
     local.import_state(got["Z"].cpu().numpy(), got["Y"].cpu().numpy(), got["alpha"], got["wt"])
     return local
 

@@ -9,7 +9,7 @@ include/safereach.h (Gram + blocked fp64-MFMA Cholesky at model-update time; fus
 cross-covariance / triangular contraction kernels at prediction time).
 
 Not on the hot path and therefore not provided: hyper-parameter optimisation (``opt_hyp=True``),
-sparse GP, ``sample_from_gp``, ``information_gain``, non-RBF kernels (ranked "next").
+sparse GP, ``sample_from_gp``, ``information_gain``.
 """
 import ctypes
 import warnings
@@ -81,7 +81,10 @@ class SimpleGPModel(StateSpaceModel):
 
     # ------------------------------------------------------------------ construction helpers
     def _init_kernel_function(self, kern_types=None, hyp=None):
-        """Kernel bookkeeping (ssm_gpy/gaussian_process.py:421-489).  Only "rbf" is on the hot path."""
+        """Kernel bookkeeping (ssm_gpy/gaussian_process.py:421-489, hyper-parameter key names of
+        ``_create_hyp_dict`` :491-544).  Supported identifiers: "rbf", "mat52" (ARD over all inputs),
+        "lin_rbf", "lin_mat52" (linear x stationary on input dimension 1 + ARD linear, the structure
+        the reference's in-tree formulas evaluate: gp_models_utils_casadi.py:72-128)."""
         D = self.n_s_in + self.n_u
         if kern_types is None:
             kern_types = ["rbf"] * self.n_s_out
@@ -89,25 +92,55 @@ class SimpleGPModel(StateSpaceModel):
             hyp = [None] * self.n_s_out
         if len(kern_types) != self.n_s_out or len(hyp) != self.n_s_out:
             raise ValueError("kern_types / hyp need one entry per output dimension")
+
+        def vec(h, key, n, default=1.0):
+            v = np.reshape(np.asarray(h.get(key, default), dtype=np.float64), (-1,))
+            if v.size == 1:
+                v = np.full(n, float(v[0]))
+            if v.size != n:
+                raise ValueError("{} needs {} entries".format(key, n))
+            return v
+
+        def scal(h, key, default=1.0):
+            return float(np.asarray(h.get(key, default), dtype=np.float64).reshape(-1)[0])
+
         hyp_out = []
         self._noise = np.empty(self.n_s_out)
         for i in range(self.n_s_out):
-            if kern_types[i] != "rbf":
-                if kern_types[i] in ("mat52", "lin_rbf", "lin_mat52"):
-                    raise NotImplementedError("kernel type '{}' is not on the MI355X hot path yet "
-                                              "(north_star: RBF)".format(kern_types[i]))
-                raise ValueError("kernel type '{}' not supported".format(kern_types[i]))
+            kt = kern_types[i]
             h = dict(hyp[i]) if hyp[i] is not None else {}
-            ls = np.reshape(np.asarray(h.get("lengthscale", np.ones(D)), dtype=np.float64), (-1,))
-            if ls.size == 1:
-                ls = np.full(D, float(ls[0]))
-            if ls.size != D:
-                raise ValueError("lengthscale needs {} entries".format(D))
-            var = float(np.asarray(h.get("variance", 1.0)).reshape(-1)[0])
-            self._noise[i] = float(np.asarray(h.get("noise_variance", 1.0)).reshape(-1)[0])
-            hyp_out.append({"lengthscale": ls, "variance": var})
+            self._noise[i] = scal(h, "noise_variance")
+            if kt in ("rbf", "mat52"):
+                hyp_out.append({"lengthscale": vec(h, "lengthscale", D), "variance": scal(h, "variance")})
+            elif kt in ("lin_rbf", "lin_mat52"):
+                st = "rbf" if kt == "lin_rbf" else "mat52"
+                hyp_out.append({"prod.%s.lengthscale" % st: vec(h, "prod.%s.lengthscale" % st, 1),
+                                "prod.%s.variance" % st: scal(h, "prod.%s.variance" % st),
+                                "prod.linear.variances": vec(h, "prod.linear.variances", 1),
+                                "linear.variances": vec(h, "linear.variances", D)})
+            else:
+                raise ValueError("kernel type '{}' not supported".format(kt))
         self.kern_types = list(kern_types)
         self.hyp = hyp_out
+
+    def _pack_kernel_params(self):
+        """(n_out, 3+3D) packed parameters of sr_gp_set_data_general:
+        [kappa, v, c0, s[D], a[D], b[D]] with k = (c0 + sum a x y) v kappa(r) + sum b x y."""
+        D = self.n_s_in + self.n_u
+        kp = np.zeros((self.n_s_out, 3 + 3 * D))
+        for i, (kt, h) in enumerate(zip(self.kern_types, self.hyp)):
+            if kt in ("rbf", "mat52"):
+                kp[i, 0] = 0.0 if kt == "rbf" else 1.0
+                kp[i, 1], kp[i, 2] = h["variance"], 1.0
+                kp[i, 3:3 + D] = 1.0 / h["lengthscale"]
+            else:
+                st = "rbf" if kt == "lin_rbf" else "mat52"
+                kp[i, 0] = 0.0 if st == "rbf" else 1.0
+                kp[i, 1], kp[i, 2] = h["prod.%s.variance" % st], 0.0
+                kp[i, 3 + 1] = 1.0 / h["prod.%s.lengthscale" % st][0]          # stationary factor: input dim 1
+                kp[i, 3 + D + 1] = h["prod.linear.variances"][0]               # product-linear factor: dim 1
+                kp[i, 3 + 2 * D:3 + 3 * D] = h["linear.variances"]
+        return kp
 
     @classmethod
     def from_dict(cls, gp_dict):
@@ -193,18 +226,26 @@ class SimpleGPModel(StateSpaceModel):
         dev = B.resolve_device(self._device_arg)
         N, D = Z.shape
         handle = _Handle(dev, N, D, self.n_s_out)
-        ls = np.stack([h["lengthscale"] for h in self.hyp])
-        sf2 = np.array([h["variance"] for h in self.hyp])
         # diagonal term: sigma_n^2 + noise_diag (gaussian_process.py:252-253) + GPy's internal jitter
         noise = self._noise + float(noise_diag) + GPY_JITTER
         s = B.stream_ptr(dev)
-        tz, ty, tl, tf, tn = (B.as_dev(a, dev) for a in (Z, Y, ls, sf2, noise))
-        check(lib.sr_gp_set_data(handle.h, B.ptr(tz), B.ptr(ty), B.ptr(tl), B.ptr(tf), B.ptr(tn), s))
+        self._set_data(handle, Z, Y, noise, dev, s)
         info = (ctypes.c_int * self.n_s_out)()
         check(lib.sr_gp_factorize(handle.h, s, info))
         self._handle = handle
         self._beta = None
         self._inv_K = None
+
+    def _set_data(self, handle, Z, Y, noise, dev, s):
+        tz, ty, tn = (B.as_dev(a, dev) for a in (Z, Y, noise))
+        if all(kt == "rbf" for kt in self.kern_types):          # ARD-RBF fast path (north_star kernel)
+            ls = np.stack([h["lengthscale"] for h in self.hyp])
+            sf2 = np.array([h["variance"] for h in self.hyp])
+            tl, tf = B.as_dev(ls, dev), B.as_dev(sf2, dev)
+            check(lib.sr_gp_set_data(handle.h, B.ptr(tz), B.ptr(ty), B.ptr(tl), B.ptr(tf), B.ptr(tn), s))
+        else:
+            tk = B.as_dev(self._pack_kernel_params(), dev)
+            check(lib.sr_gp_set_data_general(handle.h, B.ptr(tz), B.ptr(ty), B.ptr(tk), B.ptr(tn), s))
 
     # ------------------------------------------------------------------ cached posterior state
     def _need_trained(self):
@@ -259,12 +300,9 @@ class SimpleGPModel(StateSpaceModel):
         Y = np.asarray(Y, dtype=np.float64)
         N, D = Z.shape
         handle = _Handle(dev, N, D, self.n_s_out)
-        ls = np.stack([h["lengthscale"] for h in self.hyp])
-        sf2 = np.array([h["variance"] for h in self.hyp])
         noise = self._noise + float(noise_diag) + GPY_JITTER
         s = B.stream_ptr(dev)
-        tz, ty, tl, tf, tn = (B.as_dev(a, dev) for a in (Z, Y, ls, sf2, noise))
-        check(lib.sr_gp_set_data(handle.h, B.ptr(tz), B.ptr(ty), B.ptr(tl), B.ptr(tf), B.ptr(tn), s))
+        self._set_data(handle, Z, Y, noise, dev, s)
         ta = B.as_dev(alpha, dev, (self.n_s_out, N))
         tw = B.as_dev(wt, dev, (self.n_s_out, handle.Np, handle.Np))
         check(lib.sr_gp_import(handle.h, B.ptr(ta), B.ptr(tw), s))

@@ -176,6 +176,41 @@ def main():
     gp_case("gp_pend.npz", 101, 60, 2, 1, 33)
     gp_case("gp_cart.npz", 102, 90, 4, 1, 20)
 
+    # ------------------------------------------------------------------ 3b. non-RBF kernel types (8(f).1)
+    for kt in ("mat52", "lin_rbf", "lin_mat52"):
+        rng = np.random.default_rng({"mat52": 301, "lin_rbf": 302, "lin_mat52": 303}[kt])
+        n_s, n_u, N, T = 2, 1, 50, 21
+        D = n_s + n_u
+        Z = rng.uniform(-1, 1, (N, D))
+        Y = np.sin(2.0 * Z.dot(rng.standard_normal((D, n_s)))) + 0.05 * rng.standard_normal((N, n_s))
+        x_new = 0.5 * rng.standard_normal((T, D))
+        hyp = [orc.make_hyp(kt, rng, D) for _ in range(n_s)]
+        noise = np.full(n_s, 1e-2 + 1e-5)
+        beta, inv_K = orc.gp_fit_k(Z, Y, [kt] * n_s, hyp, noise)
+        mu, var = orc.gp_predict_k(x_new, Z, beta, inv_K, [kt] * n_s, hyp)
+        ref_mu = np.empty_like(mu); ref_var = np.empty_like(var)
+        ref_K0 = None
+        for d in range(n_s):
+            kern = gpu._get_kernel_function(kt, hyp[d])
+            Kref = np.asarray(kern(x_new, y=Z))
+            assert np.allclose(Kref, orc.kernel_matrix(kt, hyp[d], x_new, Z), rtol=1e-12, atol=1e-14), kt
+            if d == 0:
+                ref_K0 = Kref      # (k(Z,Z) is not taken from the reference: its unclipped sqrt(r2) gives NaN
+                #                    on the diagonal whenever -2xy+x^2+y^2 rounds below zero)
+            for t in range(T):
+                m_t, s_t = gpu.gp_pred(x_new[t:t + 1], kern, beta[:, d:d + 1], Z, inv_K[d], True)
+                ref_mu[t, d] = np.asarray(m_t).item()
+                ref_var[t, d] = np.asarray(s_t).item()
+        assert np.allclose(ref_mu, mu, rtol=1e-11, atol=1e-12), kt
+        assert np.allclose(ref_var, var, rtol=0, atol=1e-10), (kt, np.abs(ref_var - var).max())
+        flat = {}
+        for d in range(n_s):
+            for k, v in hyp[d].items():
+                flat["hyp%d_%s" % (d, k)] = np.asarray(v)
+        _save("kern_%s.npz" % kt, Z=Z, Y=Y, x_new=x_new, noise_var=noise, beta=beta, mu=mu, var=var,
+              ref_mu=ref_mu, ref_var=ref_var, ref_kstar0=ref_K0,
+              jac_fd=orc.gp_mean_jacobian_fd(x_new, Z, beta, [kt] * n_s, hyp), **flat)
+
     # ------------------------------------------------------------------ 4. reachability through the reference
     def reach_case(name, seed, N, n_s, n_u, T, H, l_mu, l_sigma, c_safety, a_scale=1.0, sf2=1.0):
         syn = orc.make_synthetic(seed, N, n_s, n_u, T, sf2=sf2)

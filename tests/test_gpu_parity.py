@@ -422,3 +422,66 @@ def test_splitk_path_matches_plain_path(N, T):
     om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
     _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
     np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
+
+
+def _kern_hyp(g, kt, n_out=2):
+    hyp = []
+    for d in range(n_out):
+        pref = "hyp%d_" % d
+        hyp.append({k[len(pref):]: g[k] for k in g.files if k.startswith(pref)})
+    return hyp
+
+
+@pytest.mark.parametrize("kt", ["mat52", "lin_rbf", "lin_mat52"])
+def test_non_rbf_kernels_vs_reference_formulas(kt):
+    """Matern-5/2 and the linear x stationary + linear kernels.  Fixtures hold the
+    outputs of the reference's own _k_mat52/_k_lin/_k_lin_rbf/_k_lin_mat52 + gp_pred on numbers."""
+    from safe_exploration_amd import SimpleGPModel
+    g = load_golden("kern_%s.npz" % kt)
+    hyp = _kern_hyp(g, kt)
+    for h, nv in zip(hyp, g["noise_var"]):
+        h["noise_variance"] = nv - 1e-5
+    gp = SimpleGPModel(2, 2, 1, kern_types=[kt] * 2, hyp=hyp)
+    gp.train(g["Z"], g["Y"], opt_hyp=False)
+    np.testing.assert_allclose(gp.beta, g["beta"], rtol=1e-7, atol=1e-9 * np.abs(g["beta"]).max())
+    mu, var, jac = gp.predict(g["x_new"], None, True)
+    scale = np.abs(g["beta"]).sum(0).max()
+    np.testing.assert_allclose(mu, g["ref_mu"], rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(var, g["ref_var"], rtol=0, atol=1e-8 * max(1.0, float(g["ref_var"].max())))
+    np.testing.assert_allclose(jac, g["jac_fd"], rtol=2e-5, atol=1e-6 * scale)    # central differences
+    # the Gram matrix the factorisation saw: K^-1 from the device vs the reference's kernel matrix
+    np.testing.assert_allclose(orc.kernel_matrix(kt, hyp[0], g["x_new"], g["Z"]), g["ref_kstar0"], rtol=1e-12, atol=1e-14)
+    Ky = orc.kernel_matrix(kt, hyp[0], g["Z"], g["Z"]) + (g["noise_var"][0] + 1e-8) * np.eye(g["Z"].shape[0])
+    np.testing.assert_allclose(gp.inv_K[0].dot(Ky), np.eye(Ky.shape[0]), rtol=0, atol=1e-6)
+    m1, s1, j1 = gp(g["x_new"][2:3, :2], g["x_new"][2:3, 2:])
+    np.testing.assert_allclose(m1[:, 0], g["ref_mu"][2], rtol=1e-9, atol=1e-11 * scale)
+    with pytest.raises(NotImplementedError):
+        gp.linearize_predict(g["x_new"][:1, :2], g["x_new"][:1, 2:], True)
+
+
+def test_reachability_with_lin_mat52_kernel():
+    """the journal experiments' kernel through the fused path == predict + ellipsoid kernel, and the
+    oracle's algebra on the same GP outputs."""
+    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach
+    g = load_golden("kern_lin_mat52.npz")
+    hyp = _kern_hyp(g, "lin_mat52")
+    for h, nv in zip(hyp, g["noise_var"]):
+        h["noise_variance"] = nv - 1e-5
+    gp = SimpleGPModel(2, 2, 1, kern_types=["lin_mat52"] * 2, hyp=hyp)
+    gp.train(g["Z"], g["Y"], opt_hyp=False)
+    T = g["x_new"].shape[0]
+    rng = np.random.default_rng(8)
+    p, kff = g["x_new"][:, :2], g["x_new"][:, 2:]
+    kfb = 0.1 * rng.standard_normal((T, 1, 2))
+    A = rng.standard_normal((T, 2, 2))
+    Q = 0.01 * np.einsum('tij,tkj->tik', A, A) + 0.01 * np.eye(2)[None]
+    l = np.array([0.05, 0.02])
+    p1, q1 = reach.onestep_reachability_batch(p, gp, kff, l, l, Q, kfb, 2.0, check_bounds=True)
+    mu, var, jac = gp.predict(g["x_new"], None, True)
+    p2, q2 = reach.ellipsoid_step_batch(p, kff, mu, var, jac, l, l, Q, kfb, 2.0)
+    np.testing.assert_allclose(p1, p2, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(q1, q2, rtol=1e-12, atol=1e-16)
+    for t in range(T):
+        rp, rq = orc.onestep_reachability_from_gp(p[t], Q[t], kff[t], kfb[t], mu[t], var[t], jac[t], l, l, 2.0,
+                                                  np.eye(2), np.zeros((2, 1)))
+        np.testing.assert_allclose(q1[t], rq, rtol=1e-11, atol=1e-15)

@@ -61,8 +61,12 @@ def test_simple_gp_model_surface(lib_built):
     assert set(gp.hyp[0]) == {"lengthscale", "variance"} and gp.hyp[0]["lengthscale"].shape == (3,)
     with pytest.raises(ValueError):
         SimpleGPModel(2, 2, 1, kern_types=["rbf", "nope"])
-    with pytest.raises(NotImplementedError):
-        SimpleGPModel(2, 2, 1, kern_types=["rbf", "lin_mat52"])
+    g = SimpleGPModel(2, 2, 1, kern_types=["mat52", "lin_mat52"])
+    assert set(g.hyp[1]) == {"prod.mat52.lengthscale", "prod.mat52.variance", "prod.linear.variances",
+                             "linear.variances"}
+    kp = g._pack_kernel_params()
+    assert kp.shape == (2, 12) and kp[0, 0] == 1.0 and kp[0, 2] == 1.0 and kp[1, 2] == 0.0
+    assert kp[1, 3 + 1] == 1.0 and kp[1, 3 + 0] == 0.0 and kp[1, 3 + 3 + 1] == 1.0     # product part on dim 1
     with pytest.raises(NotImplementedError):                  # opt_hyp=True is outside the hot path
         gp.train(np.zeros((4, 3)), np.zeros((4, 2)))
     with pytest.raises(ValueError):

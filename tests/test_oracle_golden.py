@@ -156,3 +156,21 @@ def test_anchor_numbers_of_the_survey():
     np.testing.assert_allclose(q1, g["q_ell"], rtol=1e-13)
     um, us = orc.compute_remainder_overapproximations(g["Q"], g["k_fb"], g["l"], g["l"])
     np.testing.assert_allclose(um, [0.0080762036885, 0.0032304814754], rtol=1e-10)
+
+
+@pytest.mark.parametrize("kt", ["mat52", "lin_rbf", "lin_mat52"])
+def test_non_rbf_kernels_oracle_vs_reference(kt):
+    """oracle kernels == the reference's _k_mat52/_k_lin/_k_lin_rbf/_k_lin_mat52 + gp_pred outputs."""
+    g = load_golden("kern_%s.npz" % kt)
+    hyp = []
+    for d in range(2):
+        pref = "hyp%d_" % d
+        hyp.append({k[len(pref):]: g[k] for k in g.files if k.startswith(pref)})
+    np.testing.assert_allclose(orc.kernel_matrix(kt, hyp[0], g["x_new"], g["Z"]), g["ref_kstar0"], rtol=1e-12, atol=1e-14)
+    beta, inv_K = orc.gp_fit_k(g["Z"], g["Y"], [kt] * 2, hyp, g["noise_var"])
+    mu, var = orc.gp_predict_k(g["x_new"], g["Z"], beta, inv_K, [kt] * 2, hyp)
+    np.testing.assert_allclose(mu, g["ref_mu"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(var, g["ref_var"], rtol=0, atol=1e-9)
+    # k(x,x) of the linear kernels is not constant
+    kd = orc.kernel_diag(kt, hyp[0], g["x_new"])
+    np.testing.assert_allclose(kd, np.diag(orc.kernel_matrix(kt, hyp[0], g["x_new"], g["x_new"])), rtol=1e-10, atol=1e-12)
