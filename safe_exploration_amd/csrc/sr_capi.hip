@@ -403,7 +403,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         // latency regime: stream U^-1 once (HBM-bound) instead of the MFMA tiles
         if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, s));
+        SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, (int)Tc, s));
         nrb = (h->Np + 255) / 256;
     } else if (h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) {
         // few query tiles: split the K range so that no workgroup serialises a whole row block

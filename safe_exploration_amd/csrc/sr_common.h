@@ -155,7 +155,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #define SR_SMALL_T 16
 long sr_var_small_ws(int Np, int n_out);
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
-                        long Tp, int n_out, hipStream_t s);
+                        long Tp, int n_out, int T, hipStream_t s);
 
 int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, hipStream_t s);
 

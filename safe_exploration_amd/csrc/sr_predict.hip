@@ -404,11 +404,12 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //   pass 2: part[cb][t]     = sum_{i in column block cb} (sum_chunks Vp)^2     (layout of sr_finalize)
 // ------------------------------------------------------------------------------------------------
 #define SR_TS 16
+template <int TQ>   // live queries handled: 1, 4 or SR_TS (outputs are always laid out for SR_TS)
 __global__ __launch_bounds__(256) void sr_var_small_partial_kernel(const double* __restrict__ Wt,
                                                                    const double* __restrict__ Ks,
                                                                    double* __restrict__ Vp, int Np,
                                                                    long Tp, int npairs, int k_lo) {
-    __shared__ double ks[128][SR_TS];
+    __shared__ double ks[128][TQ];
     const int d = blockIdx.y;
     const int p = blockIdx.x;                       // pair index: column block cb, k-chunk j <= 2 cb + 1
     int cb = (int)((sqrt(4.0 * p + 1.0) - 1.0) * 0.5);
@@ -418,26 +419,35 @@ __global__ __launch_bounds__(256) void sr_var_small_partial_kernel(const double*
     const int k0 = j * 128;
     const int i = cb * 256 + threadIdx.x;
     const double* ksrc = Ks + (long)d * Np * Tp + (long)k0 * Tp;
-    for (int e = threadIdx.x; e < 128 * SR_TS; e += 256) {
-        const int r = e / SR_TS, t = e % SR_TS;
+    for (int e = threadIdx.x; e < 128 * TQ; e += 256) {
+        const int r = e / TQ, t = e % TQ;
         ks[r][t] = (k0 + r < Np) ? ksrc[(long)r * Tp + t] : 0.0;
     }
     __syncthreads();
-    double acc[SR_TS];
+    double acc[TQ];
 #pragma unroll
-    for (int t = 0; t < SR_TS; ++t) acc[t] = 0.0;
+    for (int t = 0; t < TQ; ++t) acc[t] = 0.0;
     const double* w = Wt + (long)d * Np * Np + (long)k0 * Np + i;
     const int kmax = (i < Np) ? min(127, i - k0) : -1;   // rows k0 .. k0 + kmax have k <= i
     const int kbeg = max(0, k_lo - k0);             // leading padding rows carry K* == 0
-#pragma unroll 4
-    for (int r = kbeg; r <= kmax; ++r) {
+    int r = kbeg;
+    for (; r + 7 <= kmax; r += 8) {                 // 8 independent 2 KiB row segments in flight per wavefront
+        double wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w[(long)(r + u) * Np];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) acc[t] = fma(wv[u], ks[r + u][t], acc[t]);
+    }
+    for (; r <= kmax; ++r) {
         const double wv = w[(long)r * Np];
 #pragma unroll
-        for (int t = 0; t < SR_TS; ++t) acc[t] = fma(wv, ks[r][t], acc[t]);
+        for (int t = 0; t < TQ; ++t) acc[t] = fma(wv, ks[r][t], acc[t]);
     }
     double* out = Vp + ((long)d * npairs + p) * SR_TS * 256;
 #pragma unroll
-    for (int t = 0; t < SR_TS; ++t) out[t * 256 + threadIdx.x] = acc[t];
+    for (int t = 0; t < SR_TS; ++t) out[t * 256 + threadIdx.x] = (t < TQ) ? acc[t < TQ ? t : 0] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void sr_var_small_reduce_kernel(const double* __restrict__ Vp,
@@ -495,12 +505,19 @@ long sr_var_small_ws(int Np, int n_out) {
 }
 
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
-                        long Tp, int n_out, hipStream_t s) {
+                        long Tp, int n_out, int T, hipStream_t s) {
     const int ncb = (Np + 255) / 256;              // Np is a multiple of 128: the last block may be half empty
     const int npairs = ncb * (ncb + 1);
     const int k_lo = Np - N;
-    hipLaunchKernelGGL(sr_var_small_partial_kernel, dim3(npairs, n_out), dim3(256), 0, s, Wt, Ks, Vp, Np,
-                       Tp, npairs, k_lo);
+    if (T <= 1)
+        hipLaunchKernelGGL(sr_var_small_partial_kernel<1>, dim3(npairs, n_out), dim3(256), 0, s, Wt, Ks, Vp,
+                           Np, Tp, npairs, k_lo);
+    else if (T <= 4)
+        hipLaunchKernelGGL(sr_var_small_partial_kernel<4>, dim3(npairs, n_out), dim3(256), 0, s, Wt, Ks, Vp,
+                           Np, Tp, npairs, k_lo);
+    else
+        hipLaunchKernelGGL(sr_var_small_partial_kernel<SR_TS>, dim3(npairs, n_out), dim3(256), 0, s, Wt, Ks,
+                           Vp, Np, Tp, npairs, k_lo);
     SR_HIP(hipGetLastError());
     hipLaunchKernelGGL(sr_var_small_reduce_kernel, dim3(ncb, n_out), dim3(256), 0, s, Vp, part, Tp, npairs,
                        ncb);

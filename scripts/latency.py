@@ -38,6 +38,17 @@ def main():
             out["N%d_T%d_predict_us" % (N, T)] = round(timeit(lambda: gp.predict_device(x, True)), 1)
             out["N%d_T%d_onestep_us" % (N, T)] = round(
                 timeit(lambda: reach.onestep_reachability_batch(tp, gp, tkff, l, l, tq, tkfb, 2.0)), 1)
+        # HBM roofline of the single-query path: bytes of U^-1 streamed / time of the variance launches
+        x = B.as_dev(np.hstack((prob["p"][:1], prob["k_ff"][:1])), dev)
+        gp.prof_reset(); gp.prof_enable(True)
+        for _ in range(20):
+            gp.predict_device(x, True)
+        gp.prof_enable(False)
+        from safe_exploration_amd import _lib
+        ms, n = gp.prof_get(_lib.K_VAR)
+        Np = gp._handle.Np
+        out["N%d_T1_var_kernels_us" % N] = round(1e3 * ms / max(n, 1), 1)
+        out["N%d_T1_var_GBps" % N] = round(2 * (Np * (Np + 1) / 2) * 8 / (ms / max(n, 1) * 1e-3) / 1e9, 1)
         x1 = B.as_dev(np.hstack((prob["p"][0], prob["k_ff"][0])), dev)
         out["N%d_linearize_us" % N] = round(timeit(lambda: gp.linearize_device(x1)), 1)
         out["N%d_call_numpy_us" % N] = round(timeit(lambda: gp(prob["p"][:1], prob["k_ff"][:1])), 1)

@@ -485,3 +485,30 @@ def test_reachability_with_lin_mat52_kernel():
         rp, rq = orc.onestep_reachability_from_gp(p[t], Q[t], kff[t], kfb[t], mu[t], var[t], jac[t], l, l, 2.0,
                                                   np.eye(2), np.zeros((2, 1)))
         np.testing.assert_allclose(q1[t], rq, rtol=1e-11, atol=1e-15)
+
+
+def test_full_size_headline_config():
+    """The headline configuration itself (C2': N=5000, T=65536): a 2048-query sample against the oracle
+    (explicit-inverse route, factorised on the CPU) plus positivity / symmetry of every result."""
+    from safe_exploration_amd import gp_reachability as reach
+    N, T = 5000, 65536
+    syn = orc.make_synthetic(5, N, 2, 1, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    l = np.array([0.05, 0.02])
+    p1, q1, var = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0,
+                                                   return_var=True)
+    assert np.all(np.isfinite(q1)) and var.min() > 0 and var.max() <= 1.0 + 1e-12
+    assert np.linalg.eigvalsh(q1).min() > 0
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    idx = np.random.default_rng(0).choice(T, 2048, replace=False)
+    rp, rq, rvar = orc.onestep_reachability_vectorised(om, syn["p"][idx], syn["Q"][idx], syn["k_ff"][idx],
+                                                       syn["k_fb"][idx], l, l, 2.0, np.eye(2), np.zeros((2, 1)))
+    np.testing.assert_allclose(p1[idx], rp, rtol=1e-9, atol=max(mu_atol(om), 1e-12))
+    np.testing.assert_allclose(var[idx], rvar, rtol=0, atol=1e-9)        # 1e-9 * sigma_f^2 (SURVEY 8d)
+    # Q1 inherits the variance difference through n_s c^2 (sigma+u)/sigma (1+1/c2) <~ 30:
+    # cond(K_y) ~ N sf2/sn2 = 5e5 makes the explicit-inverse oracle itself uncertain at the 1e-10 level
+    np.testing.assert_allclose(q1[idx], rq, rtol=1e-8, atol=30 * 1e-9)
+    # the oracle's second (triangular-solve) route agrees with the HIP factor route far more tightly
+    x = np.hstack((syn["p"][idx[:256]], syn["k_ff"][idx[:256]]))
+    _, cvar = orc.gp_predict_chol(x, om["Z"], om["beta"], om["chol"], om["lengthscale"], om["signal_var"])
+    np.testing.assert_allclose(var[idx[:256]], cvar, rtol=0, atol=2e-11)
