@@ -76,10 +76,22 @@ def cpu_baseline(prob, l_mu, l_sigma, budget_s=12.0):
         if dt > budget_s / 3 or Ts * 2 > prob["p"].shape[0]:
             break
         Ts *= 2
+    # how the reference is actually driven (gp_reachability.py:199-210): one Python call per query
+    nq = 32
+    t0 = time.time()
+    for t in range(nq):
+        z = np.hstack((prob["p"][t], prob["k_ff"][t]))
+        mu, var, jac = orc._predict_one(model, z)
+        orc.onestep_reachability_from_gp(prob["p"][t], prob["Q"][t], prob["k_ff"][t], prob["k_fb"][t], mu, var,
+                                         jac, l_mu, l_sigma, C_SAFETY, a, b)
+    loop_rate = nq / (time.time() - t0)
     return {"value": done / spent, "unit": "evals/s", "cores": int(thr), "kind": "port",
             "sample": "first %d of the same T query states, N=%d; vectorised NumPy/SciPy oracle "
                       "(explicit inv_K route of the reference), %.1f s timed; model fit (%.1f s) excluded"
-                      % (done, prob["Z"].shape[0], spent, fit_s)}
+                      % (done, prob["Z"].shape[0], spent, fit_s),
+            "per_query_loop_value": loop_rate,
+            "per_query_loop_note": "reference-style driving pattern: one onestep call per query (%d queries, "
+                                   "BLAS threads as above)" % nq}
 
 
 def main():
