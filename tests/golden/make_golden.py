@@ -290,6 +290,57 @@ def main():
     reach_case("reach_cart.npz", 202, 90, 4, 1, 16, 15, np.array([0.05] * 4), np.array([0.05] * 4), 2.0, a_scale=0.5, sf2=0.01)
     reach_case("reach_n3u2.npz", 203, 40, 3, 2, 8, 3, np.array([0.01] * 3), np.array([0.02] * 3), 1.5)
 
+    # ------------------------------------------------------------------ 4b. the reference tests' canonical scenarios
+    # on the reference's OWN data files (copied as data: tests/golden/ref_invpend_data.npz = test/invpend_data.npz,
+    # ref_data_cartpole.npz = test/data_cartpole.npz).  test_gp_reachability_casadi.py:30-67: seed 125, m = 50 random
+    # points, c_safety 2, L = 0.001, q = .2 [[.5,.2],[.2,.65]], random a, b, k_fb, k_ff, p = .1 randn, T = 3 chain.
+    # test_safempc.py:56-69,131-133: cart-pole data, 20 points, q = 0.1 I, the file's own linear model a, b.
+    # The hyper-parameters are FIXED here (the reference optimises them inside GPy, which cannot run).
+    def ref_scenario(name, data_file, n_s, n_u, m, seed, Lc, q0, hyp_ls, hyp_sf2, hyp_sn2, use_file_ab):
+        data = np.load(os.path.join(HERE, data_file))
+        X, y = data["X"], data["y"]
+        np.random.seed(seed)
+        a_lin = np.random.rand(n_s, n_s) if not use_file_ab else np.asarray(data["a"], dtype=np.float64)
+        b_lin = np.random.rand(n_s, n_u) if not use_file_ab else np.asarray(data["b"], dtype=np.float64)
+        idx = np.random.choice(X.shape[0], size=m, replace=False)
+        Z, Yz = X[idx], y[idx]
+        k_fb = np.random.rand(n_u, n_s)
+        k_ff = np.random.rand(n_u, 1)
+        p = .1 * np.random.randn(n_s, 1)
+        T = 3
+        u_0 = .2 * np.random.randn(n_u, 1)
+        k_fb_0 = np.random.randn(T - 1, n_s * n_u)
+        k_ff_m = np.random.randn(T - 1, n_u)
+        k_ff_all = np.vstack((u_0.T, k_ff_m))
+        k_fb_apply = k_fb_0.reshape(-1, n_u, n_s) + k_fb[None]
+        D = n_s + n_u
+        ls = np.full((n_s, D), hyp_ls); sf2 = np.full(n_s, hyp_sf2); noise = np.full(n_s, hyp_sn2 + 1e-5)
+        beta, inv_K, _ = orc.gp_fit(Z, Yz, ls, sf2, noise)
+        model = dict(Z=Z, beta=beta, inv_K=inv_K, lengthscale=ls, signal_var=sf2)
+
+        def ssm(states, actions):
+            z = np.ascontiguousarray(np.hstack((np.asarray(states), np.asarray(actions)))[0])
+            mm, vv, jj = orc._predict_one(model, z)
+            return mm[:, None], vv[:, None], jj
+
+        L = np.array([Lc] * n_s)
+        out = dict(Z=Z, Y=Yz, lengthscale=ls, signal_var=sf2, noise_var=noise, a_lin=a_lin, b_lin=b_lin, k_fb=k_fb,
+                   k_ff=k_ff, p=p, q0=q0, L=L, k_ff_all=k_ff_all, k_fb_apply=k_fb_apply)
+        for tag, (aa, bb) in {"id": (None, None), "lin": (a_lin, b_lin)}.items():
+            pp, qq = gr.onestep_reachability(p, ssm, k_ff, L, L, q0, k_fb, 2, 0, a=aa, b=bb)
+            out["p1_ell_" + tag], out["q1_ell_" + tag] = pp, np.real(qq)
+            pp, qq = gr.onestep_reachability(p, ssm, k_ff, L, L, None, k_fb, 2, 0, a=aa, b=bb)
+            out["p1_pt_" + tag], out["q1_pt_" + tag] = pp, np.real(qq)
+            _, _, pa, qa = gr.multistep_reachability(p, ssm, k_fb_apply, k_ff_all, L, L, None, 2, 0, aa, bb, None)
+            assert np.all(np.isfinite(qa))
+            out["ms_p_" + tag], out["ms_q_" + tag] = pa, qa
+        _save(name, **out)
+
+    ref_scenario("scen_invpend.npz", "ref_invpend_data.npz", 2, 1, 50, 125, 0.001,
+                 .2 * np.array([[.5, .2], [.2, .65]]), 0.6, 0.05, 1e-3, False)
+    ref_scenario("scen_cartpole.npz", "ref_data_cartpole.npz", 4, 1, 20, 125, 0.001, 0.1 * np.eye(4), 1.0, 0.05,
+                 1e-3, True)
+
     # ------------------------------------------------------------------ 5. worked anchor of SURVEY 8c
     p = np.array([[0.1], [-0.2]]); Q = 0.2 * np.array([[.5, .2], [.2, .65]])
     k_ff = np.array([[0.3]]); k_fb = np.array([[0.4, -0.1]])

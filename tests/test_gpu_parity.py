@@ -512,3 +512,23 @@ def test_full_size_headline_config():
     x = np.hstack((syn["p"][idx[:256]], syn["k_ff"][idx[:256]]))
     _, cvar = orc.gp_predict_chol(x, om["Z"], om["beta"], om["chol"], om["lengthscale"], om["signal_var"])
     np.testing.assert_allclose(var[idx[:256]], cvar, rtol=0, atol=2e-11)
+
+
+@pytest.mark.parametrize("name,n_s,n_u", [("scen_invpend.npz", 2, 1), ("scen_cartpole.npz", 4, 1)])
+def test_reference_test_scenarios_on_reference_data(name, n_s, n_u):
+    """the reference tests' canonical scenarios (its own data files, seed 125, c_safety 2, L = 0.001) through
+    the reference-compatible single-query API; expected values come from the imported reference functions."""
+    from safe_exploration_amd import gp_reachability as reach
+    g = load_golden(name)
+    gp = hip_model(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"], n_s, n_u)
+    for tag, a, b in (("id", None, None), ("lin", g["a_lin"], g["b_lin"])):
+        p1, q1 = reach.onestep_reachability(g["p"], gp, g["k_ff"], g["L"], g["L"], g["q0"], g["k_fb"], 2, 0, a=a, b=b)
+        np.testing.assert_allclose(p1, g["p1_ell_" + tag], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(q1, g["q1_ell_" + tag], rtol=1e-8)
+        p1, q1 = reach.onestep_reachability(g["p"], gp, g["k_ff"], g["L"], g["L"], None, g["k_fb"], 2, 0, a=a, b=b)
+        np.testing.assert_allclose(p1, g["p1_pt_" + tag], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(q1, g["q1_pt_" + tag], rtol=1e-8, atol=1e-14)
+        _, _, pa, qa = reach.multistep_reachability(g["p"], gp, g["k_fb_apply"], g["k_ff_all"], g["L"], g["L"], None,
+                                                    2, 0, a, b, None)
+        np.testing.assert_allclose(pa, g["ms_p_" + tag], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(qa, g["ms_q_" + tag], rtol=1e-6)

@@ -174,3 +174,22 @@ def test_non_rbf_kernels_oracle_vs_reference(kt):
     # k(x,x) of the linear kernels is not constant
     kd = orc.kernel_diag(kt, hyp[0], g["x_new"])
     np.testing.assert_allclose(kd, np.diag(orc.kernel_matrix(kt, hyp[0], g["x_new"], g["x_new"])), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["scen_invpend.npz", "scen_cartpole.npz"])
+def test_reference_test_scenarios_on_reference_data(name):
+    """canonical scenarios of test_gp_reachability_casadi.py:30-67 / test_safempc.py:56-69 on the
+    reference's own data files; outputs produced by the imported reference functions."""
+    g = load_golden(name)
+    m = _model(g)
+    n_s = g["p"].shape[0]
+    n_u = g["k_ff"].shape[0]
+    for tag, a, b in (("id", np.eye(n_s), np.zeros((n_s, n_u))), ("lin", g["a_lin"], g["b_lin"])):
+        p1, q1, _ = orc.onestep_reachability_batch(m, g["p"].T, g["q0"][None], g["k_ff"].T, g["k_fb"][None],
+                                                   g["L"], g["L"], 2.0, a, b)
+        np.testing.assert_allclose(p1[0], g["p1_ell_" + tag][:, 0], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(q1[0], g["q1_ell_" + tag], rtol=1e-10)
+        pa, qa = orc.multistep_reachability_batch(m, g["p"].T, g["k_fb_apply"][None], g["k_ff_all"][None], g["L"],
+                                                  g["L"], None, 2.0, a, b, None)
+        np.testing.assert_allclose(pa[0], g["ms_p_" + tag], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(qa[0], g["ms_q_" + tag], rtol=1e-8)
