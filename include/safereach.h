@@ -72,6 +72,13 @@ int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* Y, const do
  * Synchronises the stream before returning. */
 int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
 
+/* Condition on m <= 128 ADDITIONAL training points (same hyper-parameters) without refactorising:
+ * block row append of the triangular factor, O(N^2 m).  Znew m x D, Ynew m x n_out.
+ * replaces: update_model(x, y, opt_hyp=False, replace_old=False)  ssm_gpy/gaussian_process.py:347-419
+ * (the reference refactorises; its own row-append sketch is ssm_pytorch/utilities.py:74-117).
+ * info [host, n_out] like sr_gp_factorize.  On success N grows by m and Np may grow. */
+int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info);
+
 /* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and
  * columns are at the FRONT (identity block): training point i has padded index i + (Np - N). */
 int sr_gp_padded_n(sr_gp_t h, long* Np);

@@ -684,3 +684,136 @@ extern "C" int sr_prof_get(sr_gp_t h, int kernel_id, double* ms_total, long* lau
     if (launches) *launches = h->prof.launches[kernel_id];
     return SR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// block row append: condition on m <= 128 additional training points without
+// refactorising.  K1 = [K B; B^T C]  =>  U1 = [U U12; 0 U22],  U12 = U^-T B,  U22^T U22 = C - U12^T U12,
+//                 U1^-1 = [U^-1  -U^-1 U12 U22^-1; 0  U22^-1].   O(N^2 m) instead of O(N^3).
+// ---------------------------------------------------------------------------------------------
+__global__ void sr_append_queries_kernel(const double* __restrict__ Znew, double* __restrict__ Xq, int m, int D) {
+    // 128 query rows, front padded with copies of the first new point (their columns are never used)
+    const int t = blockIdx.x, j = threadIdx.x;
+    if (j >= D) return;
+    const int pf = SR_NB - m;
+    Xq[t * D + j] = Znew[(t < pf ? 0 : t - pf) * D + j];
+}
+
+__global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int N0, const double* __restrict__ Ynew,
+                                   int m, double* __restrict__ yT1, int Np1, int n_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+    if (i >= Np1) return;
+    const int off1 = Np1 - (N0 + m), off0 = Np0 - N0;
+    double v = 0.0;
+    if (i >= off1) {
+        const int k = i - off1;
+        v = (k < N0) ? yT0[(long)d * Np0 + off0 + k] : Ynew[(long)(k - N0) * n_out + d];
+    }
+    yT1[(long)d * Np1 + i] = v;
+}
+
+extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info) {
+    SR_CHECK(h != nullptr && Znew && Ynew, SR_EINVAL, "sr_gp_append: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_append: model not factorized");
+    SR_CHECK(m >= 1 && m <= SR_NB, SR_EINVAL, "sr_gp_append: m=%d outside 1..%d (append in several calls)", m, SR_NB);
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
+    const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1;
+    const int pf = SR_NB - m;
+    const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
+    double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;                 // new persistent state
+    double *Xq = nullptr, *Ks = nullptr, *dmy = nullptr, *U12 = nullptr, *U12t = nullptr, *G = nullptr,
+           *Sb = nullptr, *invS = nullptr, *wdm = nullptr, *X = nullptr, *Y2 = nullptr, *Wtr = nullptr, *v = nullptr;
+    int* info_dev = nullptr;
+    std::vector<double> sf2(n_out), noise(n_out);
+    int rc = SR_OK;
+    auto cleanup = [&](bool drop_new) {
+        dev_free(Xq); dev_free(Ks); dev_free(dmy); dev_free(U12); dev_free(U12t); dev_free(G); dev_free(Sb);
+        dev_free(invS); dev_free(wdm); dev_free(X); dev_free(Y2); dev_free(Wtr); dev_free(v); dev_free(info_dev);
+        if (drop_new) { dev_free(Z1); dev_free(yT1); dev_free(alpha1); dev_free(Wt1); }
+    };
+#define SR_A(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(true); return rc; } } while (0)
+#define SR_AH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(true); return SR_EHIP; } } while (0)
+    SR_A(dev_alloc(&Z1, (size_t)N1 * D));
+    SR_A(dev_alloc(&yT1, (size_t)n_out * Np1));
+    SR_A(dev_alloc(&alpha1, (size_t)n_out * Np1));
+    SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
+    SR_A(dev_alloc(&Xq, (size_t)SR_NB * D));
+    SR_A(dev_alloc(&Ks, (size_t)n_out * Np0 * SR_NB));
+    SR_A(dev_alloc(&dmy, (size_t)n_out * (D + 2) * SR_NB));
+    SR_A(dev_alloc(&U12, (size_t)Np0 * SR_NB));
+    SR_A(dev_alloc(&U12t, (size_t)Np0 * SR_NB));
+    SR_A(dev_alloc(&G, BB)); SR_A(dev_alloc(&Sb, BB)); SR_A(dev_alloc(&invS, BB)); SR_A(dev_alloc(&wdm, BB));
+    SR_A(dev_alloc(&X, (size_t)Np0 * SR_NB));
+    SR_A(dev_alloc(&Y2, (size_t)Np0 * SR_NB));
+    SR_A(dev_alloc(&Wtr, std::max(NN0, NN1)));
+    SR_A(dev_alloc(&v, (size_t)Np1));
+    SR_A(dev_alloc(&info_dev, (size_t)n_out));
+    SR_AH(hipMemsetAsync(info_dev, 0, sizeof(int) * n_out, s));
+    SR_AH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+    SR_AH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+    SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
+    SR_AH(hipMemcpyAsync(Z1 + (size_t)N0 * D, Znew, sizeof(double) * m * D, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(sr_append_y_kernel, dim3((Np1 + 255) / 256, n_out), dim3(256), 0, s, h->yT, Np0, N0, Ynew, m,
+                       yT1, Np1, n_out);
+    hipLaunchKernelGGL(sr_append_queries_kernel, dim3(SR_NB), dim3(64), 0, s, Znew, Xq, m, D);
+    SR_AH(hipGetLastError());
+    SR_AH(hipStreamSynchronize(s));
+    // B = K(Z_old, Z_new): the prediction kernel with the new points as queries (old padded row indexing)
+    sr_kstar_args ka;
+    ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.kp = h->general ? h->kp : nullptr; ka.kxx = dmy;
+    ka.xa = Xq; ka.lda = D; ka.na = D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
+    ka.Ks = Ks; ka.mu_part = dmy + (size_t)n_out * SR_NB; ka.jac_part = dmy + (size_t)2 * n_out * SR_NB;
+    ka.N = N0; ka.Np = Np0; ka.D = D; ka.n_out = n_out; ka.nsplit = 1; ka.T = SR_NB; ka.Tp = SR_NB;
+    SR_A(sr_launch_kstar(ka, s));
+    for (int d = 0; d < n_out; ++d) {
+        const double* Wt0 = h->Wt + (size_t)d * NN0;
+        // U12 = U^-T B  (A = U^-1 k-major, upper block triangular)
+        SR_A(sr_launch_gemm_tn(Wt0, Np0, Ks + (size_t)d * Np0 * SR_NB, SR_NB, U12, SR_NB, Np0, SR_NB, Np0, 1.0, 0.0, 3, s));
+        SR_A(sr_launch_gemm_tn(U12, SR_NB, U12, SR_NB, G, SR_NB, SR_NB, SR_NB, Np0, 1.0, 0.0, 0, s));
+        // S = C - U12^T U12 on the real (front padded) block, C = k(Znew, Znew) + noise I
+        if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], Sb, m, SR_NB, D, s));
+        else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], Sb, m, SR_NB, D, s));
+        SR_A(sr_launch_sub_block(Sb, G, pf, s));
+        SR_A(sr_launch_potrf_diag(Sb, SR_NB, invS, wdm, SR_NB, 0, info_dev + d, s));       // invS = U22^-1
+        // X = U12 U22^-1
+        SR_A(sr_launch_transpose_rect(U12, SR_NB, U12t, Np0, Np0, SR_NB, s));
+        SR_A(sr_launch_gemm_tn(U12t, Np0, invS, SR_NB, X, SR_NB, Np0, SR_NB, SR_NB, 1.0, 0.0, 0, s));
+        // Y2 = -U^-1 X   (A = U^-T = transpose of U^-1, k-major, lower block triangular)
+        SR_A(sr_launch_transpose(Wt0, Wtr, Np0, s));
+        SR_A(sr_launch_gemm_tn(Wtr, Np0, X, SR_NB, Y2, SR_NB, Np0, SR_NB, Np0, -1.0, 0.0, 4, s));
+        SR_A(sr_launch_append_assemble(Wt0, Np0, off0, N0, Y2, invS, m, Wt1 + (size_t)d * NN1, Np1, off1, s));
+        // alpha = U1^-1 (U1^-T y)
+        SR_A(sr_launch_transpose(Wt1 + (size_t)d * NN1, Wtr, Np1, s));
+        SR_A(sr_launch_trmv(Wtr, Np1, yT1 + (size_t)d * Np1, v, Np1, 1, s));
+        SR_A(sr_launch_trmv(Wt1 + (size_t)d * NN1, Np1, v, alpha1 + (size_t)d * Np1, Np1, 0, s));
+    }
+    std::vector<int> info_h(n_out, 0);
+    SR_AH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
+    SR_AH(hipStreamSynchronize(s));
+    int bad = 0;
+    for (int d = 0; d < n_out; ++d) {
+        if (info_h[d] > 0) info_h[d] = N0 + std::max(1, info_h[d] - pf);
+        if (info) info[d] = info_h[d];
+        if (info_h[d] != 0 && !bad) bad = d + 1;
+    }
+    if (bad) {
+        cleanup(true);
+        sr_set_error("sr_gp_append: Schur complement not positive definite (output %d, point %d)", bad - 1, info_h[bad - 1]);
+        return SR_ENOTPD;
+    }
+#undef SR_A
+#undef SR_AH
+    cleanup(false);
+    // adopt the new state; everything sized by Np is dropped and re-created lazily
+    dev_free(h->Z); dev_free(h->yT); dev_free(h->alpha); dev_free(h->Wt);
+    h->Z = Z1; h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
+    h->N = N1; h->Np = Np1;
+    free_ws(h);
+    dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
+    h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
+    h->splitk_cap = 0;
+    return SR_OK;
+}

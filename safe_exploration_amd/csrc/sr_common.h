@@ -96,6 +96,7 @@ struct sr_prof_scope {
 // M, N multiples of 128; K multiple of 16.
 //   mode 0: all tiles.  mode 1: only tiles with n0 >= m0 (upper block triangle).
 //   mode 2: B block-lower-triangular (B[k][n] == 0 for k < n0): per tile k starts at n0.
+//   mode 4: A block-lower-triangular (A[k][m] == 0 for k < m0): per tile k starts at m0.
 //   mode 3: A block-upper-triangular (A[k][m] == 0 for k >= m0 + 128): per tile k ends at m0 + 128.
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                       int M, int N, int K, double alpha, double beta, int mode, hipStream_t s);
@@ -115,6 +116,9 @@ int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd
 int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
                    hipStream_t s);
 int sr_launch_fill(double* p, size_t n, double v, hipStream_t s);
+int sr_launch_sub_block(double* S, const double* G, int pf, hipStream_t s);
+int sr_launch_append_assemble(const double* Wt0, int Np0, int off0, int N0, const double* Y2,
+                              const double* invS, int m, double* Wt1, int Np1, int off1, hipStream_t s);
 
 // General kernel family (formulas ssm_gpy/gp_models_utils_casadi.py:17-157):
 //   k(x,y) = (c0 + sum_j a_j x_j y_j) * v * kappa(r) + sum_j b_j x_j y_j ,  r^2 = sum_j ((x_j-y_j) s_j)^2

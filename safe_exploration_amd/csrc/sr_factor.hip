@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256, 2) void sr_gemm_tn_kernel(
     const int m0 = blockIdx.y * srt::BM;
     const int n0 = blockIdx.x * srt::BN;
     if (mode == 1 && n0 < m0) return;
-    const int k_beg = (mode == 2) ? n0 : 0;
+    const int k_beg = (mode == 2) ? n0 : ((mode == 4) ? m0 : 0);
     const int k_end = (mode == 3) ? min(K, m0 + srt::BM) : K;
 
     srt::Acc acc;
@@ -269,6 +269,53 @@ int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd
 
 int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s) {
     return sr_launch_transpose_rect(src, n, dst, n, n, n, s);
+}
+
+// ---- helpers of the block row-append update (sr_gp_append) --------------------------------------
+// S[r][c] -= G[r][c] on the real block r, c >= pf of a front-padded 128 x 128 tile
+__global__ __launch_bounds__(256) void sr_sub_block_kernel(double* __restrict__ S, const double* __restrict__ G,
+                                                           int pf) {
+    for (int idx = threadIdx.x; idx < SR_NB * SR_NB; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        if (r >= pf && c >= pf) S[idx] -= G[idx];
+    }
+}
+
+int sr_launch_sub_block(double* S, const double* G, int pf, hipStream_t s) {
+    hipLaunchKernelGGL(sr_sub_block_kernel, dim3(1), dim3(256), 0, s, S, G, pf);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// new U^-1 (Np1 x Np1, front padding off1) from the old one, the new off-diagonal columns
+// Y2 (= -U^-1 U12 U22^-1, rows in OLD padded indexing, 128 front-padded columns) and U22^-1 (invS)
+__global__ __launch_bounds__(256) void sr_append_assemble_kernel(const double* __restrict__ Wt0, int Np0,
+                                                                 int off0, int N0, const double* __restrict__ Y2,
+                                                                 const double* __restrict__ invS, int m,
+                                                                 double* __restrict__ Wt1, int Np1, int off1) {
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Np1) return;
+    const int pf = SR_NB - m;
+    double v;
+    if (r < off1 || c < off1) {
+        v = (r == c) ? 1.0 : 0.0;
+    } else {
+        const int i = r - off1, j = c - off1;
+        if (i < N0 && j < N0) v = Wt0[(long)(off0 + i) * Np0 + off0 + j];
+        else if (i < N0) v = Y2[(long)(off0 + i) * SR_NB + pf + (j - N0)];
+        else if (j >= N0) v = invS[(pf + i - N0) * SR_NB + pf + (j - N0)];
+        else v = 0.0;
+    }
+    Wt1[(long)r * Np1 + c] = v;
+}
+
+int sr_launch_append_assemble(const double* Wt0, int Np0, int off0, int N0, const double* Y2,
+                              const double* invS, int m, double* Wt1, int Np1, int off1, hipStream_t s) {
+    hipLaunchKernelGGL(sr_append_assemble_kernel, dim3((Np1 + 255) / 256, Np1), dim3(256), 0, s, Wt0, Np0, off0,
+                       N0, Y2, invS, m, Wt1, Np1, off1);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
 }
 
 // one wavefront per row; shuffle reduction

@@ -69,6 +69,7 @@ class SimpleGPModel(StateSpaceModel):
         self._beta = None
         self._inv_K = None
         self._handle = None
+        self._noise_diag = None
         self._device_arg = device
         self.do_sparse_gp = False
         self.z_fixed = Z is not None
@@ -207,6 +208,7 @@ class SimpleGPModel(StateSpaceModel):
             raise ValueError("X must be (N, n_s_in+n_u) and y (N, n_s_out)")
         Zs, yz = self._select_subset(X, y, m, Z, choose_data)
         self._fit(Zs, yz, noise_diag)
+        self._noise_diag = noise_diag
         self.z = self.Z if self.z_fixed else Zs
         self.x_train = X
         self.y_train = y
@@ -216,11 +218,40 @@ class SimpleGPModel(StateSpaceModel):
         """ssm_gpy/gaussian_process.py:347-419."""
         x = np.asarray(x, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
+        if (not replace_old and not opt_hyp and self.gp_trained and self._handle is not None
+                and self.m is None and self.x_train is not None and not self.z_fixed
+                and noise_diag == self._noise_diag and 0 < x.shape[0] <= self.append_limit):
+            self._append(x, y)                       # O(N^2 m) block row append instead of O(N^3)
+            return
         if not replace_old and self.x_train is not None:
             x = np.vstack((self.x_train, x))
             y = np.vstack((self.y_train, y))
         self.train(x, y, self.m, opt_hyp=opt_hyp, noise_diag=noise_diag, Z=self.Z,
                    choose_data=choose_data)
+
+    append_limit = 1024      # more new points than this: refactorise (a few GEMM-rich passes beat many appends)
+
+    def _append(self, x, y):
+        """Condition on additional points through sr_gp_append (chunks of <= 128 rows)."""
+        if x.ndim != 2 or y.ndim != 2 or x.shape[0] != y.shape[0] or x.shape[1] != self.n_s_in + self.n_u \
+                or y.shape[1] != self.n_s_out:
+            raise ValueError("x must be (n, n_s_in+n_u) and y (n, n_s_out)")
+        hd = self._handle
+        s = B.stream_ptr(hd.device)
+        for lo in range(0, x.shape[0], 128):
+            xs, ys = x[lo:lo + 128], y[lo:lo + 128]
+            tx, ty = B.as_dev(xs, hd.device), B.as_dev(ys, hd.device)
+            info = (ctypes.c_int * self.n_s_out)()
+            check(lib.sr_gp_append(hd.h, B.ptr(tx), B.ptr(ty), xs.shape[0], s, info))
+            hd.N += xs.shape[0]
+            npad = ctypes.c_long(0)
+            check(lib.sr_gp_padded_n(hd.h, ctypes.byref(npad)))
+            hd.Np = npad.value
+        self.x_train = np.vstack((self.x_train, x))
+        self.y_train = np.vstack((self.y_train, y))
+        self.z = self.x_train
+        self._beta = None
+        self._inv_K = None
 
     def _fit(self, Z, Y, noise_diag):
         dev = B.resolve_device(self._device_arg)

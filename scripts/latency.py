@@ -58,6 +58,15 @@ def main():
         out["N%d_multistep_T256_H15_us" % N] = round(timeit(
             lambda: reach.multistep_reachability_batch(tr["p0"], gp, tr["k_fb"], tr["k_ff"], l, l, None, 2.0, a,
                                                        np.zeros((2, 1))), 20), 1)
+    # model update: block row append vs refactorisation (exploration adds a few samples per episode)
+    prob = workload.make_problem(13, 5050, 2, 1, 8, sf2=0.01)
+    gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob), device="cuda:0")
+    t0 = time.perf_counter(); gp.train(prob["Z"][:5000], prob["Y"][:5000], opt_hyp=False); torch.cuda.synchronize()
+    out["N5000_refit_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+    t0 = time.perf_counter()
+    gp.update_model(prob["Z"][5000:], prob["Y"][5000:], opt_hyp=False, replace_old=False)
+    torch.cuda.synchronize()
+    out["N5000_append50_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
     print(json.dumps(out))
 
 

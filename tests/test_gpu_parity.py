@@ -532,3 +532,33 @@ def test_reference_test_scenarios_on_reference_data(name, n_s, n_u):
                                                     2, 0, a, b, None)
         np.testing.assert_allclose(pa, g["ms_p_" + tag], rtol=1e-7, atol=1e-10)
         np.testing.assert_allclose(qa, g["ms_q_" + tag], rtol=1e-6)
+
+
+@pytest.mark.parametrize("N0,adds", [(100, [1]), (120, [8, 1]), (250, [6, 128, 3]), (384, [130]), (700, [40])])
+def test_row_append_update_equals_refit(N0, adds):
+    """update_model(replace_old=False): block row append of the factor == refactorising on all the data
+    (SURVEY 8(f).3); crosses 128-padding boundaries, m = 1, m = 128 and m > 128 (two chunks)."""
+    ntot = N0 + sum(adds)
+    syn = orc.make_synthetic(ntot, ntot, 2, 1, 64)
+    Z, Y = syn["Z"], syn["Y"]
+    gp = hip_model(Z[:N0], Y[:N0], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    lo = N0
+    for m in adds:
+        gp.update_model(Z[lo:lo + m], Y[lo:lo + m], opt_hyp=False, replace_old=False)
+        lo += m
+    assert gp.x_train.shape[0] == ntot and gp._handle.N == ntot
+    full = hip_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    mu_a, var_a, jac_a = gp.predict(x, None, True)
+    mu_f, var_f, jac_f = full.predict(x, None, True)
+    scale = np.abs(full.beta).sum(0).max()
+    np.testing.assert_allclose(gp.beta, full.beta, rtol=1e-7, atol=1e-9 * np.abs(full.beta).max())
+    np.testing.assert_allclose(mu_a, mu_f, rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(jac_a, jac_f, rtol=1e-9, atol=1e-10 * scale)
+    np.testing.assert_allclose(var_a, var_f, rtol=0, atol=1e-9)
+    om = oracle_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
+    np.testing.assert_allclose(var_a, rvar, rtol=0, atol=1e-9)
+    # single-query latency path and explicit inverse after an append
+    np.testing.assert_allclose(gp.predict(x[:1])[1], var_f[:1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gp.inv_K[0], om["inv_K"][0], rtol=1e-6, atol=1e-8 * np.abs(om["inv_K"][0]).max())
