@@ -153,6 +153,13 @@ int sr_safety_distance(int device, long T, int n_s, int m, const double* p, cons
                        const double* h_mat, const double* h_vec, double c_safety, double* d,
                        void* stream);
 
+/* replaces: utils_ellipsoid.distance_to_center / sample_inside_ellipsoid  utils_ellipsoid.py:16-60 (batched;
+ * the Monte-Carlo verification of sampling_models.py / gp_reachability.py:323-356 evaluates it per step)
+ * T ellipsoids (p T x n_s, q T x n_s x n_s) against K samples: samples K x n_s shared by all ellipsoids
+ * (per_t = 0) or T x K x n_s (per_t = 1) -> d T x K with d = (s-p)^T Q^-1 (s-p). */
+int sr_distance_to_center(int device, long T, int K, int n_s, const double* samples, int per_t,
+                          const double* p, const double* q, double* d, void* stream);
+
 /* ---- tuning / measurement -------------------------------------------------------------------- */
 /* max queries processed per internal pass (workspace = n_out * Np * chunk * 8 B); default 65536. */
 int sr_gp_set_chunk(sr_gp_t h, long chunk);

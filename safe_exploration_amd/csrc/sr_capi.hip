@@ -629,6 +629,15 @@ extern "C" int sr_safety_distance(int device, long T, int n_s, int m, const doub
     return sr_launch_safety(T, n_s, m, p, q, h_mat, h_vec, c_safety, d, (hipStream_t)stream);
 }
 
+extern "C" int sr_distance_to_center(int device, long T, int K, int n_s, const double* samples, int per_t,
+                                     const double* p, const double* q, double* d, void* stream) {
+    SR_CHECK(T >= 0 && K >= 0 && n_s >= 1, SR_EINVAL, "sr_distance_to_center: T=%ld K=%d n_s=%d", T, K, n_s);
+    if (T == 0 || K == 0) return SR_OK;
+    SR_CHECK(samples && p && q && d, SR_EINVAL, "sr_distance_to_center: NULL argument");
+    SR_HIP(hipSetDevice(device));
+    return sr_launch_distance(T, K, n_s, samples, per_t, p, q, d, (hipStream_t)stream);
+}
+
 extern "C" int sr_gp_set_chunk(sr_gp_t h, long chunk) {
     SR_CHECK(h != nullptr && chunk >= 1, SR_EINVAL, "sr_gp_set_chunk: bad argument");
     h->chunk = chunk;

@@ -188,6 +188,8 @@ int sr_launch_ellipsoid(const sr_ell_args& a, hipStream_t s);
 int sr_launch_remainder(long T, int n_s, int n_u, const double* q, const double* k_fb,
                         const double* l_mu, const double* l_sigma, double* u_mu, double* u_sigma,
                         hipStream_t s);
+int sr_launch_distance(long T, int K, int n_s, const double* samples, int per_t, const double* p,
+                       const double* q, double* d, hipStream_t s);
 int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, const double* h_mat,
                      const double* h_vec, double c, double* d, hipStream_t s);
 

@@ -310,6 +310,62 @@ __global__ __launch_bounds__(256) void sr_safety_kernel(long T, int n_s, int m,
     }
 }
 
+// d[t][k] = (s_k - p_t)^T Q_t^-1 (s_k - p_t): T ellipsoids x K samples (samples shared, or one set per
+// ellipsoid when per_t != 0).  Cholesky of Q_t per thread, then a triangular solve: |L^-1 (s-p)|^2.
+// replaces utils_ellipsoid.distance_to_center / sample_inside_ellipsoid  utils_ellipsoid.py:16-60
+template <int NS>
+__global__ __launch_bounds__(256) void sr_distance_kernel(long T, int K, const double* __restrict__ samples,
+                                                          int per_t, const double* __restrict__ p,
+                                                          const double* __restrict__ q, double* __restrict__ d) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * K) return;
+    const long t = idx / K;
+    const int k = (int)(idx % K);
+    double L[NS][NS], y[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        double sjj = q[(t * NS + j) * NS + j];
+#pragma unroll
+        for (int c = 0; c < j; ++c) sjj -= L[j][c] * L[j][c];
+        const double ljj = sqrt(sjj);
+        L[j][j] = ljj;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+            if (i > j) {
+                double v = q[(t * NS + i) * NS + j];
+#pragma unroll
+                for (int c = 0; c < j; ++c) v -= L[i][c] * L[j][c];
+                L[i][j] = v / ljj;
+            }
+    }
+    const double* sm = samples + (per_t ? (t * K + k) : (long)k) * NS;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        double v = sm[i] - p[t * NS + i];
+#pragma unroll
+        for (int c = 0; c < i; ++c) v -= L[i][c] * y[c];
+        y[i] = v / L[i][i];
+        acc = fma(y[i], y[i], acc);
+    }
+    d[idx] = acc;
+}
+
+int sr_launch_distance(long T, int K, int n_s, const double* samples, int per_t, const double* p,
+                       const double* q, double* d, hipStream_t s) {
+    if (T <= 0 || K <= 0) return SR_OK;
+    dim3 grid((unsigned)((T * K + 255) / 256));
+#define SR_DIST_CASE(NS) case NS: hipLaunchKernelGGL(sr_distance_kernel<NS>, grid, dim3(256), 0, s, T, K, samples, per_t, p, q, d); break
+    switch (n_s) {
+        SR_DIST_CASE(1); SR_DIST_CASE(2); SR_DIST_CASE(3); SR_DIST_CASE(4);
+        SR_DIST_CASE(5); SR_DIST_CASE(6); SR_DIST_CASE(7); SR_DIST_CASE(8);
+        default: sr_set_error("distance: n_s=%d outside 1..%d", n_s, SR_MAX_NS); return SR_EUNSUPPORTED;
+    }
+#undef SR_DIST_CASE
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dispatch on (n_s, n_u)
 // ---------------------------------------------------------------------------------------------

@@ -23,6 +23,33 @@ def sample_inside_ellipsoid(samples, p_center, q_shape, c=1.):
     return distance_to_center(samples, p_center, q_shape) < c
 
 
+def distance_to_center_batch(samples, p_center, q_shape, device=None):
+    """Device batch: T ellipsoids (p (T,n_s), q (T,n_s,n_s)) x K samples -> d (T,K).
+    samples (K,n_s) are shared by all ellipsoids, samples (T,K,n_s) are per ellipsoid
+    (Monte-Carlo verification of a whole batch of trajectories, sampling_models.py:33-107)."""
+    from . import _buffers as B
+    from ._lib import lib, check
+    as_t = B.is_tensor(p_center)
+    dev = B.resolve_device(p_center.device if as_t else device)
+    p = B.as_dev(p_center, dev)
+    T, n_s = p.shape
+    q = B.as_dev(q_shape, dev, (T, n_s, n_s))
+    smp = B.as_dev(samples, dev)
+    per_t = 1 if smp.dim() == 3 else 0
+    K = smp.shape[-2]
+    if smp.shape[-1] != n_s or (per_t and smp.shape[0] != T):
+        raise ValueError("samples must be (K, n_s) or (T, K, n_s)")
+    d = B.empty((T, K), dev)
+    check(lib.sr_distance_to_center(dev.index, T, K, n_s, B.ptr(smp), per_t, B.ptr(p), B.ptr(q), B.ptr(d),
+                                    B.stream_ptr(dev)))
+    return d if as_t else B.to_numpy(d)
+
+
+def sample_inside_ellipsoid_batch(samples, p_center, q_shape, c=1., device=None):
+    """d < c for T ellipsoids x K samples (see distance_to_center_batch)."""
+    return distance_to_center_batch(samples, p_center, q_shape, device) < c
+
+
 def sum_two_ellipsoids(p_1, q_1, p_2, q_2, c=None):
     """Outer ellipsoid of the Minkowski sum; c = sqrt(tr q_1 / tr q_2) minimises the trace."""
     if c is None:

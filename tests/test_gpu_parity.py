@@ -562,3 +562,31 @@ def test_row_append_update_equals_refit(N0, adds):
     # single-query latency path and explicit inverse after an append
     np.testing.assert_allclose(gp.predict(x[:1])[1], var_f[:1], rtol=0, atol=1e-9)
     np.testing.assert_allclose(gp.inv_K[0], om["inv_K"][0], rtol=1e-6, atol=1e-8 * np.abs(om["inv_K"][0]).max())
+
+
+def test_distance_to_center_batch_vs_reference_golden():
+    """A9 batch kernel against the reference's utils_ellipsoid.distance_to_center outputs."""
+    from safe_exploration_amd import utils_ellipsoid as ue
+    g = load_golden("ellipsoid.npz")
+    for n in (2, 3, 4, 8):
+        p = g["sum_p1_%d" % n].T
+        q = g["sum_q1_%d" % n][None]
+        d = ue.distance_to_center_batch(g["dist_s_%d" % n], p, q)
+        np.testing.assert_allclose(d[0], g["dist_d_%d" % n], rtol=1e-11)
+        inside = ue.sample_inside_ellipsoid_batch(g["dist_s_%d" % n], p, q, 3.0)
+        assert list(inside[0]) == list(g["inside_%d" % n])
+    # many ellipsoids x per-ellipsoid samples == the host helper applied one by one
+    rng = np.random.default_rng(4)
+    T, K, n = 50, 9, 4
+    A = rng.standard_normal((T, n, n))
+    Q = np.einsum('tij,tkj->tik', A, A) + 0.1 * np.eye(n)
+    P = rng.standard_normal((T, n))
+    S = rng.standard_normal((T, K, n))
+    d = ue.distance_to_center_batch(S, P, Q)
+    for t in (0, 17, 49):
+        np.testing.assert_allclose(d[t], ue.distance_to_center(S[t], P[t][:, None], Q[t]), rtol=1e-10)
+    # box corners lie on the covering ellipsoid (reference test_utils_ellipsoid.py:13-25)
+    ub = np.array([0.1, 0.2, 0.3])
+    corners = np.array([[sx * ub[0], sy * ub[1], sz * ub[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    dc = ue.distance_to_center_batch(corners, np.zeros((1, 3)), ue.ellipsoid_from_rectangle(ub)[None])
+    np.testing.assert_allclose(dc, 1.0, rtol=1e-12)
