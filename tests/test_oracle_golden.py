@@ -193,3 +193,41 @@ def test_reference_test_scenarios_on_reference_data(name):
                                                   g["L"], None, 2.0, a, b, None)
         np.testing.assert_allclose(pa[0], g["ms_p_" + tag], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(qa[0], g["ms_q_" + tag], rtol=1e-8)
+
+
+def test_oracle_vs_sklearn_gaussian_process():
+    """Independent third-party witness for the exact-GP algebra (GPy itself is not installable here):
+    scikit-learn's GaussianProcessRegressor with a fixed ConstantKernel * ARD-RBF kernel and
+    alpha = noise + jitter must give the oracle's mean and variance."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel
+    g = load_golden("gp_cart.npz")
+    m = _model(g)
+    mu, var, _ = orc.gp_predict(g["x_new"], m["Z"], m["beta"], m["inv_K"], m["lengthscale"], m["signal_var"])
+    for d in range(g["Y"].shape[1]):
+        kern = ConstantKernel(g["signal_var"][d], "fixed") * RBF(g["lengthscale"][d], "fixed")
+        gpr = GaussianProcessRegressor(kern, alpha=g["noise_var"][d] + orc.GPY_JITTER, optimizer=None,
+                                       normalize_y=False).fit(g["Z"], g["Y"][:, d])
+        sm, ss = gpr.predict(g["x_new"], return_std=True)
+        np.testing.assert_allclose(mu[:, d], sm, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(var[:, d], ss ** 2, rtol=0, atol=1e-9)
+
+
+def test_oracle_mat52_vs_sklearn():
+    """same witness for the Matern-5/2 kernel (sklearn Matern(nu=2.5) with ARD length scales)."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import Matern, ConstantKernel
+    g = load_golden("kern_mat52.npz")
+    hyp = []
+    for d in range(2):
+        pref = "hyp%d_" % d
+        hyp.append({k[len(pref):]: g[k] for k in g.files if k.startswith(pref)})
+    beta, inv_K = orc.gp_fit_k(g["Z"], g["Y"], ["mat52"] * 2, hyp, g["noise_var"])
+    mu, var = orc.gp_predict_k(g["x_new"], g["Z"], beta, inv_K, ["mat52"] * 2, hyp)
+    for d in range(2):
+        kern = ConstantKernel(float(hyp[d]["variance"]), "fixed") * Matern(hyp[d]["lengthscale"], "fixed", nu=2.5)
+        gpr = GaussianProcessRegressor(kern, alpha=g["noise_var"][d] + orc.GPY_JITTER, optimizer=None).fit(
+            g["Z"], g["Y"][:, d])
+        sm, ss = gpr.predict(g["x_new"], return_std=True)
+        np.testing.assert_allclose(mu[:, d], sm, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(var[:, d], ss ** 2, rtol=0, atol=1e-9)
