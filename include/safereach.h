@@ -141,6 +141,22 @@ int sr_ellipsoid_step(int device, long T, int n_s, int n_u, const double* p, con
                       const double* l_sigma, double c_safety, double* p_out, double* q_out,
                       int* n_bad, void* stream);
 
+/* ---- Gaussian moment propagation (the CautiousMPC baseline), batched -----------------------------
+ * replaces: uncertainty_propagation_casadi.one_step_taylor / multi_step_taylor_symbolic (mode 1)
+ *           uncertainty_propagation_casadi.one_step_mean_equivalent / mean_equivalent_multistep (mode 2)
+ *           uncertainty_propagation_casadi.py:11-283 (numeric evaluation of the symbolic graphs)
+ * Step 0 starts from a point (sigma_0 = None is the only case the reference implements, :124,:170);
+ * step i >= 1 uses k_fb[i-1].  mu0 T x n_s ; k_ff T x H x n_u ; k_fb T x (H-1) x n_u x n_s
+ * -> mu_all T x H x n_s ; sigma_all T x H x n_s x n_s ; gp_var_all T x H x n_s (GP variances, or NULL). */
+int sr_multistep_moments(sr_gp_t h, long T, int H, int mode, const double* mu0, const double* k_ff,
+                         const double* k_fb, const double* a, const double* b, double* mu_all,
+                         double* sigma_all, double* gp_var_all, void* stream);
+/* one step with the GP outputs supplied by the caller (sigma_x NULL = point input). */
+int sr_moment_step(int device, long T, int n_s, int n_u, int mode, const double* mu_x,
+                   const double* sigma_x, const double* k_ff, const double* k_fb, const double* mu_g,
+                   const double* var_g, const double* jac_g, const double* a, const double* b,
+                   double* mu_out, double* sigma_out, void* stream);
+
 /* replaces: utils.compute_remainder_overapproximations  utils.py:108-144 (batched)
  * q T x n_s x n_s, k_fb T x n_u x n_s -> u_mu T x n_s, u_sigma T x n_s */
 int sr_remainder_overapprox(int device, long T, int n_s, int n_u, const double* q, const double* k_fb,

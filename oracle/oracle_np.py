@@ -411,3 +411,42 @@ def make_hyp(kern_type, rng, D):
             "prod.%s.variance" % st: float(rng.uniform(0.5, 1.5)),
             "prod.linear.variances": np.array([rng.uniform(0.5, 1.5)]),
             "linear.variances": rng.uniform(0.2, 1.0, D)}
+
+
+# --------------------------------------------------------------------------- Gaussian moment propagation (8(f).4)
+def one_step_moments(mu_x, sigma_x, k_ff, k_fb, mu_g, var_g, jac_g, a, b, taylor=True):
+    """Literal restatement of uncertainty_propagation_casadi.py:57-87 (Taylor) / :260-283 (mean-equivalent)
+    for one query: builds Sigma_z, Sigma_zg, Sigma_all and applies [a b I].  mu_x (n_s,), sigma_x (n_s,n_s) or
+    None, k_ff (n_u,), k_fb (n_u,n_s).  Returns mu_new (n_s,), sigma_new (n_s,n_s)."""
+    n_s, n_u = mu_x.shape[0], k_ff.shape[0]
+    if sigma_x is None:
+        return a.dot(mu_x) + b.dot(k_ff) + mu_g, np.diag(var_g)
+    sigma_u = k_fb.dot(sigma_x).dot(k_fb.T)
+    sigma_xu = sigma_x.dot(k_fb.T)
+    sigma_z = np.vstack((np.hstack((sigma_x, sigma_xu)), np.hstack((sigma_xu.T, sigma_u))))
+    if taylor:
+        sigma_zg = sigma_z.dot(jac_g.T)
+        sigma_g = np.diag(var_g) + jac_g.dot(sigma_z).dot(jac_g.T)
+    else:
+        sigma_zg = np.zeros((n_s + n_u, n_s))
+        sigma_g = np.diag(var_g)
+    sigma_all = np.vstack((np.hstack((sigma_z, sigma_zg)), np.hstack((sigma_zg.T, sigma_g.T))))
+    lin = np.hstack((a, b, np.eye(n_s)))
+    mu_new = lin.dot(np.concatenate((mu_x, k_ff, mu_g)))
+    return mu_new, lin.dot(sigma_all).dot(lin.T)
+
+
+def multistep_moments_batch(model, mu_0, k_ff, k_fb, a, b, taylor=True):
+    """uncertainty_propagation_casadi.py:88-146 / :149-207 with a leading T axis.
+    mu_0 (T,n_s); k_ff (T,H,n_u); k_fb (T,H-1,n_u,n_s) -> mu_all (T,H,n_s), sigma_all (T,H,n_s,n_s)."""
+    T, H, n_u = k_ff.shape
+    n_s = mu_0.shape[1]
+    mu_all = np.empty((T, H, n_s))
+    sigma_all = np.empty((T, H, n_s, n_s))
+    for t in range(T):
+        mu, sig = mu_0[t], None
+        for i in range(H):
+            m, v, j = _predict_one(model, np.concatenate((mu, k_ff[t, i])))
+            mu, sig = one_step_moments(mu, sig, k_ff[t, i], None if i == 0 else k_fb[t, i - 1], m, v, j, a, b, taylor)
+            mu_all[t, i], sigma_all[t, i] = mu, sig
+    return mu_all, sigma_all

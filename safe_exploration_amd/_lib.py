@@ -54,6 +54,8 @@ SIGNATURES = {
     "sr_gp_linearize": (_I, [_H, _P, _P, _P, _P, _P, _P, _P]),
     "sr_onestep_reach": (_I, [_H, _L, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P]),
     "sr_multistep_reach": (_I, [_H, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P]),
+    "sr_multistep_moments": (_I, [_H, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sr_moment_step": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sr_ellipsoid_step": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P,
                                _P, _P]),
     "sr_remainder_overapprox": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

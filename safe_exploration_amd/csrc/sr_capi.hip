@@ -525,29 +525,21 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
         ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
         ea.p_out = p_out + t0 * n_s; ea.ldpo = n_s;
         ea.q_out = q_out + t0 * n_s * n_s; ea.ldqo = (long)n_s * n_s;
-        ea.n_bad = n_bad;
+        ea.n_bad = n_bad; ea.mode = 0;
         sr_prof_scope ps(&h->prof, SR_K_ELL, s);
         SR_TRY(sr_launch_ellipsoid(ea, s));
     }
     return SR_OK;
 }
 
-extern "C" int sr_multistep_reach(sr_gp_t h, long T, int H, const double* p0, const double* q0,
-                                  const double* k_fb0, const double* k_ff, const double* k_fb,
-                                  const double* a, const double* b, const double* l_mu,
-                                  const double* l_sigma, double c_safety, double* p_all,
-                                  double* q_all, int* n_bad, void* stream) {
-    SR_CHECK(h != nullptr, SR_EINVAL, "sr_multistep_reach: NULL handle");
-    SR_CHECK(h->factorized, SR_ESTATE, "sr_multistep_reach: model not factorized");
-    SR_CHECK(T >= 0 && H >= 1, SR_EINVAL, "sr_multistep_reach: T=%ld H=%d", T, H);
-    if (T == 0) return SR_OK;
-    SR_CHECK(p0 && k_ff && a && b && l_mu && l_sigma && p_all && q_all, SR_EINVAL,
-             "sr_multistep_reach: NULL argument");
-    SR_CHECK(H == 1 || k_fb != nullptr, SR_EINVAL, "sr_multistep_reach: k_fb required for H > 1");
-    SR_CHECK(q0 == nullptr || k_fb0 != nullptr, SR_EINVAL, "sr_multistep_reach: k_fb0 required with q0");
+// shared H-step chain: mode 0 = robust ellipsoids (gp_reachability.py:159-212),
+// mode 1/2 = Taylor / mean-equivalent Gaussian moments (uncertainty_propagation_casadi.py:88-190)
+static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, const double* q0,
+                          const double* k_fb0, const double* k_ff, const double* k_fb, const double* a,
+                          const double* b, const double* l_mu, const double* l_sigma, double c_safety,
+                          double* p_all, double* q_all, double* gp_var_all, int* n_bad, hipStream_t s) {
     int n_s, n_u;
     SR_TRY(check_reach_dims(h, &n_s, &n_u));
-    hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
     const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
@@ -568,6 +560,10 @@ extern "C" int sr_multistep_reach(sr_gp_t h, long T, int H, const double* p0, co
             const double* kff_in = k_ff + (t0 * H + i) * n_u;
             const long ldkff = (long)H * n_u;
             SR_TRY(gp_pass(h, Tc, p_in, ldp, n_s, kff_in, ldkff, n_u, h->mu, h->var, h->jac, s));
+            if (gp_var_all)
+                SR_HIP(hipMemcpy2DAsync(gp_var_all + (t0 * H + i) * n_s, sizeof(double) * H * n_s, h->var,
+                                        sizeof(double) * n_s, sizeof(double) * n_s, Tc,
+                                        hipMemcpyDeviceToDevice, s));
             sr_ell_args ea;
             ea.T = Tc; ea.n_s = n_s; ea.n_u = n_u;
             ea.p = p_in; ea.ldp = ldp; ea.q = q_in; ea.ldq = ldq;
@@ -576,12 +572,65 @@ extern "C" int sr_multistep_reach(sr_gp_t h, long T, int H, const double* p0, co
             ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
             ea.p_out = p_all + (t0 * H + i) * n_s; ea.ldpo = (long)H * n_s;
             ea.q_out = q_all + (t0 * H + i) * nss; ea.ldqo = (long)H * nss;
-            ea.n_bad = n_bad;
+            ea.n_bad = n_bad; ea.mode = mode;
             sr_prof_scope ps(&h->prof, SR_K_ELL, s);
             SR_TRY(sr_launch_ellipsoid(ea, s));
         }
     }
     return SR_OK;
+}
+
+extern "C" int sr_multistep_reach(sr_gp_t h, long T, int H, const double* p0, const double* q0,
+                                  const double* k_fb0, const double* k_ff, const double* k_fb,
+                                  const double* a, const double* b, const double* l_mu,
+                                  const double* l_sigma, double c_safety, double* p_all,
+                                  double* q_all, int* n_bad, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_multistep_reach: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_multistep_reach: model not factorized");
+    SR_CHECK(T >= 0 && H >= 1, SR_EINVAL, "sr_multistep_reach: T=%ld H=%d", T, H);
+    if (T == 0) return SR_OK;
+    SR_CHECK(p0 && k_ff && a && b && l_mu && l_sigma && p_all && q_all, SR_EINVAL,
+             "sr_multistep_reach: NULL argument");
+    SR_CHECK(H == 1 || k_fb != nullptr, SR_EINVAL, "sr_multistep_reach: k_fb required for H > 1");
+    SR_CHECK(q0 == nullptr || k_fb0 != nullptr, SR_EINVAL, "sr_multistep_reach: k_fb0 required with q0");
+    return multistep_impl(h, T, H, 0, p0, q0, k_fb0, k_ff, k_fb, a, b, l_mu, l_sigma, c_safety, p_all, q_all,
+                          nullptr, n_bad, (hipStream_t)stream);
+}
+
+extern "C" int sr_multistep_moments(sr_gp_t h, long T, int H, int mode, const double* mu0, const double* k_ff,
+                                    const double* k_fb, const double* a, const double* b, double* mu_all,
+                                    double* sigma_all, double* gp_var_all, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_multistep_moments: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_multistep_moments: model not factorized");
+    SR_CHECK(T >= 0 && H >= 1 && (mode == 1 || mode == 2), SR_EINVAL, "sr_multistep_moments: T=%ld H=%d mode=%d",
+             T, H, mode);
+    if (T == 0) return SR_OK;
+    SR_CHECK(mu0 && k_ff && a && b && mu_all && sigma_all, SR_EINVAL, "sr_multistep_moments: NULL argument");
+    SR_CHECK(H == 1 || k_fb != nullptr, SR_EINVAL, "sr_multistep_moments: k_fb required for H > 1");
+    // l_mu / l_sigma are unused by the moment modes: any valid device pointer will do
+    return multistep_impl(h, T, H, mode, mu0, nullptr, nullptr, k_ff, k_fb, a, b, a, a, 1.0, mu_all, sigma_all,
+                          gp_var_all, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int sr_moment_step(int device, long T, int n_s, int n_u, int mode, const double* mu_x,
+                              const double* sigma_x, const double* k_ff, const double* k_fb, const double* mu_g,
+                              const double* var_g, const double* jac_g, const double* a, const double* b,
+                              double* mu_out, double* sigma_out, void* stream) {
+    SR_CHECK(T >= 0 && (mode == 1 || mode == 2), SR_EINVAL, "sr_moment_step: T=%ld mode=%d", T, mode);
+    if (T == 0) return SR_OK;
+    SR_CHECK(mu_x && k_ff && mu_g && var_g && a && b && mu_out && sigma_out, SR_EINVAL, "sr_moment_step: NULL argument");
+    SR_CHECK(sigma_x == nullptr || (k_fb != nullptr && (mode == 2 || jac_g != nullptr)), SR_EINVAL,
+             "sr_moment_step: k_fb (and jac for the Taylor mode) required with sigma_x");
+    SR_HIP(hipSetDevice(device));
+    sr_ell_args ea;
+    ea.T = T; ea.n_s = n_s; ea.n_u = n_u;
+    ea.p = mu_x; ea.ldp = n_s; ea.q = sigma_x; ea.ldq = (long)n_s * n_s;
+    ea.k_ff = k_ff; ea.ldkff = n_u; ea.k_fb = k_fb; ea.ldkfb = (long)n_u * n_s;
+    ea.mu = mu_g; ea.var = var_g; ea.jac = jac_g ? jac_g : mu_g;     // never dereferenced in mode 2
+    ea.a = a; ea.b = b; ea.l_mu = a; ea.l_sigma = a; ea.c_safety = 1.0;
+    ea.p_out = mu_out; ea.ldpo = n_s; ea.q_out = sigma_out; ea.ldqo = (long)n_s * n_s;
+    ea.n_bad = nullptr; ea.mode = mode;
+    return sr_launch_ellipsoid(ea, (hipStream_t)stream);
 }
 
 extern "C" int sr_ellipsoid_step(int device, long T, int n_s, int n_u, const double* p,
@@ -604,7 +653,7 @@ extern "C" int sr_ellipsoid_step(int device, long T, int n_s, int n_u, const dou
     ea.mu = mu; ea.var = var; ea.jac = jac;
     ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
     ea.p_out = p_out; ea.ldpo = n_s; ea.q_out = q_out; ea.ldqo = (long)n_s * n_s;
-    ea.n_bad = n_bad;
+    ea.n_bad = n_bad; ea.mode = 0;
     return sr_launch_ellipsoid(ea, (hipStream_t)stream);
 }
 

@@ -183,6 +183,8 @@ struct sr_ell_args {
     double* p_out; long ldpo;         // T x n_s
     double* q_out; long ldqo;         // T x n_s*n_s
     int* n_bad;                       // device counter (nullable): queries whose box bounds were not > 0
+    int mode;                         // 0 robust ellipsoid (gp_reachability.py), 1 Taylor / 2 mean-equivalent
+                                      // Gaussian moment propagation (uncertainty_propagation_casadi.py)
 };
 int sr_launch_ellipsoid(const sr_ell_args& a, hipStream_t s);
 int sr_launch_remainder(long T, int n_s, int n_u, const double* q, const double* k_fb,

@@ -163,12 +163,14 @@ __global__ __launch_bounds__(256) void sr_ellipsoid_kernel(sr_ell_args a) {
 
     if (a.q == nullptr) {
         // point branch: Q1 = diag(n_s (c sqrt(var))^2)     (gp_reachability.py:78-80)
+        // moment modes: Sigma1 = diag(var)                  (uncertainty_propagation_casadi.py:50-55, 253-258)
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const double ub = a.c_safety * sqrt(var[i]);
             bad |= !(ub > 0.0);
+            const double dv = (a.mode == 0) ? NS * ub * ub : var[i];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) qo[i * NS + j] = (i == j) ? NS * ub * ub : 0.0;
+            for (int j = 0; j < NS; ++j) qo[i * NS + j] = (i == j) ? dv : 0.0;
         }
         if (bad && n_bad) atomicAdd(n_bad, 1);
         return;
@@ -185,15 +187,17 @@ __global__ __launch_bounds__(256) void sr_ellipsoid_kernel(sr_ell_args a) {
         for (int j = 0; j < NS; ++j) kfb[k][j] = a.k_fb[t * a.ldkfb + k * NS + j];
 
     // H = a + a_mu + (b_mu + b) k_fb                          (gp_reachability.py:110-114)
+    // (mean-equivalent propagation drops the Jacobian terms: H = a + b k_fb)
     const double* jac = a.jac + t * NS * D;
+    const double jw = (a.mode == 2) ? 0.0 : 1.0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         double bm[NU];
 #pragma unroll
-        for (int k = 0; k < NU; ++k) bm[k] = jac[i * D + NS + k] + a.b[i * NU + k];
+        for (int k = 0; k < NU; ++k) bm[k] = (a.mode == 2 ? 0.0 : jac[i * D + NS + k]) + a.b[i * NU + k];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-            double s = a.a[i * NS + j] + jac[i * D + j];
+            double s = a.a[i * NS + j] + (a.mode == 2 ? 0.0 : jw * jac[i * D + j]);
 #pragma unroll
             for (int k = 0; k < NU; ++k) s = fma(bm[k], kfb[k][j], s);
             H[i][j] = s;
@@ -221,6 +225,15 @@ __global__ __launch_bounds__(256) void sr_ellipsoid_kernel(sr_ell_args a) {
             Q0[i][j] = s;
             if (i == j) trQ0 += s;
         }
+    if (a.mode != 0) {
+        // Gaussian moment propagation: [a b I] Sigma_all [a b I]^T collapses to H Sigma H^T + diag(var)
+        // (uncertainty_propagation_casadi.py:57-87 with the Jacobian cross terms, :260-283 without)
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) qo[i * NS + j] = Q0[i][j] + ((i == j) ? var[i] : 0.0);
+        return;
+    }
     // remainder boxes                                          (:125-137, utils.py:129-142)
     const double r2 = sr_lambda_max_qb<NS, NU>(q, kfb);
     const double r1 = sqrt(r2);

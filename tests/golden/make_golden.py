@@ -37,6 +37,7 @@ REF = "/root/reference"
 
 CASADI_SHIM = '''
 import numpy as _np
+import numpy as np          # the reference relies on `from casadi import *` exporting np
 def reshape(a, s): return _np.reshape(a, s, order="F")
 def mtimes(a, b): return _np.dot(a, b)
 def exp(a): return _np.exp(a)
@@ -48,6 +49,12 @@ def horzcat(*a): return _np.hstack([x for x in a if _np.size(x)])
 class SX(object):
     def __new__(cls, *a):
         return _np.zeros((1, 1)) if len(a) < 2 else _np.zeros(a)
+def diag(a):
+    a = _np.asarray(a)
+    return _np.diagflat(a) if (a.ndim == 1 or 1 in a.shape) else _np.diag(a)[:, None]
+class MX(object):
+    eye = staticmethod(_np.eye)
+    zeros = staticmethod(lambda *a: _np.zeros(a))
 class Function(object):
     def __init__(self, *a, **k): raise NotImplementedError("numeric shim only")
 '''
@@ -62,6 +69,8 @@ def _import_reference():
     sys.path.insert(0, ROOT)
     warnings.simplefilter("ignore")
     from safe_exploration import utils_ellipsoid, utils, gp_reachability
+    global ref_prop
+    from safe_exploration import uncertainty_propagation_casadi as ref_prop
     spec = importlib.util.spec_from_file_location(
         "ref_gp_models_utils_casadi",
         os.path.join(REF, "safe_exploration/ssm_gpy/gp_models_utils_casadi.py"))
@@ -340,6 +349,43 @@ def main():
                  .2 * np.array([[.5, .2], [.2, .65]]), 0.6, 0.05, 1e-3, False)
     ref_scenario("scen_cartpole.npz", "ref_data_cartpole.npz", 4, 1, 20, 125, 0.001, 0.1 * np.eye(4), 1.0, 0.05,
                  1e-3, True)
+
+    # ------------------------------------------------------------------ 4c. Gaussian moment propagation (8(f).4)
+    # the reference's symbolic graph builders evaluated on numbers (casadi array functions -> numpy)
+    def moments_case(name, seed, N, n_s, n_u, T, H):
+        syn = orc.make_synthetic(seed, N, n_s, n_u, T, sf2=0.01)
+        beta, inv_K, _ = orc.gp_fit(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+        model = dict(Z=syn["Z"], beta=beta, inv_K=inv_K, lengthscale=syn["lengthscale"], signal_var=syn["signal_var"])
+        rng = np.random.default_rng(seed + 5)
+        a_lin = 0.8 * np.eye(n_s) + 0.05 * rng.standard_normal((n_s, n_s))
+        b_lin = 0.1 * rng.standard_normal((n_s, n_u))
+        k_ff = 0.1 * rng.standard_normal((T, H, n_u))
+        k_fb = 0.1 * rng.standard_normal((T, H - 1, n_u, n_s))
+        mu0 = 0.1 * rng.standard_normal((T, n_s))
+
+        def ssm(states, actions):
+            z = np.ascontiguousarray(np.hstack((np.asarray(states), np.asarray(actions)))[0])
+            m, v, j = orc._predict_one(model, z)
+            return m[:, None], v[:, None], j
+
+        res = {k: syn[k] for k in ("Z", "Y", "lengthscale", "signal_var", "noise_var")}
+        res.update(a_lin=a_lin, b_lin=b_lin, k_ff=k_ff, k_fb=k_fb, mu0=mu0)
+        for tag, fn in (("taylor", ref_prop.multi_step_taylor_symbolic), ("meaneq", ref_prop.mean_equivalent_multistep)):
+            mu_all = np.empty((T, H, n_s)); sig_all = np.empty((T, H, n_s, n_s)); gv_all = np.empty((T, H, n_s))
+            for t in range(T):
+                m_, s_, g_ = fn(mu0[t][:, None], ssm, k_ff[t], list(k_fb[t]), None, a_lin, b_lin)
+                mu_all[t], sig_all[t] = np.asarray(m_), np.asarray(s_).reshape(H, n_s, n_s)
+                if tag == "meaneq":      # (the Taylor variant returns sigma_g as a MATRIX after step 0, :69-87)
+                    gv_all[t] = np.asarray(g_)
+            res["mu_" + tag], res["sigma_" + tag] = mu_all, sig_all
+            if tag == "meaneq":
+                res["gpvar_meaneq"] = gv_all
+            om, osig = orc.multistep_moments_batch(model, mu0, k_ff, k_fb, a_lin, b_lin, tag == "taylor")
+            assert np.allclose(om, mu_all, rtol=1e-12, atol=1e-14) and np.allclose(osig, sig_all, rtol=1e-11, atol=1e-16)
+        _save(name, **res)
+
+    moments_case("moments_pend.npz", 401, 60, 2, 1, 5, 6)
+    moments_case("moments_cart.npz", 402, 80, 4, 1, 4, 5)
 
     # ------------------------------------------------------------------ 5. worked anchor of SURVEY 8c
     p = np.array([[0.1], [-0.2]]); Q = 0.2 * np.array([[.5, .2], [.2, .65]])

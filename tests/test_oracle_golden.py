@@ -231,3 +231,22 @@ def test_oracle_mat52_vs_sklearn():
         sm, ss = gpr.predict(g["x_new"], return_std=True)
         np.testing.assert_allclose(mu[:, d], sm, rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(var[:, d], ss ** 2, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["moments_pend.npz", "moments_cart.npz"])
+def test_moment_propagation_vs_reference(name):
+    """oracle's literal restatement == the reference's multi_step_taylor_symbolic / mean_equivalent_multistep
+    evaluated on numbers (tests/golden/make_golden.py 4c)."""
+    g = load_golden(name)
+    m = _model(g)
+    for tag, taylor in (("taylor", True), ("meaneq", False)):
+        mu, sig = orc.multistep_moments_batch(m, g["mu0"], g["k_ff"], g["k_fb"], g["a_lin"], g["b_lin"], taylor)
+        np.testing.assert_allclose(mu, g["mu_" + tag], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(sig, g["sigma_" + tag], rtol=1e-9, atol=1e-15)
+    # the collapsed form the HIP kernel uses: Sigma_new = H Sigma H^T + diag(var)
+    x = np.concatenate((g["mu_taylor"][0, 0], g["k_ff"][0, 1]))
+    mg_, vg_, jg_ = orc._predict_one(m, x)
+    n_s = g["mu0"].shape[1]
+    K = g["k_fb"][0, 0]
+    H = g["a_lin"] + jg_[:, :n_s] + (jg_[:, n_s:] + g["b_lin"]).dot(K)
+    np.testing.assert_allclose(H.dot(g["sigma_taylor"][0, 0]).dot(H.T) + np.diag(vg_), g["sigma_taylor"][0, 1], rtol=1e-10)
