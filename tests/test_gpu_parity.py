@@ -626,3 +626,24 @@ def test_moment_propagation_vs_reference_golden(name, n_s, n_u):
                                      g["sigma_taylor"][0, 0], g["k_fb"][0, 0], g["a_lin"], g["b_lin"])
     np.testing.assert_allclose(m1[:, 0], g["mu_taylor"][0, 1], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(s1, g["sigma_taylor"][0, 1], rtol=1e-10, atol=1e-15)
+
+
+def test_c_abi_from_plain_hip_program(lib_built):
+    """the boundary has no Python/torch dependency: examples/capi_demo.cpp (plain HIP host code) links
+    libsafereach.so, reproduces the SURVEY anchor through sr_ellipsoid_step and runs the handle API."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    exe = os.path.join(tempfile.mkdtemp(), "capi_demo")
+    libdir = os.path.join(ROOT, "safe_exploration_amd")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "examples", "capi_demo.cpp"),
+           "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-lsafereach", "-Wl,-rpath," + libdir, "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "capi_demo OK" in res.stdout
