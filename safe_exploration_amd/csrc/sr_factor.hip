@@ -136,9 +136,13 @@ int sr_launch_gram_general(const double* Z, const double* kp, double noise, doub
 // One workgroup; 128 x 129 doubles of LDS (132 KiB of the CU's 160 KiB).
 // ------------------------------------------------------------------------------------------------
 #define SR_PD_LD 129
-__global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long lda,
-                                                               double* wt_diag, double* w_diag,
-                                                               long ldw, int kb, int* info) {
+#define SR_PD_THREADS 1024
+// 1024 threads: the per-step work is latency-bound LDS read-modify-write, so it is spread as thinly as
+// possible -- Cholesky trailing update: thread = (column, 1 of 8 row phases); inverse: 8 lanes per row
+// share one dot product (shuffle reduction inside the wavefront).
+__global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
+                                                                         double* wt_diag, double* w_diag,
+                                                                         long ldw, int kb, int* info) {
     __shared__ double S[SR_NB * SR_PD_LD];
     __shared__ double dg[SR_NB];
     __shared__ double tmp[SR_NB];
@@ -146,14 +150,14 @@ __global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long l
     const int tid = threadIdx.x;
     const long k0 = (long)kb * SR_NB;
     if (tid == 0) fail = 0;
-    for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+    for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
         const int r = idx >> 7, c = idx & 127;
         S[r * SR_PD_LD + c] = (c >= r) ? A[(k0 + r) * lda + k0 + c] : 0.0;
     }
     __syncthreads();
 
     // right-looking upper Cholesky, S[j][j] keeps the pivot d_j until the end (sqrt kept in dg)
-    const int c_own = tid & 127, half = tid >> 7;
+    const int c_own = tid & 127, phase = tid >> 7;            // 8 row phases
     for (int j = 0; j < SR_NB; ++j) {
         const double d = S[j * SR_PD_LD + j];
         if (!(d > 0.0)) {                       // also catches NaN; uniform across the workgroup
@@ -167,20 +171,20 @@ __global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long l
         __syncthreads();
         if (c_own > j) {
             const double ujc = S[j * SR_PD_LD + c_own];
-            int r = j + 1 + half;
-            // 4 independent read-modify-writes in flight (the LDS round trips do not alias: row j is
-            // read-only here, rows r > j are written by exactly one thread each)
-            for (; r + 6 <= c_own; r += 8) {
-                const double a0 = S[j * SR_PD_LD + r], a1 = S[j * SR_PD_LD + r + 2];
-                const double a2 = S[j * SR_PD_LD + r + 4], a3 = S[j * SR_PD_LD + r + 6];
+            int r = j + 1 + phase;
+            // 4 independent read-modify-writes in flight (row j is read-only here, every row r > j element is
+            // written by exactly one thread)
+            for (; r + 24 <= c_own; r += 32) {
+                const double a0 = S[j * SR_PD_LD + r], a1 = S[j * SR_PD_LD + r + 8];
+                const double a2 = S[j * SR_PD_LD + r + 16], a3 = S[j * SR_PD_LD + r + 24];
                 double* p0 = &S[r * SR_PD_LD + c_own];
-                const double b0 = p0[0], b1 = p0[2 * SR_PD_LD], b2 = p0[4 * SR_PD_LD], b3 = p0[6 * SR_PD_LD];
+                const double b0 = p0[0], b1 = p0[8 * SR_PD_LD], b2 = p0[16 * SR_PD_LD], b3 = p0[24 * SR_PD_LD];
                 p0[0] = fma(-a0, ujc, b0);
-                p0[2 * SR_PD_LD] = fma(-a1, ujc, b1);
-                p0[4 * SR_PD_LD] = fma(-a2, ujc, b2);
-                p0[6 * SR_PD_LD] = fma(-a3, ujc, b3);
+                p0[8 * SR_PD_LD] = fma(-a1, ujc, b1);
+                p0[16 * SR_PD_LD] = fma(-a2, ujc, b2);
+                p0[24 * SR_PD_LD] = fma(-a3, ujc, b3);
             }
-            for (; r <= c_own; r += 2)
+            for (; r <= c_own; r += 8)
                 S[r * SR_PD_LD + c_own] = fma(-S[j * SR_PD_LD + r], ujc, S[r * SR_PD_LD + c_own]);
         }
         __syncthreads();
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long l
     if (fail) {
         if (tid == 0 && *info == 0) *info = (int)k0 + fail;
         // keep downstream kernels finite: identity block
-        for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+        for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
             const int r = idx >> 7, c = idx & 127;
             const double v = (r == c) ? 1.0 : 0.0;
             A[(k0 + r) * lda + k0 + c] = v;
@@ -200,36 +204,39 @@ __global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long l
     }
     if (tid < SR_NB) S[tid * SR_PD_LD + tid] = dg[tid];
     __syncthreads();
-    for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+    for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
         const int r = idx >> 7, c = idx & 127;
         A[(k0 + r) * lda + k0 + c] = S[r * SR_PD_LD + c];   // strict lower part is zero in S
     }
     __syncthreads();
 
-    // in-place inverse of the upper-triangular block, column by column
+    // in-place inverse of the upper-triangular block, column by column; row i is handled by 8 lanes
+    const int row = tid >> 3, part = tid & 7;
     for (int j = 0; j < SR_NB; ++j) {
         if (tid < j) tmp[tid] = S[tid * SR_PD_LD + j];
         __syncthreads();
         const double invjj = 1.0 / S[j * SR_PD_LD + j];
         __syncthreads();
-        if (tid < j) {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int k = tid;
-            for (; k + 3 < j; k += 4) {
-                s0 = fma(S[tid * SR_PD_LD + k], tmp[k], s0);
-                s1 = fma(S[tid * SR_PD_LD + k + 1], tmp[k + 1], s1);
-                s2 = fma(S[tid * SR_PD_LD + k + 2], tmp[k + 2], s2);
-                s3 = fma(S[tid * SR_PD_LD + k + 3], tmp[k + 3], s3);
+        double s0 = 0.0, s1 = 0.0;
+        if (row < j) {
+            int k = row + part;
+            for (; k + 8 < j; k += 16) {
+                s0 = fma(S[row * SR_PD_LD + k], tmp[k], s0);
+                s1 = fma(S[row * SR_PD_LD + k + 8], tmp[k + 8], s1);
             }
-            for (; k < j; ++k) s0 = fma(S[tid * SR_PD_LD + k], tmp[k], s0);
-            const double s = (s0 + s1) + (s2 + s3);
-            S[tid * SR_PD_LD + j] = -s * invjj;
-        } else if (tid == j) {
-            S[j * SR_PD_LD + j] = invjj;
+            if (k < j) s0 = fma(S[row * SR_PD_LD + k], tmp[k], s0);
+        }
+        double sum = s0 + s1;                       // all 64 lanes take part in the shuffles
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        if (part == 0) {
+            if (row < j) S[row * SR_PD_LD + j] = -sum * invjj;
+            else if (row == j) S[j * SR_PD_LD + j] = invjj;
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < SR_NB * SR_NB; idx += 256) {
+    for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
         const int r = idx >> 7, c = idx & 127;
         wt_diag[(long)r * ldw + c] = S[r * SR_PD_LD + c];    // U_kk^-1   (upper)
         w_diag[(long)r * ldw + c] = S[c * SR_PD_LD + r];     // U_kk^-T   (lower)
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void sr_potrf_diag_kernel(double* A, long l
 
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw, int kb,
                          int* info_dev, hipStream_t s) {
-    hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(256), 0, s, A, lda, wt_diag, w_diag, ldw,
+    hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
                        kb, info_dev);
     SR_HIP(hipGetLastError());
     return SR_OK;
