@@ -157,8 +157,8 @@ static int ensure_wt(sr_gp* h) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// factorisation: K = U^T U (right-looking, block 128), W = U^-T (blocked forward substitution),
-// Wt = W^T, alpha = Wt (W y)
+// factorisation: K = U^T U (right-looking, 128-blocks in 512-panels), U^-T / U^-1 by recursive halving,
+// alpha = U^-1 (U^-T y)
 // ---------------------------------------------------------------------------------------------
 extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_factorize: NULL handle");

@@ -647,3 +647,39 @@ def test_c_abi_from_plain_hip_program(lib_built):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "capi_demo OK" in res.stdout
+
+
+@pytest.mark.parametrize("n_s,n_u", [(1, 1), (1, 3), (3, 1), (5, 4), (6, 2), (7, 1), (8, 3), (8, 4)])
+def test_all_state_action_dimensions(n_s, n_u):
+    """every (n_s, n_u) template instance of the ellipsoid kernel (Jacobi eigen-solver for n_s >= 3) and the
+    D = 2..12 paths of the covariance kernel: fused one-step + 3-step chain against the oracle."""
+    from safe_exploration_amd import gp_reachability as reach
+    T, N = 9, 70
+    syn = orc.make_synthetic(100 * n_s + n_u, N, n_s, n_u, T, sf2=0.05)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    rng = np.random.default_rng(n_s * 10 + n_u)
+    l_mu, l_sigma = rng.uniform(0.01, 0.05, n_s), rng.uniform(0.01, 0.05, n_s)
+    a = 0.7 * np.eye(n_s) + 0.05 * rng.standard_normal((n_s, n_s))
+    b = 0.1 * rng.standard_normal((n_s, n_u))
+    p1, q1, var = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l_mu, l_sigma, syn["Q"], syn["k_fb"],
+                                                   1.7, a, b, check_bounds=True, return_var=True)
+    rp, rq, rvar = orc.onestep_reachability_batch(om, syn["p"], syn["Q"], syn["k_ff"], syn["k_fb"], l_mu, l_sigma,
+                                                  1.7, a, b)
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(p1, rp, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(q1, rq, rtol=1e-8, atol=1e-12)
+    H = 3
+    kfb = 0.1 * rng.standard_normal((T, H - 1, n_u, n_s))
+    kff = 0.1 * rng.standard_normal((T, H, n_u))
+    pa, qa = reach.multistep_reachability_batch(syn["p"], gp, kfb, kff, l_mu, l_sigma, None, 1.7, a, b)
+    rpa, rqa = orc.multistep_reachability_batch(om, syn["p"], kfb, kff, l_mu, l_sigma, None, 1.7, a, b)
+    np.testing.assert_allclose(pa, rpa, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(qa, rqa, rtol=1e-7, atol=1e-11)
+    # remainder over-approximation and safety distance for the same dimensions
+    from safe_exploration_amd import utils
+    um, us = utils.compute_remainder_overapproximations_batch(syn["Q"], syn["k_fb"], l_mu, l_sigma)
+    for t in range(T):
+        rum, rus = orc.compute_remainder_overapproximations(syn["Q"][t], syn["k_fb"][t], l_mu, l_sigma)
+        np.testing.assert_allclose(um[t], rum, rtol=1e-11)
+        np.testing.assert_allclose(us[t], rus, rtol=1e-11)
