@@ -39,6 +39,8 @@ WORKLOADS = {
             "one-step ellipsoid branch, fp64", 5, 5000, 2, 1, 65536, 1, 1.0, 1.0),
     "c2": ("C2 pendulum n_s=2 n_u=1 D=3, N=2000 train pts, T=65536 query states/GPU/step, "
            "one-step ellipsoid branch, fp64", 2, 2000, 2, 1, 65536, 1, 1.0, 1.0),
+    "c5": ("C5 pendulum n_s=2 n_u=1 D=3, N=5000 train pts, T=1048576 query states/GPU/step (8M over 8 GPUs), "
+           "16 chunks of 65536 through the bounded workspace, fp64", 5, 5000, 2, 1, 1048576, 1, 1.0, 1.0),
     # the 15-step chain is only numerically meaningful for a contracting prior model and a GP that
     # models a small residual (sigma_f^2 = 0.01, a = 0.5 I), as in the golden chain fixtures
     "c3": ("C3 cart-pole n_s=4 n_u=1 D=5, N=5000 train pts, T=65536 rollouts/GPU/step, H=15 multi-step "
