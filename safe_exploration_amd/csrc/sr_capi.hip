@@ -32,7 +32,9 @@ struct sr_gp {
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 32;
-    int small_path = 1;      // T <= 16: HBM-bound streaming kernels instead of the MFMA tiles
+    int small_path = 1;      // latency paths (streaming T <= 16, 64-tiles, split-K) instead of the plain MFMA tiles
+    int last_streamed = 0;   // the last gp_pass went through the streaming kernels (their partials hold U^-T k*)
+    int force_stream = 0;    // sr_gp_linearize wants those partials whatever the model size
     int var_variant = 1;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles (default)
     sr_prof prof;
 };
@@ -350,7 +352,9 @@ extern "C" int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream) {
 static int pick_nsplit(const sr_gp* h, long Tp) {
     const long blocks = ((Tp + 255) / 256) * h->n_out;
     long ns = (768 + blocks - 1) / blocks;
-    const long maxs = h->Np / SR_NB;
+    // small models: down to 16 training rows per workgroup; never more than max(16, Np/128) partial sums per
+    // query (sr_finalize_kernel adds them serially)
+    const long maxs = std::min((long)h->Np / 16, std::max(16L, (long)h->Np / SR_NB));
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;
     return (int)ns;
@@ -399,12 +403,21 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     }
     int nrb = h->Np / SR_NB;
     const double* var_part = h->var_part;
-    if (Tc <= SR_SMALL_T && h->small_path) {
+    h->last_streamed = 0;
+    if (Tc <= SR_SMALL_T && h->small_path && (h->Np > 1024 || h->force_stream)) {
+        h->last_streamed = 1;
         // latency regime: stream U^-1 once (HBM-bound) instead of the MFMA tiles
         if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, (int)Tc, s));
         nrb = (h->Np + 255) / 256;
+    } else if (h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out)) {
+        // small model, few tiles: 64 x 64 workgroup tiles shorten the critical path of the tiny grid
+        if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));
+        var_part = h->splitk_part;             // n_out * (Np/64) * Tp <= 2 * 256 * 128 * 16 doubles
+        nrb = h->Np / 64;
+        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+        SR_TRY(sr_launch_var64(h->Wt, h->Ks, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else if (h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) {
         // few query tiles: split the K range so that no workgroup serialises a whole row block
         const long need = sr_var_splitk_ws(h->Np, Tp, h->n_out);
@@ -462,14 +475,17 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_HIP(hipSetDevice(h->device));
     if (!h->lin_v) SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np));
     if (!h->lin_g) SR_TRY(dev_alloc(&h->lin_g, (size_t)h->n_out * h->Np));
-    SR_TRY(gp_pass(h, 1, x, h->D, h->D, nullptr, 0, 0, mu, var, jac_mu, s));    // leaves K*(:,0) in the workspace
+    h->force_stream = 1;
+    const int rc_pass = gp_pass(h, 1, x, h->D, h->D, nullptr, 0, 0, mu, var, jac_mu, s);   // leaves K*(:,0) in the workspace
+    h->force_stream = 0;
+    SR_TRY(rc_pass);
     const long Tp = srt::BN;
-    if (h->small_path)       // v = U^-T k* is what the streaming variance pass just accumulated
+    if (h->last_streamed)    // v = U^-T k* is what the streaming variance pass just accumulated
         SR_TRY(sr_launch_var_small_gather(h->small_vp, h->lin_v, h->Np, h->n_out, 0, s));
     for (int d = 0; d < h->n_out; ++d) {
         const double* Wt = h->Wt + (size_t)d * h->Np * h->Np;
         const double* ks = h->Ks + (size_t)d * h->Np * Tp;
-        if (!h->small_path)
+        if (!h->last_streamed)
             SR_TRY(sr_launch_trmv_t(Wt, h->Np, ks, Tp, h->lin_v + (size_t)d * h->Np, h->Np, s));  // v = U^-T k*
         SR_TRY(sr_launch_trmv(Wt, h->Np, h->lin_v + (size_t)d * h->Np, h->lin_g + (size_t)d * h->Np,
                               h->Np, 0, s));                                                       // g = U^-1 v

@@ -149,6 +149,11 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                   int group, int variant, hipStream_t s);
 
+// 64 x 64 tile variant for small models (sr_predict.hip, K2m): part layout [d][Np/64][Tp]
+bool sr_var64_wanted(int Np, long Tp, int n_out);
+int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
+                    hipStream_t s);
+
 // split-K form of the variance kernel for few query tiles (sr_predict.hip, K2k)
 long sr_var_splitk_ws(int Np, long Tp, int n_out);
 bool sr_var_splitk_wanted(int Np, long Tp, int n_out);

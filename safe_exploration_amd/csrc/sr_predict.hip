@@ -294,6 +294,111 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
 
 
 // ------------------------------------------------------------------------------------------------
+// K2m: 64 x 64 workgroup tile for SMALL models (Np <= 1024, few workgroups): the regime the reference's
+// own experiments run in (N = 25 .. 150 inducing points, a few hundred candidate states per step).
+// Same contraction as K2; 4 wavefronts of 32 x 32 (2 x 2 MFMA tiles), register-staged double-buffered
+// LDS tiles, triangular K range at 64-row granularity.  A k-step costs 16 MFMAs per wavefront instead of
+// 64, so the critical path of the (tiny) grid is 4x shorter.
+// ------------------------------------------------------------------------------------------------
+#define SR_T64 64
+#define SR_LD64 80      // 64 + 16 doubles: row stride 160 dwords == 32 mod 64 (conflict-free ds_read_b64)
+__global__ __launch_bounds__(256) void sr_var64_kernel(const double* __restrict__ Wt,
+                                                       const double* __restrict__ Ks,
+                                                       double* __restrict__ part, int Np, long Tp, int k_beg) {
+    __shared__ double As[2][16][SR_LD64];
+    __shared__ double Bs[2][16][SR_LD64];
+    __shared__ double red[2][SR_T64];
+    const int x = blockIdx.x, rb = blockIdx.y, d = blockIdx.z;      // 64-query tile, 64-row block, output
+    const int nrb = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const double* A = Wt + (long)d * Np * Np + (long)rb * SR_T64;
+    const double* B = Ks + (long)d * Np * Tp + (long)x * SR_T64;
+    const int k_end = (rb + 1) * SR_T64;
+    // staging map: 16 rows x 32 double2 per operand = 512 double2; thread takes rows r0, r0 + 8
+    const int c2 = tid & 31, r0 = tid >> 5;
+    double2 ra0, ra1, rb0, rb1;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+#define SR64_GLOAD(k0)                                                                              \
+    do {                                                                                             \
+        ra0 = *reinterpret_cast<const double2*>(A + (long)((k0) + r0) * Np + 2 * c2);               \
+        ra1 = *reinterpret_cast<const double2*>(A + (long)((k0) + r0 + 8) * Np + 2 * c2);           \
+        rb0 = *reinterpret_cast<const double2*>(B + (long)((k0) + r0) * Tp + 2 * c2);               \
+        rb1 = *reinterpret_cast<const double2*>(B + (long)((k0) + r0 + 8) * Tp + 2 * c2);           \
+    } while (0)
+#define SR64_SSTORE(buf)                                                                             \
+    do {                                                                                             \
+        *reinterpret_cast<double2*>(&As[buf][r0][2 * c2]) = ra0;                                     \
+        *reinterpret_cast<double2*>(&As[buf][r0 + 8][2 * c2]) = ra1;                                 \
+        *reinterpret_cast<double2*>(&Bs[buf][r0][2 * c2]) = rb0;                                     \
+        *reinterpret_cast<double2*>(&Bs[buf][r0 + 8][2 * c2]) = rb1;                                 \
+    } while (0)
+    if (k_beg < k_end) {
+        SR64_GLOAD(k_beg);
+        SR64_SSTORE(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
+        const bool more = (k0 + 16) < k_end;
+        if (more) SR64_GLOAD(k0 + 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = As[buf][kk * 4 + (lane >> 4)][wm * 32 + i * 16 + (lane & 15)];
+                bf[i] = Bs[buf][kk * 4 + (lane >> 4)][wn * 32 + i * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) SR64_SSTORE(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef SR64_GLOAD
+#undef SR64_SSTORE
+    // column sums of squares over the 64 rows: in-lane, across the 4 row groups, across the 2 wavefront rows
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        double v = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v = fma(acc[mi][ni][r], acc[mi][ni][r], v);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) red[wm][wn * 32 + ni * 16 + lane] = v;
+    }
+    __syncthreads();
+    if (tid < SR_T64) part[((long)d * nrb + rb) * Tp + (long)x * SR_T64 + tid] = red[0][tid] + red[1][tid];
+}
+
+// profitable when the model is small and the 128-tile grid would leave most of the chip idle
+bool sr_var64_wanted(int Np, long Tp, int n_out) {
+    const long wgs128 = (long)(Np / srt::BM) * (Tp / srt::BN) * n_out;
+    return Np <= 1024 && wgs128 < 256;
+}
+
+int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
+                    hipStream_t s) {
+    const int k_beg = ((Np - N) / 16) * 16;
+    hipLaunchKernelGGL(sr_var64_kernel, dim3((unsigned)(Tp / SR_T64), Np / SR_T64, n_out), dim3(256), 0, s, Wt, Ks,
+                       part, Np, Tp, k_beg);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2k: split-K form of K2 for FEW query tiles (16 < T <~ 1500 at N = 5000: batches of candidate
 // rollouts).  With so few tiles the plain kernel is serialised on its longest row block (40 k-blocks);
 // here every (row block, query tile) is cut into chunks of 8 k-blocks that run as independent
