@@ -176,6 +176,21 @@ int sr_safety_distance(int device, long T, int n_s, int m, const double* p, cons
 int sr_distance_to_center(int device, long T, int K, int n_s, const double* samples, int per_t,
                           const double* p, const double* q, double* d, void* stream);
 
+/* replaces: the determinant inside SimpleGPModel.information_gain  ssm_gpy/gaussian_process.py:621-634
+ * (log det(I + K/sigma_n^2) = log det(K + sigma_n^2 I) - N log sigma_n^2).
+ * logdet[d] = log det(K_d + noise_d I) of the factorised (or imported) model, from the diagonal of U^-1. */
+int sr_gp_logdet(sr_gp_t h, double* logdet /* n_out, device */, void* stream);
+
+/* replaces: SimpleGPModel.sample_from_gp  ssm_gpy/gaussian_process.py:598-619 (marginal posterior samples,
+ * GPy posterior_samples_f(full_cov=False)) and the propagation step of
+ * MonteCarloSafetyVerification.sample_n_step  sampling_models.py:66-80.
+ * mu, var T x n_out (from sr_gp_predict), eps T x size x n_out standard-normal draws supplied by the
+ * caller -> S T x size x n_out = mu + sqrt(var) * eps.  If z_next != NULL it also receives the next GP
+ * inputs T x size x (n_out + n_u): [S, k_fb S + k_ff] with k_fb n_u x n_out, k_ff n_u. */
+int sr_gp_sample(int device, long T, int size, int n_out, int n_u, const double* mu, const double* var,
+                 const double* eps, double* S, const double* k_fb, const double* k_ff, double* z_next,
+                 void* stream);
+
 /* ---- tuning / measurement -------------------------------------------------------------------- */
 /* max queries processed per internal pass (workspace = n_out * Np * chunk * 8 B); default 65536. */
 int sr_gp_set_chunk(sr_gp_t h, long chunk);

@@ -450,3 +450,39 @@ def multistep_moments_batch(model, mu_0, k_ff, k_fb, a, b, taylor=True):
             mu, sig = one_step_moments(mu, sig, k_ff[t, i], None if i == 0 else k_fb[t, i - 1], m, v, j, a, b, taylor)
             mu_all[t, i], sigma_all[t, i] = mu, sig
     return mu_all, sigma_all
+
+
+# --------------------------------------------------------------------------- Monte-Carlo verification
+def sample_from_gp(model, inp, eps):
+    """ssm_gpy/gaussian_process.py:598-619 with GPy posterior_samples_f(full_cov=False): independent
+    marginal draws per test input.  inp (n, D), eps (n, size, n_s) standard normal -> S (n, size, n_s)."""
+    mu, var = gp_predict(inp, model["Z"], model["beta"], model["inv_K"], model["lengthscale"],
+                         model["signal_var"], compute_gradients=False)
+    return mu[:, None, :] + np.sqrt(var)[:, None, :] * eps
+
+
+def mc_sample_n_step(model, x0, K, k, eps):
+    """sampling_models.py:33-80.  x0 (n_s,1), K (n, n_u, n_s), k (n, n_u), eps (n, n_samples, n_s)
+    -> S_all (n, n_samples, n_s)."""
+    n, n_samples, n_s = eps.shape
+    u0 = K[0].dot(x0) + k[0, :, None]
+    inp0 = np.vstack((x0, u0)).T
+    S_all = np.empty((n, n_samples, n_s))
+    S = sample_from_gp(model, inp0, eps[0][None]).reshape(n_samples, n_s)
+    S_all[0] = S
+    for i in range(1, n):
+        U = S.dot(K[i].T) + k[i][None, :]
+        S = sample_from_gp(model, np.hstack((S, U)), eps[i][:, None, :]).reshape(n_samples, n_s)
+        S_all[i] = S
+    return S_all
+
+
+def information_gain(Z, lengthscale, signal_var, noise_var_fixed):
+    """ssm_gpy/gaussian_process.py:621-634: per output log det(I + K/sigma_n^2), K the noise-free training
+    Gram matrix (GPy ``posterior._K``), sigma_n^2 the fixed Gaussian noise (incl. noise_diag, :252-253)."""
+    out = []
+    N = Z.shape[0]
+    for d in range(len(signal_var)):
+        Kd = rbf_kernel(Z, Z, signal_var[d], lengthscale[d])
+        out.append(np.linalg.slogdet(np.eye(N) + Kd / noise_var_fixed[d])[1])
+    return out

@@ -321,6 +321,13 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
     return SR_OK;
 }
 
+extern "C" int sr_gp_logdet(sr_gp_t h, double* logdet, void* stream) {
+    SR_CHECK(h && logdet, SR_EINVAL, "sr_gp_logdet: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_logdet: model not factorized");
+    SR_HIP(hipSetDevice(h->device));
+    return sr_launch_logdet(h->Wt, h->Np, h->n_out, logdet, (hipStream_t)stream);
+}
+
 extern "C" int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream) {
     SR_CHECK(h && inv_k, SR_EINVAL, "sr_gp_inv_k: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_inv_k: model not factorized");
@@ -352,9 +359,10 @@ extern "C" int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream) {
 static int pick_nsplit(const sr_gp* h, long Tp) {
     const long blocks = ((Tp + 255) / 256) * h->n_out;
     long ns = (768 + blocks - 1) / blocks;
-    // small models: down to 16 training rows per workgroup; never more than max(16, Np/128) partial sums per
-    // query (sr_finalize_kernel adds them serially)
-    const long maxs = std::min((long)h->Np / 16, std::max(16L, (long)h->Np / SR_NB));
+    // down to 16 training rows per workgroup (a 16-long exp chain); beyond SR_FINAL_WAVE_T queries
+    // sr_finalize_kernel adds the partial sums serially per thread: never more than max(16, Np/128) there
+    const long maxs = Tp <= SR_FINAL_WAVE_T ? (long)h->Np / 16
+                                            : std::min((long)h->Np / 16, std::max(16L, (long)h->Np / SR_NB));
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;
     return (int)ns;
@@ -481,7 +489,7 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_TRY(rc_pass);
     const long Tp = srt::BN;
     if (h->last_streamed)    // v = U^-T k* is what the streaming variance pass just accumulated
-        SR_TRY(sr_launch_var_small_gather(h->small_vp, h->lin_v, h->Np, h->n_out, 0, s));
+        SR_TRY(sr_launch_var_small_gather(h->small_vp, h->lin_v, h->Np, h->n_out, 0, 1, s));
     for (int d = 0; d < h->n_out; ++d) {
         const double* Wt = h->Wt + (size_t)d * h->Np * h->Np;
         const double* ks = h->Ks + (size_t)d * h->Np * Tp;
@@ -701,6 +709,18 @@ extern "C" int sr_distance_to_center(int device, long T, int K, int n_s, const d
     SR_CHECK(samples && p && q && d, SR_EINVAL, "sr_distance_to_center: NULL argument");
     SR_HIP(hipSetDevice(device));
     return sr_launch_distance(T, K, n_s, samples, per_t, p, q, d, (hipStream_t)stream);
+}
+
+extern "C" int sr_gp_sample(int device, long T, int size, int n_out, int n_u, const double* mu,
+                            const double* var, const double* eps, double* S, const double* k_fb,
+                            const double* k_ff, double* z_next, void* stream) {
+    SR_CHECK(T >= 0 && size >= 0 && n_out >= 1 && n_out <= SR_MAX_NS && n_u >= 0, SR_EINVAL,
+             "sr_gp_sample: T=%ld size=%d n_out=%d n_u=%d", T, size, n_out, n_u);
+    if (T == 0 || size == 0) return SR_OK;
+    SR_CHECK(mu && var && eps && S, SR_EINVAL, "sr_gp_sample: NULL argument");
+    SR_CHECK(!z_next || n_u == 0 || (k_fb && k_ff), SR_EINVAL, "sr_gp_sample: z_next needs k_fb and k_ff");
+    SR_HIP(hipSetDevice(device));
+    return sr_launch_sample(T, size, n_out, n_u, mu, var, eps, S, k_fb, k_ff, z_next, (hipStream_t)stream);
 }
 
 extern "C" int sr_gp_set_chunk(sr_gp_t h, long chunk) {

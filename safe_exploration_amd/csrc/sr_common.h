@@ -115,6 +115,7 @@ int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd
 // y[r] = sum_c M[r][c] x[c], c in [0..r] (lower=1) or [r..n) (lower=0)
 int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
                    hipStream_t s);
+int sr_launch_logdet(const double* Wt, int Np, int n_out, double* out, hipStream_t s);
 int sr_launch_fill(double* p, size_t n, double v, hipStream_t s);
 int sr_launch_sub_block(double* S, const double* G, int pf, hipStream_t s);
 int sr_launch_append_assemble(const double* Wt0, int Np0, int off0, int N0, const double* Y2,
@@ -162,11 +163,12 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 
 // small-batch (T <= 16) variance path: U^-1 streamed once at HBM rate (sr_predict.hip, K2s)
 #define SR_SMALL_T 16
+#define SR_FINAL_WAVE_T 4096   /* up to here sr_finalize runs one wavefront per (query, output) */
 long sr_var_small_ws(int Np, int n_out);
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
                         long Tp, int n_out, int T, hipStream_t s);
 
-int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, hipStream_t s);
+int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, int T, hipStream_t s);
 
 struct sr_final_args {
     const double* mu_part; const double* jac_part; const double* var_part; const double* sf2;
@@ -195,6 +197,9 @@ int sr_launch_ellipsoid(const sr_ell_args& a, hipStream_t s);
 int sr_launch_remainder(long T, int n_s, int n_u, const double* q, const double* k_fb,
                         const double* l_mu, const double* l_sigma, double* u_mu, double* u_sigma,
                         hipStream_t s);
+int sr_launch_sample(long T, int size, int n_out, int n_u, const double* mu, const double* var,
+                     const double* eps, double* S, const double* k_fb, const double* k_ff, double* z,
+                     hipStream_t s);
 int sr_launch_distance(long T, int K, int n_s, const double* samples, int per_t, const double* p,
                        const double* q, double* d, hipStream_t s);
 int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, const double* h_mat,

@@ -380,6 +380,51 @@ int sr_launch_distance(long T, int K, int n_s, const double* samples, int per_t,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Monte-Carlo propagation step (sampling_models.py:66-80 + ssm_gpy/gaussian_process.py:598-619):
+//   S[t][j][:]  = mu[t][:] + sqrt(var[t][:]) * eps[t][j][:]          (marginal posterior samples)
+//   z[t][j][:]  = [ S[t][j][:],  k_fb S[t][j][:] + k_ff ]            (next GP inputs, optional)
+// One thread per sample; pure streaming (eps in, S/z out).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_sample_kernel(long T, int size, int n_out, int n_u,
+                                                        const double* __restrict__ mu,
+                                                        const double* __restrict__ var,
+                                                        const double* __restrict__ eps,
+                                                        double* __restrict__ S,
+                                                        const double* __restrict__ k_fb,
+                                                        const double* __restrict__ k_ff,
+                                                        double* __restrict__ z) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * size) return;
+    const long t = idx / size;
+    double sv[SR_MAX_NS];
+    for (int d = 0; d < n_out; ++d) {
+        const double v = mu[t * n_out + d] + sqrt(var[t * n_out + d]) * eps[idx * n_out + d];
+        sv[d] = v;
+        S[idx * n_out + d] = v;
+    }
+    if (z) {
+        double* zr = z + idx * (n_out + n_u);
+        for (int d = 0; d < n_out; ++d) zr[d] = sv[d];
+        for (int u = 0; u < n_u; ++u) {
+            double a = k_ff[u];
+            for (int d = 0; d < n_out; ++d) a = fma(k_fb[u * n_out + d], sv[d], a);
+            zr[n_out + u] = a;
+        }
+    }
+}
+
+int sr_launch_sample(long T, int size, int n_out, int n_u, const double* mu, const double* var,
+                     const double* eps, double* S, const double* k_fb, const double* k_ff, double* z,
+                     hipStream_t s) {
+    if (T <= 0 || size <= 0) return SR_OK;
+    dim3 grid((unsigned)((T * size + 255) / 256));
+    hipLaunchKernelGGL(sr_sample_kernel, grid, dim3(256), 0, s, T, size, n_out, n_u, mu, var, eps, S, k_fb,
+                       k_ff, z);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // dispatch on (n_s, n_u)
 // ---------------------------------------------------------------------------------------------
 template <int NS>

@@ -360,3 +360,25 @@ int sr_launch_fill(double* p, size_t n, double v, hipStream_t s) {
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// log det(K_y) per output from the diagonal of U^-1:  log det = -2 sum_i log (U^-1)_ii.
+// One workgroup per output; the padding block has unit diagonal and contributes nothing.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sr_logdet_kernel(const double* __restrict__ Wt, int Np,
+                                                        double* __restrict__ out) {
+    __shared__ double red[4];
+    const double* W = Wt + (size_t)blockIdx.x * Np * Np;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < Np; i += 256) acc += log(W[(size_t)i * Np + i]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = -2.0 * (red[0] + red[1] + red[2] + red[3]);
+}
+
+int sr_launch_logdet(const double* Wt, int Np, int n_out, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(sr_logdet_kernel, dim3(n_out), dim3(256), 0, s, Wt, Np, out);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}

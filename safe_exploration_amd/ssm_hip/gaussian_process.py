@@ -339,6 +339,7 @@ class SimpleGPModel(StateSpaceModel):
         check(lib.sr_gp_import(handle.h, B.ptr(ta), B.ptr(tw), s))
         torch.cuda.current_stream(dev).synchronize()
         self._handle = handle
+        self._noise_diag = noise_diag
         self._beta = None
         self._inv_K = None
         self.z = Z
@@ -493,11 +494,57 @@ class SimpleGPModel(StateSpaceModel):
         grad = seed[:n].dot(jm) + seed[n:2 * n].dot(jv) + np.einsum('ij,ijk->k', seed[2 * n:].reshape(n, D), hm)
         return grad[:self.n_s_in, None], grad[self.n_s_in:, None]
 
-    def sample_from_gp(self, inp, size=10):
-        raise NotImplementedError("posterior sampling is outside the MI355X hot path")
+    def sample_device(self, inp, size=10, eps=None, generator=None, k_fb=None, k_ff=None):
+        """Marginal posterior samples on the device: inp (n, D) -> S (n, size, n_s_out) = mu + sqrt(var) eps.
+        eps (n, size, n_s_out) standard-normal draws may be supplied (tests, common random numbers);
+        otherwise they come from torch's device generator.  With k_fb (n_u, n_s), k_ff (n_u,) the next GP
+        inputs [S, k_fb S + k_ff] (n, size, D) are returned as well (sampling_models.py:66-80)."""
+        mu, var = self.predict_device(inp)
+        hd = self._handle
+        n, n_out = mu.shape
+        size = int(size)
+        if eps is None:
+            eps = torch.randn((n, size, n_out), dtype=torch.float64, device=hd.device, generator=generator)
+        else:
+            eps = B.as_dev(eps, hd.device, (n, size, n_out))
+        S = B.empty((n, size, n_out), hd.device)
+        z = tk = tf = None
+        n_u = 0
+        if k_fb is not None:
+            n_u = hd.D - n_out
+            if n_u < 0:
+                raise ValueError("next inputs need D = n_s_out + n_u")
+            tk = B.as_dev(k_fb, hd.device, (n_u, n_out))
+            tf = B.as_dev(k_ff, hd.device, (n_u,))
+            z = B.empty((n, size, hd.D), hd.device)
+        check(lib.sr_gp_sample(hd.device.index, n, size, n_out, n_u, B.ptr(mu), B.ptr(var), B.ptr(eps),
+                               B.ptr(S), B.ptr(tk), B.ptr(tf), B.ptr(z), B.stream_ptr(hd.device)))
+        return S if z is None else (S, z)
+
+    def sample_from_gp(self, inp, size=10, eps=None, generator=None):
+        """Sample from the GP predictive (latent, marginal) distribution  gaussian_process.py:598-619.
+
+        inp (n, n_s+n_u) -> S (n, size, n_s_out); S[i, :, d] ~ N(mu_d(x_i), var_d(x_i)) independently per test
+        input, as GPy's ``posterior_samples_f(full_cov=False)`` draws them."""
+        S = self.sample_device(inp, size, eps, generator)
+        return S if B.is_tensor(inp) else B.to_numpy(S)
 
     def information_gain(self, x=None):
-        raise NotImplementedError("information gain is outside the MI355X hot path")
+        """Mutual information between the training samples and the system  gaussian_process.py:621-634:
+        per output log det(I + K/sigma_n^2) = log det(K + sigma_n^2 I) - N log sigma_n^2, sigma_n^2 being the
+        fixed Gaussian noise incl. noise_diag.  The reference always uses the TRAINING Gram matrix
+        (``posterior._K``) and x only for its size, so only x=None / x=z is meaningful.  The factor held
+        here carries GPy's 1e-8 inference jitter on top: absolute deviation <= N*1e-8/sigma_n^2."""
+        self._need_trained()
+        hd = self._handle
+        if x is not None and np.shape(x)[0] != hd.N:
+            raise ValueError("information_gain is defined on the training inputs (got {} rows, model holds {})"
+                             .format(np.shape(x)[0], hd.N))
+        out = B.empty((hd.n_out,), hd.device)
+        check(lib.sr_gp_logdet(hd.h, B.ptr(out), B.stream_ptr(hd.device)))
+        nv = self._noise + float(self._noise_diag)
+        ld = B.to_numpy(out) - hd.N * np.log(nv)
+        return [float(v) for v in ld]
 
     # ------------------------------------------------------------------ measurement hooks
     def set_chunk(self, chunk):

@@ -387,6 +387,50 @@ def main():
     moments_case("moments_pend.npz", 401, 60, 2, 1, 5, 6)
     moments_case("moments_cart.npz", 402, 80, 4, 1, 4, 5)
 
+    # ------------------------------------------------------------------ 6. Monte-Carlo verification
+    # The reference's MonteCarloSafetyVerification driven with a stand-in GP whose sample_from_gp replays
+    # stored standard-normal draws through the oracle posterior: pins the closed-loop bookkeeping
+    # (K[0] on x0, K[i] on the particles of step i-1, shapes) and inside_ellipsoid_ratio.
+    from safe_exploration import sampling_models as ref_mc
+
+    def mc_case(name, seed, N, n_s, n_u, n, n_samples):
+        syn = orc.make_synthetic(seed, N, n_s, n_u, 4, sf2=0.01)
+        beta, inv_K, _ = orc.gp_fit(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+        model = dict(Z=syn["Z"], beta=beta, inv_K=inv_K, lengthscale=syn["lengthscale"], signal_var=syn["signal_var"])
+        rng = np.random.default_rng(seed + 9)
+        eps = rng.standard_normal((n, n_samples, n_s))
+        K = 0.1 * rng.standard_normal((n, n_u, n_s))
+        k = 0.1 * rng.standard_normal((n, n_u))
+        x0 = 0.1 * rng.standard_normal((n_s, 1))
+
+        class ReplayGP(object):
+            def __init__(self):
+                self.n_s, self.n_u, self.calls = n_s, n_u, 0
+
+            def sample_from_gp(self, inp, size=10):
+                e = eps[self.calls][None] if self.calls == 0 else eps[self.calls][:, None, :]
+                self.calls += 1
+                assert e.shape == (inp.shape[0], size, n_s)
+                return orc.sample_from_gp(model, np.asarray(inp, dtype=np.float64), e)
+
+        mc = ref_mc.MonteCarloSafetyVerification(ReplayGP())
+        S, S_all = mc.sample_n_step(x0, K, k, n, n_samples)
+        assert np.allclose(orc.mc_sample_n_step(model, x0, K, k, eps), S_all, rtol=1e-13, atol=1e-15)
+        # ellipsoids around the particle clouds, sized so that a fraction of the particles falls outside
+        p = S_all.mean(axis=1)
+        Q = np.empty((n, n_s, n_s)); ratio = np.empty(n); inside = np.empty((n, n_samples), dtype=bool)
+        for i in range(n):
+            c = np.cov(S_all[i].T) + 1e-12 * np.eye(n_s)
+            Q[i] = (1.0 + 0.5 * i) * c * 2.0
+            r, rb = mc.inside_ellipsoid_ratio(S_all[i][None], Q[i][None], p[i][None])   # (the reference's float() needs n == 1)
+            ratio[i], inside[i] = r, rb[0].astype(bool)
+        res = {kk: syn[kk] for kk in ("Z", "Y", "lengthscale", "signal_var", "noise_var")}
+        res.update(eps=eps, K=K, k=k, x0=x0, S_all=S_all, S_last=S, ell_p=p, ell_q=Q, ratio=ratio, inside=inside)
+        _save(name, **res)
+
+    mc_case("mc_pend.npz", 501, 60, 2, 1, 4, 64)      # n_u = 1: the reference's repmat of k[i] is only shaped right there
+    mc_case("mc_cart.npz", 502, 80, 4, 1, 3, 48)
+
     # ------------------------------------------------------------------ 5. worked anchor of SURVEY 8c
     p = np.array([[0.1], [-0.2]]); Q = 0.2 * np.array([[.5, .2], [.2, .65]])
     k_ff = np.array([[0.3]]); k_fb = np.array([[0.4, -0.1]])

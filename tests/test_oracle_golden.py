@@ -250,3 +250,28 @@ def test_moment_propagation_vs_reference(name):
     K = g["k_fb"][0, 0]
     H = g["a_lin"] + jg_[:, :n_s] + (jg_[:, n_s:] + g["b_lin"]).dot(K)
     np.testing.assert_allclose(H.dot(g["sigma_taylor"][0, 0]).dot(H.T) + np.diag(vg_), g["sigma_taylor"][0, 1], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["mc_pend.npz", "mc_cart.npz"])
+def test_monte_carlo_propagation_vs_reference(name):
+    """oracle's particle propagation == the reference's MonteCarloSafetyVerification.sample_n_step replaying the
+    same standard-normal draws (tests/golden/make_golden.py 6); containment == its inside_ellipsoid_ratio."""
+    g = load_golden(name)
+    m = _model(g)
+    S_all = orc.mc_sample_n_step(m, g["x0"], g["K"], g["k"], g["eps"])
+    np.testing.assert_allclose(S_all, g["S_all"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_array_equal(S_all[-1], g["S_last"])
+    for i in range(S_all.shape[0]):
+        inside = orc.distance_to_center(g["S_all"][i], g["ell_p"][i][:, None], g["ell_q"][i]) < 1.0
+        np.testing.assert_array_equal(inside, g["inside"][i])
+        assert abs(inside.mean() - g["ratio"][i]) < 1e-15
+
+
+def test_information_gain_identity():
+    """log det(I + K/s) == log det(K + s I) - N log s: the form the device computes from the factor."""
+    syn = orc.make_synthetic(77, 40, 2, 1, 2)
+    ig = orc.information_gain(syn["Z"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    for d in range(2):
+        K = orc.rbf_kernel(syn["Z"], syn["Z"], syn["signal_var"][d], syn["lengthscale"][d])
+        alt = np.linalg.slogdet(K + syn["noise_var"][d] * np.eye(40))[1] - 40 * np.log(syn["noise_var"][d])
+        assert abs(ig[d] - alt) < 1e-9
