@@ -14,7 +14,7 @@ import torch  # noqa: F401  MUST precede CDLL below: PyTorch-ROCm bundles its ow
 from ._build import LIB_PATH
 
 SR_OK, SR_EINVAL, SR_EHIP, SR_ENOTPD, SR_ESTATE, SR_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-K_GRAM, K_POTRF, K_GEMM, K_KSTAR, K_VAR, K_FINAL, K_ELL, K_TRINV = range(8)
+K_GRAM, K_POTRF, K_GEMM, K_KSTAR, K_VAR, K_FINAL, K_ELL, K_TRINV, K_SMALL = range(9)
 KERNEL_NAMES = {K_GRAM: "sr_gram_kernel", K_POTRF: "sr_potrf_diag_kernel", K_GEMM: "sr_gemm_tn_kernel",
                 K_KSTAR: "sr_kstar_kernel", K_VAR: "sr_var_kernel", K_FINAL: "sr_finalize_kernel",
                 K_ELL: "sr_ellipsoid_kernel"}

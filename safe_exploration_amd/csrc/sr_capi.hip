@@ -395,6 +395,17 @@ static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
 // GP posterior of Tc queries x = [xa | xb] into (mu, var, jac) in API layout (jac may be NULL).
 static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb,
                    int nb, double* mu, double* var, double* jac, hipStream_t s) {
+    if (h->small_path == 1 && !h->force_stream && sr_gp_small_wanted(h->Np, Tc, h->D, h->general != 0)) {
+        // small model, few queries: one launch, no workspace (sr_small.hip)
+        sr_kstar_args ka{};
+        ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+        ka.xa = xa; ka.lda = lda; ka.na = na; ka.xb = xb; ka.ldb = ldb; ka.nb = nb;
+        ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = 1;
+        ka.T = Tc; ka.Tp = Tc;
+        h->last_streamed = 0;
+        sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
+        return sr_launch_gp_small(ka, h->Wt, mu, var, jac, s);
+    }
     const long Tp = round_up(Tc, srt::BN);
     const int nsplit = pick_nsplit(h, Tp);
     SR_TRY(ensure_ws(h, Tp, nsplit));
@@ -737,7 +748,7 @@ extern "C" int sr_gp_set_var_group(sr_gp_t h, int group) {
 
 extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_small_path: NULL handle");
-    h->small_path = on ? 1 : 0;
+    h->small_path = on;      // 0: plain three-kernel pass only; 1: all latency paths; 2: all but the fused K0
     return SR_OK;
 }
 

@@ -146,6 +146,11 @@ struct sr_kstar_args {
 };
 int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 
+// K0 (sr_small.hip): whole posterior of a small ARD-RBF model in one launch, outputs in the API layout
+bool sr_gp_small_wanted(int Np, long T, int D, bool general);
+int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
+                       hipStream_t s);
+
 // part[d][rb][t] = sum_{i in row block rb} ( sum_k Wt[d][k][i] Ks[d][k][t] )^2
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                   int group, int variant, hipStream_t s);
@@ -163,6 +168,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 
 // small-batch (T <= 16) variance path: U^-1 streamed once at HBM rate (sr_predict.hip, K2s)
 #define SR_SMALL_T 16
+#define SR_FUSED_T 1024        /* up to here a model with Np <= 256 takes the one-launch pass of sr_small.hip */
 #define SR_FINAL_WAVE_T 4096   /* up to here sr_finalize runs one wavefront per (query, output) */
 long sr_var_small_ws(int Np, int n_out);
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,

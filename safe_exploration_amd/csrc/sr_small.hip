@@ -1,0 +1,212 @@
+// sr_small.hip -- K0: the whole GP posterior of a SMALL model in one launch.
+//
+// Regime: the reference's own experiments (25 .. 150 inducing points; Np <= 256 here)
+// driven with one query (CasADi/IPOPT callback) up to ~1000 candidate states per step.  There the
+// three-kernel pass K1 -> K2m -> K3 is three dependent launches of tiny grids, each bound by its own chain
+// of global-load round trips (6 + 13 + 5 us at N = 200); nothing is bound by flops or bytes.
+// One workgroup of 16 wavefronts evaluates SR_FQ = 16 queries of ONE output, everything on the fp64 MFMA
+// 16x16x4 tile so that no operand is ever broadcast through LDS:
+//
+//   phase A  wavefront w owns Np/16 training rows: each lane evaluates k*[i][t] for its (i, t) of the
+//            MFMA A-fragment, stores it to LDS and multiplies it on the spot with the B-fragment
+//            M[i][:] = alpha_i [1, z_i/l]:  R[t][:] = sum_i k*[i][t] M[i][:]  gives
+//            mu_t = R[t][0]  and  d mu_t/dx_j = (R[t][1+j] - x_tj/l_j R[t][0]) / l_j
+//   phase B  V[i][t] = sum_{k<=i} Wt[k][i] k*[k][t]: 16-column strips of U^-1, strips s and Np/16-1-s paired
+//            and their k range cut into 32/(Np/16) parts so that all 16 wavefronts carry the same number of
+//            MFMAs (34 at Np = 256); A-fragments straight from L2, up to 16 loads in flight per lane
+//   phase C  parts added in a fixed order, var_t = max(sf2 - sum_i V[i][t]^2, 1e-15)
+//
+// Outputs go straight to the API layout: no partial buffers in HBM, no finalize launch.
+// formulas: /root/reference/safe_exploration/ssm_gpy/gp_models_utils_casadi.py:17-40,160-197
+// shapes:   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:546-596
+#include "sr_common.h"
+
+#define SR_FQ 16         // queries per workgroup == N of the MFMA tile
+typedef double sr_d4 __attribute__((ext_vector_type(4)));
+
+template <int NP, int DT>
+__global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, const double* __restrict__ Wt,
+                                                           double* __restrict__ mu, double* __restrict__ var,
+                                                           double* __restrict__ jac) {
+    constexpr int NSTRIP = NP / 16;          // 16-column strips of U^-1
+    constexpr int NSPLIT = 32 / NSTRIP;      // wavefronts sharing one strip pair (k range cut into NSPLIT parts)
+    constexpr int RPW = NP / 16;             // training rows per wavefront in phase A
+    static_assert(DT + 1 <= 16, "the mean/Jacobian right-hand side must fit the 16 MFMA columns");
+    __shared__ double ks[NP][SR_FQ];                     // k*[k][t]
+    __shared__ double xq[SR_FQ][DT];                     // queries of this tile, scaled by 1/lengthscale
+    __shared__ double pA[16][256];                       // phase A: per-wavefront partial R (accumulator layout)
+    __shared__ double Rs[SR_FQ][16];                     // R[t][c]
+    __shared__ double pB[NSPLIT - 1][NSTRIP][256];       // phase B: partial V tiles of the parts h > 0
+    __shared__ double redC[NSTRIP][SR_FQ];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, ln = lane & 15;             // fragment coordinates: k offset, m/n index
+    const int d = blockIdx.y;
+    const long t0 = (long)blockIdx.x * SR_FQ;
+    const int off = NP - a.N;                             // front padding
+
+    const int pr = wave / NSPLIT, h = wave % NSPLIT;      // phase-B work: part h of strips pr and NSTRIP-1-pr
+    const double sf2 = a.sf2[d];
+    const bool live = t0 + ln < a.T;
+
+    // ---- phase A ------------------------------------------------------------------------------
+    {
+        // all global loads of the phase first (one round trip), then the arithmetic
+        double xs[DT], il[DT], zv[RPW / 4][DT], al[RPW / 4];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            il[j] = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
+            xs[j] = 0.0;
+            if (live && j < a.D) xs[j] = (j < a.na) ? a.xa[(t0 + ln) * a.lda + j] : a.xb[(t0 + ln) * a.ldb + (j - a.na)];
+        }
+#pragma unroll
+        for (int st = 0; st < RPW / 4; ++st) {
+            const int i = wave * RPW + 4 * st + lk;
+            const bool valid = i >= off;
+            al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) zv[st][j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            il[j] = (j < a.D) ? 1.0 / il[j] : 0.0;
+            xs[j] *= il[j];
+        }
+        sr_d4 accA = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < RPW / 4; ++st) {
+            const int i = wave * RPW + 4 * st + lk;
+            double r2 = 0.0, bfrag = (ln == 0) ? al[st] : 0.0;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const double zs = zv[st][j] * il[j];
+                const double df = xs[j] - zs;
+                r2 = fma(df, df, r2);
+                if (ln == j + 1) bfrag = al[st] * zs;
+            }
+            const double k = (i >= off && live) ? sf2 * exp(-0.5 * r2) : 0.0;
+            ks[i][ln] = k;
+            accA = __builtin_amdgcn_mfma_f64_16x16x4f64(k, bfrag, accA, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pA[wave][r * 64 + lane] = accA[r];
+        if (wave == 0 && lk == 0) {
+#pragma unroll
+            for (int j = 0; j < DT; ++j) xq[ln][j] = xs[j];
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += pA[w][tid];
+        const int l2 = tid & 63, r = tid >> 6;
+        Rs[(l2 >> 4) + 4 * r][l2 & 15] = v;
+    }
+
+    // ---- phase B ------------------------------------------------------------------------------
+    sr_d4 accB[2];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int sidx = which ? NSTRIP - 1 - pr : pr;
+        const int chunk = 4 * (sidx + 1) / NSPLIT;               // k-steps (of 4 rows) of this part
+        int st = h * chunk;
+        const int st_end = st + chunk;
+        const double* wcol = Wt + (long)d * NP * NP + (long)lk * NP + 16 * sidx + ln;
+        sr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (; st + 16 <= st_end; st += 16) {
+            double af[16], bf[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) af[u] = wcol[(long)(4 * (st + u)) * NP];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) bf[u] = ks[4 * (st + u) + lk][ln];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
+        }
+        for (; st + 4 <= st_end; st += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) af[u] = wcol[(long)(4 * (st + u)) * NP];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bf[u] = ks[4 * (st + u) + lk][ln];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
+        }
+        for (; st < st_end; ++st) {
+            const double af = wcol[(long)(4 * st) * NP];
+            const double bf = ks[4 * st + lk][ln];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+        }
+        accB[which] = acc;
+        if (h > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pB[h - 1][sidx][r * 64 + lane] = acc[r];
+        }
+    }
+    __syncthreads();
+
+    // ---- mean / mean-Jacobian out (R is complete since the barrier above) ----------------------
+    if (tid < SR_FQ * (DT + 1)) {
+        const int t = tid / (DT + 1), j = tid % (DT + 1);
+        if (t0 + t < a.T) {
+            const double m = Rs[t][0];
+            if (j == DT) mu[(t0 + t) * a.n_out + d] = m;
+            else if (jac && j < a.D)
+                jac[((t0 + t) * a.n_out + d) * a.D + j] = (Rs[t][1 + j] - xq[t][j] * m) / a.ls[d * a.D + j];
+        }
+    }
+
+    // ---- phase C ------------------------------------------------------------------------------
+    if (h == 0) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int sidx = which ? NSTRIP - 1 - pr : pr;
+            double q = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = accB[which][r];
+#pragma unroll
+                for (int hh = 0; hh < NSPLIT - 1; ++hh) v += pB[hh][sidx][r * 64 + lane];
+                q = fma(v, v, q);
+            }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (lane < 16) redC[sidx][lane] = q;
+        }
+    }
+    __syncthreads();
+    if (tid < SR_FQ && t0 + tid < a.T) {
+        double qn = 0.0;
+#pragma unroll
+        for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += redC[sidx][tid];
+        double v = sf2 - qn;
+        if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+        var[(t0 + tid) * a.n_out + d] = v;
+    }
+}
+
+bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
+    return !general && (Np == 128 || Np == 256) && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
+}
+
+template <int NP>
+static int launch_small_np(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
+                           hipStream_t s) {
+    dim3 grid((unsigned)((a.T + SR_FQ - 1) / SR_FQ), a.n_out);
+#define SR_SMALL_CASE(DT) hipLaunchKernelGGL((sr_gp_small_kernel<NP, DT>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac)
+    if (a.D <= 3) SR_SMALL_CASE(3);
+    else if (a.D <= 5) SR_SMALL_CASE(5);
+    else SR_SMALL_CASE(8);
+#undef SR_SMALL_CASE
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
+                       hipStream_t s) {
+    if (a.Np == 128) return launch_small_np<128>(a, Wt, mu, var, jac, s);
+    if (a.Np == 256) return launch_small_np<256>(a, Wt, mu, var, jac, s);
+    sr_set_error("gp_small: Np=%d not supported", a.Np);
+    return SR_EUNSUPPORTED;
+}

@@ -45,6 +45,27 @@ class _Handle(object):
         except Exception:
             pass
 
+    def single_io(self):
+        """Staging of the single-query (CasADi/IPOPT callback) entry points: one pinned host block in, one
+        packed device block [mu | var | jac_mu | jac_var | hess_mu] out, one pinned host block back -- two
+        async copies and one stream sync per call instead of a pageable copy per array."""
+        io = getattr(self, "_single_io", None)
+        if io is None:
+            n, D = self.n_out, self.D
+            total = 2 * n + 2 * n * D + n * D * D
+            io = {"h_in": torch.empty(D, dtype=torch.float64).pin_memory(),
+                  "d_in": torch.empty((1, D), dtype=torch.float64, device=self.device),
+                  "d_out": torch.empty(total, dtype=torch.float64, device=self.device),
+                  "h_out": torch.empty(total, dtype=torch.float64).pin_memory()}
+            o = io["d_out"]
+            io["mu"], io["var"] = o[:n], o[n:2 * n]
+            io["jm"] = o[2 * n:2 * n + n * D]
+            io["jv"] = o[2 * n + n * D:2 * n + 2 * n * D]
+            io["hm"] = o[2 * n + 2 * n * D:]
+            io["h_in_np"], io["h_out_np"] = io["h_in"].numpy(), io["h_out"].numpy()
+            self._single_io = io
+        return io
+
 
 class SimpleGPModel(StateSpaceModel):
     """GP dynamics model x_{t+1} - prior(x_t,u_t) ~ GP, one output per state dimension.
@@ -414,8 +435,23 @@ class SimpleGPModel(StateSpaceModel):
         if N > 1:
             raise NotImplementedError("Currently do not support multiple state-action pairs to "
                                       "evaluate on.")
-        mu, var, jac = self.predict_device(np.hstack((states, actions)), True)
-        return B.to_numpy(mu).T, B.to_numpy(var).T, B.to_numpy(jac)[0]
+        self._need_trained()
+        hd = self._handle
+        n, D = hd.n_out, hd.D
+        if states.shape[1] + actions.shape[1] != D:
+            raise ValueError("states and actions must have {} columns together".format(D))
+        io = hd.single_io()
+        io["h_in_np"][:states.shape[1]] = states[0]
+        io["h_in_np"][states.shape[1]:] = actions[0]
+        stream = torch.cuda.current_stream(hd.device)
+        io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
+        check(lib.sr_gp_predict(hd.h, B.ptr(io["d_in"]), 1, B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
+                                ctypes.c_void_p(stream.cuda_stream)))
+        k = 2 * n + n * D
+        io["h_out"][:k].copy_(io["d_out"][:k], non_blocking=True)
+        stream.synchronize()
+        o = io["h_out_np"][:k].copy()
+        return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
 
     def linearize_device(self, x):
         """Single query x (D,) -> device tensors (mu (n,), var (n,), jac_mu (n,D), jac_var (n,D),
@@ -448,9 +484,29 @@ class SimpleGPModel(StateSpaceModel):
         if N > 1:
             raise NotImplementedError("'linearize_predict' currently only allows for single inputs, "
                                       "i.e. (1 x n) arrays, when computing jacobians.")
-        mu, var, jm, jv, hm = (B.to_numpy(t) for t in self.linearize_device(np.hstack((states, actions))[0]))
+        mu, var, jm, jv, hm = self._linearize_host(np.hstack((states, actions))[0])
         self._linearize_forward_cache = (jm, jv, hm)
         return mu[:, None], var[:, None], jm, jv, hm
+
+    def _linearize_host(self, x):
+        """sr_gp_linearize through the pinned single-query staging: host x (D,) -> host arrays."""
+        self._need_trained()
+        hd = self._handle
+        n, D = hd.n_out, hd.D
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        if x.size != D:
+            raise ValueError("x must have {} entries".format(D))
+        io = hd.single_io()
+        io["h_in_np"][:] = x
+        stream = torch.cuda.current_stream(hd.device)
+        io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
+        check(lib.sr_gp_linearize(hd.h, B.ptr(io["d_in"]), B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
+                                  B.ptr(io["jv"]), B.ptr(io["hm"]), ctypes.c_void_p(stream.cuda_stream)))
+        io["h_out"].copy_(io["d_out"], non_blocking=True)
+        stream.synchronize()
+        o = io["h_out_np"].copy()
+        a, b, c = 2 * n, 2 * n + n * D, 2 * n + 2 * n * D
+        return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
 
     def predict_with_jacobians(self, states, actions):
         """Base-class ``predict(states, actions, jacobians=True)`` (state_space_models.py:74-104):
@@ -463,8 +519,7 @@ class SimpleGPModel(StateSpaceModel):
         mean, var = np.empty((N, hd.n_out)), np.empty((N, hd.n_out))
         jm, jv = np.empty((N, hd.n_out, hd.D)), np.empty((N, hd.n_out, hd.D))
         for t in range(N):
-            o = [B.to_numpy(v) for v in self.linearize_device(x[t])]
-            mean[t], var[t], jm[t], jv[t] = o[0], o[1], o[2], o[3]
+            mean[t], var[t], jm[t], jv[t], _ = self._linearize_host(x[t])
         if N == 1:
             self._forward_cache = (jm[0], jv[0])
         return mean, var, jm, jv
@@ -561,7 +616,7 @@ class SimpleGPModel(StateSpaceModel):
 
     def set_small_path(self, on):
         self._need_trained()
-        check(lib.sr_gp_set_small_path(self._handle.h, 1 if on else 0))
+        check(lib.sr_gp_set_small_path(self._handle.h, int(on)))
 
     def prof_enable(self, on=True):
         self._need_trained()

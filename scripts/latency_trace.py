@@ -5,8 +5,8 @@
         python $REPO/scripts/latency_trace.py run 5000 1
     python scripts/latency_trace.py show gpurun_out/lat
 
-`run N T` issues 200 predict calls of T queries against an N-point pendulum model (plus wall time per
-call); `show DIR` prints the top_kernels view of the rocpd database rocprofv3 left in DIR."""
+`run N T [H]` issues 200 predict calls of T queries against an N-point pendulum model (plus wall time per
+call; with H also 50 H-step reachability chains over T rollouts); `show DIR` prints the top_kernels view of the rocpd database rocprofv3 left in DIR."""
 import glob
 import os
 import sqlite3
@@ -14,7 +14,7 @@ import sys
 import time
 
 
-def run(N, T):
+def run(N, T, H=1):
     import numpy as np
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,6 +31,20 @@ def run(N, T):
         gp.predict_device(x, True)
     torch.cuda.synchronize()
     print("N=%d T=%d wall per predict call: %.1f us" % (N, T, (time.perf_counter() - t0) / 200 * 1e6))
+    if H > 1:
+        from safe_exploration_amd import gp_reachability as reach
+        roll = workload.random_rollout_controls(3, T, H, 2, 1)
+        tr = {k: B.as_dev(v, gp.device) for k, v in roll.items()}
+        l, a, b = np.array([0.05, 0.02]), 0.8 * np.eye(2), np.zeros((2, 1))
+        f = lambda: reach.multistep_reachability_batch(tr["p0"], gp, tr["k_fb"], tr["k_ff"], l, l, None, 2.0, a, b)
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            f()
+        torch.cuda.synchronize()
+        print("N=%d T=%d H=%d wall per multistep call: %.1f us" % (N, T, H, (time.perf_counter() - t0) / 50 * 1e6))
 
 
 def show(d):
@@ -39,12 +53,12 @@ def show(d):
         con = sqlite3.connect(db)
         print("%-64s %7s %12s %10s" % ("kernel", "calls", "total_us", "avg_us"))
         for name, calls, tot, avg, pct in con.execute("select * from top_kernels"):
-            if calls >= 100:
+            if calls >= 50:
                 print("%-64s %7d %12.0f %10.2f" % (name[:64], calls, tot, avg))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(int(sys.argv[2]), int(sys.argv[3]))
+        run(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     else:
         show(sys.argv[2])
