@@ -104,7 +104,8 @@ int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, double* var, 
 /* ---- single query with second-order outputs (the CasADi Jacobian callback) ------------------------
  * replaces: linearize_predict(states 1xn, actions 1xm, jacobians=True)  state_space_models.py:106-138,
  *           consumed at :402-415; reference implementation ssm_pytorch/gaussian_process.py:333-385.
- * x D -> mu n_out, var n_out, jac_mu n_out x D, jac_var n_out x D (d var/dx), hess_mu n_out x D x D. */
+ * x D -> mu n_out, var n_out, jac_mu n_out x D, jac_var n_out x D (d var/dx), hess_mu n_out x D x D.
+ * All kernel identifiers (rbf, mat52, lin_rbf, lin_mat52) in closed form. */
 int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* var, double* jac_mu,
                     double* jac_var, double* hess_mu, void* stream);
 

@@ -401,6 +401,66 @@ def gp_mean_jacobian_fd(x_new, Z, beta, kern_types, hyp, eps=1e-6):
     return jac
 
 
+def _stationary_radial(kind, r):
+    """kappa(r), g = kappa'(r)/r, h = g'(r)/r of the two stationary families (unit variance)."""
+    if kind == "rbf":
+        k = np.exp(-0.5 * r ** 2)
+        return k, -k, k
+    e = np.exp(-SQRT5 * r)
+    return (1.0 + SQRT5 * r + 5.0 / 3.0 * r ** 2) * e, -(5.0 / 3.0) * (1.0 + SQRT5 * r) * e, (25.0 / 3.0) * e
+
+
+def kernel_derivatives(kern_type, hyp, x, Z):
+    """First and second derivatives of k(x, z_i) w.r.t. the single query x (D,) for the reference's four
+    kernel identifiers (formulas differentiated by hand from gp_models_utils_casadi.py:17-157; the
+    reference itself leaves this to CasADi's AD).  Returns k (N,), grad (N,D), hess (N,D,D), and the
+    gradient of the prior variance k(x,x) (D,)."""
+    x = np.asarray(x, np.float64).reshape(-1)
+    N, D = Z.shape
+    grad = np.zeros((N, D))
+    hess = np.zeros((N, D, D))
+    if kern_type in ("rbf", "mat52"):
+        ls = np.asarray(hyp["lengthscale"], np.float64).reshape(-1) * np.ones(D)
+        u = (x[None, :] - Z) / ls[None, :] ** 2                       # (N,D)
+        r = np.sqrt(np.sum(((x[None, :] - Z) / ls[None, :]) ** 2, axis=1))
+        kap, g, h = _stationary_radial(kern_type, r)
+        v = float(hyp["variance"])
+        k = v * kap
+        grad = v * g[:, None] * u
+        hess = v * (h[:, None, None] * u[:, :, None] * u[:, None, :] + g[:, None, None] * np.diag(1.0 / ls ** 2)[None])
+        return k, grad, hess, np.zeros(D)
+    st = "rbf" if kern_type == "lin_rbf" else "mat52"
+    ell = float(np.asarray(hyp["prod.%s.lengthscale" % st]).reshape(-1)[0])
+    vs = float(hyp["prod.%s.variance" % st])
+    vp = float(np.asarray(hyp["prod.linear.variances"]).reshape(-1)[0])
+    vl = np.asarray(hyp["linear.variances"], np.float64).reshape(-1) * np.ones(D)
+    x1, z1 = x[1], Z[:, 1]
+    u1 = (x1 - z1) / ell ** 2
+    kap, g, h = _stationary_radial(st, np.abs(x1 - z1) / ell)
+    c = vp * vs * z1
+    k = c * x1 * kap + Z.dot(vl * x)
+    grad = Z * vl[None, :]
+    grad[:, 1] += c * (kap + x1 * g * u1)
+    hess[:, 1, 1] = c * (2.0 * g * u1 + x1 * (h * u1 ** 2 + g / ell ** 2))
+    gxx = 2.0 * vl * x
+    gxx[1] += 2.0 * vp * vs * x1
+    return k, grad, hess, gxx
+
+
+def gp_linearize_extras_k(x, Z, beta, inv_K, kern_types, hyp):
+    """d sigma2/dx and Hessian of mu for arbitrary kernel identifiers (the second-order outputs of
+    linearize_predict(jacobians=True), state_space_models.py:106-138):
+        d sigma2/dx = d k(x,x)/dx - 2 sum_i (K^-1 k*)_i d k*_i/dx ,   d2 mu/dx2 = sum_i beta_i d2 k*_i/dx2."""
+    n_out = beta.shape[1]
+    D = Z.shape[1]
+    jv, hm = np.empty((n_out, D)), np.empty((n_out, D, D))
+    for d in range(n_out):
+        k, grad, hess, gxx = kernel_derivatives(kern_types[d], hyp[d], x, Z)
+        jv[d] = gxx - 2.0 * inv_K[d].dot(k).dot(grad)
+        hm[d] = np.einsum('i,ijk->jk', beta[:, d], hess)
+    return jv, hm
+
+
 def make_hyp(kern_type, rng, D):
     """random hyper-parameters with the key names of SimpleGPModel._create_hyp_dict
     (ssm_gpy/gaussian_process.py:491-544)."""

@@ -489,7 +489,6 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_linearize: NULL handle");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_linearize: model not factorized");
     SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
-    SR_CHECK(!h->general, SR_EUNSUPPORTED, "sr_gp_linearize: second-order outputs are implemented for ARD-RBF only");
     hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
     if (!h->lin_v) SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np));
@@ -511,6 +510,7 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     }
     sr_lin_args la;
     la.Z = h->Z; la.alpha = h->alpha; la.ls = h->ls; la.Ks = h->Ks; la.g = h->lin_g; la.x = x;
+    la.kp = h->general ? h->kp : nullptr;
     la.jac_var = jac_var; la.hess_mu = hess_mu;
     la.N = h->N; la.Np = h->Np; la.D = h->D; la.n_out = h->n_out; la.Tp = Tp;
     return sr_launch_linearize(la, s);

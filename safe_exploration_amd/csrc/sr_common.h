@@ -215,6 +215,7 @@ int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, c
 struct sr_lin_args {
     const double* Z; const double* alpha; const double* ls; const double* Ks; const double* g;
     const double* x;                 // D query coordinates
+    const double* kp;                // general kernels: n_out x SR_KP(D) packed parameters, else NULL (ARD-RBF)
     double* jac_var; double* hess_mu;   // n_out x D, n_out x D x D
     int N, Np, D, n_out; long Tp;
 };

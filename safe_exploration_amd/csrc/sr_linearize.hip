@@ -6,6 +6,7 @@
 //   d var/dx_j      = -2 sum_i g_i k*_i (z_ij - x_j) / l_j^2
 //   d2 mu/dx_j dx_k = sum_i alpha_i k*_i [ (z_ij-x_j)(z_ik-x_k)/(l_j^2 l_k^2) - delta_jk / l_j^2 ]
 // Latency path (T = 1): three small launches per output, HBM-bound on the 2 x N^2/2 factor reads.
+// The other kernel identifiers (mat52, lin_rbf, lin_mat52) go through sr_linearize_general_kernel below.
 #include "sr_common.h"
 
 // y[i] = sum_{k <= i} M[k][i] * x[k * xs]   (M upper triangular, row-major): v = U^-T k*
@@ -98,8 +99,119 @@ __global__ __launch_bounds__(256) void sr_linearize_kernel(sr_lin_args a) {
     }
 }
 
+// General kernel family of sr_common.h (Matern-5/2, linear x stationary + linear; the kernels the reference's
+// journal experiments use, ssm_gpy/gp_models_utils_casadi.py:43-157), differentiated by hand -- the reference
+// leaves these derivatives to CasADi's AD.  With u_j = s_j^2 (x_j - z_j), c = c0 + sum a_j x_j z_j,
+// g = kappa'(r)/r, h = g'(r)/r   (RBF: g = -kappa, h = kappa;  Matern-5/2: g = -5/3 (1 + sqrt5 r) e, h = 25/3 e,
+// e = exp(-sqrt5 r)):
+//   d k/dx_j       = a_j z_j v kappa + c v g u_j + b_j z_j
+//   d2 k/dx_j dx_l = v g (a_j z_j u_l + a_l z_l u_j) + c v (h u_j u_l + g s_j^2 delta_jl)
+//   d var/dx_j     = 2 (a_j v + b_j) x_j - 2 sum_i G_i d k_i/dx_j ,   G = K_y^-1 k*
+template <int DT>
+__global__ __launch_bounds__(256) void sr_linearize_general_kernel(sr_lin_args a) {
+    constexpr int NH = DT * (DT + 1) / 2;
+    constexpr int NACC = DT + NH;
+    __shared__ double red[4][NACC];
+    const int d = blockIdx.x;
+    const int off = a.Np - a.N;
+    const double* kp = a.kp + (long)d * SR_KP(a.D);
+    const int kind = (int)kp[0];
+    const double var = kp[1], c0 = kp[2];
+    const double* G = a.g + (long)d * a.Np;
+    const double* al = a.alpha + (long)d * a.Np;
+    double s2[DT], av[DT], bv[DT], x[DT], acc[NACC];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        const double sj = (j < a.D) ? kp[3 + j] : 0.0;
+        s2[j] = sj * sj;
+        av[j] = (j < a.D) ? kp[3 + a.D + j] : 0.0;
+        bv[j] = (j < a.D) ? kp[3 + 2 * a.D + j] : 0.0;
+        x[j] = (j < a.D) ? a.x[j] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
+    for (int i = threadIdx.x; i < a.N; i += 256) {
+        double z[DT], u[DT], r2 = 0.0, la = 0.0;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            z[j] = (j < a.D) ? a.Z[(long)i * a.D + j] : 0.0;
+            const double df = x[j] - z[j];
+            u[j] = s2[j] * df;
+            r2 = fma(u[j], df, r2);
+            la = fma(av[j] * x[j], z[j], la);
+        }
+        double kap, g, h;
+        if (kind == 0) {
+            kap = exp(-0.5 * r2);
+            g = -kap;
+            h = kap;
+        } else {
+            const double rr = sqrt(r2);
+            const double e = exp(-2.23606797749978969641 * rr);
+            kap = (1.0 + 2.23606797749978969641 * rr + (5.0 / 3.0) * r2) * e;
+            g = -(5.0 / 3.0) * (1.0 + 2.23606797749978969641 * rr) * e;
+            h = (25.0 / 3.0) * e;
+        }
+        const double pre = (c0 + la) * var;
+        const double Gi = G[i + off], w = al[i + off];
+        const double vk = var * kap, pg = pre * g, ph = pre * h, vg = var * g;
+        int q = DT;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const double azj = av[j] * z[j];
+            acc[j] = fma(Gi, fma(vk, azj, fma(pg, u[j], bv[j] * z[j])), acc[j]);
+#pragma unroll
+            for (int c = 0; c < DT; ++c)
+                if (c >= j) {
+                    double hv = fma(vg, fma(azj, u[c], av[c] * z[c] * u[j]), ph * u[j] * u[c]);
+                    if (c == j) hv = fma(pg, s2[j], hv);
+                    acc[q] = fma(w, hv, acc[q]);
+                    ++q;
+                }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) {
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int q = DT;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            if (j < a.D)
+                a.jac_var[d * a.D + j] = 2.0 * (av[j] * var + bv[j]) * x[j] -
+                                         2.0 * (red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+#pragma unroll
+            for (int c = 0; c < DT; ++c)
+                if (c >= j) {
+                    if (j < a.D && c < a.D) {
+                        const double hv = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+                        a.hess_mu[((long)d * a.D + j) * a.D + c] = hv;
+                        a.hess_mu[((long)d * a.D + c) * a.D + j] = hv;
+                    }
+                    ++q;
+                }
+        }
+    }
+}
+
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s) {
     dim3 grid(a.n_out);
+    if (a.kp) {
+#define SR_LING_CASE(DT) hipLaunchKernelGGL(sr_linearize_general_kernel<DT>, grid, dim3(256), 0, s, a)
+        if (a.D <= 3) SR_LING_CASE(3);
+        else if (a.D <= 5) SR_LING_CASE(5);
+        else if (a.D <= 8) SR_LING_CASE(8);
+        else if (a.D <= 12) SR_LING_CASE(12);
+        else { sr_set_error("linearize: D=%d > %d", a.D, SR_MAX_D); return SR_EUNSUPPORTED; }
+#undef SR_LING_CASE
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
 #define SR_LIN_CASE(DT) hipLaunchKernelGGL(sr_linearize_kernel<DT>, grid, dim3(256), 0, s, a)
     if (a.D <= 3) SR_LIN_CASE(3);
     else if (a.D <= 5) SR_LIN_CASE(5);

@@ -456,8 +456,18 @@ def test_non_rbf_kernels_vs_reference_formulas(kt):
     np.testing.assert_allclose(gp.inv_K[0].dot(Ky), np.eye(Ky.shape[0]), rtol=0, atol=1e-6)
     m1, s1, j1 = gp(g["x_new"][2:3, :2], g["x_new"][2:3, 2:])
     np.testing.assert_allclose(m1[:, 0], g["ref_mu"][2], rtol=1e-9, atol=1e-11 * scale)
-    with pytest.raises(NotImplementedError):
-        gp.linearize_predict(g["x_new"][:1, :2], g["x_new"][:1, 2:], True)
+    # second-order outputs of the CasADi Jacobian callback for this kernel (closed forms; the reference leaves
+    # them to CasADi's AD): oracle == hand-differentiated formulas checked against finite differences on the CPU
+    beta, inv_K = orc.gp_fit_k(g["Z"], g["Y"], [kt] * 2, hyp, g["noise_var"])
+    for q in (0, 3):
+        x1 = g["x_new"][q]
+        rjv, rhm = orc.gp_linearize_extras_k(x1, g["Z"], beta, inv_K, [kt] * 2, hyp)
+        mu1, var1, jm1, jv1, hm1 = gp.linearize_predict(x1[None, :2], x1[None, 2:], True)
+        np.testing.assert_allclose(mu1[:, 0], mu[q], rtol=1e-9, atol=1e-11 * scale)
+        np.testing.assert_allclose(jm1, jac[q], rtol=1e-9, atol=1e-10 * scale)
+        np.testing.assert_allclose(jv1, rjv, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(rjv).max()))
+        np.testing.assert_allclose(hm1, rhm, rtol=1e-8, atol=1e-10 * scale)
+        np.testing.assert_array_equal(hm1, np.transpose(hm1, (0, 2, 1)))
 
 
 def test_reachability_with_lin_mat52_kernel():

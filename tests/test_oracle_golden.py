@@ -275,3 +275,39 @@ def test_information_gain_identity():
         K = orc.rbf_kernel(syn["Z"], syn["Z"], syn["signal_var"][d], syn["lengthscale"][d])
         alt = np.linalg.slogdet(K + syn["noise_var"][d] * np.eye(40))[1] - 40 * np.log(syn["noise_var"][d])
         assert abs(ig[d] - alt) < 1e-9
+
+
+@pytest.mark.parametrize("kt", ["rbf", "mat52", "lin_rbf", "lin_mat52"])
+def test_second_order_outputs_of_all_kernels_vs_finite_differences(kt):
+    """hand-differentiated d var/dx and Hessian of mu (oracle.gp_linearize_extras_k) against central differences
+    of the oracle's own posterior; for rbf also against the dedicated closed form."""
+    rng = np.random.default_rng(17)
+    N, D = 40, 3
+    Z = rng.uniform(-1, 1, (N, D))
+    Y = rng.standard_normal((N, 2))
+    hyp = [orc.make_hyp(kt, rng, D) for _ in range(2)]
+    beta, inv_K = orc.gp_fit_k(Z, Y, [kt] * 2, hyp, np.full(2, 1e-2))
+    x = rng.uniform(-0.5, 0.5, D)
+    jv, hm = orc.gp_linearize_extras_k(x, Z, beta, inv_K, [kt] * 2, hyp)
+    eps = 1e-5
+    for j in range(D):
+        e = np.zeros(D)
+        e[j] = eps
+        vp = orc.gp_predict_k((x + e)[None], Z, beta, inv_K, [kt] * 2, hyp)[1][0]
+        vm = orc.gp_predict_k((x - e)[None], Z, beta, inv_K, [kt] * 2, hyp)[1][0]
+        np.testing.assert_allclose(jv[:, j], (vp - vm) / (2 * eps), rtol=1e-6, atol=1e-8)
+        for d in range(2):
+            gp_ = orc.kernel_derivatives(kt, hyp[d], x + e, Z)[1]
+            gm_ = orc.kernel_derivatives(kt, hyp[d], x - e, Z)[1]
+            np.testing.assert_allclose(hm[d][:, j], beta[:, d].dot(gp_ - gm_) / (2 * eps), rtol=1e-5,
+                                       atol=1e-6 * np.abs(hm[d]).max())
+    # the analytic gradient used above is itself the mean Jacobian (checked against differences of k)
+    jac_fd = orc.gp_mean_jacobian_fd(x[None], Z, beta, [kt] * 2, hyp)[0]
+    for d in range(2):
+        np.testing.assert_allclose(beta[:, d].dot(orc.kernel_derivatives(kt, hyp[d], x, Z)[1]), jac_fd[d], rtol=1e-6,
+                                   atol=1e-8)
+    if kt == "rbf":
+        ls = np.array([h["lengthscale"] for h in hyp])
+        jv0, hm0 = orc.gp_linearize_extras(x, Z, beta, inv_K, ls, [h["variance"] for h in hyp])
+        np.testing.assert_allclose(jv, jv0, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(hm, hm0, rtol=1e-12, atol=1e-13)
