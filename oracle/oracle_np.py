@@ -546,3 +546,20 @@ def information_gain(Z, lengthscale, signal_var, noise_var_fixed):
         Kd = rbf_kernel(Z, Z, signal_var[d], lengthscale[d])
         out.append(np.linalg.slogdet(np.eye(N) + Kd / noise_var_fixed[d])[1])
     return out
+
+
+# --------------------------------------------------------------------------- data selection
+def choose_datapoints_maxvar(x, y, m, init_idx, lengthscale, signal_var, noise_var):
+    """Greedy part of ssm_gpy/gaussian_process.py:323-343 with fixed hyper-parameters: starting from the
+    seed rows ``init_idx`` add, m - len(init_idx) times, the pool point with the largest summed posterior
+    variance under the GP conditioned on the rows chosen so far (GPy ``set_XY(x_chosen, ...)``, :340-341).
+    Refits from scratch every round.  Returns the chosen row indices in order."""
+    chosen = [int(i) for i in init_idx]
+    n_data = x.shape[0]
+    while len(chosen) < m:
+        beta, inv_K, _ = gp_fit(x[chosen], y[chosen], lengthscale, signal_var, noise_var)
+        _, var = gp_predict(x, x[chosen], beta, inv_K, lengthscale, signal_var, compute_gradients=False)
+        score = var.sum(axis=1)
+        score[chosen] = -np.inf
+        chosen.append(int(np.argmax(score)))
+    return np.asarray(chosen)

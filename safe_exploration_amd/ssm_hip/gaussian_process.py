@@ -199,7 +199,7 @@ class SimpleGPModel(StateSpaceModel):
         return new
 
     # ------------------------------------------------------------------ training
-    def _select_subset(self, X, y, m, Z, choose_data):
+    def _select_subset(self, X, y, m, Z, choose_data, noise_diag=1e-5):
         n_data = X.shape[0]
         if m is None or n_data < m:
             if m is not None:
@@ -207,11 +207,59 @@ class SimpleGPModel(StateSpaceModel):
                               "of {} Datapoints!".format(n_data))
             return X, y
         if choose_data:
-            raise NotImplementedError("max-variance data selection (choose_data=True, "
-                                      "ssm_gpy/gaussian_process.py:280-345) is training-time logic "
-                                      "outside the hot path; pass choose_data=False or m=None")
+            return self.choose_datapoints_maxvar(X, y, m, noise_diag=noise_diag)
         idx = np.random.choice(n_data, size=m, replace=False)
         return X[idx, :], y[idx, :]
+
+    def choose_datapoints_maxvar(self, x, y, m, k=10, min_ratio_k=0.25, n_reopt_gp=1, init_idx=None,
+                                 noise_diag=1e-5, return_index=False):
+        """Choose m datapoints by the maximum-predicted-variance criterion  (gaussian_process.py:280-345).
+
+        Same scheme as the reference: k-means picks ``k`` seed points (one random member per cluster), then
+        the point of the remaining pool with the largest summed posterior variance under the GP conditioned on
+        the points chosen so far is added, m - k times.  Here every round is one batched ``sr_gp_predict`` over
+        the whole pool (resident on the device) and one row append ``sr_gp_append`` -- no refactorisation.
+        Differences, both forced: hyper-parameters are fixed (the reference re-optimises them on the pool
+        ``n_reopt_gp`` times, :327-328, which also makes those rounds score the pool with a GP conditioned on
+        the pool itself), and the seed set is random (k-means + ``np.random.choice``) unless ``init_idx`` is
+        given."""
+        x = np.asarray(x, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        n_data = x.shape[0]
+        if n_data <= m:
+            return (x, y, np.arange(n_data)) if return_index else (x, y)
+        if init_idx is None:
+            from sklearn import cluster
+            k = int(np.minimum(int(n_data * min_ratio_k), k))
+            clust_ids = cluster.KMeans(n_clusters=k, n_init=10).fit_predict(x)
+            init_idx = [int(np.random.choice(np.nonzero(clust_ids == c)[0])) for c in np.unique(clust_ids)]
+        chosen = [int(i) for i in init_idx][:m]
+        if len(set(chosen)) != len(chosen) or min(chosen) < 0 or max(chosen) >= n_data:
+            raise ValueError("init_idx must hold distinct row indices of x")
+        self._fit(x[chosen], y[chosen], noise_diag)
+        self._noise_diag = noise_diag
+        self.gp_trained = True
+        hd = self._handle
+        s = B.stream_ptr(hd.device)
+        tx, ty = B.as_dev(x, hd.device), B.as_dev(y, hd.device)
+        taken = torch.zeros(n_data, dtype=torch.bool, device=hd.device)
+        taken[torch.as_tensor(chosen, device=hd.device)] = True
+        info = (ctypes.c_int * self.n_s_out)()
+        npad = ctypes.c_long(0)
+        while len(chosen) < m:
+            _, var = self.predict_device(tx)
+            score = var.sum(dim=1).masked_fill_(taken, -float("inf"))
+            j = int(torch.argmax(score))
+            chosen.append(j)
+            taken[j] = True
+            check(lib.sr_gp_append(hd.h, B.ptr(tx[j:j + 1]), B.ptr(ty[j:j + 1]), 1, s, info))
+            hd.N += 1
+            check(lib.sr_gp_padded_n(hd.h, ctypes.byref(npad)))
+            hd.Np = npad.value
+        idx = np.asarray(chosen)
+        self.z, self.x_train, self.y_train = x[idx], x, y         # the model now is the GP on the chosen rows
+        self._beta = self._inv_K = None
+        return (x[idx], y[idx], idx) if return_index else (x[idx], y[idx])
 
     def train(self, X, y, m=None, opt_hyp=True, noise_diag=1e-5, Z=None, choose_data=True):
         """Condition the GPs on data (ssm_gpy/gaussian_process.py:189-278).
@@ -227,7 +275,7 @@ class SimpleGPModel(StateSpaceModel):
             raise ValueError("X must be (N, n_s_in+n_u) and y (N, n_s_out)")
         if X.shape[1] != self.n_s_in + self.n_u or y.shape[1] != self.n_s_out:
             raise ValueError("X must be (N, n_s_in+n_u) and y (N, n_s_out)")
-        Zs, yz = self._select_subset(X, y, m, Z, choose_data)
+        Zs, yz = self._select_subset(X, y, m, Z, choose_data, noise_diag)
         self._fit(Zs, yz, noise_diag)
         self._noise_diag = noise_diag
         self.z = self.Z if self.z_fixed else Zs

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from _helpers import hip_model, oracle_model, mu_atol
+from _helpers import hip_model, oracle_model, mu_atol, hyp_from
 from oracle import oracle_np as orc
 
 pytestmark = pytest.mark.gpu
@@ -807,3 +807,37 @@ def test_fused_small_model_pass(N, n_s, n_u, T):
     np.testing.assert_allclose(mu, mu3, rtol=1e-12, atol=1e-3 * at)
     np.testing.assert_allclose(jac, jac3, rtol=1e-11, atol=1e-2 * at)
     np.testing.assert_allclose(var, var3, rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_max_variance_data_selection():
+    """choose_datapoints_maxvar (gaussian_process.py:280-345): greedy max-variance subset, one batched predict over
+    the pool + one row append per round.  Same picks, in the same order, as the oracle refitting from scratch."""
+    from safe_exploration_amd import SimpleGPModel
+    syn = orc.make_synthetic(123, 300, 2, 1, 4)
+    hyp = hyp_from(syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=hyp, m=40)
+    init = [3, 57, 111, 160, 201, 250, 299, 8, 77, 140]
+    xs, ys, idx = gp.choose_datapoints_maxvar(syn["Z"], syn["Y"], 40, init_idx=init, return_index=True)
+    ref = orc.choose_datapoints_maxvar(syn["Z"], syn["Y"], 40, init, syn["lengthscale"], syn["signal_var"],
+                                       syn["noise_var"])
+    np.testing.assert_array_equal(idx, ref)
+    np.testing.assert_array_equal(xs, syn["Z"][ref])
+    np.testing.assert_array_equal(ys, syn["Y"][ref])
+    # the incrementally conditioned model equals a fresh fit on the chosen rows
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    mu_inc, var_inc = gp.predict(x)
+    om = oracle_model(xs, ys, syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    rmu, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
+    np.testing.assert_allclose(mu_inc, rmu, rtol=1e-9, atol=max(mu_atol(om), 1e-12))
+    np.testing.assert_allclose(var_inc, rvar, rtol=0, atol=1e-9)
+    # the reference's entry points: train(m=...) / update_model with the default choose_data=True (k-means seeds)
+    np.random.seed(0)
+    gp.train(syn["Z"], syn["Y"], m=40, opt_hyp=False)
+    assert gp.z.shape == (40, 3) and gp.x_train.shape == (300, 3)
+    assert len({tuple(r) for r in gp.z}) == 40 and all(tuple(r) in {tuple(q) for q in syn["Z"]} for r in gp.z)
+    gp.update_model(syn["Z"][:50], syn["Y"][:50], opt_hyp=False, replace_old=True)
+    assert gp.z.shape == (40, 3)
+    with pytest.warns(UserWarning):
+        gp.update_model(syn["Z"][:30], syn["Y"][:30], opt_hyp=False, replace_old=True)      # fewer than m: all of them
+    assert gp.z.shape == (30, 3)
