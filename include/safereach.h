@@ -178,6 +178,15 @@ int sr_safety_distance(int device, long T, int n_s, int m, const double* p, cons
 int sr_distance_to_center(int device, long T, int K, int n_s, const double* samples, int per_t,
                           const double* p, const double* q, double* d, void* stream);
 
+/* replaces: the objective that GPy's model.optimize() minimises inside SimpleGPModel.train(opt_hyp=True)
+ * ssm_gpy/gaussian_process.py:249-250 (the optimiser itself stays on the host: L-BFGS-B over these values).
+ * For the factorised model (data set with sr_gp_set_data_general):
+ *   nll[d]  = 1/2 y^T alpha + 1/2 log det K_y + N/2 log 2pi
+ *   grad[d] = d nll / d [v, c0, s[D], a[D], b[D], noise]   (SR_KP(D) = 3+3D entries per output, the packed
+ *             kernel parameters in their order, then the diagonal noise term). */
+int sr_gp_mll(sr_gp_t h, double* nll /* n_out, device */, double* grad /* n_out x (3+3D), device */,
+              void* stream);
+
 /* replaces: the determinant inside SimpleGPModel.information_gain  ssm_gpy/gaussian_process.py:621-634
  * (log det(I + K/sigma_n^2) = log det(K + sigma_n^2 I) - N log sigma_n^2).
  * logdet[d] = log det(K_d + noise_d I) of the factorised (or imported) model, from the diagonal of U^-1. */

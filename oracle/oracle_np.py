@@ -563,3 +563,48 @@ def choose_datapoints_maxvar(x, y, m, init_idx, lengthscale, signal_var, noise_v
         score[chosen] = -np.inf
         chosen.append(int(np.argmax(score)))
     return np.asarray(chosen)
+
+
+# --------------------------------------------------------------------------- marginal likelihood (opt_hyp=True)
+def gp_nll_grad(Z, y, kern_type, hyp, noise_var):
+    """Negative log marginal likelihood of one output and its gradient with respect to every hyper-parameter
+    (natural scale), the objective behind ``model_gp.optimize()`` in ssm_gpy/gaussian_process.py:249-250:
+        nll = 1/2 y^T K_y^-1 y + 1/2 log det K_y + N/2 log 2pi ,  K_y = K + (noise_var + 1e-8) I
+        d nll/d theta = 1/2 tr((K_y^-1 - alpha alpha^T) dK_y/d theta).
+    dK/d theta is written out per kernel identifier (not through the packed family the device uses).
+    Returns nll, {key: gradient array}."""
+    N, D = Z.shape
+    K = kernel_matrix(kern_type, hyp, Z, Z)
+    Ky = K + (noise_var + GPY_JITTER) * np.eye(N)
+    L = sla.cholesky(Ky, lower=True)
+    alpha = sla.cho_solve((L, True), y)
+    Kinv = sla.cho_solve((L, True), np.eye(N))
+    nll = 0.5 * y.dot(alpha) + np.sum(np.log(np.diag(L))) + 0.5 * N * np.log(2 * np.pi)
+    M = 0.5 * (Kinv - np.outer(alpha, alpha))
+    grad = {"noise_variance": np.array([np.trace(M)])}
+
+    def radial(st, x, ell):
+        """kappa and d kappa / d ell_j for unit variance; x (N,d), ell (d,)"""
+        diff2 = (x[:, None, :] - x[None, :, :]) ** 2                       # (N,N,d)
+        r = np.sqrt(np.sum(diff2 / ell ** 2, axis=2))
+        kap, g, _ = _stationary_radial(st, r)
+        dl = -g[:, :, None] * diff2 / ell ** 3                               # d kappa/d ell_j = kappa'(r) dr/d ell_j
+        return kap, dl
+
+    if kern_type in ("rbf", "mat52"):
+        ell = np.asarray(hyp["lengthscale"], np.float64).reshape(-1) * np.ones(D)
+        kap, dl = radial(kern_type, Z, ell)
+        grad["variance"] = np.array([np.sum(M * kap)])
+        grad["lengthscale"] = float(hyp["variance"]) * np.einsum('ij,ijk->k', M, dl)
+        return nll, grad
+    st = "rbf" if kern_type == "lin_rbf" else "mat52"
+    ell = np.asarray(hyp["prod.%s.lengthscale" % st], np.float64).reshape(-1)[:1]
+    vs = float(hyp["prod.%s.variance" % st])
+    vp = float(np.asarray(hyp["prod.linear.variances"]).reshape(-1)[0])
+    kap, dl = radial(st, Z[:, 1:2], ell)
+    zz = np.outer(Z[:, 1], Z[:, 1])
+    grad["prod.%s.variance" % st] = np.array([np.sum(M * vp * zz * kap)])
+    grad["prod.%s.lengthscale" % st] = np.array([np.sum(M * vp * vs * zz * dl[:, :, 0])])
+    grad["prod.linear.variances"] = np.array([np.sum(M * vs * zz * kap)])
+    grad["linear.variances"] = np.array([np.sum(M * np.outer(Z[:, j], Z[:, j])) for j in range(D)])
+    return nll, grad

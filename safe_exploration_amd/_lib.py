@@ -61,6 +61,7 @@ SIGNATURES = {
     "sr_remainder_overapprox": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sr_safety_distance": (_I, [_I, _L, _I, _I, _P, _P, _P, _P, _D, _P, _P]),
     "sr_distance_to_center": (_I, [_I, _L, _I, _I, _P, _I, _P, _P, _P, _P]),
+    "sr_gp_mll": (_I, [_H, _P, _P, _P]),
     "sr_gp_logdet": (_I, [_H, _P, _P]),
     "sr_gp_sample": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sr_gp_set_chunk": (_I, [_H, _L]),

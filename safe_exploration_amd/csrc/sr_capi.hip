@@ -321,6 +321,38 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
     return SR_OK;
 }
 
+extern "C" int sr_gp_mll(sr_gp_t h, double* nll, double* grad, void* stream) {
+    SR_CHECK(h && nll && grad, SR_EINVAL, "sr_gp_mll: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_mll: model not factorized");
+    SR_CHECK(h->general, SR_ESTATE, "sr_gp_mll: set the data with sr_gp_set_data_general (packed parameters)");
+    hipStream_t s = (hipStream_t)stream;
+    SR_HIP(hipSetDevice(h->device));
+    const int Np = h->Np, D = h->D;
+    const size_t NN = (size_t)Np * Np;
+    const int ng = SR_KP(D);                        // [v, c0, s[D], a[D], b[D], noise]
+    double *W = nullptr, *Kinv = nullptr, *partial = nullptr, *ld = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&W, NN)) || (rc = dev_alloc(&Kinv, NN)) || (rc = dev_alloc(&partial, (size_t)sr_mll_ws(h->N))) ||
+        (rc = dev_alloc(&ld, (size_t)h->n_out))) {
+        dev_free(W); dev_free(Kinv); dev_free(partial); dev_free(ld);
+        return rc;
+    }
+    rc = sr_launch_logdet(h->Wt, Np, h->n_out, ld, s);
+    for (int d = 0; d < h->n_out && rc == SR_OK; ++d) {
+        // K_y^-1 = U^-1 U^-T = sum_k W[k][i] W[k][j]  (W = Wt^T, k-major)
+        rc = sr_launch_transpose(h->Wt + (size_t)d * NN, W, Np, s);
+        if (rc == SR_OK) rc = sr_launch_gemm_tn(W, Np, W, Np, Kinv, Np, Np, Np, Np, 1.0, 0.0, 0, s);
+        if (rc == SR_OK)
+            rc = sr_launch_mll(Kinv, Np, h->N, h->alpha + (size_t)d * Np, h->yT + (size_t)d * Np, h->Z,
+                               h->kp + (size_t)d * SR_KP(D), D, ld + d, partial, nll + d, grad + (size_t)d * ng, s);
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    dev_free(W); dev_free(Kinv); dev_free(partial); dev_free(ld);
+    if (rc != SR_OK) return rc;
+    SR_HIP(e);
+    return SR_OK;
+}
+
 extern "C" int sr_gp_logdet(sr_gp_t h, double* logdet, void* stream) {
     SR_CHECK(h && logdet, SR_EINVAL, "sr_gp_logdet: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_logdet: model not factorized");

@@ -115,6 +115,10 @@ int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd
 // y[r] = sum_c M[r][c] x[c], c in [0..r] (lower=1) or [r..n) (lower=0)
 int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
                    hipStream_t s);
+long sr_mll_ws(int N);
+int sr_launch_mll(const double* Kinv, int Np, int N, const double* alpha, const double* yT, const double* Z,
+                  const double* kp, int D, const double* logdet, double* partial, double* nll, double* grad,
+                  hipStream_t s);
 int sr_launch_logdet(const double* Wt, int Np, int n_out, double* out, hipStream_t s);
 int sr_launch_fill(double* p, size_t n, double v, hipStream_t s);
 int sr_launch_sub_block(double* S, const double* G, int pf, hipStream_t s);

@@ -128,6 +128,8 @@ class SimpleGPModel(StateSpaceModel):
 
         hyp_out = []
         self._noise = np.empty(self.n_s_out)
+        # keys given by the caller stay fixed under opt_hyp=True (the reference fixes them in GPy, :478-486)
+        self._hyp_fixed = [set(h.keys()) if h is not None else set() for h in hyp]
         for i in range(self.n_s_out):
             kt = kern_types[i]
             h = dict(hyp[i]) if hyp[i] is not None else {}
@@ -145,12 +147,14 @@ class SimpleGPModel(StateSpaceModel):
         self.kern_types = list(kern_types)
         self.hyp = hyp_out
 
-    def _pack_kernel_params(self):
+    def _pack_kernel_params(self, only=None):
         """(n_out, 3+3D) packed parameters of sr_gp_set_data_general:
-        [kappa, v, c0, s[D], a[D], b[D]] with k = (c0 + sum a x y) v kappa(r) + sum b x y."""
+        [kappa, v, c0, s[D], a[D], b[D]] with k = (c0 + sum a x y) v kappa(r) + sum b x y.
+        ``only=i`` packs output i alone (1, 3+3D)."""
         D = self.n_s_in + self.n_u
-        kp = np.zeros((self.n_s_out, 3 + 3 * D))
-        for i, (kt, h) in enumerate(zip(self.kern_types, self.hyp)):
+        pairs = list(zip(self.kern_types, self.hyp)) if only is None else [(self.kern_types[only], self.hyp[only])]
+        kp = np.zeros((len(pairs), 3 + 3 * D))
+        for i, (kt, h) in enumerate(pairs):
             if kt in ("rbf", "mat52"):
                 kp[i, 0] = 0.0 if kt == "rbf" else 1.0
                 kp[i, 1], kp[i, 2] = h["variance"], 1.0
@@ -264,11 +268,8 @@ class SimpleGPModel(StateSpaceModel):
     def train(self, X, y, m=None, opt_hyp=True, noise_diag=1e-5, Z=None, choose_data=True):
         """Condition the GPs on data (ssm_gpy/gaussian_process.py:189-278).
 
-        ``opt_hyp=True`` (marginal-likelihood optimisation inside GPy) is outside the hot path:
-        construct the model with fixed ``hyp`` and call with ``opt_hyp=False``."""
-        if opt_hyp:
-            raise NotImplementedError("hyper-parameter optimisation is not part of the MI355X hot "
-                                      "path; pass hyp=... and opt_hyp=False")
+        ``opt_hyp=True`` maximises the exact marginal likelihood over the hyper-parameters the caller did not fix
+        (``optimize_hyperparameters``; the reference calls GPy's ``optimize`` there, :249-250)."""
         X = np.asarray(X, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
         if X.ndim != 2 or y.ndim != 2 or X.shape[0] != y.shape[0]:
@@ -276,12 +277,99 @@ class SimpleGPModel(StateSpaceModel):
         if X.shape[1] != self.n_s_in + self.n_u or y.shape[1] != self.n_s_out:
             raise ValueError("X must be (N, n_s_in+n_u) and y (N, n_s_out)")
         Zs, yz = self._select_subset(X, y, m, Z, choose_data, noise_diag)
+        if opt_hyp:
+            self.optimize_hyperparameters(Zs, yz)
         self._fit(Zs, yz, noise_diag)
         self._noise_diag = noise_diag
         self.z = self.Z if self.z_fixed else Zs
         self.x_train = X
         self.y_train = y
         self.gp_trained = True
+
+    def _free_hyp(self, i):
+        """[(key, size)] of the hyper-parameters of output i that ``opt_hyp`` may move: everything the caller
+        did not pass in ``hyp`` (ssm_gpy/gaussian_process.py:478-486 fixes what was passed), noise included."""
+        return [(k, int(np.size(v))) for k, v in list(self.hyp[i].items()) + [("noise_variance", self._noise[i])]
+                if k not in self._hyp_fixed[i]]
+
+    def neg_log_marginal_likelihood(self, Z, Y, i, with_grad=True):
+        """nll of output i on (Z, Y[:, i]) at the current hyper-parameters and its gradient with respect to the
+        FREE hyper-parameters (natural scale, order of ``_free_hyp``), through sr_gp_factorize + sr_gp_mll.
+        Noise term as during GPy's optimisation: sigma_n^2 + 1e-8, no ``noise_diag``.  Returns (inf, None) when
+        K_y is not positive definite at these hyper-parameters."""
+        dev = B.resolve_device(self._device_arg)
+        Z = np.asarray(Z, dtype=np.float64)
+        N, D = Z.shape
+        hd = _Handle(dev, N, D, 1)
+        s = B.stream_ptr(dev)
+        tz = B.as_dev(Z, dev)
+        ty = B.as_dev(np.ascontiguousarray(np.asarray(Y, dtype=np.float64)[:, i:i + 1]), dev)
+        tk = B.as_dev(self._pack_kernel_params(only=i), dev)
+        tn = B.as_dev(np.array([self._noise[i] + GPY_JITTER]), dev)
+        check(lib.sr_gp_set_data_general(hd.h, B.ptr(tz), B.ptr(ty), B.ptr(tk), B.ptr(tn), s))
+        info = (ctypes.c_int * 1)()
+        if lib.sr_gp_factorize(hd.h, s, info) != 0:
+            return np.inf, None
+        nll, g = B.empty((1,), dev), B.empty((3 + 3 * D,), dev)
+        check(lib.sr_gp_mll(hd.h, B.ptr(nll), B.ptr(g), s))
+        nll, g = float(nll.item()), B.to_numpy(g)
+        if not with_grad:
+            return nll, None
+        kt, h = self.kern_types[i], self.hyp[i]
+        full = {"noise_variance": np.array([g[-1]])}
+        if kt in ("rbf", "mat52"):
+            full["variance"] = np.array([g[0]])
+            full["lengthscale"] = -g[2:2 + D] / h["lengthscale"] ** 2            # s = 1 / lengthscale
+        else:
+            st = "rbf" if kt == "lin_rbf" else "mat52"
+            full["prod.%s.variance" % st] = np.array([g[0]])
+            full["prod.%s.lengthscale" % st] = np.array([-g[2 + 1] / h["prod.%s.lengthscale" % st][0] ** 2])
+            full["prod.linear.variances"] = np.array([g[2 + D + 1]])
+            full["linear.variances"] = g[2 + 2 * D:2 + 3 * D]
+        free = self._free_hyp(i)
+        return nll, (np.concatenate([full[k] for k, _ in free]) if free else np.zeros(0))
+
+    def _get_free(self, i):
+        vals = dict(self.hyp[i], noise_variance=self._noise[i])
+        free = self._free_hyp(i)
+        return np.concatenate([np.reshape(vals[k], (-1,)) for k, _ in free]) if free else np.zeros(0)
+
+    def _set_free(self, i, theta):
+        pos = 0
+        for k, n in self._free_hyp(i):
+            v = np.asarray(theta[pos:pos + n], dtype=np.float64)
+            pos += n
+            if k == "noise_variance":
+                self._noise[i] = float(v[0])
+            elif np.ndim(self.hyp[i][k]) == 0:
+                self.hyp[i][k] = float(v[0])
+            else:
+                self.hyp[i][k] = v.copy()
+
+    def optimize_hyperparameters(self, Z, Y, max_iters=1000):
+        """Maximum-likelihood hyper-parameters per output (what ``model_gp.optimize(max_iters=1000)`` does in
+        ssm_gpy/gaussian_process.py:249-250): L-BFGS-B (scipy) over the logarithms of the free parameters,
+        every objective/gradient evaluation is one factorisation + ``sr_gp_mll`` on the device.  GPy's own
+        parameter transformation and stopping rule are not reproduced (GPy is not available: parity unpinned
+        at that boundary); the optimum of the same likelihood is."""
+        from scipy import optimize
+        for i in range(self.n_s_out):
+            if not self._free_hyp(i):
+                continue
+            start = self._get_free(i)
+
+            def fun(phi):
+                self._set_free(i, np.exp(np.clip(phi, -25.0, 25.0)))
+                nll, g = self.neg_log_marginal_likelihood(Z, Y, i)
+                if not np.isfinite(nll):
+                    return 1e25, np.zeros_like(phi)
+                return nll, g * np.exp(np.clip(phi, -25.0, 25.0))
+
+            res = optimize.minimize(fun, np.log(start), jac=True, method="L-BFGS-B",
+                                    options={"maxiter": int(max_iters)})
+            best = np.exp(np.clip(res.x, -25.0, 25.0))
+            self._set_free(i, best if np.isfinite(res.fun) and res.fun < 1e24 else start)
+        return self.hyp
 
     def update_model(self, x, y, opt_hyp=False, replace_old=True, noise_diag=1e-5, choose_data=True):
         """ssm_gpy/gaussian_process.py:347-419."""

@@ -841,3 +841,61 @@ def test_max_variance_data_selection():
     with pytest.warns(UserWarning):
         gp.update_model(syn["Z"][:30], syn["Y"][:30], opt_hyp=False, replace_old=True)      # fewer than m: all of them
     assert gp.z.shape == (30, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kt", ["rbf", "mat52", "lin_rbf", "lin_mat52"])
+def test_marginal_likelihood_and_gradient(kt):
+    """sr_gp_mll (objective/gradient of train(opt_hyp=True), gaussian_process.py:249-250) against the oracle's
+    per-kernel closed forms (themselves checked against finite differences on the CPU)."""
+    from safe_exploration_amd import SimpleGPModel
+    rng = np.random.default_rng(8)
+    N, D = 150, 3
+    Z = rng.uniform(-1, 1, (N, D))
+    Y = rng.standard_normal((N, 2))
+    hyp = [orc.make_hyp(kt, rng, D) for _ in range(2)]
+    gp = SimpleGPModel(2, 2, 1, kern_types=[kt] * 2)           # nothing fixed: every hyper-parameter is free
+    for i in range(2):
+        gp.hyp[i] = {k: (np.array(v, dtype=float) if np.ndim(v) else float(v)) for k, v in hyp[i].items()}
+        gp._noise[i] = 0.03 + 0.02 * i
+        nll, g = gp.neg_log_marginal_likelihood(Z, Y, i)
+        rnll, rg = orc.gp_nll_grad(Z, Y[:, i], kt, hyp[i], gp._noise[i])
+        ref = np.concatenate([np.reshape(rg[k], (-1,)) for k, _ in gp._free_hyp(i)])
+        assert abs(nll - rnll) < 1e-9 * abs(rnll)
+        np.testing.assert_allclose(g, ref, rtol=1e-7, atol=1e-8 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_train_with_hyperparameter_optimisation():
+    """train(opt_hyp=True): data drawn from a GP with known hyper-parameters; the maximum-likelihood fit lowers the
+    nll below its starting value AND below the value at the generating parameters, ends at a stationary point,
+    and recovers them to the accuracy 200 points allow.  Keys passed in ``hyp`` stay fixed."""
+    from safe_exploration_amd import SimpleGPModel
+    rng = np.random.default_rng(21)
+    N, D = 200, 3
+    Z = rng.uniform(-2, 2, (N, D))
+    true = {"lengthscale": np.array([0.8, 1.5, 1.1]), "variance": 1.7}
+    K = orc.rbf_kernel(Z, Z, true["variance"], true["lengthscale"]) + 0.01 * np.eye(N)
+    Y = np.linalg.cholesky(K).dot(rng.standard_normal((N, 2)))
+    gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2)
+    start = [gp.neg_log_marginal_likelihood(Z, Y, i, with_grad=False)[0] for i in range(2)]
+    gp.train(Z, Y, opt_hyp=True)
+    for i in range(2):
+        nll, g = gp.neg_log_marginal_likelihood(Z, Y, i)
+        at_truth = orc.gp_nll_grad(Z, Y[:, i], "rbf", true, 0.01)[0]
+        assert nll < start[i] - 10 and nll <= at_truth + 1e-6
+        theta = gp._get_free(i)
+        assert np.abs(g * theta).max() < 1e-2                       # stationary in log-parameters
+        assert 0.5 * 0.01 < gp._noise[i] < 2 * 0.01
+        np.testing.assert_allclose(gp.hyp[i]["lengthscale"], true["lengthscale"], rtol=0.35)
+        # the oracle's own optimum from the same start agrees
+        rn = orc.gp_nll_grad(Z, Y[:, i], "rbf", gp.hyp[i], gp._noise[i])[0]
+        assert abs(rn - nll) < 1e-8 * abs(nll)
+    mu, var = gp.predict(Z[:5])
+    assert np.abs(mu - Y[:5]).max() < 0.5 and var.max() < 0.1
+    # fixed keys stay fixed, the rest (variance, noise) moves
+    gp2 = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=[{"lengthscale": np.array([1.0, 1.0, 1.0])}] * 2)
+    gp2.train(Z, Y, opt_hyp=True)
+    for i in range(2):
+        np.testing.assert_array_equal(gp2.hyp[i]["lengthscale"], np.ones(3))
+        assert gp2.hyp[i]["variance"] != 1.0 and gp2._noise[i] != 1.0

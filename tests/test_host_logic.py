@@ -67,8 +67,13 @@ def test_simple_gp_model_surface(lib_built):
     kp = g._pack_kernel_params()
     assert kp.shape == (2, 12) and kp[0, 0] == 1.0 and kp[0, 2] == 1.0 and kp[1, 2] == 0.0
     assert kp[1, 3 + 1] == 1.0 and kp[1, 3 + 0] == 0.0 and kp[1, 3 + 3 + 1] == 1.0     # product part on dim 1
-    with pytest.raises(NotImplementedError):                  # opt_hyp=True is outside the hot path
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # opt_hyp=True evaluates the likelihood on the GPU
         gp.train(np.zeros((4, 3)), np.zeros((4, 2)))
+    assert gp._free_hyp(0) == [("lengthscale", 3), ("variance", 1), ("noise_variance", 1)]
+    fixed = SimpleGPModel(2, 2, 1, hyp=[{"lengthscale": np.ones(3), "noise_variance": 0.1}] * 2)
+    assert fixed._free_hyp(1) == [("variance", 1)]
+    fixed._set_free(1, np.array([2.5]))
+    assert fixed.hyp[1]["variance"] == 2.5 and fixed._get_free(1).tolist() == [2.5]
     with pytest.raises(ValueError):
         gp.train(np.zeros((4, 2)), np.zeros((4, 2)), opt_hyp=False)
     with pytest.raises(RuntimeError):

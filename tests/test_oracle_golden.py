@@ -311,3 +311,36 @@ def test_second_order_outputs_of_all_kernels_vs_finite_differences(kt):
         jv0, hm0 = orc.gp_linearize_extras(x, Z, beta, inv_K, ls, [h["variance"] for h in hyp])
         np.testing.assert_allclose(jv, jv0, rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(hm, hm0, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("kt", ["rbf", "mat52", "lin_rbf", "lin_mat52"])
+def test_marginal_likelihood_gradient_vs_finite_differences(kt):
+    """oracle.gp_nll_grad (the objective of train(opt_hyp=True)) against central differences in every
+    hyper-parameter, and against scikit-learn's log marginal likelihood for the plain rbf case."""
+    rng = np.random.default_rng(5)
+    N, D = 30, 3
+    Z = rng.uniform(-1, 1, (N, D))
+    y = rng.standard_normal(N)
+    hyp, nv = orc.make_hyp(kt, rng, D), 0.05
+    nll, g = orc.gp_nll_grad(Z, y, kt, hyp, nv)
+    eps = 1e-6
+    for key, val in g.items():
+        for j in range(val.size):
+            def at(sign):
+                h = {k: (np.array(v, dtype=float).copy() if np.ndim(v) > 0 else float(v)) for k, v in hyp.items()}
+                n = nv
+                if key == "noise_variance":
+                    n = nv + sign * eps
+                elif np.ndim(h[key]) == 0:
+                    h[key] = h[key] + sign * eps
+                else:
+                    h[key].reshape(-1)[j] += sign * eps
+                return orc.gp_nll_grad(Z, y, kt, h, n)[0]
+            fd = (at(1) - at(-1)) / (2 * eps)
+            assert abs(fd - val[j]) <= 2e-6 * max(1.0, abs(fd)), (key, j, fd, val[j])
+    if kt == "rbf":
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        from sklearn.gaussian_process.kernels import RBF, ConstantKernel
+        kern = ConstantKernel(float(hyp["variance"]), "fixed") * RBF(hyp["lengthscale"], "fixed")
+        gpr = GaussianProcessRegressor(kern, alpha=nv + orc.GPY_JITTER, optimizer=None).fit(Z, y)
+        assert abs(-gpr.log_marginal_likelihood_value_ - nll) < 1e-9 * abs(nll)
