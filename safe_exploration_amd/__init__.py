@@ -4,8 +4,7 @@ Drop-in for the hot path of befelix/safe-exploration (and nothing else):
 
     from safe_exploration_amd import SimpleGPModel, gp_reachability, utils_ellipsoid, utils
 
-Importing the package loads libsafereach.so (built in-tree by ``python -m
-safe_exploration_amd._build``); it fails loudly when the library is missing, and every compute
+Importing the package loads libsafereach.so (built in-tree by ``make -C safe_exploration_amd/csrc``); it fails loudly when the library is missing, and every compute
 call fails loudly when no ROCm GPU is visible -- there is no CPU fallback.
 """
 from . import _lib  # noqa: F401  (ImportError here == library not built)

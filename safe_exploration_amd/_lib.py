@@ -21,7 +21,7 @@ KERNEL_NAMES = {K_GRAM: "sr_gram_kernel", K_POTRF: "sr_potrf_diag_kernel", K_GEM
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
-        "libsafereach.so not found at %s -- build it with `python -m safe_exploration_amd._build` "
+        "libsafereach.so not found at %s -- build it with `make -C safe_exploration_amd/csrc` or `python __graft_entry__.py` "
         "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
 
 lib = ctypes.CDLL(LIB_PATH)
