@@ -234,3 +234,53 @@ def lin_ellipsoid_safety_distance(p_center, q_shape, h_mat, h_vec, c_safety=1.0)
                                             np.asarray(q_shape, dtype=np.float64)[None], h_mat, h_vec,
                                             c_safety)
     return d.reshape(m, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# closed-loop roll-outs of the TRUE system against the predicted ellipsoids (gp_reachability.py:253-356).
+# `env` is the caller's environment object (duck-typed: ``simulate_onestep(state, action) -> (state, ...)``,
+# attributes n_s / n_u); these are host-side bookkeeping around the batched containment kernels.
+# ------------------------------------------------------------------------------------------------
+def simulate_trajectory(env, p_0, k_fb, k_ff, p_ctrl):
+    """Roll the environment forward under u_0 = k_ff[0], u_i = k_fb[i-1] (x_i - p_ctrl[i-1]) + k_ff[i]
+    (gp_reachability.py:253-283).  k_ff (n, n_u); k_fb (n-1, n_u*n_s); p_ctrl (n-1, n_s) -> x_all (n+1, n_s)."""
+    from .utils import feedback_ctrl
+    k_ff = np.asarray(k_ff, dtype=np.float64)
+    n, n_u = k_ff.shape
+    x = np.asarray(p_0, dtype=np.float64).reshape(-1)
+    n_s = x.size
+    x_all = np.empty((n + 1, n_s))
+    x_all[0] = x
+    for i in range(n):
+        if i == 0:
+            action = k_ff[0]
+        else:
+            action = feedback_ctrl(x[:, None], k_ff[i, :, None], np.reshape(k_fb[i - 1], (n_u, n_s)),
+                                   np.asarray(p_ctrl[i - 1], dtype=np.float64)[:, None])
+        x = np.asarray(env.simulate_onestep(x, action)[0], dtype=np.float64).reshape(-1)
+        x_all[i + 1] = x
+    return x_all
+
+
+def verify_trajectory_safety(env, p_0, k_fb, k_ff, p_ctrl, h_mat_safe, h_safe, h_mat_obs=None, h_obs=None):
+    """True trajectory inside the obstacle-free polytope at steps 1..n-1 and inside the terminal safe polytope at
+    the last step (gp_reachability.py:286-320).  Returns (bool, x_all)."""
+    from .utils import sample_inside_polytope
+    n = np.shape(k_ff)[0]
+    x_all = simulate_trajectory(env, p_0, k_fb, k_ff, p_ctrl)
+    inside = True
+    if h_mat_obs is not None and n > 1:
+        inside = bool(np.all(sample_inside_polytope(x_all[1:n], h_mat_obs, h_obs)))
+    inside = inside and bool(np.all(sample_inside_polytope(x_all[None, -1, :], h_mat_safe, h_safe)))
+    return inside, x_all
+
+
+def trajectory_inside_ellipsoid(env, p_0, p_all, q_all, k_fb, k_ff):
+    """Is the true state at step i inside the predicted ellipsoid (p_all[i], q_all[i])?  (gp_reachability.py:323-356)
+    p_all (n, n_s); q_all (n, n_s*n_s) -> bool (n,)."""
+    n = np.shape(k_ff)[0]
+    n_s = env.n_s
+    x_all = simulate_trajectory(env, p_0, k_fb, k_ff, p_all)[1:]
+    centred = x_all - np.asarray(p_all, dtype=np.float64).reshape(n, n_s)
+    q_all = np.asarray(q_all, dtype=np.float64).reshape(n, n_s, n_s)
+    return np.einsum('ij,ij->i', centred, np.linalg.solve(q_all, centred[:, :, None])[:, :, 0]) < 1.0

@@ -431,6 +431,45 @@ def main():
     mc_case("mc_pend.npz", 501, 60, 2, 1, 4, 64)      # n_u = 1: the reference's repmat of k[i] is only shaped right there
     mc_case("mc_cart.npz", 502, 80, 4, 1, 3, 48)
 
+    # ------------------------------------------------------------------ 7. true-system roll-outs vs ellipsoids
+    # gp_reachability.simulate_trajectory / verify_trajectory_safety / trajectory_inside_ellipsoid driven with a
+    # stand-in environment (the reference's environments need scipy.integrate setups that are out of scope).
+    np.bool = bool                                # gp_reachability.py:350 still uses the removed alias
+
+    class ToyEnv(object):
+        n_s, n_u = 2, 1
+
+        def __init__(self, A, Bm):
+            self.A, self.Bm = A, Bm
+
+        def simulate_onestep(self, x, u):
+            x = np.asarray(x, dtype=np.float64).reshape(-1)
+            u = np.asarray(u, dtype=np.float64).reshape(-1)
+            xn = self.A.dot(x) + self.Bm.dot(u) + 0.05 * np.sin(x)
+            return xn, None
+
+    rng = np.random.default_rng(77)
+    A = np.array([[0.9, 0.1], [-0.05, 0.85]]); Bm = np.array([[0.0], [0.3]])
+    env = ToyEnv(A, Bm)
+    n = 6
+    p_0 = 0.2 * rng.standard_normal(2)
+    k_ff = 0.2 * rng.standard_normal((n, 1))
+    k_fb = 0.3 * rng.standard_normal((n - 1, 2))
+    p_all = 0.15 * rng.standard_normal((n, 2))
+    q_all = np.empty((n, 4))
+    for i in range(n):
+        Bq = rng.standard_normal((2, 2))
+        q_all[i] = ((0.02 + 0.03 * i) * (Bq.dot(Bq.T) + np.eye(2))).reshape(-1)
+    x_all = gr.simulate_trajectory(env, p_0, k_fb, k_ff, p_all[:n - 1])
+    inside = gr.trajectory_inside_ellipsoid(env, p_0, p_all, q_all, k_fb, k_ff)
+    h_mat = np.vstack((np.eye(2), -np.eye(2)))
+    ok_wide, _ = gr.verify_trajectory_safety(env, p_0, k_fb, k_ff, p_all[:n - 1], h_mat, np.full((4, 1), 5.0), h_mat,
+                                             np.full((4, 1), 5.0))
+    lim = float(np.abs(x_all[-1]).max()) * 0.9
+    ok_tight, _ = gr.verify_trajectory_safety(env, p_0, k_fb, k_ff, p_all[:n - 1], h_mat, np.full((4, 1), lim))
+    _save("traj.npz", A=A, Bm=Bm, p_0=p_0, k_ff=k_ff, k_fb=k_fb, p_all=p_all, q_all=q_all, x_all=x_all,
+          inside=np.asarray(inside, dtype=bool), h_mat=h_mat, ok_wide=bool(ok_wide), ok_tight=bool(ok_tight), lim=lim)
+
     # ------------------------------------------------------------------ 5. worked anchor of SURVEY 8c
     p = np.array([[0.1], [-0.2]]); Q = 0.2 * np.array([[.5, .2], [.2, .65]])
     k_ff = np.array([[0.3]]); k_fb = np.array([[0.4, -0.1]])

@@ -161,3 +161,35 @@ def test_reshape_derivatives():
     d3 = np.arange(2 * 3 * 4, dtype=float).reshape(2, 3, 4)
     d2 = utils.reshape_derivatives_3d_to_2d(d3)
     assert d2.shape == (6, 4) and d2[4, 1] == d3[1, 1, 1]
+
+
+def test_true_system_rollouts_vs_reference_golden():
+    """simulate_trajectory / verify_trajectory_safety / trajectory_inside_ellipsoid (gp_reachability.py:253-356)
+    against the reference's own functions driven with the same stand-in environment (make_golden.py 7)."""
+    from safe_exploration_amd import gp_reachability as reach
+    g = load_golden("traj.npz")
+
+    class ToyEnv(object):
+        n_s, n_u = 2, 1
+
+        def simulate_onestep(self, x, u):
+            x, u = np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(u, dtype=np.float64).reshape(-1)
+            return g["A"].dot(x) + g["Bm"].dot(u) + 0.05 * np.sin(x), None
+
+    env, n = ToyEnv(), g["k_ff"].shape[0]
+    x_all = reach.simulate_trajectory(env, g["p_0"], g["k_fb"], g["k_ff"], g["p_all"][:n - 1])
+    np.testing.assert_allclose(x_all, g["x_all"], rtol=1e-13, atol=1e-15)
+    inside = reach.trajectory_inside_ellipsoid(env, g["p_0"], g["p_all"], g["q_all"], g["k_fb"], g["k_ff"])
+    np.testing.assert_array_equal(inside, g["inside"])
+    assert inside.dtype == bool and not inside.all() and inside.any()
+    wide = np.full((4, 1), 5.0)
+    ok, xa = reach.verify_trajectory_safety(env, g["p_0"], g["k_fb"], g["k_ff"], g["p_all"][:n - 1], g["h_mat"], wide,
+                                            g["h_mat"], wide)
+    assert ok == bool(g["ok_wide"]) and ok is True
+    np.testing.assert_array_equal(xa, x_all)
+    ok2, _ = reach.verify_trajectory_safety(env, g["p_0"], g["k_fb"], g["k_ff"], g["p_all"][:n - 1], g["h_mat"],
+                                            np.full((4, 1), float(g["lim"])))
+    assert ok2 == bool(g["ok_tight"]) and ok2 is False
+    # n = 1: no feedback stage at all
+    x1 = reach.simulate_trajectory(env, g["p_0"], None, g["k_ff"][:1], None)
+    np.testing.assert_allclose(x1[1], g["x_all"][1], rtol=1e-13)
