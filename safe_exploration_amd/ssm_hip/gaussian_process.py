@@ -33,6 +33,7 @@ class _Handle(object):
         self.h = ctypes.c_void_p()
         check(lib.sr_gp_create(ctypes.byref(self.h), device.index, N, D, n_out))
         self.N, self.D, self.n_out = N, D, n_out
+        self.shared = False              # set when a deep copy of the model holds this handle too
         npad = ctypes.c_long(0)
         check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
         self.Np = npad.value
@@ -200,6 +201,8 @@ class SimpleGPModel(StateSpaceModel):
         memo[id(self)] = new
         for k, v in self.__dict__.items():
             new.__dict__[k] = v          # arrays are replaced, never mutated, on update
+        if self._handle is not None:
+            self._handle.shared = True   # from now on updates build a new handle instead of touching this one
         return new
 
     # ------------------------------------------------------------------ training
@@ -300,7 +303,9 @@ class SimpleGPModel(StateSpaceModel):
         dev = B.resolve_device(self._device_arg)
         Z = np.asarray(Z, dtype=np.float64)
         N, D = Z.shape
-        hd = _Handle(dev, N, D, 1)
+        hd = getattr(self, "_mll_handle", None)
+        if hd is None or (hd.N, hd.D, hd.device) != (N, D, dev):
+            hd = self._mll_handle = _Handle(dev, N, D, 1)      # reused by every evaluation of the optimiser
         s = B.stream_ptr(dev)
         tz = B.as_dev(Z, dev)
         ty = B.as_dev(np.ascontiguousarray(np.asarray(Y, dtype=np.float64)[:, i:i + 1]), dev)
@@ -369,6 +374,7 @@ class SimpleGPModel(StateSpaceModel):
                                     options={"maxiter": int(max_iters)})
             best = np.exp(np.clip(res.x, -25.0, 25.0))
             self._set_free(i, best if np.isfinite(res.fun) and res.fun < 1e24 else start)
+        self._mll_handle = None
         return self.hyp
 
     def update_model(self, x, y, opt_hyp=False, replace_old=True, noise_diag=1e-5, choose_data=True):
@@ -376,7 +382,7 @@ class SimpleGPModel(StateSpaceModel):
         x = np.asarray(x, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
         if (not replace_old and not opt_hyp and self.gp_trained and self._handle is not None
-                and self.m is None and self.x_train is not None and not self.z_fixed
+                and not self._handle.shared and self.m is None and self.x_train is not None and not self.z_fixed
                 and noise_diag == self._noise_diag and 0 < x.shape[0] <= self.append_limit):
             self._append(x, y)                       # O(N^2 m) block row append instead of O(N^3)
             return
@@ -413,7 +419,12 @@ class SimpleGPModel(StateSpaceModel):
     def _fit(self, Z, Y, noise_diag):
         dev = B.resolve_device(self._device_arg)
         N, D = Z.shape
-        handle = _Handle(dev, N, D, self.n_s_out)
+        old = self._handle
+        if (old is not None and not old.shared and (old.N, old.D, old.n_out) == (N, D, self.n_s_out)
+                and old.device == dev):
+            handle = old                 # same shape: refactorise in place, no device allocation
+        else:
+            handle = _Handle(dev, N, D, self.n_s_out)
         # diagonal term: sigma_n^2 + noise_diag (gaussian_process.py:252-253) + GPy's internal jitter
         noise = self._noise + float(noise_diag) + GPY_JITTER
         s = B.stream_ptr(dev)

@@ -31,6 +31,10 @@ def main():
     t0 = time.time()
     gp.train(prob["Z"], prob["Y"], opt_hyp=False)
     torch.cuda.synchronize()
+    cold_s = time.time() - t0               # includes the 40 GB of first-touch device allocation
+    t0 = time.time()
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)      # same shape: refactorises in place
+    torch.cuda.synchronize()
     fit_s = time.time() - t0
     # second, profiled update (hipEvent pairs per launch) for the per-kernel split
     gp2 = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device="cuda:0")
@@ -69,7 +73,7 @@ def main():
         res_var = max(res_var, float(np.abs(var[:, d] - (s2n[d] - s2n[d] ** 2 * kinv_ii)).max()))
     del wt
     flops = n_s * (2.0 / 3.0) * float(N) ** 3         # potrf N^3/3 + trtri N^3/3 per output
-    out = {"config": "C4 pendulum dims n_out=2, N=%d, fp64" % N, "Np": Np, "model_update_s": fit_s,
+    out = {"config": "C4 pendulum dims n_out=2, N=%d, fp64" % N, "Np": Np, "model_update_s": fit_s, "first_update_s": cold_s,
            "algorithmic_TFLOPs": flops / 1e12, "achieved_TFLOP/s": flops / fit_s / 1e12,
            "check_sample": Ts, "max|mu + s2n*alpha - y|": float(res_mu),
            "max|var - (s2n - s2n^2 Kinv_ii)|": float(res_var),

@@ -899,3 +899,38 @@ def test_train_with_hyperparameter_optimisation():
     for i in range(2):
         np.testing.assert_array_equal(gp2.hyp[i]["lengthscale"], np.ones(3))
         assert gp2.hyp[i]["variance"] != 1.0 and gp2._noise[i] != 1.0
+
+
+@pytest.mark.gpu
+def test_refit_reuses_the_handle_and_deep_copies_keep_their_model():
+    """update_model with the same N refactorises in place (no device allocation); a deep copy (what
+    get_forward_model_casadi hands to CasADi, state_space_models.py:166) must keep predicting with the model it
+    was copied from, whatever happens to the original afterwards (refit or row append)."""
+    import copy
+    a = orc.make_synthetic(301, 180, 2, 1, 16)
+    b = orc.make_synthetic(302, 180, 2, 1, 16)
+    gp = hip_model(a["Z"], a["Y"], a["lengthscale"], a["signal_var"], a["noise_var"], 2, 1)
+    x = np.hstack((a["p"], a["k_ff"]))
+    mu_a, var_a = gp.predict(x)
+    h0 = gp._handle
+    gp.update_model(b["Z"], b["Y"], opt_hyp=False, replace_old=True)
+    assert gp._handle is h0                                     # reused
+    fresh = hip_model(b["Z"], b["Y"], a["lengthscale"], a["signal_var"], a["noise_var"], 2, 1)
+    mu_b, var_b = gp.predict(x)
+    np.testing.assert_array_equal(mu_b, fresh.predict(x)[0])
+    np.testing.assert_array_equal(var_b, fresh.predict(x)[1])
+    assert np.abs(mu_b - mu_a).max() > 1e-3
+    snap = copy.deepcopy(gp)
+    gp.update_model(a["Z"], a["Y"], opt_hyp=False, replace_old=True)
+    assert gp._handle is not h0 and snap._handle is h0          # shared handle left alone
+    np.testing.assert_array_equal(snap.predict(x)[0], mu_b)
+    np.testing.assert_array_equal(gp.predict(x)[0], mu_a)
+    snap2 = copy.deepcopy(gp)
+    gp.update_model(b["Z"][:20], b["Y"][:20], opt_hyp=False, replace_old=False)    # append path must not touch snap2
+    assert gp.z.shape[0] == 200 and snap2.z.shape[0] == 180
+    np.testing.assert_array_equal(snap2.predict(x)[0], mu_a)
+    both = orc.gp_fit(np.vstack((a["Z"], b["Z"][:20])), np.vstack((a["Y"], b["Y"][:20])), a["lengthscale"],
+                      a["signal_var"], a["noise_var"])
+    rmu, _ = orc.gp_predict(x, np.vstack((a["Z"], b["Z"][:20])), both[0], both[1], a["lengthscale"], a["signal_var"],
+                            False)
+    np.testing.assert_allclose(gp.predict(x)[0], rmu, rtol=1e-8, atol=1e-10)
