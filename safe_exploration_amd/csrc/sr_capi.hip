@@ -36,8 +36,14 @@ struct sr_gp {
     int last_streamed = 0;   // the last gp_pass went through the streaming kernels (their partials hold U^-T k*)
     int force_stream = 0;    // sr_gp_linearize wants those partials whatever the model size
     int var_variant = 1;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles (default)
+    // factorisation: the outputs are independent problems -- below SR_FACT_PAR_BYTES of scratch each gets its own
+    // HIP stream (the small-grid kernels of a modest model then overlap) and the scratch stays with the handle
+    double* fact_ws = nullptr; size_t fact_cap = 0;      // n_par x (U, W: Np^2 each, v: Np)
+    hipStream_t fact_stream[SR_MAX_NS] = {nullptr};
+    hipEvent_t fact_fork = nullptr, fact_join[SR_MAX_NS] = {nullptr};
     sr_prof prof;
 };
+#define SR_FACT_PAR_BYTES ((size_t)8 << 30)
 
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
@@ -98,6 +104,12 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     free_ws(h);
+    dev_free(h->fact_ws);
+    for (int d = 0; d < SR_MAX_NS; ++d) {
+        if (h->fact_stream[d]) (void)hipStreamDestroy(h->fact_stream[d]);
+        if (h->fact_join[d]) (void)hipEventDestroy(h->fact_join[d]);
+    }
+    if (h->fact_fork) (void)hipEventDestroy(h->fact_fork);
     h->prof.destroy();
     delete h;
     return SR_OK;
@@ -165,29 +177,62 @@ static int ensure_wt(sr_gp* h) {
 extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_factorize: NULL handle");
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
-    hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
     SR_TRY(ensure_wt(h));
     const int Np = h->Np, nb = Np / SR_NB;
     const size_t NN = (size_t)Np * Np;
-    double *U = nullptr, *W = nullptr, *v = nullptr;
+    const size_t per = 2 * NN + (size_t)Np;              // scratch doubles per output: U, W, v
+    const bool par = h->n_out > 1 && per * h->n_out * sizeof(double) <= SR_FACT_PAR_BYTES;
+    const int n_par = par ? h->n_out : 1;
+    double* scratch = nullptr;                           // owned here only when it is not kept in the handle
     int* info_dev = nullptr;
     std::vector<double> sf2(h->n_out), noise(h->n_out);
     int rc = SR_OK;
-    auto cleanup = [&]() { dev_free(U); dev_free(W); dev_free(v); dev_free(info_dev); };
+    hipStream_t s0 = (hipStream_t)stream;
+    auto cleanup = [&]() {
+        if (par) {                                       // never return with work in flight on the side streams
+            for (int d = 1; d < h->n_out; ++d)
+                if (h->fact_stream[d]) (void)hipStreamSynchronize(h->fact_stream[d]);
+        }
+        dev_free(scratch); dev_free(info_dev);
+    };
 #define SR_F(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(); return rc; } } while (0)
 #define SR_FH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); return SR_EHIP; } } while (0)
-    SR_F(dev_alloc(&U, NN));
-    SR_F(dev_alloc(&W, NN));
-    SR_F(dev_alloc(&v, (size_t)Np));
+    double* ws;
+    if (per * n_par * sizeof(double) <= SR_FACT_PAR_BYTES) {
+        if (h->fact_cap < per * n_par) {
+            (void)hipDeviceSynchronize();
+            dev_free(h->fact_ws);
+            h->fact_ws = nullptr; h->fact_cap = 0;
+            SR_F(dev_alloc(&h->fact_ws, per * n_par));
+            h->fact_cap = per * n_par;
+        }
+        ws = h->fact_ws;
+    } else {
+        SR_F(dev_alloc(&scratch, per));
+        ws = scratch;
+    }
     SR_F(dev_alloc(&info_dev, (size_t)h->n_out));
-    SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s));
-    SR_FH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s));
-    SR_FH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s));
-    SR_FH(hipStreamSynchronize(s));
+    SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s0));
+    SR_FH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0));
+    SR_FH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0));
+    SR_FH(hipStreamSynchronize(s0));
+    if (par) {
+        if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
+        SR_FH(hipEventRecord(h->fact_fork, s0));
+        for (int d = 1; d < h->n_out; ++d) {
+            if (!h->fact_stream[d]) SR_FH(hipStreamCreateWithFlags(&h->fact_stream[d], hipStreamNonBlocking));
+            if (!h->fact_join[d]) SR_FH(hipEventCreateWithFlags(&h->fact_join[d], hipEventDisableTiming));
+            SR_FH(hipStreamWaitEvent(h->fact_stream[d], h->fact_fork, 0));
+        }
+    }
 
     for (int d = 0; d < h->n_out; ++d) {
+        hipStream_t s = (par && d > 0) ? h->fact_stream[d] : s0;
+        double* U = ws + (size_t)(par ? d : 0) * per;
+        double* W = U + NN;
+        double* v = W + NN;
         double* Wt = h->Wt + (size_t)d * NN;
         SR_FH(hipMemsetAsync(W, 0, NN * sizeof(double), s));
         SR_FH(hipMemsetAsync(Wt, 0, NN * sizeof(double), s));
@@ -267,10 +312,14 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         // alpha = Wt (W y)
         SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d * Np, v, Np, 1, s));
         SR_F(sr_launch_trmv(Wt, Np, v, h->alpha + (size_t)d * Np, Np, 0, s));
+        if (par && d > 0) {
+            SR_FH(hipEventRecord(h->fact_join[d], s));
+            SR_FH(hipStreamWaitEvent(s0, h->fact_join[d], 0));
+        }
     }
     std::vector<int> info_h(h->n_out, 0);
-    SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s));
-    SR_FH(hipStreamSynchronize(s));
+    SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s0));
+    SR_FH(hipStreamSynchronize(s0));
     cleanup();
 #undef SR_F
 #undef SR_FH
