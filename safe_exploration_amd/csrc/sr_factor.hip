@@ -133,21 +133,29 @@ int sr_launch_gram_general(const double* Z, const double* kp, double noise, doub
 
 // ------------------------------------------------------------------------------------------------
 // Diagonal block: A_kk = U_kk^T U_kk (upper Cholesky) and in-place inverse of U_kk, all in LDS.
-// One workgroup; 128 x 129 doubles of LDS (132 KiB of the CU's 160 KiB).
+// One workgroup of 16 wavefronts; 128 x 129 doubles of LDS (132 KiB of the CU's 160 KiB).
+// This kernel sits on the critical path of the blocked factorisation (one launch per 128 rows), so it is
+// built to keep block-wide barriers rare: both halves work on 16 x 16 sub-blocks.
+//   Cholesky, per 16-column panel (3 barriers): the 16 x 16 diagonal sub-block is factored by ONE wavefront
+//   in lock step (no barrier inside), the panel row is solved by forward substitution (thread = column, the
+//   16 x 16 factor broadcast from LDS), the trailing sub-matrix takes its rank-16 update on the MFMA tile.
+//   Inverse: the eight 16 x 16 diagonal sub-blocks are inverted by eight wavefronts in lock step, then
+//   [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1] is applied at block sizes 16, 32, 64 with both products on
+//   the MFMA tile; the intermediate A^-1 B is parked in the (unused) lower-left block.
+// The strict lower triangle of S is scratch throughout and masked on every read that means "U" or "U^-1".
 // ------------------------------------------------------------------------------------------------
 #define SR_PD_LD 129
 #define SR_PD_THREADS 1024
-// 1024 threads: the per-step work is latency-bound LDS read-modify-write, so it is spread as thinly as
-// possible -- Cholesky trailing update: thread = (column, 1 of 8 row phases); inverse: 8 lanes per row
-// share one dot product (shuffle reduction inside the wavefront).
+#define SR_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+
 __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
                                                                          double* wt_diag, double* w_diag,
                                                                          long ldw, int kb, int* info) {
     __shared__ double S[SR_NB * SR_PD_LD];
-    __shared__ double dg[SR_NB];
-    __shared__ double tmp[SR_NB];
     __shared__ int fail;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
     const long k0 = (long)kb * SR_NB;
     if (tid == 0) fail = 0;
     for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
@@ -156,40 +164,72 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
     }
     __syncthreads();
 
-    // right-looking upper Cholesky, S[j][j] keeps the pivot d_j until the end (sqrt kept in dg)
-    const int c_own = tid & 127, phase = tid >> 7;            // 8 row phases
-    for (int j = 0; j < SR_NB; ++j) {
-        const double d = S[j * SR_PD_LD + j];
-        if (!(d > 0.0)) {                       // also catches NaN; uniform across the workgroup
-            if (tid == 0) fail = j + 1;
-            break;
-        }
-        const double sd = sqrt(d);
-        const double inv = 1.0 / sd;
-        if (tid == 0) dg[j] = sd;
-        if (tid < SR_NB && tid > j) S[j * SR_PD_LD + tid] *= inv;
-        __syncthreads();
-        if (c_own > j) {
-            const double ujc = S[j * SR_PD_LD + c_own];
-            int r = j + 1 + phase;
-            // 4 independent read-modify-writes in flight (row j is read-only here, every row r > j element is
-            // written by exactly one thread)
-            for (; r + 24 <= c_own; r += 32) {
-                const double a0 = S[j * SR_PD_LD + r], a1 = S[j * SR_PD_LD + r + 8];
-                const double a2 = S[j * SR_PD_LD + r + 16], a3 = S[j * SR_PD_LD + r + 24];
-                double* p0 = &S[r * SR_PD_LD + c_own];
-                const double b0 = p0[0], b1 = p0[8 * SR_PD_LD], b2 = p0[16 * SR_PD_LD], b3 = p0[24 * SR_PD_LD];
-                p0[0] = fma(-a0, ujc, b0);
-                p0[8 * SR_PD_LD] = fma(-a1, ujc, b1);
-                p0[16 * SR_PD_LD] = fma(-a2, ujc, b2);
-                p0[24 * SR_PD_LD] = fma(-a3, ujc, b3);
+    // ---- blocked right-looking upper Cholesky ------------------------------------------------------
+    for (int p = 0; p < SR_NB / 16; ++p) {
+        const int j0 = 16 * p;
+        if (wave == 0) {
+            // 16 x 16 diagonal sub-block, one wavefront in lock step: lane = (row r, 4 columns)
+            const int r = lane >> 2, cg = (lane & 3) * 4;
+            for (int j = 0; j < 16; ++j) {
+                double d = S[(j0 + j) * SR_PD_LD + j0 + j];
+                if (!(d > 0.0)) {                          // also catches NaN
+                    if (lane == 0 && fail == 0) fail = j0 + j + 1;
+                    d = 1.0;
+                }
+                const double sd = sqrt(d), inv = 1.0 / sd;
+                SR_WAVE_FENCE();
+                if (lane < 16 && lane >= j) {
+                    const double v = S[(j0 + j) * SR_PD_LD + j0 + lane];
+                    S[(j0 + j) * SR_PD_LD + j0 + lane] = (lane == j) ? sd : v * inv;
+                }
+                SR_WAVE_FENCE();
+                if (r > j) {
+                    const double ujr = S[(j0 + j) * SR_PD_LD + j0 + r];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = cg + q;
+                        if (c >= r)
+                            S[(j0 + r) * SR_PD_LD + j0 + c] =
+                                fma(-ujr, S[(j0 + j) * SR_PD_LD + j0 + c], S[(j0 + r) * SR_PD_LD + j0 + c]);
+                    }
+                }
+                SR_WAVE_FENCE();
             }
-            for (; r <= c_own; r += 8)
-                S[r * SR_PD_LD + c_own] = fma(-S[j * SR_PD_LD + r], ujc, S[r * SR_PD_LD + c_own]);
+        }
+        __syncthreads();
+        // panel row: U[j0 .. j0+15][c] = D^-T A[j0 .. j0+15][c] for the columns right of the panel
+        if (tid < SR_NB && tid >= j0 + 16) {
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double x = S[(j0 + i) * SR_PD_LD + tid];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < i) x = fma(-S[(j0 + k) * SR_PD_LD + j0 + i], v[k], x);
+                v[i] = x / S[(j0 + i) * SR_PD_LD + j0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[(j0 + i) * SR_PD_LD + tid] = v[i];
+        }
+        __syncthreads();
+        // trailing rank-16 update on the MFMA tile: tiles (ti <= tj) of the blocks right of / below the panel
+        const int nbt = SR_NB / 16 - 1 - p;
+        for (int e = wave; e < nbt * (nbt + 1) / 2; e += SR_PD_THREADS / 64) {
+            int ti = 0, rem = e;
+            while (rem >= nbt - ti) { rem -= nbt - ti; ++ti; }
+            const int r0 = 16 * (p + 1 + ti), c0 = 16 * (p + 1 + ti + rem);
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double af = S[(j0 + 4 * kk + lk) * SR_PD_LD + r0 + ln];
+                const double bf = S[(j0 + 4 * kk + lk) * SR_PD_LD + c0 + ln];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[(r0 + lk + 4 * q) * SR_PD_LD + c0 + ln] -= acc[q];
         }
         __syncthreads();
     }
-    __syncthreads();
     if (fail) {
         if (tid == 0 && *info == 0) *info = (int)k0 + fail;
         // keep downstream kernels finite: identity block
@@ -202,44 +242,71 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
         }
         return;
     }
-    if (tid < SR_NB) S[tid * SR_PD_LD + tid] = dg[tid];
-    __syncthreads();
     for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
         const int r = idx >> 7, c = idx & 127;
-        A[(k0 + r) * lda + k0 + c] = S[r * SR_PD_LD + c];   // strict lower part is zero in S
+        A[(k0 + r) * lda + k0 + c] = (c >= r) ? S[r * SR_PD_LD + c] : 0.0;
     }
-    __syncthreads();
+    __syncthreads();                                     // S is overwritten from here on
 
-    // in-place inverse of the upper-triangular block, column by column; row i is handled by 8 lanes
-    const int row = tid >> 3, part = tid & 7;
-    for (int j = 0; j < SR_NB; ++j) {
-        if (tid < j) tmp[tid] = S[tid * SR_PD_LD + j];
-        __syncthreads();
-        const double invjj = 1.0 / S[j * SR_PD_LD + j];
-        __syncthreads();
-        double s0 = 0.0, s1 = 0.0;
-        if (row < j) {
-            int k = row + part;
-            for (; k + 8 < j; k += 16) {
-                s0 = fma(S[row * SR_PD_LD + k], tmp[k], s0);
-                s1 = fma(S[row * SR_PD_LD + k + 8], tmp[k + 8], s1);
-            }
-            if (k < j) s0 = fma(S[row * SR_PD_LD + k], tmp[k], s0);
+    // ---- inverse of the upper-triangular block -----------------------------------------------------
+    // (a) the eight 16 x 16 diagonal sub-blocks, column by column, one wavefront each in lock step:
+    //     X[i][j] = -(sum_{k=i}^{j-1} X[i][k] U[k][j]) / U[j][j],  X[j][j] = 1 / U[j][j]
+    if (wave < SR_NB / 16) {
+        const int b0 = 16 * wave;
+        for (int j = 0; j < 16; ++j) {
+            const double invjj = 1.0 / S[(b0 + j) * SR_PD_LD + b0 + j];
+            double sum = 0.0;
+            if (lane < j)
+                for (int k = lane; k < j; ++k)
+                    sum = fma(S[(b0 + lane) * SR_PD_LD + b0 + k], S[(b0 + k) * SR_PD_LD + b0 + j], sum);
+            SR_WAVE_FENCE();
+            if (lane < j) S[(b0 + lane) * SR_PD_LD + b0 + j] = -sum * invjj;
+            else if (lane == j) S[(b0 + j) * SR_PD_LD + b0 + j] = invjj;
+            SR_WAVE_FENCE();
         }
-        double sum = s0 + s1;                       // all 64 lanes take part in the shuffles
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        sum += __shfl_xor(sum, 4);
-        if (part == 0) {
-            if (row < j) S[row * SR_PD_LD + j] = -sum * invjj;
-            else if (row == j) S[j * SR_PD_LD + j] = invjj;
+    }
+    __syncthreads();
+    // (b) combine at block sizes 16, 32, 64
+    for (int n = 16; n < SR_NB; n *= 2) {
+        const int tpb = n / 16;                          // 16-tiles per block edge
+        const int items = (SR_NB / (2 * n)) * tpb * tpb;
+        // T^T = (A^-1 B)^T into the lower-left block
+        for (int e = wave; e < items; e += SR_PD_THREADS / 64) {
+            const int pq = e / (tpb * tpb), t2 = e % (tpb * tpb);
+            const int a0 = 2 * n * pq, m0 = 16 * (t2 / tpb), n0 = 16 * (t2 % tpb);
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kb4 = m0 / 4; kb4 < n / 4; ++kb4) {     // A^-1 is upper triangular: k >= m
+                const int k = 4 * kb4 + lk, m = m0 + ln;
+                const double af = (k >= m) ? S[(a0 + m) * SR_PD_LD + a0 + k] : 0.0;
+                const double bf = S[(a0 + k) * SR_PD_LD + a0 + n + n0 + ln];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[(a0 + n + n0 + ln) * SR_PD_LD + a0 + m0 + lk + 4 * q] = acc[q];
+        }
+        __syncthreads();
+        // X12 = -T C^-1 into the upper-right block
+        for (int e = wave; e < items; e += SR_PD_THREADS / 64) {
+            const int pq = e / (tpb * tpb), t2 = e % (tpb * tpb);
+            const int a0 = 2 * n * pq, m0 = 16 * (t2 / tpb), c0 = 16 * (t2 % tpb);
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kb4 = 0; kb4 < (c0 + 16) / 4; ++kb4) {  // C^-1 is upper triangular: k <= c
+                const int k = 4 * kb4 + lk, c = c0 + ln;
+                const double af = S[(a0 + n + k) * SR_PD_LD + a0 + m0 + ln];
+                const double bf = (k <= c) ? S[(a0 + n + k) * SR_PD_LD + a0 + n + c] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+            }
+            // every wavefront must have read T and C^-1 of this block pair before X12 lands on top of B:
+            // B is only read by the first product (barrier above), so the write is safe here
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[(a0 + m0 + lk + 4 * q) * SR_PD_LD + a0 + n + c0 + ln] = -acc[q];
         }
         __syncthreads();
     }
     for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
         const int r = idx >> 7, c = idx & 127;
-        wt_diag[(long)r * ldw + c] = S[r * SR_PD_LD + c];    // U_kk^-1   (upper)
-        w_diag[(long)r * ldw + c] = S[c * SR_PD_LD + r];     // U_kk^-T   (lower)
+        wt_diag[(long)r * ldw + c] = (c >= r) ? S[r * SR_PD_LD + c] : 0.0;    // U_kk^-1   (upper)
+        w_diag[(long)r * ldw + c] = (r >= c) ? S[c * SR_PD_LD + r] : 0.0;     // U_kk^-T   (lower)
     }
 }
 
