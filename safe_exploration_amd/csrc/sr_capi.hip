@@ -572,6 +572,15 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
+    if (h->small_path == 1 && sr_gp_small_wanted(h->Np, 1, h->D, h->general != 0)) {
+        // small model: everything in one launch (sr_small.hip, LIN mode)
+        sr_kstar_args ka{};
+        ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+        ka.xa = x; ka.lda = h->D; ka.na = h->D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
+        ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = 1; ka.T = 1; ka.Tp = 1;
+        sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
+        return sr_launch_gp_small_lin(ka, h->Wt, mu, var, jac_mu, jac_var, hess_mu, s);
+    }
     if (!h->lin_v) SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np));
     if (!h->lin_g) SR_TRY(dev_alloc(&h->lin_g, (size_t)h->n_out * h->Np));
     h->force_stream = 1;

@@ -154,6 +154,8 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 bool sr_gp_small_wanted(int Np, long T, int D, bool general);
 int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
                        hipStream_t s);
+int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac_mu,
+                           double* jac_var, double* hess_mu, hipStream_t s);
 
 // part[d][rb][t] = sum_{i in row block rb} ( sum_k Wt[d][k][i] Ks[d][k][t] )^2
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,

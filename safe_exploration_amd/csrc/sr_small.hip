@@ -24,10 +24,17 @@
 #define SR_FQ 16         // queries per workgroup == N of the MFMA tile
 typedef double sr_d4 __attribute__((ext_vector_type(4)));
 
-template <int NP, int DT>
+// LIN: single query with second-order outputs (sr_gp_linearize).  The 16 MFMA columns then carry
+// [k*, dk*/dx_1 .. dk*/dx_D] instead of 16 queries (dk*_i/dx_j = k*_i (z_ij - x_j)/l_j^2):
+//   R[c][:] = sum_i col_c[i] M[i][:]   ->  mu = R[0][0],  d mu/dx_j = R[1+j][0],
+//                                          d2 mu/dx_j dx_l = (R[1+j][1+l] - x_l/l_l R[1+j][0])/l_l - delta_jl mu/l_j^2
+//   V_c = U^-T col_c                   ->  var = sf2 - V_0.V_0,  d var/dx_j = -2 V_j.V_0
+// -- the same two phases, no second pass over U^-1.
+template <int NP, int DT, bool LIN>
 __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, const double* __restrict__ Wt,
                                                            double* __restrict__ mu, double* __restrict__ var,
-                                                           double* __restrict__ jac) {
+                                                           double* __restrict__ jac, double* __restrict__ jac_var,
+                                                           double* __restrict__ hess) {
     constexpr int NSTRIP = NP / 16;          // 16-column strips of U^-1
     constexpr int NSPLIT = 32 / NSTRIP;      // wavefronts sharing one strip pair (k range cut into NSPLIT parts)
     constexpr int RPW = NP / 16;             // training rows per wavefront in phase A
@@ -48,7 +55,8 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 
     const int pr = wave / NSPLIT, h = wave % NSPLIT;      // phase-B work: part h of strips pr and NSTRIP-1-pr
     const double sf2 = a.sf2[d];
-    const bool live = t0 + ln < a.T;
+    const int qt = LIN ? 0 : ln;                          // query index of this lane's column
+    const bool live = LIN ? true : (t0 + ln < a.T);
 
     // ---- phase A ------------------------------------------------------------------------------
     {
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         for (int j = 0; j < DT; ++j) {
             il[j] = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
             xs[j] = 0.0;
-            if (live && j < a.D) xs[j] = (j < a.na) ? a.xa[(t0 + ln) * a.lda + j] : a.xb[(t0 + ln) * a.ldb + (j - a.na)];
+            if (live && j < a.D) xs[j] = (j < a.na) ? a.xa[(t0 + qt) * a.lda + j] : a.xb[(t0 + qt) * a.ldb + (j - a.na)];
         }
 #pragma unroll
         for (int st = 0; st < RPW / 4; ++st) {
@@ -77,15 +85,19 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 #pragma unroll
         for (int st = 0; st < RPW / 4; ++st) {
             const int i = wave * RPW + 4 * st + lk;
-            double r2 = 0.0, bfrag = (ln == 0) ? al[st] : 0.0;
+            double r2 = 0.0, bfrag = (ln == 0) ? al[st] : 0.0, scale = (ln == 0) ? 1.0 : 0.0;
 #pragma unroll
             for (int j = 0; j < DT; ++j) {
                 const double zs = zv[st][j] * il[j];
                 const double df = xs[j] - zs;
                 r2 = fma(df, df, r2);
-                if (ln == j + 1) bfrag = al[st] * zs;
+                if (ln == j + 1) {
+                    bfrag = al[st] * zs;
+                    scale = -df * il[j];                    // (z_j - x_j) / l_j^2
+                }
             }
-            const double k = (i >= off && live) ? sf2 * exp(-0.5 * r2) : 0.0;
+            double k = (i >= off && live) ? sf2 * exp(-0.5 * r2) : 0.0;
+            if (LIN) k *= scale;                            // column c: k* (c = 0), dk*/dx_{c-1}, 0 beyond D
             ks[i][ln] = k;
             accA = __builtin_amdgcn_mfma_f64_16x16x4f64(k, bfrag, accA, 0, 0, 0);
         }
@@ -147,7 +159,18 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
     __syncthreads();
 
     // ---- mean / mean-Jacobian out (R is complete since the barrier above) ----------------------
-    if (tid < SR_FQ * (DT + 1)) {
+    if (LIN) {
+        const double m = Rs[0][0];
+        if (tid == 0) mu[d] = m;
+        if (tid < a.D) jac[d * a.D + tid] = Rs[1 + tid][0];
+        if (tid < a.D * a.D) {
+            const int j = min(tid / a.D, tid % a.D), l = max(tid / a.D, tid % a.D);
+            const double ilj = 1.0 / a.ls[d * a.D + j], ill = 1.0 / a.ls[d * a.D + l];
+            double hv = (Rs[1 + j][1 + l] - xq[0][l] * Rs[1 + j][0]) * ill;
+            if (j == l) hv -= m * ilj * ilj;
+            hess[(long)d * a.D * a.D + tid] = hv;
+        }
+    } else if (tid < SR_FQ * (DT + 1)) {
         const int t = tid / (DT + 1), j = tid % (DT + 1);
         if (t0 + t < a.T) {
             const double m = Rs[t][0];
@@ -168,7 +191,8 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
                 double v = accB[which][r];
 #pragma unroll
                 for (int hh = 0; hh < NSPLIT - 1; ++hh) v += pB[hh][sidx][r * 64 + lane];
-                q = fma(v, v, q);
+                const double w = LIN ? __shfl(v, lane & 48) : v;     // LIN: dot with column 0 of the same row
+                q = fma(v, w, q);
             }
             q += __shfl_xor(q, 16);
             q += __shfl_xor(q, 32);
@@ -176,7 +200,20 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         }
     }
     __syncthreads();
-    if (tid < SR_FQ && t0 + tid < a.T) {
+    if (LIN) {
+        if (tid <= a.D) {
+            double qn = 0.0;
+#pragma unroll
+            for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += redC[sidx][tid];
+            if (tid == 0) {
+                double v = sf2 - qn;
+                if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+                var[d] = v;
+            } else {
+                jac_var[d * a.D + tid - 1] = -2.0 * qn;
+            }
+        }
+    } else if (tid < SR_FQ && t0 + tid < a.T) {
         double qn = 0.0;
 #pragma unroll
         for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += redC[sidx][tid];
@@ -192,9 +229,19 @@ bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
 
 template <int NP>
 static int launch_small_np(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
-                           hipStream_t s) {
+                           double* jac_var, double* hess, hipStream_t s) {
+    if (hess) {                                            // single query with second-order outputs
+        dim3 grid(1, a.n_out);
+#define SR_SMALL_LIN(DT) hipLaunchKernelGGL((sr_gp_small_kernel<NP, DT, true>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac, jac_var, hess)
+        if (a.D <= 3) SR_SMALL_LIN(3);
+        else if (a.D <= 5) SR_SMALL_LIN(5);
+        else SR_SMALL_LIN(8);
+#undef SR_SMALL_LIN
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
     dim3 grid((unsigned)((a.T + SR_FQ - 1) / SR_FQ), a.n_out);
-#define SR_SMALL_CASE(DT) hipLaunchKernelGGL((sr_gp_small_kernel<NP, DT>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac)
+#define SR_SMALL_CASE(DT) hipLaunchKernelGGL((sr_gp_small_kernel<NP, DT, false>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac, nullptr, nullptr)
     if (a.D <= 3) SR_SMALL_CASE(3);
     else if (a.D <= 5) SR_SMALL_CASE(5);
     else SR_SMALL_CASE(8);
@@ -205,8 +252,16 @@ static int launch_small_np(const sr_kstar_args& a, const double* Wt, double* mu,
 
 int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
                        hipStream_t s) {
-    if (a.Np == 128) return launch_small_np<128>(a, Wt, mu, var, jac, s);
-    if (a.Np == 256) return launch_small_np<256>(a, Wt, mu, var, jac, s);
+    if (a.Np == 128) return launch_small_np<128>(a, Wt, mu, var, jac, nullptr, nullptr, s);
+    if (a.Np == 256) return launch_small_np<256>(a, Wt, mu, var, jac, nullptr, nullptr, s);
+    sr_set_error("gp_small: Np=%d not supported", a.Np);
+    return SR_EUNSUPPORTED;
+}
+
+int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac_mu,
+                           double* jac_var, double* hess_mu, hipStream_t s) {
+    if (a.Np == 128) return launch_small_np<128>(a, Wt, mu, var, jac_mu, jac_var, hess_mu, s);
+    if (a.Np == 256) return launch_small_np<256>(a, Wt, mu, var, jac_mu, jac_var, hess_mu, s);
     sr_set_error("gp_small: Np=%d not supported", a.Np);
     return SR_EUNSUPPORTED;
 }

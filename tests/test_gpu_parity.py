@@ -934,3 +934,33 @@ def test_refit_reuses_the_handle_and_deep_copies_keep_their_model():
     rmu, _ = orc.gp_predict(x, np.vstack((a["Z"], b["Z"][:20])), both[0], both[1], a["lengthscale"], a["signal_var"],
                             False)
     np.testing.assert_allclose(gp.predict(x)[0], rmu, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,n_s,n_u", [(1, 2, 1), (60, 2, 1), (128, 4, 1), (200, 2, 1), (256, 3, 2), (200, 4, 4)])
+def test_fused_small_model_linearize(N, n_s, n_u):
+    """Np <= 256: linearize_predict(jacobians=True) is ONE launch (the MFMA columns carry [k*, dk*/dx]); checked
+    against the oracle's closed forms and against the multi-kernel route of the same library."""
+    from safe_exploration_amd import _lib
+    syn = orc.make_synthetic(4000 + N + n_u, N, n_s, n_u, 3)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    x = np.hstack((syn["p"], syn["k_ff"]))[1]
+    gp.prof_reset(); gp.prof_enable(True)
+    mu, var, jm, jv, hm = gp.linearize_predict(x[None, :n_s], x[None, n_s:], True)
+    gp.prof_enable(False)
+    assert gp.prof_get(_lib.K_SMALL)[1] == 1 and gp.prof_get(_lib.K_KSTAR)[1] == 0
+    rmu, rvar, rjac = orc.gp_predict(x[None], om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], True)
+    rjv, rhm = orc.gp_linearize_extras(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"])
+    at = max(mu_atol(om), 1e-12)
+    np.testing.assert_allclose(mu[:, 0], rmu[0], rtol=1e-9, atol=at)
+    np.testing.assert_allclose(var[:, 0], rvar[0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(jm, rjac[0], rtol=1e-9, atol=10 * at)
+    np.testing.assert_allclose(jv, rjv, rtol=1e-7, atol=1e-9 * float(np.max(syn["signal_var"])))
+    np.testing.assert_allclose(hm, rhm, rtol=1e-8, atol=100 * at)
+    np.testing.assert_array_equal(hm, np.swapaxes(hm, 1, 2))
+    gp.set_small_path(2)
+    out2 = gp.linearize_predict(x[None, :n_s], x[None, n_s:], True)
+    gp.set_small_path(1)
+    for a_, b_, tol in zip((mu, var, jm, jv, hm), out2, (at, 1e-12, 10 * at, 1e-10, 100 * at)):
+        np.testing.assert_allclose(a_, b_, rtol=1e-9, atol=tol)
