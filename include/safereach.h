@@ -39,7 +39,7 @@ typedef struct sr_gp* sr_gp_t;
 #define SR_K_FINAL     5
 #define SR_K_ELL       6   /* ellipsoid propagate/sum                                  */
 #define SR_K_TRINV     7   /* GEMMs of the blocked triangular inversion W = U^-T            */
-#define SR_K_SMALL     8   /* one-launch posterior of a small model (Np <= 256, T <= 1024)  */
+#define SR_K_SMALL     8   /* one-launch posterior of a small model (Np <= 512, T <= 1024)  */
 #define SR_K_COUNT     9
 
 int         sr_version(void);
@@ -210,7 +210,7 @@ int sr_gp_set_var_group(sr_gp_t h, int group);
 /* tile staging of the variance kernel: 0 = register-staged (global->VGPR->LDS), 1 = LDS-DMA
  * (global_load_lds_dwordx4, default).  Same results bit for bit; a measurement knob. */
 int sr_gp_set_var_variant(sr_gp_t h, int variant);
-/* latency paths instead of the plain MFMA tiles: one-launch pass for small models (Np <= 256, T <= 1024),
+/* latency paths instead of the plain MFMA tiles: one-launch pass for small models (Np <= 512, T <= 1024),
  * HBM-bound streaming of U^-1 for batches of <= 16 queries, 64 x 64 tiles, split-K.  on = 1 (default) all
  * of them, 2 all but the one-launch pass, 0 none; an A/B measurement knob.  Results agree to rounding. */
 int sr_gp_set_small_path(sr_gp_t h, int on);

@@ -1,6 +1,6 @@
 // sr_small.hip -- K0: the whole GP posterior of a SMALL model in one launch.
 //
-// Regime: the reference's own experiments (25 .. 150 inducing points; Np <= 256 here)
+// Regime: the reference's own experiments (25 .. 150 inducing points; Np <= 512 here)
 // driven with one query (CasADi/IPOPT callback) up to ~1000 candidate states per step.  There the
 // three-kernel pass K1 -> K2m -> K3 is three dependent launches of tiny grids, each bound by its own chain
 // of global-load round trips (6 + 13 + 5 us at N = 200); nothing is bound by flops or bytes.
@@ -36,14 +36,18 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
                                                            double* __restrict__ jac, double* __restrict__ jac_var,
                                                            double* __restrict__ hess) {
     constexpr int NSTRIP = NP / 16;          // 16-column strips of U^-1
-    constexpr int NSPLIT = 32 / NSTRIP;      // wavefronts sharing one strip pair (k range cut into NSPLIT parts)
+    constexpr int NPAIR = NSTRIP / 2;        // strips s and NSTRIP-1-s are paired (equal work per pair)
+    constexpr int NSPLIT = (16 / NPAIR) > 0 ? 16 / NPAIR : 1;   // wavefronts sharing one pair (k range cut in parts)
     constexpr int RPW = NP / 16;             // training rows per wavefront in phase A
+    constexpr int KSA = RPW / 4;             // phase-A k-steps per wavefront
+    constexpr int HC = KSA <= 4 ? KSA : KSA / 2;     // k-steps whose global loads are hoisted together
     static_assert(DT + 1 <= 16, "the mean/Jacobian right-hand side must fit the 16 MFMA columns");
+    static_assert(NP % 128 == 0 && NP <= 512 && KSA % HC == 0, "Np in {128, 256, 384, 512}");
     __shared__ double ks[NP][SR_FQ];                     // k*[k][t]
     __shared__ double xq[SR_FQ][DT];                     // queries of this tile, scaled by 1/lengthscale
     __shared__ double pA[16][256];                       // phase A: per-wavefront partial R (accumulator layout)
     __shared__ double Rs[SR_FQ][16];                     // R[t][c]
-    __shared__ double pB[NSPLIT - 1][NSTRIP][256];       // phase B: partial V tiles of the parts h > 0
+    __shared__ double pB[NSPLIT > 1 ? NSPLIT - 1 : 1][NSPLIT > 1 ? NSTRIP : 1][256];   // phase B: partial V tiles, parts h > 0
     __shared__ double redC[NSTRIP][SR_FQ];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -60,21 +64,13 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 
     // ---- phase A ------------------------------------------------------------------------------
     {
-        // all global loads of the phase first (one round trip), then the arithmetic
-        double xs[DT], il[DT], zv[RPW / 4][DT], al[RPW / 4];
+        // global loads of HC k-steps first (one round trip), then the arithmetic
+        double xs[DT], il[DT];
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
             il[j] = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
             xs[j] = 0.0;
             if (live && j < a.D) xs[j] = (j < a.na) ? a.xa[(t0 + qt) * a.lda + j] : a.xb[(t0 + qt) * a.ldb + (j - a.na)];
-        }
-#pragma unroll
-        for (int st = 0; st < RPW / 4; ++st) {
-            const int i = wave * RPW + 4 * st + lk;
-            const bool valid = i >= off;
-            al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
-#pragma unroll
-            for (int j = 0; j < DT; ++j) zv[st][j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
         }
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
@@ -83,23 +79,35 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         }
         sr_d4 accA = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int st = 0; st < RPW / 4; ++st) {
-            const int i = wave * RPW + 4 * st + lk;
-            double r2 = 0.0, bfrag = (ln == 0) ? al[st] : 0.0, scale = (ln == 0) ? 1.0 : 0.0;
+        for (int c0 = 0; c0 < KSA; c0 += HC) {
+            double zv[HC][DT], al[HC];
 #pragma unroll
-            for (int j = 0; j < DT; ++j) {
-                const double zs = zv[st][j] * il[j];
-                const double df = xs[j] - zs;
-                r2 = fma(df, df, r2);
-                if (ln == j + 1) {
-                    bfrag = al[st] * zs;
-                    scale = -df * il[j];                    // (z_j - x_j) / l_j^2
-                }
+            for (int st = 0; st < HC; ++st) {
+                const int i = wave * RPW + 4 * (c0 + st) + lk;
+                const bool valid = i >= off;
+                al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
+#pragma unroll
+                for (int j = 0; j < DT; ++j) zv[st][j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
             }
-            double k = (i >= off && live) ? sf2 * exp(-0.5 * r2) : 0.0;
-            if (LIN) k *= scale;                            // column c: k* (c = 0), dk*/dx_{c-1}, 0 beyond D
-            ks[i][ln] = k;
-            accA = __builtin_amdgcn_mfma_f64_16x16x4f64(k, bfrag, accA, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < HC; ++st) {
+                const int i = wave * RPW + 4 * (c0 + st) + lk;
+                double r2 = 0.0, bfrag = (ln == 0) ? al[st] : 0.0, scale = (ln == 0) ? 1.0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    const double zs = zv[st][j] * il[j];
+                    const double df = xs[j] - zs;
+                    r2 = fma(df, df, r2);
+                    if (ln == j + 1) {
+                        bfrag = al[st] * zs;
+                        scale = -df * il[j];                    // (z_j - x_j) / l_j^2
+                    }
+                }
+                double k = (i >= off && live) ? sf2 * exp(-0.5 * r2) : 0.0;
+                if (LIN) k *= scale;                            // column c: k* (c = 0), dk*/dx_{c-1}, 0 beyond D
+                ks[i][ln] = k;
+                accA = __builtin_amdgcn_mfma_f64_16x16x4f64(k, bfrag, accA, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) pA[wave][r * 64 + lane] = accA[r];
@@ -119,8 +127,11 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 
     // ---- phase B ------------------------------------------------------------------------------
     sr_d4 accB[2];
+    accB[0] = sr_d4{0.0, 0.0, 0.0, 0.0};
+    accB[1] = sr_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
+        if (pr >= NPAIR) break;                                   // Np = 384: 12 pairs, 4 wavefronts idle here
         const int sidx = which ? NSTRIP - 1 - pr : pr;
         const int chunk = 4 * (sidx + 1) / NSPLIT;               // k-steps (of 4 rows) of this part
         int st = h * chunk;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
         }
         accB[which] = acc;
-        if (h > 0) {
+        if (NSPLIT > 1 && h > 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) pB[h - 1][sidx][r * 64 + lane] = acc[r];
         }
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
     }
 
     // ---- phase C ------------------------------------------------------------------------------
-    if (h == 0) {
+    if (h == 0 && pr < NPAIR) {
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             const int sidx = which ? NSTRIP - 1 - pr : pr;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
             for (int r = 0; r < 4; ++r) {
                 double v = accB[which][r];
 #pragma unroll
-                for (int hh = 0; hh < NSPLIT - 1; ++hh) v += pB[hh][sidx][r * 64 + lane];
+                for (int hh = 0; hh < NSPLIT - 1; ++hh) v += pB[hh][NSPLIT > 1 ? sidx : 0][r * 64 + lane];
                 const double w = LIN ? __shfl(v, lane & 48) : v;     // LIN: dot with column 0 of the same row
                 q = fma(v, w, q);
             }
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 }
 
 bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
-    return !general && (Np == 128 || Np == 256) && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
+    return !general && Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
 }
 
 template <int NP>
@@ -254,6 +265,8 @@ int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, dou
                        hipStream_t s) {
     if (a.Np == 128) return launch_small_np<128>(a, Wt, mu, var, jac, nullptr, nullptr, s);
     if (a.Np == 256) return launch_small_np<256>(a, Wt, mu, var, jac, nullptr, nullptr, s);
+    if (a.Np == 384) return launch_small_np<384>(a, Wt, mu, var, jac, nullptr, nullptr, s);
+    if (a.Np == 512) return launch_small_np<512>(a, Wt, mu, var, jac, nullptr, nullptr, s);
     sr_set_error("gp_small: Np=%d not supported", a.Np);
     return SR_EUNSUPPORTED;
 }
@@ -262,6 +275,8 @@ int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu,
                            double* jac_var, double* hess_mu, hipStream_t s) {
     if (a.Np == 128) return launch_small_np<128>(a, Wt, mu, var, jac_mu, jac_var, hess_mu, s);
     if (a.Np == 256) return launch_small_np<256>(a, Wt, mu, var, jac_mu, jac_var, hess_mu, s);
+    if (a.Np == 384) return launch_small_np<384>(a, Wt, mu, var, jac_mu, jac_var, hess_mu, s);
+    if (a.Np == 512) return launch_small_np<512>(a, Wt, mu, var, jac_mu, jac_var, hess_mu, s);
     sr_set_error("gp_small: Np=%d not supported", a.Np);
     return SR_EUNSUPPORTED;
 }

@@ -780,9 +780,10 @@ def test_sample_from_gp_and_information_gain():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,n_s,n_u,T", [(1, 2, 1, 3), (2, 2, 1, 8), (100, 2, 1, 1), (128, 4, 1, 9), (129, 2, 1, 17),
-                                         (200, 4, 1, 300), (256, 2, 1, 1024), (150, 3, 2, 64)])
+                                         (200, 4, 1, 300), (256, 2, 1, 1024), (150, 3, 2, 64), (257, 2, 1, 33),
+                                         (384, 4, 1, 16), (400, 2, 1, 250), (512, 3, 2, 17)])
 def test_fused_small_model_pass(N, n_s, n_u, T):
-    """K0 (sr_small.hip): Np <= 256 and T <= 1024 evaluate the whole posterior in one launch.  Checked against
+    """K0 (sr_small.hip): Np <= 512 and T <= 1024 evaluate the whole posterior in one launch.  Checked against
     the oracle, against the three-kernel pass of the same library, and that it is the path that ran."""
     from safe_exploration_amd import _lib
     syn = orc.make_synthetic(1000 + 3 * N + T, N, n_s, n_u, T)
@@ -937,9 +938,10 @@ def test_refit_reuses_the_handle_and_deep_copies_keep_their_model():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,n_s,n_u", [(1, 2, 1), (60, 2, 1), (128, 4, 1), (200, 2, 1), (256, 3, 2), (200, 4, 4)])
+@pytest.mark.parametrize("N,n_s,n_u", [(1, 2, 1), (60, 2, 1), (128, 4, 1), (200, 2, 1), (256, 3, 2), (200, 4, 4),
+                                       (300, 2, 1), (384, 4, 1), (500, 2, 1)])
 def test_fused_small_model_linearize(N, n_s, n_u):
-    """Np <= 256: linearize_predict(jacobians=True) is ONE launch (the MFMA columns carry [k*, dk*/dx]); checked
+    """Np <= 512: linearize_predict(jacobians=True) is ONE launch (the MFMA columns carry [k*, dk*/dx]); checked
     against the oracle's closed forms and against the multi-kernel route of the same library."""
     from safe_exploration_amd import _lib
     syn = orc.make_synthetic(4000 + N + n_u, N, n_s, n_u, 3)
