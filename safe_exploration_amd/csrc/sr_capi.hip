@@ -480,6 +480,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         // small model, few queries: one launch, no workspace (sr_small.hip)
         sr_kstar_args ka{};
         ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+        ka.kp = h->general ? h->kp : nullptr;
         ka.xa = xa; ka.lda = lda; ka.na = na; ka.xb = xb; ka.ldb = ldb; ka.nb = nb;
         ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = 1;
         ka.T = Tc; ka.Tp = Tc;
@@ -572,8 +573,8 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
-    if (h->small_path == 1 && sr_gp_small_wanted(h->Np, 1, h->D, h->general != 0)) {
-        // small model: everything in one launch (sr_small.hip, LIN mode)
+    if (h->small_path == 1 && !h->general && sr_gp_small_wanted(h->Np, 1, h->D, false)) {
+        // small ARD-RBF model: everything in one launch (sr_small.hip, LIN mode)
         sr_kstar_args ka{};
         ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
         ka.xa = x; ka.lda = h->D; ka.na = h->D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;

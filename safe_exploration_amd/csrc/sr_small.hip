@@ -24,6 +24,78 @@
 #define SR_FQ 16         // queries per workgroup == N of the MFMA tile
 typedef double sr_d4 __attribute__((ext_vector_type(4)));
 
+// Phases B and C, shared by the kernels below: V = U^-T [columns of ks] on the MFMA tile, then per column c
+// redC[strip][c] = sum_{rows of the strip} V[i][c] * (DOT0 ? V[i][0] : V[i][c]).  Ends with a barrier.
+template <int NP, bool DOT0>
+__device__ __forceinline__ void sr_small_contract(const double* __restrict__ Wd, const double (*ks)[SR_FQ],
+                                                  double* pB, double (*redC)[SR_FQ], int wave, int lane) {
+    constexpr int NSTRIP = NP / 16, NPAIR = NSTRIP / 2;
+    constexpr int NSPLIT = (16 / NPAIR) > 0 ? 16 / NPAIR : 1;
+    const int lk = lane >> 4, ln = lane & 15;
+    const int pr = wave / NSPLIT, h = wave % NSPLIT;      // part h of strips pr and NSTRIP-1-pr
+    sr_d4 accB[2];
+    accB[0] = sr_d4{0.0, 0.0, 0.0, 0.0};
+    accB[1] = sr_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (pr >= NPAIR) break;                                   // Np = 384: 12 pairs, 4 wavefronts idle here
+        const int sidx = which ? NSTRIP - 1 - pr : pr;
+        const int chunk = 4 * (sidx + 1) / NSPLIT;               // k-steps (of 4 rows) of this part
+        int st = h * chunk;
+        const int st_end = st + chunk;
+        const double* wcol = Wd + (long)lk * NP + 16 * sidx + ln;
+        sr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (; st + 16 <= st_end; st += 16) {
+            double af[16], bf[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) af[u] = wcol[(long)(4 * (st + u)) * NP];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) bf[u] = ks[4 * (st + u) + lk][ln];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
+        }
+        for (; st + 4 <= st_end; st += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) af[u] = wcol[(long)(4 * (st + u)) * NP];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bf[u] = ks[4 * (st + u) + lk][ln];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
+        }
+        for (; st < st_end; ++st) {
+            const double af = wcol[(long)(4 * st) * NP];
+            const double bf = ks[4 * st + lk][ln];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+        }
+        accB[which] = acc;
+        if (NSPLIT > 1 && h > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pB[((h - 1) * NSTRIP + sidx) * 256 + r * 64 + lane] = acc[r];
+        }
+    }
+    __syncthreads();
+    if (h == 0 && pr < NPAIR) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int sidx = which ? NSTRIP - 1 - pr : pr;
+            double q = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = accB[which][r];
+#pragma unroll
+                for (int hh = 0; hh < NSPLIT - 1; ++hh) v += pB[(hh * NSTRIP + sidx) * 256 + r * 64 + lane];
+                const double w = DOT0 ? __shfl(v, lane & 48) : v;    // DOT0: dot with column 0 of the same row
+                q = fma(v, w, q);
+            }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (lane < 16) redC[sidx][lane] = q;
+        }
+    }
+    __syncthreads();
+}
+
 // LIN: single query with second-order outputs (sr_gp_linearize).  The 16 MFMA columns then carry
 // [k*, dk*/dx_1 .. dk*/dx_D] instead of 16 queries (dk*_i/dx_j = k*_i (z_ij - x_j)/l_j^2):
 //   R[c][:] = sum_i col_c[i] M[i][:]   ->  mu = R[0][0],  d mu/dx_j = R[1+j][0],
@@ -57,7 +129,6 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
     const long t0 = (long)blockIdx.x * SR_FQ;
     const int off = NP - a.N;                             // front padding
 
-    const int pr = wave / NSPLIT, h = wave % NSPLIT;      // phase-B work: part h of strips pr and NSTRIP-1-pr
     const double sf2 = a.sf2[d];
     const int qt = LIN ? 0 : ln;                          // query index of this lane's column
     const bool live = LIN ? true : (t0 + ln < a.T);
@@ -125,51 +196,10 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         Rs[(l2 >> 4) + 4 * r][l2 & 15] = v;
     }
 
-    // ---- phase B ------------------------------------------------------------------------------
-    sr_d4 accB[2];
-    accB[0] = sr_d4{0.0, 0.0, 0.0, 0.0};
-    accB[1] = sr_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        if (pr >= NPAIR) break;                                   // Np = 384: 12 pairs, 4 wavefronts idle here
-        const int sidx = which ? NSTRIP - 1 - pr : pr;
-        const int chunk = 4 * (sidx + 1) / NSPLIT;               // k-steps (of 4 rows) of this part
-        int st = h * chunk;
-        const int st_end = st + chunk;
-        const double* wcol = Wt + (long)d * NP * NP + (long)lk * NP + 16 * sidx + ln;
-        sr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        for (; st + 16 <= st_end; st += 16) {
-            double af[16], bf[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) af[u] = wcol[(long)(4 * (st + u)) * NP];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) bf[u] = ks[4 * (st + u) + lk][ln];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
-        }
-        for (; st + 4 <= st_end; st += 4) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) af[u] = wcol[(long)(4 * (st + u)) * NP];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) bf[u] = ks[4 * (st + u) + lk][ln];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
-        }
-        for (; st < st_end; ++st) {
-            const double af = wcol[(long)(4 * st) * NP];
-            const double bf = ks[4 * st + lk][ln];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
-        }
-        accB[which] = acc;
-        if (NSPLIT > 1 && h > 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pB[h - 1][sidx][r * 64 + lane] = acc[r];
-        }
-    }
-    __syncthreads();
+    // ---- phases B, C ---------------------------------------------------------------------------
+    sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, ks, &pB[0][0][0], redC, wave, lane);
 
-    // ---- mean / mean-Jacobian out (R is complete since the barrier above) ----------------------
+    // ---- outputs ----------------------------------------------------------------------------------
     if (LIN) {
         const double m = Rs[0][0];
         if (tid == 0) mu[d] = m;
@@ -191,26 +221,6 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         }
     }
 
-    // ---- phase C ------------------------------------------------------------------------------
-    if (h == 0 && pr < NPAIR) {
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const int sidx = which ? NSTRIP - 1 - pr : pr;
-            double q = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = accB[which][r];
-#pragma unroll
-                for (int hh = 0; hh < NSPLIT - 1; ++hh) v += pB[hh][NSPLIT > 1 ? sidx : 0][r * 64 + lane];
-                const double w = LIN ? __shfl(v, lane & 48) : v;     // LIN: dot with column 0 of the same row
-                q = fma(v, w, q);
-            }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
-            if (lane < 16) redC[sidx][lane] = q;
-        }
-    }
-    __syncthreads();
     if (LIN) {
         if (tid <= a.D) {
             double qn = 0.0;
@@ -234,8 +244,139 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
     }
 }
 
+// General kernel family (Matern-5/2, linear x stationary + linear: sr_common.h; the kernels of the reference's
+// journal experiments) through the same one-launch pass.  k = c v kappa + l with c = c0 + sum a x z, l = sum b x z:
+//   dk/dx_j = a_j z_j v kappa + c v g s_j^2 (x_j - z_j) + b_j z_j ,  g = kappa'(r)/r
+// so the mean-Jacobian needs four products against M[i] = alpha_i [1, z_i] instead of one:
+//   Rk = k^T M (mu), Rq = kappa^T M, Rg = (c g)^T M, R1 = 1^T M:
+//   d mu/dx_j = a_j v Rq[t][1+j] + v s_j^2 (x_tj Rg[t][0] - Rg[t][1+j]) + b_j R1[t][1+j]
+// and the prior variance is k(x,x) = (c0 + sum a x^2) v + sum b x^2.
+template <int NP, int DT>
+__global__ __launch_bounds__(1024) void sr_gp_small_general_kernel(sr_kstar_args a, const double* __restrict__ Wt,
+                                                                   double* __restrict__ mu,
+                                                                   double* __restrict__ var,
+                                                                   double* __restrict__ jac) {
+    constexpr int NSTRIP = NP / 16, NPAIR = NSTRIP / 2;
+    constexpr int NSPLIT = (16 / NPAIR) > 0 ? 16 / NPAIR : 1;
+    constexpr int RPW = NP / 16, KSA = RPW / 4;
+    __shared__ double ks[NP][SR_FQ];
+    __shared__ double xq[SR_FQ][DT];                     // queries of this tile (unscaled)
+    __shared__ double pA[16][256];
+    __shared__ double Rs[4][SR_FQ][16];                  // Rk, Rq, Rg, R1
+    __shared__ double pB[(NSPLIT > 1 ? NSPLIT - 1 : 1) * (NSPLIT > 1 ? NSTRIP : 1) * 256];
+    __shared__ double redC[NSTRIP][SR_FQ];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
+    const int d = blockIdx.y;
+    const long t0 = (long)blockIdx.x * SR_FQ;
+    const int off = NP - a.N;
+    const double* kp = a.kp + (long)d * SR_KP(a.D);
+    const int kind = (int)kp[0];
+    const double vv = kp[1], c0 = kp[2];
+    const bool live = t0 + ln < a.T;
+
+    double x[DT], s2[DT], ax[DT], bx[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        x[j] = 0.0;
+        if (live && j < a.D) x[j] = (j < a.na) ? a.xa[(t0 + ln) * a.lda + j] : a.xb[(t0 + ln) * a.ldb + (j - a.na)];
+        const double sj = (j < a.D) ? kp[3 + j] : 0.0;
+        s2[j] = sj * sj;
+        ax[j] = (j < a.D) ? kp[3 + a.D + j] * x[j] : 0.0;
+        bx[j] = (j < a.D) ? kp[3 + 2 * a.D + j] * x[j] : 0.0;
+    }
+    sr_d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = sr_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < KSA; ++st) {
+        const int i = wave * RPW + 4 * st + lk;
+        const bool valid = i >= off;
+        const double al = valid ? a.alpha[(long)d * NP + i] : 0.0;
+        double r2 = 0.0, la = 0.0, lb = 0.0, bfrag = (ln == 0) ? al : 0.0;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const double z = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
+            const double df = x[j] - z;
+            r2 = fma(df * s2[j], df, r2);
+            la = fma(ax[j], z, la);
+            lb = fma(bx[j], z, lb);
+            if (ln == j + 1) bfrag = al * z;
+        }
+        double kap, g;
+        if (kind == 0) {
+            kap = exp(-0.5 * r2);
+            g = -kap;
+        } else {
+            const double rr = sqrt(r2);
+            const double e = exp(-2.23606797749978969641 * rr);
+            kap = (1.0 + 2.23606797749978969641 * rr + (5.0 / 3.0) * r2) * e;
+            g = -(5.0 / 3.0) * (1.0 + 2.23606797749978969641 * rr) * e;
+        }
+        const bool on = valid && live;
+        const double cc = c0 + la;
+        const double k = on ? fma(cc * vv, kap, lb) : 0.0;
+        ks[i][ln] = k;
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(k, bfrag, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(on ? kap : 0.0, bfrag, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(on ? cc * g : 0.0, bfrag, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(on ? 1.0 : 0.0, bfrag, acc[3], 0, 0, 0);
+    }
+    if (wave == 0 && lk == 0) {
+#pragma unroll
+        for (int j = 0; j < DT; ++j) xq[ln][j] = x[j];
+    }
+    // the four partial products are summed over the wavefronts one after the other through the same buffer
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pA[wave][r * 64 + lane] = acc[q][r];
+        __syncthreads();
+        if (tid < 256) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) v += pA[w][tid];
+            const int l2 = tid & 63, r = tid >> 6;
+            Rs[q][(l2 >> 4) + 4 * r][l2 & 15] = v;
+        }
+        __syncthreads();
+    }
+
+    sr_small_contract<NP, false>(Wt + (long)d * NP * NP, ks, pB, redC, wave, lane);
+
+    if (tid < SR_FQ * (DT + 1)) {
+        const int t = tid / (DT + 1), j = tid % (DT + 1);
+        if (t0 + t < a.T) {
+            if (j == DT) {
+                mu[(t0 + t) * a.n_out + d] = Rs[0][t][0];
+            } else if (jac && j < a.D) {
+                const double sj = kp[3 + j], aj = kp[3 + a.D + j], bj = kp[3 + 2 * a.D + j];
+                jac[((t0 + t) * a.n_out + d) * a.D + j] =
+                    aj * vv * Rs[1][t][1 + j] + vv * sj * sj * (xq[t][j] * Rs[2][t][0] - Rs[2][t][1 + j]) +
+                    bj * Rs[3][t][1 + j];
+            }
+        }
+    }
+    if (tid < SR_FQ && t0 + tid < a.T) {
+        double qn = 0.0;
+#pragma unroll
+        for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += redC[sidx][tid];
+        double kxx = c0 * vv;
+        for (int j = 0; j < a.D; ++j) {
+            const double xv = xq[tid][j];
+            kxx = fma((kp[3 + a.D + j] * vv + kp[3 + 2 * a.D + j]) * xv, xv, kxx);
+        }
+        double v = kxx - qn;
+        if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+        var[(t0 + tid) * a.n_out + d] = v;
+    }
+}
+
 bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
-    return !general && Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
+    (void)general;   // ARD-RBF and the general family both have a one-launch kernel
+    return Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
 }
 
 template <int NP>
@@ -252,6 +393,15 @@ static int launch_small_np(const sr_kstar_args& a, const double* Wt, double* mu,
         return SR_OK;
     }
     dim3 grid((unsigned)((a.T + SR_FQ - 1) / SR_FQ), a.n_out);
+    if (a.kp) {                                            // general kernel family
+#define SR_SMALL_GEN(DT) hipLaunchKernelGGL((sr_gp_small_general_kernel<NP, DT>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac)
+        if (a.D <= 3) SR_SMALL_GEN(3);
+        else if (a.D <= 5) SR_SMALL_GEN(5);
+        else SR_SMALL_GEN(8);
+#undef SR_SMALL_GEN
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
 #define SR_SMALL_CASE(DT) hipLaunchKernelGGL((sr_gp_small_kernel<NP, DT, false>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac, nullptr, nullptr)
     if (a.D <= 3) SR_SMALL_CASE(3);
     else if (a.D <= 5) SR_SMALL_CASE(5);

@@ -966,3 +966,38 @@ def test_fused_small_model_linearize(N, n_s, n_u):
     gp.set_small_path(1)
     for a_, b_, tol in zip((mu, var, jm, jv, hm), out2, (at, 1e-12, 10 * at, 1e-10, 100 * at)):
         np.testing.assert_allclose(a_, b_, rtol=1e-9, atol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kt,N,T", [("mat52", 90, 5), ("lin_mat52", 150, 40), ("lin_rbf", 256, 300), ("mat52", 400, 17),
+                                    ("lin_mat52", 1, 3)])
+def test_fused_small_model_pass_general_kernels(kt, N, T):
+    """the journal experiments' kernels through the one-launch pass (sr_gp_small_general_kernel): against the
+    oracle's per-kernel formulas, finite-difference Jacobians, and the three-kernel route of the same library."""
+    from safe_exploration_amd import SimpleGPModel, _lib
+    rng = np.random.default_rng(900 + N)
+    D = 3
+    Z = rng.uniform(-1, 1, (N, D))
+    Y = rng.standard_normal((N, 2))
+    hyp = [orc.make_hyp(kt, rng, D) for _ in range(2)]
+    noise = np.array([0.02, 0.03])
+    beta, inv_K = orc.gp_fit_k(Z, Y, [kt] * 2, hyp, noise + 1e-5)
+    hh = [dict(h, noise_variance=nv) for h, nv in zip(hyp, noise)]
+    gp = SimpleGPModel(2, 2, 1, kern_types=[kt] * 2, hyp=hh)
+    gp.train(Z, Y, opt_hyp=False)
+    x = rng.uniform(-0.8, 0.8, (T, D))
+    gp.prof_reset(); gp.prof_enable(True)
+    mu, var, jac = gp.predict(x, None, True)
+    gp.prof_enable(False)
+    assert gp.prof_get(_lib.K_SMALL)[1] == 1 and gp.prof_get(_lib.K_VAR)[1] == 0
+    rmu, rvar = orc.gp_predict_k(x, Z, beta, inv_K, [kt] * 2, hyp)
+    scale = max(np.abs(beta).sum(0).max(), 1.0)
+    np.testing.assert_allclose(mu, rmu, rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-8 * max(1.0, float(rvar.max())))
+    np.testing.assert_allclose(jac, orc.gp_mean_jacobian_fd(x, Z, beta, [kt] * 2, hyp), rtol=2e-5, atol=1e-6 * scale)
+    gp.set_small_path(2)
+    mu2, var2, jac2 = gp.predict(x, None, True)
+    gp.set_small_path(1)
+    np.testing.assert_allclose(mu, mu2, rtol=1e-11, atol=1e-13 * scale)
+    np.testing.assert_allclose(jac, jac2, rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(var, var2, rtol=0, atol=1e-11 * max(1.0, float(rvar.max())))
