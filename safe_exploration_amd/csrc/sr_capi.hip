@@ -505,20 +505,13 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     int nrb = h->Np / SR_NB;
     const double* var_part = h->var_part;
     h->last_streamed = 0;
-    if (Tc <= SR_SMALL_T && h->small_path && (h->Np > 1024 || h->force_stream)) {
+    if (Tc <= SR_SMALL_T && h->small_path && (h->Np > SR_STREAM_MIN_NP || h->force_stream)) {
         h->last_streamed = 1;
         // latency regime: stream U^-1 once (HBM-bound) instead of the MFMA tiles
         if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, (int)Tc, s));
         nrb = (h->Np + 255) / 256;
-    } else if (h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out)) {
-        // small model, few tiles: 64 x 64 workgroup tiles shorten the critical path of the tiny grid
-        if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));
-        var_part = h->splitk_part;             // n_out * (Np/64) * Tp <= 2 * 256 * 128 * 16 doubles
-        nrb = h->Np / 64;
-        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var64(h->Wt, h->Ks, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else if (h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) {
         // few query tiles: split the K range so that no workgroup serialises a whole row block
         const long need = sr_var_splitk_ws(h->Np, Tp, h->n_out);
@@ -534,6 +527,13 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         nrb = 4 * (h->Np / SR_NB);
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_splitk(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
+    } else if (h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out)) {
+        // small model, few tiles: 64 x 64 workgroup tiles shorten the critical path of the tiny grid
+        if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));
+        var_part = h->splitk_part;             // n_out * (Np/64) * Tp <= 2 * 256 * 128 * 16 doubles
+        nrb = h->Np / 64;
+        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+        SR_TRY(sr_launch_var64(h->Wt, h->Ks, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else {
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, h->var_variant, s));
@@ -573,7 +573,7 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
-    if (h->small_path == 1 && !h->general && sr_gp_small_wanted(h->Np, 1, h->D, false)) {
+    if (h->small_path == 1 && !h->general && sr_gp_small_wanted(h->Np, SR_SMALL_T, h->D, false)) {
         // small ARD-RBF model: everything in one launch (sr_small.hip, LIN mode)
         sr_kstar_args ka{};
         ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;

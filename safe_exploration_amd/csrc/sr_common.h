@@ -176,6 +176,9 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #define SR_SMALL_T 16
 #define SR_FUSED_T 1024        /* up to here a model with Np <= SR_FUSED_NP takes the one-launch pass of sr_small.hip */
 #define SR_FUSED_NP 512
+#ifndef SR_STREAM_MIN_NP
+#define SR_STREAM_MIN_NP 384    /* T <= 16 streams U^-1 (K2s) above this padded size unless the one-launch pass K0 takes it */
+#endif
 #define SR_FINAL_WAVE_T 4096   /* up to here sr_finalize runs one wavefront per (query, output) */
 long sr_var_small_ws(int Np, int n_out);
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,

@@ -461,14 +461,18 @@ __global__ __launch_bounds__(256) void sr_var_splitk_reduce_kernel(const double*
     if (half == 0) part[((long)d * (4 * nrb) + rb * 4 + q) * Tp + (long)x * srt::BN + n] = s + red[n];
 }
 
-// k-blocks per chunk: 4 when all chunk workgroups of that size are co-resident (2 per CU), else 8
-// (measured at N = 5000: T=128 -> 4 is 30 % faster, T=256 -> 8 is 12 % faster)
+// k-blocks per chunk: the finest of 1, 2, 4, 8 that keeps the chunk workgroups within ~1.5 residency rounds
+// (768 of them; measured on N = 700 .. 5000, T = 32 .. 1024: a chunk of one k-block is 8 k-tiles = 7 us of
+// serial work, and the partial tiles it writes cost bandwidth, so finer is better only while everything is
+// co-resident).  N = 1024, T <= 256: 71 -> 46 us; N = 2000, T <= 128: 92 -> 63 us; N = 5000 keeps 4 / 8.
 static int splitk_kcb(int Np, long Tp, int n_out) {
     const long nrb = Np / srt::BM;
-    long wg4 = 0;
-    for (long rb = 0; rb < nrb; ++rb) wg4 += (rb + 4) / 4;
-    wg4 *= (Tp / srt::BN) * n_out;
-    return wg4 <= 512 ? 4 : 8;
+    for (int kcb = 1; kcb < 8; kcb *= 2) {
+        long wg = 0;
+        for (long rb = 0; rb < nrb; ++rb) wg += (rb + kcb) / kcb;
+        if (wg * (Tp / srt::BN) * n_out <= 768) return kcb;
+    }
+    return 8;
 }
 
 long sr_var_splitk_ws(int Np, long Tp, int n_out) {
@@ -482,7 +486,7 @@ long sr_var_splitk_ws(int Np, long Tp, int n_out) {
 bool sr_var_splitk_wanted(int Np, long Tp, int n_out) {
     const int nrb = Np / srt::BM;
     const long wgs = (long)nrb * (Tp / srt::BN) * n_out;
-    return nrb > 8 && wgs <= 1024;
+    return nrb > 2 && wgs <= 1024;
 }
 
 int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,
