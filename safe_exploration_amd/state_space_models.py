@@ -33,15 +33,26 @@ class StateSpaceModel(object):
                                   "get_forward_model_casadi() method")
 
     def get_forward_model_casadi(self, linearize_mu=True):
-        """state_space_models.py:140-166 wraps ``copy.deepcopy(self)`` in a casadi.Callback.
-        casadi is an optional dependency of the *caller*; without it this raises ImportError."""
+        """state_space_models.py:140-166 wraps ``copy.deepcopy(self)`` in a ``casadi.Callback``.
+
+        The callback class is CasADi glue of the *caller* (it only uses ``linearize_predict`` / ``predict`` /
+        ``get_reverse`` / ``get_linearize_reverse`` and ``copy.deepcopy`` of this object, all provided here), so
+        when the reference package is importable its own ``CasadiSSMEvaluator`` is used unchanged on top of this
+        model; nothing CasADi-specific is re-implemented (casadi is not installed where this library is built and
+        tested)."""
         try:
             import casadi  # noqa: F401
         except ImportError as exc:
             raise ImportError("get_forward_model_casadi needs casadi (the CasADi MPC is the caller of "
                               "this surface, not part of the MI355X hot path)") from exc
-        raise NotImplementedError("the CasADi callback wrapper (T=1 latency path) is ranked 'next' in "
-                                  "DESIGN.md; the batched surface is complete")
+        try:
+            from safe_exploration.state_space_models import CasadiSSMEvaluator
+        except ImportError as exc:
+            raise NotImplementedError("no CasADi callback class available: install the reference package "
+                                      "(safe_exploration.state_space_models.CasadiSSMEvaluator works on this "
+                                      "model unchanged)") from exc
+        import copy
+        return CasadiSSMEvaluator(copy.deepcopy(self), linearize_mu)
 
     def get_reverse(self, seed):
         raise NotImplementedError("Need to implement this in a sublass when providing reverse AD "

@@ -193,3 +193,57 @@ def test_true_system_rollouts_vs_reference_golden():
     # n = 1: no feedback stage at all
     x1 = reach.simulate_trajectory(env, g["p_0"], None, g["k_ff"][:1], None)
     np.testing.assert_allclose(x1[1], g["x_all"][1], rtol=1e-13)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/safe_exploration"),
+                    reason="needs the reference checkout (build container only)")
+def test_reference_casadi_evaluator_runs_on_this_surface(tmp_path, monkeypatch):
+    """get_forward_model_casadi hands a deep copy of the model to the REFERENCE's CasadiSSMEvaluator
+    (state_space_models.py:166, 214-566).  casadi itself is absent here, so a stand-in module provides the three
+    names the evaluator touches (Callback.construct, Sparsity.dense, reshape); what is pinned is the contract between
+    that evaluator and this package's StateSpaceModel surface: call signatures, output shapes, stacked Jacobian."""
+    import sys
+    import textwrap
+    (tmp_path / "casadi.py").write_text(textwrap.dedent('''
+        import numpy as _np
+        def reshape(a, s): return _np.reshape(a, s, order="F")
+        class Sparsity(object):
+            @staticmethod
+            def dense(r, c=1): return (r, c)
+        class Callback(object):
+            def __init__(self): self.constructed = None
+            def construct(self, name, opts): self.constructed = name
+    '''))
+    monkeypatch.syspath_prepend(str(tmp_path))
+    monkeypatch.syspath_prepend("/root/reference")
+    for m in [k for k in sys.modules if k == "casadi" or k.startswith("safe_exploration.") or k == "safe_exploration"]:
+        monkeypatch.delitem(sys.modules, m)
+    from safe_exploration_amd import StateSpaceModel
+
+    class Linear(StateSpaceModel):
+        """mu = A [x; u], var = 0.1 + (w.[x; u])^2: closed forms for every derivative the evaluator asks for."""
+        A = np.array([[0.9, 0.1, 0.3], [-0.2, 0.8, 0.5]])
+        w = np.array([0.3, -0.4, 0.2])
+
+        def linearize_predict(self, states, actions, jacobians=False, full_cov=False):
+            z = np.hstack((np.asarray(states), np.asarray(actions)))[0]
+            mu = self.A.dot(z)[:, None]
+            var = np.full((2, 1), 0.1 + self.w.dot(z) ** 2)
+            if not jacobians:
+                return mu, var, self.A
+            jv = np.tile(2 * self.w.dot(z) * self.w, (2, 1))
+            return mu, var, self.A, jv, np.zeros((2, 3, 3))
+
+    ssm = Linear(2, 1)
+    ev = ssm.get_forward_model_casadi(True)
+    assert type(ev).__name__ == "CasadiSSMEvaluator" and ev.ssm is not ssm and ev.constructed
+    assert ev.get_n_in() == 2 and ev.get_n_out() == 3 and ev.get_sparsity_out(2) == (2, 3)
+    x, u = np.array([[0.2], [-0.1]]), np.array([[0.4]])
+    mu, var, jac = ev.eval([x, u])
+    np.testing.assert_allclose(mu[:, 0], Linear.A.dot([0.2, -0.1, 0.4]))
+    assert var.shape == (2, 1) and jac.shape == (2, 3)
+    jfun = ev.get_jacobian("jac", [], [], {})
+    (stacked,) = jfun.eval([x, u, mu, var, jac])
+    assert stacked.shape == (2 * 2 + 2 * 3, 3)                 # [jac_mu; jac_var; d jac_mu / dz]
+    np.testing.assert_allclose(stacked[:2], Linear.A)
+    np.testing.assert_allclose(stacked[2:4], np.tile(2 * Linear.w.dot([0.2, -0.1, 0.4]) * Linear.w, (2, 1)))
