@@ -39,6 +39,10 @@ struct sr_gp {
     // factorisation: the outputs are independent problems -- below SR_FACT_PAR_BYTES of scratch each gets its own
     // HIP stream (the small-grid kernels of a modest model then overlap) and the scratch stays with the handle
     double* fact_ws = nullptr; size_t fact_cap = 0;      // n_par x (U, W: Np^2 each, v: Np)
+    // row append of few points (m <= 16): scratch and a second U^-1 buffer the new factor is assembled into
+    // (kept while the padded size does not change: appends then allocate nothing big)
+    double* app_ws = nullptr; size_t app_cap = 0;
+    double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
     hipStream_t fact_stream[SR_MAX_NS] = {nullptr};
     hipEvent_t fact_fork = nullptr, fact_join[SR_MAX_NS] = {nullptr};
     sr_prof prof;
@@ -104,7 +108,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     free_ws(h);
-    dev_free(h->fact_ws);
+    dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (int d = 0; d < SR_MAX_NS; ++d) {
         if (h->fact_stream[d]) (void)hipStreamDestroy(h->fact_stream[d]);
         if (h->fact_join[d]) (void)hipEventDestroy(h->fact_join[d]);
@@ -907,12 +911,129 @@ __global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int 
     yT1[(long)d * Np1 + i] = v;
 }
 
+// m <= 16 new points: U12 = U^-T B through the streaming kernels of the prediction path (the new points are
+// the queries), everything else as matrix-vector shaped passes -- see sr_factor.hip.  No big allocation while
+// the padded size stays the same (U^-1 ping-pongs between two buffers).
+static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m, hipStream_t s, int* info) {
+    const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
+    const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1, pf = SR_NB - m;
+    const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
+    // scratch layout
+    const size_t o_u12 = 0, o_xt = o_u12 + (size_t)n_out * SR_SMALL_T * Np0, o_y2 = o_xt + (size_t)SR_SMALL_T * Np0,
+                 o_g = o_y2 + (size_t)Np0 * SR_NB, o_sb = o_g + BB, o_inv = o_sb + BB, o_wdm = o_inv + BB,
+                 o_v = o_wdm + BB, o_info = o_v + (size_t)Np1, need = o_info + (size_t)n_out;
+    if (h->app_cap < need) {
+        (void)hipDeviceSynchronize();
+        dev_free(h->app_ws);
+        h->app_ws = nullptr; h->app_cap = 0;
+        SR_TRY(dev_alloc(&h->app_ws, need));
+        h->app_cap = need;
+    }
+    double* ws = h->app_ws;
+    double *U12t = ws + o_u12, *Xt = ws + o_xt, *Y2 = ws + o_y2, *G = ws + o_g, *Sb = ws + o_sb, *invS = ws + o_inv,
+           *wdm = ws + o_wdm, *v = ws + o_v;
+    int* info_dev = reinterpret_cast<int*>(ws + o_info);
+    double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;
+    const bool reuse_alt = (Np1 == Np0) && h->Wt_alt && h->wt_alt_cap >= (size_t)n_out * NN1;
+    std::vector<double> sf2(n_out), noise(n_out);
+    int rc = SR_OK;
+    auto drop_new = [&]() {
+        dev_free(Z1); dev_free(yT1); dev_free(alpha1);
+        if (!reuse_alt) dev_free(Wt1);
+    };
+#define SR_A(expr) do { rc = (expr); if (rc != SR_OK) { drop_new(); return rc; } } while (0)
+#define SR_AH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); drop_new(); return SR_EHIP; } } while (0)
+    SR_A(dev_alloc(&Z1, (size_t)N1 * D));
+    SR_A(dev_alloc(&yT1, (size_t)n_out * Np1));
+    SR_A(dev_alloc(&alpha1, (size_t)n_out * Np1));
+    if (reuse_alt) Wt1 = h->Wt_alt;
+    else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
+    SR_AH(hipMemsetAsync(info_dev, 0, sizeof(int) * n_out, s));
+    SR_AH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+    SR_AH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+    SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
+    SR_AH(hipMemcpyAsync(Z1 + (size_t)N0 * D, Znew, sizeof(double) * m * D, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(sr_append_y_kernel, dim3((Np1 + 255) / 256, n_out), dim3(256), 0, s, h->yT, Np0, N0, Ynew, m,
+                       yT1, Np1, n_out);
+    SR_AH(hipGetLastError());
+    SR_AH(hipStreamSynchronize(s));
+    // B = K(Z_old, Z_new) with the new points as queries, then U12 = U^-T B by streaming U^-1 once
+    const long Tp = srt::BN;
+    const int nsplit = pick_nsplit(h, Tp);
+    SR_A(ensure_ws(h, Tp, nsplit));
+    sr_kstar_args ka;
+    ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.kp = h->general ? h->kp : nullptr; ka.kxx = h->kxx;
+    ka.xa = Znew; ka.lda = D; ka.na = D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
+    ka.Ks = h->Ks; ka.mu_part = h->mu_part; ka.jac_part = h->jac_part;
+    ka.N = N0; ka.Np = Np0; ka.D = D; ka.n_out = n_out; ka.nsplit = nsplit; ka.T = m; ka.Tp = Tp;
+    SR_A(sr_launch_kstar(ka, s));
+    if (!h->small_vp) SR_A(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(Np0, n_out)));
+    SR_A(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, N0, Np0, Tp, n_out, m, s));
+    SR_A(sr_launch_var_small_gather_all(h->small_vp, U12t, Np0, n_out, m, s));
+    for (int d = 0; d < n_out; ++d) {
+        const double* Wt0 = h->Wt + (size_t)d * NN0;
+        const double* u12 = U12t + (size_t)d * m * Np0;
+        SR_AH(hipMemsetAsync(G, 0, BB * sizeof(double), s));
+        SR_A(sr_launch_append_small(u12, Wt0, Np0, m, 0, G, nullptr, nullptr, nullptr, s));      // G = U12^T U12
+        if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], Sb, m, SR_NB, D, s));
+        else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], Sb, m, SR_NB, D, s));
+        SR_A(sr_launch_sub_block(Sb, G, pf, s));                                                   // S = C - G
+        SR_A(sr_launch_potrf_diag(Sb, SR_NB, invS, wdm, SR_NB, 0, info_dev + d, s));               // invS = U22^-1
+        SR_A(sr_launch_append_small(u12, Wt0, Np0, m, 1, nullptr, invS, Xt, Y2, s));               // Y2 = -U^-1 U12 U22^-1
+        SR_A(sr_launch_append_assemble(Wt0, Np0, off0, N0, Y2, invS, m, Wt1 + (size_t)d * NN1, Np1, off1, s));
+        // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1
+        SR_A(sr_launch_append_alpha(h->alpha + (size_t)d * Np0, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, d, Tp,
+                                    Ynew, m, alpha1 + (size_t)d * Np1, Np1, s));
+    }
+    (void)v;
+    std::vector<int> info_h(n_out, 0);
+    SR_AH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
+    SR_AH(hipStreamSynchronize(s));
+#undef SR_A
+#undef SR_AH
+    int bad = 0;
+    for (int d = 0; d < n_out; ++d) {
+        if (info_h[d] > 0) info_h[d] = N0 + std::max(1, info_h[d] - pf);
+        if (info) info[d] = info_h[d];
+        if (info_h[d] != 0 && !bad) bad = d + 1;
+    }
+    if (bad) {
+        drop_new();
+        sr_set_error("sr_gp_append: Schur complement not positive definite (output %d, point %d)", bad - 1, info_h[bad - 1]);
+        return SR_ENOTPD;
+    }
+    double* old_wt = h->Wt;
+    dev_free(h->Z); dev_free(h->yT); dev_free(h->alpha);
+    h->Z = Z1; h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
+    h->N = N1;
+    if (Np1 == Np0) {
+        // keep the previous buffer for the next append (bounded: not for huge factors)
+        if (!reuse_alt) dev_free(h->Wt_alt);
+        if ((size_t)n_out * NN0 * sizeof(double) <= SR_FACT_PAR_BYTES * 2) { h->Wt_alt = old_wt; h->wt_alt_cap = (size_t)n_out * NN0; }
+        else { dev_free(old_wt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; }
+    } else {
+        dev_free(old_wt);
+        dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0;
+        h->Np = Np1;
+        free_ws(h);
+        dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
+        h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
+        h->splitk_cap = 0;
+        dev_free(h->fact_ws); h->fact_ws = nullptr; h->fact_cap = 0;
+        dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
+    }
+    return SR_OK;
+}
+
 extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info) {
     SR_CHECK(h != nullptr && Znew && Ynew, SR_EINVAL, "sr_gp_append: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_append: model not factorized");
     SR_CHECK(m >= 1 && m <= SR_NB, SR_EINVAL, "sr_gp_append: m=%d outside 1..%d (append in several calls)", m, SR_NB);
     hipStream_t s = (hipStream_t)stream;
     SR_HIP(hipSetDevice(h->device));
+    if (m <= SR_SMALL_T) return append_small(h, Znew, Ynew, m, s, info);
     const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
     const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1;
     const int pf = SR_NB - m;

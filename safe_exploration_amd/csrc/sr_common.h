@@ -185,6 +185,12 @@ int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* 
                         long Tp, int n_out, int T, hipStream_t s);
 
 int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, int T, hipStream_t s);
+int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_out, int T, hipStream_t s);
+int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
+                           const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
+                           double* alpha1, int Np1, hipStream_t s);
+int sr_launch_append_small(const double* U12t, const double* Wt0, int Np0, int m, int stage, double* G,
+                           const double* invS, double* Xt, double* Y2, hipStream_t s);
 
 struct sr_final_args {
     const double* mu_part; const double* jac_part; const double* var_part; const double* sf2;

@@ -392,6 +392,125 @@ int sr_launch_append_assemble(const double* Wt0, int Np0, int off0, int N0, cons
     return SR_OK;
 }
 
+// ---- row append with FEW new points (m <= 16): matrix-vector shaped kernels, every pass over U^-1 is one
+// coalesced stream (the GEMM route pads the m columns to a 128-wide tile and serialises 40 workgroups).
+// U12t[a][i] (a < m, i < Np0, padded row indexing) holds U12 = U^-T K(Z_old, Z_new) column by column.
+
+// G[pf+a][pf+b] = sum_i U12t[a][i] U12t[b][i] inside a zeroed 128 x 128 block; grid (m, m)
+__global__ __launch_bounds__(256) void sr_append_gsmall_kernel(const double* __restrict__ U12t, int Np0, int m,
+                                                               double* __restrict__ G) {
+    __shared__ double red[4];
+    const int a = blockIdx.x, b = blockIdx.y, pf = SR_NB - m;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < Np0; i += 256) v = fma(U12t[(long)a * Np0 + i], U12t[(long)b * Np0 + i], v);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) G[(pf + a) * SR_NB + pf + b] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Xt[c][i] = sum_{a <= c} U12t[a][i] invS[pf+a][pf+c]   (X = U12 U22^-1, U22^-1 upper triangular)
+__global__ __launch_bounds__(256) void sr_append_xt_kernel(const double* __restrict__ U12t,
+                                                           const double* __restrict__ invS, int Np0, int m,
+                                                           double* __restrict__ Xt) {
+    const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, pf = SR_NB - m;
+    if (i >= Np0) return;
+    double v = 0.0;
+    for (int a = 0; a <= c; ++a) v = fma(U12t[(long)a * Np0 + i], invS[(pf + a) * SR_NB + pf + c], v);
+    Xt[(long)c * Np0 + i] = v;
+}
+
+// Y2[i][pf+c] = -sum_{k >= i} Wt0[i][k] Xt[c][k]  (Y2 = -U^-1 X): one wavefront per row, lanes over k, MC columns
+template <int MC>
+__global__ __launch_bounds__(256) void sr_append_y2_kernel(const double* __restrict__ Wt0, int Np0,
+                                                           const double* __restrict__ Xt, int m,
+                                                           double* __restrict__ Y2) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, pf = SR_NB - m;
+    if (row >= Np0) return;
+    double acc[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) acc[c] = 0.0;
+    for (int k = row + lane; k < Np0; k += 64) {
+        const double w = Wt0[(long)row * Np0 + k];
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < m) acc[c] = fma(w, Xt[(long)c * Np0 + k], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        double v = acc[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && c < m) Y2[(long)row * SR_NB + pf + c] = -v;
+    }
+}
+
+// alpha of the grown model without another pass over U^-1:  with r = y_new - mu_old(z_new) (the old model's
+// mean at the new points, which the K* pass has just produced) and v2 = U22^-T r,
+//   alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2].     One workgroup recomputes v2 (m <= 16), grid over the rows.
+__global__ __launch_bounds__(256) void sr_append_alpha_kernel(const double* __restrict__ alpha0, int Np0, int N0,
+                                                              const double* __restrict__ Y2,
+                                                              const double* __restrict__ invS,
+                                                              const double* __restrict__ mu_part, int nsplit,
+                                                              int n_out, int d, long Tp,
+                                                              const double* __restrict__ Ynew, int m,
+                                                              double* __restrict__ alpha1, int Np1) {
+    __shared__ double r[SR_SMALL_T], v2[SR_SMALL_T];
+    const int pf = SR_NB - m, off0 = Np0 - N0, off1 = Np1 - (N0 + m);
+    if (threadIdx.x < m) {
+        double mu = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) mu += mu_part[((long)sp * n_out + d) * Tp + threadIdx.x];
+        r[threadIdx.x] = Ynew[(long)threadIdx.x * n_out + d] - mu;
+    }
+    __syncthreads();
+    if (threadIdx.x < m) {
+        double v = 0.0;
+        for (int b = 0; b <= (int)threadIdx.x; ++b) v = fma(invS[(pf + b) * SR_NB + pf + threadIdx.x], r[b], v);
+        v2[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;           // index in the new padded vector
+    if (i >= Np1) return;
+    double a = 0.0;
+    if (i >= off1) {
+        const int k = i - off1;
+        if (k < N0) {
+            a = alpha0[off0 + k];
+            for (int c = 0; c < m; ++c) a = fma(Y2[(long)(off0 + k) * SR_NB + pf + c], v2[c], a);
+        } else {
+            const int q = k - N0;
+            for (int c = q; c < m; ++c) a = fma(invS[(pf + q) * SR_NB + pf + c], v2[c], a);
+        }
+    }
+    alpha1[i] = a;
+}
+
+int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
+                           const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
+                           double* alpha1, int Np1, hipStream_t s) {
+    hipLaunchKernelGGL(sr_append_alpha_kernel, dim3((Np1 + 255) / 256), dim3(256), 0, s, alpha0, Np0, N0, Y2, invS,
+                       mu_part, nsplit, n_out, d, Tp, Ynew, m, alpha1, Np1);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_launch_append_small(const double* U12t, const double* Wt0, int Np0, int m, int stage, double* G,
+                           const double* invS, double* Xt, double* Y2, hipStream_t s) {
+    if (stage == 0) {
+        hipLaunchKernelGGL(sr_append_gsmall_kernel, dim3(m, m), dim3(256), 0, s, U12t, Np0, m, G);
+    } else {
+        hipLaunchKernelGGL(sr_append_xt_kernel, dim3((Np0 + 255) / 256, m), dim3(256), 0, s, U12t, invS, Np0, m, Xt);
+        SR_HIP(hipGetLastError());
+        if (m <= 1)
+            hipLaunchKernelGGL(sr_append_y2_kernel<1>, dim3((Np0 + 3) / 4), dim3(256), 0, s, Wt0, Np0, Xt, m, Y2);
+        else if (m <= 4)
+            hipLaunchKernelGGL(sr_append_y2_kernel<4>, dim3((Np0 + 3) / 4), dim3(256), 0, s, Wt0, Np0, Xt, m, Y2);
+        else
+            hipLaunchKernelGGL(sr_append_y2_kernel<16>, dim3((Np0 + 3) / 4), dim3(256), 0, s, Wt0, Np0, Xt, m, Y2);
+    }
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 // one wavefront per row; shuffle reduction
 __global__ __launch_bounds__(256) void sr_trmv_kernel(const double* __restrict__ M, long ld,
                                                       const double* __restrict__ x,

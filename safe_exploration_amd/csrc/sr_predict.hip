@@ -608,6 +608,31 @@ __global__ __launch_bounds__(256) void sr_var_small_gather_kernel(const double* 
 
 static inline int small_tq(int T) { return T <= 1 ? 1 : (T <= 4 ? 4 : SR_TS); }
 
+// all live queries at once: v[(d * tq_out + t) * Np + i], grid (ncb, n_out, nt)
+__global__ __launch_bounds__(256) void sr_var_small_gather_all_kernel(const double* __restrict__ Vp,
+                                                                      double* __restrict__ v, int Np, int npairs,
+                                                                      int tq, int nt) {
+    const int cb = blockIdx.x, d = blockIdx.y, t = blockIdx.z;
+    const int i = cb * 256 + threadIdx.x;
+    if (i >= Np) return;
+    const int p0 = cb * (cb + 1), nch = 2 * cb + 2;
+    const double* src = Vp + (((long)d * npairs + p0) * tq + t) * 256 + threadIdx.x;
+    double v0 = 0.0, v1 = 0.0;
+    for (int j = 0; j + 1 < nch; j += 2) {
+        v0 += src[(long)j * tq * 256];
+        v1 += src[(long)(j + 1) * tq * 256];
+    }
+    v[((long)d * nt + t) * Np + i] = v0 + v1;
+}
+
+int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_out, int T, hipStream_t s) {
+    const int ncb = (Np + 255) / 256;
+    hipLaunchKernelGGL(sr_var_small_gather_all_kernel, dim3(ncb, n_out, T), dim3(256), 0, s, Vp, v, Np,
+                       ncb * (ncb + 1), small_tq(T), T);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, int T, hipStream_t s) {
     const int ncb = (Np + 255) / 256;
     hipLaunchKernelGGL(sr_var_small_gather_kernel, dim3(ncb, n_out), dim3(256), 0, s, Vp, v, Np,

@@ -545,7 +545,8 @@ def test_reference_test_scenarios_on_reference_data(name, n_s, n_u):
         np.testing.assert_allclose(qa, g["ms_q_" + tag], rtol=1e-6)
 
 
-@pytest.mark.parametrize("N0,adds", [(100, [1]), (120, [8, 1]), (250, [6, 128, 3]), (384, [130]), (700, [40])])
+@pytest.mark.parametrize("N0,adds", [(100, [1]), (120, [8, 1]), (250, [6, 128, 3]), (384, [130]), (700, [40]),
+                                     (300, [16, 16, 1, 5, 2]), (127, [1, 1, 1]), (1300, [2, 16, 1]), (1, [1, 3])])
 def test_row_append_update_equals_refit(N0, adds):
     """update_model(replace_old=False): block row append of the factor == refactorising on all the data
     (SURVEY 8(f).3); crosses 128-padding boundaries, m = 1, m = 128 and m > 128 (two chunks)."""
