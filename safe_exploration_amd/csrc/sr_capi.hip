@@ -931,7 +931,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     }
     double* ws = h->app_ws;
     double *U12t = ws + o_u12, *Xt = ws + o_xt, *Y2 = ws + o_y2, *G = ws + o_g, *Sb = ws + o_sb, *invS = ws + o_inv,
-           *wdm = ws + o_wdm, *v = ws + o_v;
+           *wdm = ws + o_wdm;
     int* info_dev = reinterpret_cast<int*>(ws + o_info);
     double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;
     const bool reuse_alt = (Np1 == Np0) && h->Wt_alt && h->wt_alt_cap >= (size_t)n_out * NN1;
@@ -987,7 +987,6 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         SR_A(sr_launch_append_alpha(h->alpha + (size_t)d * Np0, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, d, Tp,
                                     Ynew, m, alpha1 + (size_t)d * Np1, Np1, s));
     }
-    (void)v;
     std::vector<int> info_h(n_out, 0);
     SR_AH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
     SR_AH(hipStreamSynchronize(s));
