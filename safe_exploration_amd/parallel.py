@@ -65,6 +65,44 @@ def replicate_model(gp, prob, src=0):
     return local
 
 
+def fit_outputs_sharded(n_s_out, n_s_in, n_u, Z, Y, kern_types=None, hyp=None, noise_diag=1e-5, device=None):
+    """Model update with the OUTPUTS sharded over the ranks (the large-N alternative): the n_s_out
+    Gaussian processes are independent problems, so rank r factorises outputs d = r, r + world, ... on its GPU with
+    no communication, then every factor is broadcast once from its owner (RCCL over xGMI; alpha and U^-1 only)
+    and each rank adopts the complete posterior through ``import_state``.  Returns the rank-local full model.
+    Config 4 (N = 50000, n_out = 2) on two GPUs: half the factorisation time plus one 20 GB broadcast."""
+    from .ssm_hip.gaussian_process import SimpleGPModel
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    kern_types = list(kern_types) if kern_types is not None else ["rbf"] * n_s_out
+    hyp = list(hyp) if hyp is not None else [None] * n_s_out
+    Z = np.asarray(Z, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    mine = [d for d in range(n_s_out) if d % world == rank]
+    part = None
+    if mine:
+        sub = SimpleGPModel(len(mine), n_s_in, n_u, kern_types=[kern_types[d] for d in mine],
+                            hyp=[hyp[d] for d in mine], device=dev)
+        sub.train(Z, Y[:, mine], opt_hyp=False, noise_diag=noise_diag)
+        part = sub.export_state()                       # alpha (len(mine), N), U^-1 (len(mine), Np, Np)
+    N = Z.shape[0]
+    Np = -(-N // 128) * 128
+    alpha = torch.empty((n_s_out, N), dtype=torch.float64, device=dev)
+    wt = torch.empty((n_s_out, Np, Np), dtype=torch.float64, device=dev)
+    for d in range(n_s_out):
+        owner = d % world
+        if owner == rank:
+            k = mine.index(d)
+            alpha[d].copy_(part[0][k])
+            wt[d].copy_(part[1][k])
+        dist.broadcast(alpha[d], src=owner)
+        dist.broadcast(wt[d], src=owner)
+    del part
+    full = SimpleGPModel(n_s_out, n_s_in, n_u, kern_types=kern_types, hyp=hyp, device=dev)
+    full.import_state(Z, Y, alpha, wt, noise_diag=noise_diag)
+    return full
+
+
 def gather_rows(local, dst=0):
     """Gather per-rank row blocks (numpy, possibly different lengths) on `dst` in rank order."""
     objs = [None] * dist.get_world_size() if dist.get_rank() == dst else None

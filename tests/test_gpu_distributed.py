@@ -50,6 +50,20 @@ def _worker(rank, world, port, ret):
         else:
             np.testing.assert_array_equal(gp.beta.shape, (N, n_s))     # imported alpha readable
         dist.barrier()
+        # outputs sharded over the ranks for the model update (rank d % world factorises output d)
+        n4 = 3
+        prob4 = workload.make_problem(22, 260, n4, 1, 64, sf2=0.01)
+        hyp4 = workload.hyp_list(prob4)
+        sharded = parallel.fit_outputs_sharded(n4, n4, 1, prob4["Z"], prob4["Y"], ["rbf"] * n4, hyp4)
+        x4 = np.hstack((prob4["p"], prob4["k_ff"]))
+        mu_s, var_s = sharded.predict(x4)
+        if rank == 0:
+            single = SimpleGPModel(n4, n4, 1, kern_types=["rbf"] * n4, hyp=hyp4)
+            single.train(prob4["Z"], prob4["Y"], opt_hyp=False)
+            mu_1, var_1 = single.predict(x4)
+            ret["d_mu_sharded_fit"] = float(np.abs(mu_s - mu_1).max())
+            ret["d_var_sharded_fit"] = float(np.abs(var_s - var_1).max())
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 
@@ -61,3 +75,4 @@ def test_two_ranks_share_one_gpu(lib_built):
         mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
         assert ret["shape"] == (1001, 2, 2)
         assert ret["dp"] < 1e-13 and ret["dq"] < 1e-12
+        assert ret["d_mu_sharded_fit"] == 0.0 and ret["d_var_sharded_fit"] == 0.0
