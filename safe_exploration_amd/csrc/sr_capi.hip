@@ -1038,13 +1038,13 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     const int pf = SR_NB - m;
     const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
     double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;                 // new persistent state
-    double *Xq = nullptr, *Ks = nullptr, *dmy = nullptr, *U12 = nullptr, *U12t = nullptr, *G = nullptr,
+    double *Xq = nullptr, *Ks = nullptr, *U12 = nullptr, *U12t = nullptr, *G = nullptr,
            *Sb = nullptr, *invS = nullptr, *wdm = nullptr, *X = nullptr, *Y2 = nullptr, *Wtr = nullptr, *v = nullptr;
     int* info_dev = nullptr;
     std::vector<double> sf2(n_out), noise(n_out);
     int rc = SR_OK;
     auto cleanup = [&](bool drop_new) {
-        dev_free(Xq); dev_free(Ks); dev_free(dmy); dev_free(U12); dev_free(U12t); dev_free(G); dev_free(Sb);
+        dev_free(Xq); dev_free(Ks); dev_free(U12); dev_free(U12t); dev_free(G); dev_free(Sb);
         dev_free(invS); dev_free(wdm); dev_free(X); dev_free(Y2); dev_free(Wtr); dev_free(v); dev_free(info_dev);
         if (drop_new) { dev_free(Z1); dev_free(yT1); dev_free(alpha1); dev_free(Wt1); }
     };
@@ -1057,7 +1057,6 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
     SR_A(dev_alloc(&Xq, (size_t)SR_NB * D));
     SR_A(dev_alloc(&Ks, (size_t)n_out * Np0 * SR_NB));
-    SR_A(dev_alloc(&dmy, (size_t)n_out * (D + 2) * SR_NB));
     SR_A(dev_alloc(&U12, (size_t)Np0 * SR_NB));
     SR_A(dev_alloc(&U12t, (size_t)Np0 * SR_NB));
     SR_A(dev_alloc(&G, BB)); SR_A(dev_alloc(&Sb, BB)); SR_A(dev_alloc(&invS, BB)); SR_A(dev_alloc(&wdm, BB));
@@ -1077,12 +1076,16 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     SR_AH(hipGetLastError());
     SR_AH(hipStreamSynchronize(s));
     // B = K(Z_old, Z_new): the prediction kernel with the new points as queries (old padded row indexing)
+    // (the mean / Jacobian partial sums of the pass are not needed: they land in the prediction workspace; the
+    //  N-split keeps the per-thread exp chain short -- one split cost 0.9 ms at N = 5000)
+    const int nsplit = pick_nsplit(h, SR_NB);
+    SR_A(ensure_ws(h, SR_NB, nsplit));
     sr_kstar_args ka;
     ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
-    ka.kp = h->general ? h->kp : nullptr; ka.kxx = dmy;
+    ka.kp = h->general ? h->kp : nullptr; ka.kxx = h->kxx;
     ka.xa = Xq; ka.lda = D; ka.na = D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
-    ka.Ks = Ks; ka.mu_part = dmy + (size_t)n_out * SR_NB; ka.jac_part = dmy + (size_t)2 * n_out * SR_NB;
-    ka.N = N0; ka.Np = Np0; ka.D = D; ka.n_out = n_out; ka.nsplit = 1; ka.T = SR_NB; ka.Tp = SR_NB;
+    ka.Ks = Ks; ka.mu_part = h->mu_part; ka.jac_part = h->jac_part;
+    ka.N = N0; ka.Np = Np0; ka.D = D; ka.n_out = n_out; ka.nsplit = nsplit; ka.T = SR_NB; ka.Tp = SR_NB;
     SR_A(sr_launch_kstar(ka, s));
     for (int d = 0; d < n_out; ++d) {
         const double* Wt0 = h->Wt + (size_t)d * NN0;
