@@ -21,7 +21,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst = {"mu": 0.0, "var": 0.0, "jac": 0.0, "q": 0.0}
     for c in range(cases):
-        n_s, n_u = [(2, 1), (4, 1), (3, 2)][rng.integers(3)]
+        n_s, n_u = [(2, 1), (4, 1), (3, 2), (5, 4), (8, 4)][rng.integers(5)]
         N = int(rng.choice([1, 2, 17, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 640, 1100, 1300]))
         T = int(rng.choice([1, 2, 5, 15, 16, 17, 63, 64, 65, 127, 128, 129, 300, 1024, 1025, 1500]))
         syn = orc.make_synthetic(int(rng.integers(1 << 30)), N, n_s, n_u, T, sf2=float(rng.choice([1.0, 0.01])))
@@ -34,7 +34,7 @@ def main():
         e_mu = np.abs(mu - rmu).max() / (at + 1e-9 * np.abs(rmu).max())
         e_jac = np.abs(jac - rjac).max() / (10 * at + 1e-9 * np.abs(rjac).max())
         e_var = np.abs(var - rvar).max() / (1e-9 * float(np.max(syn["signal_var"])))
-        l = np.full(n_s, 0.05)
+        l = np.full(n_s, 0.05 if n_s <= 4 else 0.01)
         p1, q1 = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0)
         rp, rq, _ = orc.onestep_reachability_vectorised(om, syn["p"], syn["Q"], syn["k_ff"], syn["k_fb"], l, l, 2.0,
                                                         np.eye(n_s), np.zeros((n_s, n_u)))
