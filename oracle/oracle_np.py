@@ -11,6 +11,12 @@ Pinning status
   reference's in-tree restatement ``gp_models_utils_casadi._k_rbf/_unscaled_dist/gp_pred``
   executed on numbers (casadi's 6 array functions replaced by numpy equivalents in the
   generator script only); fixtures ``tests/golden/gp_*.npz``.
+* Matern-5/2 / lin_* kernels, Gaussian moment propagation, Monte-Carlo particle propagation: PINNED against the
+  reference's in-tree formulas / functions evaluated on numbers (``kern_*.npz``, ``moments_*.npz``, ``mc_*.npz``).
+* Second-order outputs of the non-RBF kernels (``gp_linearize_extras_k``), marginal likelihood and its gradient
+  (``gp_nll_grad``), greedy max-variance selection (``choose_datapoints_maxvar``): the reference delegates these
+  to CasADi's AD resp. GPy's optimiser / model objects, so there are no reference numbers; they are checked
+  against central differences, scikit-learn, and refits from scratch in tests/test_oracle_golden.py.
 * GPy boundary (``GPRegression`` internals: +1e-8 jitter, 1e-15 variance clip, r2>=0 clip):
   **parity unpinned** -- GPy (unpinned in the reference's setup.py:20) is not installed and
   no stored GPy outputs exist in the reference tree.  Those three details are restated from
