@@ -1002,3 +1002,55 @@ def test_fused_small_model_pass_general_kernels(kt, N, T):
     np.testing.assert_allclose(mu, mu2, rtol=1e-11, atol=1e-13 * scale)
     np.testing.assert_allclose(jac, jac2, rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(var, var2, rtol=0, atol=1e-11 * max(1.0, float(rvar.max())))
+
+
+@pytest.mark.gpu
+def test_config3_cartpole_chain_full_model_size():
+    """BASELINE configs[2]: cart-pole dims (n_s=4, n_u=1), N=5000, H=15.  A batch of 200 rollouts through
+    sr_multistep_reach; three of them against the oracle chain (per-query route, factorised on the CPU), and the
+    size-independent property that the one-call chain equals H one-step calls fed with their own outputs."""
+    from safe_exploration_amd import gp_reachability as reach, workload
+    N, T, H, n_s, n_u = 5000, 200, 15, 4, 1
+    syn = orc.make_synthetic(3, N, n_s, n_u, 8, sf2=0.01)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    roll = workload.random_rollout_controls(33, T, H, n_s, n_u)
+    l = np.full(n_s, 0.05)
+    a, b = 0.5 * np.eye(n_s), np.zeros((n_s, n_u))
+    p_all, q_all = reach.multistep_reachability_batch(roll["p0"], gp, roll["k_fb"], roll["k_ff"], l, l, None, 2.0, a, b)
+    assert p_all.shape == (T, H, n_s) and q_all.shape == (T, H, n_s, n_s) and np.all(np.isfinite(q_all))
+    assert np.linalg.eigvalsh(q_all.reshape(-1, n_s, n_s)).min() > 0
+    # chain == repeated one-step calls (point branch first, then ellipsoid branch with k_fb[i-1])
+    p, q = reach.onestep_reachability_batch(roll["p0"], gp, roll["k_ff"][:, 0], l, l, None, None, 2.0, a, b)
+    np.testing.assert_allclose(p, p_all[:, 0], rtol=1e-13, atol=1e-15)
+    for i in range(1, H):
+        p, q = reach.onestep_reachability_batch(p, gp, roll["k_ff"][:, i], l, l, q, roll["k_fb"][:, i - 1], 2.0, a, b)
+        np.testing.assert_allclose(p, p_all[:, i], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(q, q_all[:, i], rtol=1e-11, atol=1e-16)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    rp, rq = orc.multistep_reachability_batch(om, roll["p0"][:3], roll["k_fb"][:3], roll["k_ff"][:3], l, l, None, 2.0,
+                                              a, b)
+    np.testing.assert_allclose(p_all[:3], rp, rtol=1e-8, atol=max(mu_atol(om), 1e-11))
+    np.testing.assert_allclose(q_all[:3], rq, rtol=1e-6, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_config4_identities_at_a_panelled_size():
+    """BASELINE configs[3] uses identities of the exact posterior instead of an oracle (scripts/config4.py, N=50000);
+    the same identities at N=3000 -- 24 row blocks = 6 panels of the two-level Cholesky, 5 levels of the recursive
+    inversion -- where the oracle can still confirm them:  mu(z_i) + s2n alpha_i = y_i,  var(z_i) = s2n - s2n^2 (K_y^-1)_ii."""
+    N = 3000
+    syn = orc.make_synthetic(4, N, 2, 1, 4)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    s2n = syn["noise_var"] + 1e-8
+    idx = np.random.default_rng(1).choice(N, 512, replace=False)
+    mu, var = gp.predict(syn["Z"][idx])
+    alpha = gp.beta
+    assert np.abs(mu + s2n[None, :] * alpha[idx] - syn["Y"][idx]).max() < 1e-9
+    _, wt = gp.export_state()
+    off = gp._handle.Np - N
+    for d in range(2):
+        rows = __import__("torch").from_numpy(idx + off).to(wt.device)
+        kinv_ii = (wt[d].index_select(0, rows) ** 2).sum(1).cpu().numpy()
+        np.testing.assert_allclose(var[:, d], s2n[d] - s2n[d] ** 2 * kinv_ii, rtol=0, atol=1e-11)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    np.testing.assert_allclose(alpha, om["beta"], rtol=1e-6, atol=1e-8 * np.abs(om["beta"]).max())
