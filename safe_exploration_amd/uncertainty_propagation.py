@@ -132,3 +132,6 @@ def multi_step_taylor(mu_0, ssm, k_ff, k_fb, sigma_0=None, a=None, b=None, a_gp_
 def mean_equivalent_multistep(mu_0, ssm, k_ff, k_fb, sigma_0=None, a=None, b=None, a_gp_inp_x=None):
     """uncertainty_propagation_casadi.py:149-207."""
     return _multi(mu_0, ssm, k_ff, k_fb, sigma_0, a, b, a_gp_inp_x, MEAN_EQUIVALENT)
+
+
+multi_step_taylor_symbolic = multi_step_taylor      # the reference's name (uncertainty_propagation_casadi.py:11)

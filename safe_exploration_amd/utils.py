@@ -48,6 +48,18 @@ def feedback_ctrl(x, k_ff, k_fb=None, p=None):
     return np.dot(k_fb, (x - p)) + k_ff
 
 
+def dlqr(a, b, q, r):
+    """Infinite-horizon discrete LQR for x+ = a x + b u, u = -k x (utils.py:20-35): returns the gain k (n_u, n_s),
+    the Riccati solution x and the closed-loop eigenvalues of a - b k.  Host helper of the callers that build the
+    feedback gains k_fb handed to the reachability functions."""
+    import scipy.linalg as sla
+    a, b = np.atleast_2d(np.asarray(a, dtype=np.float64)), np.atleast_2d(np.asarray(b, dtype=np.float64))
+    q, r = np.atleast_2d(np.asarray(q, dtype=np.float64)), np.atleast_2d(np.asarray(r, dtype=np.float64))
+    x = sla.solve_discrete_are(a, b, q, r)
+    k = np.linalg.solve(b.T.dot(x).dot(b) + r, b.T.dot(x).dot(a))
+    return k, x, np.linalg.eigvals(a - b.dot(k))
+
+
 def array_of_vec_to_array_of_mat(array_of_vec, n, m):
     """(T, n*m) -> (T, n, m) (utils.py:208-227)."""
     return np.reshape(array_of_vec, (-1, n, m))

@@ -470,6 +470,17 @@ def main():
     _save("traj.npz", A=A, Bm=Bm, p_0=p_0, k_ff=k_ff, k_fb=k_fb, p_all=p_all, q_all=q_all, x_all=x_all,
           inside=np.asarray(inside, dtype=bool), h_mat=h_mat, ok_wide=bool(ok_wide), ok_tight=bool(ok_tight), lim=lim)
 
+    # ------------------------------------------------------------------ 8. LQR gains (utils.dlqr, :20-35)
+    rng = np.random.default_rng(3)
+    out = {}
+    for tag, (n, m) in zip("ab", [(2, 1), (4, 2)]):
+        a_ = np.eye(n) + 0.1 * rng.standard_normal((n, n)); b_ = rng.standard_normal((n, m))
+        q_ = np.eye(n) * 2.0; r_ = np.eye(m) * 0.5
+        k_, x_, ev_ = ut.dlqr(a_, b_, q_, r_)
+        out.update({"a_" + tag: a_, "b_" + tag: b_, "q_" + tag: q_, "r_" + tag: r_, "k_" + tag: k_, "x_" + tag: x_,
+                    "ev_" + tag: np.sort_complex(ev_)})
+    _save("dlqr.npz", **out)
+
     # ------------------------------------------------------------------ 5. worked anchor of SURVEY 8c
     p = np.array([[0.1], [-0.2]]); Q = 0.2 * np.array([[.5, .2], [.2, .65]])
     k_ff = np.array([[0.3]]); k_fb = np.array([[0.4, -0.1]])

@@ -247,3 +247,18 @@ def test_reference_casadi_evaluator_runs_on_this_surface(tmp_path, monkeypatch):
     assert stacked.shape == (2 * 2 + 2 * 3, 3)                 # [jac_mu; jac_var; d jac_mu / dz]
     np.testing.assert_allclose(stacked[:2], Linear.A)
     np.testing.assert_allclose(stacked[2:4], np.tile(2 * Linear.w.dot([0.2, -0.1, 0.4]) * Linear.w, (2, 1)))
+
+
+def test_dlqr_and_name_aliases_vs_reference_golden():
+    """utils.dlqr (utils.py:20-35) against the reference's own gains; the reference's module / function names of the
+    moment propagation resolve to the batched numeric implementation."""
+    from safe_exploration_amd import utils
+    g = load_golden("dlqr.npz")
+    for tag in "ab":
+        k, x, ev = utils.dlqr(g["a_" + tag], g["b_" + tag], g["q_" + tag], g["r_" + tag])
+        np.testing.assert_allclose(k, g["k_" + tag], rtol=1e-10)
+        np.testing.assert_allclose(x, g["x_" + tag], rtol=1e-10)
+        np.testing.assert_allclose(np.sort_complex(ev), g["ev_" + tag], rtol=1e-9, atol=1e-12)
+        assert np.abs(ev).max() < 1.0
+    from safe_exploration_amd import uncertainty_propagation_casadi as upc, uncertainty_propagation as up
+    assert upc.multi_step_taylor_symbolic is up.multi_step_taylor and upc.mean_equivalent_multistep is up.mean_equivalent_multistep
