@@ -29,6 +29,7 @@ struct sr_gp {
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr, *kxx = nullptr;
     double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch
+    size_t lin_cap = 0;                                                 // doubles behind lin_v
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 32;
@@ -586,7 +587,39 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         return sr_launch_gp_small_lin(ka, h->Wt, mu, var, jac_mu, jac_var, hess_mu, s);
     }
-    if (!h->lin_v) SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np));
+    if (h->small_path != 0) {
+        // streamed route, every kernel identifier: the columns [k*, dk*/dx_j] go through ONE streaming pass over
+        // U^-1 whose reduce step forms the dot products with the k* column (sr_linearize.hip)
+        const int tq = (1 + h->D) <= 4 ? 4 : SR_SMALL_T;
+        const long Tp = srt::BN;
+        SR_TRY(ensure_ws(h, Tp, pick_nsplit(h, Tp)));
+        const int nblk = (h->Np + 255) / 256;
+        const size_t need = (size_t)h->n_out * nblk * sr_lin_nacc(h->D);
+        if (!h->lin_v || h->lin_cap < need) {
+            (void)hipStreamSynchronize(s);
+            dev_free(h->lin_v);
+            h->lin_v = nullptr; h->lin_cap = 0;
+            SR_TRY(dev_alloc(&h->lin_v, std::max(need, (size_t)h->n_out * h->Np)));
+            h->lin_cap = std::max(need, (size_t)h->n_out * h->Np);
+        }
+        if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
+        sr_lin_args la;
+        la.Z = h->Z; la.alpha = h->alpha; la.ls = h->ls; la.sf2 = h->sf2; la.Ks = h->Ks; la.g = nullptr; la.x = x;
+        la.kp = h->general ? h->kp : nullptr;
+        la.jac_var = jac_var; la.hess_mu = hess_mu;
+        la.N = h->N; la.Np = h->Np; la.D = h->D; la.n_out = h->n_out; la.Tp = Tp;
+        {
+            sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
+            SR_TRY(sr_launch_lin_columns(la, tq, h->Ks, h->lin_v, s));
+        }
+        {
+            sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+            SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, tq == 4 ? 4 : SR_SMALL_T, s, 1));
+        }
+        sr_prof_scope ps(&h->prof, SR_K_FINAL, s);
+        return sr_launch_lin_final(la, h->lin_v, h->var_part, (h->Np + 255) / 256, mu, var, jac_mu, s);
+    }
+    if (!h->lin_v) { SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np)); h->lin_cap = (size_t)h->n_out * h->Np; }
     if (!h->lin_g) SR_TRY(dev_alloc(&h->lin_g, (size_t)h->n_out * h->Np));
     h->force_stream = 1;
     const int rc_pass = gp_pass(h, 1, x, h->D, h->D, nullptr, 0, 0, mu, var, jac_mu, s);   // leaves K*(:,0) in the workspace
@@ -604,7 +637,7 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
                               h->Np, 0, s));                                                       // g = U^-1 v
     }
     sr_lin_args la;
-    la.Z = h->Z; la.alpha = h->alpha; la.ls = h->ls; la.Ks = h->Ks; la.g = h->lin_g; la.x = x;
+    la.Z = h->Z; la.alpha = h->alpha; la.ls = h->ls; la.sf2 = h->sf2; la.Ks = h->Ks; la.g = h->lin_g; la.x = x;
     la.kp = h->general ? h->kp : nullptr;
     la.jac_var = jac_var; la.hess_mu = hess_mu;
     la.N = h->N; la.Np = h->Np; la.D = h->D; la.n_out = h->n_out; la.Tp = Tp;

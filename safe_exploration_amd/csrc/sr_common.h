@@ -182,7 +182,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #define SR_FINAL_WAVE_T 4096   /* up to here sr_finalize runs one wavefront per (query, output) */
 long sr_var_small_ws(int Np, int n_out);
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
-                        long Tp, int n_out, int T, hipStream_t s);
+                        long Tp, int n_out, int T, hipStream_t s, int dot0 = 0);
 
 int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, int T, hipStream_t s);
 int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_out, int T, hipStream_t s);
@@ -230,6 +230,7 @@ int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, c
 // ---- single-query second-order outputs (sr_linearize.hip) --------------------------------------
 struct sr_lin_args {
     const double* Z; const double* alpha; const double* ls; const double* Ks; const double* g;
+    const double* sf2;               // ARD-RBF signal variances (n_out)
     const double* x;                 // D query coordinates
     const double* kp;                // general kernels: n_out x SR_KP(D) packed parameters, else NULL (ARD-RBF)
     double* jac_var; double* hess_mu;   // n_out x D, n_out x D x D
@@ -237,3 +238,7 @@ struct sr_lin_args {
 };
 int sr_launch_trmv_t(const double* M, long ld, const double* x, long xs, double* y, int n, hipStream_t s);
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s);
+int sr_lin_nacc(int D);
+int sr_launch_lin_columns(const sr_lin_args& a, int tq, double* Ks, double* lin_part, hipStream_t s);
+int sr_launch_lin_final(const sr_lin_args& a, const double* lin_part, const double* dots, int ncb, double* mu,
+                        double* var, double* jac_mu, hipStream_t s);

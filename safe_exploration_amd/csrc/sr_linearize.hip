@@ -199,6 +199,220 @@ __global__ __launch_bounds__(256) void sr_linearize_general_kernel(sr_lin_args a
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streamed route (any model size, every kernel identifier): ONE pass over U^-1 instead of two.
+//   d var/dx_j = d k(x,x)/dx_j - 2 (U^-T dk*/dx_j) . (U^-T k*)
+// so the right-hand sides [k*, dk*/dx_1 .. dk*/dx_D] go through the streaming contraction of the prediction
+// path (sr_var_small_*, 1 + D <= 16 columns) whose reduce pass forms the dot products with column 0; mean,
+// mean-Jacobian and mean-Hessian are plain reductions over the training points done while the columns are written.
+//   sr_lin_columns_kernel : grid (Np/256, n_out) -- columns into the K* workspace + partial sums per workgroup
+//   sr_lin_final_kernel   : grid (n_out)         -- adds the partials, writes the five outputs
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void sr_lin_columns_kernel(sr_lin_args a, int tq, double* __restrict__ Ks,
+                                                             double* __restrict__ lin_part) {
+    constexpr int NH = DT * (DT + 1) / 2;
+    constexpr int NACC = 1 + DT + NH;                  // mu, d mu/dx, upper triangle of the Hessian
+    __shared__ double red[4][NACC];
+    const int d = blockIdx.y;
+    const int ip = blockIdx.x * 256 + threadIdx.x;       // padded training index
+    const int off = a.Np - a.N;
+    const bool valid = ip < a.Np && ip >= off;
+    double acc[NACC];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
+    double col[DT + 1];
+#pragma unroll
+    for (int c = 0; c <= DT; ++c) col[c] = 0.0;
+    if (valid) {
+        const int i = ip - off;
+        const double w = a.alpha[(long)d * a.Np + ip];
+        double z[DT], u[DT], x[DT], r2 = 0.0;
+        if (a.kp == nullptr) {                           // ARD-RBF: u_j = (z_j - x_j) / l_j^2
+            double il2[DT];
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const double l = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
+                il2[j] = (j < a.D) ? 1.0 / (l * l) : 0.0;
+                z[j] = (j < a.D) ? a.Z[(long)i * a.D + j] : 0.0;
+                x[j] = (j < a.D) ? a.x[j] : 0.0;
+                u[j] = (z[j] - x[j]) * il2[j];
+                r2 = fma(u[j], z[j] - x[j], r2);
+            }
+            const double k = a.sf2[d] * exp(-0.5 * r2);
+            col[0] = k;
+            acc[0] = w * k;
+            int q = 1 + DT;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                col[1 + j] = k * u[j];
+                acc[1 + j] = w * k * u[j];
+#pragma unroll
+                for (int c = 0; c < DT; ++c)
+                    if (c >= j) {
+                        double hv = u[j] * u[c];
+                        if (c == j) hv -= il2[j];
+                        acc[q] = w * k * hv;
+                        ++q;
+                    }
+            }
+        } else {                                         // general family, formulas of sr_linearize_general_kernel
+            const double* kp = a.kp + (long)d * SR_KP(a.D);
+            const int kind = (int)kp[0];
+            const double var = kp[1], c0 = kp[2];
+            double s2[DT], av[DT], bv[DT], la = 0.0, lb = 0.0;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const double sj = (j < a.D) ? kp[3 + j] : 0.0;
+                s2[j] = sj * sj;
+                av[j] = (j < a.D) ? kp[3 + a.D + j] : 0.0;
+                bv[j] = (j < a.D) ? kp[3 + 2 * a.D + j] : 0.0;
+                z[j] = (j < a.D) ? a.Z[(long)i * a.D + j] : 0.0;
+                x[j] = (j < a.D) ? a.x[j] : 0.0;
+                const double df = x[j] - z[j];
+                u[j] = s2[j] * df;
+                r2 = fma(u[j], df, r2);
+                la = fma(av[j] * x[j], z[j], la);
+                lb = fma(bv[j] * x[j], z[j], lb);
+            }
+            double kap, g, h;
+            if (kind == 0) {
+                kap = exp(-0.5 * r2);
+                g = -kap;
+                h = kap;
+            } else {
+                const double rr = sqrt(r2);
+                const double e = exp(-2.23606797749978969641 * rr);
+                kap = (1.0 + 2.23606797749978969641 * rr + (5.0 / 3.0) * r2) * e;
+                g = -(5.0 / 3.0) * (1.0 + 2.23606797749978969641 * rr) * e;
+                h = (25.0 / 3.0) * e;
+            }
+            const double pre = (c0 + la) * var;
+            const double k = fma(pre, kap, lb);
+            col[0] = k;
+            acc[0] = w * k;
+            const double vk = var * kap, pg = pre * g, ph = pre * h, vg = var * g;
+            int q = 1 + DT;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const double azj = av[j] * z[j];
+                const double dk = fma(vk, azj, fma(pg, u[j], bv[j] * z[j]));
+                col[1 + j] = dk;
+                acc[1 + j] = w * dk;
+#pragma unroll
+                for (int c = 0; c < DT; ++c)
+                    if (c >= j) {
+                        double hv = fma(vg, fma(azj, u[c], av[c] * z[c] * u[j]), ph * u[j] * u[c]);
+                        if (c == j) hv = fma(pg, s2[j], hv);
+                        acc[q] = w * hv;
+                        ++q;
+                    }
+            }
+        }
+    }
+    if (ip < a.Np) {
+        double* dst = Ks + ((long)d * a.Np + ip) * a.Tp;
+#pragma unroll
+        for (int c = 0; c <= DT; ++c)
+            if (c < tq) dst[c] = (c <= a.D) ? col[c] : 0.0;
+        for (int c = DT + 1; c < tq; ++c) dst[c] = 0.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) {
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC)
+        lin_part[((long)d * gridDim.x + blockIdx.x) * NACC + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void sr_lin_final_kernel(sr_lin_args a, const double* __restrict__ lin_part,
+                                                          int nblk, const double* __restrict__ dots, int ncb,
+                                                          double* __restrict__ mu, double* __restrict__ var,
+                                                          double* __restrict__ jac_mu) {
+    constexpr int NH = DT * (DT + 1) / 2;
+    constexpr int NACC = 1 + DT + NH;
+    __shared__ double tot[NACC], dt[DT + 1];
+    const int d = blockIdx.x, t = threadIdx.x;
+    if (t < NACC) {
+        double v = 0.0;
+        for (int b = 0; b < nblk; ++b) v += lin_part[((long)d * nblk + b) * NACC + t];
+        tot[t] = v;
+    }
+    if (t <= DT) {
+        double v = 0.0;
+        if (t <= a.D)
+            for (int cb = 0; cb < ncb; ++cb) v += dots[((long)d * ncb + cb) * a.Tp + t];
+        dt[t] = v;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double kxx, x2a = 0.0;
+        if (a.kp == nullptr) kxx = a.sf2[d];
+        else {
+            const double* kp = a.kp + (long)d * SR_KP(a.D);
+            for (int j = 0; j < a.D; ++j) x2a = fma((kp[3 + a.D + j] * kp[1] + kp[3 + 2 * a.D + j]) * a.x[j], a.x[j], x2a);
+            kxx = kp[2] * kp[1] + x2a;
+        }
+        double v = kxx - dt[0];
+        if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+        mu[d] = tot[0];
+        var[d] = v;
+    }
+    if (t < a.D) {
+        jac_mu[d * a.D + t] = tot[1 + t];
+        double dkxx = 0.0;
+        if (a.kp != nullptr) {
+            const double* kp = a.kp + (long)d * SR_KP(a.D);
+            dkxx = 2.0 * (kp[3 + a.D + t] * kp[1] + kp[3 + 2 * a.D + t]) * a.x[t];
+        }
+        a.jac_var[d * a.D + t] = dkxx - 2.0 * dt[1 + t];
+    }
+    if (t < a.D * a.D) {
+        const int j = min(t / a.D, t % a.D), c = max(t / a.D, t % a.D);
+        // position of (j, c), j <= c, in the DT-wide upper-triangle enumeration
+        const int q = 1 + DT + j * DT - j * (j - 1) / 2 + (c - j);
+        a.hess_mu[(long)d * a.D * a.D + t] = tot[q];
+    }
+}
+
+int sr_launch_lin_columns(const sr_lin_args& a, int tq, double* Ks, double* lin_part, hipStream_t s) {
+    dim3 grid((a.Np + 255) / 256, a.n_out);
+#define SR_LC_CASE(DT) hipLaunchKernelGGL(sr_lin_columns_kernel<DT>, grid, dim3(256), 0, s, a, tq, Ks, lin_part)
+    if (a.D <= 3) SR_LC_CASE(3);
+    else if (a.D <= 5) SR_LC_CASE(5);
+    else if (a.D <= 8) SR_LC_CASE(8);
+    else if (a.D <= 12) SR_LC_CASE(12);
+    else { sr_set_error("linearize: D=%d > %d", a.D, SR_MAX_D); return SR_EUNSUPPORTED; }
+#undef SR_LC_CASE
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_lin_nacc(int D) {
+    const int DT = D <= 3 ? 3 : (D <= 5 ? 5 : (D <= 8 ? 8 : 12));
+    return 1 + DT + DT * (DT + 1) / 2;
+}
+
+int sr_launch_lin_final(const sr_lin_args& a, const double* lin_part, const double* dots, int ncb, double* mu,
+                        double* var, double* jac_mu, hipStream_t s) {
+    const int nblk = (a.Np + 255) / 256;
+    // NACC <= 91 (D = 12) and D*D <= 144 threads are needed: one block of 256 covers every case
+#define SR_LF_CASE(DT) hipLaunchKernelGGL(sr_lin_final_kernel<DT>, dim3(a.n_out), dim3(256), 0, s, a, lin_part, nblk, dots, ncb, mu, var, jac_mu)
+    if (a.D <= 3) SR_LF_CASE(3);
+    else if (a.D <= 5) SR_LF_CASE(5);
+    else if (a.D <= 8) SR_LF_CASE(8);
+    else SR_LF_CASE(12);
+#undef SR_LF_CASE
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s) {
     dim3 grid(a.n_out);
     if (a.kp) {

@@ -568,21 +568,32 @@ __global__ __launch_bounds__(256) void sr_var_small_partial_kernel(const double*
     for (int t = 0; t < TQ; ++t) out[t * 256 + threadIdx.x] = acc[t];
 }
 
-// part[cb][t] = sum_{i in column block cb} (sum_chunks Vp)^2 ; grid (ncb, n_out, tq): one query per workgroup
+// part[cb][t] = sum_{i in column block cb} V_t[i] * (dot0 ? V_0[i] : V_t[i]),  V_t = sum_chunks Vp ;
+// grid (ncb, n_out, tq): one query (column) per workgroup.  dot0 serves sr_gp_linearize, whose columns are
+// [k*, dk*/dx_j] and whose outputs are the dot products with the k* column.
 __global__ __launch_bounds__(256) void sr_var_small_reduce_kernel(const double* __restrict__ Vp,
                                                                   double* __restrict__ part, long Tp,
-                                                                  int npairs, int ncb, int tq) {
+                                                                  int npairs, int ncb, int tq, int dot0) {
     __shared__ double red[4];
     const int cb = blockIdx.x, d = blockIdx.y, t = blockIdx.z;
     const int p0 = cb * (cb + 1), nch = 2 * cb + 2;
     const double* src = Vp + (((long)d * npairs + p0) * tq + t) * 256 + threadIdx.x;
     double v0 = 0.0, v1 = 0.0;
-    int j = 0;
-    for (; j + 1 < nch; j += 2) {
+    for (int j = 0; j + 1 < nch; j += 2) {
         v0 += src[(long)j * tq * 256];
         v1 += src[(long)(j + 1) * tq * 256];
     }
-    double q = (v0 + v1) * (v0 + v1);
+    double w = v0 + v1;
+    if (dot0 && t != 0) {
+        const double* s0 = Vp + (((long)d * npairs + p0) * tq) * 256 + threadIdx.x;
+        double w0 = 0.0, w1 = 0.0;
+        for (int j = 0; j + 1 < nch; j += 2) {
+            w0 += s0[(long)j * tq * 256];
+            w1 += s0[(long)(j + 1) * tq * 256];
+        }
+        w = w0 + w1;
+    }
+    double q = (v0 + v1) * w;
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
     __syncthreads();
@@ -648,7 +659,7 @@ long sr_var_small_ws(int Np, int n_out) {
 }
 
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
-                        long Tp, int n_out, int T, hipStream_t s) {
+                        long Tp, int n_out, int T, hipStream_t s, int dot0) {
     const int ncb = (Np + 255) / 256;              // Np is a multiple of 128: the last block may be half empty
     const int npairs = ncb * (ncb + 1);
     const int k_lo = Np - N;
@@ -664,7 +675,7 @@ int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* 
     SR_HIP(hipGetLastError());
     const int tq = small_tq(T);
     hipLaunchKernelGGL(sr_var_small_reduce_kernel, dim3(ncb, n_out, tq), dim3(256), 0, s, Vp, part, Tp,
-                       npairs, ncb, tq);
+                       npairs, ncb, tq, dot0);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

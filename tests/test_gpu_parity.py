@@ -1054,3 +1054,38 @@ def test_config4_identities_at_a_panelled_size():
         np.testing.assert_allclose(var[:, d], s2n[d] - s2n[d] ** 2 * kinv_ii, rtol=0, atol=1e-11)
     om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
     np.testing.assert_allclose(alpha, om["beta"], rtol=1e-6, atol=1e-8 * np.abs(om["beta"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kt,N,n_s,n_u", [("rbf", 700, 2, 1), ("rbf", 1300, 4, 1), ("rbf", 600, 3, 2), ("mat52", 650, 2, 1),
+                                          ("lin_mat52", 900, 2, 1), ("lin_rbf", 130, 2, 1)])
+def test_streamed_linearize_all_kernels(kt, N, n_s, n_u):
+    """linearize_predict(jacobians=True) beyond the one-launch sizes: the columns [k*, dk*/dx_j] take ONE streaming pass
+    over U^-1 (d var/dx_j = d k(x,x)/dx_j - 2 (U^-T dk*/dx_j).(U^-T k*)).  Against the oracle's closed forms and
+    against the two-pass route of the same library (set_small_path(0))."""
+    from safe_exploration_amd import SimpleGPModel
+    rng = np.random.default_rng(70 + N)
+    D = n_s + n_u
+    Z = rng.uniform(-1, 1, (N, D))
+    Y = rng.standard_normal((N, n_s))
+    hyp = [orc.make_hyp(kt, rng, D) for _ in range(n_s)]
+    noise = np.full(n_s, 0.02)
+    beta, inv_K = orc.gp_fit_k(Z, Y, [kt] * n_s, hyp, noise + 1e-5)
+    gp = SimpleGPModel(n_s, n_s, n_u, kern_types=[kt] * n_s, hyp=[dict(h, noise_variance=nv) for h, nv in zip(hyp, noise)])
+    gp.train(Z, Y, opt_hyp=False)
+    x = rng.uniform(-0.6, 0.6, D)
+    mu, var, jm, jv, hm = gp.linearize_predict(x[None, :n_s], x[None, n_s:], True)
+    rmu, rvar = orc.gp_predict_k(x[None], Z, beta, inv_K, [kt] * n_s, hyp)
+    rjv, rhm = orc.gp_linearize_extras_k(x, Z, beta, inv_K, [kt] * n_s, hyp)
+    scale = max(np.abs(beta).sum(0).max(), 1.0)
+    np.testing.assert_allclose(mu[:, 0], rmu[0], rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(var[:, 0], rvar[0], rtol=0, atol=1e-8 * max(1.0, float(rvar.max())))
+    np.testing.assert_allclose(jm, orc.gp_mean_jacobian_fd(x[None], Z, beta, [kt] * n_s, hyp)[0], rtol=2e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(jv, rjv, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(rjv).max()))
+    np.testing.assert_allclose(hm, rhm, rtol=1e-8, atol=1e-10 * scale)
+    np.testing.assert_array_equal(hm, np.swapaxes(hm, 1, 2))
+    gp.set_small_path(0)                                   # K1 -> K2 -> K3, U^-1 (U^-T k*), reduction kernel
+    out0 = gp.linearize_predict(x[None, :n_s], x[None, n_s:], True)
+    gp.set_small_path(1)
+    for a_, b_, tol in zip((mu, var, jm, jv, hm), out0, (1e-12 * scale, 1e-11, 1e-11 * scale, 1e-9, 1e-10 * scale)):
+        np.testing.assert_allclose(a_, b_, rtol=1e-8, atol=tol)
