@@ -231,7 +231,8 @@ int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, c
 struct sr_lin_args {
     const double* Z; const double* alpha; const double* ls; const double* Ks; const double* g;
     const double* sf2;               // ARD-RBF signal variances (n_out)
-    const double* x;                 // D query coordinates
+    const double* x;                 // D query coordinates (or the first na of them when xb is set)
+    const double* xb = nullptr; int na = 0;   // streamed route: coordinates na .. D-1 come from xb
     const double* kp;                // general kernels: n_out x SR_KP(D) packed parameters, else NULL (ARD-RBF)
     double* jac_var; double* hess_mu;   // n_out x D, n_out x D x D
     int N, Np, D, n_out; long Tp;

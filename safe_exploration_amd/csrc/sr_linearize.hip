@@ -208,6 +208,12 @@ __global__ __launch_bounds__(256) void sr_linearize_general_kernel(sr_lin_args a
 //   sr_lin_columns_kernel : grid (Np/256, n_out) -- columns into the K* workspace + partial sums per workgroup
 //   sr_lin_final_kernel   : grid (n_out)         -- adds the partials, writes the five outputs
 // ------------------------------------------------------------------------------------------------
+// query coordinate j: the first na from x, the rest from xb (the reachability entry points hand p and k_ff
+// separately); xb == NULL means all D coordinates are in x
+__device__ __forceinline__ double sr_lin_x(const sr_lin_args& a, int j) {
+    return (a.xb && j >= a.na) ? a.xb[j - a.na] : a.x[j];
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void sr_lin_columns_kernel(sr_lin_args a, int tq, double* __restrict__ Ks,
                                                              double* __restrict__ lin_part) {
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void sr_lin_columns_kernel(sr_lin_args a, int 
                 const double l = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
                 il2[j] = (j < a.D) ? 1.0 / (l * l) : 0.0;
                 z[j] = (j < a.D) ? a.Z[(long)i * a.D + j] : 0.0;
-                x[j] = (j < a.D) ? a.x[j] : 0.0;
+                x[j] = (j < a.D) ? sr_lin_x(a, j) : 0.0;
                 u[j] = (z[j] - x[j]) * il2[j];
                 r2 = fma(u[j], z[j] - x[j], r2);
             }
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void sr_lin_columns_kernel(sr_lin_args a, int 
                 av[j] = (j < a.D) ? kp[3 + a.D + j] : 0.0;
                 bv[j] = (j < a.D) ? kp[3 + 2 * a.D + j] : 0.0;
                 z[j] = (j < a.D) ? a.Z[(long)i * a.D + j] : 0.0;
-                x[j] = (j < a.D) ? a.x[j] : 0.0;
+                x[j] = (j < a.D) ? sr_lin_x(a, j) : 0.0;
                 const double df = x[j] - z[j];
                 u[j] = s2[j] * df;
                 r2 = fma(u[j], df, r2);
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void sr_lin_final_kernel(sr_lin_args a, const 
         if (a.kp == nullptr) kxx = a.sf2[d];
         else {
             const double* kp = a.kp + (long)d * SR_KP(a.D);
-            for (int j = 0; j < a.D; ++j) x2a = fma((kp[3 + a.D + j] * kp[1] + kp[3 + 2 * a.D + j]) * a.x[j], a.x[j], x2a);
+            for (int j = 0; j < a.D; ++j) x2a = fma((kp[3 + a.D + j] * kp[1] + kp[3 + 2 * a.D + j]) * sr_lin_x(a, j), sr_lin_x(a, j), x2a);
             kxx = kp[2] * kp[1] + x2a;
         }
         double v = kxx - dt[0];
@@ -365,15 +371,15 @@ __global__ __launch_bounds__(256) void sr_lin_final_kernel(sr_lin_args a, const 
         var[d] = v;
     }
     if (t < a.D) {
-        jac_mu[d * a.D + t] = tot[1 + t];
+        if (jac_mu) jac_mu[d * a.D + t] = tot[1 + t];
         double dkxx = 0.0;
         if (a.kp != nullptr) {
             const double* kp = a.kp + (long)d * SR_KP(a.D);
-            dkxx = 2.0 * (kp[3 + a.D + t] * kp[1] + kp[3 + 2 * a.D + t]) * a.x[t];
+            dkxx = 2.0 * (kp[3 + a.D + t] * kp[1] + kp[3 + 2 * a.D + t]) * sr_lin_x(a, t);
         }
-        a.jac_var[d * a.D + t] = dkxx - 2.0 * dt[1 + t];
+        if (a.jac_var) a.jac_var[d * a.D + t] = dkxx - 2.0 * dt[1 + t];
     }
-    if (t < a.D * a.D) {
+    if (a.hess_mu && t < a.D * a.D) {
         const int j = min(t / a.D, t % a.D), c = max(t / a.D, t % a.D);
         // position of (j, c), j <= c, in the DT-wide upper-triangle enumeration
         const int q = 1 + DT + j * DT - j * (j - 1) / 2 + (c - j);
