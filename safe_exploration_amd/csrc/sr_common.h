@@ -181,6 +181,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #endif
 #define SR_FINAL_WAVE_T 4096   /* up to here sr_finalize runs one wavefront per (query, output) */
 long sr_var_small_ws(int Np, int n_out);
+int sr_var_small_groups_max(int Np, int n_out);   // query groups of 16 the streaming path may take (1 .. 8)
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
                         long Tp, int n_out, int T, hipStream_t s, int dot0 = 0);
 

@@ -568,6 +568,68 @@ __global__ __launch_bounds__(256) void sr_var_small_partial_kernel(const double*
     for (int t = 0; t < TQ; ++t) out[t * 256 + threadIdx.x] = acc[t];
 }
 
+// 16 live queries: the VALU kernel above spends 16 FMAs and 8 broadcast LDS reads per loaded element (LDS-issue
+// bound at ~5 TB/s, and 7 us of serial work per workgroup); here the same (column block, k-chunk) pair is one
+// workgroup of 16 wavefronts, wavefront w owning the 16-column strip w on the MFMA 16x16x4 tile: A-fragments
+// straight from global (the 16 strips of a row are one contiguous 2 KiB segment), B-fragments = the K* rows in
+// LDS, one ds_read_b64 per MFMA.  Same Vp layout as the VALU kernel (the reduce / gather kernels are shared).
+__global__ __launch_bounds__(1024) void sr_var_small_partial_mfma_kernel(const double* __restrict__ Wt,
+                                                                         const double* __restrict__ Ks,
+                                                                         double* __restrict__ Vp, int Np,
+                                                                         long Tp, int npairs, int k_lo) {
+    __shared__ double ks[128][SR_TS];
+    const int d = blockIdx.y;
+    const int p = blockIdx.x;
+    const int grp = blockIdx.z;                          // group of 16 queries (columns grp*16 .. grp*16+15 of K*)
+    int cb = (int)((sqrt(4.0 * p + 1.0) - 1.0) * 0.5);
+    while ((cb + 1) * (cb + 2) <= p) ++cb;
+    while (cb * (cb + 1) > p) --cb;
+    const int j = p - cb * (cb + 1);
+    const int k0 = j * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
+    const double* ksrc = Ks + (long)d * Np * Tp + (long)k0 * Tp + grp * SR_TS;
+    for (int e = threadIdx.x; e < 128 * SR_TS; e += 1024) {
+        const int r = e / SR_TS, t = e % SR_TS;
+        ks[r][t] = (k0 + r < Np) ? ksrc[(long)r * Tp + t] : 0.0;
+    }
+    __syncthreads();
+    const int i0 = cb * 256 + 16 * wave;                 // first column of this strip
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    if (i0 < Np) {
+        // k-steps of 4 rows: rows k0 + 4u + lk.  Rows beyond the strip's last column hold zeros of U^-1 (skipped),
+        // rows in front of k_lo carry K* == 0 (skipped at k-step granularity).
+        const int u_end = min(32, (i0 + 15 - k0) / 4 + 1);
+        int u = max(0, (k_lo - k0) / 4);
+        const double* w = Wt + (long)d * Np * Np + (long)(k0 + lk) * Np + i0 + ln;
+        for (; u + 16 <= u_end; u += 16) {
+            double af[16], bf[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) af[q] = w[(long)(4 * (u + q)) * Np];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bf[q] = ks[4 * (u + q) + lk][ln];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bf[q], acc, 0, 0, 0);
+        }
+        for (; u + 4 <= u_end; u += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) af[q] = w[(long)(4 * (u + q)) * Np];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bf[q] = ks[4 * (u + q) + lk][ln];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], bf[q], acc, 0, 0, 0);
+        }
+        for (; u < u_end; ++u)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[(long)(4 * u) * Np], ks[4 * u + lk][ln], acc, 0, 0, 0);
+    }
+    // acc[r] = V[column i0 + lk + 4r][query ln]
+    double* out = Vp + (((long)grp * gridDim.y + d) * npairs + p) * SR_TS * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[ln * 256 + 16 * wave + lk + 4 * r] = acc[r];
+}
+
 // part[cb][t] = sum_{i in column block cb} V_t[i] * (dot0 ? V_0[i] : V_t[i]),  V_t = sum_chunks Vp ;
 // grid (ncb, n_out, tq): one query (column) per workgroup.  dot0 serves sr_gp_linearize, whose columns are
 // [k*, dk*/dx_j] and whose outputs are the dot products with the k* column.
@@ -575,8 +637,9 @@ __global__ __launch_bounds__(256) void sr_var_small_reduce_kernel(const double* 
                                                                   double* __restrict__ part, long Tp,
                                                                   int npairs, int ncb, int tq, int dot0) {
     __shared__ double red[4];
-    const int cb = blockIdx.x, d = blockIdx.y, t = blockIdx.z;
+    const int cb = blockIdx.x, d = blockIdx.y, t = blockIdx.z % tq, grp = blockIdx.z / tq;
     const int p0 = cb * (cb + 1), nch = 2 * cb + 2;
+    Vp += (long)grp * gridDim.y * npairs * tq * 256;     // query groups of the MFMA streaming kernel
     const double* src = Vp + (((long)d * npairs + p0) * tq + t) * 256 + threadIdx.x;
     double v0 = 0.0, v1 = 0.0;
     for (int j = 0; j + 1 < nch; j += 2) {
@@ -597,7 +660,7 @@ __global__ __launch_bounds__(256) void sr_var_small_reduce_kernel(const double* 
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
     __syncthreads();
-    if (threadIdx.x == 0) part[((long)d * ncb + cb) * Tp + t] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) part[((long)d * ncb + cb) * Tp + grp * tq + t] = red[0] + red[1] + red[2] + red[3];
 }
 
 // v[d][i] = sum_chunks Vp[..][t][i]  (= (U^-T k*_t)[i]) -- reused by sr_gp_linearize
@@ -655,7 +718,17 @@ int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, i
 // workspace need of the small path: n_out * npairs * SR_TS * 256 doubles for Vp
 long sr_var_small_ws(int Np, int n_out) {
     const int ncb = (Np + 255) / 256;
-    return (long)n_out * ncb * (ncb + 1) * SR_TS * 256;
+    return (long)n_out * ncb * (ncb + 1) * SR_TS * 256 * sr_var_small_groups_max(Np, n_out);
+}
+
+// The MFMA streaming kernel also serves 17 .. 128 queries as groups of 16 (every group re-reads U^-1 from
+// L2 / Infinity Cache) as long as that stays cheap: n_out Np^2/2 8 B x groups <= 300 MB.  Measured at N = 700,
+// T = 128: 41 -> 25 us against the split-K tiles; N = 2000: 71 -> 40 us; from N = 3000 on the tiles win.
+int sr_var_small_groups_max(int Np, int n_out) {
+    const double bytes = (double)n_out * Np * (double)Np * 4.0;
+    int g = (int)(300e6 / bytes);
+    if (g > 8) g = 8;
+    return g < 1 ? 1 : g;
 }
 
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
@@ -663,6 +736,7 @@ int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* 
     const int ncb = (Np + 255) / 256;              // Np is a multiple of 128: the last block may be half empty
     const int npairs = ncb * (ncb + 1);
     const int k_lo = Np - N;
+    const int groups = T > SR_TS ? (T + SR_TS - 1) / SR_TS : 1;
     // plain (cached) loads: at N = 5000 the 210 MB of U^-1 stay in the 256 MB Infinity Cache between calls --
     // measured 6.8 TB/s effective; non-temporal loads were 14 % slower
 #define SR_SMALL_LAUNCH(TQ)                                                                              \
@@ -670,11 +744,13 @@ int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* 
                        Tp, npairs, k_lo)
     if (T <= 1) SR_SMALL_LAUNCH(1);
     else if (T <= 4) SR_SMALL_LAUNCH(4);
-    else SR_SMALL_LAUNCH(SR_TS);
+    else
+        hipLaunchKernelGGL(sr_var_small_partial_mfma_kernel, dim3(npairs, n_out, groups), dim3(1024), 0, s, Wt, Ks, Vp,
+                           Np, Tp, npairs, k_lo);
 #undef SR_SMALL_LAUNCH
     SR_HIP(hipGetLastError());
     const int tq = small_tq(T);
-    hipLaunchKernelGGL(sr_var_small_reduce_kernel, dim3(ncb, n_out, tq), dim3(256), 0, s, Vp, part, Tp,
+    hipLaunchKernelGGL(sr_var_small_reduce_kernel, dim3(ncb, n_out, tq * groups), dim3(256), 0, s, Vp, part, Tp,
                        npairs, ncb, tq, dot0);
     SR_HIP(hipGetLastError());
     return SR_OK;
