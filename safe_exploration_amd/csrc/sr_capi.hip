@@ -516,7 +516,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     const double* var_part = h->var_part;
     h->last_streamed = 0;
     if (h->small_path && ((Tc <= SR_SMALL_T && (h->Np > SR_STREAM_MIN_NP || h->force_stream)) ||
-                          (h->small_path == 1 && h->Np > SR_FUSED_NP &&
+                          (h->small_path == 1 && h->Np > SR_STREAM_MIN_NP &&
                            Tc <= (long)SR_SMALL_T * sr_var_small_groups_max(h->Np, h->n_out)))) {
         h->last_streamed = 1;
         // latency regime: stream U^-1 once (HBM-bound) instead of the MFMA tiles

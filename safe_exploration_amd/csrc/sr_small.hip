@@ -376,7 +376,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_general_kernel(sr_kstar_args
 
 bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
     (void)general;   // ARD-RBF and the general family both have a one-launch kernel
-    if (Np == 512 && T <= 4) return false;   // measured: streaming U^-1 (K2s) 22 us against 28 us here
+    if (Np == 512 && T <= 128) return false;  // measured: streaming U^-1 (K2s, groups of 16 queries) 22-23 us against 28 us here
     return Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
 }
 
