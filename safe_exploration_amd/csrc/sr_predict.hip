@@ -721,13 +721,13 @@ long sr_var_small_ws(int Np, int n_out) {
     return (long)n_out * ncb * (ncb + 1) * SR_TS * 256 * sr_var_small_groups_max(Np, n_out);
 }
 
-// The MFMA streaming kernel also serves 17 .. 128 queries as groups of 16 (every group re-reads U^-1 from
+// The MFMA streaming kernel also serves 17 .. 1024 queries as groups of 16 (every group re-reads U^-1 from
 // L2 / Infinity Cache) as long as that stays cheap: n_out Np^2/2 8 B x groups <= 300 MB.  Measured at N = 700,
 // T = 128: 41 -> 25 us against the split-K tiles; N = 2000: 71 -> 40 us; from N = 3000 on the tiles win.
 int sr_var_small_groups_max(int Np, int n_out) {
     const double bytes = (double)n_out * Np * (double)Np * 4.0;
     int g = (int)(300e6 / bytes);
-    if (g > 8) g = 8;
+    if (g > 64) g = 64;
     return g < 1 ? 1 : g;
 }
 
