@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- one-step reachability throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2p|c2|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2p|c2|c3|c5|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks
+(torch.multiprocessing.spawn, one per GPU, rendezvous on 127.0.0.1); under torch.distributed.run the
+ranks it finds are used as they are.  Either way the backend is "nccl" (= RCCL on ROCm).
 
 One *step* = one pass of the hot path over one batch of T synthetic query states per GPU:
 GP posterior (mu, var, d mu/dx at z=[p;k_ff]) + ellipsoid branch of onestep_reachability, through
@@ -96,18 +100,128 @@ def cpu_baseline(prob, l_mu, l_sigma, budget_s=12.0):
                                    "BLAS threads as above)" % nq}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2p", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2p", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--queries", type=int, default=0, help="override T per GPU")
+    ap.add_argument("--n-train", type=int, default=0, help="override the number of training points")
     ap.add_argument("--var-group", type=int, default=0)
     ap.add_argument("--var-variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned_rank(local_rank, argv, world, port):
+    """One rank of a self-launched run: the environment torch.distributed.run would have provided."""
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (RCCL)
+    run(parse_args(argv))
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU
+        import torch
+        import torch.multiprocessing as mp
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("--gpus %d but only %d device(s) visible" % (args.gpus, have))
+        mp.spawn(_spawned_rank, args=(list(sys.argv[1:] if argv is None else argv), args.gpus, _free_port()),
+                 nprocs=args.gpus, join=True)
+        return
+    run(args)
+
+
+def run_model_update(args, dev, world, rank):
+    """--workload c4 (BASELINE configs[3]): one *step* = one model update of a GP with N training points and
+    n_out = 2 outputs -- Gram matrix, blocked fp64 Cholesky with MFMA trailing updates, explicit U^-1, alpha --
+    through sr_gp_set_data + sr_gp_factorize.  N = 50000 unless --n-train says otherwise (the 40 GB of factors stay
+    resident in HBM).  value = algorithmic TFLOP/s, (2/3) N^3 n_out per update (potrf N^3/3 + trtri N^3/3).
+    Every rank updates its own replica of the model (the path has no exchange step); value sums over ranks."""
+    import torch
+    import torch.distributed as dist
+    from safe_exploration_amd import SimpleGPModel, workload, _lib
+    N = args.n_train or 50000
+    n_s, n_u = 2, 1
+    prob = workload.make_problem(4, N, n_s, n_u, 16)
+    gp = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device=dev)
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)          # first update allocates the factors
+    for _ in range(max(args.warmup - 1, 0)):
+        gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+    gp.prof_reset()
+    gp.prof_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gp.train(prob["Z"], prob["Y"], opt_hyp=False)      # same shape: refactorises in place
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gp.prof_enable(False)
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    # posterior identities at the training inputs (no CPU oracle reaches N = 50000): K_y alpha = y
+    idx = np.random.default_rng(0).choice(N, min(N, 1024), replace=False)
+    s2n = prob["noise_var"] + 1e-5 + 1e-8
+    mu, var = gp.predict(prob["Z"][idx])
+    res_mu = float(np.abs(mu + s2n[None, :] * gp.beta[idx] - prob["Y"][idx]).max())
+    assert res_mu < 1e-7, "posterior identity violated: %g" % res_mu
+    if rank == 0:
+        flops = n_s * (2.0 / 3.0) * float(N) ** 3
+        per = elapsed / args.steps
+        ms = {k: gp.prof_get(i) for k, i in (("sr_gram_kernel", _lib.K_GRAM), ("sr_potrf_diag_kernel", _lib.K_POTRF),
+                                              ("sr_gemm_tn_kernel[cholesky]", _lib.K_GEMM),
+                                              ("sr_gemm_tn_kernel[inverse]", _lib.K_TRINV))}
+        gemm_ms = ms["sr_gemm_tn_kernel[cholesky]"][0] + ms["sr_gemm_tn_kernel[inverse]"][0]
+        line = {
+            "metric": "GP model update TFLOP/s (blocked fp64 Cholesky + explicit triangular inverse), N=%d train pts" % N,
+            "value": world * flops / per / 1e12, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * per, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4 pendulum dims n_out=2, N=%d training points, model update "
+                                   "(sr_gp_set_data + sr_gp_factorize), factors HBM-resident (%.1f GB), fp64"
+                                   % (N, n_s * gp._handle.Np ** 2 * 8 / 1e9),
+                       "N": N, "n_out": n_s, "parallelism": "replica x%d (no exchange step)" % world,
+                       "max|mu(z)+s2n*alpha-y|": res_mu},
+            "roofline": {"kernel": "sr_gemm_tn_kernel", "bound": "mfma", "achieved": flops / per / 1e12,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / per / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_step": flops,
+                         "note": "achieved = (2/3) N^3 n_out / wall time of the whole update (all kernels, both "
+                                 "outputs); kernel_ms_per_step sums hipEvent pairs per launch (outputs overlap on "
+                                 "their own streams, so the sum can exceed the wall time)"},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in ms.items()},
+            "kernel_launches_per_step": {k: v[1] / args.steps for k, v in ms.items()},
+            "gemm_TFLOPs_over_gemm_ms": flops / max(gemm_ms / args.steps, 1e-9) / 1e9,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run(args):
     import torch
     import torch.distributed as dist
     from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload, parallel
@@ -117,18 +231,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = "single process"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "%s world=%d" % (dist.get_backend(), dist.get_world_size())   # what RCCL itself reports
 
+    if args.workload == "c4":
+        return run_model_update(args, dev, world, rank)
     desc, seed, N, n_s, n_u, T, H, sf2, a_scale = WORKLOADS[args.workload]
     if args.queries:
         T = args.queries
+    if args.n_train:
+        N = args.n_train
+        desc += " [N overridden: %d]" % N
     prob = workload.make_problem(seed, N, n_s, n_u, T, sf2=sf2)     # model part identical on every rank
     a_lin, b_lin = a_scale * np.eye(n_s), np.zeros((n_s, n_u))
     l_mu = l_sigma = L_CONST[n_s]
@@ -199,11 +320,15 @@ def main():
         flops_launch = float(n_s) * N * N * Tc
         avg_ms = var_ms / max(var_n, 1)
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
+        # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass (counters cannot be read from
+        # inside the run); the committed summary is quoted and its source named, never presented as live
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not args.n_train and not args.queries:
             try:
-                traffic = json.load(open(pmc)).get("sr_var_kernel_hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get("sr_var_kernel_hbm_bytes_per_launch")
+                traffic_src = "committed PMC pass: %s (not measured in this run)" % pj.get("source", "profiles/pmc_%s.json" % args.workload)
             except Exception:
                 traffic = None
         line = {
@@ -213,12 +338,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc, "N": N, "queries_per_gpu_per_step": T, "horizon": H,
                        "n_s": n_s, "n_u": n_u,
-                       "parallelism": "query-shard x%d, one-time RCCL broadcast of Z/alpha/U^-1, no "
-                                      "data-path collective" % world,
+                       "parallelism": "query-shard x%d (%s), one-time RCCL broadcast of Z/alpha/U^-1, no "
+                                      "data-path collective" % (world, backend),
                        "model_fit_s": round(fit_s, 3), "broadcast_s": round(bcast_s, 3)},
             "roofline": {"kernel": "sr_var_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "flops_per_launch": flops_launch, "avg_launch_ms": avg_ms,
                          "launches": var_n},
             "kernel_ms_per_step": {"sr_kstar_kernel": ks_ms / args.steps, "sr_var_kernel": var_ms / args.steps,

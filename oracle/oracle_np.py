@@ -453,6 +453,21 @@ def kernel_derivatives(kern_type, hyp, x, Z):
     return k, grad, hess, gxx
 
 
+def gp_mean_jacobian_k(x_new, Z, beta, kern_types, hyp):
+    """Analytic d mu/dx (T, n_out, D) for arbitrary kernel identifiers: sum_i beta_i d k(x, z_i)/dx with the
+    closed-form kernel gradients of ``kernel_derivatives`` (hand-differentiated from
+    gp_models_utils_casadi.py:17-157; the reference obtains this Jacobian from CasADi's AD, :272-280).
+    Pinned against torch-fp64 autograd of the reference's kernel formulas in tests/test_oracle_golden.py."""
+    x_new = np.asarray(x_new, np.float64)
+    T, D = x_new.shape
+    n_out = beta.shape[1]
+    jac = np.empty((T, n_out, D))
+    for t in range(T):
+        for d in range(n_out):
+            jac[t, d] = beta[:, d].dot(kernel_derivatives(kern_types[d], hyp[d], x_new[t], Z)[1])
+    return jac
+
+
 def gp_linearize_extras_k(x, Z, beta, inv_K, kern_types, hyp):
     """d sigma2/dx and Hessian of mu for arbitrary kernel identifiers (the second-order outputs of
     linearize_predict(jacobians=True), state_space_models.py:106-138):

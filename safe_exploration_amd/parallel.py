@@ -40,28 +40,43 @@ def broadcast_tensors(tensors, src=0, device=None):
     return out
 
 
-def replicate_model(gp, prob, src=0):
-    """Rank `src` holds a trained HIP SimpleGPModel; every other rank receives Z, Y, alpha and U^-1
-    over RCCL and adopts them without factorising.  `prob` supplies the (replicated, tiny)
-    hyper-parameters on every rank.  Returns the rank-local model."""
+def model_spec(gp):
+    """Everything but the arrays that a receiver needs to rebuild ``gp``: dimensions, kernel identifiers, the
+    hyper-parameters INCLUDING the Gaussian noise (``hyp`` alone does not carry it) and the ``noise_diag`` the
+    source was trained with."""
+    hyp = []
+    for i, h in enumerate(gp.hyp):
+        h = {k: np.asarray(v, dtype=np.float64).tolist() for k, v in h.items()}
+        h["noise_variance"] = float(gp._noise[i])
+        hyp.append(h)
+    return {"n_s_out": gp.n_s_out, "n_s_in": gp.n_s_in, "n_u": gp.n_u, "kern_types": list(gp.kern_types),
+            "hyp": hyp, "noise_diag": float(gp._noise_diag if gp._noise_diag is not None else 1e-5)}
+
+
+def replicate_model(gp, prob=None, src=0, device=None):
+    """Rank `src` holds a trained HIP SimpleGPModel; every other rank receives the model description (object
+    broadcast: dimensions, kernels, hyper-parameters, noise), then Z, the targets that belong to Z, alpha and
+    U^-1 over RCCL, and adopts them without factorising (sr_gp_import).  ``prob`` is accepted for backward
+    compatibility and ignored: the source model is the single source of truth.  Returns the rank-local model."""
     from .ssm_hip.gaussian_process import SimpleGPModel
-    from .workload import hyp_list
     rank = dist.get_rank()
-    n_s = len(prob["signal_var"])
-    D = prob["lengthscale"].shape[1]
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    spec = [model_spec(gp) if rank == src else None]
+    dist.broadcast_object_list(spec, src=src)
+    spec = spec[0]
     payload = None
     if rank == src:
         alpha, wt = gp.export_state()
-        payload = {"Z": torch.from_numpy(np.ascontiguousarray(gp.z)).to(dev),
-                   "Y": torch.from_numpy(np.ascontiguousarray(gp.y_train)).to(dev),
+        payload = {"Z": torch.from_numpy(np.ascontiguousarray(gp.z_fit)).to(dev),
+                   "Y": torch.from_numpy(np.ascontiguousarray(gp.y_z)).to(dev),
                    "alpha": alpha, "wt": wt}
     got = broadcast_tensors(payload, src=src, device=dev)
     if rank == src:
         return gp
-    local = SimpleGPModel(n_s, n_s, D - n_s, kern_types=prob.get("kern_types", ["rbf"] * n_s),
-                          hyp=prob.get("hyp", None) or hyp_list(prob), device=dev)
-    local.import_state(got["Z"].cpu().numpy(), got["Y"].cpu().numpy(), got["alpha"], got["wt"])
+    local = SimpleGPModel(spec["n_s_out"], spec["n_s_in"], spec["n_u"], kern_types=spec["kern_types"],
+                          hyp=spec["hyp"], device=dev)
+    local.import_state(got["Z"].cpu().numpy(), got["Y"].cpu().numpy(), got["alpha"], got["wt"],
+                       noise_diag=spec["noise_diag"])
     return local
 
 

@@ -8,8 +8,10 @@ y_train, gp_trained``), but none of its implementation: GPy is replaced by the C
 include/safereach.h (Gram + blocked fp64-MFMA Cholesky at model-update time; fused RBF
 cross-covariance / triangular contraction kernels at prediction time).
 
-Not on the hot path and therefore not provided: hyper-parameter optimisation (``opt_hyp=True``),
-sparse GP, ``sample_from_gp``, ``information_gain``.
+Also provided, each through its own C entry point: ``opt_hyp=True`` (L-BFGS-B over ``sr_gp_mll``),
+``choose_datapoints_maxvar``, ``sample_from_gp`` (``sr_gp_sample``), ``information_gain`` (``sr_gp_logdet``),
+``linearize_predict(jacobians=True)`` with ``get_reverse`` / ``get_linearize_reverse`` (``has_reverse`` is True).
+Not provided: sparse GP regression (``do_sparse_gp``, GPy's ``SparseGPRegression``).
 """
 import ctypes
 import warnings
@@ -92,13 +94,17 @@ class SimpleGPModel(StateSpaceModel):
         self._inv_K = None
         self._handle = None
         self._noise_diag = None
+        self._z_fit = None           # the inputs / targets the device model is conditioned on (== z unless Z was
+        self._y_z = None             # fixed by the caller): what a broadcast receiver has to be given
         self._device_arg = device
         self.do_sparse_gp = False
         self.z_fixed = Z is not None
         self._init_kernel_function(kern_types, hyp)
         if X is None or y is None:
             train = False
-        super(SimpleGPModel, self).__init__(n_s_out, n_u)
+        # reverse mode is implemented (get_reverse / get_linearize_reverse below): CasadiSSMEvaluator reads both
+        # flags from the model it wraps (state_space_models.py:166, 423-425)
+        super(SimpleGPModel, self).__init__(n_s_out, n_u, has_jacobian=True, has_reverse=True)
         if train:
             self.train(X, y, m, Z=Z)
 
@@ -265,6 +271,7 @@ class SimpleGPModel(StateSpaceModel):
             hd.Np = npad.value
         idx = np.asarray(chosen)
         self.z, self.x_train, self.y_train = x[idx], x, y         # the model now is the GP on the chosen rows
+        self._z_fit, self._y_z = x[idx], y[idx]
         self._beta = self._inv_K = None
         return (x[idx], y[idx], idx) if return_index else (x[idx], y[idx])
 
@@ -284,6 +291,7 @@ class SimpleGPModel(StateSpaceModel):
             self.optimize_hyperparameters(Zs, yz)
         self._fit(Zs, yz, noise_diag)
         self._noise_diag = noise_diag
+        self._z_fit, self._y_z = Zs, yz
         self.z = self.Z if self.z_fixed else Zs
         self.x_train = X
         self.y_train = y
@@ -408,16 +416,19 @@ class SimpleGPModel(StateSpaceModel):
             xs, ys = x[lo:lo + step], y[lo:lo + step]
             tx, ty = B.as_dev(xs, hd.device), B.as_dev(ys, hd.device)
             info = (ctypes.c_int * self.n_s_out)()
+            # a failing chunk (SR_ENOTPD on a near-duplicate point, out of memory) leaves the handle as it was
+            # before THAT chunk: the host state below is committed chunk by chunk, so both always agree
             check(lib.sr_gp_append(hd.h, B.ptr(tx), B.ptr(ty), xs.shape[0], s, info))
             hd.N += xs.shape[0]
             npad = ctypes.c_long(0)
             check(lib.sr_gp_padded_n(hd.h, ctypes.byref(npad)))
             hd.Np = npad.value
-        self.x_train = np.vstack((self.x_train, x))
-        self.y_train = np.vstack((self.y_train, y))
-        self.z = self.x_train
-        self._beta = None
-        self._inv_K = None
+            self.x_train = np.vstack((self.x_train, xs))
+            self.y_train = np.vstack((self.y_train, ys))
+            self.z = self.x_train
+            self._z_fit, self._y_z = self.x_train, self.y_train
+            self._beta = None
+            self._inv_K = None
 
     def _fit(self, Z, Y, noise_diag):
         dev = B.resolve_device(self._device_arg)
@@ -516,7 +527,19 @@ class SimpleGPModel(StateSpaceModel):
         self.z = Z
         self.x_train = Z
         self.y_train = Y
+        self._z_fit, self._y_z = Z, Y
         self.gp_trained = True
+
+    @property
+    def y_z(self):
+        """(N, n_s_out) targets of the rows the model is conditioned on (the reference's local ``y_z``,
+        gaussian_process.py:207-230; equals ``y_train`` unless ``m`` selected a subset)."""
+        return self._y_z
+
+    @property
+    def z_fit(self):
+        """(N, D) inputs the device model is conditioned on (``z`` unless the caller fixed ``Z``)."""
+        return self._z_fit
 
     # ------------------------------------------------------------------ prediction
     def predict_device(self, x_new, compute_gradients=False):

@@ -2,10 +2,183 @@
 
 Mirrors the interface of /root/reference/safe_exploration/state_space_models.py:14-211
 (``StateSpaceModel``): attribute names, method names, argument meaning and the
-NotImplementedError behaviour of the abstract methods.  The CasADi callback wrapper of the
-reference (``CasadiSSMEvaluator``, state_space_models.py:214-566) is a *consumer* of this surface
-and only exists where casadi is importable; it is out of scope of the MI355X hot path.
+NotImplementedError behaviour of the abstract methods, and the CasADi callback wrapper
+``CasadiSSMEvaluator`` (state_space_models.py:214-566) through which the MPC's IPOPT loop evaluates a
+state-space model once per iteration (:278-303 forward, :384-417 Jacobian, :534-562 reverse).  The
+wrapper is built lazily on whatever ``casadi`` module is importable (``casadi.Callback`` is its base
+class); this package never needs casadi for anything else.
 """
+import copy
+
+import numpy as np
+
+_EVALUATOR_CACHE = {}
+
+
+def _dense(x):
+    """casadi DM / numpy -> 2-D float64 numpy array."""
+    a = np.array(x, dtype=np.float64)
+    return a.reshape(-1, 1) if a.ndim < 2 else a
+
+
+def _evaluator_class(cas):
+    """``CasadiSSMEvaluator`` on top of the given casadi module (cached per module)."""
+    cached = _EVALUATOR_CACHE.get(id(cas))
+    if cached is not None:
+        return cached
+
+    def dense_in(ssm, linearize_mu, with_outputs, with_seeds):
+        """sparsity list of [state, action | outputs | output seeds] (state_space_models.py:262-278,369-381,501-527)"""
+        n, m = ssm.num_states, ssm.num_actions
+        outs = [cas.Sparsity.dense(n, 1), cas.Sparsity.dense(n, 1)]
+        if linearize_mu:
+            outs.append(cas.Sparsity.dense(n, n + m))
+        sp = [cas.Sparsity.dense(n, 1), cas.Sparsity.dense(m, 1)]
+        if with_outputs:
+            sp += outs
+        if with_seeds:
+            sp += outs
+        return sp
+
+    class _Derivative(cas.Callback):
+        """Shared shell of the two nested callbacks of the reference (JacFun :328-417, BackFun :455-562): no
+        derivatives of their own, dense inputs, evaluation delegated to a bound method of the evaluator."""
+
+        def __init__(self, name, ssm, sp_in, sp_out, fn, opts):
+            cas.Callback.__init__(self)
+            self.ssm, self._sp_in, self._sp_out, self._fn = ssm, sp_in, sp_out, fn
+            self.construct(name, opts)
+
+        def get_n_in(self):
+            return len(self._sp_in)
+
+        def get_n_out(self):
+            return len(self._sp_out)
+
+        def get_sparsity_in(self, i):
+            return self._sp_in[i]
+
+        def get_sparsity_out(self, i):
+            return self._sp_out[i]
+
+        def has_reverse(self, nadj):
+            return False
+
+        def has_forward(self, nfwd):
+            return False
+
+        def has_jacobian(self):
+            return False
+
+        def eval(self, arg):
+            return self._fn(arg)
+
+    class CasadiSSMEvaluator(cas.Callback):
+        """casadi.Callback evaluating a StateSpaceModel: inputs (state n x 1, action m x 1), outputs
+        (mean n x 1, variance n x 1[, jac_mean n x (n+m)]) -- state_space_models.py:214-303.
+
+        Derivatives: ``get_jacobian`` returns a callback producing the stacked (2n [+ n(n+m)]) x (n+m) matrix
+        [jac_mean; jac_variance[; d jac_mean/dz]] (:305-419); ``get_reverse`` one producing the adjoints of
+        (state, action) for the output seeds (:435-566).  One model evaluation per call of either."""
+
+        def __init__(self, ssm, linearize_mu=True, has_jacobian=True, has_reverse=False, opts={}):
+            cas.Callback.__init__(self)
+            self.v_has_jacobian = has_jacobian
+            self.v_has_reverse = has_reverse
+            self.v_has_forward = False
+            if not (has_jacobian or has_reverse):
+                raise ValueError("Need to specify either has_jacobian or has_reverse")
+            self.ssm = ssm
+            self.linearize_mu = linearize_mu
+            self.construct("CasadiModelEvaluator", opts)
+
+        def get_n_in(self):
+            return 2
+
+        def get_n_out(self):
+            return 3 if self.linearize_mu else 2
+
+        def get_sparsity_in(self, i):
+            return dense_in(self.ssm, self.linearize_mu, False, False)[i]
+
+        def get_sparsity_out(self, i):
+            return dense_in(self.ssm, self.linearize_mu, True, False)[2 + i]
+
+        def eval(self, arg):
+            state, action = _dense(arg[0]), _dense(arg[1])
+            if self.linearize_mu:
+                mu, sigma, jac_mu = self.ssm.linearize_predict(state.T, action.T, False, False)
+                return [mu, sigma, jac_mu]
+            mu, sigma = self.ssm.predict(state.T, action.T)
+            return [np.reshape(mu, (-1, 1)), np.reshape(sigma, (-1, 1))]
+
+        # -- Jacobian callback ------------------------------------------------------------------------
+        def _eval_jacobian(self, arg):
+            state, action = _dense(arg[0]), _dense(arg[1])
+            n, D = self.ssm.num_states, self.ssm.num_states + self.ssm.num_actions
+            if self.linearize_mu:
+                _, _, jac_mu, jac_sigma, hess_mu = self.ssm.linearize_predict(state.T, action.T, True, False)
+                # (n, D, D) -> (n D, D): row i*D + j holds d jac_mu[i, j] / dz (utils.py:357-380)
+                return [np.vstack((jac_mu, jac_sigma, np.reshape(hess_mu, (n * D, D))))]
+            _, _, jac_mu, jac_sigma = self.ssm.predict(state.T, action.T, True, False)
+            return [np.vstack((np.reshape(jac_mu, (n, D)), np.reshape(jac_sigma, (n, D))))]
+
+        def get_jacobian(self, name, inames, onames, opts):
+            n, D = self.ssm.num_states, self.ssm.num_states + self.ssm.num_actions
+            rows = 2 * n + (n * D if self.linearize_mu else 0)
+            self.jac_callback = _Derivative(name, self.ssm, dense_in(self.ssm, self.linearize_mu, True, False),
+                                            [cas.Sparsity.dense(rows, D)], self._eval_jacobian, opts)
+            return self.jac_callback
+
+        def has_reverse(self, nadj):
+            return self.v_has_reverse and nadj == 1
+
+        def has_forward(self, nfwd):
+            return self.v_has_forward
+
+        def has_jacobian(self):
+            return self.v_has_jacobian
+
+        # -- reverse-mode callback --------------------------------------------------------------------
+        def _eval_reverse(self, arg):
+            # arg = [state, action | outputs | seeds]; the seeds follow the n_out outputs (:556-562)
+            n_out = self.get_n_out()
+            seeds = [_dense(a) for a in arg[2 + n_out:2 + 2 * n_out]]
+            # the adjoint needs the linearisation at THIS point: re-evaluate instead of trusting a cache that an
+            # interleaved forward call may have overwritten
+            state, action = _dense(arg[0]), _dense(arg[1])
+            if self.linearize_mu:
+                self.ssm.linearize_predict(state.T, action.T, True, False)
+                # jac_mean seed flattened row-major: entry i*D + j multiplies d jac_mean[i, j] / dz, the layout
+                # of the third block of the stacked Jacobian above
+                seed = np.concatenate((seeds[0].reshape(-1), seeds[1].reshape(-1), seeds[2].reshape(-1)))
+                adj_state, adj_action = self.ssm.get_linearize_reverse(seed)
+            else:
+                self.ssm.predict(state.T, action.T, True, False)
+                seed = np.concatenate((seeds[0].reshape(-1), seeds[1].reshape(-1)))
+                adj_state, adj_action = self.ssm.get_reverse(seed)
+            return [cas.DM(np.reshape(adj_state, (-1, 1))), cas.DM(np.reshape(adj_action, (-1, 1)))]
+
+        def get_reverse(self, nadj, name, inames, onames, opts):
+            if not self.v_has_reverse:
+                raise ValueError("Calling reverse even though it is not provided! This should not happen.")
+            n, m = self.ssm.num_states, self.ssm.num_actions
+            self.reverse_callback = _Derivative(name, self.ssm, dense_in(self.ssm, self.linearize_mu, True, True),
+                                                [cas.Sparsity.dense(n, 1), cas.Sparsity.dense(m, 1)],
+                                                self._eval_reverse, opts)
+            return self.reverse_callback
+
+    _EVALUATOR_CACHE[id(cas)] = CasadiSSMEvaluator
+    return CasadiSSMEvaluator
+
+
+def __getattr__(name):
+    # ``from safe_exploration_amd.state_space_models import CasadiSSMEvaluator`` where casadi is installed
+    if name == "CasadiSSMEvaluator":
+        import casadi
+        return _evaluator_class(casadi)
+    raise AttributeError(name)
+
 
 class StateSpaceModel(object):
     """x_{t+1} = f(x_t, u_t) with uncertainty information; x in (1 x n), u in (1 x m).
@@ -33,26 +206,14 @@ class StateSpaceModel(object):
                                   "get_forward_model_casadi() method")
 
     def get_forward_model_casadi(self, linearize_mu=True):
-        """state_space_models.py:140-166 wraps ``copy.deepcopy(self)`` in a ``casadi.Callback``.
-
-        The callback class is CasADi glue of the *caller* (it only uses ``linearize_predict`` / ``predict`` /
-        ``get_reverse`` / ``get_linearize_reverse`` and ``copy.deepcopy`` of this object, all provided here), so
-        when the reference package is importable its own ``CasadiSSMEvaluator`` is used unchanged on top of this
-        model; nothing CasADi-specific is re-implemented (casadi is not installed where this library is built and
-        tested)."""
+        """state_space_models.py:140-166: a ``CasadiSSMEvaluator`` around ``copy.deepcopy(self)``, with this
+        model's ``has_jacobian`` / ``has_reverse`` flags."""
         try:
-            import casadi  # noqa: F401
+            import casadi
         except ImportError as exc:
             raise ImportError("get_forward_model_casadi needs casadi (the CasADi MPC is the caller of "
-                              "this surface, not part of the MI355X hot path)") from exc
-        try:
-            from safe_exploration.state_space_models import CasadiSSMEvaluator
-        except ImportError as exc:
-            raise NotImplementedError("no CasADi callback class available: install the reference package "
-                                      "(safe_exploration.state_space_models.CasadiSSMEvaluator works on this "
-                                      "model unchanged)") from exc
-        import copy
-        return CasadiSSMEvaluator(copy.deepcopy(self), linearize_mu)
+                              "this surface)") from exc
+        return _evaluator_class(casadi)(copy.deepcopy(self), linearize_mu, self.has_jacobian, self.has_reverse)
 
     def get_reverse(self, seed):
         raise NotImplementedError("Need to implement this in a sublass when providing reverse AD "

@@ -26,3 +26,15 @@ def hip_model(Z, Y, ls, sf2, noise_var, n_s, n_u):
 def mu_atol(model):
     """atol for mu / jac: 1e-12 * sigma_f * |alpha|_1  (SURVEY 8d)."""
     return 1e-12 * float(np.sqrt(np.max(model["signal_var"])) * np.abs(model["beta"]).sum(0).max())
+
+
+_ORACLE_CACHE = {}
+
+
+def cached_oracle_model(seed, N, n_s, n_u, sf2=1.0):
+    """oracle fit of orc.make_synthetic(seed, N, ...) -- O(N^3) on the CPU, shared between the full-size tests."""
+    key = (seed, N, n_s, n_u, sf2)
+    if key not in _ORACLE_CACHE:
+        syn = orc.make_synthetic(seed, N, n_s, n_u, 4, sf2=sf2)
+        _ORACLE_CACHE[key] = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    return _ORACLE_CACHE[key]

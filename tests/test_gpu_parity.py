@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from _helpers import hip_model, oracle_model, mu_atol, hyp_from
+from _helpers import hip_model, oracle_model, mu_atol, hyp_from, cached_oracle_model
 from oracle import oracle_np as orc
 
 pytestmark = pytest.mark.gpu
@@ -449,7 +449,11 @@ def test_non_rbf_kernels_vs_reference_formulas(kt):
     scale = np.abs(g["beta"]).sum(0).max()
     np.testing.assert_allclose(mu, g["ref_mu"], rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(var, g["ref_var"], rtol=0, atol=1e-8 * max(1.0, float(g["ref_var"].max())))
-    np.testing.assert_allclose(jac, g["jac_fd"], rtol=2e-5, atol=1e-6 * scale)    # central differences
+    np.testing.assert_allclose(jac, g["jac_fd"], rtol=2e-5, atol=1e-6 * scale)    # central differences (fixture)
+    # analytic Jacobian of the oracle (validated against torch-fp64 autograd on the CPU): same bar as the RBF path
+    beta_o, _ = orc.gp_fit_k(g["Z"], g["Y"], [kt] * 2, hyp, g["noise_var"])
+    np.testing.assert_allclose(jac, orc.gp_mean_jacobian_k(g["x_new"], g["Z"], beta_o, [kt] * 2, hyp), rtol=1e-9,
+                               atol=1e-11 * scale)
     # the Gram matrix the factorisation saw: K^-1 from the device vs the reference's kernel matrix
     np.testing.assert_allclose(orc.kernel_matrix(kt, hyp[0], g["x_new"], g["Z"]), g["ref_kstar0"], rtol=1e-12, atol=1e-14)
     Ky = orc.kernel_matrix(kt, hyp[0], g["Z"], g["Z"]) + (g["noise_var"][0] + 1e-8) * np.eye(g["Z"].shape[0])
@@ -510,7 +514,7 @@ def test_full_size_headline_config():
                                                    return_var=True)
     assert np.all(np.isfinite(q1)) and var.min() > 0 and var.max() <= 1.0 + 1e-12
     assert np.linalg.eigvalsh(q1).min() > 0
-    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    om = cached_oracle_model(5, N, 2, 1)
     idx = np.random.default_rng(0).choice(T, 2048, replace=False)
     rp, rq, rvar = orc.onestep_reachability_vectorised(om, syn["p"][idx], syn["Q"][idx], syn["k_ff"][idx],
                                                        syn["k_fb"][idx], l, l, 2.0, np.eye(2), np.zeros((2, 1)))
@@ -996,7 +1000,7 @@ def test_fused_small_model_pass_general_kernels(kt, N, T):
     scale = max(np.abs(beta).sum(0).max(), 1.0)
     np.testing.assert_allclose(mu, rmu, rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-8 * max(1.0, float(rvar.max())))
-    np.testing.assert_allclose(jac, orc.gp_mean_jacobian_fd(x, Z, beta, [kt] * 2, hyp), rtol=2e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(jac, orc.gp_mean_jacobian_k(x, Z, beta, [kt] * 2, hyp), rtol=1e-9, atol=1e-11 * scale)
     gp.set_small_path(2)
     mu2, var2, jac2 = gp.predict(x, None, True)
     gp.set_small_path(1)
@@ -1081,7 +1085,7 @@ def test_streamed_linearize_all_kernels(kt, N, n_s, n_u):
     scale = max(np.abs(beta).sum(0).max(), 1.0)
     np.testing.assert_allclose(mu[:, 0], rmu[0], rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(var[:, 0], rvar[0], rtol=0, atol=1e-8 * max(1.0, float(rvar.max())))
-    np.testing.assert_allclose(jm, orc.gp_mean_jacobian_fd(x[None], Z, beta, [kt] * n_s, hyp)[0], rtol=2e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(jm, orc.gp_mean_jacobian_k(x[None], Z, beta, [kt] * n_s, hyp)[0], rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(jv, rjv, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(rjv).max()))
     np.testing.assert_allclose(hm, rhm, rtol=1e-8, atol=1e-10 * scale)
     np.testing.assert_array_equal(hm, np.swapaxes(hm, 1, 2))

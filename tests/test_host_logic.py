@@ -56,7 +56,7 @@ def test_simple_gp_model_surface(lib_built):
     gp = SimpleGPModel(2, 2, 1)
     assert isinstance(gp, StateSpaceModel)
     assert (gp.n_s_out, gp.n_s_in, gp.n_u, gp.num_states, gp.num_actions) == (2, 2, 1, 2, 1)
-    assert gp.has_jacobian and not gp.has_reverse and not gp.gp_trained
+    assert gp.has_jacobian and gp.has_reverse and not gp.gp_trained      # reverse mode is implemented
     assert gp.kern_types == ["rbf", "rbf"] and gp.beta is None and gp.inv_K is None
     assert set(gp.hyp[0]) == {"lengthscale", "variance"} and gp.hyp[0]["lengthscale"].shape == (3,)
     with pytest.raises(ValueError):
@@ -195,58 +195,137 @@ def test_true_system_rollouts_vs_reference_golden():
     np.testing.assert_allclose(x1[1], g["x_all"][1], rtol=1e-13)
 
 
-@pytest.mark.skipif(not os.path.isdir("/root/reference/safe_exploration"),
-                    reason="needs the reference checkout (build container only)")
-def test_reference_casadi_evaluator_runs_on_this_surface(tmp_path, monkeypatch):
-    """get_forward_model_casadi hands a deep copy of the model to the REFERENCE's CasadiSSMEvaluator
-    (state_space_models.py:166, 214-566).  casadi itself is absent here, so a stand-in module provides the three
-    names the evaluator touches (Callback.construct, Sparsity.dense, reshape); what is pinned is the contract between
-    that evaluator and this package's StateSpaceModel surface: call signatures, output shapes, stacked Jacobian."""
-    import sys
-    import textwrap
-    (tmp_path / "casadi.py").write_text(textwrap.dedent('''
-        import numpy as _np
-        def reshape(a, s): return _np.reshape(a, s, order="F")
-        class Sparsity(object):
-            @staticmethod
-            def dense(r, c=1): return (r, c)
-        class Callback(object):
-            def __init__(self): self.constructed = None
-            def construct(self, name, opts): self.constructed = name
-    '''))
-    monkeypatch.syspath_prepend(str(tmp_path))
-    monkeypatch.syspath_prepend("/root/reference")
-    for m in [k for k in sys.modules if k == "casadi" or k.startswith("safe_exploration.") or k == "safe_exploration"]:
-        monkeypatch.delitem(sys.modules, m)
+STANDIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "standin")
+
+
+def _linear_ssm():
     from safe_exploration_amd import StateSpaceModel
 
     class Linear(StateSpaceModel):
-        """mu = A [x; u], var = 0.1 + (w.[x; u])^2: closed forms for every derivative the evaluator asks for."""
+        """mu = A z + 0.5 (c.z)^2 e_0, var = 0.1 + (w.z)^2 (z = [x; u]): closed forms for every derivative the
+        evaluator asks for, reverse mode included."""
         A = np.array([[0.9, 0.1, 0.3], [-0.2, 0.8, 0.5]])
         w = np.array([0.3, -0.4, 0.2])
+        c = np.array([0.5, 0.25, -1.0])
+
+        def _all(self, z):
+            mu = self.A.dot(z)
+            mu[0] += 0.5 * self.c.dot(z) ** 2
+            jm = self.A.copy()
+            jm[0] += self.c.dot(z) * self.c
+            hm = np.zeros((2, 3, 3))
+            hm[0] = np.outer(self.c, self.c)
+            return (mu[:, None], np.full((2, 1), 0.1 + self.w.dot(z) ** 2), jm,
+                    np.tile(2 * self.w.dot(z) * self.w, (2, 1)), hm)
 
         def linearize_predict(self, states, actions, jacobians=False, full_cov=False):
-            z = np.hstack((np.asarray(states), np.asarray(actions)))[0]
-            mu = self.A.dot(z)[:, None]
-            var = np.full((2, 1), 0.1 + self.w.dot(z) ** 2)
-            if not jacobians:
-                return mu, var, self.A
-            jv = np.tile(2 * self.w.dot(z) * self.w, (2, 1))
-            return mu, var, self.A, jv, np.zeros((2, 3, 3))
+            out = self._all(np.hstack((np.asarray(states), np.asarray(actions)))[0])
+            self._linearize_forward_cache = out[2:]
+            return out if jacobians else out[:3]
 
-    ssm = Linear(2, 1)
-    ev = ssm.get_forward_model_casadi(True)
-    assert type(ev).__name__ == "CasadiSSMEvaluator" and ev.ssm is not ssm and ev.constructed
+        def get_linearize_reverse(self, seed):
+            jm, jv, hm = self._linearize_forward_cache
+            seed = np.asarray(seed, dtype=np.float64).reshape(-1)
+            g = seed[:2].dot(jm) + seed[2:4].dot(jv) + np.einsum("ij,ijk->k", seed[4:].reshape(2, 3), hm)
+            return g[:2, None], g[2:, None]
+
+    return Linear
+
+
+def _drive_evaluator(ev, ssm_cls, has_reverse):
+    """the call sequence IPOPT drives through casadi: forward, Jacobian callback, reverse callback"""
+    z = np.array([0.2, -0.1, 0.4])
+    x, u = z[:2, None], z[2:, None]
+    ref = ssm_cls(2, 1)._all(z)
     assert ev.get_n_in() == 2 and ev.get_n_out() == 3 and ev.get_sparsity_out(2) == (2, 3)
-    x, u = np.array([[0.2], [-0.1]]), np.array([[0.4]])
     mu, var, jac = ev.eval([x, u])
-    np.testing.assert_allclose(mu[:, 0], Linear.A.dot([0.2, -0.1, 0.4]))
-    assert var.shape == (2, 1) and jac.shape == (2, 3)
+    np.testing.assert_allclose(mu, ref[0])
+    np.testing.assert_allclose(var, ref[1])
+    np.testing.assert_allclose(jac, ref[2])
     jfun = ev.get_jacobian("jac", [], [], {})
+    assert jfun.get_n_in() == 5 and jfun.get_n_out() == 1 and jfun.get_sparsity_out(0) == (2 * 2 + 2 * 3, 3)
     (stacked,) = jfun.eval([x, u, mu, var, jac])
+    stacked = np.array(stacked)
     assert stacked.shape == (2 * 2 + 2 * 3, 3)                 # [jac_mu; jac_var; d jac_mu / dz]
-    np.testing.assert_allclose(stacked[:2], Linear.A)
-    np.testing.assert_allclose(stacked[2:4], np.tile(2 * Linear.w.dot([0.2, -0.1, 0.4]) * Linear.w, (2, 1)))
+    np.testing.assert_allclose(stacked[:2], ref[2])
+    np.testing.assert_allclose(stacked[2:4], ref[3])
+    np.testing.assert_allclose(stacked[4:], ref[4].reshape(6, 3))
+    assert ev.has_jacobian() and ev.has_reverse(1) == has_reverse and not ev.has_reverse(2) and not ev.has_forward(1)
+    if not has_reverse:
+        with pytest.raises(ValueError):
+            ev.get_reverse(1, "rev", [], [], {})
+        return None
+    bfun = ev.get_reverse(1, "rev", [], [], {})
+    assert bfun.get_n_in() == 8 and bfun.get_n_out() == 2 and bfun.get_sparsity_in(7) == (2, 3)
+    return bfun, stacked, (x, u, mu, var, jac)
+
+
+def test_casadi_evaluator_contract_forward_jacobian_reverse(monkeypatch):
+    """This package's CasadiSSMEvaluator (state_space_models.py:214-566 of the reference) on a stand-in casadi
+    module: arities, sparsities, the stacked (2n + nD) x D Jacobian and the reverse-mode adjoints -- the three
+    callbacks IPOPT reaches -- against closed forms.  ``get_forward_model_casadi`` passes has_jacobian / has_reverse
+    of the model like state_space_models.py:166."""
+    import sys
+    monkeypatch.syspath_prepend(STANDIN)
+    monkeypatch.delitem(sys.modules, "casadi", raising=False)
+    import casadi
+    Linear = _linear_ssm()
+    ssm = Linear(2, 1, has_jacobian=True, has_reverse=True)
+    ev = ssm.get_forward_model_casadi(True)
+    assert type(ev).__name__ == "CasadiSSMEvaluator" and ev.ssm is not ssm and ev.constructed == "CasadiModelEvaluator"
+    assert ev.v_has_reverse is True and ev.v_has_jacobian is True
+    bfun, stacked, (x, u, mu, var, jac) = _drive_evaluator(ev, Linear, True)
+    rng = np.random.default_rng(0)
+    s_mu, s_var, s_jac = rng.standard_normal((2, 1)), rng.standard_normal((2, 1)), rng.standard_normal((2, 3))
+    adj_x, adj_u = bfun.eval([casadi.DM(a) for a in (x, u, mu, var, jac, s_mu, s_var, s_jac)])
+    want = np.concatenate((s_mu.ravel(), s_var.ravel(), s_jac.ravel())).dot(stacked)     # seed^T J, row-major jac seed
+    np.testing.assert_allclose(np.array(adj_x).ravel(), want[:2], rtol=1e-13)
+    np.testing.assert_allclose(np.array(adj_u).ravel(), want[2:], rtol=1e-13)
+    # numeric call path with shape checks against the declared sparsities
+    out = ev(x, u)
+    assert [o.shape for o in out] == [(2, 1), (2, 1), (2, 3)]
+    # a model without reverse mode: the flag travels, get_reverse refuses
+    ev2 = Linear(2, 1).get_forward_model_casadi(True)
+    assert ev2.v_has_reverse is False
+    _drive_evaluator(ev2, Linear, False)
+    with pytest.raises(ValueError):
+        from safe_exploration_amd import state_space_models as ssm_mod
+        ssm_mod.CasadiSSMEvaluator(ssm, True, False, False)
+    # not linearised: two outputs, (2n) x D Jacobian
+    from safe_exploration_amd import state_space_models as ssm_mod
+    assert ssm_mod.CasadiSSMEvaluator is type(ev)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/safe_exploration"),
+                    reason="needs the reference checkout (build container only)")
+def test_reference_casadi_evaluator_runs_on_this_surface(monkeypatch):
+    """The REFERENCE's own CasadiSSMEvaluator (state_space_models.py:214-566) driven over this package's
+    StateSpaceModel surface with the same stand-in casadi module, through JacFun.eval and BackFun.eval
+    (:384-417, :534-562): it must accept the surface unchanged and produce what this package's evaluator does."""
+    import sys
+    monkeypatch.syspath_prepend(STANDIN)
+    monkeypatch.syspath_prepend("/root/reference")
+    for m in [k for k in sys.modules if k == "casadi" or k.startswith("safe_exploration.") or k == "safe_exploration"]:
+        monkeypatch.delitem(sys.modules, m)
+    import casadi
+    from safe_exploration.state_space_models import CasadiSSMEvaluator as RefEvaluator
+    Linear = _linear_ssm()
+    ssm = Linear(2, 1, has_jacobian=True, has_reverse=True)
+    ev = RefEvaluator(ssm, True, ssm.has_jacobian, ssm.has_reverse)
+    bfun, stacked, (x, u, mu, var, jac) = _drive_evaluator(ev, Linear, True)
+    mine = ssm.get_forward_model_casadi(True)
+    (stacked_mine,) = mine.get_jacobian("jac", [], [], {}).eval([x, u, mu, var, jac])
+    np.testing.assert_array_equal(stacked, np.array(stacked_mine))
+    # reverse: the reference flattens the jac_mean seed with casadi's column-major reshape (:555-556) while its own
+    # GPyTorchSSM caches jac_mean row-major (ssm_pytorch/gaussian_process.py:372); the two agree for a seed whose
+    # two flattenings coincide, e.g. one that only touches the first column
+    s_mu, s_var = np.array([[0.3], [-0.7]]), np.array([[1.1], [0.2]])
+    s_jac = np.zeros((2, 3))
+    ssm.linearize_predict(x.T, u.T, True)
+    adj_ref = bfun.eval([casadi.DM(a) for a in (x, u, mu, var, jac, s_mu, s_var, s_jac)])
+    adj_mine = mine.get_reverse(1, "rev", [], [], {}).eval([casadi.DM(a) for a in (x, u, mu, var, jac, s_mu, s_var, s_jac)])
+    for a, b in zip(adj_ref, adj_mine):
+        np.testing.assert_allclose(np.array(a), np.array(b), rtol=1e-6)      # the reference casts its seed to float32
 
 
 def test_dlqr_and_name_aliases_vs_reference_golden():

@@ -313,6 +313,61 @@ def test_second_order_outputs_of_all_kernels_vs_finite_differences(kt):
         np.testing.assert_allclose(hm, hm0, rtol=1e-12, atol=1e-13)
 
 
+def _torch_kernel(kt, hyp, x, Z):
+    """k(x, Z) (N,) in torch fp64 written directly from the reference's formulas
+    (gp_models_utils_casadi.py:17-157: -2xy + x^2 + y^2 distances, product part on input dimension 1)."""
+    import torch
+    t = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float64))
+
+    def dist(a, b, ls):
+        a, b = a / ls, b / ls
+        r2 = -2.0 * (b * a[None, :]).sum(1) + (a * a).sum() + (b * b).sum(1)
+        return torch.clamp(r2, min=0.0)
+
+    def stationary(kind, a, b, var, ls):
+        r2 = dist(a, b, ls)
+        if kind == "rbf":
+            return var * torch.exp(-0.5 * r2)
+        r = torch.sqrt(r2)
+        return var * (1.0 + np.sqrt(5.0) * r + 5.0 / 3.0 * r2) * torch.exp(-np.sqrt(5.0) * r)
+
+    D = Z.shape[1]
+    if kt in ("rbf", "mat52"):
+        return stationary(kt, x, t(Z), float(hyp["variance"]), t(hyp["lengthscale"]) * torch.ones(D, dtype=torch.float64))
+    st = "rbf" if kt == "lin_rbf" else "mat52"
+    vl = t(hyp["linear.variances"]) * torch.ones(D, dtype=torch.float64)
+    vp = float(np.asarray(hyp["prod.linear.variances"]).reshape(-1)[0])
+    x1, z1 = x[1:2], t(Z)[:, 1:2]
+    k_st = stationary(st, x1, z1, float(hyp["prod.%s.variance" % st]), t(hyp["prod.%s.lengthscale" % st]).reshape(-1)[:1])
+    return vp * x1[0] * z1[:, 0] * k_st + (t(Z) * vl[None, :] * x[None, :]).sum(1)
+
+
+@pytest.mark.parametrize("kt", ["rbf", "mat52", "lin_rbf", "lin_mat52"])
+def test_analytic_mean_jacobian_vs_torch_autograd(kt):
+    """oracle.gp_mean_jacobian_k (what the GPU tests compare d mu/dx of the non-RBF kernels with, at rtol 1e-9)
+    against torch-fp64 autograd of the reference's kernel formulas, plus the autograd Hessian of the mean."""
+    import torch
+    rng = np.random.default_rng({"rbf": 1, "mat52": 2, "lin_rbf": 3, "lin_mat52": 4}[kt])
+    N, D = 50, 3
+    Z = rng.uniform(-1, 1, (N, D))
+    Y = rng.standard_normal((N, 2))
+    hyp = [orc.make_hyp(kt, rng, D) for _ in range(2)]
+    beta, inv_K = orc.gp_fit_k(Z, Y, [kt] * 2, hyp, np.full(2, 1e-2))
+    X = rng.uniform(-0.7, 0.7, (6, D))
+    jac = orc.gp_mean_jacobian_k(X, Z, beta, [kt] * 2, hyp)
+    for t_ in range(X.shape[0]):
+        for d in range(2):
+            f = lambda x: (_torch_kernel(kt, hyp[d], x, Z) * torch.from_numpy(beta[:, d])).sum()
+            x = torch.tensor(X[t_], dtype=torch.float64, requires_grad=True)
+            g_auto = torch.autograd.functional.jacobian(f, x).numpy()
+            scale = np.abs(beta[:, d]).sum()
+            np.testing.assert_allclose(jac[t_, d], g_auto, rtol=1e-10, atol=1e-12 * scale)
+            if t_ == 0:
+                h_auto = torch.autograd.functional.hessian(f, x).numpy()
+                _, hm = orc.gp_linearize_extras_k(X[t_], Z, beta, inv_K, [kt] * 2, hyp)
+                np.testing.assert_allclose(hm[d], h_auto, rtol=1e-9, atol=1e-11 * scale)
+
+
 @pytest.mark.parametrize("kt", ["rbf", "mat52", "lin_rbf", "lin_mat52"])
 def test_marginal_likelihood_gradient_vs_finite_differences(kt):
     """oracle.gp_nll_grad (the objective of train(opt_hyp=True)) against central differences in every
