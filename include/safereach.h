@@ -212,6 +212,9 @@ int sr_gp_set_var_group(sr_gp_t h, int group);
 /* tile staging of the variance kernel: 0 = register-staged (global->VGPR->LDS), 1 = LDS-DMA
  * (global_load_lds_dwordx4, default).  Same results bit for bit; a measurement knob. */
 int sr_gp_set_var_variant(sr_gp_t h, int variant);
+/* blocks of 128 rows per Cholesky panel of sr_gp_factorize (the trailing matrix is read-modify-written once per
+ * panel); 0 = chosen by size (default).  Results agree to rounding; a measurement knob. */
+int sr_gp_set_fact_panel(sr_gp_t h, int panel);
 /* latency paths instead of the plain MFMA tiles: one-launch pass for small models (Np <= 512, T <= 1024),
  * HBM-bound streaming of U^-1 for batches of <= 16 queries, 64 x 64 tiles, split-K.  on = 1 (default) all
  * of them, 2 all but the one-launch pass, 0 none; an A/B measurement knob.  Results agree to rounding. */
@@ -221,6 +224,11 @@ int sr_gp_set_small_path(sr_gp_t h, int on);
  * Exposed so the fp64-MFMA tile can be tested in isolation. */
 int sr_test_gemm_tn(int device, const double* A, long lda, const double* B, long ldb, double* C,
                     long ldc, int M, int N, int K, double alpha, double beta, int mode, void* stream);
+/* diagnostic: the diagonal-block kernel of the factorisation alone: A (128 x 128 SPD, upper triangle read, leading
+ * dimension lda) -> upper Cholesky factor in place, wt = its inverse, w = the inverse transposed (leading dimension
+ * ldw); info: device int, 0 or the 1-based first non-positive pivot.  skip != 0 leaves phases out (timing ablation). */
+int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, long ldw, int* info, int skip,
+                       void* stream);
 /* per-kernel hipEvent timing inside the library (adds an event pair per launch while enabled). */
 int sr_prof_enable(sr_gp_t h, int on);
 int sr_prof_reset (sr_gp_t h);

@@ -24,8 +24,7 @@ struct sr_gp {
     int general = 0;
     int have_data = 0, factorized = 0;
     // per-chunk workspace (grow-only)
-    long chunk = 65536, ws_Tp = 0;
-    int ws_nsplit = 0;
+    long chunk = 65536, ws_Tp = 0, ws_part = 0;     // ws_part: capacity of mu_part in units of n_out doubles
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr, *kxx = nullptr;
     double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch
@@ -44,11 +43,34 @@ struct sr_gp {
     // (kept while the padded size does not change: appends then allocate nothing big)
     double* app_ws = nullptr; size_t app_cap = 0;
     double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
-    hipStream_t fact_stream[SR_MAX_NS] = {nullptr};
-    hipEvent_t fact_fork = nullptr, fact_join[SR_MAX_NS] = {nullptr};
+    // up to SR_FACT_SLOTS outputs are in flight at once (output d uses slot d % n_par); every slot has a CRITICAL
+    // stream (diagonal blocks, panel rows, look-ahead rows, inversion; slot 0: the caller's stream) and a BULK
+    // stream (the trailing update behind the look-ahead rows)
+    hipStream_t fact_stream[SR_FACT_SLOTS] = {nullptr}, bulk_stream[SR_FACT_SLOTS] = {nullptr};
+    hipEvent_t fact_fork = nullptr, fact_join[SR_FACT_SLOTS] = {nullptr};
+    hipEvent_t ev_panel[SR_FACT_SLOTS][2] = {{nullptr}}, ev_bulk[SR_FACT_SLOTS][2] = {{nullptr}};
+    int fact_panel = 0;                                  // blocks per Cholesky panel; 0 = by size
+    int bulk_masked = 0;                                 // the bulk streams carry the CU mask
+    // job lists of the level-batched triangular inversion (depend on Np only)
+    sr_gemm_job* inv_jobs = nullptr; int inv_jobs_np = 0;
+    struct inv_level { int off1, off2, count, maxM, maxN; long tiles; };
+    std::vector<inv_level> inv_levels;
     sr_prof prof;
 };
 #define SR_FACT_PAR_BYTES ((size_t)8 << 30)
+#define SR_FACT_RESERVED_CUS 32     // CU-mask bits the bulk streams of the factorisation leave out (1 CU per shader engine)
+
+// every entry point runs on the handle's device and leaves the caller's current device as it found it
+// (PyTorch reads its current device from the HIP runtime)
+struct sr_dev_guard {
+    int prev = -1; hipError_t err = hipSuccess;
+    explicit sr_dev_guard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~sr_dev_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define SR_DEVICE(dev) sr_dev_guard dev_guard_(dev); SR_HIP(dev_guard_.err)
 
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
@@ -80,7 +102,7 @@ extern "C" int sr_gp_create(sr_gp_t* out, int device, int N, int D, int n_out) {
     SR_CHECK(N >= 1 && D >= 1 && n_out >= 1, SR_EINVAL, "sr_gp_create: N=%d D=%d n_out=%d", N, D, n_out);
     SR_CHECK(D <= SR_MAX_D, SR_EUNSUPPORTED, "sr_gp_create: D=%d > %d", D, SR_MAX_D);
     SR_CHECK(n_out <= 64, SR_EUNSUPPORTED, "sr_gp_create: n_out=%d > 64", n_out);
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     sr_gp* h = new sr_gp();
     h->device = device; h->N = N; h->D = D; h->n_out = n_out;
     h->Np = (int)round_up(N, SR_NB);
@@ -99,22 +121,28 @@ static void free_ws(sr_gp* h) {
     dev_free(h->Ks); dev_free(h->mu_part); dev_free(h->jac_part); dev_free(h->var_part);
     dev_free(h->mu); dev_free(h->var); dev_free(h->jac); dev_free(h->kxx);
     h->Ks = h->mu_part = h->jac_part = h->var_part = h->mu = h->var = h->jac = h->kxx = nullptr;
-    h->ws_Tp = 0; h->ws_nsplit = 0;
+    h->ws_Tp = 0; h->ws_part = 0;
 }
 
 extern "C" int sr_gp_destroy(sr_gp_t h) {
     if (!h) return SR_OK;
-    (void)hipSetDevice(h->device);
+    sr_dev_guard guard(h->device);
     (void)hipDeviceSynchronize();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
-    for (int d = 0; d < SR_MAX_NS; ++d) {
+    for (int d = 0; d < SR_FACT_SLOTS; ++d) {
         if (h->fact_stream[d]) (void)hipStreamDestroy(h->fact_stream[d]);
+        if (h->bulk_stream[d]) (void)hipStreamDestroy(h->bulk_stream[d]);
         if (h->fact_join[d]) (void)hipEventDestroy(h->fact_join[d]);
+        for (int e = 0; e < 2; ++e) {
+            if (h->ev_panel[d][e]) (void)hipEventDestroy(h->ev_panel[d][e]);
+            if (h->ev_bulk[d][e]) (void)hipEventDestroy(h->ev_bulk[d][e]);
+        }
     }
     if (h->fact_fork) (void)hipEventDestroy(h->fact_fork);
+    dev_free(h->inv_jobs);
     h->prof.destroy();
     delete h;
     return SR_OK;
@@ -132,7 +160,7 @@ extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const
                               const double* sf2, const double* noise, void* stream) {
     SR_CHECK(h && Z && Y && ls && sf2 && noise, SR_EINVAL, "sr_gp_set_data: NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->ls, ls, sizeof(double) * h->n_out * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->sf2, sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToDevice, s));
@@ -150,7 +178,7 @@ extern "C" int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* 
                                       const double* noise, void* stream) {
     SR_CHECK(h && Z && Y && kparams && noise, SR_EINVAL, "sr_gp_set_data_general: NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     if (!h->kp) SR_TRY(dev_alloc(&h->kp, (size_t)h->n_out * SR_KP(h->D)));
     SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->kp, kparams, sizeof(double) * h->n_out * SR_KP(h->D), hipMemcpyDeviceToDevice, s));
@@ -171,33 +199,112 @@ extern "C" int sr_gp_padded_n(sr_gp_t h, long* Np) {
 }
 
 static int ensure_wt(sr_gp* h) {
-    if (!h->Wt) SR_TRY(dev_alloc(&h->Wt, (size_t)h->n_out * h->Np * h->Np));
+    if (!h->Wt) {
+        SR_TRY(dev_alloc(&h->Wt, (size_t)h->n_out * h->Np * h->Np));
+        // the strict lower triangle of U^-1 is never written by the factorisation: zero it once
+        SR_HIP(hipMemset(h->Wt, 0, sizeof(double) * h->n_out * h->Np * h->Np));
+    }
     return SR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// factorisation: K = U^T U (right-looking, 128-blocks in 512-panels), U^-T / U^-1 by recursive halving,
-// alpha = U^-1 (U^-T y)
+// factorisation: K = U^T U (right-looking, 128-blocks in panels, look-ahead), U^-T / U^-1 by recursive halving
+// with all nodes of a level in one launch, alpha = U^-1 (U^-T y)
 // ---------------------------------------------------------------------------------------------
+// job lists of the recursive inversion  [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22],  L21 = U12^T,
+// one list per depth of the halving tree (children before parents):
+//   product 1:  Y   = U12^T W11   (A = U12 k-major -- the factor's off-diagonal blocks live in W's upper block
+//               triangle --, B = W11 lower-triangular: mode 2) -> parked in the unused strict lower triangle of U
+//   product 2:  W21 = -Wt22^T Y   (A = Wt22 = U22^-1 upper-triangular: mode 3), written to W and, transposed,
+//               to Wt12 (keeps U^-1 complete for the parent level)
+static int ensure_inv_jobs(sr_gp* h) {
+    if (h->inv_jobs && h->inv_jobs_np == h->Np) return SR_OK;
+    const int Np = h->Np, nb = Np / SR_NB;
+    struct Node { int lo, hi, depth; };
+    std::vector<Node> nodes, stack;
+    stack.push_back({0, nb, 0});
+    int max_depth = 0;
+    while (!stack.empty()) {
+        const Node r = stack.back();
+        stack.pop_back();
+        if (r.hi - r.lo <= 1) continue;
+        nodes.push_back(r);
+        max_depth = std::max(max_depth, r.depth);
+        const int mid = (r.lo + r.hi) / 2;
+        stack.push_back({r.lo, mid, r.depth + 1});
+        stack.push_back({mid, r.hi, r.depth + 1});
+    }
+    std::vector<sr_gemm_job> jobs;
+    h->inv_levels.clear();
+    for (int depth = max_depth; depth >= 0; --depth) {
+        sr_gp::inv_level lv{};
+        std::vector<sr_gemm_job> j1, j2;
+        for (const Node& r : nodes) {
+            if (r.depth != depth) continue;
+            const int mid = (r.lo + r.hi) / 2;
+            const int n1 = (mid - r.lo) * SR_NB, n2 = (r.hi - mid) * SR_NB;
+            const long o11 = (long)r.lo * SR_NB * Np + (long)r.lo * SR_NB;
+            const long o12 = (long)r.lo * SR_NB * Np + (long)mid * SR_NB;
+            const long o21 = (long)mid * SR_NB * Np + (long)r.lo * SR_NB;
+            const long o22 = (long)mid * SR_NB * Np + (long)mid * SR_NB;
+            j1.push_back({o12, o11, o21, 0, n2, n1, n1, 0});      // Y (in U's lower triangle) = U12^T W11
+            j2.push_back({o22, o21, o21, o12, n2, n1, n2, 0});    // W21 = -Wt22^T Y ; Wt12 = W21^T
+            lv.maxM = std::max(lv.maxM, n2);
+            lv.maxN = std::max(lv.maxN, n1);
+            lv.tiles += (long)(n2 / SR_NB) * (n1 / SR_NB);
+        }
+        lv.count = (int)j1.size();
+        if (lv.count == 0) continue;
+        lv.off1 = (int)jobs.size();
+        jobs.insert(jobs.end(), j1.begin(), j1.end());
+        lv.off2 = (int)jobs.size();
+        jobs.insert(jobs.end(), j2.begin(), j2.end());
+        h->inv_levels.push_back(lv);
+    }
+    dev_free(h->inv_jobs);
+    h->inv_jobs = nullptr; h->inv_jobs_np = 0;
+    if (jobs.empty()) { h->inv_jobs_np = Np; return SR_OK; }
+    SR_TRY(dev_alloc(&h->inv_jobs, jobs.size()));
+    SR_HIP(hipMemcpy(h->inv_jobs, jobs.data(), jobs.size() * sizeof(sr_gemm_job), hipMemcpyHostToDevice));
+    h->inv_jobs_np = Np;
+    return SR_OK;
+}
+
+// blocks per Cholesky panel.  Inside a panel a factored block row updates only the panel's remaining rows;
+// everything below is updated once per panel with K = panel * 128, which divides the read-modify-write traffic
+// of the trailing matrix by `panel` and gives the bulk update K = panel * 128 (a K = 128 update spends most of its
+// time in the prologue and the read-modify-write epilogue of its tiles: measured 35 % of the K = 512 rate).
+// Measured at N = 1000 ... 10000: 4 beats 1 and 2 everywhere (N = 5000: 6.9 against 7.2-7.9 ms).
+static int pick_fact_panel(const sr_gp* h) {
+    if (h->fact_panel > 0) return h->fact_panel;
+    const int nb = h->Np / SR_NB;
+    return nb <= 160 ? 4 : 8;
+}
+
 extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_factorize: NULL handle");
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     SR_TRY(ensure_wt(h));
+    SR_TRY(ensure_inv_jobs(h));
     const int Np = h->Np, nb = Np / SR_NB;
+    const int P = pick_fact_panel(h);
     const size_t NN = (size_t)Np * Np;
-    const size_t per = 2 * NN + (size_t)Np;              // scratch doubles per output: U, W, v
-    const bool par = h->n_out > 1 && per * h->n_out * sizeof(double) <= SR_FACT_PAR_BYTES;
-    const int n_par = par ? h->n_out : 1;
+    const size_t per = 2 * NN + (size_t)Np;              // scratch doubles per output in flight: U, W, v
+    // outputs in flight: as many as fit SR_FACT_PAR_BYTES of scratch, at most SR_FACT_SLOTS
+    int n_par = (int)std::min<size_t>((size_t)std::min(h->n_out, SR_FACT_SLOTS),
+                                      std::max<size_t>(1, SR_FACT_PAR_BYTES / (per * sizeof(double))));
+    const bool keep = per * n_par * sizeof(double) <= SR_FACT_PAR_BYTES;   // scratch stays with the handle
     double* scratch = nullptr;                           // owned here only when it is not kept in the handle
     int* info_dev = nullptr;
     std::vector<double> sf2(h->n_out), noise(h->n_out);
     int rc = SR_OK;
     hipStream_t s0 = (hipStream_t)stream;
     auto cleanup = [&]() {
-        if (par) {                                       // never return with work in flight on the side streams
-            for (int d = 1; d < h->n_out; ++d)
-                if (h->fact_stream[d]) (void)hipStreamSynchronize(h->fact_stream[d]);
+        // never return with work in flight on the side streams
+        for (int sl = 0; sl < SR_FACT_SLOTS; ++sl) {
+            if (h->fact_stream[sl]) (void)hipStreamSynchronize(h->fact_stream[sl]);
+            if (h->bulk_stream[sl]) (void)hipStreamSynchronize(h->bulk_stream[sl]);
         }
         dev_free(scratch); dev_free(info_dev);
     };
@@ -205,7 +312,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
 #define SR_FH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); return SR_EHIP; } } while (0)
     double* ws;
-    if (per * n_par * sizeof(double) <= SR_FACT_PAR_BYTES) {
+    if (keep) {
         if (h->fact_cap < per * n_par) {
             (void)hipDeviceSynchronize();
             dev_free(h->fact_ws);
@@ -223,104 +330,178 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_FH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0));
     SR_FH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0));
     SR_FH(hipStreamSynchronize(s0));
-    if (par) {
-        if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
-        SR_FH(hipEventRecord(h->fact_fork, s0));
-        for (int d = 1; d < h->n_out; ++d) {
-            if (!h->fact_stream[d]) SR_FH(hipStreamCreateWithFlags(&h->fact_stream[d], hipStreamNonBlocking));
-            if (!h->fact_join[d]) SR_FH(hipEventCreateWithFlags(&h->fact_join[d], hipEventDisableTiming));
-            SR_FH(hipStreamWaitEvent(h->fact_stream[d], h->fact_fork, 0));
+    if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
+    SR_FH(hipEventRecord(h->fact_fork, s0));
+    {
+        // the chain of diagonal blocks is latency-bound and must never queue behind the (throughput-bound) bulk
+        // update: critical streams get the highest priority, bulk streams the lowest
+        int prio_lo = 0, prio_hi = 0;
+        SR_FH(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        const int want_mask = nb <= 128 ? 1 : 0;          // beyond that the update is GEMM-bound: all CUs to the bulk
+        for (int sl = 0; sl < n_par; ++sl) {
+            if (!h->fact_stream[sl]) SR_FH(hipStreamCreateWithPriority(&h->fact_stream[sl], hipStreamNonBlocking, prio_hi));
+            if (h->bulk_stream[sl] && h->bulk_masked != want_mask) {
+                (void)hipStreamSynchronize(h->bulk_stream[sl]);
+                (void)hipStreamDestroy(h->bulk_stream[sl]);
+                h->bulk_stream[sl] = nullptr;
+            }
+            if (!h->bulk_stream[sl]) {
+                // The bulk update fills every CU it may use, and the diagonal-block kernel needs a CU to itself
+                // (150 KB of LDS): without a reserve it only starts when the bulk grid drains (measured: 61 us alone,
+                // 140-210 us beside the bulk update).  A workgroup is bound to a shader engine before it waits for a
+                // CU, so the reserve has to exist in EVERY shader engine: the driver deals the CU-mask bits
+                // round-robin over the 8 XCDs and, inside an XCD, over its 4 shader engines (scripts/cumask_probe.hip),
+                // so leaving the first 32 bits out of the bulk streams' mask keeps one CU per shader engine free.
+                // Only for models whose update is bound by that chain (want_mask); the critical kernels run anywhere.
+                hipError_t e = hipErrorNotSupported;
+                if (want_mask) {
+                    hipDeviceProp_t prop;
+                    SR_FH(hipGetDeviceProperties(&prop, h->device));
+                    const int ncu = prop.multiProcessorCount;
+                    if (ncu > 2 * SR_FACT_RESERVED_CUS) {
+                        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+                        for (int c = SR_FACT_RESERVED_CUS; c < ncu; ++c) mask[c / 32] |= 1u << (c % 32);
+                        e = hipExtStreamCreateWithCUMask(&h->bulk_stream[sl], (uint32_t)mask.size(), mask.data());
+                    }
+                }
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    SR_FH(hipStreamCreateWithPriority(&h->bulk_stream[sl], hipStreamNonBlocking, prio_lo));
+                }
+            }
+            if (!h->fact_join[sl]) SR_FH(hipEventCreateWithFlags(&h->fact_join[sl], hipEventDisableTiming));
+            for (int e = 0; e < 2; ++e) {
+                if (!h->ev_panel[sl][e]) SR_FH(hipEventCreateWithFlags(&h->ev_panel[sl][e], hipEventDisableTiming));
+                if (!h->ev_bulk[sl][e]) SR_FH(hipEventCreateWithFlags(&h->ev_bulk[sl][e], hipEventDisableTiming));
+            }
+            SR_FH(hipStreamWaitEvent(h->fact_stream[sl], h->fact_fork, 0));
         }
+        for (int sl = n_par; sl < SR_FACT_SLOTS; ++sl)    // slots of an earlier, wider call: same kind or gone
+            if (h->bulk_stream[sl] && h->bulk_masked != want_mask) {
+                (void)hipStreamDestroy(h->bulk_stream[sl]);
+                h->bulk_stream[sl] = nullptr;
+            }
+        h->bulk_masked = want_mask;
     }
 
-    for (int d = 0; d < h->n_out; ++d) {
-        hipStream_t s = (par && d > 0) ? h->fact_stream[d] : s0;
-        double* U = ws + (size_t)(par ? d : 0) * per;
-        double* W = U + NN;
-        double* v = W + NN;
-        double* Wt = h->Wt + (size_t)d * NN;
-        SR_FH(hipMemsetAsync(W, 0, NN * sizeof(double), s));
-        SR_FH(hipMemsetAsync(Wt, 0, NN * sizeof(double), s));
-        {
-            sr_prof_scope ps(&h->prof, SR_K_GRAM, s);
+    // Outputs are processed in rounds of n_par; inside a round the host walks the panels in the OUTER loop and the
+    // outputs in the inner one, so that all chains advance together (enqueueing one output's 200 launches before
+    // the next one's would serialise them at the host's launch rate).
+    // Buffers per output in flight:
+    //   U  = Gram matrix, updated in place; its diagonal blocks end up factored; its strict lower block triangle
+    //        is scratch of the inversion (Y).
+    //   W  = strict upper block triangle: the FINAL off-diagonal block rows of the factor (the block row solve
+    //        writes them here, out of place: with the 64 x 64 tile two workgroups share the 128 rows of a column
+    //        block, so an in-place solve would race); diagonal + lower: U^-T.  Every block of W is written before
+    //        it is read: no memset.
+    //   Wt = U^-1 (diagonal blocks from the diagonal-block kernel, upper blocks from the inversion; the strict
+    //        lower triangle is zero from allocation and never written).
+    for (int d0 = 0; d0 < h->n_out; d0 += n_par) {
+        const int nd = std::min(n_par, h->n_out - d0);
+        int n_bulk[SR_FACT_SLOTS] = {0};                  // bulk updates issued so far (event ping-pong)
+        for (int sl = 0; sl < nd; ++sl) {
+            const int d = d0 + sl;
+            hipStream_t sc = h->fact_stream[sl];
+            double* U = ws + (size_t)sl * per;
+            sr_prof_scope ps(&h->prof, SR_K_GRAM, sc);
             if (h->general)
-                SR_F(sr_launch_gram_general(h->Z, h->kp + (size_t)d * SR_KP(h->D), noise[d], U, h->N, Np, h->D, s));
+                SR_F(sr_launch_gram_general(h->Z, h->kp + (size_t)d * SR_KP(h->D), noise[d], U, h->N, Np, h->D, sc));
             else
-                SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, s));
+                SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, sc));
         }
-        // --- Cholesky K = U^T U, right-looking, two-level blocking: 128-row blocks inside panels of
-        // SR_PANEL blocks.  Inside a panel a factored block row updates only the panel's remaining
-        // rows; everything below the panel is updated once per panel with K = SR_PANEL*128, which
-        // divides the read-modify-write traffic of the trailing matrix by SR_PANEL.
-        for (int p0 = 0; p0 < nb; p0 += SR_PANEL) {
-            const int p1 = std::min(nb, p0 + SR_PANEL);
+        // --- Cholesky K = U^T U, right-looking in panels of P blocks with look-ahead: after a panel is factored
+        // (critical stream: diagonal block, block row, the panel's own remaining rows), the trailing update is
+        // split -- the rows of the NEXT panel on the critical stream, so that its factorisation can start at
+        // once, everything behind them on the bulk stream, which may lag one panel behind.
+        int pi = 0;
+        for (int p0 = 0; p0 < nb; p0 += P, ++pi) {
+            const int p1 = std::min(nb, p0 + P);
             for (int kb = p0; kb < p1; ++kb) {
-                const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
-                {
-                    sr_prof_scope ps(&h->prof, SR_K_POTRF, s);
-                    SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, s));
-                }
-                const int ncols = Np - (kb + 1) * SR_NB;
-                if (ncols > 0) {
-                    double* Urow = U + dg + SR_NB;                // U[kb rows][cols right of the block]
-                    sr_prof_scope ps(&h->prof, SR_K_GEMM, s);
-                    // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major) -- in place
-                    SR_F(sr_launch_gemm_tn(Wt + dg, Np, Urow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, s));
-                    const int mrows = (p1 - kb - 1) * SR_NB;      // remaining rows of this panel
-                    if (mrows > 0)
-                        SR_F(sr_launch_gemm_tn(Urow, Np, Urow, Np, U + dg + (size_t)SR_NB * Np + SR_NB, Np,
-                                               mrows, ncols, SR_NB, -1.0, 1.0, 1, s));
+                for (int sl = 0; sl < nd; ++sl) {
+                    const int d = d0 + sl;
+                    hipStream_t sc = h->fact_stream[sl];
+                    double* U = ws + (size_t)sl * per;
+                    double* W = U + NN;
+                    double* Wt = h->Wt + (size_t)d * NN;
+                    const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
+                    {
+                        sr_prof_scope ps(&h->prof, SR_K_POTRF, sc);
+                        SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, sc));
+                    }
+                    const int ncols = Np - (kb + 1) * SR_NB;
+                    if (ncols > 0) {
+                        const double* Arow = U + dg + SR_NB;          // updated Gram rows right of the block
+                        double* Urow = W + dg + SR_NB;                // factor rows U[kb][cols right of the block]
+                        sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                        // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major)
+                        SR_F(sr_launch_gemm_tn(Wt + dg, Np, Arow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, sc, 1));
+                        const int mrows = (p1 - kb - 1) * SR_NB;      // remaining rows of this panel
+                        if (mrows > 0)
+                            SR_F(sr_launch_gemm_tn_upper(Urow, Np, Urow, Np, U + dg + (size_t)SR_NB * Np + SR_NB, Np,
+                                                         mrows, ncols, SR_NB, -1.0, 1.0, sc, 1));
+                    }
                 }
             }
             const int rest = Np - p1 * SR_NB;
-            if (rest > 0) {
-                sr_prof_scope ps(&h->prof, SR_K_GEMM, s);
-                const double* Upan = U + (size_t)p0 * SR_NB * Np + (size_t)p1 * SR_NB;
-                SR_F(sr_launch_gemm_tn(Upan, Np, Upan, Np, U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB, Np,
-                                       rest, rest, (p1 - p0) * SR_NB, -1.0, 1.0, 1, s));
+            if (rest <= 0) continue;
+            for (int sl = 0; sl < nd; ++sl) {
+                hipStream_t sc = h->fact_stream[sl], sb = h->bulk_stream[sl];
+                double* U = ws + (size_t)sl * per;
+                double* W = U + NN;
+                const int Kp = (p1 - p0) * SR_NB;
+                const double* Upan = W + (size_t)p0 * SR_NB * Np + (size_t)p1 * SR_NB;    // factor rows of the panel
+                double* Cnext = U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB;
+                const int la = std::min(P * SR_NB, rest);         // rows of the next panel
+                const int bulk = rest - la;
+                if (bulk > 0) SR_FH(hipEventRecord(h->ev_panel[sl][pi & 1], sc));     // the panel's rows are final
+                // the previous bulk update wrote the look-ahead rows too: it has to be through
+                if (n_bulk[sl] > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[sl][(n_bulk[sl] - 1) & 1], 0));
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1));
+                }
+                if (bulk > 0) {
+                    SR_FH(hipStreamWaitEvent(sb, h->ev_panel[sl][pi & 1], 0));
+                    {
+                        sr_prof_scope ps(&h->prof, SR_K_GEMM, sb);
+                        SR_F(sr_launch_gemm_tn_upper(Upan + la, Np, Upan + la, Np, Cnext + (size_t)la * Np + la, Np,
+                                                     bulk, bulk, Kp, -1.0, 1.0, sb));
+                    }
+                    SR_FH(hipEventRecord(h->ev_bulk[sl][n_bulk[sl] & 1], sb));
+                    ++n_bulk[sl];
+                }
             }
         }
-        // --- W = U^-T (lower) and Wt = U^-1 (upper) by recursive halving of the block range:
-        //   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22],  L21 = U12^T.
-        // Both products are TN GEMMs over large ranges (good occupancy at every level above the leaves):
-        //   Y   = U12^T W11      (A = U12 k-major, B = W11 block-lower-triangular, mode 2)  -> parked in the
-        //                         unused strict lower triangle of U, exactly where W21 will live in W
-        //   W21 = -Wt22^T Y      (A = Wt22 = U22^-1 upper-triangular, mode 3)
-        //   Wt12 = W21^T         (keeps U^-1 complete for the next level)
-        // The diagonal blocks of W / Wt were written by sr_potrf_diag_kernel.
-        {
-            struct Rng { int lo, hi; bool expanded; };
-            std::vector<Rng> stack;
-            stack.push_back({0, nb, false});
-            while (!stack.empty()) {
-                Rng r = stack.back();
-                stack.pop_back();
-                if (r.hi - r.lo <= 1) continue;
-                const int mid = (r.lo + r.hi) / 2;
-                if (!r.expanded) {
-                    stack.push_back({r.lo, r.hi, true});       // combine after both halves
-                    stack.push_back({r.lo, mid, false});
-                    stack.push_back({mid, r.hi, false});
-                    continue;
-                }
-                const int n1 = (mid - r.lo) * SR_NB, n2 = (r.hi - mid) * SR_NB;
-                const size_t o11 = (size_t)r.lo * SR_NB * Np + (size_t)r.lo * SR_NB;
-                const size_t o12 = (size_t)r.lo * SR_NB * Np + (size_t)mid * SR_NB;
-                const size_t o21 = (size_t)mid * SR_NB * Np + (size_t)r.lo * SR_NB;
-                const size_t o22 = (size_t)mid * SR_NB * Np + (size_t)mid * SR_NB;
-                sr_prof_scope ps(&h->prof, SR_K_TRINV, s);
-                SR_F(sr_launch_gemm_tn(U + o12, Np, W + o11, Np, U + o21, Np, n2, n1, n1, 1.0, 0.0, 2, s));
-                SR_F(sr_launch_gemm_tn(Wt + o22, Np, U + o21, Np, W + o21, Np, n2, n1, n2, -1.0, 0.0, 3, s));
-                SR_F(sr_launch_transpose_rect(W + o21, Np, Wt + o12, Np, n2, n1, s));
+        for (int sl = 0; sl < nd; ++sl)
+            if (n_bulk[sl] > 0) SR_FH(hipStreamWaitEvent(h->fact_stream[sl], h->ev_bulk[sl][(n_bulk[sl] - 1) & 1], 0));
+        // --- W = U^-T (lower) and Wt = U^-1 (upper) by recursive halving of the block range, level by level
+        // (ensure_inv_jobs).  The diagonal blocks of W / Wt were written by sr_potrf_diag_kernel.
+        for (const sr_gp::inv_level& lv : h->inv_levels) {
+            for (int sl = 0; sl < nd; ++sl) {
+                hipStream_t sc = h->fact_stream[sl];
+                double* U = ws + (size_t)sl * per;
+                double* W = U + NN;
+                double* Wt = h->Wt + (size_t)(d0 + sl) * NN;
+                sr_prof_scope ps(&h->prof, SR_K_TRINV, sc);
+                SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, lv.count, lv.maxM, lv.maxN, lv.tiles, 1.0, 2, sc));
+                SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2, lv.count, lv.maxM, lv.maxN, lv.tiles, -1.0, 3, sc));
             }
         }
         // alpha = Wt (W y)
-        SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d * Np, v, Np, 1, s));
-        SR_F(sr_launch_trmv(Wt, Np, v, h->alpha + (size_t)d * Np, Np, 0, s));
-        if (par && d > 0) {
-            SR_FH(hipEventRecord(h->fact_join[d], s));
-            SR_FH(hipStreamWaitEvent(s0, h->fact_join[d], 0));
+        for (int sl = 0; sl < nd; ++sl) {
+            const int d = d0 + sl;
+            hipStream_t sc = h->fact_stream[sl];
+            double* U = ws + (size_t)sl * per;
+            double* W = U + NN;
+            double* v = W + NN;
+            double* Wt = h->Wt + (size_t)d * NN;
+            SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d * Np, v, Np, 1, sc));
+            SR_F(sr_launch_trmv(Wt, Np, v, h->alpha + (size_t)d * Np, Np, 0, sc));
         }
+    }
+    for (int sl = 0; sl < n_par; ++sl) {
+        SR_FH(hipEventRecord(h->fact_join[sl], h->fact_stream[sl]));
+        SR_FH(hipStreamWaitEvent(s0, h->fact_join[sl], 0));
     }
     std::vector<int> info_h(h->n_out, 0);
     SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s0));
@@ -343,11 +524,17 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     return SR_OK;
 }
 
+extern "C" int sr_gp_set_fact_panel(sr_gp_t h, int panel) {
+    SR_CHECK(h != nullptr && panel >= 0 && panel <= 64, SR_EINVAL, "sr_gp_set_fact_panel: bad argument");
+    h->fact_panel = panel;
+    return SR_OK;
+}
+
 extern "C" int sr_gp_export(sr_gp_t h, double* alpha, double* Wt, void* stream) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_export: NULL handle");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_export: model not factorized");
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     if (alpha)
         SR_HIP(hipMemcpy2DAsync(alpha, sizeof(double) * h->N, h->alpha + (h->Np - h->N),
                                 sizeof(double) * h->Np, sizeof(double) * h->N, h->n_out,
@@ -363,7 +550,7 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_import: call sr_gp_set_data first (Z and hyper-parameters)");
     SR_CHECK(alpha && Wt, SR_EINVAL, "sr_gp_import: alpha and Wt are both required");
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     SR_TRY(ensure_wt(h));
     SR_HIP(hipMemsetAsync(h->alpha, 0, sizeof(double) * h->n_out * h->Np, s));
     SR_HIP(hipMemcpy2DAsync(h->alpha + (h->Np - h->N), sizeof(double) * h->Np, alpha,
@@ -380,7 +567,7 @@ extern "C" int sr_gp_mll(sr_gp_t h, double* nll, double* grad, void* stream) {
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_mll: model not factorized");
     SR_CHECK(h->general, SR_ESTATE, "sr_gp_mll: set the data with sr_gp_set_data_general (packed parameters)");
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     const int Np = h->Np, D = h->D;
     const size_t NN = (size_t)Np * Np;
     const int ng = SR_KP(D);                        // [v, c0, s[D], a[D], b[D], noise]
@@ -410,7 +597,7 @@ extern "C" int sr_gp_mll(sr_gp_t h, double* nll, double* grad, void* stream) {
 extern "C" int sr_gp_logdet(sr_gp_t h, double* logdet, void* stream) {
     SR_CHECK(h && logdet, SR_EINVAL, "sr_gp_logdet: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_logdet: model not factorized");
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     return sr_launch_logdet(h->Wt, h->Np, h->n_out, logdet, (hipStream_t)stream);
 }
 
@@ -419,7 +606,7 @@ extern "C" int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream) {
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_inv_k: model not factorized");
     SR_CHECK(d >= 0 && d < h->n_out, SR_EINVAL, "sr_gp_inv_k: d=%d out of range", d);
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     const int Np = h->Np;
     const size_t NN = (size_t)Np * Np;
     double *W = nullptr, *out = nullptr;
@@ -455,16 +642,20 @@ static int pick_nsplit(const sr_gp* h, long Tp) {
 }
 
 static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
-    if (Tp <= h->ws_Tp && nsplit <= h->ws_nsplit) return SR_OK;
+    // two capacities: buffers sized by the padded batch (K*, row-block partials, outputs) and the N-split partials
+    // of mu / jac, sized by the PRODUCT nsplit * Tp actually requested (nsplit is largest for tiny batches, Tp for
+    // big ones: sizing by max(nsplit) x max(Tp) would hold GBs of dead workspace)
+    const long need_part = (long)nsplit * Tp;
+    if (Tp <= h->ws_Tp && need_part <= h->ws_part) return SR_OK;
     const long nTp = std::max(Tp, h->ws_Tp);
-    const int nsp = std::max(nsplit, h->ws_nsplit);
+    const long npart = std::max(need_part, h->ws_part);
     (void)hipDeviceSynchronize();
     free_ws(h);
     const int nrb = h->Np / SR_NB;
     int rc;
     if ((rc = dev_alloc(&h->Ks, (size_t)h->n_out * h->Np * nTp)) ||
-        (rc = dev_alloc(&h->mu_part, (size_t)nsp * h->n_out * nTp)) ||
-        (rc = dev_alloc(&h->jac_part, (size_t)nsp * h->n_out * h->D * nTp)) ||
+        (rc = dev_alloc(&h->mu_part, (size_t)npart * h->n_out)) ||
+        (rc = dev_alloc(&h->jac_part, (size_t)npart * h->n_out * h->D)) ||
         (rc = dev_alloc(&h->var_part, (size_t)h->n_out * nrb * nTp)) ||
         (rc = dev_alloc(&h->mu, (size_t)h->n_out * nTp)) ||
         (rc = dev_alloc(&h->var, (size_t)h->n_out * nTp)) ||
@@ -474,7 +665,7 @@ static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
         return rc;
     }
     h->ws_Tp = nTp;
-    h->ws_nsplit = nsp;
+    h->ws_part = npart;
     return SR_OK;
 }
 
@@ -569,7 +760,7 @@ extern "C" int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, do
     if (T == 0) return SR_OK;
     SR_CHECK(Xq && mu && var, SR_EINVAL, "sr_gp_predict: NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
         SR_TRY(gp_pass(h, Tc, Xq + t0 * h->D, h->D, h->D, nullptr, 0, 0, mu + t0 * h->n_out,
@@ -623,7 +814,7 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_linearize: model not factorized");
     SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     if (h->small_path == 1 && !h->general && sr_gp_small_wanted(h->Np, SR_SMALL_T, h->D, false)) {
         // small ARD-RBF model: everything in one launch (sr_small.hip, LIN mode)
         sr_kstar_args ka{};
@@ -685,7 +876,7 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
     int n_s, n_u;
     SR_TRY(check_reach_dims(h, &n_s, &n_u));
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
         double* var_dst = var_out ? var_out + t0 * n_s : nullptr;
@@ -719,7 +910,7 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
                           double* p_all, double* q_all, double* gp_var_all, int* n_bad, hipStream_t s) {
     int n_s, n_u;
     SR_TRY(check_reach_dims(h, &n_s, &n_u));
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
@@ -800,7 +991,7 @@ extern "C" int sr_moment_step(int device, long T, int n_s, int n_u, int mode, co
     SR_CHECK(mu_x && k_ff && mu_g && var_g && a && b && mu_out && sigma_out, SR_EINVAL, "sr_moment_step: NULL argument");
     SR_CHECK(sigma_x == nullptr || (k_fb != nullptr && (mode == 2 || jac_g != nullptr)), SR_EINVAL,
              "sr_moment_step: k_fb (and jac for the Taylor mode) required with sigma_x");
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     sr_ell_args ea;
     ea.T = T; ea.n_s = n_s; ea.n_u = n_u;
     ea.p = mu_x; ea.ldp = n_s; ea.q = sigma_x; ea.ldq = (long)n_s * n_s;
@@ -824,7 +1015,7 @@ extern "C" int sr_ellipsoid_step(int device, long T, int n_s, int n_u, const dou
              "sr_ellipsoid_step: NULL argument");
     SR_CHECK(q == nullptr || (k_fb != nullptr && jac != nullptr), SR_EINVAL,
              "sr_ellipsoid_step: k_fb and jac required with q");
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     sr_ell_args ea;
     ea.T = T; ea.n_s = n_s; ea.n_u = n_u;
     ea.p = p; ea.ldp = n_s; ea.q = q; ea.ldq = (long)n_s * n_s;
@@ -843,7 +1034,7 @@ extern "C" int sr_remainder_overapprox(int device, long T, int n_s, int n_u, con
     if (T == 0) return SR_OK;
     SR_CHECK(q && k_fb && l_mu && l_sigma && u_mu && u_sigma, SR_EINVAL,
              "sr_remainder_overapprox: NULL argument");
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     return sr_launch_remainder(T, n_s, n_u, q, k_fb, l_mu, l_sigma, u_mu, u_sigma, (hipStream_t)stream);
 }
 
@@ -853,7 +1044,7 @@ extern "C" int sr_safety_distance(int device, long T, int n_s, int m, const doub
     SR_CHECK(T >= 0 && n_s >= 1 && m >= 1, SR_EINVAL, "sr_safety_distance: T=%ld n_s=%d m=%d", T, n_s, m);
     if (T == 0) return SR_OK;
     SR_CHECK(p && q && h_mat && h_vec && d, SR_EINVAL, "sr_safety_distance: NULL argument");
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     return sr_launch_safety(T, n_s, m, p, q, h_mat, h_vec, c_safety, d, (hipStream_t)stream);
 }
 
@@ -862,7 +1053,7 @@ extern "C" int sr_distance_to_center(int device, long T, int K, int n_s, const d
     SR_CHECK(T >= 0 && K >= 0 && n_s >= 1, SR_EINVAL, "sr_distance_to_center: T=%ld K=%d n_s=%d", T, K, n_s);
     if (T == 0 || K == 0) return SR_OK;
     SR_CHECK(samples && p && q && d, SR_EINVAL, "sr_distance_to_center: NULL argument");
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     return sr_launch_distance(T, K, n_s, samples, per_t, p, q, d, (hipStream_t)stream);
 }
 
@@ -874,7 +1065,7 @@ extern "C" int sr_gp_sample(int device, long T, int size, int n_out, int n_u, co
     if (T == 0 || size == 0) return SR_OK;
     SR_CHECK(mu && var && eps && S, SR_EINVAL, "sr_gp_sample: NULL argument");
     SR_CHECK(!z_next || n_u == 0 || (k_fb && k_ff), SR_EINVAL, "sr_gp_sample: z_next needs k_fb and k_ff");
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     return sr_launch_sample(T, size, n_out, n_u, mu, var, eps, S, k_fb, k_ff, z_next, (hipStream_t)stream);
 }
 
@@ -906,20 +1097,27 @@ extern "C" int sr_test_gemm_tn(int device, const double* A, long lda, const doub
                                double* C, long ldc, int M, int N, int K, double alpha, double beta,
                                int mode, void* stream) {
     SR_CHECK(A && B && C, SR_EINVAL, "sr_test_gemm_tn: NULL argument");
-    SR_HIP(hipSetDevice(device));
+    SR_DEVICE(device);
     return sr_launch_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, mode, (hipStream_t)stream);
+}
+
+extern "C" int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, long ldw, int* info,
+                                  int skip, void* stream) {
+    SR_CHECK(A && wt && w && info, SR_EINVAL, "sr_test_potrf_diag: NULL argument");
+    SR_DEVICE(device);
+    return sr_launch_potrf_diag(A, lda, wt, w, ldw, 0, info, (hipStream_t)stream, skip);
 }
 
 extern "C" int sr_prof_enable(sr_gp_t h, int on) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_prof_enable: NULL handle");
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     if (!on) h->prof.resolve();
     h->prof.enabled = on ? 1 : 0;
     return SR_OK;
 }
 extern "C" int sr_prof_reset(sr_gp_t h) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_prof_reset: NULL handle");
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     h->prof.resolve();
     for (int i = 0; i < SR_K_COUNT; ++i) { h->prof.ms[i] = 0.0; h->prof.launches[i] = 0; }
     return SR_OK;
@@ -927,7 +1125,7 @@ extern "C" int sr_prof_reset(sr_gp_t h) {
 extern "C" int sr_prof_get(sr_gp_t h, int kernel_id, double* ms_total, long* launches) {
     SR_CHECK(h != nullptr && kernel_id >= 0 && kernel_id < SR_K_COUNT, SR_EINVAL,
              "sr_prof_get: bad argument");
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     h->prof.resolve();
     if (ms_total) *ms_total = h->prof.ms[kernel_id];
     if (launches) *launches = h->prof.launches[kernel_id];
@@ -1080,7 +1278,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_append: model not factorized");
     SR_CHECK(m >= 1 && m <= SR_NB, SR_EINVAL, "sr_gp_append: m=%d outside 1..%d (append in several calls)", m, SR_NB);
     hipStream_t s = (hipStream_t)stream;
-    SR_HIP(hipSetDevice(h->device));
+    SR_DEVICE(h->device);
     if (m <= SR_SMALL_T) return append_small(h, Znew, Ynew, m, s, info);
     const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
     const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1;

@@ -10,6 +10,7 @@
 #define SR_NB 128          // factor block size == GEMM tile edge; Np is a multiple of it
 #define SR_PANEL 4         // factor blocks per Cholesky panel (deferred trailing update with K = 512)
 #define SR_MAX_NS 8
+#define SR_FACT_SLOTS 8      // outputs factorised concurrently (own streams + scratch each)
 #define SR_MAX_NU 4
 #define SR_MAX_D 12
 #define SR_VAR_CLIP 1e-15  // GPy GP._raw_predict clips the predictive variance here
@@ -98,8 +99,21 @@ struct sr_prof_scope {
 //   mode 2: B block-lower-triangular (B[k][n] == 0 for k < n0): per tile k starts at n0.
 //   mode 4: A block-lower-triangular (A[k][m] == 0 for k < m0): per tile k starts at m0.
 //   mode 3: A block-upper-triangular (A[k][m] == 0 for k >= m0 + 128): per tile k ends at m0 + 128.
+// prio != 0: the workgroups raise their wavefront priority (critical-path products that share CUs with bulk work)
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s);
+                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s, int prio = 0);
+
+// upper block triangle only (tiles n0 >= m0; M <= N) on a linear grid -- the trailing updates of the Cholesky
+int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio = 0);
+// a list of independent TN products in one launch (one level of the recursive triangular inversion):
+// C_j = alpha A_j^T B_j, optionally also CT_j = C_j^T; operands at offsets (doubles) of common base pointers,
+// common leading dimension.  mode 2 / 3 as above.
+struct sr_gemm_job { long a, b, c, ct; int M, N, K, pad; };
+// tiles128: 128 x 128 tiles of the whole list (picks the workgroup tile)
+int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, double* CTb, long ld,
+                           const sr_gemm_job* jobs_dev, int njobs, int maxM, int maxN, long tiles128, double alpha,
+                           int mode, hipStream_t s);
 
 // padded index space: the Np - N padding rows/cols sit at the FRONT (identity), training point i lives
 // at padded index i + (Np - N); the contraction kernels simply start at k = 16*floor((Np-N)/16).
@@ -108,7 +122,7 @@ int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, 
 // factor the diagonal block kb of the Np x Np matrix A (upper), write U_kk in place, U_kk^-1 to
 // wt_diag (into Wt's diagonal block) and U_kk^-T to w_diag (into W's diagonal block).
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
-                         int kb, int* info_dev, hipStream_t s);
+                         int kb, int* info_dev, hipStream_t s, int skip = 0);
 int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s);
 int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd, int rows, int cols,
                              hipStream_t s);

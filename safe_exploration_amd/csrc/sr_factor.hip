@@ -6,32 +6,47 @@
 #include "sr_mfma_tile.h"
 
 // ------------------------------------------------------------------------------------------------
-// generic TN GEMM on the fp64 matrix cores
+// TN GEMMs on the fp64 matrix cores, on either workgroup tile of sr_mfma_tile.h
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void sr_gemm_tn_kernel(
-    const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* C,
-    long ldc, int K, double alpha, double beta, int mode) {
-    __shared__ double smem[srt::SMEM_DOUBLES];
-    const int m0 = blockIdx.y * srt::BM;
-    const int n0 = blockIdx.x * srt::BN;
-    if (mode == 1 && n0 < m0) return;
-    const int k_beg = (mode == 2) ? n0 : ((mode == 4) ? m0 : 0);
-    const int k_end = (mode == 3) ? min(K, m0 + srt::BM) : K;
+struct sr_tile128 {
+    using Acc = srt::Acc;
+    static constexpr int T = 128, NI = 4, SMEM = srt::SMEM_DOUBLES, WPS = 2;
+    static __device__ __forceinline__ void mainloop(const double* A, long lda, const double* B, long ldb, int k0,
+                                                    int k1, double* smem, Acc& acc) {
+        srt::mainloop_tn_glds<16>(A, lda, B, ldb, k0, k1, smem, acc);   // LDS-DMA staging (+5 % over register staging)
+    }
+    static __device__ __forceinline__ int row(int wm, int mi, int lane, int r) { return srt::acc_row(wm, mi, lane, r); }
+    static __device__ __forceinline__ int col(int wn, int ni, int lane) { return srt::acc_col(wn, ni, lane); }
+};
+struct sr_tile64 {
+    using Acc = srt64::Acc;
+    static constexpr int T = 64, NI = 2, SMEM = srt64::SMEM_DOUBLES, WPS = 4;
+    static __device__ __forceinline__ void mainloop(const double* A, long lda, const double* B, long ldb, int k0,
+                                                    int k1, double* smem, Acc& acc) {
+        srt64::mainloop_tn(A, lda, B, ldb, k0, k1, smem, acc);
+    }
+    static __device__ __forceinline__ int row(int wm, int mi, int lane, int r) { return srt64::acc_row(wm, mi, lane, r); }
+    static __device__ __forceinline__ int col(int wn, int ni, int lane) { return srt64::acc_col(wn, ni, lane); }
+};
 
-    srt::Acc acc;
+// C = alpha A^T B + beta C on one tile at (m0, n0), k in [k_beg, k_end)
+template <class TL>
+__device__ __forceinline__ void sr_gemm_tile(const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                             long ldb, double* C, long ldc, int m0, int n0, int k_beg, int k_end,
+                                             double alpha, double beta, double* smem) {
+    typename TL::Acc acc;
     acc.zero();
-    srt::mainloop_tn_glds<16>(A + m0, lda, B + n0, ldb, k_beg, k_end, smem, acc);   // LDS-DMA staging (+5 % over register staging)
-
+    TL::mainloop(A + m0, lda, B + n0, ldb, k_beg, k_end, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < TL::NI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < TL::NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long row = m0 + srt::acc_row(wm, mi, lane, r);
-                const long col = n0 + srt::acc_col(wn, ni, lane);
+                const long row = m0 + TL::row(wm, mi, lane, r);
+                const long col = n0 + TL::col(wn, ni, lane);
                 double* c = C + row * ldc + col;
                 double v = alpha * acc.v[mi][ni][r];
                 if (beta != 0.0) v += beta * (*c);
@@ -39,13 +54,157 @@ __global__ __launch_bounds__(256, 2) void sr_gemm_tn_kernel(
             }
 }
 
+// rectangular grid; mode as documented in sr_common.h (k ranges at the tile's own granularity)
+template <class TL>
+__global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_kernel(
+    const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* C, long ldc, int K,
+    double alpha, double beta, int mode, int prio) {
+    __shared__ double smem[TL::SMEM];
+    if (prio) __builtin_amdgcn_s_setprio(3);       // critical-path product: win the issue arbitration on a shared SIMD
+    const int m0 = blockIdx.y * TL::T;
+    const int n0 = blockIdx.x * TL::T;
+    if (mode == 1 && (n0 & ~127) < (m0 & ~127)) return;        // triangular structure is defined on 128-blocks
+    const int k_beg = (mode == 2) ? (n0 & ~127) : ((mode == 4) ? (m0 & ~127) : 0);
+    const int k_end = (mode == 3) ? min(K, (m0 & ~127) + 128) : K;
+    sr_gemm_tile<TL>(A, lda, B, ldb, C, ldc, m0, n0, k_beg, k_end, alpha, beta, smem);
+}
+
+// One fp64 MFMA holds its SIMD for 64 cycles: a 128 x 128 tile with K = 128 is 14 us of one CU, whatever else
+// happens.  Products of few tiles are therefore latency-bound (the block row and the look-ahead row of the
+// Cholesky sit on its critical path) or balance-bound (triangular k ranges); they take the 64 x 64 tile.
+static inline bool sr_use_tile64(long tiles128) { return tiles128 < 1024; }
+
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s) {
+                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s, int prio) {
     SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && M > 0 && N > 0, SR_EINVAL,
              "gemm_tn: M=%d N=%d K=%d must be tile multiples", M, N, K);
-    dim3 grid(N / srt::BN, M / srt::BM);
-    hipLaunchKernelGGL(sr_gemm_tn_kernel, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
-                       beta, mode);
+    if (sr_use_tile64((long)(M / 128) * (N / 128)))
+        hipLaunchKernelGGL(sr_gemm_tn_kernel<sr_tile64>, dim3(N / 64, M / 64), dim3(256), 0, s, A, lda, B, ldb, C, ldc,
+                           K, alpha, beta, mode, prio);
+    else
+        hipLaunchKernelGGL(sr_gemm_tn_kernel<sr_tile128>, dim3(N / 128, M / 128), dim3(256), 0, s, A, lda, B, ldb, C,
+                           ldc, K, alpha, beta, mode, prio);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Upper block triangle only (mode 1 above) on a LINEAR grid: tile b -> (m, n >= m), rows of tn - m tiles.
+// The rectangular grid of the trailing update starts (and retires) tm*tn/2 empty workgroups; at N = 50000
+// that is 47 000 of them per panel.  C (op)= alpha A^T B + beta C on the tiles n0 >= m0.
+// ------------------------------------------------------------------------------------------------
+template <class TL>
+__global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_upper_kernel(
+    const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* C, long ldc,
+    int K, int tn, double alpha, double beta, int prio) {
+    __shared__ double smem[TL::SMEM];
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    // row m holds tiles [c(m), c(m+1)), c(m) = m tn - m (m - 1) / 2
+    const long b = blockIdx.x;
+    int m = (int)((2.0 * tn + 1.0 - sqrt((2.0 * tn + 1.0) * (2.0 * tn + 1.0) - 8.0 * (double)b)) * 0.5);
+    if (m < 0) m = 0;
+    while ((long)(m + 1) * tn - (long)(m + 1) * m / 2 <= b) ++m;
+    while ((long)m * tn - (long)m * (m - 1) / 2 > b) --m;
+    const int n = m + (int)(b - ((long)m * tn - (long)m * (m - 1) / 2));
+    sr_gemm_tile<TL>(A, lda, B, ldb, C, ldc, m * TL::T, n * TL::T, 0, K, alpha, beta, smem);
+}
+
+// C: M x N with only the tiles n0 >= m0 touched (M <= N, both multiples of 128).  With the 64 x 64 tile the
+// lower-left quarter of every diagonal 128-block stays untouched as well: nothing reads it (the diagonal-block
+// kernel loads the upper triangle only).
+int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio) {
+    SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && M > 0 && N >= M, SR_EINVAL,
+             "gemm_tn_upper: M=%d N=%d K=%d", M, N, K);
+    const long tm128 = M / 128, tn128 = N / 128;
+    const bool t64 = sr_use_tile64(tm128 * tn128 - tm128 * (tm128 - 1) / 2);
+    const long tm = t64 ? M / 64 : tm128, tn = t64 ? N / 64 : tn128;
+    const long tiles = tm * tn - tm * (tm - 1) / 2;
+    SR_CHECK(tiles < 2147483647L, SR_EINVAL, "gemm_tn_upper: grid too large");
+    if (t64)
+        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile64>, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, B, ldb,
+                           C, ldc, K, (int)tn, alpha, beta, prio);
+    else
+        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile128>, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, B, ldb,
+                           C, ldc, K, (int)tn, alpha, beta, prio);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A LIST of independent TN products in one launch (blockIdx.z = job): the nodes of one level of the recursive
+// triangular inversion.  Per job C = alpha A^T B with the operands at job-specific offsets of common base
+// pointers; optionally the transpose of C is written as well (through LDS, coalesced both ways) -- the second
+// product of a node yields W21 and U^-1's block Wt12 = W21^T at once, so no transpose pass is needed.
+//   mode 2: B lower-triangular (k starts at n0);  mode 3: A upper-triangular (k ends at m0 + tile).
+// (first version: one launch per product and node -- 2 x 39 GEMM + 39 transpose launches at N = 5000, most of them
+//  a handful of workgroups wide and serialised on one stream.)
+// ------------------------------------------------------------------------------------------------
+template <class TL>
+__global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_jobs_kernel(
+    const double* __restrict__ Ab, const double* __restrict__ Bb, double* Cb, double* CTb, long ld,
+    const sr_gemm_job* __restrict__ jobs, double alpha, int mode) {
+    __shared__ double smem[TL::SMEM];
+    const sr_gemm_job jb = jobs[blockIdx.z];
+    const int tm = jb.M / TL::T;
+    if ((int)blockIdx.x * TL::T >= jb.N || (int)blockIdx.y >= tm) return;
+    // heavy tiles first: mode 2 is heaviest at small n0 (natural order), mode 3 at large m0 (reversed)
+    const int m0 = ((mode == 3) ? (tm - 1 - (int)blockIdx.y) : (int)blockIdx.y) * TL::T;
+    const int n0 = blockIdx.x * TL::T;
+    const int k_beg = (mode == 2) ? n0 : 0;
+    const int k_end = (mode == 3) ? min(jb.K, m0 + TL::T) : jb.K;
+
+    typename TL::Acc acc;
+    acc.zero();
+    TL::mainloop(Ab + jb.a + m0, ld, Bb + jb.b + n0, ld, k_beg, k_end, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    double* C = Cb + jb.c;
+#pragma unroll
+    for (int mi = 0; mi < TL::NI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TL::NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc.v[mi][ni][r] *= alpha;
+                C[(long)(m0 + TL::row(wm, mi, lane, r)) * ld + n0 + TL::col(wn, ni, lane)] = acc.v[mi][ni][r];
+            }
+    if (CTb == nullptr) return;
+    // CT[n][m] = C[m][n] through T[tile n][65]: 64 rows (m) at a time (one pass for the 64-tile, two for 128)
+    double* CT = CTb + jb.ct;
+    double* T = smem;
+    constexpr int TLD = 65;
+    constexpr int HALVES = TL::T / 64;           // wavefront rows per pass: all (64-tile) or one of two (128-tile)
+#pragma unroll 1
+    for (int h = 0; h < HALVES; ++h) {
+        if (HALVES == 1 || wm == h) {
+#pragma unroll
+            for (int mi = 0; mi < TL::NI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TL::NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        T[TL::col(wn, ni, lane) * TLD + (TL::row(wm, mi, lane, r) & 63)] = acc.v[mi][ni][r];
+        }
+        __syncthreads();
+        for (int nrow = wave; nrow < TL::T; nrow += 4)        // one wavefront = one 512 B row segment of CT
+            CT[(long)(n0 + nrow) * ld + m0 + h * 64 + lane] = T[nrow * TLD + lane];
+        __syncthreads();
+    }
+}
+
+int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, double* CTb, long ld,
+                           const sr_gemm_job* jobs_dev, int njobs, int maxM, int maxN, long tiles128, double alpha,
+                           int mode, hipStream_t s) {
+    SR_CHECK(njobs > 0 && njobs <= 65535 && maxM % srt::BM == 0 && maxN % srt::BN == 0 && (mode == 2 || mode == 3),
+             SR_EINVAL, "gemm_tn_jobs: njobs=%d maxM=%d maxN=%d mode=%d", njobs, maxM, maxN, mode);
+    if (sr_use_tile64(tiles128))
+        hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile64>, dim3(maxN / 64, maxM / 64, njobs), dim3(256), 0, s, Ab,
+                           Bb, Cb, CTb, ld, jobs_dev, alpha, mode);
+    else
+        hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile128>, dim3(maxN / 128, maxM / 128, njobs), dim3(256), 0, s,
+                           Ab, Bb, Cb, CTb, ld, jobs_dev, alpha, mode);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -62,6 +221,7 @@ __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= Np) return;
+    if ((j | 127) < i) return;               // blocks left of the diagonal are never read (upper factorisation)
     const int off = Np - N;                  // front padding
     double v;
     if (i < off || j < off) {
@@ -100,6 +260,7 @@ __global__ __launch_bounds__(256) void sr_gram_general_kernel(const double* __re
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= Np) return;
+    if ((j | 127) < i) return;               // blocks left of the diagonal are never read (upper factorisation)
     const int off = Np - N;
     double v;
     if (i < off || j < off) {
@@ -133,72 +294,129 @@ int sr_launch_gram_general(const double* Z, const double* kp, double noise, doub
 
 // ------------------------------------------------------------------------------------------------
 // Diagonal block: A_kk = U_kk^T U_kk (upper Cholesky) and in-place inverse of U_kk, all in LDS.
-// One workgroup of 16 wavefronts; 128 x 129 doubles of LDS (132 KiB of the CU's 160 KiB).
-// This kernel sits on the critical path of the blocked factorisation (one launch per 128 rows), so it is
-// built to keep block-wide barriers rare: both halves work on 16 x 16 sub-blocks.
-//   Cholesky, per 16-column panel (3 barriers): the 16 x 16 diagonal sub-block is factored by ONE wavefront
-//   in lock step (no barrier inside), the panel row is solved by forward substitution (thread = column, the
-//   16 x 16 factor broadcast from LDS), the trailing sub-matrix takes its rank-16 update on the MFMA tile.
-//   Inverse: the eight 16 x 16 diagonal sub-blocks are inverted by eight wavefronts in lock step, then
-//   [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1] is applied at block sizes 16, 32, 64 with both products on
-//   the MFMA tile; the intermediate A^-1 B is parked in the (unused) lower-left block.
+// One workgroup of 16 wavefronts; 128 x 129 doubles of LDS + the eight inverted 16 x 16 diagonal sub-blocks.
+// This kernel sits on the critical path of the blocked factorisation (one launch per 128 rows): its serial core
+// is the chain of 128 pivots (sqrt -> reciprocal -> rank-1 update -> next pivot).  Structure, per 16-column panel p:
+//   (1) the 16 x 16 diagonal sub-block is factored by ONE wavefront entirely in registers: lane c holds column c,
+//       pivots and multipliers travel through v_readlane (compile-time lanes) -- no LDS round trip, no fence;
+//   (2) the panel row is solved by forward substitution with the stored pivot reciprocals (thread = column, the
+//       factor broadcast from LDS) while a spare wavefront inverts the sub-block (rows in lanes) on the side;
+//   (3) the trailing sub-matrix takes its rank-16 update on the MFMA tile; the wavefront that owns the next
+//       diagonal tile goes straight on to factor it (step (1) of panel p + 1) while the others finish the update.
+// Two block-wide barriers per panel.  Inverse: [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1] at block sizes
+// 16, 32, 64 with both products on the MFMA tile; the intermediate A^-1 B is parked in the lower-left block.
 // The strict lower triangle of S is scratch throughout and masked on every read that means "U" or "U^-1".
+// (first version: sub-block steps through LDS in lock step, 3 barriers per panel, division per element: 88 us.)
 // ------------------------------------------------------------------------------------------------
 #define SR_PD_LD 129
 #define SR_PD_THREADS 1024
-#define SR_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#define SR_PD_XLD 17
+
+__device__ __forceinline__ double sr_readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// sd = sqrt(d), inv = 1 / sqrt(d) for a positive, normal d: v_rsq_f64 seed, one coupled Goldschmidt step
+// (g -> sqrt, h -> 1/(2 sqrt), both to ~2^-52) and one residual correction each.  The library sqrt() + 1.0 / x
+// pair costs ~32 dependent instructions (range scaling, v_div_scale / v_div_fmas / v_div_fixup); this chain is
+// 9, and it sits 128 times on the critical path of every diagonal block.  |sd^2 - d| <= 1 ulp(d), |inv sd - 1| <= 2^-52.
+__device__ __forceinline__ void sr_sqrt_rsqrt(double d, double& sd, double& inv) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double e = fma(-g, g, d);
+    g = fma(e, h, g);
+    const double r2 = fma(-h, g, 0.5);
+    h = fma(h, r2, h);
+    sd = g;
+    inv = h + h;
+}
+
+// upper Cholesky of the 16 x 16 sub-block at (j0, j0) of S by one wavefront, in registers.
+// invd[j0 + j] receives 1 / U[j][j]; *fail the 1-based index of the first non-positive pivot.
+__device__ __forceinline__ void sr_factor16(double* S, int j0, double* invd, int* fail, int lane) {
+    const int c = lane & 15;                       // lanes 16 .. 63 mirror lanes 0 .. 15 (same addresses: broadcast)
+    double a[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = S[(j0 + r) * SR_PD_LD + j0 + c];
+    double myinv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double d = sr_readlane_f64(a[j], j);       // pivot: wavefront-uniform
+        if (!(d > 0.0)) {                          // also catches NaN
+            if (lane == 0 && *fail == 0) *fail = j0 + j + 1;
+            d = 1.0;
+        }
+        double sd, inv;
+        sr_sqrt_rsqrt(d, sd, inv);
+        if (c == j) myinv = inv;
+        a[j] = (c == j) ? sd : a[j] * inv;         // row j of U (meaningful on lanes c >= j)
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) {
+            const double ujr = sr_readlane_f64(a[j], r);     // U[j][r]: wavefront-uniform
+            a[r] = fma(-ujr, a[j], a[r]);
+        }
+    }
+    if (lane < 16) {
+        invd[j0 + c] = myinv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (r <= c) S[(j0 + r) * SR_PD_LD + j0 + c] = a[r];
+    }
+}
+
+// X = U^-1 of the factored 16 x 16 sub-block at (j0, j0) by one wavefront: lane i holds row i of X,
+//   X[i][j] = -(sum_{k < j} X[i][k] U[k][j]) / U[j][j],  X[j][j] = 1 / U[j][j];   U broadcast from LDS.
+__device__ __forceinline__ void sr_invert16(const double* S, int j0, const double* invd, double* X, int lane) {
+    const int i = lane & 15;
+    double x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = fma(x[k], S[(j0 + k) * SR_PD_LD + j0 + j], s);
+        const double ij = invd[j0 + j];
+        x[j] = (i == j) ? ij : ((i < j) ? -s * ij : 0.0);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) X[i * SR_PD_XLD + j] = x[j];
+    }
+}
 
 __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
                                                                          double* wt_diag, double* w_diag,
-                                                                         long ldw, int kb, int* info) {
+                                                                         long ldw, int kb, int* info, int skip) {
+    // skip: ablation bits of sr_test_potrf_diag (0 in production): 1 pivots, 2 panel rows, 4 trailing update,
+    // 8 sub-block inverses, 16 inverse combination, 32 global loads / stores
     __shared__ double S[SR_NB * SR_PD_LD];
+    __shared__ double Xd[(SR_NB / 16) * 16 * SR_PD_XLD];
+    __shared__ double invd[SR_NB];
     __shared__ int fail;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, ln = lane & 15;
     const long k0 = (long)kb * SR_NB;
+    __builtin_amdgcn_s_setprio(3);
     if (tid == 0) fail = 0;
     for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
         const int r = idx >> 7, c = idx & 127;
-        S[r * SR_PD_LD + c] = (c >= r) ? A[(k0 + r) * lda + k0 + c] : 0.0;
+        S[r * SR_PD_LD + c] = (c >= r) ? ((skip & 32) ? (r == c ? 2.0 : 0.01) : A[(k0 + r) * lda + k0 + c]) : 0.0;
     }
+    if (tid < SR_NB) invd[tid] = 1.0;
     __syncthreads();
 
     // ---- blocked right-looking upper Cholesky ------------------------------------------------------
+    if (wave == 0 && !(skip & 1)) sr_factor16(S, 0, invd, &fail, lane);
+    __syncthreads();
     for (int p = 0; p < SR_NB / 16; ++p) {
         const int j0 = 16 * p;
-        if (wave == 0) {
-            // 16 x 16 diagonal sub-block, one wavefront in lock step: lane = (row r, 4 columns)
-            const int r = lane >> 2, cg = (lane & 3) * 4;
-            for (int j = 0; j < 16; ++j) {
-                double d = S[(j0 + j) * SR_PD_LD + j0 + j];
-                if (!(d > 0.0)) {                          // also catches NaN
-                    if (lane == 0 && fail == 0) fail = j0 + j + 1;
-                    d = 1.0;
-                }
-                const double sd = sqrt(d), inv = 1.0 / sd;
-                SR_WAVE_FENCE();
-                if (lane < 16 && lane >= j) {
-                    const double v = S[(j0 + j) * SR_PD_LD + j0 + lane];
-                    S[(j0 + j) * SR_PD_LD + j0 + lane] = (lane == j) ? sd : v * inv;
-                }
-                SR_WAVE_FENCE();
-                if (r > j) {
-                    const double ujr = S[(j0 + j) * SR_PD_LD + j0 + r];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = cg + q;
-                        if (c >= r)
-                            S[(j0 + r) * SR_PD_LD + j0 + c] =
-                                fma(-ujr, S[(j0 + j) * SR_PD_LD + j0 + c], S[(j0 + r) * SR_PD_LD + j0 + c]);
-                    }
-                }
-                SR_WAVE_FENCE();
-            }
-        }
-        __syncthreads();
         // panel row: U[j0 .. j0+15][c] = D^-T A[j0 .. j0+15][c] for the columns right of the panel
-        if (tid < SR_NB && tid >= j0 + 16) {
+        if (tid < SR_NB && tid >= j0 + 16 && !(skip & 2)) {
             double v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -206,15 +424,18 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
                     if (k < i) x = fma(-S[(j0 + k) * SR_PD_LD + j0 + i], v[k], x);
-                v[i] = x / S[(j0 + i) * SR_PD_LD + j0 + i];
+                v[i] = x * invd[j0 + i];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) S[(j0 + i) * SR_PD_LD + tid] = v[i];
         }
+        if (wave == SR_PD_THREADS / 64 - 1 && !(skip & 8)) sr_invert16(S, j0, invd, Xd + p * 16 * SR_PD_XLD, lane);
         __syncthreads();
-        // trailing rank-16 update on the MFMA tile: tiles (ti <= tj) of the blocks right of / below the panel
+        // trailing rank-16 update on the MFMA tile: tiles (ti <= tj) of the blocks right of / below the panel.
+        // Tile 0 is the next diagonal sub-block: its owner (wavefront 0) factors it right away.
         const int nbt = SR_NB / 16 - 1 - p;
-        for (int e = wave; e < nbt * (nbt + 1) / 2; e += SR_PD_THREADS / 64) {
+        const int ntile = (skip & 4) ? 0 : nbt * (nbt + 1) / 2;
+        for (int e = (wave == 0) ? 0 : wave; e < ntile; e += (wave == 0) ? ntile : SR_PD_THREADS / 64 - 1) {
             int ti = 0, rem = e;
             while (rem >= nbt - ti) { rem -= nbt - ti; ++ti; }
             const int r0 = 16 * (p + 1 + ti), c0 = 16 * (p + 1 + ti + rem);
@@ -227,6 +448,10 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) S[(r0 + lk + 4 * q) * SR_PD_LD + c0 + ln] -= acc[q];
+        }
+        if (wave == 0 && nbt > 0 && !(skip & 1)) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // the tile update above, then its reads below
+            sr_factor16(S, j0 + 16, invd, &fail, lane);
         }
         __syncthreads();
     }
@@ -242,32 +467,22 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
         }
         return;
     }
-    for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        A[(k0 + r) * lda + k0 + c] = (c >= r) ? S[r * SR_PD_LD + c] : 0.0;
-    }
+    if (!(skip & 32))
+        for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
+            const int r = idx >> 7, c = idx & 127;
+            A[(k0 + r) * lda + k0 + c] = (c >= r) ? S[r * SR_PD_LD + c] : 0.0;
+        }
     __syncthreads();                                     // S is overwritten from here on
 
     // ---- inverse of the upper-triangular block -----------------------------------------------------
-    // (a) the eight 16 x 16 diagonal sub-blocks, column by column, one wavefront each in lock step:
-    //     X[i][j] = -(sum_{k=i}^{j-1} X[i][k] U[k][j]) / U[j][j],  X[j][j] = 1 / U[j][j]
-    if (wave < SR_NB / 16) {
-        const int b0 = 16 * wave;
-        for (int j = 0; j < 16; ++j) {
-            const double invjj = 1.0 / S[(b0 + j) * SR_PD_LD + b0 + j];
-            double sum = 0.0;
-            if (lane < j)
-                for (int k = lane; k < j; ++k)
-                    sum = fma(S[(b0 + lane) * SR_PD_LD + b0 + k], S[(b0 + k) * SR_PD_LD + b0 + j], sum);
-            SR_WAVE_FENCE();
-            if (lane < j) S[(b0 + lane) * SR_PD_LD + b0 + j] = -sum * invjj;
-            else if (lane == j) S[(b0 + j) * SR_PD_LD + b0 + j] = invjj;
-            SR_WAVE_FENCE();
-        }
+    // (a) the eight inverted 16 x 16 diagonal sub-blocks (computed on the side above) take their places
+    for (int idx = tid; idx < (SR_NB / 16) * 256; idx += SR_PD_THREADS) {
+        const int b = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+        S[(16 * b + i) * SR_PD_LD + 16 * b + j] = Xd[(b * 16 + i) * SR_PD_XLD + j];
     }
     __syncthreads();
     // (b) combine at block sizes 16, 32, 64
-    for (int n = 16; n < SR_NB; n *= 2) {
+    for (int n = 16; n < ((skip & 16) ? 0 : SR_NB); n *= 2) {
         const int tpb = n / 16;                          // 16-tiles per block edge
         const int items = (SR_NB / (2 * n)) * tpb * tpb;
         // T^T = (A^-1 B)^T into the lower-left block
@@ -303,6 +518,10 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
         }
         __syncthreads();
     }
+    if (skip & 32) {
+        if (tid == 0) wt_diag[0] = S[5 * SR_PD_LD + 7];
+        return;
+    }
     for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
         const int r = idx >> 7, c = idx & 127;
         wt_diag[(long)r * ldw + c] = (c >= r) ? S[r * SR_PD_LD + c] : 0.0;    // U_kk^-1   (upper)
@@ -311,9 +530,9 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
 }
 
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw, int kb,
-                         int* info_dev, hipStream_t s) {
+                         int* info_dev, hipStream_t s, int skip) {
     hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
-                       kb, info_dev);
+                       kb, info_dev, skip);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

@@ -191,3 +191,93 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
 }
 
 }  // namespace srt
+
+// ------------------------------------------------------------------------------------------------
+// 64 x 64 workgroup tile, same contract (k-major operands): 4 wavefronts (2 x 2) of 32 x 32 = 2 x 2 MFMA tiles.
+// One fp64 MFMA occupies its SIMD for 64 cycles, so a 128 x 128 x 128 tile product is 14 us of one CU however
+// it is scheduled; products with FEW 128-tiles (the block row / look-ahead row of the Cholesky, the small and the
+// triangular levels of the inversion) are latency- and balance-bound, and a 4 x finer tile cuts both by 4.
+// LDS-DMA staging: one global_load_lds_dwordx4 moves 1 KiB = TWO 64-double tile rows (lanes 0-31: row r,
+// lanes 32-63: row r + 2); the pair is contiguous in LDS, pairs are 144 doubles apart.  With rows (r, r + 2) paired
+// the k-rows lk = 0, 1 of a 32-lane ds_read_b64 group sit in different pairs, i.e. on opposite bank halves
+// (pair stride 288 dwords == 32 mod 64): conflict-free fragment reads.  36 KiB of LDS: 4 workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+namespace srt64 {
+
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDP = 144;                     // doubles between row pairs
+constexpr int STAGE = (BK / 2) * LDP;        // doubles per operand per stage
+constexpr int SMEM_DOUBLES = 4 * STAGE;      // A, B x 2 stages (36,864 B)
+
+struct Acc {
+    d4_t v[2][2];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    }
+};
+// element (mi, ni, r): row = wm*32 + mi*16 + (lane>>4) + 4*r ,  col = wn*32 + ni*16 + (lane&15)
+__device__ __forceinline__ int acc_row(int wm, int mi, int lane, int r) { return wm * 32 + mi * 16 + (lane >> 4) + 4 * r; }
+__device__ __forceinline__ int acc_col(int wn, int ni, int lane) { return wn * 32 + ni * 16 + (lane & 15); }
+
+// LDS offset (doubles) of tile row r inside a stage: rows (r, r + 2) share a pair
+__device__ __forceinline__ int row_off(int r) { return (((r >> 2) << 1) + (r & 1)) * LDP + ((r >> 1) & 1) * 64; }
+
+__device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                            long ldb, int k_beg, int k_end, double* smem, Acc& acc) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    double* As = smem;
+    double* Bs = smem + 2 * STAGE;
+    if (k_beg >= k_end) return;
+    // wavefront w moves pairs w and w + 4 of each operand: pair q = rows (4 (q >> 1) + (q & 1), that + 2)
+    const int half = lane >> 5, l32 = lane & 31;
+    const int r0 = 4 * (wave >> 1) + (wave & 1) + 2 * half;            // row of pair `wave` this lane loads
+    const double* ga = A + (long)r0 * lda + 2 * l32;
+    const double* gb = B + (long)r0 * ldb + 2 * l32;
+    const int so = wave * LDP;                                          // pair `wave`; pair wave + 4 is 8 rows further
+#define SRT64_DMA(k0, buf)                                                                             \
+    do {                                                                                               \
+        const double* pa_ = ga + (long)(k0) * lda;                                                     \
+        const double* pb_ = gb + (long)(k0) * ldb;                                                     \
+        double* sa_ = As + (buf) * STAGE + so;                                                         \
+        double* sb_ = Bs + (buf) * STAGE + so;                                                         \
+        __builtin_amdgcn_global_load_lds(SRT_AS1(pa_), SRT_AS3(sa_), 16, 0, 0);                        \
+        __builtin_amdgcn_global_load_lds(SRT_AS1(pb_), SRT_AS3(sb_), 16, 0, 0);                        \
+        __builtin_amdgcn_global_load_lds(SRT_AS1(pa_ + 8 * lda), SRT_AS3(sa_ + 4 * LDP), 16, 0, 0);    \
+        __builtin_amdgcn_global_load_lds(SRT_AS1(pb_ + 8 * ldb), SRT_AS3(sb_ + 4 * LDP), 16, 0, 0);    \
+    } while (0)
+    SRT64_DMA(k_beg, 0);
+    const int lk = lane >> 4, ln = lane & 15;
+    int buf = 0;
+    for (int k0 = k_beg; k0 < k_end; k0 += BK) {
+        __syncthreads();                       // vmcnt(0) + s_barrier: tile k0 landed, the other stage is free
+        if (k0 + BK < k_end) SRT64_DMA(k0 + BK, buf ^ 1);
+        const double* as = As + buf * STAGE + wm * 32 + ln;
+        const double* bs = Bs + buf * STAGE + wn * 32 + ln;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int ro = row_off(4 * kk + lk);
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = as[ro + i * 16];
+                bf[i] = bs[ro + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    __syncthreads();                           // callers reuse smem after the main loop
+#undef SRT64_DMA
+}
+
+}  // namespace srt64

@@ -53,25 +53,31 @@ def model_spec(gp):
             "hyp": hyp, "noise_diag": float(gp._noise_diag if gp._noise_diag is not None else 1e-5)}
 
 
+def broadcast_model_state(gp, src=0, device=None):
+    """The communication half of ``replicate_model``: returns (spec, tensors) on every rank -- the model
+    description as a Python object and Z / targets / alpha / U^-1 as tensors on ``device``.  Only rank ``src``
+    reads ``gp``.  Backend-agnostic (RCCL on the GPUs, gloo in the CPU tests)."""
+    rank = dist.get_rank()
+    spec = [model_spec(gp) if rank == src else None]
+    dist.broadcast_object_list(spec, src=src)
+    payload = None
+    if rank == src:
+        alpha, wt = gp.export_state()
+        payload = {"Z": torch.from_numpy(np.ascontiguousarray(gp.z_fit)),
+                   "Y": torch.from_numpy(np.ascontiguousarray(gp.y_z)),
+                   "alpha": alpha, "wt": wt}
+    return spec[0], broadcast_tensors(payload, src=src, device=device)
+
+
 def replicate_model(gp, prob=None, src=0, device=None):
     """Rank `src` holds a trained HIP SimpleGPModel; every other rank receives the model description (object
     broadcast: dimensions, kernels, hyper-parameters, noise), then Z, the targets that belong to Z, alpha and
     U^-1 over RCCL, and adopts them without factorising (sr_gp_import).  ``prob`` is accepted for backward
     compatibility and ignored: the source model is the single source of truth.  Returns the rank-local model."""
     from .ssm_hip.gaussian_process import SimpleGPModel
-    rank = dist.get_rank()
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    spec = [model_spec(gp) if rank == src else None]
-    dist.broadcast_object_list(spec, src=src)
-    spec = spec[0]
-    payload = None
-    if rank == src:
-        alpha, wt = gp.export_state()
-        payload = {"Z": torch.from_numpy(np.ascontiguousarray(gp.z_fit)).to(dev),
-                   "Y": torch.from_numpy(np.ascontiguousarray(gp.y_z)).to(dev),
-                   "alpha": alpha, "wt": wt}
-    got = broadcast_tensors(payload, src=src, device=dev)
-    if rank == src:
+    spec, got = broadcast_model_state(gp, src=src, device=dev)
+    if dist.get_rank() == src:
         return gp
     local = SimpleGPModel(spec["n_s_out"], spec["n_s_in"], spec["n_u"], kern_types=spec["kern_types"],
                           hyp=spec["hyp"], device=dev)

@@ -443,6 +443,8 @@ class SimpleGPModel(StateSpaceModel):
         noise = self._noise + float(noise_diag) + GPY_JITTER
         s = B.stream_ptr(dev)
         self._set_data(handle, Z, Y, noise, dev, s)
+        if getattr(self, "_fact_panel", None) is not None:
+            check(lib.sr_gp_set_fact_panel(handle.h, self._fact_panel))
         info = (ctypes.c_int * self.n_s_out)()
         check(lib.sr_gp_factorize(handle.h, s, info))
         self._handle = handle
@@ -786,6 +788,12 @@ class SimpleGPModel(StateSpaceModel):
     def set_var_variant(self, variant):
         self._need_trained()
         check(lib.sr_gp_set_var_variant(self._handle.h, int(variant)))
+
+    def set_fact_panel(self, panel):
+        """blocks per Cholesky panel of the NEXT model update (0 = by size); works before training too"""
+        self._fact_panel = int(panel)
+        if self._handle is not None:
+            check(lib.sr_gp_set_fact_panel(self._handle.h, int(panel)))
 
     def set_small_path(self, on):
         self._need_trained()

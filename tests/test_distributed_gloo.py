@@ -56,6 +56,57 @@ def test_shard_broadcast_gather_world2():
         np.testing.assert_array_equal(full[:, 0], np.arange(T) * ret["scale"])
 
 
+def _model_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from safe_exploration_amd import SimpleGPModel
+        gp = None
+        if rank == 0:
+            # a model object as rank 0 would hold it after train(m=...): z_fit / y_z are the SELECTED rows, y_train
+            # the full data set; the device export is replaced by host tensors (no GPU in this test)
+            rng = np.random.default_rng(3)
+            hyp = [{"lengthscale": np.array([0.5, 1.0, 1.5]), "variance": 0.7, "noise_variance": 0.02},
+                   {"lengthscale": np.array([1.5, 1.0, 0.5]), "variance": 1.3, "noise_variance": 0.03}]
+            gp = SimpleGPModel(2, 2, 1, kern_types=["rbf", "mat52"], hyp=hyp)
+            gp.x_train, gp.y_train = rng.standard_normal((9, 3)), rng.standard_normal((9, 2))
+            gp._z_fit, gp._y_z = gp.x_train[[1, 4, 7, 8, 2]], gp.y_train[[1, 4, 7, 8, 2]]
+            gp.z, gp._noise_diag = gp._z_fit, 3e-5
+            gp.export_state = lambda: (torch.from_numpy(rng.standard_normal((2, 5))),
+                                       torch.from_numpy(rng.standard_normal((2, 128, 128))))
+            ret["z"], ret["y"] = gp._z_fit, gp._y_z
+        spec, got = parallel.broadcast_model_state(gp, src=0, device=torch.device("cpu"))
+        if rank == 1:
+            ret["spec"] = spec
+            ret["Z"], ret["Y"] = got["Z"].numpy(), got["Y"].numpy()
+            ret["shapes"] = (tuple(got["alpha"].shape), tuple(got["wt"].shape))
+            # the receiver can rebuild an identical (untrained) model description from the spec alone
+            local = SimpleGPModel(spec["n_s_out"], spec["n_s_in"], spec["n_u"], kern_types=spec["kern_types"],
+                                  hyp=spec["hyp"])
+            ret["noise"] = local._noise.copy()
+            ret["ls1"] = local.hyp[1]["lengthscale"]
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_state_broadcast_world2():
+    """what replicate_model sends: the rows the model is conditioned on (not the full data set), their targets,
+    kernel identifiers, hyper-parameters with the Gaussian noise, and the source's noise_diag."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_model_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        np.testing.assert_array_equal(ret["Z"], ret["z"])
+        np.testing.assert_array_equal(ret["Y"], ret["y"])
+        assert ret["Z"].shape == (5, 3) and ret["shapes"] == ((2, 5), (2, 128, 128))
+        spec = ret["spec"]
+        assert spec["kern_types"] == ["rbf", "mat52"] and spec["noise_diag"] == 3e-5
+        assert (spec["n_s_out"], spec["n_s_in"], spec["n_u"]) == (2, 2, 1)
+        np.testing.assert_array_equal(ret["noise"], [0.02, 0.03])
+        np.testing.assert_array_equal(ret["ls1"], [1.5, 1.0, 0.5])
+
+
 def test_shard_bounds_partition():
     for T in (0, 1, 7, 64, 65536, 8388608 + 3):
         for world in (1, 2, 3, 8):

@@ -101,6 +101,31 @@ def test_predict_ragged_sizes(N, n_s, n_u, T):
     np.testing.assert_allclose(var, cvar, rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("n_out,N", [(9, 150), (11, 300), (17, 140)])
+def test_more_outputs_than_factorisation_slots(n_out, N):
+    """n_out > 8: the outputs share the 8 factorisation slots (streams + scratch) round-robin; every output's
+    posterior still equals the oracle's."""
+    rng = np.random.default_rng(n_out)
+    D, T = 3, 40
+    Z = rng.uniform(-1, 1, (N, D))
+    Y = rng.standard_normal((N, n_out))
+    ls = rng.uniform(0.5, 1.5, (n_out, D))
+    sf2 = rng.uniform(0.5, 1.5, n_out)
+    noise = np.full(n_out, 1e-2 + 1e-5)
+    from safe_exploration_amd import SimpleGPModel
+    gp = SimpleGPModel(n_out, 2, 1, kern_types=["rbf"] * n_out, hyp=hyp_from(ls, sf2, noise))
+    gp.train(Z, Y, opt_hyp=False)
+    om = oracle_model(Z, Y, ls, sf2, noise)
+    x = rng.uniform(-0.8, 0.8, (T, D))
+    mu, var, jac = gp.predict(x, None, True)
+    rmu, rvar, rjac = orc.gp_predict(x, Z, om["beta"], om["inv_K"], ls, sf2)
+    at = max(mu_atol(om), 1e-12)
+    np.testing.assert_allclose(gp.beta, om["beta"], rtol=1e-7, atol=1e-9 * np.abs(om["beta"]).max())
+    np.testing.assert_allclose(mu, rmu, rtol=1e-10, atol=at)
+    np.testing.assert_allclose(jac, rjac, rtol=1e-10, atol=10 * at)
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-9 * sf2.max())
+
+
 def test_predict_empty_batch():
     syn = orc.make_synthetic(5, 40, 2, 1, 4)
     gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
