@@ -224,6 +224,11 @@ int sr_gp_set_small_path(sr_gp_t h, int on);
  * Exposed so the fp64-MFMA tile can be tested in isolation. */
 int sr_test_gemm_tn(int device, const double* A, long lda, const double* B, long ldb, double* C,
                     long ldc, int M, int N, int K, double alpha, double beta, int mode, void* stream);
+/* diagnostic: the trailing-update product of the factorisation alone: C (M x N, only the 128-tiles n0 >= m0) =
+ * alpha A^T B + beta C, A (K x M), B (K x N) k-major, M <= N multiples of 128; order 0 row-major tiles, 1 XCD-aware
+ * super-tiles, -1 chosen by size. */
+int sr_test_gemm_tn_upper(int device, const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                          int M, int N, int K, double alpha, double beta, int order, void* stream);
 /* diagnostic: the diagonal-block kernel of the factorisation alone: A (128 x 128 SPD, upper triangle read, leading
  * dimension lda) -> upper Cholesky factor in place, wt = its inverse, w = the inverse transposed (leading dimension
  * ldw); info: device int, 0 or the 1-based first non-positive pivot.  skip != 0 leaves phases out (timing ablation). */

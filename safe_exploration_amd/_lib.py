@@ -70,6 +70,7 @@ SIGNATURES = {
     "sr_gp_set_small_path": (_I, [_H, _I]),
     "sr_gp_set_fact_panel": (_I, [_H, _I]),
     "sr_test_gemm_tn": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
+    "sr_test_gemm_tn_upper": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_potrf_diag": (_I, [_I, _P, _L, _P, _P, _L, _P, _I, _P]),
     "sr_prof_enable": (_I, [_H, _I]),
     "sr_prof_reset": (_I, [_H]),

@@ -50,7 +50,9 @@ struct sr_gp {
     hipEvent_t fact_fork = nullptr, fact_join[SR_FACT_SLOTS] = {nullptr};
     hipEvent_t ev_panel[SR_FACT_SLOTS][2] = {{nullptr}}, ev_bulk[SR_FACT_SLOTS][2] = {{nullptr}};
     int fact_panel = 0;                                  // blocks per Cholesky panel; 0 = by size
-    int bulk_masked = 0;                                 // the bulk streams carry the CU mask
+    int fact_regime = 0;                                 // how the streams below were made: 0 none, 1 chain-bound, 2 GEMM-bound
+    hipStream_t diag_stream[SR_FACT_SLOTS] = {nullptr};   // regime 2: diagonal blocks on their own (reserved) CUs
+    hipEvent_t ev_diag[SR_FACT_SLOTS][2] = {{nullptr}};   // critical -> diag, diag -> critical
     // job lists of the level-batched triangular inversion (depend on Np only)
     sr_gemm_job* inv_jobs = nullptr; int inv_jobs_np = 0;
     struct inv_level { int off1, off2, count, maxM, maxN; long tiles; };
@@ -135,10 +137,12 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     for (int d = 0; d < SR_FACT_SLOTS; ++d) {
         if (h->fact_stream[d]) (void)hipStreamDestroy(h->fact_stream[d]);
         if (h->bulk_stream[d]) (void)hipStreamDestroy(h->bulk_stream[d]);
+        if (h->diag_stream[d]) (void)hipStreamDestroy(h->diag_stream[d]);
         if (h->fact_join[d]) (void)hipEventDestroy(h->fact_join[d]);
         for (int e = 0; e < 2; ++e) {
             if (h->ev_panel[d][e]) (void)hipEventDestroy(h->ev_panel[d][e]);
             if (h->ev_bulk[d][e]) (void)hipEventDestroy(h->ev_bulk[d][e]);
+            if (h->ev_diag[d][e]) (void)hipEventDestroy(h->ev_diag[d][e]);
         }
     }
     if (h->fact_fork) (void)hipEventDestroy(h->fact_fork);
@@ -281,6 +285,63 @@ static int pick_fact_panel(const sr_gp* h) {
     return nb <= 160 ? 4 : 8;
 }
 
+// Streams of the factorisation.  The chain of diagonal blocks is latency-bound and must never queue behind the
+// (throughput-bound) bulk update; the diagonal-block kernel moreover needs a CU to itself (150 KB of LDS), and a
+// workgroup is bound to a shader engine before it waits for a CU.  CU masks are dealt by the driver round-robin over
+// the 8 XCDs and, inside an XCD, over its 4 shader engines (scripts/cumask_probe.hip).
+//   regime 1 (chain-bound sizes, nb <= 128): critical stream = highest priority, every CU; bulk stream = CU mask
+//     without the first 32 bits: one CU per shader engine stays free, wherever the diagonal block lands
+//     (measured at N = 5000: 61 us alone, 140-210 us beside an unmasked bulk update, 75 us with the reserve);
+//   regime 2 (GEMM-bound sizes): the bulk stream leaves only the first 8 bits out (one CU per XCD, 3 % of the
+//     chip), and the diagonal blocks run on a third stream that owns exactly those 8 CUs -- the bulk tiles last
+//     200 us there and would otherwise keep a diagonal block waiting for ~1.4 ms (N = 50000: the chain of 391 blocks
+//     then IS the critical path of the whole Cholesky).  The critical stream keeps every CU and its priority (a
+//     CU-masked stream cannot have one: with all three streams masked the look-ahead rows queued 1:1 with the bulk
+//     tiles and the update got 7 % slower); it is idle while a diagonal block runs, so the reserve is free then.
+// Few streams on purpose: streams of one priority share a small pool of hardware queues, and two chains on one
+// queue serialise (a third high-priority stream per output cost 45 % at N = 5000).
+static int make_masked_stream(hipStream_t* st, int ncu, int first_bit, int last_bit) {
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int c = first_bit; c < last_bit; ++c) mask[c / 32] |= 1u << (c % 32);
+    SR_HIP(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+    return SR_OK;
+}
+
+static void drop_fact_streams(sr_gp* h) {
+    for (int sl = 0; sl < SR_FACT_SLOTS; ++sl) {
+        hipStream_t* all[3] = {&h->fact_stream[sl], &h->bulk_stream[sl], &h->diag_stream[sl]};
+        for (hipStream_t* st : all)
+            if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
+    }
+    h->fact_regime = 0;
+}
+
+static int ensure_fact_streams(sr_gp* h, int n_par, int regime) {
+    if (h->fact_regime != regime) drop_fact_streams(h);
+    int prio_lo = 0, prio_hi = 0;
+    SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    hipDeviceProp_t prop;
+    SR_HIP(hipGetDeviceProperties(&prop, h->device));
+    const int ncu = prop.multiProcessorCount;
+    const bool can_mask = ncu >= 64;
+    for (int sl = 0; sl < n_par; ++sl) {
+        if (!h->fact_stream[sl]) SR_HIP(hipStreamCreateWithPriority(&h->fact_stream[sl], hipStreamNonBlocking, prio_hi));
+        if (!h->bulk_stream[sl]) {
+            if (can_mask) SR_TRY(make_masked_stream(&h->bulk_stream[sl], ncu, regime == 2 ? 8 : SR_FACT_RESERVED_CUS, ncu));
+            else SR_HIP(hipStreamCreateWithPriority(&h->bulk_stream[sl], hipStreamNonBlocking, prio_lo));
+        }
+        if (regime == 2 && can_mask && !h->diag_stream[sl]) SR_TRY(make_masked_stream(&h->diag_stream[sl], ncu, 0, 8));
+        if (!h->fact_join[sl]) SR_HIP(hipEventCreateWithFlags(&h->fact_join[sl], hipEventDisableTiming));
+        for (int e = 0; e < 2; ++e) {
+            if (!h->ev_panel[sl][e]) SR_HIP(hipEventCreateWithFlags(&h->ev_panel[sl][e], hipEventDisableTiming));
+            if (!h->ev_bulk[sl][e]) SR_HIP(hipEventCreateWithFlags(&h->ev_bulk[sl][e], hipEventDisableTiming));
+            if (!h->ev_diag[sl][e]) SR_HIP(hipEventCreateWithFlags(&h->ev_diag[sl][e], hipEventDisableTiming));
+        }
+    }
+    h->fact_regime = regime;
+    return SR_OK;
+}
+
 extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_factorize: NULL handle");
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
@@ -305,6 +366,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         for (int sl = 0; sl < SR_FACT_SLOTS; ++sl) {
             if (h->fact_stream[sl]) (void)hipStreamSynchronize(h->fact_stream[sl]);
             if (h->bulk_stream[sl]) (void)hipStreamSynchronize(h->bulk_stream[sl]);
+            if (h->diag_stream[sl]) (void)hipStreamSynchronize(h->diag_stream[sl]);
         }
         dev_free(scratch); dev_free(info_dev);
     };
@@ -332,57 +394,9 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_FH(hipStreamSynchronize(s0));
     if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
     SR_FH(hipEventRecord(h->fact_fork, s0));
-    {
-        // the chain of diagonal blocks is latency-bound and must never queue behind the (throughput-bound) bulk
-        // update: critical streams get the highest priority, bulk streams the lowest
-        int prio_lo = 0, prio_hi = 0;
-        SR_FH(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        const int want_mask = nb <= 128 ? 1 : 0;          // beyond that the update is GEMM-bound: all CUs to the bulk
-        for (int sl = 0; sl < n_par; ++sl) {
-            if (!h->fact_stream[sl]) SR_FH(hipStreamCreateWithPriority(&h->fact_stream[sl], hipStreamNonBlocking, prio_hi));
-            if (h->bulk_stream[sl] && h->bulk_masked != want_mask) {
-                (void)hipStreamSynchronize(h->bulk_stream[sl]);
-                (void)hipStreamDestroy(h->bulk_stream[sl]);
-                h->bulk_stream[sl] = nullptr;
-            }
-            if (!h->bulk_stream[sl]) {
-                // The bulk update fills every CU it may use, and the diagonal-block kernel needs a CU to itself
-                // (150 KB of LDS): without a reserve it only starts when the bulk grid drains (measured: 61 us alone,
-                // 140-210 us beside the bulk update).  A workgroup is bound to a shader engine before it waits for a
-                // CU, so the reserve has to exist in EVERY shader engine: the driver deals the CU-mask bits
-                // round-robin over the 8 XCDs and, inside an XCD, over its 4 shader engines (scripts/cumask_probe.hip),
-                // so leaving the first 32 bits out of the bulk streams' mask keeps one CU per shader engine free.
-                // Only for models whose update is bound by that chain (want_mask); the critical kernels run anywhere.
-                hipError_t e = hipErrorNotSupported;
-                if (want_mask) {
-                    hipDeviceProp_t prop;
-                    SR_FH(hipGetDeviceProperties(&prop, h->device));
-                    const int ncu = prop.multiProcessorCount;
-                    if (ncu > 2 * SR_FACT_RESERVED_CUS) {
-                        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-                        for (int c = SR_FACT_RESERVED_CUS; c < ncu; ++c) mask[c / 32] |= 1u << (c % 32);
-                        e = hipExtStreamCreateWithCUMask(&h->bulk_stream[sl], (uint32_t)mask.size(), mask.data());
-                    }
-                }
-                if (e != hipSuccess) {
-                    (void)hipGetLastError();
-                    SR_FH(hipStreamCreateWithPriority(&h->bulk_stream[sl], hipStreamNonBlocking, prio_lo));
-                }
-            }
-            if (!h->fact_join[sl]) SR_FH(hipEventCreateWithFlags(&h->fact_join[sl], hipEventDisableTiming));
-            for (int e = 0; e < 2; ++e) {
-                if (!h->ev_panel[sl][e]) SR_FH(hipEventCreateWithFlags(&h->ev_panel[sl][e], hipEventDisableTiming));
-                if (!h->ev_bulk[sl][e]) SR_FH(hipEventCreateWithFlags(&h->ev_bulk[sl][e], hipEventDisableTiming));
-            }
-            SR_FH(hipStreamWaitEvent(h->fact_stream[sl], h->fact_fork, 0));
-        }
-        for (int sl = n_par; sl < SR_FACT_SLOTS; ++sl)    // slots of an earlier, wider call: same kind or gone
-            if (h->bulk_stream[sl] && h->bulk_masked != want_mask) {
-                (void)hipStreamDestroy(h->bulk_stream[sl]);
-                h->bulk_stream[sl] = nullptr;
-            }
-        h->bulk_masked = want_mask;
-    }
+    const int regime = nb <= 128 ? 1 : 2;
+    SR_F(ensure_fact_streams(h, n_par, regime));
+    for (int sl = 0; sl < n_par; ++sl) SR_FH(hipStreamWaitEvent(h->fact_stream[sl], h->fact_fork, 0));
 
     // Outputs are processed in rounds of n_par; inside a round the host walks the panels in the OUTER loop and the
     // outputs in the inner one, so that all chains advance together (enqueueing one output's 200 launches before
@@ -410,8 +424,8 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                 SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, sc));
         }
         // --- Cholesky K = U^T U, right-looking in panels of P blocks with look-ahead: after a panel is factored
-        // (critical stream: diagonal block, block row, the panel's own remaining rows), the trailing update is
-        // split -- the rows of the NEXT panel on the critical stream, so that its factorisation can start at
+        // (critical stream, per block: update of its row by the panel's rows above, diagonal block, block row solve),
+        // the trailing update is split -- the rows of the NEXT panel on the critical stream, so that its factorisation can start at
         // once, everything behind them on the bulk stream, which may lag one panel behind.
         int pi = 0;
         for (int p0 = 0; p0 < nb; p0 += P, ++pi) {
@@ -424,7 +438,27 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                     double* W = U + NN;
                     double* Wt = h->Wt + (size_t)d * NN;
                     const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
-                    {
+                    if (kb > p0) {
+                        // left-looking INSIDE the panel: block row kb takes the updates of the panel's rows above it in
+                        // one product with K = (kb - p0) * 128, right before it is needed -- each row block of the
+                        // panel is read-modify-written once (eager rank-128 updates of all remaining panel rows
+                        // touched it up to P - 1 times with K = 128, where prologue and epilogue dominate a tile)
+                        const double* Upr = W + (size_t)p0 * SR_NB * Np + (size_t)kb * SR_NB;   // rows p0..kb-1, cols >= kb
+                        sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                        SR_F(sr_launch_gemm_tn_upper(Upr, Np, Upr, Np, U + dg, Np, SR_NB, Np - kb * SR_NB, (kb - p0) * SR_NB,
+                                                     -1.0, 1.0, sc, 1));
+                    }
+                    if (hipStream_t sd = h->diag_stream[sl]) {
+                        // the block lives on the reserved CUs: hand over, factor, hand back
+                        SR_FH(hipEventRecord(h->ev_diag[sl][0], sc));
+                        SR_FH(hipStreamWaitEvent(sd, h->ev_diag[sl][0], 0));
+                        {
+                            sr_prof_scope ps(&h->prof, SR_K_POTRF, sd);
+                            SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, sd));
+                        }
+                        SR_FH(hipEventRecord(h->ev_diag[sl][1], sd));
+                        SR_FH(hipStreamWaitEvent(sc, h->ev_diag[sl][1], 0));
+                    } else {
                         sr_prof_scope ps(&h->prof, SR_K_POTRF, sc);
                         SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, sc));
                     }
@@ -435,10 +469,6 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                         sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
                         // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major)
                         SR_F(sr_launch_gemm_tn(Wt + dg, Np, Arow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, sc, 1));
-                        const int mrows = (p1 - kb - 1) * SR_NB;      // remaining rows of this panel
-                        if (mrows > 0)
-                            SR_F(sr_launch_gemm_tn_upper(Urow, Np, Urow, Np, U + dg + (size_t)SR_NB * Np + SR_NB, Np,
-                                                         mrows, ncols, SR_NB, -1.0, 1.0, sc, 1));
                     }
                 }
             }
@@ -1099,6 +1129,13 @@ extern "C" int sr_test_gemm_tn(int device, const double* A, long lda, const doub
     SR_CHECK(A && B && C, SR_EINVAL, "sr_test_gemm_tn: NULL argument");
     SR_DEVICE(device);
     return sr_launch_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, mode, (hipStream_t)stream);
+}
+
+extern "C" int sr_test_gemm_tn_upper(int device, const double* A, long lda, const double* B, long ldb, double* C,
+                                     long ldc, int M, int N, int K, double alpha, double beta, int order, void* stream) {
+    SR_CHECK(A && B && C, SR_EINVAL, "sr_test_gemm_tn_upper: NULL argument");
+    SR_DEVICE(device);
+    return sr_launch_gemm_tn_upper(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, (hipStream_t)stream, 0, order);
 }
 
 extern "C" int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, long ldw, int* info,

@@ -105,7 +105,8 @@ int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, doub
 
 // upper block triangle only (tiles n0 >= m0; M <= N) on a linear grid -- the trailing updates of the Cholesky
 int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio = 0);
+                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio = 0,
+                            int order = -1);   // order: 0 row-major tiles, 1 XCD-aware super-tiles, -1 by size
 // a list of independent TN products in one launch (one level of the recursive triangular inversion):
 // C_j = alpha A_j^T B_j, optionally also CT_j = C_j^T; operands at offsets (doubles) of common base pointers,
 // common leading dimension.  mode 2 / 3 as above.

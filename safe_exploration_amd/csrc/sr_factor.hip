@@ -93,19 +93,46 @@ int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, doub
 // The rectangular grid of the trailing update starts (and retires) tm*tn/2 empty workgroups; at N = 50000
 // that is 47 000 of them per panel.  C (op)= alpha A^T B + beta C on the tiles n0 >= m0.
 // ------------------------------------------------------------------------------------------------
+// tile (m, n) of linear index b in the row-major enumeration of the upper triangle: row m holds tiles
+// [c(m), c(m+1)), c(m) = m tn - m (m - 1) / 2, columns n = m .. tn - 1
+__device__ __forceinline__ void sr_upper_index(long b, int tn, int& m, int& n) {
+    m = (int)((2.0 * tn + 1.0 - sqrt((2.0 * tn + 1.0) * (2.0 * tn + 1.0) - 8.0 * (double)b)) * 0.5);
+    if (m < 0) m = 0;
+    if (m > tn) m = tn;
+    while (m < tn && (long)(m + 1) * tn - (long)(m + 1) * m / 2 <= b) ++m;      // b past the end: m = tn
+    while (m > 0 && (long)m * tn - (long)m * (m - 1) / 2 > b) --m;
+    n = m + (int)(b - ((long)m * tn - (long)m * (m - 1) / 2));
+}
+
+// order 0: tiles in row-major order of the upper triangle (small grids).
+// order 1: XCD-aware super-tiles.  Workgroup b runs on XCD b % 8 (dispatch is round-robin over the XCDs), each XCD has
+//   its own 4 MiB L2.  XCD x therefore takes the super-tiles s = x, x + 8, ... of 8 x 8 tiles, 64 consecutive
+//   workgroups of ITS sequence b / 8 per super-tile -- just the 64 workgroups its 32 CUs hold at a time: they walk k
+//   together, every A tile row is shared by 8 of them and every B tile row by 8.  Without it a K = 1024 update
+//   streams 2 MB of operands per 33.5 MFlop tile (16 flop/B: 3.3 TB/s at the measured 55 TF, i.e. bound by the
+//   fabric, not by the matrix cores).
 template <class TL>
 __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_upper_kernel(
     const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* C, long ldc,
-    int K, int tn, double alpha, double beta, int prio) {
+    int K, int tm, int tn, double alpha, double beta, int prio, int order) {
     __shared__ double smem[TL::SMEM];
     if (prio) __builtin_amdgcn_s_setprio(3);
-    // row m holds tiles [c(m), c(m+1)), c(m) = m tn - m (m - 1) / 2
-    const long b = blockIdx.x;
-    int m = (int)((2.0 * tn + 1.0 - sqrt((2.0 * tn + 1.0) * (2.0 * tn + 1.0) - 8.0 * (double)b)) * 0.5);
-    if (m < 0) m = 0;
-    while ((long)(m + 1) * tn - (long)(m + 1) * m / 2 <= b) ++m;
-    while ((long)m * tn - (long)m * (m - 1) / 2 > b) --m;
-    const int n = m + (int)(b - ((long)m * tn - (long)m * (m - 1) / 2));
+    int m, n;
+    if (order == 0) {
+        sr_upper_index(blockIdx.x, tn, m, n);
+    } else {
+        const long b = blockIdx.x;
+        const int xcd = (int)(b & 7);
+        const long l = b >> 3;
+        const long st = (l >> 6) * 8 + xcd;              // super-tile of this workgroup
+        const int stn = (tn + 7) >> 3;
+        int sm, sn;
+        sr_upper_index(st, stn, sm, sn);
+        const int w = (int)(l & 63);
+        m = sm * 8 + (w >> 3);
+        n = sn * 8 + (w & 7);
+        if (sm >= ((tm + 7) >> 3) || m >= tm || n >= tn || n < m) return;
+    }
     sr_gemm_tile<TL>(A, lda, B, ldb, C, ldc, m * TL::T, n * TL::T, 0, K, alpha, beta, smem);
 }
 
@@ -113,20 +140,29 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_upper_kernel(
 // lower-left quarter of every diagonal 128-block stays untouched as well: nothing reads it (the diagonal-block
 // kernel loads the upper triangle only).
 int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio) {
+                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio, int order) {
     SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && M > 0 && N >= M, SR_EINVAL,
              "gemm_tn_upper: M=%d N=%d K=%d", M, N, K);
     const long tm128 = M / 128, tn128 = N / 128;
-    const bool t64 = sr_use_tile64(tm128 * tn128 - tm128 * (tm128 - 1) / 2);
+    const long tiles128 = tm128 * tn128 - tm128 * (tm128 - 1) / 2;
+    const bool t64 = sr_use_tile64(tiles128);
     const long tm = t64 ? M / 64 : tm128, tn = t64 ? N / 64 : tn128;
-    const long tiles = tm * tn - tm * (tm - 1) / 2;
-    SR_CHECK(tiles < 2147483647L, SR_EINVAL, "gemm_tn_upper: grid too large");
+    if (order < 0) order = tiles128 >= 4096 ? 1 : 0;     // super-tiles pay once the grid is many times the chip
+    long blocks;
+    if (order == 0) {
+        blocks = tm * tn - tm * (tm - 1) / 2;
+    } else {
+        const long stm = (tm + 7) / 8, stn = (tn + 7) / 8;
+        const long nst = stm * stn - stm * (stm - 1) / 2;      // super-tiles (sm, sn >= sm)
+        blocks = ((nst + 7) / 8) * 8 * 64;
+    }
+    SR_CHECK(blocks < 2147483647L, SR_EINVAL, "gemm_tn_upper: grid too large");
     if (t64)
-        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile64>, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, B, ldb,
-                           C, ldc, K, (int)tn, alpha, beta, prio);
+        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile64>, dim3((unsigned)blocks), dim3(256), 0, s, A, lda, B, ldb,
+                           C, ldc, K, (int)tm, (int)tn, alpha, beta, prio, order);
     else
-        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile128>, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, B, ldb,
-                           C, ldc, K, (int)tn, alpha, beta, prio);
+        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile128>, dim3((unsigned)blocks), dim3(256), 0, s, A, lda, B, ldb,
+                           C, ldc, K, (int)tm, (int)tn, alpha, beta, prio, order);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -147,10 +183,13 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_jobs_kernel(
     __shared__ double smem[TL::SMEM];
     const sr_gemm_job jb = jobs[blockIdx.z];
     const int tm = jb.M / TL::T;
-    if ((int)blockIdx.x * TL::T >= jb.N || (int)blockIdx.y >= tm) return;
-    // heavy tiles first: mode 2 is heaviest at small n0 (natural order), mode 3 at large m0 (reversed)
-    const int m0 = ((mode == 3) ? (tm - 1 - (int)blockIdx.y) : (int)blockIdx.y) * TL::T;
-    const int n0 = blockIdx.x * TL::T;
+    // heavy tiles first, so that the tail of the grid consists of the SHORT k ranges: the slow grid index (y) walks
+    // the dimension that sets the k range -- mode 2: n ascending (k starts at n0), mode 3: m descending (k ends at m0 + T)
+    const int mt = (mode == 2) ? (int)blockIdx.x : tm - 1 - (int)blockIdx.y;
+    const int nt = (mode == 2) ? (int)blockIdx.y : (int)blockIdx.x;
+    if (nt * TL::T >= jb.N || mt >= tm || mt < 0) return;
+    const int m0 = mt * TL::T;
+    const int n0 = nt * TL::T;
     const int k_beg = (mode == 2) ? n0 : 0;
     const int k_end = (mode == 3) ? min(jb.K, m0 + TL::T) : jb.K;
 
@@ -199,12 +238,14 @@ int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, doubl
                            int mode, hipStream_t s) {
     SR_CHECK(njobs > 0 && njobs <= 65535 && maxM % srt::BM == 0 && maxN % srt::BN == 0 && (mode == 2 || mode == 3),
              SR_EINVAL, "gemm_tn_jobs: njobs=%d maxM=%d maxN=%d mode=%d", njobs, maxM, maxN, mode);
-    if (sr_use_tile64(tiles128))
-        hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile64>, dim3(maxN / 64, maxM / 64, njobs), dim3(256), 0, s, Ab,
-                           Bb, Cb, CTb, ld, jobs_dev, alpha, mode);
+    const int T = sr_use_tile64(tiles128) ? 64 : 128;
+    const dim3 grid = (mode == 2) ? dim3(maxM / T, maxN / T, njobs) : dim3(maxN / T, maxM / T, njobs);
+    if (T == 64)
+        hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile64>, grid, dim3(256), 0, s, Ab, Bb, Cb, CTb, ld, jobs_dev, alpha,
+                           mode);
     else
-        hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile128>, dim3(maxN / 128, maxM / 128, njobs), dim3(256), 0, s,
-                           Ab, Bb, Cb, CTb, ld, jobs_dev, alpha, mode);
+        hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile128>, grid, dim3(256), 0, s, Ab, Bb, Cb, CTb, ld, jobs_dev,
+                           alpha, mode);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
