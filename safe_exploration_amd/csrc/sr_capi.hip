@@ -29,6 +29,8 @@ struct sr_gp {
            *mu = nullptr, *var = nullptr, *jac = nullptr, *kxx = nullptr;
     double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch
     size_t lin_cap = 0;                                                 // doubles behind lin_v
+    double* stream_vp = nullptr; long stream_vp_cap = 0;   // fused small-batch path: partial sums (grow-only)
+    unsigned* stream_tickets = nullptr;
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 32;
@@ -132,6 +134,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     (void)hipDeviceSynchronize();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
+    dev_free(h->stream_vp); dev_free(h->stream_tickets);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (int d = 0; d < SR_FACT_SLOTS; ++d) {
@@ -699,6 +702,103 @@ static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
     return SR_OK;
 }
 
+// ---- fused small-batch route (sr_stream.hip) ----------------------------------------------------------------
+// Models beyond the one-launch sizes, up to 128 columns (queries, or [k*, dk*/dx] of one query): U^-1 is streamed
+// once, reduction and final stage hang behind tickets.  ARD-RBF with D <= 5 and <= 4 columns: ONE launch (the
+// workgroups evaluate their chunk of the columns themselves); otherwise the column pass (K1 / sr_lin_columns) first.
+static int stream_buffers(sr_gp* h, int ncols, hipStream_t s) {
+    const long need = sr_stream_vp_doubles(h->Np, h->n_out, sr_stream_width(ncols));
+    if (need > h->stream_vp_cap) {
+        (void)hipStreamSynchronize(s);
+        dev_free(h->stream_vp);
+        h->stream_vp = nullptr; h->stream_vp_cap = 0;
+        SR_TRY(dev_alloc(&h->stream_vp, (size_t)need));
+        h->stream_vp_cap = need;
+    }
+    if (!h->stream_tickets) {
+        const int n = sr_stream_tickets(h->Np, h->n_out);
+        SR_TRY(dev_alloc(&h->stream_tickets, (size_t)n));
+        SR_HIP(hipMemset(h->stream_tickets, 0, sizeof(unsigned) * n));
+    }
+    return SR_OK;
+}
+
+static void stream_common(const sr_gp* h, sr_stream_args& a, int ncols, long Tp) {
+    a.Wt = h->Wt; a.Ks = h->Ks; a.Vp = h->stream_vp; a.part = h->var_part; a.tickets = h->stream_tickets;
+    a.N = h->N; a.Np = h->Np; a.D = h->D; a.n_out = h->n_out; a.k_lo = h->Np - h->N; a.ncols = ncols; a.ncols_pad = ncols;
+    a.Tp = Tp;
+    a.Z = h->Z; a.alpha = h->alpha; a.ls = h->ls; a.sf2 = h->sf2;
+    a.mu_part_w = h->mu_part; a.jac_part_w = h->jac_part;
+}
+
+static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb, int nb,
+                          double* mu, double* var, double* jac, hipStream_t s) {
+    const long Tp = srt::BN;
+    const int ncb = (h->Np + 255) / 256;
+    const bool fused = !h->general && h->D <= 5 && Tc <= 4;
+    const int nsplit = fused ? 2 * ncb : pick_nsplit(h, Tp);
+    SR_TRY(ensure_ws(h, Tp, std::max(nsplit, 2 * ncb)));
+    SR_TRY(stream_buffers(h, (int)Tc, s));
+    if (!fused) {
+        sr_kstar_args ka;
+        ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+        ka.kp = h->general ? h->kp : nullptr; ka.kxx = h->kxx;
+        ka.xa = xa; ka.lda = lda; ka.na = na; ka.xb = xb; ka.ldb = ldb; ka.nb = nb;
+        ka.Ks = h->Ks; ka.mu_part = h->mu_part; ka.jac_part = h->jac_part;
+        ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = nsplit; ka.T = Tc; ka.Tp = Tp;
+        sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
+        SR_TRY(sr_launch_kstar(ka, s));
+    }
+    sr_stream_args a{};
+    stream_common(h, a, (int)Tc, Tp);
+    a.mode = 0; a.dot0 = 0;
+    a.xa = xa; a.lda = lda; a.na = na; a.xb = xb; a.ldb = ldb;
+    a.fa.mu_part = h->mu_part; a.fa.jac_part = h->jac_part; a.fa.var_part = h->var_part; a.fa.sf2 = h->sf2;
+    a.fa.ls = h->ls; a.fa.kxx = h->general ? h->kxx : nullptr; a.fa.mu = mu; a.fa.var = var; a.fa.jac = jac;
+    a.fa.n_out = h->n_out; a.fa.D = h->D; a.fa.nsplit = nsplit; a.fa.nrb = ncb; a.fa.T = Tc; a.fa.Tp = Tp;
+    h->last_streamed = 0;
+    sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+    return sr_launch_stream(a, fused ? 1 : 0, s);
+}
+
+static int stream_linearize(sr_gp* h, const double* x, double* mu, double* var, double* jac_mu, double* jac_var,
+                            double* hess_mu, hipStream_t s) {
+    const long Tp = srt::BN;
+    const int ncb = (h->Np + 255) / 256, ncols = 1 + h->D;
+    const bool fused = !h->general && h->D <= 3;
+    SR_TRY(ensure_ws(h, Tp, std::max(pick_nsplit(h, Tp), 2 * ncb)));
+    SR_TRY(stream_buffers(h, ncols, s));
+    const int nblk256 = (h->Np + 255) / 256;
+    const size_t need = (size_t)h->n_out * std::max(nblk256, 2 * ncb) * sr_lin_nacc(h->D);
+    if (!h->lin_v || h->lin_cap < need) {
+        (void)hipStreamSynchronize(s);
+        dev_free(h->lin_v);
+        h->lin_v = nullptr; h->lin_cap = 0;
+        SR_TRY(dev_alloc(&h->lin_v, std::max(need, (size_t)h->n_out * h->Np)));
+        h->lin_cap = std::max(need, (size_t)h->n_out * h->Np);
+    }
+    sr_lin_args la;
+    la.Z = h->Z; la.alpha = h->alpha; la.ls = h->ls; la.sf2 = h->sf2; la.Ks = h->Ks; la.g = nullptr;
+    la.x = x; la.xb = nullptr; la.na = h->D;
+    la.kp = h->general ? h->kp : nullptr;
+    la.jac_var = jac_var; la.hess_mu = hess_mu;
+    la.N = h->N; la.Np = h->Np; la.D = h->D; la.n_out = h->n_out; la.Tp = Tp;
+    if (!fused) {
+        sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
+        SR_TRY(sr_launch_lin_columns(la, sr_stream_width(ncols), h->Ks, h->lin_v, s));
+    }
+    sr_stream_args a{};
+    stream_common(h, a, ncols, Tp);
+    a.mode = 1; a.dot0 = 1;
+    a.la = la; a.lin_part = h->lin_v; a.lin_part_w = h->lin_v;
+    a.nblk = fused ? 2 * ncb : nblk256;
+    a.lin_dt = h->D <= 3 ? 3 : (h->D <= 5 ? 5 : (h->D <= 8 ? 8 : 12));
+    a.lmu = mu; a.lvar = var; a.ljac_mu = jac_mu;
+    h->last_streamed = 0;
+    sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+    return sr_launch_stream(a, fused ? 2 : 0, s);
+}
+
 // GP posterior of Tc queries x = [xa | xb] into (mu, var, jac) in API layout (jac may be NULL).
 static int single_query_streamed(sr_gp* h, const double* xa, int na, const double* xb, double* mu, double* var,
                                  double* jac_mu, double* jac_var, double* hess_mu, hipStream_t s);
@@ -717,8 +817,8 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         return sr_launch_gp_small(ka, h->Wt, mu, var, jac, s);
     }
-    if (Tc == 1 && h->small_path == 1 && !h->force_stream && h->Np > SR_STREAM_MIN_NP)
-        return single_query_streamed(h, xa, na, xb, mu, var, jac, nullptr, nullptr, s);   // three launches, no N-split partials
+    if (h->small_path != 0 && !h->force_stream && h->Np > SR_STREAM_MIN_NP && Tc <= SR_STREAM_MAX_T)
+        return stream_predict(h, Tc, xa, lda, na, xb, ldb, nb, mu, var, jac, s);   // U^-1 streamed once, 1-3 launches
     const long Tp = round_up(Tc, srt::BN);
     const int nsplit = pick_nsplit(h, Tp);
     SR_TRY(ensure_ws(h, Tp, nsplit));
@@ -855,7 +955,7 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
         return sr_launch_gp_small_lin(ka, h->Wt, mu, var, jac_mu, jac_var, hess_mu, s);
     }
     if (h->small_path != 0)
-        return single_query_streamed(h, x, h->D, nullptr, mu, var, jac_mu, jac_var, hess_mu, s);
+        return stream_linearize(h, x, mu, var, jac_mu, jac_var, hess_mu, s);
     if (!h->lin_v) { SR_TRY(dev_alloc(&h->lin_v, (size_t)h->n_out * h->Np)); h->lin_cap = (size_t)h->n_out * h->Np; }
     if (!h->lin_g) SR_TRY(dev_alloc(&h->lin_g, (size_t)h->n_out * h->Np));
     h->force_stream = 1;
@@ -1304,6 +1404,8 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
         h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
         h->splitk_cap = 0;
+        dev_free(h->stream_vp); dev_free(h->stream_tickets);
+        h->stream_vp = nullptr; h->stream_vp_cap = 0; h->stream_tickets = nullptr;
         dev_free(h->fact_ws); h->fact_ws = nullptr; h->fact_cap = 0;
         dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
     }
@@ -1418,5 +1520,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
     h->splitk_cap = 0;
+    dev_free(h->stream_vp); dev_free(h->stream_tickets);
+    h->stream_vp = nullptr; h->stream_vp_cap = 0; h->stream_tickets = nullptr;
     return SR_OK;
 }

@@ -194,6 +194,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #ifndef SR_STREAM_MIN_NP
 #define SR_STREAM_MIN_NP 384    /* T <= 16 streams U^-1 (K2s) above this padded size unless the one-launch pass K0 takes it */
 #endif
+#define SR_STREAM_MAX_T 64     /* up to here a batch beyond the one-launch sizes streams U^-1 once (sr_stream.hip) */
 #define SR_FINAL_WAVE_T 4096   /* up to here sr_finalize runs one wavefront per (query, output) */
 long sr_var_small_ws(int Np, int n_out);
 int sr_var_small_groups_max(int Np, int n_out);   // query groups of 16 the streaming path may take (1 .. 8)
@@ -243,6 +244,8 @@ int sr_launch_distance(long T, int K, int n_s, const double* samples, int per_t,
 int sr_launch_safety(long T, int n_s, int m, const double* p, const double* q, const double* h_mat,
                      const double* h_vec, double c, double* d, hipStream_t s);
 
+// ---- fused small-batch posterior (sr_stream.hip) ------------------------------------------------------
+struct sr_lin_args;
 // ---- single-query second-order outputs (sr_linearize.hip) --------------------------------------
 struct sr_lin_args {
     const double* Z; const double* alpha; const double* ls; const double* Ks; const double* g;
@@ -254,6 +257,25 @@ struct sr_lin_args {
     int N, Np, D, n_out; long Tp;
 };
 int sr_launch_trmv_t(const double* M, long ld, const double* x, long xs, double* y, int n, hipStream_t s);
+
+// fused small-batch posterior (sr_stream.hip): up to 128 columns through U^-1 in one pass, reduction and final stage
+// behind tickets.  mode 0: columns = queries (predict), fa describes the final stage; mode 1: columns = [k*, dk*/dx]
+// of one query (linearize), la / lin_part / nblk / lin_dt / lmu.. describe it.
+struct sr_stream_args {
+    const double* Wt; const double* Ks; double* Vp; double* part; unsigned* tickets;
+    int N, Np, D, n_out, ncb, npairs, k_lo, ncols, ncols_pad, dot0, mode;
+    long Tp;
+    // columns evaluated in the kernel (ARD-RBF): model and queries
+    const double* Z; const double* alpha; const double* ls; const double* sf2;
+    const double* xa; long lda; int na; const double* xb; long ldb;
+    double* mu_part_w; double* jac_part_w; double* lin_part_w;
+    sr_final_args fa;
+    sr_lin_args la; const double* lin_part; int nblk, lin_dt; double* lmu; double* lvar; double* ljac_mu;
+};
+long sr_stream_vp_doubles(int Np, int n_out, int ncols);
+int sr_stream_tickets(int Np, int n_out);
+int sr_stream_width(int ncols);
+int sr_launch_stream(sr_stream_args a, int src, hipStream_t s);
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s);
 int sr_lin_nacc(int D);
 int sr_launch_lin_columns(const sr_lin_args& a, int tq, double* Ks, double* lin_part, hipStream_t s);

@@ -8,6 +8,7 @@
 // Latency path (T = 1): three small launches per output, HBM-bound on the 2 x N^2/2 factor reads.
 // The other kernel identifiers (mat52, lin_rbf, lin_mat52) go through sr_linearize_general_kernel below.
 #include "sr_common.h"
+#include "sr_final_dev.h"
 
 // y[i] = sum_{k <= i} M[k][i] * x[k * xs]   (M upper triangular, row-major): v = U^-T k*
 __global__ __launch_bounds__(256) void sr_trmv_t_kernel(const double* __restrict__ M, long ld,
@@ -208,12 +209,6 @@ __global__ __launch_bounds__(256) void sr_linearize_general_kernel(sr_lin_args a
 //   sr_lin_columns_kernel : grid (Np/256, n_out) -- columns into the K* workspace + partial sums per workgroup
 //   sr_lin_final_kernel   : grid (n_out)         -- adds the partials, writes the five outputs
 // ------------------------------------------------------------------------------------------------
-// query coordinate j: the first na from x, the rest from xb (the reachability entry points hand p and k_ff
-// separately); xb == NULL means all D coordinates are in x
-__device__ __forceinline__ double sr_lin_x(const sr_lin_args& a, int j) {
-    return (a.xb && j >= a.na) ? a.xb[j - a.na] : a.x[j];
-}
-
 template <int DT>
 __global__ __launch_bounds__(256) void sr_lin_columns_kernel(sr_lin_args a, int tq, double* __restrict__ Ks,
                                                              double* __restrict__ lin_part) {
@@ -336,55 +331,12 @@ __global__ __launch_bounds__(256) void sr_lin_columns_kernel(sr_lin_args a, int 
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-template <int DT>
 __global__ __launch_bounds__(256) void sr_lin_final_kernel(sr_lin_args a, const double* __restrict__ lin_part,
-                                                          int nblk, const double* __restrict__ dots, int ncb,
+                                                          int nblk, int DT, const double* __restrict__ dots, int ncb,
                                                           double* __restrict__ mu, double* __restrict__ var,
                                                           double* __restrict__ jac_mu) {
-    constexpr int NH = DT * (DT + 1) / 2;
-    constexpr int NACC = 1 + DT + NH;
-    __shared__ double tot[NACC], dt[DT + 1];
-    const int d = blockIdx.x, t = threadIdx.x;
-    if (t < NACC) {
-        double v = 0.0;
-        for (int b = 0; b < nblk; ++b) v += lin_part[((long)d * nblk + b) * NACC + t];
-        tot[t] = v;
-    }
-    if (t <= DT) {
-        double v = 0.0;
-        if (t <= a.D)
-            for (int cb = 0; cb < ncb; ++cb) v += dots[((long)d * ncb + cb) * a.Tp + t];
-        dt[t] = v;
-    }
-    __syncthreads();
-    if (t == 0) {
-        double kxx, x2a = 0.0;
-        if (a.kp == nullptr) kxx = a.sf2[d];
-        else {
-            const double* kp = a.kp + (long)d * SR_KP(a.D);
-            for (int j = 0; j < a.D; ++j) x2a = fma((kp[3 + a.D + j] * kp[1] + kp[3 + 2 * a.D + j]) * sr_lin_x(a, j), sr_lin_x(a, j), x2a);
-            kxx = kp[2] * kp[1] + x2a;
-        }
-        double v = kxx - dt[0];
-        if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
-        mu[d] = tot[0];
-        var[d] = v;
-    }
-    if (t < a.D) {
-        if (jac_mu) jac_mu[d * a.D + t] = tot[1 + t];
-        double dkxx = 0.0;
-        if (a.kp != nullptr) {
-            const double* kp = a.kp + (long)d * SR_KP(a.D);
-            dkxx = 2.0 * (kp[3 + a.D + t] * kp[1] + kp[3 + 2 * a.D + t]) * sr_lin_x(a, t);
-        }
-        if (a.jac_var) a.jac_var[d * a.D + t] = dkxx - 2.0 * dt[1 + t];
-    }
-    if (a.hess_mu && t < a.D * a.D) {
-        const int j = min(t / a.D, t % a.D), c = max(t / a.D, t % a.D);
-        // position of (j, c), j <= c, in the DT-wide upper-triangle enumeration
-        const int q = 1 + DT + j * DT - j * (j - 1) / 2 + (c - j);
-        a.hess_mu[(long)d * a.D * a.D + t] = tot[q];
-    }
+    __shared__ double sh[91 + 13];
+    sr_lin_final_dev(a, lin_part, nblk, DT, dots, ncb, mu, var, jac_mu, blockIdx.x, threadIdx.x, sh);
 }
 
 int sr_launch_lin_columns(const sr_lin_args& a, int tq, double* Ks, double* lin_part, hipStream_t s) {
@@ -409,12 +361,9 @@ int sr_launch_lin_final(const sr_lin_args& a, const double* lin_part, const doub
                         double* var, double* jac_mu, hipStream_t s) {
     const int nblk = (a.Np + 255) / 256;
     // NACC <= 91 (D = 12) and D*D <= 144 threads are needed: one block of 256 covers every case
-#define SR_LF_CASE(DT) hipLaunchKernelGGL(sr_lin_final_kernel<DT>, dim3(a.n_out), dim3(256), 0, s, a, lin_part, nblk, dots, ncb, mu, var, jac_mu)
-    if (a.D <= 3) SR_LF_CASE(3);
-    else if (a.D <= 5) SR_LF_CASE(5);
-    else if (a.D <= 8) SR_LF_CASE(8);
-    else SR_LF_CASE(12);
-#undef SR_LF_CASE
+    const int DT = a.D <= 3 ? 3 : (a.D <= 5 ? 5 : (a.D <= 8 ? 8 : 12));
+    hipLaunchKernelGGL(sr_lin_final_kernel, dim3(a.n_out), dim3(256), 0, s, a, lin_part, nblk, DT, dots, ncb, mu, var,
+                       jac_mu);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

@@ -9,6 +9,7 @@
 // formulas: /root/reference/safe_exploration/ssm_gpy/gp_models_utils_casadi.py:17-40,160-197
 // shapes:   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:546-596
 #include "sr_mfma_tile.h"
+#include "sr_final_dev.h"
 
 // ------------------------------------------------------------------------------------------------
 // K1: one thread per (query, output); training inputs staged through LDS in tiles of 256 rows,
@@ -783,39 +784,11 @@ __global__ __launch_bounds__(256) void sr_finalize_kernel(sr_final_args a) {
 
 // Few queries: one wavefront per (query, output), lanes stride over the partial sums and combine
 // with a butterfly -- the serial chain of the thread-per-query form (nsplit * (1 + D) + nrb dependent
-// loads) dominates the latency of the small-batch path otherwise.
-__device__ __forceinline__ double sr_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
+// loads) dominates the latency of the small-batch path otherwise.  (sr_final_dev.h)
 __global__ __launch_bounds__(256) void sr_finalize_wave_kernel(sr_final_args a) {
-    const int lane = threadIdx.x & 63;
     const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int d = blockIdx.y;
     if (t >= a.T) return;
-    double m = 0.0;
-    for (int s = lane; s < a.nsplit; s += 64) m += a.mu_part[((long)s * a.n_out + d) * a.Tp + t];
-    m = sr_wave_sum(m);
-    double q = 0.0;
-    for (int rb = lane; rb < a.nrb; rb += 64) q += a.var_part[((long)d * a.nrb + rb) * a.Tp + t];
-    q = sr_wave_sum(q);
-    double v = (a.kxx ? a.kxx[(long)d * a.Tp + t] : a.sf2[d]) - q;
-    if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
-    if (lane == 0) {
-        a.mu[t * a.n_out + d] = m;
-        a.var[t * a.n_out + d] = v;
-    }
-    if (a.jac) {
-        for (int j = 0; j < a.D; ++j) {
-            double gj = 0.0;
-            for (int s = lane; s < a.nsplit; s += 64)
-                gj += a.jac_part[(((long)s * a.n_out + d) * a.D + j) * a.Tp + t];
-            gj = sr_wave_sum(gj);
-            if (lane == 0) a.jac[(t * a.n_out + d) * a.D + j] = gj;
-        }
-    }
+    sr_final_query_wave(a, t, blockIdx.y, threadIdx.x & 63);
 }
 
 int sr_launch_finalize(const sr_final_args& a, hipStream_t s) {

@@ -1,0 +1,455 @@
+// sr_stream.hip -- the small-batch posterior in as few launches as the data flow allows (the
+// CasADi / IPOPT callback evaluates ONE query per iteration, state_space_models.py:278-303, 384-417; candidate
+// batches of the MPC are a few dozen queries).  At N = 5000 the floor of such a call is the 210 MB of U^-1 that
+// have to be streamed once (26 us at 8 TB/s); the first version spent as long again in three auxiliary launches
+// (K* pass 8.7 + reduce 6.5 + finalize 9.8 us of mostly fixed cost).
+//
+//   sr_stream1_kernel<TQ, SRC, DT>  up to 4 columns, ONE launch: every workgroup owns a (256-column block, 128-row
+//       chunk) pair of U^-1 as before, but (SRC 1, 2) evaluates its chunk of the ARD-RBF cross-covariance columns
+//       itself -- [k*] per query, or [k*, dk*/dx_1..D] of the single query in linearize mode -- instead of reading
+//       them from a pass of their own, stores its partial sums, and takes a ticket: the LAST workgroup of a column
+//       block adds that block's partials (fixed order: deterministic), squares and reduces; the last column block
+//       runs the final stage (mean, variance, Jacobian[, d var/dx, Hessian]).  SRC 0 takes the columns from the
+//       workspace (general kernel family, D > 5).
+//   sr_stream_mfma_kernel<G>        5 .. 128 columns on the MFMA 16x16x4 tile: 16 G columns per workgroup, U^-1
+//       streamed ONCE for all of them (the first version ran one workgroup per group of 16 queries, each re-reading
+//       U^-1 from L2 / Infinity Cache, and fell back to split-K tiles at 17 queries: 70 -> 165 us).
+//   sr_stream_reduce_kernel         their reduction, one workgroup per (column block, output, column), fused with the
+//       final stage through a ticket per query.
+//
+// Inter-workgroup hand-off (cdna_hip_programming.md, Guideline 16): everything one workgroup hands to another goes out
+// with agent-scope (write-through) stores and comes in with agent-scope loads; every storing wave drains
+// (s_waitcnt vmcnt(0)) -> __syncthreads -> lane 0: relaxed agent atomic on the ticket -> __syncthreads.  No release fence: an L2 write-back per workgroup (buffer_wbl2) costs microseconds
+// and serialises per XCD (first version: 243 us for the 5120 workgroups of the T = 128 reduction).  Tickets are
+// zeroed at allocation and reset by the last arriver.
+#include "sr_mfma_tile.h"
+#include "sr_final_dev.h"
+
+#define SR_ST_ROWS 128
+#define SR_ST_COLS 256
+
+// pair index p -> column block cb, k-chunk j <= 2 cb + 1
+__device__ __forceinline__ void sr_pair_decode(int p, int& cb, int& j) {
+    cb = (int)((sqrt(4.0 * p + 1.0) - 1.0) * 0.5);
+    while ((cb + 1) * (cb + 2) <= p) ++cb;
+    while (cb * (cb + 1) > p) --cb;
+    j = p - cb * (cb + 1);
+}
+
+// returns true in exactly one workgroup: the one whose arrival completes `expected` on *ticket (which it resets).
+// All threads of the workgroup must call; on return in the elected workgroup every other arriver's stores are visible.
+__device__ __forceinline__ bool sr_ticket_last(unsigned* ticket, unsigned expected, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old == expected - 1u);
+        // (no acquire fence: whatever the elected workgroup reads of the others' results it reads with agent-scope
+        //  loads, which never hit this CU's L1 -- the fence costs 1.7 us on the tail of the launch, twice)
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = last;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// sum of one double per thread over the workgroup (256 or 1024 threads); result valid in thread 0
+__device__ __forceinline__ double sr_block_sum(double v, double* red) {
+    v = sr_wave_sum(v);
+    const int nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < nw; ++w) s += red[w];
+    return s;
+}
+
+// the final stage, by the elected last workgroup (any block size that is a multiple of 64, >= 256)
+__device__ __forceinline__ void sr_stream_final(const sr_stream_args& a, double* sh) {
+    if (a.mode == 0) {
+        const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (long q = threadIdx.x >> 6; q < a.fa.T * a.fa.n_out; q += nw)
+            sr_final_query_wave<true>(a.fa, q / a.fa.n_out, (int)(q % a.fa.n_out), lane);
+    } else {
+        // one wavefront per output (the first four wavefronts: sh holds 4 x 120 doubles)
+        const int wave = threadIdx.x >> 6;
+        if (wave < 4)
+            for (int d = wave; d < a.n_out; d += 4)
+                sr_lin_final_wave<true>(a.la, a.lin_part, a.nblk, a.lin_dt, a.part, a.ncb, a.lmu, a.lvar, a.ljac_mu, d,
+                                        threadIdx.x & 63, sh + wave * 120);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// <= 4 columns, one launch.  256 threads: thread = one column i of U^-1 inside the column block, 16 independent row
+// loads in flight.  The first batch of rows is requested BEFORE the columns are evaluated: the prologue hides behind
+// its latency.  (Two adjacent columns per thread with 16-byte loads measured the same at one column and 25 % slower
+// at four: 66 against 52 us at N = 5000.)
+// ------------------------------------------------------------------------------------------------
+#define SR_ST1_THREADS 256
+template <int TQ, int SRC, int DT>
+__global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_args a) {
+    constexpr int NH = DT * (DT + 1) / 2;
+    constexpr int NACC = (SRC == 2) ? 1 + DT + NH : TQ * (1 + DT);
+    __shared__ double ks[SR_ST_ROWS][TQ];
+    __shared__ double sh[4 * 120];
+    __shared__ int s_flag;
+    // pairs in DESCENDING order: the column blocks with many chunks (expensive reductions) are dispatched first and
+    // their reductions overlap with the streaming of the rest; the tail of the launch reduces the short ones
+    const int d = blockIdx.y, p = (int)gridDim.x - 1 - (int)blockIdx.x;
+    int cb, j;
+    sr_pair_decode(p, cb, j);
+    const int k0 = j * SR_ST_ROWS;
+    const int tid = threadIdx.x;
+
+    // ---- this thread's share of U^-1: column i, rows k0 + r0 .. k0 + kmax (k <= i)
+    const int i = cb * SR_ST_COLS + tid;
+    const double* w = a.Wt + (long)d * a.Np * a.Np + (long)k0 * a.Np + i;
+    const int kmax = (i < a.Np) ? min(SR_ST_ROWS - 1, i - k0) : -1;
+    const int r0 = max(0, a.k_lo - k0);                    // leading padding rows carry zeros
+    double wv[16];
+    const bool first16 = r0 + 15 <= kmax;
+    if (first16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = w[(long)(r0 + u) * a.Np];
+    }
+
+    if (SRC == 0) {
+        const double* ksrc = a.Ks + (long)d * a.Np * a.Tp + (long)k0 * a.Tp;
+        for (int e = tid; e < SR_ST_ROWS * TQ; e += SR_ST1_THREADS) {
+            const int r = e / TQ, t = e % TQ;
+            ks[r][t] = (k0 + r < a.Np) ? ksrc[(long)r * a.Tp + t] : 0.0;
+        }
+    } else {
+        // this chunk of the ARD-RBF columns, evaluated here: threads 0 .. 127, one training row each.  The workgroup
+        // with the smallest column block of the chunk (cb == j / 2) also owns the chunk's share of the sums over the
+        // training points (mean, mean-Jacobian [, Hessian]): slot j of the N-split partials.
+        const bool owner = (cb == (j >> 1));
+        const int off = a.Np - a.N;
+        double acc[NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
+        if (tid < SR_ST_ROWS) {
+            const int ip = k0 + tid, it = ip - off;
+            const bool valid = ip < a.Np && it >= 0;
+            double col[TQ];
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) col[t] = 0.0;
+            if (valid) {
+                const double wgt = a.alpha[(long)d * a.Np + ip];
+                const double sf2 = a.sf2[d];
+                double z[DT], il2[DT];
+#pragma unroll
+                for (int c = 0; c < DT; ++c) {
+                    const double l = (c < a.D) ? a.ls[d * a.D + c] : 1.0;
+                    il2[c] = (c < a.D) ? 1.0 / (l * l) : 0.0;
+                    z[c] = (c < a.D) ? a.Z[(long)it * a.D + c] : 0.0;
+                }
+                if (SRC == 1) {
+#pragma unroll
+                    for (int t = 0; t < TQ; ++t) {
+                        if (t < a.ncols) {
+                            double u[DT], r2 = 0.0;
+#pragma unroll
+                            for (int c = 0; c < DT; ++c) {
+                                double x = 0.0;
+                                if (c < a.D) x = (c < a.na) ? a.xa[(long)t * a.lda + c] : a.xb[(long)t * a.ldb + (c - a.na)];
+                                u[c] = (z[c] - x) * il2[c];
+                                r2 = fma(u[c], z[c] - x, r2);
+                            }
+                            const double k = sf2 * exp(-0.5 * r2);
+                            col[t] = k;
+                            acc[t * (1 + DT)] = wgt * k;
+#pragma unroll
+                            for (int c = 0; c < DT; ++c) acc[t * (1 + DT) + 1 + c] = wgt * k * u[c];
+                        }
+                    }
+                } else {
+                    double u[DT], r2 = 0.0;
+#pragma unroll
+                    for (int c = 0; c < DT; ++c) {
+                        const double x = (c < a.D) ? sr_lin_x(a.la, c) : 0.0;
+                        u[c] = (z[c] - x) * il2[c];
+                        r2 = fma(u[c], z[c] - x, r2);
+                    }
+                    const double k = sf2 * exp(-0.5 * r2);
+                    col[0] = k;
+                    acc[0] = wgt * k;
+                    int q = 1 + DT;
+#pragma unroll
+                    for (int c = 0; c < DT; ++c) {
+                        if (1 + c < TQ) col[1 + c] = k * u[c];
+                        acc[1 + c] = wgt * k * u[c];
+#pragma unroll
+                        for (int e = 0; e < DT; ++e)
+                            if (e >= c) {
+                                double hv = u[c] * u[e];
+                                if (e == c) hv -= il2[c];
+                                acc[q] = wgt * k * hv;
+                                ++q;
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) ks[tid][t] = col[t];
+        }
+        if (owner) {                                  // workgroup-uniform
+            // rows live in wavefronts 0 and 1: butterfly per wavefront, one pass through shared memory
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) {
+                const double v = sr_wave_sum(acc[q]);
+                if ((tid & 63) == 0 && tid < SR_ST_ROWS) sh[(tid >> 6) * NACC + q] = v;
+            }
+            __syncthreads();
+            if (tid < NACC) {
+                const double sum = sh[tid] + sh[NACC + tid];
+                if (SRC == 2) {
+                    sr_st_agent(a.lin_part_w + ((long)d * a.nblk + j) * NACC + tid, sum);
+                } else {
+                    const int t = tid / (1 + DT), c = tid % (1 + DT);
+                    if (t < a.ncols) {
+                        if (c == 0) sr_st_agent(a.mu_part_w + ((long)j * a.n_out + d) * a.Tp + t, sum);
+                        else if (c - 1 < a.D) sr_st_agent(a.jac_part_w + (((long)j * a.n_out + d) * a.D + (c - 1)) * a.Tp + t, sum);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- this (column block, k-chunk) of V = U^-T [columns]
+    double acc[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) acc[t] = 0.0;
+    {
+        int r = r0;
+        if (first16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) acc[t] = fma(wv[u], ks[r0 + u][t], acc[t]);
+            r += 16;
+        }
+        for (; r + 15 <= kmax; r += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w[(long)(r + u) * a.Np];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) acc[t] = fma(wv[u], ks[r + u][t], acc[t]);
+        }
+        for (; r + 3 <= kmax; r += 4) {
+            double w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w4[u] = w[(long)(r + u) * a.Np];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) acc[t] = fma(w4[u], ks[r + u][t], acc[t]);
+        }
+        for (; r <= kmax; ++r) {
+            const double w1 = w[(long)r * a.Np];
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) acc[t] = fma(w1, ks[r][t], acc[t]);
+        }
+    }
+    double* out = a.Vp + ((long)d * a.npairs + p) * TQ * SR_ST_COLS;
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) sr_st_agent(out + t * SR_ST_COLS + tid, acc[t]);
+
+    // ---- last workgroup of this column block: add the chunks, square (or multiply with column 0), reduce
+    const int nch = 2 * cb + 2;
+    if (!sr_ticket_last(a.tickets + d * a.ncb + cb, (unsigned)nch, &s_flag)) return;
+    {
+        const double* src = a.Vp + ((long)d * a.npairs + cb * (cb + 1)) * TQ * SR_ST_COLS + tid;
+        double v[TQ];
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            // same association as the stand-alone reduce kernel (even chunks, odd chunks), 8 loads in flight
+            double v0 = 0.0, v1 = 0.0;
+            for (int c = 0; c < nch; c += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    x[u] = (c + u < nch) ? sr_ld<true>(src + ((long)(c + u) * TQ + t) * SR_ST_COLS) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { v0 += x[u]; v1 += x[u + 1]; }
+            }
+            v[t] = v0 + v1;
+        }
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+            const double q = sr_block_sum(v[t] * ((a.dot0 && t != 0) ? v[0] : v[t]), sh);
+            if (tid == 0) sr_st_agent(a.part + ((long)d * a.ncb + cb) * a.Tp + t, q);
+        }
+    }
+    // ---- last column block of the call: final stage
+    if (!sr_ticket_last(a.tickets + a.n_out * a.ncb, (unsigned)(a.n_out * a.ncb), &s_flag)) return;
+    sr_stream_final(a, sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16 G columns per workgroup on the MFMA 16x16x4 tile.  The (column block, k-chunk) pair is one workgroup of 16
+// wavefronts, wavefront w owning the 16-column strip w: A-fragments straight from global (the 16 strips of a row are
+// one contiguous 2 KiB segment), B-fragments = the K* rows in LDS (row stride 16 G + 16 doubles for G > 1: the two
+// k-rows of a 32-lane ds_read_b64 group then sit on opposite bank halves), one ds_read_b64 per MFMA, G MFMAs per loaded
+// A-fragment.  Vp[(d, pair)][column][256].
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) {
+    constexpr int NC = 16 * G;
+    constexpr int LDK = (G == 1) ? 16 : NC + 16;
+    __shared__ double ks[SR_ST_ROWS * LDK];
+    const int d = blockIdx.y, p = blockIdx.x;
+    int cb, j;
+    sr_pair_decode(p, cb, j);
+    const int k0 = j * SR_ST_ROWS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
+    const int c0 = blockIdx.z * NC;                      // first column of this workgroup (grid.z: column blocks)
+    const double* ksrc = a.Ks + (long)d * a.Np * a.Tp + (long)k0 * a.Tp + c0;
+    for (int e = threadIdx.x; e < SR_ST_ROWS * NC; e += 1024) {
+        const int r = e / NC, t = e % NC;
+        ks[r * LDK + t] = (k0 + r < a.Np && c0 + t < a.ncols_pad) ? ksrc[(long)r * a.Tp + t] : 0.0;
+    }
+    __syncthreads();
+    const int i0 = cb * SR_ST_COLS + 16 * wave;          // first column of this strip
+    d4_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (i0 < a.Np) {
+        // k-steps of 4 rows: rows k0 + 4u + lk.  Rows beyond the strip's last column hold zeros of U^-1 (skipped),
+        // rows in front of k_lo carry K* == 0 (skipped at k-step granularity).
+        const int u_end = min(32, (i0 + 15 - k0) / 4 + 1);
+        int u = max(0, (a.k_lo - k0) / 4);
+        const double* w = a.Wt + (long)d * a.Np * a.Np + (long)(k0 + lk) * a.Np + i0 + ln;
+        constexpr int UB = (G <= 2) ? 16 : 8;            // A-fragments in flight per batch
+        for (; u + UB <= u_end; u += UB) {
+            double af[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) af[q] = w[(long)(4 * (u + q)) * a.Np];
+#pragma unroll
+            for (int q = 0; q < UB; ++q)
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], ks[(4 * (u + q) + lk) * LDK + 16 * g + ln], acc[g], 0, 0, 0);
+        }
+        for (; u < u_end; ++u) {
+            const double af = w[(long)(4 * u) * a.Np];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, ks[(4 * u + lk) * LDK + 16 * g + ln], acc[g], 0, 0, 0);
+        }
+    }
+    // acc[g][r] = V[column i0 + lk + 4r][query 16 g + ln]
+    double* out = a.Vp + (((long)d * a.npairs + p) * (NC * gridDim.z) + c0) * SR_ST_COLS;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(long)(16 * g + ln) * SR_ST_COLS + 16 * wave + lk + 4 * r] = acc[g][r];
+}
+
+// part[d][cb][t] = sum_{i in column block cb} V_t[i] (dot0 ? V_0[i] : V_t[i]),  V_t = sum_chunks Vp;
+// grid (ncb, n_out, live columns).  The last workgroup of a COLUMN t (predict: query t) runs that query's final stage;
+// in linearize mode the last workgroup of the whole grid runs the single query's.
+__global__ __launch_bounds__(256) void sr_stream_reduce_kernel(sr_stream_args a, int nc) {
+    __shared__ double sh[4 * 120];
+    __shared__ int s_flag;
+    const int cb = blockIdx.x, d = blockIdx.y, t = blockIdx.z;
+    const int p0 = cb * (cb + 1), nch = 2 * cb + 2;
+    const double* src = a.Vp + (((long)d * a.npairs + p0) * nc + t) * SR_ST_COLS + threadIdx.x;
+    const long cs = (long)nc * SR_ST_COLS;               // chunk stride
+    double v0 = 0.0, v1 = 0.0;
+    for (int c = 0; c < nch; c += 8) {                    // (plain loads: Vp comes from the previous launch)
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (c + u < nch) ? src[(c + u) * cs] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { v0 += x[u]; v1 += x[u + 1]; }
+    }
+    double w = v0 + v1;
+    if (a.dot0 && t != 0) {
+        const double* s0 = a.Vp + (((long)d * a.npairs + p0) * nc) * SR_ST_COLS + threadIdx.x;
+        double w0 = 0.0, w1 = 0.0;
+        for (int c = 0; c < nch; c += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (c + u < nch) ? s0[(c + u) * cs] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { w0 += x[u]; w1 += x[u + 1]; }
+        }
+        w = w0 + w1;
+    }
+    const double q = sr_block_sum((v0 + v1) * w, sh);
+    if (threadIdx.x == 0) sr_st_agent(a.part + ((long)d * a.ncb + cb) * a.Tp + t, q);
+    if (a.mode == 0) {
+        if (!sr_ticket_last(a.tickets + t, (unsigned)(a.n_out * a.ncb), &s_flag)) return;
+        for (int dd = threadIdx.x >> 6; dd < a.n_out; dd += 4) sr_final_query_wave<true>(a.fa, t, dd, threadIdx.x & 63);
+    } else {
+        if (!sr_ticket_last(a.tickets, (unsigned)(a.n_out * a.ncb * gridDim.z), &s_flag)) return;
+        sr_stream_final(a, sh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+long sr_stream_vp_doubles(int Np, int n_out, int ncols) {
+    const int ncb = (Np + SR_ST_COLS - 1) / SR_ST_COLS;
+    return (long)n_out * ncb * (ncb + 1) * ncols * SR_ST_COLS;
+}
+int sr_stream_tickets(int Np, int n_out) {
+    const int ncb = (Np + SR_ST_COLS - 1) / SR_ST_COLS;
+    return std::max(n_out * ncb + 1, 128 + 1);
+}
+// columns the accumulate kernel works on for `ncols` live ones: 1, 4, or a multiple of 16 (<= 128)
+int sr_stream_width(int ncols) {
+    if (ncols <= 1) return 1;
+    if (ncols <= 4) return 4;
+    if (ncols <= 16) return 16;
+    if (ncols <= 32) return 32;
+    if (ncols <= 64) return 64;
+    return 128;
+}
+
+// src: 0 columns from a.Ks, 1 ARD-RBF predict columns evaluated in the kernel, 2 ARD-RBF linearize columns
+int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
+    a.ncb = (a.Np + SR_ST_COLS - 1) / SR_ST_COLS;
+    a.npairs = a.ncb * (a.ncb + 1);
+    const int nc = sr_stream_width(a.ncols);
+    SR_CHECK(a.ncols >= 1 && a.ncols <= 128, SR_EINVAL, "stream: %d columns", a.ncols);
+    dim3 grid(a.npairs, a.n_out);
+    if (nc <= 4) {
+        SR_CHECK(src == 0 || (a.D <= 5 && (src == 1 || a.D + 1 <= 4)), SR_EINVAL, "stream: src %d with D = %d", src, a.D);
+#define SR_ST1(TQ, SRC, DT) hipLaunchKernelGGL((sr_stream1_kernel<TQ, SRC, DT>), grid, dim3(SR_ST1_THREADS), 0, s, a)
+        if (src == 0) { if (nc == 1) SR_ST1(1, 0, 1); else SR_ST1(4, 0, 1); }
+        else if (src == 1) {
+            if (a.D <= 3) { if (nc == 1) SR_ST1(1, 1, 3); else SR_ST1(4, 1, 3); }
+            else { if (nc == 1) SR_ST1(1, 1, 5); else SR_ST1(4, 1, 5); }
+        } else SR_ST1(4, 2, 3);
+#undef SR_ST1
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
+    SR_CHECK(src == 0, SR_EINVAL, "stream: more than 4 columns come from the workspace");
+    a.ncols_pad = a.ncols;
+    // columns per workgroup: as many as possible (U^-1 is then read once for all of them) while the grid still
+    // covers the chip; a small model keeps its column groups side by side in grid.z (they re-read U^-1 from L2)
+    int g = nc / 16;
+    while (g > 1 && (long)a.npairs * a.n_out * (nc / (16 * g)) < 256) g >>= 1;
+    grid.z = nc / (16 * g);
+    switch (g) {
+        case 1: hipLaunchKernelGGL(sr_stream_mfma_kernel<1>, grid, dim3(1024), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(sr_stream_mfma_kernel<2>, grid, dim3(1024), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(sr_stream_mfma_kernel<4>, grid, dim3(1024), 0, s, a); break;
+        default: hipLaunchKernelGGL(sr_stream_mfma_kernel<8>, grid, dim3(1024), 0, s, a); break;
+    }
+    SR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sr_stream_reduce_kernel, dim3(a.ncb, a.n_out, a.ncols), dim3(256), 0, s, a, nc);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}

@@ -1119,3 +1119,48 @@ def test_streamed_linearize_all_kernels(kt, N, n_s, n_u):
     gp.set_small_path(1)
     for a_, b_, tol in zip((mu, var, jm, jv, hm), out0, (1e-12 * scale, 1e-11, 1e-11 * scale, 1e-9, 1e-10 * scale)):
         np.testing.assert_allclose(a_, b_, rtol=1e-8, atol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,n_s,n_u", [(1300, 2, 1), (2600, 4, 1)])
+def test_fused_stream_path_under_changing_inputs(N, n_s, n_u):
+    """The fused small-batch route hands partial results from workgroup to workgroup inside one launch (tickets,
+    agent-scope stores / loads, sr_stream.hip) and reuses the same scratch addresses call after call: a stale line
+    from the PREVIOUS call would go unnoticed if every call evaluated the same query.  300 calls with different
+    queries and batch sizes each, every result against the plain three-kernel MFMA path evaluated on the whole set at
+    once; the single-query linearisation likewise against its own non-streamed route."""
+    import torch
+    rng = np.random.default_rng(N)
+    D = n_s + n_u
+    syn = orc.make_synthetic(N, N, n_s, n_u, 4, sf2=0.5)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    X = rng.uniform(-0.9, 0.9, (700, D))
+    gp.set_small_path(0)
+    rmu, rvar, rjac = gp.predict(X, None, True)
+    gp.set_small_path(1)
+    dev = gp.device
+    tX = torch.from_numpy(X).to(dev)
+    scale = max(float(np.abs(gp.beta).sum(0).max()), 1.0)
+    pos, sizes = 0, [1, 3, 1, 9, 2, 40, 1, 4, 17, 1, 64, 5]
+    k = 0
+    while pos + 64 <= X.shape[0]:
+        T = sizes[k % len(sizes)]
+        k += 1
+        mu, var, jac = gp.predict_device(tX[pos:pos + T], True)
+        np.testing.assert_allclose(mu.cpu().numpy(), rmu[pos:pos + T], rtol=1e-10, atol=1e-12 * scale)
+        np.testing.assert_allclose(var.cpu().numpy(), rvar[pos:pos + T], rtol=0, atol=2e-11)
+        np.testing.assert_allclose(jac.cpu().numpy(), rjac[pos:pos + T], rtol=1e-10, atol=1e-11 * scale)
+        pos += T
+    assert k > 40
+    # linearize: streamed route, a different query every call, interleaved with predict calls on the same handle
+    refs = []
+    gp.set_small_path(0)
+    for q in range(12):
+        refs.append(gp.linearize_predict(X[q:q + 1, :n_s], X[q:q + 1, n_s:], True))
+    gp.set_small_path(1)
+    for rep in range(3):
+        for q in range(12):
+            out = gp.linearize_predict(X[q:q + 1, :n_s], X[q:q + 1, n_s:], True)
+            gp.predict_device(tX[100 + q:101 + q], True)
+            for a_, b_, tol in zip(out, refs[q], (1e-12 * scale, 2e-11, 1e-11 * scale, 1e-9, 1e-10 * scale)):
+                np.testing.assert_allclose(a_, b_, rtol=1e-8, atol=tol)
