@@ -295,6 +295,10 @@ static int pick_fact_panel(const sr_gp* h) {
 //   regime 1 (chain-bound sizes, nb <= 128): critical stream = highest priority, every CU; bulk stream = CU mask
 //     without the first 32 bits: one CU per shader engine stays free, wherever the diagonal block lands
 //     (measured at N = 5000: 61 us alone, 140-210 us beside an unmasked bulk update, 75 us with the reserve);
+//     (a stream of their own for the diagonal blocks, so that a block is factored BESIDE the update of the rest of
+//     its block row, was measured here and lost: every hand-over between two hardware queues costs more than the
+//     25 us it hides -- N = 5000: 6.9 -> 15.2 ms.  The same holds for a third priority stream per output and for a
+//     row-wise inversion running beside the chain: 6.9 -> 12.5 resp. 8.0 -> 10.6 ms.  One critical stream per output.)
 //   regime 2 (GEMM-bound sizes): the bulk stream leaves only the first 8 bits out (one CU per XCD, 3 % of the
 //     chip), and the diagonal blocks run on a third stream that owns exactly those 8 CUs -- the bulk tiles last
 //     200 us there and would otherwise keep a diagonal block waiting for ~1.4 ms (N = 50000: the chain of 391 blocks
@@ -416,6 +420,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     for (int d0 = 0; d0 < h->n_out; d0 += n_par) {
         const int nd = std::min(n_par, h->n_out - d0);
         int n_bulk[SR_FACT_SLOTS] = {0};                  // bulk updates issued so far (event ping-pong)
+        bool diag_ready[SR_FACT_SLOTS] = {false};         // "diagonal tile of the next block is final" already recorded
         for (int sl = 0; sl < nd; ++sl) {
             const int d = d0 + sl;
             hipStream_t sc = h->fact_stream[sl];
@@ -441,31 +446,41 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                     double* W = U + NN;
                     double* Wt = h->Wt + (size_t)d * NN;
                     const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
+                    const int ncols = Np - (kb + 1) * SR_NB;
+                    hipStream_t sd = h->diag_stream[sl];
+                    // left-looking INSIDE the panel: block row kb takes the updates of the panel's rows above it in
+                    // one product with K = (kb - p0) * 128, right before it is needed -- each row block of the
+                    // panel is read-modify-written once (eager rank-128 updates of all remaining panel rows
+                    // touched it up to P - 1 times with K = 128, where prologue and epilogue dominate a tile).
+                    // With a stream of its own for the diagonal blocks the update is split: the diagonal tile first,
+                    // then the diagonal block (62 us on its reserved CU) BESIDE the rest of the row's update.
+                    const double* Upr = W + (size_t)p0 * SR_NB * Np + (size_t)kb * SR_NB;       // rows p0..kb-1, cols >= kb
+                    const int Kin = (kb - p0) * SR_NB;
                     if (kb > p0) {
-                        // left-looking INSIDE the panel: block row kb takes the updates of the panel's rows above it in
-                        // one product with K = (kb - p0) * 128, right before it is needed -- each row block of the
-                        // panel is read-modify-written once (eager rank-128 updates of all remaining panel rows
-                        // touched it up to P - 1 times with K = 128, where prologue and epilogue dominate a tile)
-                        const double* Upr = W + (size_t)p0 * SR_NB * Np + (size_t)kb * SR_NB;   // rows p0..kb-1, cols >= kb
                         sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
-                        SR_F(sr_launch_gemm_tn_upper(Upr, Np, Upr, Np, U + dg, Np, SR_NB, Np - kb * SR_NB, (kb - p0) * SR_NB,
+                        SR_F(sr_launch_gemm_tn_upper(Upr, Np, Upr, Np, U + dg, Np, SR_NB, sd ? SR_NB : Np - kb * SR_NB, Kin,
                                                      -1.0, 1.0, sc, 1));
                     }
-                    if (hipStream_t sd = h->diag_stream[sl]) {
-                        // the block lives on the reserved CUs: hand over, factor, hand back
-                        SR_FH(hipEventRecord(h->ev_diag[sl][0], sc));
+                    if (sd) {
+                        // hand the block over (unless the look-ahead already recorded "tile ready"), factor it there
+                        if (!diag_ready[sl]) SR_FH(hipEventRecord(h->ev_diag[sl][0], sc));
+                        diag_ready[sl] = false;
                         SR_FH(hipStreamWaitEvent(sd, h->ev_diag[sl][0], 0));
                         {
                             sr_prof_scope ps(&h->prof, SR_K_POTRF, sd);
                             SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, sd));
                         }
                         SR_FH(hipEventRecord(h->ev_diag[sl][1], sd));
+                        if (kb > p0 && ncols > 0) {               // rest of row kb: A[kb][kb+1:] -= Upr[:, kb]^T Upr[:, kb+1:]
+                            sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                            SR_F(sr_launch_gemm_tn(Upr, Np, Upr + SR_NB, Np, U + dg + SR_NB, Np, SR_NB, ncols, Kin, -1.0, 1.0, 0,
+                                                   sc, 1));
+                        }
                         SR_FH(hipStreamWaitEvent(sc, h->ev_diag[sl][1], 0));
                     } else {
                         sr_prof_scope ps(&h->prof, SR_K_POTRF, sc);
                         SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, sc));
                     }
-                    const int ncols = Np - (kb + 1) * SR_NB;
                     if (ncols > 0) {
                         const double* Arow = U + dg + SR_NB;          // updated Gram rows right of the block
                         double* Urow = W + dg + SR_NB;                // factor rows U[kb][cols right of the block]
@@ -489,7 +504,19 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                 if (bulk > 0) SR_FH(hipEventRecord(h->ev_panel[sl][pi & 1], sc));     // the panel's rows are final
                 // the previous bulk update wrote the look-ahead rows too: it has to be through
                 if (n_bulk[sl] > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[sl][(n_bulk[sl] - 1) & 1], 0));
-                {
+                if (h->diag_stream[sl]) {
+                    // the next panel's first diagonal tile first: its diagonal block then runs beside the rest
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, SR_NB, SR_NB, Kp, -1.0, 1.0, sc, 1));
+                    SR_FH(hipEventRecord(h->ev_diag[sl][0], sc));
+                    diag_ready[sl] = true;
+                    if (rest > SR_NB)          // row p1 right of its diagonal tile
+                        SR_F(sr_launch_gemm_tn(Upan, Np, Upan + SR_NB, Np, Cnext + SR_NB, Np, SR_NB, rest - SR_NB, Kp, -1.0, 1.0, 0,
+                                               sc, 1));
+                    if (la > SR_NB)            // the other rows of the next panel
+                        SR_F(sr_launch_gemm_tn_upper(Upan + SR_NB, Np, Upan + SR_NB, Np, Cnext + (size_t)SR_NB * Np + SR_NB, Np,
+                                                     la - SR_NB, rest - SR_NB, Kp, -1.0, 1.0, sc, 1));
+                } else {
                     sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
                     SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1));
                 }
