@@ -78,8 +78,9 @@ int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
  * replaces: update_model(x, y, opt_hyp=False, replace_old=False)  ssm_gpy/gaussian_process.py:347-419
  * (the reference refactorises; its own row-append sketch is ssm_pytorch/utilities.py:74-117).
  * info [host, n_out] like sr_gp_factorize.  On success N grows by m and Np may grow.
- * m <= 16 takes matrix-vector shaped passes (U12 through the streaming prediction kernels, alpha updated from the
- * old model's mean at the new points; 0.9 ms at N = 5000), larger m the GEMM route. */
+ * m <= 16 takes matrix-vector shaped passes (U12 through the streaming prediction kernels; 0.9 ms at N = 5000), larger m
+ * the same algebra on 64 x 64 MFMA tiles; either way alpha is updated from the old model's mean at the new points and no
+ * buffer of the factor's size is allocated while the padded size stays the same. */
 int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info);
 
 /* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and

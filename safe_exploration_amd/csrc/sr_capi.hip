@@ -1446,38 +1446,45 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
     if (m <= SR_SMALL_T) return append_small(h, Znew, Ynew, m, s, info);
+    // 17 .. 128 new points: the same algebra on the MFMA tile (64 x 64 workgroup tiles: the products are 128 columns wide).
+    // Scratch lives with the handle, U^-1 ping-pongs between two buffers while the padded size stays, alpha is updated
+    // from the old model's mean at the new points like in the few-points route -- no allocation of the factor's size, no
+    // pass over the new U^-1 (first version: 12 hipMallocs, two 210 MB transposes and two triangular mat-vecs per
+    // output: 7 ms at N = 5000).
     const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
     const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1;
     const int pf = SR_NB - m;
-    const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
+    const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB, PB = (size_t)Np0 * SR_NB;
+    const size_t o_xq = 0, o_ks = o_xq + (size_t)SR_NB * D, o_u12 = o_ks + (size_t)n_out * PB, o_u12t = o_u12 + PB,
+                 o_x = o_u12t + PB, o_y2 = o_x + PB, o_g = o_y2 + PB, o_sb = o_g + BB, o_inv = o_sb + BB, o_wdm = o_inv + BB,
+                 o_wtr = o_wdm + BB, o_info = o_wtr + NN0, need = o_info + (size_t)n_out;
+    if (h->app_cap < need) {
+        (void)hipDeviceSynchronize();
+        dev_free(h->app_ws);
+        h->app_ws = nullptr; h->app_cap = 0;
+        SR_TRY(dev_alloc(&h->app_ws, need));
+        h->app_cap = need;
+    }
+    double* ws = h->app_ws;
+    double *Xq = ws + o_xq, *Ks = ws + o_ks, *U12 = ws + o_u12, *U12t = ws + o_u12t, *X = ws + o_x, *Y2 = ws + o_y2,
+           *G = ws + o_g, *Sb = ws + o_sb, *invS = ws + o_inv, *wdm = ws + o_wdm, *Wtr = ws + o_wtr;
+    int* info_dev = reinterpret_cast<int*>(ws + o_info);
     double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;                 // new persistent state
-    double *Xq = nullptr, *Ks = nullptr, *U12 = nullptr, *U12t = nullptr, *G = nullptr,
-           *Sb = nullptr, *invS = nullptr, *wdm = nullptr, *X = nullptr, *Y2 = nullptr, *Wtr = nullptr, *v = nullptr;
-    int* info_dev = nullptr;
+    const bool reuse_alt = (Np1 == Np0) && h->Wt_alt && h->wt_alt_cap >= (size_t)n_out * NN1;
     std::vector<double> sf2(n_out), noise(n_out);
     int rc = SR_OK;
-    auto cleanup = [&](bool drop_new) {
-        dev_free(Xq); dev_free(Ks); dev_free(U12); dev_free(U12t); dev_free(G); dev_free(Sb);
-        dev_free(invS); dev_free(wdm); dev_free(X); dev_free(Y2); dev_free(Wtr); dev_free(v); dev_free(info_dev);
-        if (drop_new) { dev_free(Z1); dev_free(yT1); dev_free(alpha1); dev_free(Wt1); }
+    auto drop_new = [&]() {
+        dev_free(Z1); dev_free(yT1); dev_free(alpha1);
+        if (!reuse_alt) dev_free(Wt1);
     };
-#define SR_A(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(true); return rc; } } while (0)
+#define SR_A(expr) do { rc = (expr); if (rc != SR_OK) { drop_new(); return rc; } } while (0)
 #define SR_AH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
-        sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(true); return SR_EHIP; } } while (0)
+        sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); drop_new(); return SR_EHIP; } } while (0)
     SR_A(dev_alloc(&Z1, (size_t)N1 * D));
     SR_A(dev_alloc(&yT1, (size_t)n_out * Np1));
     SR_A(dev_alloc(&alpha1, (size_t)n_out * Np1));
-    SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
-    SR_A(dev_alloc(&Xq, (size_t)SR_NB * D));
-    SR_A(dev_alloc(&Ks, (size_t)n_out * Np0 * SR_NB));
-    SR_A(dev_alloc(&U12, (size_t)Np0 * SR_NB));
-    SR_A(dev_alloc(&U12t, (size_t)Np0 * SR_NB));
-    SR_A(dev_alloc(&G, BB)); SR_A(dev_alloc(&Sb, BB)); SR_A(dev_alloc(&invS, BB)); SR_A(dev_alloc(&wdm, BB));
-    SR_A(dev_alloc(&X, (size_t)Np0 * SR_NB));
-    SR_A(dev_alloc(&Y2, (size_t)Np0 * SR_NB));
-    SR_A(dev_alloc(&Wtr, std::max(NN0, NN1)));
-    SR_A(dev_alloc(&v, (size_t)Np1));
-    SR_A(dev_alloc(&info_dev, (size_t)n_out));
+    if (reuse_alt) Wt1 = h->Wt_alt;
+    else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
     SR_AH(hipMemsetAsync(info_dev, 0, sizeof(int) * n_out, s));
     SR_AH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
     SR_AH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
@@ -1488,9 +1495,8 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     hipLaunchKernelGGL(sr_append_queries_kernel, dim3(SR_NB), dim3(64), 0, s, Znew, Xq, m, D);
     SR_AH(hipGetLastError());
     SR_AH(hipStreamSynchronize(s));
-    // B = K(Z_old, Z_new): the prediction kernel with the new points as queries (old padded row indexing)
-    // (the mean / Jacobian partial sums of the pass are not needed: they land in the prediction workspace; the
-    //  N-split keeps the per-thread exp chain short -- one split cost 0.9 ms at N = 5000)
+    // B = K(Z_old, Z_new): the prediction kernel with the new points as queries (old padded row indexing); its
+    // mean partial sums (the old model's mean at the new points) feed the alpha update below
     const int nsplit = pick_nsplit(h, SR_NB);
     SR_A(ensure_ws(h, SR_NB, nsplit));
     sr_kstar_args ka;
@@ -1503,7 +1509,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     for (int d = 0; d < n_out; ++d) {
         const double* Wt0 = h->Wt + (size_t)d * NN0;
         // U12 = U^-T B  (A = U^-1 k-major, upper block triangular)
-        SR_A(sr_launch_gemm_tn(Wt0, Np0, Ks + (size_t)d * Np0 * SR_NB, SR_NB, U12, SR_NB, Np0, SR_NB, Np0, 1.0, 0.0, 3, s));
+        SR_A(sr_launch_gemm_tn(Wt0, Np0, Ks + (size_t)d * PB, SR_NB, U12, SR_NB, Np0, SR_NB, Np0, 1.0, 0.0, 3, s));
         SR_A(sr_launch_gemm_tn(U12, SR_NB, U12, SR_NB, G, SR_NB, SR_NB, SR_NB, Np0, 1.0, 0.0, 0, s));
         // S = C - U12^T U12 on the real (front padded) block, C = k(Znew, Znew) + noise I
         if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], Sb, m, SR_NB, D, s));
@@ -1517,14 +1523,15 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
         SR_A(sr_launch_transpose(Wt0, Wtr, Np0, s));
         SR_A(sr_launch_gemm_tn(Wtr, Np0, X, SR_NB, Y2, SR_NB, Np0, SR_NB, Np0, -1.0, 0.0, 4, s));
         SR_A(sr_launch_append_assemble(Wt0, Np0, off0, N0, Y2, invS, m, Wt1 + (size_t)d * NN1, Np1, off1, s));
-        // alpha = U1^-1 (U1^-T y)
-        SR_A(sr_launch_transpose(Wt1 + (size_t)d * NN1, Wtr, Np1, s));
-        SR_A(sr_launch_trmv(Wtr, Np1, yT1 + (size_t)d * Np1, v, Np1, 1, s));
-        SR_A(sr_launch_trmv(Wt1 + (size_t)d * NN1, Np1, v, alpha1 + (size_t)d * Np1, Np1, 0, s));
+        // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1
+        SR_A(sr_launch_append_alpha(h->alpha + (size_t)d * Np0, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, d, SR_NB, Ynew,
+                                    m, alpha1 + (size_t)d * Np1, Np1, s, pf));
     }
     std::vector<int> info_h(n_out, 0);
     SR_AH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
     SR_AH(hipStreamSynchronize(s));
+#undef SR_A
+#undef SR_AH
     int bad = 0;
     for (int d = 0; d < n_out; ++d) {
         if (info_h[d] > 0) info_h[d] = N0 + std::max(1, info_h[d] - pf);
@@ -1532,22 +1539,32 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
         if (info_h[d] != 0 && !bad) bad = d + 1;
     }
     if (bad) {
-        cleanup(true);
+        drop_new();
         sr_set_error("sr_gp_append: Schur complement not positive definite (output %d, point %d)", bad - 1, info_h[bad - 1]);
         return SR_ENOTPD;
     }
-#undef SR_A
-#undef SR_AH
-    cleanup(false);
-    // adopt the new state; everything sized by Np is dropped and re-created lazily
-    dev_free(h->Z); dev_free(h->yT); dev_free(h->alpha); dev_free(h->Wt);
+    double* old_wt = h->Wt;
+    dev_free(h->Z); dev_free(h->yT); dev_free(h->alpha);
     h->Z = Z1; h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
-    h->N = N1; h->Np = Np1;
-    free_ws(h);
-    dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
-    h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
-    h->splitk_cap = 0;
-    dev_free(h->stream_vp); dev_free(h->stream_tickets);
-    h->stream_vp = nullptr; h->stream_vp_cap = 0; h->stream_tickets = nullptr;
+    h->N = N1;
+    if (Np1 == Np0) {
+        // keep the previous buffer for the next append (bounded: not for huge factors)
+        if (!reuse_alt) dev_free(h->Wt_alt);
+        if ((size_t)n_out * NN0 * sizeof(double) <= SR_FACT_PAR_BYTES * 2) { h->Wt_alt = old_wt; h->wt_alt_cap = (size_t)n_out * NN0; }
+        else { dev_free(old_wt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; }
+    } else {
+        // everything sized by Np is dropped and re-created lazily
+        dev_free(old_wt);
+        dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0;
+        h->Np = Np1;
+        free_ws(h);
+        dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
+        h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
+        h->splitk_cap = 0;
+        dev_free(h->stream_vp); dev_free(h->stream_tickets);
+        h->stream_vp = nullptr; h->stream_vp_cap = 0; h->stream_tickets = nullptr;
+        dev_free(h->fact_ws); h->fact_ws = nullptr; h->fact_cap = 0;
+        dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
+    }
     return SR_OK;
 }

@@ -205,7 +205,7 @@ int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, i
 int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_out, int T, hipStream_t s);
 int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
                            const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
-                           double* alpha1, int Np1, hipStream_t s);
+                           double* alpha1, int Np1, hipStream_t s, int qoff = 0);
 int sr_launch_append_small(const double* U12t, const double* Wt0, int Np0, int m, int stage, double* G,
                            const double* invS, double* Xt, double* Y2, hipStream_t s);
 

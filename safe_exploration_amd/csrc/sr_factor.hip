@@ -713,12 +713,13 @@ __global__ __launch_bounds__(256) void sr_append_alpha_kernel(const double* __re
                                                               const double* __restrict__ mu_part, int nsplit,
                                                               int n_out, int d, long Tp,
                                                               const double* __restrict__ Ynew, int m,
-                                                              double* __restrict__ alpha1, int Np1) {
-    __shared__ double r[SR_SMALL_T], v2[SR_SMALL_T];
+                                                              double* __restrict__ alpha1, int Np1, int qoff) {
+    // qoff: position of the first new point among the queries of the K* pass (front-padded query block: 128 - m)
+    __shared__ double r[SR_NB], v2[SR_NB];
     const int pf = SR_NB - m, off0 = Np0 - N0, off1 = Np1 - (N0 + m);
     if (threadIdx.x < m) {
         double mu = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) mu += mu_part[((long)sp * n_out + d) * Tp + threadIdx.x];
+        for (int sp = 0; sp < nsplit; ++sp) mu += mu_part[((long)sp * n_out + d) * Tp + qoff + threadIdx.x];
         r[threadIdx.x] = Ynew[(long)threadIdx.x * n_out + d] - mu;
     }
     __syncthreads();
@@ -746,9 +747,9 @@ __global__ __launch_bounds__(256) void sr_append_alpha_kernel(const double* __re
 
 int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
                            const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
-                           double* alpha1, int Np1, hipStream_t s) {
+                           double* alpha1, int Np1, hipStream_t s, int qoff) {
     hipLaunchKernelGGL(sr_append_alpha_kernel, dim3((Np1 + 255) / 256), dim3(256), 0, s, alpha0, Np0, N0, Y2, invS,
-                       mu_part, nsplit, n_out, d, Tp, Ynew, m, alpha1, Np1);
+                       mu_part, nsplit, n_out, d, Tp, Ynew, m, alpha1, Np1, qoff);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

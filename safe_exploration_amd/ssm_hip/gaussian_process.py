@@ -409,9 +409,9 @@ class SimpleGPModel(StateSpaceModel):
             raise ValueError("x must be (n, n_s_in+n_u) and y (n, n_s_out)")
         hd = self._handle
         s = B.stream_ptr(hd.device)
-        # <= 16 rows per call take the matrix-vector shaped path of sr_gp_append (0.9-1.3 ms at N = 5000); the
-        # GEMM path of a 17..128-row chunk costs 7 ms there but only 1-2 ms on small models
-        step = 16 if (x.shape[0] <= 16 or (hd.Np >= 2048 and x.shape[0] <= 96)) else 128
+        # <= 16 rows per call take the matrix-vector shaped path of sr_gp_append (0.9-1.3 ms at N = 5000), more rows
+        # go 128 at a time through its MFMA path
+        step = 16 if x.shape[0] <= 16 else 128
         for lo in range(0, x.shape[0], step):
             xs, ys = x[lo:lo + step], y[lo:lo + step]
             tx, ty = B.as_dev(xs, hd.device), B.as_dev(ys, hd.device)
