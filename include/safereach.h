@@ -12,7 +12,8 @@
  *     thread-local message.  Nothing throws across the boundary.
  *   - work is enqueued asynchronously on the hipStream_t passed as `void* stream` (NULL = default
  *     stream).  A handle is bound to one device and is not thread-safe.
- *   - n_out (GP outputs) == n_s for the reachability entry points; D = n_s + n_u.
+ *   - n_out (GP outputs) == n_s for the reachability entry points; D = n_s + n_u (D = n_x_in + n_u with an input
+ *     transform, sr_gp_set_input_transform).
  */
 #ifndef SAFEREACH_H
 #define SAFEREACH_H
@@ -111,6 +112,14 @@ int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, double* var, 
  * All kernel identifiers (rbf, mat52, lin_rbf, lin_mat52) in closed form. */
 int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* var, double* jac_mu,
                     double* jac_var, double* hess_mu, void* stream);
+
+/* ---- GP input transform ---------------------------------------------------------------------------
+ * replaces: the t_z_gp / a_gp_inp_x arguments of gp_reachability_casadi.onestep_reachability (:60-61,85,94-97) and
+ * uncertainty_propagation_casadi.one_step_taylor (:40-47,60): the GP is evaluated at x_gp = Tz x (the journal's cart-pole
+ * model drops the cart position: D = 4), its state Jacobian is jac[:, :n_x_in] Tz.  Tz [device] n_x_in x n_out (copied);
+ * NULL restores the identity.  While set, the reachability / moment entry points below use n_s = n_out,
+ * n_u = D - n_x_in.  Plain predictions are not affected. */
+int sr_gp_set_input_transform(sr_gp_t h, const double* Tz, int n_x_in, void* stream);
 
 /* ---- one-step reachability, batched over T queries ------------------------------------------
  * replaces: gp_reachability.onestep_reachability  gp_reachability.py:19-156

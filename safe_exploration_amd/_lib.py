@@ -52,6 +52,7 @@ SIGNATURES = {
     "sr_gp_inv_k": (_I, [_H, _I, _P, _P]),
     "sr_gp_predict": (_I, [_H, _P, _L, _P, _P, _P, _P]),
     "sr_gp_linearize": (_I, [_H, _P, _P, _P, _P, _P, _P, _P]),
+    "sr_gp_set_input_transform": (_I, [_H, _P, _I, _P]),
     "sr_onestep_reach": (_I, [_H, _L, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _P]),
     "sr_multistep_reach": (_I, [_H, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P]),
     "sr_multistep_moments": (_I, [_H, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -21,6 +21,9 @@ struct sr_gp {
     double *Z = nullptr, *yT = nullptr, *ls = nullptr, *sf2 = nullptr, *noise = nullptr,
            *alpha = nullptr, *Wt = nullptr;
     double* kp = nullptr;     // general kernel family: n_out x SR_KP(D) packed parameters (else NULL)
+    // GP input transform of the reachability / moment entry points: x_gp = Tz x (Tz n_xin x n_s), NULL = identity
+    double* Tz = nullptr; int n_xin = 0;
+    double *tz_x = nullptr, *tz_jac = nullptr; long tz_cap = 0;   // transformed inputs / chain-ruled Jacobians (per chunk)
     int general = 0;
     int have_data = 0, factorized = 0;
     // per-chunk workspace (grow-only)
@@ -135,6 +138,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
+    dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (int d = 0; d < SR_FACT_SLOTS; ++d) {
@@ -1008,9 +1012,87 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     return sr_launch_linearize(la, s);
 }
 
+// ---- GP input transform (gp_reachability_casadi.py:60-61,85,94-97; uncertainty_propagation_casadi.py:40-47,60):
+// the GP sees x_gp = Tz x (e.g. the cart-pole model without the cart position: D = 4), its Jacobian with respect to
+// the state is jac[:, :n_xin] Tz.
+__global__ __launch_bounds__(256) void sr_tz_apply_kernel(const double* __restrict__ p, long ldp,
+                                                          const double* __restrict__ Tz, double* __restrict__ xbar,
+                                                          long T, int n_s, int n_xin) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= T * n_xin) return;
+    const long t = e / n_xin;
+    const int i = (int)(e % n_xin);
+    double v = 0.0;
+    for (int j = 0; j < n_s; ++j) v = fma(Tz[i * n_s + j], p[t * ldp + j], v);
+    xbar[e] = v;
+}
+
+// jacs[t][o][:n_s] = jacg[t][o][:n_xin] Tz ,  jacs[t][o][n_s:] = jacg[t][o][n_xin:]
+__global__ __launch_bounds__(256) void sr_tz_jac_kernel(const double* __restrict__ jacg, const double* __restrict__ Tz,
+                                                        double* __restrict__ jacs, long T, int n_out, int n_s, int n_xin,
+                                                        int n_u) {
+    const int Ds = n_s + n_u, Dg = n_xin + n_u;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= T * n_out * Ds) return;
+    const long row = e / Ds;                              // (t, o)
+    const int c = (int)(e % Ds);
+    const double* g = jacg + row * Dg;
+    double v;
+    if (c < n_s) {
+        v = 0.0;
+        for (int i = 0; i < n_xin; ++i) v = fma(g[i], Tz[i * n_s + c], v);
+    } else {
+        v = g[n_xin + (c - n_s)];
+    }
+    jacs[e] = v;
+}
+
+extern "C" int sr_gp_set_input_transform(sr_gp_t h, const double* Tz, int n_x_in, void* stream) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_input_transform: NULL handle");
+    SR_DEVICE(h->device);
+    if (Tz == nullptr) { h->n_xin = 0; return SR_OK; }
+    SR_CHECK(n_x_in >= 1 && n_x_in < h->D, SR_EINVAL, "sr_gp_set_input_transform: n_x_in=%d with D=%d", n_x_in, h->D);
+    if (!h->Tz) SR_TRY(dev_alloc(&h->Tz, (size_t)SR_MAX_D * SR_MAX_NS));
+    SR_CHECK(h->n_out <= SR_MAX_NS, SR_EUNSUPPORTED, "sr_gp_set_input_transform: n_out=%d > %d", h->n_out, SR_MAX_NS);
+    SR_HIP(hipMemcpyAsync(h->Tz, Tz, sizeof(double) * n_x_in * h->n_out, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    h->n_xin = n_x_in;
+    return SR_OK;
+}
+
+static int ensure_tz(sr_gp* h, long Tc, int n_s, int n_u) {
+    if (h->n_xin == 0 || Tc <= h->tz_cap) return SR_OK;
+    (void)hipDeviceSynchronize();
+    dev_free(h->tz_x); dev_free(h->tz_jac);
+    h->tz_x = h->tz_jac = nullptr; h->tz_cap = 0;
+    SR_TRY(dev_alloc(&h->tz_x, (size_t)Tc * SR_MAX_D));
+    SR_TRY(dev_alloc(&h->tz_jac, (size_t)Tc * n_s * (n_s + n_u)));
+    h->tz_cap = Tc;
+    return SR_OK;
+}
+
+// GP posterior at the (possibly transformed) states p [ldp] and controls k_ff [ldkff]: mu, var into the given buffers,
+// the Jacobian with respect to [state; control] (T x n_s x (n_s + n_u)) behind *jac_out.
+static int gp_pass_states(sr_gp* h, long Tc, const double* p, long ldp, int n_s, const double* kff, long ldkff, int n_u,
+                          double* mu, double* var, const double** jac_out, hipStream_t s) {
+    if (h->n_xin == 0) {
+        *jac_out = h->jac;
+        return gp_pass(h, Tc, p, ldp, n_s, kff, ldkff, n_u, mu, var, h->jac, s);
+    }
+    SR_TRY(ensure_tz(h, Tc, n_s, n_u));
+    hipLaunchKernelGGL(sr_tz_apply_kernel, dim3((unsigned)((Tc * h->n_xin + 255) / 256)), dim3(256), 0, s, p, ldp, h->Tz,
+                       h->tz_x, Tc, n_s, h->n_xin);
+    SR_HIP(hipGetLastError());
+    SR_TRY(gp_pass(h, Tc, h->tz_x, h->n_xin, h->n_xin, kff, ldkff, n_u, mu, var, h->jac, s));
+    hipLaunchKernelGGL(sr_tz_jac_kernel, dim3((unsigned)((Tc * h->n_out * (n_s + n_u) + 255) / 256)), dim3(256), 0, s,
+                       h->jac, h->Tz, h->tz_jac, Tc, h->n_out, n_s, h->n_xin, n_u);
+    SR_HIP(hipGetLastError());
+    *jac_out = h->tz_jac;
+    return SR_OK;
+}
+
 static int check_reach_dims(const sr_gp* h, int* n_s, int* n_u) {
     *n_s = h->n_out;
-    *n_u = h->D - h->n_out;
+    *n_u = h->D - (h->n_xin ? h->n_xin : h->n_out);
     SR_CHECK(*n_u >= 1, SR_EINVAL, "reachability needs D = n_s + n_u with n_u >= 1 (D=%d, n_out=%d)",
              h->D, h->n_out);
     SR_CHECK(*n_s <= SR_MAX_NS && *n_u <= SR_MAX_NU, SR_EUNSUPPORTED,
@@ -1040,15 +1122,15 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
         // gp_pass may (re)allocate the workspace: resolve internal pointers after it
         SR_TRY(ensure_ws(h, round_up(Tc, srt::BN), pick_nsplit(h, round_up(Tc, srt::BN))));
         if (!var_dst) var_dst = h->var;
-        SR_TRY(gp_pass(h, Tc, p + t0 * n_s, n_s, n_s, k_ff + t0 * n_u, n_u, n_u, h->mu, var_dst,
-                       h->jac, s));
+        const double* jac_su = nullptr;
+        SR_TRY(gp_pass_states(h, Tc, p + t0 * n_s, n_s, n_s, k_ff + t0 * n_u, n_u, n_u, h->mu, var_dst, &jac_su, s));
         sr_ell_args ea;
         ea.T = Tc; ea.n_s = n_s; ea.n_u = n_u;
         ea.p = p + t0 * n_s; ea.ldp = n_s;
         ea.q = q ? q + t0 * n_s * n_s : nullptr; ea.ldq = (long)n_s * n_s;
         ea.k_ff = k_ff + t0 * n_u; ea.ldkff = n_u;
         ea.k_fb = k_fb ? k_fb + t0 * n_u * n_s : nullptr; ea.ldkfb = (long)n_u * n_s;
-        ea.mu = h->mu; ea.var = var_dst; ea.jac = h->jac;
+        ea.mu = h->mu; ea.var = var_dst; ea.jac = jac_su;
         ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
         ea.p_out = p_out + t0 * n_s; ea.ldpo = n_s;
         ea.q_out = q_out + t0 * n_s * n_s; ea.ldqo = (long)n_s * n_s;
@@ -1086,7 +1168,8 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
             }
             const double* kff_in = k_ff + (t0 * H + i) * n_u;
             const long ldkff = (long)H * n_u;
-            SR_TRY(gp_pass(h, Tc, p_in, ldp, n_s, kff_in, ldkff, n_u, h->mu, h->var, h->jac, s));
+            const double* jac_su = nullptr;
+            SR_TRY(gp_pass_states(h, Tc, p_in, ldp, n_s, kff_in, ldkff, n_u, h->mu, h->var, &jac_su, s));
             if (gp_var_all)
                 SR_HIP(hipMemcpy2DAsync(gp_var_all + (t0 * H + i) * n_s, sizeof(double) * H * n_s, h->var,
                                         sizeof(double) * n_s, sizeof(double) * n_s, Tc,
@@ -1095,7 +1178,7 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
             ea.T = Tc; ea.n_s = n_s; ea.n_u = n_u;
             ea.p = p_in; ea.ldp = ldp; ea.q = q_in; ea.ldq = ldq;
             ea.k_ff = kff_in; ea.ldkff = ldkff; ea.k_fb = kfb_in; ea.ldkfb = ldkfb;
-            ea.mu = h->mu; ea.var = h->var; ea.jac = h->jac;
+            ea.mu = h->mu; ea.var = h->var; ea.jac = jac_su;
             ea.a = a; ea.b = b; ea.l_mu = l_mu; ea.l_sigma = l_sigma; ea.c_safety = c_safety;
             ea.p_out = p_all + (t0 * H + i) * n_s; ea.ldpo = (long)H * n_s;
             ea.q_out = q_all + (t0 * H + i) * nss; ea.ldqo = (long)H * nss;

@@ -25,6 +25,38 @@ def _lin_model(a, b, n_s, n_u):
     return np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
 
 
+class _input_transform(object):
+    """``with _input_transform(ssm, t_z_gp):`` -- the GP is evaluated at t_z_gp @ state for the reachability calls
+    inside the block (gp_reachability_casadi.py:60-61,85,94-97); restored to the identity afterwards."""
+
+    def __init__(self, ssm, t_z_gp):
+        self.hd, self.t = ssm._handle, t_z_gp
+
+    def __enter__(self):
+        if self.t is not None:
+            hd = self.hd
+            t = np.asarray(self.t, dtype=np.float64)
+            if t.ndim != 2 or t.shape[1] != hd.n_out or not (1 <= t.shape[0] < hd.D):
+                raise ValueError("t_z_gp must be (n_x_in, {}) with n_x_in < D = {}".format(hd.n_out, hd.D))
+            self.dev_t = B.as_dev(t, hd.device)
+            check(lib.sr_gp_set_input_transform(hd.h, B.ptr(self.dev_t), int(t.shape[0]), B.stream_ptr(hd.device)))
+        return self
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            check(lib.sr_gp_set_input_transform(self.hd.h, None, 0, B.stream_ptr(self.hd.device)))
+        return False
+
+
+def _reach_dims(hd, t_z_gp):
+    """(n_s, n_u) of the reachability problem on this model: D = n_x_in + n_u with n_x_in = rows of t_z_gp"""
+    n_xin = hd.n_out if t_z_gp is None else int(np.shape(t_z_gp)[0])
+    if hd.D - n_xin < 1:
+        raise ValueError("the model has {} inputs for {} states: a GP input transform (t_z_gp / a_gp_inp_x, "
+                         "(n_x_in, n_s) with n_x_in < {}) is needed".format(hd.D, hd.n_out, hd.D))
+    return hd.n_out, hd.D - n_xin
+
+
 def _raise_if_bad(n_bad):
     if n_bad is not None and int(n_bad.item()) > 0:
         # the reference asserts inside ellipsoid_from_rectangle (utils_ellipsoid.py:226-228)
@@ -33,11 +65,13 @@ def _raise_if_bad(n_bad):
 
 
 def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None, k_fb=None,
-                               c_safety=1., a=None, b=None, check_bounds=False, return_var=False):
+                               c_safety=1., a=None, b=None, check_bounds=False, return_var=False, t_z_gp=None):
     """Batched ``onestep_reachability``.
 
     p_center (T,n_s); k_ff (T,n_u); q_shape (T,n_s,n_s) or None; k_fb (T,n_u,n_s) or None.
     numpy in -> numpy out, torch (device) in -> torch out.  Requires a HIP ``SimpleGPModel``.
+    t_z_gp (n_x_in, n_s): the GP's state inputs are t_z_gp @ state (the argument of the same name of
+    gp_reachability_casadi.onestep_reachability, :17-19,60-61); the model then has D = n_x_in + n_u inputs.
     Returns p_new (T,n_s), q_new (T,n_s,n_s) [, var (T,n_s)].
     """
     if not isinstance(ssm, SimpleGPModel):
@@ -46,7 +80,7 @@ def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None,
     hd = ssm._handle
     ssm._need_trained()
     dev = hd.device
-    n_s, n_u = hd.n_out, hd.D - hd.n_out
+    n_s, n_u = _reach_dims(hd, t_z_gp)
     p = B.as_dev(p_center, dev)
     T = p.shape[0]
     if p.dim() != 2 or p.shape[1] != n_s:
@@ -63,9 +97,10 @@ def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None,
     q_out = B.empty((T, n_s, n_s), dev)
     var = B.empty((T, n_s), dev) if return_var else None
     n_bad = B.zeros_i32(1, dev) if check_bounds else None
-    check(lib.sr_onestep_reach(hd.h, T, B.ptr(p), B.ptr(q), B.ptr(kff), B.ptr(kfb), B.ptr(ta),
-                               B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety), B.ptr(p_out),
-                               B.ptr(q_out), B.ptr(var), B.ptr(n_bad), B.stream_ptr(dev)))
+    with _input_transform(ssm, t_z_gp):
+        check(lib.sr_onestep_reach(hd.h, T, B.ptr(p), B.ptr(q), B.ptr(kff), B.ptr(kfb), B.ptr(ta),
+                                   B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety), B.ptr(p_out),
+                                   B.ptr(q_out), B.ptr(var), B.ptr(n_bad), B.stream_ptr(dev)))
     _raise_if_bad(n_bad)
     outs = (p_out, q_out, var) if return_var else (p_out, q_out)
     return outs if as_t else tuple(B.to_numpy(o) for o in outs)
@@ -102,7 +137,7 @@ def ellipsoid_step_batch(p_center, k_ff, mu, var, jac, l_mu, l_sigma, q_shape=No
 
 
 def onestep_reachability(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None, k_fb=None,
-                         c_safety=1., verbose=1, a=None, b=None):
+                         c_safety=1., verbose=1, a=None, b=None, t_z_gp=None):
     """Overapproximate the reachable set of states under the affine control law u = K(x-p) + k.
 
     Single-query semantics and argument order of gp_reachability.py:19-156.
@@ -122,11 +157,16 @@ def onestep_reachability(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None, k_fb=
     kfb_b = None if (k_fb is None or q_shape is None) else np.asarray(k_fb, dtype=np.float64)[None]
     if isinstance(ssm, SimpleGPModel):
         p1, q1 = onestep_reachability_batch(p_center.T, ssm, k_ff.T, l_mu, l_sigma, q_b, kfb_b,
-                                            c_safety, a, b, check_bounds=True)
+                                            c_safety, a, b, check_bounds=True, t_z_gp=t_z_gp)
     else:
-        out = ssm(p_center.T, k_ff.T)                  # (mu n x 1, sigma n x 1, jac n x D)
+        x_bar = p_center if t_z_gp is None else np.asarray(t_z_gp, dtype=np.float64).dot(p_center)
+        out = ssm(x_bar.T, k_ff.T)                     # (mu n x 1, sigma n x 1, jac n x D)
         mu_0, sigm_0 = np.array(out[0], dtype=np.float64), np.array(out[1], dtype=np.float64)
-        jac_mu = np.array(out[2], dtype=np.float64)[None] if q_shape is not None else None
+        jac_mu = np.array(out[2], dtype=np.float64) if q_shape is not None else None
+        if jac_mu is not None and t_z_gp is not None:   # chain rule through the constant input map
+            t = np.asarray(t_z_gp, dtype=np.float64)
+            jac_mu = np.hstack((jac_mu[:, :t.shape[0]].dot(t), jac_mu[:, t.shape[0]:]))
+        jac_mu = jac_mu[None] if jac_mu is not None else None
         p1, q1 = ellipsoid_step_batch(p_center.T, k_ff.T, mu_0.reshape(1, n_s), sigm_0.reshape(1, n_s),
                                       jac_mu, l_mu, l_sigma, q_b, kfb_b, c_safety, a, b,
                                       check_bounds=True)
@@ -137,7 +177,7 @@ def onestep_reachability(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None, k_fb=
 
 
 def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_safety=1., a=None,
-                                 b=None, k_fb_init=None, check_bounds=False):
+                                 b=None, k_fb_init=None, check_bounds=False, t_z_gp=None):
     """Batched ``multistep_reachability``: T independent trajectories, H sequential steps each.
 
     p_0 (T,n_s); k_fb (T,H-1,n_u,n_s); k_ff (T,H,n_u); q_0 (T,n_s,n_s) or None;
@@ -149,7 +189,7 @@ def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_
     as_t = B.is_tensor(p_0)
     hd = gp._handle
     dev = hd.device
-    n_s, n_u = hd.n_out, hd.D - hd.n_out
+    n_s, n_u = _reach_dims(hd, t_z_gp)
     p0 = B.as_dev(p_0, dev)
     T = p0.shape[0]
     kff = B.as_dev(k_ff, dev)
@@ -167,15 +207,16 @@ def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_
     p_all = B.empty((T, H, n_s), dev)
     q_all = B.empty((T, H, n_s, n_s), dev)
     n_bad = B.zeros_i32(1, dev) if check_bounds else None
-    check(lib.sr_multistep_reach(hd.h, T, H, B.ptr(p0), B.ptr(q0), B.ptr(kfb0), B.ptr(kff), B.ptr(kfb),
-                                 B.ptr(ta), B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety),
-                                 B.ptr(p_all), B.ptr(q_all), B.ptr(n_bad), B.stream_ptr(dev)))
+    with _input_transform(gp, t_z_gp):
+        check(lib.sr_multistep_reach(hd.h, T, H, B.ptr(p0), B.ptr(q0), B.ptr(kfb0), B.ptr(kff), B.ptr(kfb),
+                                     B.ptr(ta), B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety),
+                                     B.ptr(p_all), B.ptr(q_all), B.ptr(n_bad), B.stream_ptr(dev)))
     _raise_if_bad(n_bad)
     return (p_all, q_all) if as_t else (B.to_numpy(p_all), B.to_numpy(q_all))
 
 
 def multistep_reachability(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_safety=1., verbose=1,
-                           a=None, b=None, k_fb_init=None):
+                           a=None, b=None, k_fb_init=None, t_z_gp=None):
     """Ellipsoidal overapproximation after n actions (gp_reachability.py:159-212).
 
     p_0 (n_s,1); k_fb (n-1,n_u,n_s); k_ff (n,n_u).  Returns p_new (n_s,1), q_new (n_s,n_s),
@@ -190,17 +231,17 @@ def multistep_reachability(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_safety
         kfb0 = None if (k_fb_init is None or q_0 is None) else np.asarray(k_fb_init, dtype=np.float64)[None]
         p_all, q_all = multistep_reachability_batch(np.asarray(p_0, dtype=np.float64).reshape(1, n_s), gp,
                                                     k_fb[None], k_ff[None], L_mu, L_sigm, q0, c_safety,
-                                                    a, b, kfb0, check_bounds=True)
+                                                    a, b, kfb0, check_bounds=True, t_z_gp=t_z_gp)
         p_all, q_all = p_all[0], q_all[0]
     else:
         p_all = np.empty((n, n_s))
         q_all = np.empty((n, n_s, n_s))
         p_new, q_new = onestep_reachability(p_0, gp, k_ff[0, :, None], L_mu, L_sigm, q_0, k_fb_init,
-                                            c_safety, verbose, a, b)
+                                            c_safety, verbose, a, b, t_z_gp)
         p_all[0], q_all[0] = p_new.T, q_new
         for i in range(1, n):
             p_new, q_new = onestep_reachability(p_new, gp, k_ff[i, :, None], L_mu, L_sigm, q_new,
-                                                k_fb[i - 1], c_safety, verbose, a, b)
+                                                k_fb[i - 1], c_safety, verbose, a, b, t_z_gp)
             p_all[i], q_all[i] = p_new.T, q_new
     return p_all[-1][:, None].copy(), q_all[-1].copy(), p_all, q_all
 

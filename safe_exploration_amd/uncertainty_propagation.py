@@ -6,7 +6,8 @@ multi_step_taylor_symbolic :88-146, mean_equivalent_multistep :149-207, one_step
 :210-283) with the same argument orders.  The covariance algebra of both schemes collapses to
 ``Sigma_new = H Sigma H^T + diag(var)`` with ``H = a + J_x + (b + J_u) K`` (Taylor) or ``H = a + b K``
 (mean-equivalent); it runs in the same per-query kernel as the robust ellipsoid step.
-The input transform ``a_gp_inp_x`` of the reference is not supported (identity only).
+The input transform ``a_gp_inp_x`` of the reference (the GP sees ``a_gp_inp_x @ state``, :40-47,60) is supported:
+the state Jacobian is chain-ruled through the constant matrix.
 """
 import numpy as np
 
@@ -23,16 +24,17 @@ def _lin(a, b, n_s, n_u):
     return np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
 
 
-def multistep_moments_batch(mu_0, ssm, k_ff, k_fb, a=None, b=None, mode=TAYLOR):
-    """T trajectories x H steps.  mu_0 (T,n_s); k_ff (T,H,n_u); k_fb (T,H-1,n_u,n_s).
+def multistep_moments_batch(mu_0, ssm, k_ff, k_fb, a=None, b=None, mode=TAYLOR, a_gp_inp_x=None):
+    """T trajectories x H steps.  mu_0 (T,n_s); k_ff (T,H,n_u); k_fb (T,H-1,n_u,n_s); a_gp_inp_x (n_x_in,n_s) or None.
     Returns mu_all (T,H,n_s), sigma_all (T,H,n_s,n_s), gp_var_all (T,H,n_s)."""
+    from .gp_reachability import _input_transform, _reach_dims
     if not isinstance(ssm, SimpleGPModel):
         raise TypeError("multistep_moments_batch needs the HIP SimpleGPModel")
     ssm._need_trained()
     as_t = B.is_tensor(mu_0)
     hd = ssm._handle
     dev = hd.device
-    n_s, n_u = hd.n_out, hd.D - hd.n_out
+    n_s, n_u = _reach_dims(hd, a_gp_inp_x)
     m0 = B.as_dev(mu_0, dev)
     T = m0.shape[0]
     kff = B.as_dev(k_ff, dev)
@@ -44,8 +46,9 @@ def multistep_moments_batch(mu_0, ssm, k_ff, k_fb, a=None, b=None, mode=TAYLOR):
     ta, tb = B.const_dev(a, dev, (n_s, n_s)), B.const_dev(b, dev, (n_s, n_u))
     mu_all, sigma_all = B.empty((T, H, n_s), dev), B.empty((T, H, n_s, n_s), dev)
     var_all = B.empty((T, H, n_s), dev)
-    check(lib.sr_multistep_moments(hd.h, T, H, int(mode), B.ptr(m0), B.ptr(kff), B.ptr(kfb), B.ptr(ta), B.ptr(tb),
-                                   B.ptr(mu_all), B.ptr(sigma_all), B.ptr(var_all), B.stream_ptr(dev)))
+    with _input_transform(ssm, a_gp_inp_x):
+        check(lib.sr_multistep_moments(hd.h, T, H, int(mode), B.ptr(m0), B.ptr(kff), B.ptr(kfb), B.ptr(ta), B.ptr(tb),
+                                       B.ptr(mu_all), B.ptr(sigma_all), B.ptr(var_all), B.stream_ptr(dev)))
     outs = (mu_all, sigma_all, var_all)
     return outs if as_t else tuple(B.to_numpy(o) for o in outs)
 
@@ -75,14 +78,17 @@ def moment_step_batch(mu_x, k_ff, mu_g, var_g, jac_g, sigma_x=None, k_fb=None, a
 
 
 def _one_step(mu_x, ssm, k_ff, sigma_x, k_fb, a, b, a_gp_inp_x, mode):
-    if a_gp_inp_x is not None:
-        raise NotImplementedError("a_gp_inp_x (GP input transform) is not supported")
     mu_x = np.asarray(mu_x, dtype=np.float64)
     k_ff = np.asarray(k_ff, dtype=np.float64)
     n_s = mu_x.shape[0]
-    out = ssm(mu_x.T, k_ff.T)                          # (mu n x 1, var n x 1, jac n x D)
+    t = None if a_gp_inp_x is None else np.asarray(a_gp_inp_x, dtype=np.float64)
+    x_bar = mu_x if t is None else t.dot(mu_x)
+    out = ssm(x_bar.T, k_ff.T)                         # (mu n x 1, var n x 1, jac n x D)
     mu_g, var_g = np.asarray(out[0], dtype=np.float64), np.asarray(out[1], dtype=np.float64)
-    jac = np.asarray(out[2], dtype=np.float64)[None] if sigma_x is not None else None
+    jac = np.asarray(out[2], dtype=np.float64) if sigma_x is not None else None
+    if jac is not None and t is not None:              # chain rule through the constant input map (:60)
+        jac = np.hstack((jac[:, :t.shape[0]].dot(t), jac[:, t.shape[0]:]))
+    jac = jac[None] if jac is not None else None
     sx = None if sigma_x is None else np.asarray(sigma_x, dtype=np.float64)[None]
     kfb = None if sigma_x is None else np.asarray(k_fb, dtype=np.float64)[None]
     mu_new, sigma_new = moment_step_batch(mu_x.T, k_ff.T, mu_g.reshape(1, n_s), var_g.reshape(1, n_s), jac, sx,
@@ -104,21 +110,19 @@ def one_step_mean_equivalent(mu_x, ssm, k_ff, sigma_x=None, k_fb=None, a=None, b
 def _multi(mu_0, ssm, k_ff, k_fb, sigma_0, a, b, a_gp_inp_x, mode):
     if sigma_0 is not None:
         raise NotImplementedError("Still need  to do this")        # like the reference (:124, :170)
-    if a_gp_inp_x is not None:
-        raise NotImplementedError("a_gp_inp_x (GP input transform) is not supported")
     k_ff = np.asarray(k_ff, dtype=np.float64)
     T, n_u = k_ff.shape
     n_s = np.shape(mu_0)[0]
     kfb = np.asarray(k_fb, dtype=np.float64).reshape(T - 1, n_u, n_s)[None] if T > 1 else None
     if isinstance(ssm, SimpleGPModel):
         mu_all, sigma_all, var_all = multistep_moments_batch(np.asarray(mu_0, dtype=np.float64).reshape(1, n_s),
-                                                             ssm, k_ff[None], kfb, a, b, mode)
+                                                             ssm, k_ff[None], kfb, a, b, mode, a_gp_inp_x)
         return mu_all[0], sigma_all[0].reshape(T, n_s * n_s), var_all[0]
     one = one_step_taylor if mode == TAYLOR else one_step_mean_equivalent
-    mu_new, sigma_new, gv = one(mu_0, ssm, k_ff[0].reshape(n_u, 1), None, None, a, b)
+    mu_new, sigma_new, gv = one(mu_0, ssm, k_ff[0].reshape(n_u, 1), None, None, a, b, a_gp_inp_x)
     mus, sigmas, gvs = [mu_new.T], [sigma_new.reshape(1, -1)], [gv]
     for i in range(T - 1):
-        mu_new, sigma_new, gv = one(mu_new, ssm, k_ff[i + 1].reshape(n_u, 1), sigma_new, kfb[0, i], a, b)
+        mu_new, sigma_new, gv = one(mu_new, ssm, k_ff[i + 1].reshape(n_u, 1), sigma_new, kfb[0, i], a, b, a_gp_inp_x)
         mus.append(mu_new.T), sigmas.append(sigma_new.reshape(1, -1)), gvs.append(gv)
     return np.vstack(mus), np.vstack(sigmas), np.vstack(gvs)
 

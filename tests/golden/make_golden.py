@@ -299,6 +299,78 @@ def main():
     reach_case("reach_cart.npz", 202, 90, 4, 1, 16, 15, np.array([0.05] * 4), np.array([0.05] * 4), 2.0, a_scale=0.5, sf2=0.01)
     reach_case("reach_n3u2.npz", 203, 40, 3, 2, 8, 3, np.array([0.01] * 3), np.array([0.02] * 3), 1.5)
 
+    # ------------------------------------------------------------------ 4a'. GP input transform (t_z_gp / a_gp_inp_x)
+    # gp_reachability_casadi.onestep_reachability(..., t_z_gp) (:60-61,85,94-97) evaluates the GP at t_z_gp @ state and
+    # chain-rules its state Jacobian; with the SSM wrapped accordingly the reference's NUMERIC onestep/multistep functions
+    # compute exactly that (H = a + jac[:, :n_in] T + (jac[:, n_in:] + b) K).  The journal cart-pole configuration drops
+    # the cart position (defaultconfig_episode.py:28,44): n_s = 4, n_x_in = 3, D = 4.  The moment propagation takes
+    # a_gp_inp_x directly (uncertainty_propagation_casadi.py:40-47,60).
+    def tz_case(name, seed, N, n_s, n_xin, n_u, T, H, tz, l_mu, l_sigma, c_safety, a_scale):
+        rng = np.random.default_rng(seed)
+        Dg = n_xin + n_u
+        Z = rng.uniform(-1, 1, (N, Dg))
+        Wd = rng.standard_normal((n_s, Dg))
+        sf2 = 0.01
+        Y = np.sqrt(sf2) * (np.sin(2.0 * Z.dot(Wd.T)) + 0.05 * rng.standard_normal((N, n_s)))
+        ls = rng.uniform(0.5, 1.5, (n_s, Dg))
+        signal_var = np.full(n_s, sf2)
+        noise_var = np.full(n_s, 1e-2 * sf2 + 1e-5)
+        beta, inv_K, _ = orc.gp_fit(Z, Y, ls, signal_var, noise_var)
+        model = dict(Z=Z, beta=beta, inv_K=inv_K, lengthscale=ls, signal_var=signal_var)
+        a_lin = a_scale * np.eye(n_s) + 0.05 * rng.standard_normal((n_s, n_s))
+        b_lin = 0.1 * rng.standard_normal((n_s, n_u))
+        p = 0.3 * rng.standard_normal((T, n_s))
+        k_ff = 0.1 * rng.standard_normal((T, n_u))
+        k_fb = 0.1 * rng.standard_normal((T, n_u, n_s))
+        A = rng.standard_normal((T, n_s, n_s))
+        Q = 0.01 * np.einsum('tij,tkj->tik', A, A) + 0.01 * np.eye(n_s)[None]
+
+        def ssm_full(states, actions):        # full state in, GP evaluated at tz @ state, Jacobian w.r.t. [state; action]
+            x = tz.dot(np.asarray(states)[0])
+            m, v, j = orc._predict_one(model, np.hstack((x, np.asarray(actions)[0])))
+            return m[:, None], v[:, None], np.hstack((j[:, :n_xin].dot(tz), j[:, n_xin:]))
+
+        def ssm_gp(states, actions):          # what the casadi-side functions call: the GP on its own inputs
+            m, v, j = orc._predict_one(model, np.hstack((np.asarray(states)[0], np.asarray(actions)[0])))
+            return m[:, None], v[:, None], j
+
+        res = dict(Z=Z, Y=Y, lengthscale=ls, signal_var=signal_var, noise_var=noise_var, tz=tz, p=p, k_ff=k_ff, k_fb=k_fb,
+                   Q=Q, a_lin=a_lin, b_lin=b_lin, l_mu=l_mu, l_sigma=l_sigma, c_safety=c_safety)
+        p1_pt = np.empty((T, n_s)); q1_pt = np.empty((T, n_s, n_s)); p1_el = np.empty((T, n_s)); q1_el = np.empty((T, n_s, n_s))
+        for t in range(T):
+            pp, qq = gr.onestep_reachability(p[t][:, None], ssm_full, k_ff[t][:, None], l_mu, l_sigma, None, None,
+                                             c_safety, 0, a_lin, b_lin)
+            p1_pt[t], q1_pt[t] = pp[:, 0], qq
+            pp, qq = gr.onestep_reachability(p[t][:, None], ssm_full, k_ff[t][:, None], l_mu, l_sigma, Q[t], k_fb[t],
+                                             c_safety, 0, a_lin, b_lin)
+            assert np.all(np.imag(qq) == 0)
+            p1_el[t], q1_el[t] = pp[:, 0], np.real(qq)
+        res.update(p1_point=p1_pt, q1_point=q1_pt, p1_ell=p1_el, q1_ell=q1_el)
+        Tm = min(T, 5)
+        k_fb_m = 0.1 * rng.standard_normal((Tm, H - 1, n_u, n_s))
+        k_ff_m = 0.1 * rng.standard_normal((Tm, H, n_u))
+        p0_m = 0.1 * rng.standard_normal((Tm, n_s))
+        p_all = np.empty((Tm, H, n_s)); q_all = np.empty((Tm, H, n_s, n_s))
+        for t in range(Tm):
+            _, _, pa, qa = gr.multistep_reachability(p0_m[t][:, None], ssm_full, k_fb_m[t], k_ff_m[t], l_mu, l_sigma, None,
+                                                     c_safety, 0, a_lin, b_lin, None)
+            p_all[t], q_all[t] = pa, qa
+        assert np.all(np.isfinite(q_all)), "chain diverged"
+        res.update(ms_k_fb=k_fb_m, ms_k_ff=k_ff_m, ms_p0=p0_m, ms_p_all=p_all, ms_q_all=q_all)
+        # moment propagation through the reference's own builders with a_gp_inp_x = tz
+        for tag, fn in (("taylor", ref_prop.multi_step_taylor_symbolic), ("meaneq", ref_prop.mean_equivalent_multistep)):
+            mu_all = np.empty((Tm, H, n_s)); sig_all = np.empty((Tm, H, n_s, n_s))
+            for t in range(Tm):
+                m_, s_, _ = fn(p0_m[t][:, None], ssm_gp, k_ff_m[t], list(k_fb_m[t]), None, a_lin, b_lin, tz)
+                mu_all[t], sig_all[t] = np.asarray(m_), np.asarray(s_).reshape(H, n_s, n_s)
+            res["mu_" + tag], res["sigma_" + tag] = mu_all, sig_all
+        _save(name, **res)
+
+    tz_case("reach_tz_cart.npz", 271, 70, 4, 3, 1, 10, 8, np.hstack((np.zeros((3, 1)), np.eye(3))),
+            np.array([0.05] * 4), np.array([0.05] * 4), 2.0, 0.5)
+    tz_case("reach_tz_n3.npz", 272, 50, 3, 2, 2, 6, 4, np.random.default_rng(5).standard_normal((2, 3)) * 0.7,
+            np.array([0.01] * 3), np.array([0.02] * 3), 1.5, 0.6)
+
     # ------------------------------------------------------------------ 4b. the reference tests' canonical scenarios
     # on the reference's OWN data files (copied as data: tests/golden/ref_invpend_data.npz = test/invpend_data.npz,
     # ref_data_cartpole.npz = test/data_cartpole.npz).  test_gp_reachability_casadi.py:30-67: seed 125, m = 50 random

@@ -655,7 +655,7 @@ def test_moment_propagation_vs_reference_golden(name, n_s, n_u):
     mu_me, sig_me, _ = prop.mean_equivalent_multistep(g["mu0"][1][:, None], gp, g["k_ff"][1], list(g["k_fb"][1]),
                                                       None, g["a_lin"], g["b_lin"])
     np.testing.assert_allclose(mu_me, g["mu_meaneq"][1], rtol=1e-8, atol=1e-11)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):       # sigma_0 is "Still need to do this" in the reference too (:124)
         prop.multi_step_taylor(g["mu0"][0][:, None], gp, g["k_ff"][0], list(g["k_fb"][0]), np.eye(n_s))
     # one step with a foreign StateSpaceModel (GP outputs computed on the host by the caller)
     om = oracle_model(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"])
@@ -1164,3 +1164,59 @@ def test_fused_stream_path_under_changing_inputs(N, n_s, n_u):
             gp.predict_device(tX[100 + q:101 + q], True)
             for a_, b_, tol in zip(out, refs[q], (1e-12 * scale, 2e-11, 1e-11 * scale, 1e-9, 1e-10 * scale)):
                 np.testing.assert_allclose(a_, b_, rtol=1e-8, atol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_s,n_xin,n_u", [("reach_tz_cart.npz", 4, 3, 1), ("reach_tz_n3.npz", 3, 2, 2)])
+def test_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
+    """t_z_gp / a_gp_inp_x (gp_reachability_casadi.py:60-61,85,94-97; uncertainty_propagation_casadi.py:40-47,60): the GP
+    sees t_z_gp @ state -- the journal cart-pole configuration drops the cart position (n_s = 4, D = 4).  Fixtures: the
+    reference's numeric onestep / multistep functions on the wrapped model and its moment-propagation builders with
+    a_gp_inp_x, both evaluated in the build container (tests/golden/make_golden.py, tz_case)."""
+    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, uncertainty_propagation as prop
+    g = load_golden(name)
+    tz = g["tz"]
+    gp = SimpleGPModel(n_s, n_xin, n_u, kern_types=["rbf"] * n_s,
+                       hyp=hyp_from(g["lengthscale"], g["signal_var"], g["noise_var"]))
+    gp.train(g["Z"], g["Y"], opt_hyp=False)
+    c = float(g["c_safety"])
+    p1, q1 = reach.onestep_reachability_batch(g["p"], gp, g["k_ff"], g["l_mu"], g["l_sigma"], None, None, c,
+                                              g["a_lin"], g["b_lin"], t_z_gp=tz)
+    np.testing.assert_allclose(p1, g["p1_point"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(q1, g["q1_point"], rtol=1e-7, atol=1e-14)
+    p1, q1 = reach.onestep_reachability_batch(g["p"], gp, g["k_ff"], g["l_mu"], g["l_sigma"], g["Q"], g["k_fb"], c,
+                                              g["a_lin"], g["b_lin"], t_z_gp=tz)
+    np.testing.assert_allclose(p1, g["p1_ell"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(q1, g["q1_ell"], rtol=1e-7, atol=1e-14)
+    pa, qa = reach.multistep_reachability_batch(g["ms_p0"], gp, g["ms_k_fb"], g["ms_k_ff"], g["l_mu"], g["l_sigma"], None,
+                                                c, g["a_lin"], g["b_lin"], t_z_gp=tz)
+    np.testing.assert_allclose(pa, g["ms_p_all"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(qa, g["ms_q_all"], rtol=1e-6, atol=1e-13)
+    # the transform is per call: the next call without it sees the identity again (and complains about the shapes)
+    with pytest.raises((ValueError, RuntimeError)):
+        reach.onestep_reachability_batch(g["p"], gp, g["k_ff"], g["l_mu"], g["l_sigma"], None, None, c)
+    # single-query surface, HIP model and a foreign state-space model (GP on its own inputs, chain rule on the host)
+    om = oracle_model(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"])
+
+    def ssm(st, ac):
+        m_, v_, j_ = orc._predict_one(om, np.hstack((st, ac))[0])
+        return m_[:, None], v_[:, None], j_
+    for model in (gp, ssm):
+        pp, qq = reach.onestep_reachability(g["p"][1][:, None], model, g["k_ff"][1][:, None], g["l_mu"], g["l_sigma"],
+                                            g["Q"][1], g["k_fb"][1], c, 0, g["a_lin"], g["b_lin"], tz)
+        np.testing.assert_allclose(pp[:, 0], g["p1_ell"][1], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(qq, g["q1_ell"][1], rtol=1e-7, atol=1e-14)
+    # Gaussian moment propagation with a_gp_inp_x
+    for tag, mode in (("taylor", prop.TAYLOR), ("meaneq", prop.MEAN_EQUIVALENT)):
+        mu, sig, _ = prop.multistep_moments_batch(g["ms_p0"], gp, g["ms_k_ff"], g["ms_k_fb"], g["a_lin"], g["b_lin"], mode,
+                                                  a_gp_inp_x=tz)
+        np.testing.assert_allclose(mu, g["mu_" + tag], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(sig, g["sigma_" + tag], rtol=1e-7, atol=1e-13)
+    H = g["ms_k_ff"].shape[1]
+    mu_all, sigma_all, _ = prop.multi_step_taylor(g["ms_p0"][0][:, None], gp, g["ms_k_ff"][0], list(g["ms_k_fb"][0]), None,
+                                                  g["a_lin"], g["b_lin"], tz)
+    np.testing.assert_allclose(sigma_all.reshape(H, n_s, n_s), g["sigma_taylor"][0], rtol=1e-7, atol=1e-13)
+    mu_f, sig_f, _ = prop.multi_step_taylor(g["ms_p0"][0][:, None], ssm, g["ms_k_ff"][0], list(g["ms_k_fb"][0]), None,
+                                            g["a_lin"], g["b_lin"], tz)
+    np.testing.assert_allclose(mu_f, g["mu_taylor"][0], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(sig_f.reshape(H, n_s, n_s), g["sigma_taylor"][0], rtol=1e-7, atol=1e-13)

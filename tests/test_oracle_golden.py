@@ -399,3 +399,21 @@ def test_marginal_likelihood_gradient_vs_finite_differences(kt):
         kern = ConstantKernel(float(hyp["variance"]), "fixed") * RBF(hyp["lengthscale"], "fixed")
         gpr = GaussianProcessRegressor(kern, alpha=nv + orc.GPY_JITTER, optimizer=None).fit(Z, y)
         assert abs(-gpr.log_marginal_likelihood_value_ - nll) < 1e-9 * abs(nll)
+
+
+@pytest.mark.parametrize("name,n_s,n_xin,n_u", [("reach_tz_cart.npz", 4, 3, 1), ("reach_tz_n3.npz", 3, 2, 2)])
+def test_oracle_with_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
+    """the oracle's ellipsoid step fed with the GP outputs at t_z_gp @ state and the chain-ruled Jacobian reproduces
+    what the reference's numeric functions return for the wrapped model (fixtures of make_golden.py, tz_case)."""
+    g = load_golden(name)
+    tz = g["tz"]
+    beta, inv_K, _ = orc.gp_fit(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"])
+    model = dict(Z=g["Z"], beta=beta, inv_K=inv_K, lengthscale=g["lengthscale"], signal_var=g["signal_var"])
+    for t in range(g["p"].shape[0]):
+        z = np.hstack((tz.dot(g["p"][t]), g["k_ff"][t]))
+        mu, var, jac = orc._predict_one(model, z)
+        jac = np.hstack((jac[:, :n_xin].dot(tz), jac[:, n_xin:]))
+        p1, q1 = orc.onestep_reachability_from_gp(g["p"][t], g["Q"][t], g["k_ff"][t], g["k_fb"][t], mu, var, jac,
+                                                  g["l_mu"], g["l_sigma"], float(g["c_safety"]), g["a_lin"], g["b_lin"])
+        np.testing.assert_allclose(p1, g["p1_ell"][t], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(q1, g["q1_ell"][t], rtol=1e-10, atol=1e-16)
