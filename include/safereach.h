@@ -88,6 +88,9 @@ int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void*
  * columns are at the FRONT (identity block): training point i has padded index i + (Np - N). */
 int sr_gp_padded_n(sr_gp_t h, long* Np);
 
+/* current shape of the model: training points, input dimension, outputs, padded size (any pointer may be NULL) */
+int sr_gp_dims(sr_gp_t h, int* N, int* D, int* n_out, long* Np);
+
 /* Export / import the cached posterior state (what a broadcast receiver needs):
  * alpha n_out x N ; Wt n_out x Np x Np = U^-1 (upper triangular, row-major, zero below the diagonal).
  * Either pointer may be NULL.  import marks the handle as factorized. */
@@ -248,6 +251,8 @@ int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, l
 int sr_prof_enable(sr_gp_t h, int on);
 int sr_prof_reset (sr_gp_t h);
 int sr_prof_get   (sr_gp_t h, int kernel_id, double* ms_total, long* launches);
+
+/* model replication over RCCL for hosts without PyTorch: include/safereach_comm.h (libsafereach_comm.so) */
 
 #ifdef __cplusplus
 }

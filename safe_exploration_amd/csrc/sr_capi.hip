@@ -203,6 +203,15 @@ extern "C" int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* 
     return SR_OK;
 }
 
+extern "C" int sr_gp_dims(sr_gp_t h, int* N, int* D, int* n_out, long* Np) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_dims: NULL handle");
+    if (N) *N = h->N;
+    if (D) *D = h->D;
+    if (n_out) *n_out = h->n_out;
+    if (Np) *Np = h->Np;
+    return SR_OK;
+}
+
 extern "C" int sr_gp_padded_n(sr_gp_t h, long* Np) {
     SR_CHECK(h && Np, SR_EINVAL, "sr_gp_padded_n: NULL argument");
     *Np = h->Np;

@@ -690,6 +690,31 @@ def test_c_abi_from_plain_hip_program(lib_built):
     assert "capi_demo OK" in res.stdout
 
 
+def test_rccl_replication_from_plain_hip_program(lib_built):
+    """libsafereach_comm.so (sr_comm_init_all / sr_comm_bcast / sr_comm_destroy): examples/comm_demo.cpp factorises on
+    device 0, broadcasts alpha and U^-1 over RCCL to every other visible device of the process, shards the queries and
+    compares the gathered result with device 0's.  On a one-GPU box the communicator has a single rank."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    libdir = os.path.join(ROOT, "safe_exploration_amd")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    assert os.path.exists(os.path.join(libdir, "libsafereach_comm.so"))
+    exe = os.path.join(tempfile.mkdtemp(), "comm_demo")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "examples", "comm_demo.cpp"),
+           "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-lsafereach", "-lsafereach_comm", "-Wl,-rpath," + libdir,
+           "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "comm_demo OK" in res.stdout
+
+
 @pytest.mark.parametrize("n_s,n_u", [(1, 1), (1, 3), (3, 1), (5, 4), (6, 2), (7, 1), (8, 3), (8, 4)])
 def test_all_state_action_dimensions(n_s, n_u):
     """every (n_s, n_u) template instance of the ellipsoid kernel (Jacobi eigen-solver for n_s >= 3) and the

@@ -23,6 +23,23 @@ def test_library_exports_every_declared_symbol(lib_built):
     assert _lib.lib.sr_version() >= 100
 
 
+def test_comm_library_exports_every_declared_symbol(lib_built):
+    """include/safereach_comm.h <-> libsafereach_comm.so (RCCL replication for torch-free hosts); load only, no calls"""
+    import ctypes
+    header = open(os.path.join(ROOT, "include", "safereach_comm.h")).read()
+    declared = set(re.findall(r"\b(sr_comm_[a-z_0-9]+)\s*\(", header))
+    assert declared == {"sr_comm_init_all", "sr_comm_bcast", "sr_comm_destroy", "sr_comm_last_error"}
+    from safe_exploration_amd import _lib  # noqa: F401  (loads torch's HIP runtime and libsafereach.so first)
+    path = os.path.join(ROOT, "safe_exploration_amd", "libsafereach_comm.so")
+    assert os.path.exists(path), "make -C safe_exploration_amd/csrc builds it"
+    try:
+        comm = ctypes.CDLL(path)
+    except OSError as exc:
+        pytest.skip("librccl.so not loadable here: %s" % exc)
+    for name in sorted(declared):
+        assert hasattr(comm, name), "libsafereach_comm.so does not export %s" % name
+
+
 def test_no_gpu_fails_loudly(lib_built):
     import torch
     if torch.cuda.is_available():
