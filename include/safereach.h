@@ -222,8 +222,9 @@ int sr_gp_sample(int device, long T, int size, int n_out, int n_u, const double*
 int sr_gp_set_chunk(sr_gp_t h, long chunk);
 /* query tiles per scheduling group of the variance kernel (L2/XCD locality knob); default 32. */
 int sr_gp_set_var_group(sr_gp_t h, int group);
-/* tile staging of the variance kernel: 0 = register-staged (global->VGPR->LDS), 1 = LDS-DMA
- * (global_load_lds_dwordx4, default).  Same results bit for bit; a measurement knob. */
+/* main loop of the variance kernel: 0 = register-staged tiles (global->VGPR->LDS), 1 = LDS-DMA tiles
+ * (global_load_lds_dwordx4; same results as 0 bit for bit), 2 = 1 with the structural zeros of the diagonal blocks
+ * of U^-1 left out (default; same numbers summed in another order: equal to 1e-13).  A measurement knob. */
 int sr_gp_set_var_variant(sr_gp_t h, int variant);
 /* blocks of 128 rows per Cholesky panel of sr_gp_factorize (the trailing matrix is read-modify-written once per
  * panel); 0 = chosen by size (default).  Results agree to rounding; a measurement knob. */

@@ -132,7 +132,21 @@ __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long l
 // tile about to be read, and frees the other stage for the next DMA.
 #define SRT_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
 #define SRT_AS3(p) ((__attribute__((address_space(3))) void*)(p))
-template <int BKT>
+// DIAG: the LAST 128 k of the range multiply a diagonal block of an upper-triangular A (A[k][m] == 0 for k > m inside
+// the block).  In 16 x 16 sub-blocks only the pairs (k-tile kt <= row tile it) carry numbers -- 36 of 64 -- and the plain
+// loop spends a full MFMA on each of the other 28 (2.6 % of all MFMAs of the triangular contraction at N = 5000).  With
+// DIAG the two wavefront rows own INTERLEAVED row tiles (wm = 0: it = 0, 2, 4, 6; wm = 1: it = 1, 3, 5, 7) instead of
+// the upper and the lower half, so that both lose work at the same pace (16 resp. 20 of 32 pairs each), and the eight
+// diagonal k-tiles run fully unrolled with the row tiles kt > it left out at compile time.  A workgroup advances at the
+// pace of its slower wavefront row: 20 / 32 of the diagonal block's time.  (Skipping with the half / half assignment --
+// 10 resp. 26 of 32 -- buys nothing: measured in round 1.)  Callers must use acc_row_ilv for the row of an accumulator.
+// Measured at C2' (N = 5000, 65536 queries): 69.8 -> 70.05 TFLOP/s, a quarter of the 1.8 % the MFMA count promises:
+// a k-tile with 16 .. 48 MFMAs instead of 64 no longer covers the latency of the next tile's LDS-DMA.
+__device__ __forceinline__ int acc_row_ilv(int wm, int mi, int lane, int r) {
+    return (2 * mi + wm) * 16 + (lane >> 4) + 4 * r;
+}
+
+template <int BKT, bool DIAG = false>
 __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb,
                                                  int k_beg, int k_end, double* smem, Acc& acc) {
@@ -162,10 +176,16 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
     } while (0)
 
     SRT_DMA(k_beg, 0);
-    const int fa = (lane >> 4) * LDT + wm * 64 + (lane & 15);
+    // A-fragment of row tile mi: columns (rows of the product) wm*64 + mi*16 .. , or (2 mi + wm)*16 .. when interleaved
+    const int fa = (lane >> 4) * LDT + (DIAG ? wm * 16 : wm * 64) + (lane & 15);
+    constexpr int FAS = DIAG ? 32 : 16;        // distance of consecutive row tiles of one wavefront
     const int fb = (lane >> 4) * LDT + wn * 64 + (lane & 15);
     int buf = 0;
-    for (int k0 = k_beg; k0 < k_end; k0 += BKT) {
+    // the masked walk needs the whole diagonal block inside the range (not so only for row block 0 of a padded model:
+    // the plain loop multiplies its few zeros)
+    const bool diag = DIAG && k_end - 128 >= k_beg;
+    const int k_gen_end = diag ? k_end - 128 : k_end;                 // [k_beg, k_gen_end): all row tiles
+    for (int k0 = k_beg; k0 < k_gen_end; k0 += BKT) {
         __syncthreads();                       // vmcnt(0) + s_barrier: tile k0 landed, other stage is free
         if (k0 + BKT < k_end) SRT_DMA(k0 + BKT, buf ^ 1);
         const double* as = As + buf * STG + fa;
@@ -175,7 +195,7 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
             double af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                af[i] = as[kk * 4 * LDT + i * 16];
+                af[i] = as[kk * 4 * LDT + i * FAS];
                 bf[i] = bs[kk * 4 * LDT + i * 16];
             }
 #pragma unroll
@@ -185,6 +205,43 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
                     acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0);
         }
         buf ^= 1;
+    }
+    if (diag) {
+        static_assert(!DIAG || BKT == 16, "the diagonal block is walked in k-tiles of 16");
+        int kd = k_end - 128;                  // first k of the diagonal block
+        // k-tile kt of the block: row tile it = 2 mi + wm carries numbers iff it >= kt.  Both wavefront rows use the
+        // SAME live set mi >= kt / 2 (exact for wm = 1, one 16 x 16 block of zeros too many per odd kt for wm = 0):
+        // the workgroup moves at the pace of wm = 1 anyway, and one straight-line body keeps the register allocator
+        // out of trouble (a wavefront-uniform branch over two exact copies spilled 500 VGPRs).
+#define SRT_DIAG_BODY                                                                                \
+        _Pragma("unroll") for (int kt = 0; kt < 8; ++kt) {                                           \
+            __syncthreads();                                                                         \
+            if (kt < 7) {                                                                            \
+                kd += 16;                                                                            \
+                asm volatile("" : "+s"(kd));   /* one running k: no table of 8 x 8 precomputed addresses (spills) */ \
+                SRT_DMA(kd, buf ^ 1);                                                                \
+            }                                                                                        \
+            const double* as = As + buf * STG + fa;                                                  \
+            const double* bs = Bs + buf * STG + fb;                                                  \
+            const int MI0 = kt >> 1;       /* first live row tile */                                    \
+            if (MI0 < 4) {                                                                           \
+                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                   \
+                    double af[4], bf[4];                                                             \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
+                        if (i >= MI0) af[i] = as[kk * 4 * LDT + i * FAS];                            \
+                        bf[i] = bs[kk * 4 * LDT + i * 16];                                           \
+                    }                                                                                \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                    \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
+                            if (i >= MI0)                                                            \
+                                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0); \
+                    __builtin_amdgcn_sched_barrier(0);   /* later k-steps' reads stay behind (else spills) */ \
+                }                                                                                    \
+            }                                                                                        \
+            buf ^= 1;                                                                                \
+        }
+        SRT_DIAG_BODY
+#undef SRT_DIAG_BODY
     }
     __syncthreads();                           // callers reuse smem after the main loop
 #undef SRT_DMA
