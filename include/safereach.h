@@ -233,6 +233,11 @@ int sr_gp_set_fact_panel(sr_gp_t h, int panel);
  * HBM-bound streaming of U^-1 for batches of <= 16 queries, 64 x 64 tiles, split-K.  on = 1 (default) all
  * of them, 2 all but the one-launch pass, 0 none; an A/B measurement knob.  Results agree to rounding. */
 int sr_gp_set_small_path(sr_gp_t h, int on);
+/* multi-step chains (sr_multistep_reach / sr_multistep_moments) of small ARD-RBF models (Np <= 512, <= 4096 rollouts,
+ * the reference's systems n_s <= 4) run all H steps inside ONE persistent launch; on = 0 forces the per-step launches.
+ * Default on; results agree to rounding.  sr_gp_last_chain: 1 if the last chain took the persistent kernel. */
+int sr_gp_set_chain(sr_gp_t h, int on);
+int sr_gp_last_chain(sr_gp_t h);
 /* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
  * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.
  * Exposed so the fp64-MFMA tile can be tested in isolation. */

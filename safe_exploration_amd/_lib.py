@@ -69,6 +69,8 @@ SIGNATURES = {
     "sr_gp_set_chunk": (_I, [_H, _L]),
     "sr_gp_set_var_group": (_I, [_H, _I]),
     "sr_gp_set_var_variant": (_I, [_H, _I]),
+    "sr_gp_set_chain": (_I, [_H, _I]),
+    "sr_gp_last_chain": (_I, [_H]),
     "sr_gp_set_small_path": (_I, [_H, _I]),
     "sr_gp_set_fact_panel": (_I, [_H, _I]),
     "sr_test_gemm_tn": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),

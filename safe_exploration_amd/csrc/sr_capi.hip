@@ -24,6 +24,10 @@ struct sr_gp {
     // GP input transform of the reachability / moment entry points: x_gp = Tz x (Tz n_xin x n_s), NULL = identity
     double* Tz = nullptr; int n_xin = 0;
     double *tz_x = nullptr, *tz_jac = nullptr; long tz_cap = 0;   // transformed inputs / chain-ruled Jacobians (per chunk)
+    // persistent multi-step kernel (sr_small.hip K0c): exchange buffer, group tickets (all of the first chain_valid
+    // groups stand at chain_base), switch
+    double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;
+    unsigned long long chain_base = 0; int chain_valid = 0; int chain = 1; int last_chain = 0;
     int general = 0;
     int have_data = 0, factorized = 0;
     // per-chunk workspace (grow-only)
@@ -140,6 +144,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
+    dev_free(h->chain_xch); dev_free(h->chain_tickets);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (int d = 0; d < SR_FACT_SLOTS; ++d) {
@@ -1161,6 +1166,41 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
     SR_TRY(check_reach_dims(h, &n_s, &n_u));
     SR_DEVICE(h->device);
     const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
+    h->last_chain = 0;
+    if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 && H >= 2 &&
+        T <= SR_CHAIN_MAX_T && sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
+        // small model, few rollouts: the whole chain in one launch per SR_CHAIN_GROUPS workgroups (sr_small.hip K0c)
+        const int gmax = SR_CHAIN_GROUPS / n_s;                         // groups of 16 rollouts per launch
+        if (!h->chain_xch) {
+            SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_GROUPS * 2 * SR_SMALL_T * (SR_MAX_D + 2)));
+            SR_TRY(dev_alloc(&h->chain_tickets, (size_t)SR_CHAIN_GROUPS));
+            h->chain_valid = 0;
+        }
+        sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
+        for (long t0 = 0; t0 < T; t0 += (long)gmax * SR_SMALL_T) {
+            const long Tc = std::min((long)gmax * SR_SMALL_T, T - t0);
+            const int groups = (int)((Tc + SR_SMALL_T - 1) / SR_SMALL_T);
+            if (groups > h->chain_valid) {
+                SR_HIP(hipMemsetAsync(h->chain_tickets, 0, sizeof(unsigned long long) * SR_CHAIN_GROUPS, s));
+                h->chain_base = 0; h->chain_valid = SR_CHAIN_GROUPS;
+            }
+            sr_chain_args ca{};
+            ca.k.Z = h->Z; ca.k.alpha = h->alpha; ca.k.ls = h->ls; ca.k.sf2 = h->sf2;
+            ca.k.N = h->N; ca.k.Np = h->Np; ca.k.D = h->D; ca.k.n_out = h->n_out; ca.k.na = n_s; ca.k.nb = n_u;
+            ca.Wt = h->Wt; ca.T = Tc; ca.H = H; ca.mode = mode;
+            ca.p0 = p0 + t0 * n_s; ca.q0 = q0 ? q0 + t0 * nss : nullptr; ca.k_fb0 = k_fb0 ? k_fb0 + t0 * nus : nullptr;
+            ca.k_ff = k_ff + t0 * H * n_u; ca.k_fb = k_fb ? k_fb + t0 * (H - 1) * nus : nullptr;
+            ca.a = a; ca.b = b; ca.l_mu = l_mu; ca.l_sigma = l_sigma; ca.c_safety = c_safety;
+            ca.p_all = p_all + t0 * H * n_s; ca.q_all = q_all + t0 * H * nss;
+            ca.gp_var_all = gp_var_all ? gp_var_all + t0 * H * n_s : nullptr;
+            ca.n_bad = n_bad; ca.xch = h->chain_xch; ca.tickets = h->chain_tickets; ca.base = h->chain_base;
+            SR_TRY(sr_launch_chain(ca, s));
+            h->chain_base += (unsigned long long)n_s * H;
+            h->chain_valid = groups;
+        }
+        h->last_chain = 1;
+        return SR_OK;
+    }
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
         SR_TRY(ensure_ws(h, round_up(Tc, srt::BN), pick_nsplit(h, round_up(Tc, srt::BN))));
@@ -1330,6 +1370,14 @@ extern "C" int sr_gp_set_var_group(sr_gp_t h, int group) {
     h->var_group = group;
     return SR_OK;
 }
+
+extern "C" int sr_gp_set_chain(sr_gp_t h, int on) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_chain: NULL handle");
+    h->chain = on != 0;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_last_chain(sr_gp_t h) { return h ? h->last_chain : 0; }
 
 extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_small_path: NULL handle");

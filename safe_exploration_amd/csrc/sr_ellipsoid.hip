@@ -10,266 +10,13 @@
 //   /root/reference/safe_exploration/utils_ellipsoid.py:63-94, 197-233
 //   /root/reference/safe_exploration/gp_reachability.py:215-250 (lin_ellipsoid_safety_distance)
 #include "sr_common.h"
-
-// largest eigenvalue of Q * B, Q symmetric PSD, B = I + K^T K SPD.
-// eig(Q B) == eig(L^T Q L) with B = L L^T (similarity by L^T); the latter is symmetric, so a cyclic
-// Jacobi iteration gives all eigenvalues to full fp64 accuracy.  The reference calls
-// scipy.linalg.eig on the non-symmetric product and keeps np.max (utils.py:133-134).
-template <int NS, int NU>
-__device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
-                                                   const double (&kfb)[NU][NS]) {
-    double B[NS][NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) s = fma(kfb[u][i], kfb[u][j], s);
-            B[i][j] = s;
-        }
-    if (NS == 1) return q[0][0] * B[0][0];
-    // lower Cholesky of B
-    double L[NS][NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        double s = B[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
-        const double ljj = sqrt(s);
-        L[j][j] = ljj;
-        const double inv = 1.0 / ljj;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            if (i > j) {
-                double v = B[i][j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-                L[i][j] = v * inv;
-            } else if (i < j) {
-                L[i][j] = 0.0;
-            }
-        }
-    }
-    // M = L^T Q L
-    double QL[NS][NS], M[NS][NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-                if (k >= j) s = fma(q[i][k], L[k][j], s);
-            QL[i][j] = s;
-        }
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-                if (k >= i) s = fma(L[k][i], QL[k][j], s);
-            M[i][j] = s;
-        }
-    // symmetrise (Q is symmetric by contract; removes rounding asymmetry)
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (j > i) { const double m = 0.5 * (M[i][j] + M[j][i]); M[i][j] = m; M[j][i] = m; }
-    if (NS == 2) {
-        const double tr = M[0][0] + M[1][1];
-        const double df = M[0][0] - M[1][1];
-        return 0.5 * (tr + sqrt(fma(df, df, 4.0 * M[0][1] * M[0][1])));
-    }
-    // cyclic Jacobi (eigenvalues only)
-    for (int sweep = 0; sweep < 24; ++sweep) {
-        double off = 0.0, dia = 0.0;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            dia = fma(M[i][i], M[i][i], dia);
-#pragma unroll
-            for (int j = 0; j < NS; ++j)
-                if (j > i) off = fma(M[i][j], M[i][j], off);
-        }
-        if (off <= 1e-34 * dia || off == 0.0) break;
-#pragma unroll
-        for (int p = 0; p < NS; ++p)
-#pragma unroll
-            for (int r = 0; r < NS; ++r) {
-                if (r > p) {
-                    const double apr = M[p][r];
-                    if (apr != 0.0) {
-                        const double theta = (M[r][r] - M[p][p]) / (2.0 * apr);
-                        const double tt = ((theta >= 0.0) ? 1.0 : -1.0) /
-                                          (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-                        const double c = 1.0 / sqrt(fma(tt, tt, 1.0));
-                        const double s = tt * c;
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) {   // columns p, r
-                            const double mkp = M[k][p], mkr = M[k][r];
-                            M[k][p] = c * mkp - s * mkr;
-                            M[k][r] = s * mkp + c * mkr;
-                        }
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) {   // rows p, r
-                            const double mpk = M[p][k], mrk = M[r][k];
-                            M[p][k] = c * mpk - s * mrk;
-                            M[r][k] = s * mpk + c * mrk;
-                        }
-                    }
-                }
-            }
-    }
-    double lam = M[0][0];
-#pragma unroll
-    for (int i = 1; i < NS; ++i) lam = fmax(lam, M[i][i]);
-    return lam;
-}
+#include "sr_ellipsoid_dev.h"
 
 template <int NS, int NU>
 __global__ __launch_bounds__(256) void sr_ellipsoid_kernel(sr_ell_args a) {
-    int* n_bad = a.n_bad;
-    constexpr int D = NS + NU;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= a.T) return;
-
-    double p[NS], u[NU], mu[NS], var[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        p[i] = a.p[t * a.ldp + i];
-        mu[i] = a.mu[t * NS + i];
-        var[i] = a.var[t * NS + i];
-    }
-#pragma unroll
-    for (int k = 0; k < NU; ++k) u[k] = a.k_ff[t * a.ldkff + k];
-
-    // p_lin = a p + b u + mu        (gp_reachability.py:82-83 / :115)
-    double p1[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        double s = mu[i];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) s = fma(a.a[i * NS + j], p[j], s);
-#pragma unroll
-        for (int k = 0; k < NU; ++k) s = fma(a.b[i * NU + k], u[k], s);
-        p1[i] = s;
-        a.p_out[t * a.ldpo + i] = s;
-    }
-    double* qo = a.q_out + t * a.ldqo;
-    bool bad = false;
-
-    if (a.q == nullptr) {
-        // point branch: Q1 = diag(n_s (c sqrt(var))^2)     (gp_reachability.py:78-80)
-        // moment modes: Sigma1 = diag(var)                  (uncertainty_propagation_casadi.py:50-55, 253-258)
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const double ub = a.c_safety * sqrt(var[i]);
-            bad |= !(ub > 0.0);
-            const double dv = (a.mode == 0) ? NS * ub * ub : var[i];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) qo[i * NS + j] = (i == j) ? dv : 0.0;
-        }
-        if (bad && n_bad) atomicAdd(n_bad, 1);
-        return;
-    }
-
-    double q[NS][NS], kfb[NU][NS], H[NS][NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) q[i][j] = a.q[t * a.ldq + i * NS + j];
-#pragma unroll
-    for (int k = 0; k < NU; ++k)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) kfb[k][j] = a.k_fb[t * a.ldkfb + k * NS + j];
-
-    // H = a + a_mu + (b_mu + b) k_fb                          (gp_reachability.py:110-114)
-    // (mean-equivalent propagation drops the Jacobian terms: H = a + b k_fb)
-    const double* jac = a.jac + t * NS * D;
-    const double jw = (a.mode == 2) ? 0.0 : 1.0;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        double bm[NU];
-#pragma unroll
-        for (int k = 0; k < NU; ++k) bm[k] = (a.mode == 2 ? 0.0 : jac[i * D + NS + k]) + a.b[i * NU + k];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = a.a[i * NS + j] + (a.mode == 2 ? 0.0 : jw * jac[i * D + j]);
-#pragma unroll
-            for (int k = 0; k < NU; ++k) s = fma(bm[k], kfb[k][j], s);
-            H[i][j] = s;
-        }
-    }
-    // Q0 = H Q H^T                                            (:117)
-    double HQ[NS][NS], Q0[NS][NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) s = fma(H[i][k], q[k][j], s);
-            HQ[i][j] = s;
-        }
-    double trQ0 = 0.0;
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NS; ++k) s = fma(HQ[i][k], H[j][k], s);
-            Q0[i][j] = s;
-            if (i == j) trQ0 += s;
-        }
-    if (a.mode != 0) {
-        // Gaussian moment propagation: [a b I] Sigma_all [a b I]^T collapses to H Sigma H^T + diag(var)
-        // (uncertainty_propagation_casadi.py:57-87 with the Jacobian cross terms, :260-283 without)
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int j = 0; j < NS; ++j) qo[i * NS + j] = Q0[i][j] + ((i == j) ? var[i] : 0.0);
-        return;
-    }
-    // remainder boxes                                          (:125-137, utils.py:129-142)
-    const double r2 = sr_lambda_max_qb<NS, NU>(q, kfb);
-    const double r1 = sqrt(r2);
-    double dL[NS], dM[NS];
-    double trS = 0.0, trM = 0.0;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const double ub_mu = a.l_mu[i] * r2;
-        const double ub_sg = a.c_safety * (sqrt(var[i]) + a.l_sigma[i] * r1);
-        bad |= !(ub_mu > 0.0) || !(ub_sg > 0.0);
-        const double ds = NS * ub_sg * ub_sg;
-        const double dm = NS * ub_mu * ub_mu;
-        trS += ds;
-        trM += dm;
-        dL[i] = ds;
-        dM[i] = dm;
-    }
-    // trace-optimal sums                                        (:143-148, utils_ellipsoid.py:88-92)
-    const double c1 = sqrt(trS / trM);
-    double trL = 0.0;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        dL[i] = (1.0 + 1.0 / c1) * dL[i] + (1.0 + c1) * dM[i];
-        trL += dL[i];
-    }
-    const double c2 = sqrt(trL / trQ0);
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double v = (1.0 + c2) * Q0[i][j];
-            if (i == j) v += (1.0 + 1.0 / c2) * dL[i];
-            qo[i * NS + j] = v;
-        }
-    if (bad && n_bad) atomicAdd(n_bad, 1);
-    (void)p1;
+    sr_ellipsoid_one<NS, NU>(a, t);
 }
 
 template <int NS, int NU>

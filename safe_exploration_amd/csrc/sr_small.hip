@@ -20,6 +20,8 @@
 // formulas: /root/reference/safe_exploration/ssm_gpy/gp_models_utils_casadi.py:17-40,160-197
 // shapes:   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:546-596
 #include "sr_common.h"
+#include "sr_final_dev.h"
+#include "sr_ellipsoid_dev.h"
 
 #define SR_FQ 16         // queries per workgroup == N of the MFMA tile
 typedef double sr_d4 __attribute__((ext_vector_type(4)));
@@ -102,36 +104,76 @@ __device__ __forceinline__ void sr_small_contract(const double* __restrict__ Wd,
 //                                          d2 mu/dx_j dx_l = (R[1+j][1+l] - x_l/l_l R[1+j][0])/l_l - delta_jl mu/l_j^2
 //   V_c = U^-T col_c                   ->  var = sf2 - V_0.V_0,  d var/dx_j = -2 V_j.V_0
 // -- the same two phases, no second pass over U^-1.
-template <int NP, int DT, bool LIN>
-__global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, const double* __restrict__ Wt,
-                                                           double* __restrict__ mu, double* __restrict__ var,
-                                                           double* __restrict__ jac, double* __restrict__ jac_var,
-                                                           double* __restrict__ hess) {
-    constexpr int NSTRIP = NP / 16;          // 16-column strips of U^-1
-    constexpr int NPAIR = NSTRIP / 2;        // strips s and NSTRIP-1-s are paired (equal work per pair)
-    constexpr int NSPLIT = (16 / NPAIR) > 0 ? 16 / NPAIR : 1;   // wavefronts sharing one pair (k range cut in parts)
+// LDS of one posterior evaluation (arrays live in the calling kernel)
+template <int NP, int DT>
+struct sr_small_lds {
+    double (*ks)[SR_FQ];        // [NP]      k*[k][t]
+    double (*xq)[DT];           // [SR_FQ]   queries of this tile, scaled by 1/lengthscale
+    double (*pA)[256];          // [16]      phase A: per-wavefront partial R (accumulator layout)
+    double (*Rs)[16];           // [SR_FQ]   R[t][c]
+    double* pB;                 // phase B: partial V tiles, parts h > 0
+    double (*redC)[SR_FQ];      // [NP/16]   per strip and column: sum of squares (or dots with column 0)
+};
+#define SR_SMALL_LDS_DECL(NP, DT)                                                                          \
+    __shared__ double ks_[NP][SR_FQ];                                                                      \
+    __shared__ double xq_[SR_FQ][DT];                                                                      \
+    __shared__ double pA_[16][256];                                                                        \
+    __shared__ double Rs_[SR_FQ][16];                                                                      \
+    __shared__ double pB_[((16 / (NP / 32)) > 1 ? (16 / (NP / 32)) - 1 : 1) * ((16 / (NP / 32)) > 1 ? NP / 16 : 1) * 256]; \
+    __shared__ double redC_[NP / 16][SR_FQ];                                                               \
+    sr_small_lds<NP, DT> L{ks_, xq_, pA_, Rs_, pB_, redC_}
+
+// Phases A - C for output d and the (up to) SR_FQ queries x_t = [xa[t*lda ..], xb[t*ldb ..]], t < nq, whose pointers
+// may be global or LDS.  Leaves R in L.Rs, the scaled queries in L.xq and the strip sums in L.redC; ends with a
+// barrier.  Must be called by all 1024 threads.
+// The training rows of a lane's phase-A fragments: KEEP = all NP/64 k-steps loaded once by sr_small_rows_load and
+// kept in registers by the caller (the persistent chain kernel); otherwise phase A loads them itself, HC steps at a time.
+template <int NP, int DT>
+struct sr_small_rows {
+    double zs[NP / 64][DT];     // z_ij / l_j
+    double al[NP / 64];         // alpha_i (0 on padding rows)
+};
+
+template <int NP, int DT>
+__device__ __forceinline__ void sr_small_rows_load(const sr_kstar_args& a, int d, sr_small_rows<NP, DT>& rows) {
+    constexpr int RPW = NP / 16, KSA = RPW / 4;
+    const int lane = threadIdx.x & 63, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int off = NP - a.N;
+#pragma unroll
+    for (int st = 0; st < KSA; ++st) {
+        const int i = wave * RPW + 4 * st + lk;
+        const bool valid = i >= off;
+        rows.al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < DT; ++j)      // z * (1 / l) as phase A forms it: the same bits with and without KEEP
+            rows.zs[st][j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] * (1.0 / a.ls[d * a.D + j]) : 0.0;
+    }
+}
+
+template <int NP, int DT, bool LIN, bool KEEP = false>
+__device__ __forceinline__ void sr_small_posterior(const sr_kstar_args& a, const double* __restrict__ Wt, int d,
+                                                   const double* xa, long lda, const double* xb, long ldb, long nq,
+                                                   const sr_small_lds<NP, DT>& L,
+                                                   const sr_small_rows<NP, DT>* rows = nullptr) {
     constexpr int RPW = NP / 16;             // training rows per wavefront in phase A
     constexpr int KSA = RPW / 4;             // phase-A k-steps per wavefront
     constexpr int HC = KSA <= 4 ? KSA : KSA / 2;     // k-steps whose global loads are hoisted together
     static_assert(DT + 1 <= 16, "the mean/Jacobian right-hand side must fit the 16 MFMA columns");
     static_assert(NP % 128 == 0 && NP <= 512 && KSA % HC == 0, "Np in {128, 256, 384, 512}");
-    __shared__ double ks[NP][SR_FQ];                     // k*[k][t]
-    __shared__ double xq[SR_FQ][DT];                     // queries of this tile, scaled by 1/lengthscale
-    __shared__ double pA[16][256];                       // phase A: per-wavefront partial R (accumulator layout)
-    __shared__ double Rs[SR_FQ][16];                     // R[t][c]
-    __shared__ double pB[NSPLIT > 1 ? NSPLIT - 1 : 1][NSPLIT > 1 ? NSTRIP : 1][256];   // phase B: partial V tiles, parts h > 0
-    __shared__ double redC[NSTRIP][SR_FQ];
+    double (*ks)[SR_FQ] = L.ks;
+    double (*xq)[DT] = L.xq;
+    double (*pA)[256] = L.pA;
+    double (*Rs)[16] = L.Rs;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, ln = lane & 15;             // fragment coordinates: k offset, m/n index
-    const int d = blockIdx.y;
-    const long t0 = (long)blockIdx.x * SR_FQ;
     const int off = NP - a.N;                             // front padding
 
     const double sf2 = a.sf2[d];
     const int qt = LIN ? 0 : ln;                          // query index of this lane's column
-    const bool live = LIN ? true : (t0 + ln < a.T);
+    const bool live = LIN ? true : (ln < nq);
 
     // ---- phase A ------------------------------------------------------------------------------
     {
@@ -141,7 +183,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         for (int j = 0; j < DT; ++j) {
             il[j] = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
             xs[j] = 0.0;
-            if (live && j < a.D) xs[j] = (j < a.na) ? a.xa[(t0 + qt) * a.lda + j] : a.xb[(t0 + qt) * a.ldb + (j - a.na)];
+            if (live && j < a.D) xs[j] = (j < a.na) ? xa[qt * lda + j] : xb[qt * ldb + (j - a.na)];
         }
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
@@ -156,9 +198,15 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
             for (int st = 0; st < HC; ++st) {
                 const int i = wave * RPW + 4 * (c0 + st) + lk;
                 const bool valid = i >= off;
-                al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
+                if (KEEP) {
+                    al[st] = rows->al[c0 + st];
 #pragma unroll
-                for (int j = 0; j < DT; ++j) zv[st][j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
+                    for (int j = 0; j < DT; ++j) zv[st][j] = rows->zs[c0 + st][j];
+                } else {
+                    al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) zv[st][j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
+                }
             }
 #pragma unroll
             for (int st = 0; st < HC; ++st) {
@@ -166,7 +214,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
                 double r2 = 0.0, bfrag = (ln == 0) ? al[st] : 0.0, scale = (ln == 0) ? 1.0 : 0.0;
 #pragma unroll
                 for (int j = 0; j < DT; ++j) {
-                    const double zs = zv[st][j] * il[j];
+                    const double zs = KEEP ? zv[st][j] : zv[st][j] * il[j];
                     const double df = xs[j] - zs;
                     r2 = fma(df, df, r2);
                     if (ln == j + 1) {
@@ -197,7 +245,24 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
     }
 
     // ---- phases B, C ---------------------------------------------------------------------------
-    sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, ks, &pB[0][0][0], redC, wave, lane);
+    sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, ks, L.pB, L.redC, wave, lane);
+}
+
+template <int NP, int DT, bool LIN>
+__global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, const double* __restrict__ Wt,
+                                                           double* __restrict__ mu, double* __restrict__ var,
+                                                           double* __restrict__ jac, double* __restrict__ jac_var,
+                                                           double* __restrict__ hess) {
+    constexpr int NSTRIP = NP / 16;          // 16-column strips of U^-1
+    SR_SMALL_LDS_DECL(NP, DT);
+    double (*xq)[DT] = L.xq;
+    double (*Rs)[16] = L.Rs;
+    double (*redC)[SR_FQ] = L.redC;
+    const int tid = threadIdx.x;
+    const int d = blockIdx.y;
+    const long t0 = (long)blockIdx.x * SR_FQ;
+    const double sf2 = a.sf2[d];
+    sr_small_posterior<NP, DT, LIN>(a, Wt, d, a.xa + t0 * a.lda, a.lda, a.xb + t0 * a.ldb, a.ldb, a.T - t0, L);
 
     // ---- outputs ----------------------------------------------------------------------------------
     if (LIN) {
@@ -242,6 +307,206 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
         var[(t0 + tid) * a.n_out + d] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0c: the H-step reachability chain of a small model in ONE launch (multi_step_reachability,
+// /root/reference/safe_exploration/gp_reachability.py:159-212; moment chains of
+// uncertainty_propagation_casadi.py:88-190 through `mode`).
+//
+// Launched per step the chain costs two dependent launches per step (posterior 10.7 us + ellipsoid 4.7 us at N = 200:
+// 0.23 ms for H = 15), nearly all of it launch latency: the arithmetic of a step is a few microseconds.  Here workgroup
+// (g, d) owns output d of the 16 rollouts of group g for ALL steps:
+//     step i:  posterior of output d at [p_i, k_ff_i]               (phases A - C of sr_gp_small_kernel)
+//              (mu, var, d mu/dx)[d] -> exchange buffer, agent-scope stores; ticket of the group += 1
+//              wait until the ticket shows all n_out outputs of step i, read them (agent-scope loads)
+//              ellipsoid step of the 16 rollouts, one lane each, state (p, Q) kept in LDS   (sr_ellipsoid_one)
+// Every workgroup of a group runs the (cheap) ellipsoid step itself, so that one hand-off per step is enough;
+// workgroup d = 0 writes the results.  The exchange buffer is double-buffered by step parity: a workgroup can only be
+// one step ahead of the slowest one of its group.  No fences: payload and ticket are agent-scope (write-through)
+// accesses and the ticket is bumped after s_waitcnt vmcnt(0) + barrier (the protocol of sr_stream.hip).
+// All groups x n_out workgroups must be resident at once (<= SR_CHAIN_GROUPS, one per CU); a wait that does not
+// end poisons the outputs with NaN instead of hanging the device.
+// ------------------------------------------------------------------------------------------------
+template <int NP, int DT, int NS, int NU>
+__global__ __launch_bounds__(1024) void sr_chain_kernel(sr_chain_args c) {
+    constexpr int D = NS + NU;
+    constexpr int NSTRIP = NP / 16;
+    constexpr int XW = D + 2;                      // doubles per (output, rollout) in the exchange buffer
+    static_assert(D <= DT, "query width");
+    SR_SMALL_LDS_DECL(NP, DT);
+    __shared__ double ps[SR_FQ][NS];               // centres of the 16 rollouts
+    __shared__ double qs[SR_FQ][NS * NS];          // shape matrices
+    __shared__ double mus[SR_FQ][NS], vars_[SR_FQ][NS], jacs[SR_FQ][NS * D];
+    __shared__ double cst[NS * NS + NS * NU + 2 * NS];     // a, b, l_mu, l_sigma
+    extern __shared__ double ctl[];                        // k_ff [16][H][NU], then k_fb [16][H-1][NU][NS] of the group
+    __shared__ int fail;
+
+    const int tid = threadIdx.x;
+    const int n_out = NS;
+    const int g = blockIdx.x / n_out, d = blockIdx.x % n_out;
+    const long t0 = (long)g * SR_FQ;
+    const long nq = c.T - t0 < SR_FQ ? c.T - t0 : SR_FQ;
+    const double sf2 = c.k.sf2[d];
+    const long nss = NS * NS, nus = NU * NS;
+    if (tid == 0) fail = 0;
+
+    // everything that does not change from step to step is fetched once: one round trip to L2 / HBM instead of
+    // three or four dependent ones per step
+    constexpr bool KEEP = (NP / 64) * (DT + 1) <= 16;      // training rows of phase A in registers (32 VGPRs at most:
+                                                           // they stay live across the ellipsoid step)
+    sr_small_rows<NP, DT> rows;
+    if (KEEP) sr_small_rows_load<NP, DT>(c.k, d, rows);
+    double* kffs = ctl;
+    double* kfbs = ctl + (long)SR_FQ * c.H * NU;
+    for (long e = tid; e < nq * c.H * NU; e += 1024) kffs[e] = c.k_ff[t0 * c.H * NU + e];
+    for (long e = tid; e < nq * (c.H - 1) * nus; e += 1024) kfbs[e] = c.k_fb[t0 * (c.H - 1) * nus + e];
+    if (tid < NS * NS) cst[tid] = c.a[tid];
+    else if (tid < NS * NS + NS * NU) cst[tid] = c.b[tid - NS * NS];
+    else if (tid < NS * NS + NS * NU + NS) cst[tid] = c.l_mu[tid - NS * NS - NS * NU];
+    else if (tid < NS * NS + NS * NU + 2 * NS) cst[tid] = c.l_sigma[tid - NS * NS - NS * NU - NS];
+    __syncthreads();
+
+    for (int i = 0; i < c.H; ++i) {
+        // ---- posterior of output d at the centres of step i ------------------------------------
+        const double* xa = (i == 0) ? c.p0 + t0 * NS : &ps[0][0];
+        const double* xb = kffs + i * NU;
+        sr_small_posterior<NP, DT, false, KEEP>(c.k, c.Wt, d, xa, NS, xb, (long)c.H * NU, nq, L, &rows);
+
+        double* xo = c.xch + (((long)g * 2 + (i & 1)) * n_out + d) * SR_FQ * XW;
+        if (tid < SR_FQ * XW) {
+            const int t = tid / XW, j = tid % XW;
+            double v;
+            if (j < D) {
+                v = (L.Rs[t][1 + j] - L.xq[t][j] * L.Rs[t][0]) / c.k.ls[d * D + j];
+            } else if (j == D) {
+                v = L.Rs[t][0];
+            } else {
+                double qn = 0.0;
+#pragma unroll
+                for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += L.redC[sidx][t];
+                v = sf2 - qn;
+                if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+            }
+            if (NS == 1) {
+                if (j < D) jacs[t][j] = v; else if (j == D) mus[t][0] = v; else vars_[t][0] = v;
+            } else {
+                sr_st_agent(xo + tid, v);
+            }
+        }
+        if (NS > 1) {
+            // ---- hand the n_out outputs round the group ---------------------------------------------
+            __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the stores above have left
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(c.tickets + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long want = c.base + (unsigned long long)n_out * (i + 1);
+                int it = 0;
+                while (__hip_atomic_load(c.tickets + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++it > (1 << 22)) { fail = 1; break; }      // ~1 s: a workgroup of the group never came
+                }
+            }
+            __syncthreads();
+            if (fail) break;
+            const double* xi = c.xch + ((long)g * 2 + (i & 1)) * n_out * SR_FQ * XW;
+            if (tid < n_out * SR_FQ * XW) {
+                const int o = tid / (SR_FQ * XW), r = tid % (SR_FQ * XW);
+                const int t = r / XW, j = r % XW;
+                const double v = sr_ld<true>(xi + tid);
+                if (j < D) jacs[t][o * D + j] = v; else if (j == D) mus[t][o] = v; else vars_[t][o] = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- ellipsoid step, in place in LDS ------------------------------------------------------
+        if (tid < nq) {
+            sr_ell_args ea;
+            ea.T = nq; ea.n_s = NS; ea.n_u = NU;
+            if (i == 0) {
+                ea.p = c.p0 + t0 * NS; ea.ldp = NS;
+                ea.q = c.q0 ? c.q0 + t0 * nss : nullptr; ea.ldq = nss;
+                ea.k_fb = c.k_fb0 ? c.k_fb0 + t0 * nus : nullptr; ea.ldkfb = nus;
+            } else {
+                ea.p = &ps[0][0]; ea.ldp = NS;
+                ea.q = &qs[0][0]; ea.ldq = nss;
+                ea.k_fb = kfbs + (i - 1) * nus; ea.ldkfb = (long)(c.H - 1) * nus;
+            }
+            ea.k_ff = xb; ea.ldkff = (long)c.H * NU;
+            ea.mu = &mus[0][0]; ea.var = &vars_[0][0]; ea.jac = &jacs[0][0];
+            ea.a = cst; ea.b = cst + NS * NS; ea.l_mu = cst + NS * NS + NS * NU; ea.l_sigma = cst + NS * NS + NS * NU + NS;
+            ea.c_safety = c.c_safety;
+            ea.p_out = &ps[0][0]; ea.ldpo = NS;
+            ea.q_out = &qs[0][0]; ea.ldqo = nss;
+            ea.n_bad = (d == 0) ? c.n_bad : nullptr;
+            ea.mode = c.mode;
+            sr_ellipsoid_one<NS, NU>(ea, tid);
+        }
+        __syncthreads();
+        if (d == 0) {
+            if (tid < nq * NS) {
+                const int t = tid / NS, j = tid % NS;
+                c.p_all[((t0 + t) * c.H + i) * NS + j] = ps[t][j];
+                if (c.gp_var_all) c.gp_var_all[((t0 + t) * c.H + i) * NS + j] = vars_[t][j];
+            }
+            if (tid < nq * nss) {
+                const int t = tid / (int)nss, j = tid % (int)nss;
+                c.q_all[((t0 + t) * c.H + i) * nss + j] = qs[t][j];
+            }
+        }
+        // (the next posterior starts by reading ps and writes none of the arrays read above before its first barrier)
+    }
+    if (fail && d == 0) {
+        const double nan = __builtin_nan("");
+        for (long e = tid; e < nq * c.H * NS; e += 1024) c.p_all[t0 * c.H * NS + e] = nan;
+        for (long e = tid; e < nq * c.H * nss; e += 1024) c.q_all[t0 * c.H * nss + e] = nan;
+    }
+}
+
+template <int NP, int NS, int NU>
+static int launch_chain_np(const sr_chain_args& a, hipStream_t s) {
+    constexpr int DT = (NS + NU <= 3) ? 3 : (NS + NU <= 5 ? 5 : 8);
+    const unsigned groups = (unsigned)((a.T + SR_FQ - 1) / SR_FQ);
+    const size_t ctl_bytes = sizeof(double) * SR_FQ * ((size_t)a.H * NU + (size_t)(a.H - 1) * NU * NS);
+    hipLaunchKernelGGL((sr_chain_kernel<NP, DT, NS, NU>), dim3(groups * NS), dim3(1024), ctl_bytes, s, a);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+template <int NS, int NU>
+static int launch_chain_su(const sr_chain_args& a, hipStream_t s) {
+    switch (a.k.Np) {
+        case 128: return launch_chain_np<128, NS, NU>(a, s);
+        case 256: return launch_chain_np<256, NS, NU>(a, s);
+        case 384: return launch_chain_np<384, NS, NU>(a, s);
+        case 512: return launch_chain_np<512, NS, NU>(a, s);
+    }
+    sr_set_error("chain: Np=%d not supported", a.k.Np);
+    return SR_EUNSUPPORTED;
+}
+
+// the systems of the reference's experiments (pendulum 2 + 1, cart-pole 4 + 1) and their neighbours; anything else
+// runs the per-step launches
+bool sr_chain_supported(int Np, int D, int n_s, int n_u, int H) {
+    if (!(Np % 128 == 0 && Np <= SR_FUSED_NP && D == n_s + n_u)) return false;
+    if ((long)H * (n_u + n_u * n_s) * SR_FQ * 8 > 32768) return false;      // the group's control sequence lives in LDS
+    return (n_u == 1 && n_s >= 1 && n_s <= 4) || (n_u == 2 && (n_s == 2 || n_s == 3));
+}
+
+int sr_launch_chain(const sr_chain_args& a, hipStream_t s) {
+    const int n_s = a.k.n_out, n_u = a.k.D - a.k.n_out;
+    SR_CHECK((a.T + SR_FQ - 1) / SR_FQ * n_s <= SR_CHAIN_GROUPS, SR_EINVAL, "chain: %ld rollouts x %d outputs do not fit one launch", a.T, n_s);
+    if (n_u == 1) {
+        if (n_s == 1) return launch_chain_su<1, 1>(a, s);
+        if (n_s == 2) return launch_chain_su<2, 1>(a, s);
+        if (n_s == 3) return launch_chain_su<3, 1>(a, s);
+        if (n_s == 4) return launch_chain_su<4, 1>(a, s);
+    } else if (n_u == 2) {
+        if (n_s == 2) return launch_chain_su<2, 2>(a, s);
+        if (n_s == 3) return launch_chain_su<3, 2>(a, s);
+    }
+    sr_set_error("chain: n_s=%d n_u=%d not instantiated", n_s, n_u);
+    return SR_EUNSUPPORTED;
 }
 
 // General kernel family (Matern-5/2, linear x stationary + linear: sr_common.h; the kernels of the reference's

@@ -799,6 +799,17 @@ class SimpleGPModel(StateSpaceModel):
         self._need_trained()
         check(lib.sr_gp_set_small_path(self._handle.h, int(on)))
 
+    def set_chain(self, on):
+        """multi-step chains of small models inside one persistent launch (default) or step by step"""
+        self._need_trained()
+        check(lib.sr_gp_set_chain(self._handle.h, int(bool(on))))
+
+    @property
+    def last_chain(self):
+        """True if the last multi-step chain ran inside the persistent kernel"""
+        self._need_trained()
+        return bool(lib.sr_gp_last_chain(self._handle.h))
+
     def prof_enable(self, on=True):
         self._need_trained()
         check(lib.sr_prof_enable(self._handle.h, 1 if on else 0))

@@ -1252,3 +1252,61 @@ def test_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
                                             g["a_lin"], g["b_lin"], tz)
     np.testing.assert_allclose(mu_f, g["mu_taylor"][0], rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(sig_f.reshape(H, n_s, n_s), g["sigma_taylor"][0], rtol=1e-7, atol=1e-13)
+
+
+# ------------------------------------------------------------------ persistent multi-step kernel (sr_small.hip K0c)
+@pytest.mark.parametrize("n_s,n_u,N,T,H,with_q0", [
+    (2, 1, 100, 1, 2, False),        # Np = 128, one rollout
+    (2, 1, 200, 256, 15, False),     # the regime of the reference's experiments
+    (2, 1, 200, 17, 5, True),        # ragged last group, ellipsoid start
+    (2, 1, 350, 300, 7, True),       # Np = 384
+    (2, 1, 500, 2000, 4, False),     # Np = 512, 125 groups x 2 outputs: two launches
+    (4, 1, 150, 1000, 6, True),      # cart-pole: 63 groups x 4 outputs: two launches
+    (3, 1, 120, 40, 9, False),
+    (1, 1, 90, 33, 5, True),         # one output: no hand-off between workgroups
+    (2, 2, 180, 100, 5, True),
+    (3, 2, 240, 64, 8, False),
+])
+def test_persistent_chain_matches_per_step_launches(n_s, n_u, N, T, H, with_q0):
+    """(Tolerances: the per-step route of the larger cases takes other posterior kernels -- another order of
+    summation, compounded over H steps; where both routes run the same arithmetic the results agree to the bit.)
+    All H steps inside one launch (workgroups of a group of 16 rollouts hand their outputs round through L2)
+    against the same chain launched step by step; and against the oracle's chain for a few rollouts."""
+    from safe_exploration_amd import gp_reachability as reach
+    syn = orc.make_synthetic(1000 + 7 * N + T, N, n_s, n_u, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    rng = np.random.default_rng(N + T + H)
+    k_ff = 0.3 * rng.standard_normal((T, H, n_u))
+    k_fb = 0.1 * rng.standard_normal((T, H - 1, n_u, n_s))
+    l_mu = np.linspace(0.005, 0.008, n_s)
+    l_sg = np.linspace(0.002, 0.003, n_s)
+    a = 0.6 * np.eye(n_s) + 0.03 * rng.standard_normal((n_s, n_s))      # contracting: the tubes stay bounded
+    b = 0.1 * rng.standard_normal((n_s, n_u))
+    q0 = syn["Q"] if with_q0 else None
+    kfb0 = syn["k_fb"] if with_q0 else None
+    args = (syn["p"], gp, k_fb, k_ff, l_mu, l_sg, q0, 2.0, a, b, kfb0)
+    gp.set_chain(False)
+    p_ref, q_ref = reach.multistep_reachability_batch(*args)
+    assert not gp.last_chain
+    gp.set_chain(True)
+    for _ in range(3):               # tickets carry on from launch to launch
+        p_all, q_all = reach.multistep_reachability_batch(*args)
+        assert gp.last_chain
+        assert np.all(np.isfinite(q_ref)) and np.all(np.isfinite(q_all))
+        np.testing.assert_allclose(p_all, p_ref, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(q_all, q_ref, rtol=1e-8, atol=1e-14)
+    # fewer rollouts after more (the tickets of the unused groups stay behind), then more again
+    if T > 40:
+        sub = tuple(x[:20] if isinstance(x, np.ndarray) and x.shape[:1] == (T,) else x for x in args)
+        p_s, q_s = reach.multistep_reachability_batch(*sub)
+        np.testing.assert_allclose(p_s, p_ref[:20], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(q_s, q_ref[:20], rtol=1e-8, atol=1e-14)
+        p_all, q_all = reach.multistep_reachability_batch(*args)
+        np.testing.assert_allclose(q_all, q_ref, rtol=1e-8, atol=1e-14)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    n = min(T, 24)
+    rp, rq = orc.multistep_reachability_batch(om, syn["p"][:n], k_fb[:n], k_ff[:n], l_mu, l_sg,
+                                              None if q0 is None else q0[:n], 2.0, a, b,
+                                              None if kfb0 is None else kfb0[:n])
+    np.testing.assert_allclose(p_all[:n], rp, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(q_all[:n], rq, rtol=1e-6, atol=1e-12)
