@@ -846,9 +846,6 @@ static int stream_linearize(sr_gp* h, const double* x, double* mu, double* var, 
 }
 
 // GP posterior of Tc queries x = [xa | xb] into (mu, var, jac) in API layout (jac may be NULL).
-static int single_query_streamed(sr_gp* h, const double* xa, int na, const double* xb, double* mu, double* var,
-                                 double* jac_mu, double* jac_var, double* hess_mu, hipStream_t s);
-
 static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb,
                    int nb, double* mu, double* var, double* jac, hipStream_t s) {
     if (h->small_path == 1 && !h->force_stream && sr_gp_small_wanted(h->Np, Tc, h->D, h->general != 0)) {
@@ -943,45 +940,6 @@ extern "C" int sr_gp_predict(sr_gp_t h, const double* Xq, long T, double* mu, do
                        var + t0 * h->n_out, jac ? jac + t0 * h->n_out * h->D : nullptr, s));
     }
     return SR_OK;
-}
-
-// Single query through ONE streaming pass over U^-1: columns [k*, dk*/dx_j] (or k* alone when no second-order
-// output is wanted), dot products with column 0 in the reduce step, everything else as reductions over the
-// training points (sr_linearize.hip).  xa/xb: the query coordinates, split like in gp_pass.
-static int single_query_streamed(sr_gp* h, const double* xa, int na, const double* xb, double* mu, double* var,
-                                 double* jac_mu, double* jac_var, double* hess_mu, hipStream_t s) {
-    const bool second = jac_var != nullptr;
-    const int ncol = second ? 1 + h->D : 1;
-    const int tq = ncol <= 1 ? 1 : (ncol <= 4 ? 4 : SR_SMALL_T);
-    const long Tp = srt::BN;
-    SR_TRY(ensure_ws(h, Tp, pick_nsplit(h, Tp)));
-    const int nblk = (h->Np + 255) / 256;
-    const size_t need = std::max((size_t)h->n_out * nblk * sr_lin_nacc(h->D), (size_t)h->n_out * h->Np);
-    if (!h->lin_v || h->lin_cap < need) {
-        (void)hipStreamSynchronize(s);
-        dev_free(h->lin_v);
-        h->lin_v = nullptr; h->lin_cap = 0;
-        SR_TRY(dev_alloc(&h->lin_v, need));
-        h->lin_cap = need;
-    }
-    if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
-    sr_lin_args la;
-    la.Z = h->Z; la.alpha = h->alpha; la.ls = h->ls; la.sf2 = h->sf2; la.Ks = h->Ks; la.g = nullptr;
-    la.x = xa; la.xb = xb; la.na = na;
-    la.kp = h->general ? h->kp : nullptr;
-    la.jac_var = jac_var; la.hess_mu = hess_mu;
-    la.N = h->N; la.Np = h->Np; la.D = h->D; la.n_out = h->n_out; la.Tp = Tp;
-    {
-        sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
-        SR_TRY(sr_launch_lin_columns(la, tq, h->Ks, h->lin_v, s));
-    }
-    {
-        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, tq, s, 1));
-    }
-    h->last_streamed = 0;
-    sr_prof_scope ps(&h->prof, SR_K_FINAL, s);
-    return sr_launch_lin_final(la, h->lin_v, h->var_part, nblk, mu, var, jac_mu, s);
 }
 
 extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* var, double* jac_mu,

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root:  bash scripts/evidence.sh r02
+# Collects everything profiles/<tag>_* is made of into gpurun_out/ev_<tag>/ (bench lines, latency tables, kernel
+# trace + PMC passes of the headline bench, kernel trace of the C4 model update).  Copy to profiles/ with
+#   python scripts/summarize_rocpd.py gpurun_out/prof_<tag> profiles/<tag> c2p   and   cp gpurun_out/ev_<tag>/* profiles/
+set -u
+TAG=${1:-r02}
+REPO=$(pwd)
+EV=$REPO/gpurun_out/ev_$TAG
+mkdir -p "$EV"
+ulimit -c 0
+line() { tail -n 1; }
+timeout 600 python bench.py 2>"$EV/.err" | line > "$EV/${TAG}_bench_c2p.json"
+timeout 300 python bench.py --workload c2 --no-cpu-baseline 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c2.json"
+timeout 300 python bench.py --workload c3 --no-cpu-baseline --steps 3 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c3.json"
+timeout 300 python bench.py --workload c5 --no-cpu-baseline --steps 2 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c5.json"
+timeout 600 python bench.py --workload c4 --steps 2 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c4.json"
+timeout 300 python bench.py --workload c4 --n-train 5000 --steps 20 --warmup 3 2>>"$EV/.err" | line > "$EV/${TAG}_bench_refit5000.json"
+timeout 600 python scripts/latency_grid.py > "$EV/${TAG}_latency_grid.txt" 2>>"$EV/.err"
+timeout 300 python scripts/factor_bench.py > "$EV/${TAG}_factor_bench.txt" 2>>"$EV/.err"
+timeout 300 python scripts/append_bench.py > "$EV/${TAG}_append_bench.txt" 2>>"$EV/.err"
+timeout 300 python scripts/chain_bench.py > "$EV/${TAG}_chain_bench.txt" 2>>"$EV/.err"
+timeout 300 python scripts/diag_bench.py > "$EV/${TAG}_diag_bench.txt" 2>>"$EV/.err"
+timeout 900 bash scripts/profile_gpu.sh "$TAG" > "$EV/.profile.log" 2>&1
+export TMPDIR=/tmp
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_$TAG/c4trace" -o c4 -- \
+    python "$REPO/bench.py" --workload c4 --steps 1 --warmup 1 > "$EV/.c4trace.log" 2>&1 )
+python - "$REPO/gpurun_out/prof_$TAG/c4trace" > "$EV/${TAG}_c4_kernel_stats.txt" <<'PY'
+import glob, sqlite3, sys
+dbs = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)
+print("# rocprofv3 --kernel-trace --stats  (python bench.py --workload c4 --steps 1 --warmup 1): two model updates at N=50000")
+print("%-60s %8s %16s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+for name, calls, tot, avg, pct in sqlite3.connect(dbs[0]).execute("select * from top_kernels"):
+    print("%-60s %8d %16.0f %14.1f %8.3f" % (name[:60], calls, tot * 1.0, avg * 1.0, pct))
+PY
+ls -la "$EV"
+tail -n 5 "$EV/.err"
