@@ -237,6 +237,10 @@ int sr_gp_set_small_path(sr_gp_t h, int on);
  * the reference's systems n_s <= 4) run all H steps inside ONE persistent launch; on = 0 forces the per-step launches.
  * Default on; results agree to rounding.  sr_gp_last_chain: 1 if the last chain took the persistent kernel. */
 int sr_gp_set_chain(sr_gp_t h, int on);
+/* The model update keeps its scratch (two Np x Np matrices per output in flight) with the handle while that is at most a
+ * third of the device's memory, so that refits allocate nothing (40 GB at N = 50000); the row append keeps a strip and
+ * the previous U^-1 buffer.  A host that will only evaluate the model from here on hands them back with this call. */
+int sr_gp_release_scratch(sr_gp_t h);
 int sr_gp_last_chain(sr_gp_t h);
 /* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
  * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sr_gp_set_var_group": (_I, [_H, _I]),
     "sr_gp_set_var_variant": (_I, [_H, _I]),
     "sr_gp_set_chain": (_I, [_H, _I]),
+    "sr_gp_release_scratch": (_I, [_H]),
     "sr_gp_last_chain": (_I, [_H]),
     "sr_gp_set_small_path": (_I, [_H, _I]),
     "sr_gp_set_fact_panel": (_I, [_H, _I]),

@@ -799,6 +799,11 @@ class SimpleGPModel(StateSpaceModel):
         self._need_trained()
         check(lib.sr_gp_set_small_path(self._handle.h, int(on)))
 
+    def release_scratch(self):
+        """free what the model update / row append keep for their next call (two Np x Np matrices per output)"""
+        self._need_trained()
+        check(lib.sr_gp_release_scratch(self._handle.h))
+
     def set_chain(self, on):
         """multi-step chains of small models inside one persistent launch (default) or step by step"""
         self._need_trained()

@@ -87,6 +87,10 @@ def test_config4_model_update_at_50000_training_points():
     gp.train(prob["Z"], prob["Y"], opt_hyp=False)
     hd = gp._handle
     Np, off = hd.Np, hd.Np - N
+    # the update keeps its scratch (U, W: 2 x 20 GB) for the next refit; a host that only evaluates hands it back
+    free0 = torch.cuda.mem_get_info(gp.device)[0]
+    gp.release_scratch()
+    assert torch.cuda.mem_get_info(gp.device)[0] - free0 > 35e9
     s2n = prob["noise_var"] + 1e-5 + 1e-8
     idx = np.random.default_rng(0).choice(N, 2048, replace=False)
     mu, var = gp.predict(prob["Z"][idx])

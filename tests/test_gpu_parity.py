@@ -270,6 +270,24 @@ def test_onestep_and_multistep_vs_reference_golden(name, n_s, n_u):
     np.testing.assert_allclose(d, g["d_safety"], rtol=1e-12, atol=1e-14)
 
 
+def test_release_scratch_then_refit():
+    """sr_gp_release_scratch frees what update / append keep; the next update allocates again and gives the same model."""
+    syn = orc.make_synthetic(5, 700, 2, 1, 64)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    mu0, var0 = gp.predict(x)
+    beta0 = gp.beta.copy()
+    gp.release_scratch()
+    mu1, var1 = gp.predict(x)                       # the model itself is untouched
+    np.testing.assert_array_equal(mu0, mu1)
+    np.testing.assert_array_equal(var0, var1)
+    gp.train(syn["Z"], syn["Y"], opt_hyp=False)
+    np.testing.assert_array_equal(gp.beta, beta0)
+    gp.update_model(syn["Z"][:20] + 0.01, syn["Y"][:20], opt_hyp=False, replace_old=False)
+    gp.release_scratch()
+    assert gp.predict(x)[0].shape == mu0.shape
+
+
 def test_chunking_is_invisible():
     """results do not depend on the internal chunk size (ragged last chunk included)."""
     from safe_exploration_amd import gp_reachability as reach
