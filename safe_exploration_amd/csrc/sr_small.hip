@@ -325,8 +325,8 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 // workgroup d = 0 writes the results.  The exchange buffer is double-buffered by step parity: a workgroup can only be
 // one step ahead of the slowest one of its group.  No fences: payload and ticket are agent-scope (write-through)
 // accesses and the ticket is bumped after s_waitcnt vmcnt(0) + barrier (the protocol of sr_stream.hip).
-// All groups x n_out workgroups must be resident at once (<= SR_CHAIN_GROUPS, one per CU); a wait that does not
-// end poisons the outputs with NaN instead of hanging the device.
+// All groups x n_out workgroups must be resident at once (<= SR_CHAIN_GROUPS, one per CU; other work on the device
+// only delays them); a wait that does not end within 10 s poisons the outputs with NaN instead of hanging the device.
 // ------------------------------------------------------------------------------------------------
 template <int NP, int DT, int NS, int NU>
 __global__ __launch_bounds__(1024) void sr_chain_kernel(sr_chain_args c) {
@@ -401,10 +401,12 @@ __global__ __launch_bounds__(1024) void sr_chain_kernel(sr_chain_args c) {
             if (tid == 0) {
                 __hip_atomic_fetch_add(c.tickets + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long want = c.base + (unsigned long long)n_out * (i + 1);
-                int it = 0;
+                const unsigned long long t_start = wall_clock64();          // 100 MHz
                 while (__hip_atomic_load(c.tickets + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++it > (1 << 22)) { fail = 1; break; }      // ~1 s: a workgroup of the group never came
+                    // 10 s: a workgroup of the group never came (a launch on a stream whose CU mask holds fewer
+                    // CUs than the grid has workgroups would wait for ever)
+                    if (wall_clock64() - t_start > 1000000000ull) { fail = 1; break; }
                 }
             }
             __syncthreads();
