@@ -786,10 +786,13 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
                           double* mu, double* var, double* jac, hipStream_t s) {
     const long Tp = srt::BN;
     const int ncb = (h->Np + 255) / 256;
-    const bool fused = !h->general && h->D <= 5 && Tc <= 4;
+    // 2 .. 4 queries on a moderate model: the one-launch VALU kernel has only ncb (ncb + 1) n_out workgroups of 256
+    // threads there and loses to K1 + MFMA kernel + reduce (N = 700: 27 against 21 us; N = 3000: 34 against 40 us)
+    const bool mfma_small = Tc >= 2 && Tc <= 4 && h->Np <= 2048;
+    const bool fused = !h->general && h->D <= 5 && Tc <= 4 && !mfma_small;
     const int nsplit = fused ? 2 * ncb : pick_nsplit(h, Tp);
     SR_TRY(ensure_ws(h, Tp, std::max(nsplit, 2 * ncb)));
-    SR_TRY(stream_buffers(h, (int)Tc, s));
+    SR_TRY(stream_buffers(h, mfma_small ? 16 : (int)Tc, s));
     if (!fused) {
         sr_kstar_args ka;
         ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
@@ -802,7 +805,7 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
     }
     sr_stream_args a{};
     stream_common(h, a, (int)Tc, Tp);
-    a.mode = 0; a.dot0 = 0;
+    a.mode = 0; a.dot0 = 0; a.width_min = mfma_small ? 16 : 0;
     a.xa = xa; a.lda = lda; a.na = na; a.xb = xb; a.ldb = ldb;
     a.fa.mu_part = h->mu_part; a.fa.jac_part = h->jac_part; a.fa.var_part = h->var_part; a.fa.sf2 = h->sf2;
     a.fa.ls = h->ls; a.fa.kxx = h->general ? h->kxx : nullptr; a.fa.mu = mu; a.fa.var = var; a.fa.jac = jac;

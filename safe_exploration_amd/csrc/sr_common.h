@@ -285,6 +285,7 @@ int sr_launch_trmv_t(const double* M, long ld, const double* x, long xs, double*
 struct sr_stream_args {
     const double* Wt; const double* Ks; double* Vp; double* part; unsigned* tickets;
     int N, Np, D, n_out, ncb, npairs, k_lo, ncols, ncols_pad, dot0, mode;
+    int width_min;                   // take at least this kernel width (16: the MFMA kernel also for <= 4 columns)
     long Tp;
     // columns evaluated in the kernel (ARD-RBF): model and queries
     const double* Z; const double* alpha; const double* ls; const double* sf2;

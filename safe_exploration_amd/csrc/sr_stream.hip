@@ -420,7 +420,7 @@ int sr_stream_width(int ncols) {
 int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     a.ncb = (a.Np + SR_ST_COLS - 1) / SR_ST_COLS;
     a.npairs = a.ncb * (a.ncb + 1);
-    const int nc = sr_stream_width(a.ncols);
+    const int nc = max(sr_stream_width(a.ncols), a.width_min);
     SR_CHECK(a.ncols >= 1 && a.ncols <= 128, SR_EINVAL, "stream: %d columns", a.ncols);
     dim3 grid(a.npairs, a.n_out);
     if (nc <= 4) {

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Wall time per linearize_device call (mu, var, d mu/dx, d var/dx, Hessian of mu; device tensors) by model size.
+GPU box:  python scripts/linearize_bench.py [N ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safe_exploration_amd import SimpleGPModel, workload, _buffers as B  # noqa: E402
+
+
+def timeit(fn, n=200):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+def main():
+    Ns = [int(a) for a in sys.argv[1:]] or [200, 500, 700, 1024, 1500, 2000, 3000, 5000]
+    for n_s, n_u in ((2, 1), (4, 1)):
+        row = []
+        for N in Ns:
+            prob = workload.make_problem(9, N, n_s, n_u, 4, sf2=0.01)
+            gp = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device="cuda:0")
+            gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+            x1 = B.as_dev(np.hstack((prob["p"][0], prob["k_ff"][0])), gp.device)
+            row.append(timeit(lambda: gp.linearize_device(x1)))
+            del gp
+        print("n_s=%d n_u=%d  " % (n_s, n_u) + "  ".join("N=%d: %.1f us" % (N, v) for N, v in zip(Ns, row)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
