@@ -1133,10 +1133,16 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
     SR_DEVICE(h->device);
     const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
     h->last_chain = 0;
+    // small model, few rollouts: the whole chain in one launch (sr_small.hip K0c).  One launch holds SR_CHAIN_GROUPS
+    // workgroups = gmax groups of 16 rollouts; a second launch costs as much again, which only pays where the per-step
+    // route has left its one-launch posterior (T > SR_FUSED_T).  Measured at N = 200, H = 15: 256 rollouts 241 -> 148 us,
+    // 1024 rollouts (two launches) 292 against 247 us per step, 1920 rollouts (two launches) 304 against 544 us.
+    const int parts = h->Np / 128;                                      // workgroups sharing one (group, output)
+    const int gmax = std::max(1, SR_CHAIN_GROUPS / (n_s * std::max(parts, 1)));   // groups of 16 rollouts per launch
+    const long chain_launches = ((T + SR_SMALL_T - 1) / SR_SMALL_T + gmax - 1) / gmax;
     if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 && H >= 2 &&
-        T <= SR_CHAIN_MAX_T && sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
-        // small model, few rollouts: the whole chain in one launch per SR_CHAIN_GROUPS workgroups (sr_small.hip K0c)
-        const int gmax = SR_CHAIN_GROUPS / n_s;                         // groups of 16 rollouts per launch
+        (chain_launches == 1 || (chain_launches == 2 && T > SR_FUSED_T)) &&
+        sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
         if (!h->chain_xch) {
             SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_GROUPS * 2 * SR_SMALL_T * (SR_MAX_D + 2)));
             SR_TRY(dev_alloc(&h->chain_tickets, (size_t)SR_CHAIN_GROUPS));
@@ -1161,7 +1167,7 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
             ca.gp_var_all = gp_var_all ? gp_var_all + t0 * H * n_s : nullptr;
             ca.n_bad = n_bad; ca.xch = h->chain_xch; ca.tickets = h->chain_tickets; ca.base = h->chain_base;
             SR_TRY(sr_launch_chain(ca, s));
-            h->chain_base += (unsigned long long)n_s * H;
+            h->chain_base += (unsigned long long)n_s * parts * H;
             h->chain_valid = groups;
         }
         h->last_chain = 1;

@@ -172,8 +172,8 @@ int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, dou
 int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac_mu,
                            double* jac_var, double* hess_mu, hipStream_t s);
 
-// Persistent multi-step kernel (sr_small.hip): the whole H-step chain of up to SR_CHAIN_GROUPS * 16 rollouts in ONE
-// launch (the posterior of sr_gp_small_kernel and the step of sr_ellipsoid_kernel inside a loop over the steps).
+// Persistent multi-step kernel (sr_small.hip): the whole H-step chain of up to SR_CHAIN_GROUPS / (n_out Np / 128) * 16
+// rollouts in ONE launch (the posterior of sr_gp_small_kernel and the step of sr_ellipsoid_kernel inside a loop over the steps).
 struct sr_chain_args {
     sr_kstar_args k;                  // model (Z, alpha, ls, sf2, N, Np, D, n_out, na = n_s, nb = n_u); queries unused
     const double* Wt;
@@ -183,13 +183,12 @@ struct sr_chain_args {
     const double* a; const double* b; const double* l_mu; const double* l_sigma; double c_safety;
     double* p_all; double* q_all; double* gp_var_all;             // T x H x n_s, T x H x n_s^2, T x H x n_s | NULL
     int* n_bad;
-    double* xch;                      // groups x 2 x n_out x 16 x (D + 2): per-step results handed between the
-                                      // n_out workgroups of a group of 16 rollouts
+    double* xch;                      // groups x 2 x n_out x parts x 16 x (D + 2): per-step results handed between
+                                      // the n_out x Np / 128 workgroups of a group of 16 rollouts
     unsigned long long* tickets;      // one per group; all equal `base` at launch
     unsigned long long base;
 };
 #define SR_CHAIN_GROUPS 240          /* workgroups of one launch: all must be resident (they wait for each other) */
-#define SR_CHAIN_MAX_T 4096          /* beyond: the GPU is full anyway, the per-step launches cost nothing extra */
 bool sr_chain_supported(int Np, int D, int n_s, int n_u, int H);
 int sr_launch_chain(const sr_chain_args& a, hipStream_t s);
 

@@ -128,15 +128,15 @@ struct sr_small_lds {
 // barrier.  Must be called by all 1024 threads.
 // The training rows of a lane's phase-A fragments: KEEP = all NP/64 k-steps loaded once by sr_small_rows_load and
 // kept in registers by the caller (the persistent chain kernel); otherwise phase A loads them itself, HC steps at a time.
-template <int NP, int DT>
+template <int NP, int DT, int NW = 16>
 struct sr_small_rows {
-    double zs[NP / 64][DT];     // z_ij / l_j
-    double al[NP / 64];         // alpha_i (0 on padding rows)
+    double zs[NP / (4 * NW)][DT];     // z_ij / l_j
+    double al[NP / (4 * NW)];         // alpha_i (0 on padding rows)
 };
 
-template <int NP, int DT>
-__device__ __forceinline__ void sr_small_rows_load(const sr_kstar_args& a, int d, sr_small_rows<NP, DT>& rows) {
-    constexpr int RPW = NP / 16, KSA = RPW / 4;
+template <int NP, int DT, int NW>
+__device__ __forceinline__ void sr_small_rows_load(const sr_kstar_args& a, int d, sr_small_rows<NP, DT, NW>& rows) {
+    constexpr int RPW = NP / NW, KSA = RPW / 4;
     const int lane = threadIdx.x & 63, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int off = NP - a.N;
@@ -151,16 +151,18 @@ __device__ __forceinline__ void sr_small_rows_load(const sr_kstar_args& a, int d
     }
 }
 
-template <int NP, int DT, bool LIN, bool KEEP = false>
-__device__ __forceinline__ void sr_small_posterior(const sr_kstar_args& a, const double* __restrict__ Wt, int d,
-                                                   const double* xa, long lda, const double* xb, long ldb, long nq,
-                                                   const sr_small_lds<NP, DT>& L,
-                                                   const sr_small_rows<NP, DT>* rows = nullptr) {
-    constexpr int RPW = NP / 16;             // training rows per wavefront in phase A
+// Phase A alone: k* into L.ks, R = k*^T M into L.Rs (valid for threads < 256 right away, for everybody after the next
+// barrier), the scaled queries into L.xq.
+template <int NP, int DT, bool LIN, bool KEEP = false, int NW = 16>
+__device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
+                                                 const double* xa, long lda, const double* xb, long ldb, long nq,
+                                                 const sr_small_lds<NP, DT>& L,
+                                                 const sr_small_rows<NP, DT, NW>* rows = nullptr) {
+    constexpr int RPW = NP / NW;             // training rows per wavefront in phase A
     constexpr int KSA = RPW / 4;             // phase-A k-steps per wavefront
     constexpr int HC = KSA <= 4 ? KSA : KSA / 2;     // k-steps whose global loads are hoisted together
     static_assert(DT + 1 <= 16, "the mean/Jacobian right-hand side must fit the 16 MFMA columns");
-    static_assert(NP % 128 == 0 && NP <= 512 && KSA % HC == 0, "Np in {128, 256, 384, 512}");
+    static_assert(NP % 128 == 0 && NP <= 512 && KSA % HC == 0 && KSA >= 1, "Np in {128, 256, 384, 512}");
     double (*ks)[SR_FQ] = L.ks;
     double (*xq)[DT] = L.xq;
     double (*pA)[256] = L.pA;
@@ -239,13 +241,20 @@ __device__ __forceinline__ void sr_small_posterior(const sr_kstar_args& a, const
     if (tid < 256) {
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) v += pA[w][tid];
+        for (int w = 0; w < NW; ++w) v += pA[w][tid];
         const int l2 = tid & 63, r = tid >> 6;
         Rs[(l2 >> 4) + 4 * r][l2 & 15] = v;
     }
+}
 
+template <int NP, int DT, bool LIN, bool KEEP = false>
+__device__ __forceinline__ void sr_small_posterior(const sr_kstar_args& a, const double* __restrict__ Wt, int d,
+                                                   const double* xa, long lda, const double* xb, long ldb, long nq,
+                                                   const sr_small_lds<NP, DT>& L,
+                                                   const sr_small_rows<NP, DT, 16>* rows = nullptr) {
+    sr_small_phase_a<NP, DT, LIN, KEEP, 16>(a, d, xa, lda, xb, ldb, nq, L, rows);
     // ---- phases B, C ---------------------------------------------------------------------------
-    sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, ks, L.pB, L.redC, wave, lane);
+    sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, L.ks, L.pB, L.redC, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 template <int NP, int DT, bool LIN>
@@ -315,92 +324,212 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 // uncertainty_propagation_casadi.py:88-190 through `mode`).
 //
 // Launched per step the chain costs two dependent launches per step (posterior 10.7 us + ellipsoid 4.7 us at N = 200:
-// 0.23 ms for H = 15), nearly all of it launch latency: the arithmetic of a step is a few microseconds.  Here workgroup
-// (g, d) owns output d of the 16 rollouts of group g for ALL steps:
-//     step i:  posterior of output d at [p_i, k_ff_i]               (phases A - C of sr_gp_small_kernel)
-//              (mu, var, d mu/dx)[d] -> exchange buffer, agent-scope stores; ticket of the group += 1
-//              wait until the ticket shows all n_out outputs of step i, read them (agent-scope loads)
+// 0.23 ms for H = 15), much of it launch latency.  Here workgroup (g, d, part) owns, for ALL steps, output d of the 16
+// rollouts of group g and P = Np / 128 workgroups share the contraction with U^-1 of one (g, d):
+//     once:    everything that does not change from step to step is fetched: the wavefront's fragments of U^-1 into
+//              REGISTERS (2 (Np / 16 + 1) doubles per lane; 8 wavefronts per workgroup = 256 VGPRs per lane), the
+//              training rows of phase A into registers where they fit,
+//              the group's control sequence and the constants of the ellipsoid step into LDS
+//     step i:  phase A at [p_i, k_ff_i] (all parts: k* is needed in full)
+//              phase B on the part's 4 strip pairs (strips s and Np/16-1-s; 2 wavefronts per pair, each half of the
+//              k range: 2 (Np / 16 + 1) MFMAs per wavefront whatever the pair), squared and summed per rollout
+//              (mu, d mu/dx)[d] from part 0 and every part's share of |U^-T k*|^2 -> exchange buffer, agent-scope
+//              stores; the group's ticket += 1
+//              wait until the ticket shows all n_out P workgroups of step i, read their results (agent-scope loads)
 //              ellipsoid step of the 16 rollouts, one lane each, state (p, Q) kept in LDS   (sr_ellipsoid_one)
 // Every workgroup of a group runs the (cheap) ellipsoid step itself, so that one hand-off per step is enough;
-// workgroup d = 0 writes the results.  The exchange buffer is double-buffered by step parity: a workgroup can only be
-// one step ahead of the slowest one of its group.  No fences: payload and ticket are agent-scope (write-through)
-// accesses and the ticket is bumped after s_waitcnt vmcnt(0) + barrier (the protocol of sr_stream.hip).
-// All groups x n_out workgroups must be resident at once (<= SR_CHAIN_GROUPS, one per CU; other work on the device
-// only delays them); a wait that does not end within 10 s poisons the outputs with NaN instead of hanging the device.
+// workgroup (d, part) = (0, 0) writes the results.  The exchange buffer is double-buffered by step parity: a
+// workgroup can only be one step ahead of the slowest one of its group.  No fences: payload and ticket are agent-scope
+// (write-through) accesses and the ticket is bumped after s_waitcnt vmcnt(0) + barrier (the protocol of
+// sr_stream.hip).  All groups x n_out x P workgroups must be resident at once (<= SR_CHAIN_GROUPS, one per CU; other
+// work on the device only delays them); a wait that does not end within 10 s poisons the outputs with NaN instead of
+// hanging the device.
+// Measured per step at N = 200 (in-kernel clock): first version (one workgroup per (g, d), U^-1 fragments from L2 every
+// step) posterior 8.1 us + hand-off 2.0 + ellipsoid 1.4 + output 0.5.
 // ------------------------------------------------------------------------------------------------
+#define SR_CHAIN_PARTS(NP) ((NP) / 128)
+#define SR_CHAIN_NW 8                /* wavefronts per workgroup: 256 registers per lane, room for the U^-1 fragments */
+#define SR_CHAIN_TOT(NP) (2 * ((NP) / 16 + 1))
+
+// strips and k-ranges of a wavefront in the split contraction: pair pr = 4 part + wave / 2, half h = wave % 2
+template <int NP>
+struct sr_flat_geo {
+    int sA, sB, nA, stA, stB;
+    __device__ __forceinline__ sr_flat_geo(int part, int wave) {
+        const int pr = 4 * part + (wave >> 1), h = wave & 1;
+        sA = pr; sB = NP / 16 - 1 - pr;
+        nA = 2 * (sA + 1);                     // k-steps (of 4 rows) of this half of strip A; strip B: 2 (sB + 1)
+        stA = h * nA; stB = h * 2 * (sB + 1);
+    }
+};
+
+template <int NP>
+__device__ __forceinline__ void sr_flat_load(const double* __restrict__ Wd, int part, int wave, int lane,
+                                             double (&w)[SR_CHAIN_TOT(NP)]) {
+    const sr_flat_geo<NP> g(part, wave);
+    const int lk = lane >> 4, ln = lane & 15;
+#pragma unroll
+    for (int u = 0; u < SR_CHAIN_TOT(NP); ++u) {
+        const bool inA = u < g.nA;
+        const int st = inA ? g.stA + u : g.stB + (u - g.nA);
+        const int strip = inA ? g.sA : g.sB;
+        w[u] = Wd[(long)(4 * st + lk) * NP + 16 * strip + ln];
+    }
+}
+
+// The MFMAs of one wavefront with the length NA of its strip-A run known at compile time: straight-line code, so that
+// the scheduler batches the LDS reads of the B-fragments (with a wavefront-uniform branch per MFMA every read waited for
+// its own latency: 4.1 us per step at Np = 256 instead of the 1.8 us the MFMA pipe needs).  Two accumulators per strip
+// break the dependent chain.
+template <int NP, int NA>
+__device__ __forceinline__ void sr_flat_mfma(const double (&w)[SR_CHAIN_TOT(NP)], const double (*ks)[SR_FQ], int stA,
+                                             int stB, int lk, int ln, sr_d4 (&acc)[2]) {
+    constexpr int TOT = SR_CHAIN_TOT(NP);
+    sr_d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+    for (int u = 0; u < NA; u += 2) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u], ks[4 * (stA + u) + lk][ln], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u + 1], ks[4 * (stA + u + 1) + lk][ln], a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = NA; u < TOT; u += 2) {
+        b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u], ks[4 * (stB + u - NA) + lk][ln], b0, 0, 0, 0);
+        b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[u + 1], ks[4 * (stB + u + 1 - NA) + lk][ln], b1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc[0][r] = a0[r] + a1[r];
+        acc[1][r] = b0[r] + b1[r];
+    }
+}
+
+// redP[2 q + which][t] = sum over the rows of strip (pair q of the part, which) of V[i][t]^2.  Ends with a barrier.
+template <int NP>
+__device__ __forceinline__ void sr_flat_contract(const double (&w)[SR_CHAIN_TOT(NP)], const double (*ks)[SR_FQ],
+                                                 double* pB, double (*redP)[SR_FQ], int part, int wave, int lane) {
+    const sr_flat_geo<NP> g(part, wave);
+    const int lk = lane >> 4, ln = lane & 15, q = wave >> 1, h = wave & 1;
+    sr_d4 acc[2];
+    // nA = 2 (pair + 1), pair = 0 .. Np / 32 - 1 (both NA and TOT - NA are even)
+#define SR_FLAT_CASE(PR) case PR: if (PR < NP / 32) sr_flat_mfma<NP, (PR < NP / 32) ? 2 * (PR + 1) : 2>(w, ks, g.stA, g.stB, lk, ln, acc); break;
+    switch (g.sA) {
+        SR_FLAT_CASE(0) SR_FLAT_CASE(1) SR_FLAT_CASE(2) SR_FLAT_CASE(3) SR_FLAT_CASE(4) SR_FLAT_CASE(5) SR_FLAT_CASE(6)
+        SR_FLAT_CASE(7) SR_FLAT_CASE(8) SR_FLAT_CASE(9) SR_FLAT_CASE(10) SR_FLAT_CASE(11) SR_FLAT_CASE(12)
+        SR_FLAT_CASE(13) SR_FLAT_CASE(14) SR_FLAT_CASE(15)
+    }
+#undef SR_FLAT_CASE
+    if (h > 0) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pB[((2 * q + which) * 4 + r) * 64 + lane] = acc[which][r];
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            double sq = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = acc[which][r] + pB[((2 * q + which) * 4 + r) * 64 + lane];
+                sq = fma(v, v, sq);
+            }
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            if (lane < 16) redP[2 * q + which][lane] = sq;
+        }
+    }
+    __syncthreads();
+}
+
 template <int NP, int DT, int NS, int NU>
-__global__ __launch_bounds__(1024) void sr_chain_kernel(sr_chain_args c) {
+__global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_args c) {
     constexpr int D = NS + NU;
-    constexpr int NSTRIP = NP / 16;
-    constexpr int XW = D + 2;                      // doubles per (output, rollout) in the exchange buffer
+    constexpr int P = SR_CHAIN_PARTS(NP);
+    constexpr int NW = SR_CHAIN_NW, NT = 64 * NW;
+    constexpr int TOT = SR_CHAIN_TOT(NP);          // U^-1 fragments (doubles) per lane
+    constexpr int XW = D + 2;                      // doubles per (output, part, rollout) in the exchange buffer
     static_assert(D <= DT, "query width");
-    SR_SMALL_LDS_DECL(NP, DT);
+    __shared__ double ks_[NP][SR_FQ];
+    __shared__ double xq_[SR_FQ][DT];
+    __shared__ double Rs_[SR_FQ][16];
+    __shared__ double big_[8 * 256];               // phase A: pA[8][256]; phase B: pB[8 strips][256] (16 KiB)
+    __shared__ double redP[8][SR_FQ];
+    sr_small_lds<NP, DT> L{ks_, xq_, reinterpret_cast<double (*)[256]>(big_), Rs_, big_, nullptr};
     __shared__ double ps[SR_FQ][NS];               // centres of the 16 rollouts
     __shared__ double qs[SR_FQ][NS * NS];          // shape matrices
     __shared__ double mus[SR_FQ][NS], vars_[SR_FQ][NS], jacs[SR_FQ][NS * D];
-    __shared__ double cst[NS * NS + NS * NU + 2 * NS];     // a, b, l_mu, l_sigma
+    __shared__ double cst[NS * NS + NS * NU + 3 * NS];     // a, b, l_mu, l_sigma, sf2
     extern __shared__ double ctl[];                        // k_ff [16][H][NU], then k_fb [16][H-1][NU][NS] of the group
     __shared__ int fail;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_out = NS;
-    const int g = blockIdx.x / n_out, d = blockIdx.x % n_out;
+    const int part = blockIdx.x % P, d = (blockIdx.x / P) % n_out, g = blockIdx.x / (P * n_out);
     const long t0 = (long)g * SR_FQ;
     const long nq = c.T - t0 < SR_FQ ? c.T - t0 : SR_FQ;
-    const double sf2 = c.k.sf2[d];
     const long nss = NS * NS, nus = NU * NS;
+    const bool writer = (d == 0 && part == 0);
     if (tid == 0) fail = 0;
 
-    // everything that does not change from step to step is fetched once: one round trip to L2 / HBM instead of
-    // three or four dependent ones per step
-    constexpr bool KEEP = (NP / 64) * (DT + 1) <= 16;      // training rows of phase A in registers (32 VGPRs at most:
-                                                           // they stay live across the ellipsoid step)
-    sr_small_rows<NP, DT> rows;
-    if (KEEP) sr_small_rows_load<NP, DT>(c.k, d, rows);
+    // everything that does not change from step to step is fetched once
+    double wreg[TOT];
+    sr_flat_load<NP>(c.Wt + (long)d * NP * NP, part, wave, lane, wreg);
+    // training rows of phase A in registers too while fragments + rows stay below ~180 of the 256 VGPRs
+    constexpr bool KEEP = (NP / (4 * NW)) * (DT + 1) + TOT <= 90;
+    sr_small_rows<NP, DT, NW> rows;
+    if (KEEP) sr_small_rows_load<NP, DT, NW>(c.k, d, rows);
     double* kffs = ctl;
     double* kfbs = ctl + (long)SR_FQ * c.H * NU;
-    for (long e = tid; e < nq * c.H * NU; e += 1024) kffs[e] = c.k_ff[t0 * c.H * NU + e];
-    for (long e = tid; e < nq * (c.H - 1) * nus; e += 1024) kfbs[e] = c.k_fb[t0 * (c.H - 1) * nus + e];
-    if (tid < NS * NS) cst[tid] = c.a[tid];
-    else if (tid < NS * NS + NS * NU) cst[tid] = c.b[tid - NS * NS];
-    else if (tid < NS * NS + NS * NU + NS) cst[tid] = c.l_mu[tid - NS * NS - NS * NU];
-    else if (tid < NS * NS + NS * NU + 2 * NS) cst[tid] = c.l_sigma[tid - NS * NS - NS * NU - NS];
+    for (long e = tid; e < nq * c.H * NU; e += NT) kffs[e] = c.k_ff[t0 * c.H * NU + e];
+    for (long e = tid; e < nq * (c.H - 1) * nus; e += NT) kfbs[e] = c.k_fb[t0 * (c.H - 1) * nus + e];
+    constexpr int C_B = NS * NS, C_LM = C_B + NS * NU, C_LS = C_LM + NS, C_SF = C_LS + NS;
+    if (tid < C_B) cst[tid] = c.a[tid];
+    else if (tid < C_LM) cst[tid] = c.b[tid - C_B];
+    else if (tid < C_LS) cst[tid] = c.l_mu[tid - C_LM];
+    else if (tid < C_SF) cst[tid] = c.l_sigma[tid - C_LS];
+    else if (tid < C_SF + NS) cst[tid] = c.k.sf2[tid - C_SF];
     __syncthreads();
 
     for (int i = 0; i < c.H; ++i) {
         // ---- posterior of output d at the centres of step i ------------------------------------
         const double* xa = (i == 0) ? c.p0 + t0 * NS : &ps[0][0];
         const double* xb = kffs + i * NU;
-        sr_small_posterior<NP, DT, false, KEEP>(c.k, c.Wt, d, xa, NS, xb, (long)c.H * NU, nq, L, &rows);
+        sr_small_phase_a<NP, DT, false, KEEP, NW>(c.k, d, xa, NS, xb, (long)c.H * NU, nq, L, &rows);
+        __syncthreads();                                   // R complete: the partial-R buffer becomes the partial-V buffer
+        sr_flat_contract<NP>(wreg, ks_, big_, redP, part, wave, lane);
 
-        double* xo = c.xch + (((long)g * 2 + (i & 1)) * n_out + d) * SR_FQ * XW;
+        double* xo = c.xch + ((((long)g * 2 + (i & 1)) * n_out + d) * P + part) * SR_FQ * XW;
         if (tid < SR_FQ * XW) {
             const int t = tid / XW, j = tid % XW;
-            double v;
+            double v = 0.0;
+            bool mine = true;
             if (j < D) {
-                v = (L.Rs[t][1 + j] - L.xq[t][j] * L.Rs[t][0]) / c.k.ls[d * D + j];
+                v = (Rs_[t][1 + j] - xq_[t][j] * Rs_[t][0]) / c.k.ls[d * D + j];
+                mine = (part == 0);
             } else if (j == D) {
-                v = L.Rs[t][0];
+                v = Rs_[t][0];
+                mine = (part == 0);
             } else {
-                double qn = 0.0;
 #pragma unroll
-                for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += L.redC[sidx][t];
-                v = sf2 - qn;
-                if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+                for (int sidx = 0; sidx < 8; ++sidx) v += redP[sidx][t];       // this part's share of |U^-T k*|^2
             }
-            if (NS == 1) {
-                if (j < D) jacs[t][j] = v; else if (j == D) mus[t][0] = v; else vars_[t][0] = v;
-            } else {
+            if (NS == 1 && P == 1) {
+                if (j < D) jacs[t][j] = v;
+                else if (j == D) mus[t][0] = v;
+                else { v = cst[C_SF] - v; vars_[t][0] = (v > SR_VAR_CLIP) ? v : SR_VAR_CLIP; }
+            } else if (mine) {
                 sr_st_agent(xo + tid, v);
             }
         }
-        if (NS > 1) {
-            // ---- hand the n_out outputs round the group ---------------------------------------------
+        if (NS > 1 || P > 1) {
+            // ---- hand the results round the group -------------------------------------------------------
             __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the stores above have left
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_fetch_add(c.tickets + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long want = c.base + (unsigned long long)n_out * (i + 1);
+                const unsigned long long want = c.base + (unsigned long long)(n_out * P) * (i + 1);
                 const unsigned long long t_start = wall_clock64();          // 100 MHz
                 while (__hip_atomic_load(c.tickets + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
@@ -411,12 +540,21 @@ __global__ __launch_bounds__(1024) void sr_chain_kernel(sr_chain_args c) {
             }
             __syncthreads();
             if (fail) break;
-            const double* xi = c.xch + ((long)g * 2 + (i & 1)) * n_out * SR_FQ * XW;
+            const double* xi = c.xch + ((long)g * 2 + (i & 1)) * n_out * P * SR_FQ * XW;
             if (tid < n_out * SR_FQ * XW) {
                 const int o = tid / (SR_FQ * XW), r = tid % (SR_FQ * XW);
                 const int t = r / XW, j = r % XW;
-                const double v = sr_ld<true>(xi + tid);
-                if (j < D) jacs[t][o * D + j] = v; else if (j == D) mus[t][o] = v; else vars_[t][o] = v;
+                const double* src = xi + (long)o * P * SR_FQ * XW + r;            // part 0 of output o
+                if (j <= D) {
+                    const double v = sr_ld<true>(src);
+                    if (j < D) jacs[t][o * D + j] = v; else mus[t][o] = v;
+                } else {
+                    double qn = 0.0;
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp) qn += sr_ld<true>(src + (long)pp * SR_FQ * XW);
+                    const double v = cst[C_SF + o] - qn;
+                    vars_[t][o] = (v > SR_VAR_CLIP) ? v : SR_VAR_CLIP;
+                }
             }
         }
         __syncthreads();
@@ -436,16 +574,16 @@ __global__ __launch_bounds__(1024) void sr_chain_kernel(sr_chain_args c) {
             }
             ea.k_ff = xb; ea.ldkff = (long)c.H * NU;
             ea.mu = &mus[0][0]; ea.var = &vars_[0][0]; ea.jac = &jacs[0][0];
-            ea.a = cst; ea.b = cst + NS * NS; ea.l_mu = cst + NS * NS + NS * NU; ea.l_sigma = cst + NS * NS + NS * NU + NS;
+            ea.a = cst; ea.b = cst + C_B; ea.l_mu = cst + C_LM; ea.l_sigma = cst + C_LS;
             ea.c_safety = c.c_safety;
             ea.p_out = &ps[0][0]; ea.ldpo = NS;
             ea.q_out = &qs[0][0]; ea.ldqo = nss;
-            ea.n_bad = (d == 0) ? c.n_bad : nullptr;
+            ea.n_bad = writer ? c.n_bad : nullptr;
             ea.mode = c.mode;
             sr_ellipsoid_one<NS, NU>(ea, tid);
         }
         __syncthreads();
-        if (d == 0) {
+        if (writer) {
             if (tid < nq * NS) {
                 const int t = tid / NS, j = tid % NS;
                 c.p_all[((t0 + t) * c.H + i) * NS + j] = ps[t][j];
@@ -456,12 +594,12 @@ __global__ __launch_bounds__(1024) void sr_chain_kernel(sr_chain_args c) {
                 c.q_all[((t0 + t) * c.H + i) * nss + j] = qs[t][j];
             }
         }
-        // (the next posterior starts by reading ps and writes none of the arrays read above before its first barrier)
+        // (the next phase A starts by reading ps and writes none of the arrays read above before its first barrier)
     }
-    if (fail && d == 0) {
+    if (fail && writer) {
         const double nan = __builtin_nan("");
-        for (long e = tid; e < nq * c.H * NS; e += 1024) c.p_all[t0 * c.H * NS + e] = nan;
-        for (long e = tid; e < nq * c.H * nss; e += 1024) c.q_all[t0 * c.H * nss + e] = nan;
+        for (long e = tid; e < nq * c.H * NS; e += NT) c.p_all[t0 * c.H * NS + e] = nan;
+        for (long e = tid; e < nq * c.H * nss; e += NT) c.q_all[t0 * c.H * nss + e] = nan;
     }
 }
 
@@ -470,7 +608,7 @@ static int launch_chain_np(const sr_chain_args& a, hipStream_t s) {
     constexpr int DT = (NS + NU <= 3) ? 3 : (NS + NU <= 5 ? 5 : 8);
     const unsigned groups = (unsigned)((a.T + SR_FQ - 1) / SR_FQ);
     const size_t ctl_bytes = sizeof(double) * SR_FQ * ((size_t)a.H * NU + (size_t)(a.H - 1) * NU * NS);
-    hipLaunchKernelGGL((sr_chain_kernel<NP, DT, NS, NU>), dim3(groups * NS), dim3(1024), ctl_bytes, s, a);
+    hipLaunchKernelGGL((sr_chain_kernel<NP, DT, NS, NU>), dim3(groups * NS * SR_CHAIN_PARTS(NP)), dim3(64 * SR_CHAIN_NW), ctl_bytes, s, a);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -491,13 +629,14 @@ static int launch_chain_su(const sr_chain_args& a, hipStream_t s) {
 // runs the per-step launches
 bool sr_chain_supported(int Np, int D, int n_s, int n_u, int H) {
     if (!(Np % 128 == 0 && Np <= SR_FUSED_NP && D == n_s + n_u)) return false;
-    if ((long)H * (n_u + n_u * n_s) * SR_FQ * 8 > 32768) return false;      // the group's control sequence lives in LDS
+    if ((long)H * (n_u + n_u * n_s) * SR_FQ * 8 > 24576) return false;      // the group's control sequence lives in LDS
     return (n_u == 1 && n_s >= 1 && n_s <= 4) || (n_u == 2 && (n_s == 2 || n_s == 3));
 }
 
 int sr_launch_chain(const sr_chain_args& a, hipStream_t s) {
     const int n_s = a.k.n_out, n_u = a.k.D - a.k.n_out;
-    SR_CHECK((a.T + SR_FQ - 1) / SR_FQ * n_s <= SR_CHAIN_GROUPS, SR_EINVAL, "chain: %ld rollouts x %d outputs do not fit one launch", a.T, n_s);
+    SR_CHECK((a.T + SR_FQ - 1) / SR_FQ * n_s * (a.k.Np / 128) <= SR_CHAIN_GROUPS, SR_EINVAL,
+             "chain: %ld rollouts x %d outputs x %d parts do not fit one launch", a.T, n_s, a.k.Np / 128);
     if (n_u == 1) {
         if (n_s == 1) return launch_chain_su<1, 1>(a, s);
         if (n_s == 2) return launch_chain_su<2, 1>(a, s);

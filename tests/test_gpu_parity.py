@@ -1278,8 +1278,9 @@ def test_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
     (2, 1, 200, 256, 15, False),     # the regime of the reference's experiments
     (2, 1, 200, 17, 5, True),        # ragged last group, ellipsoid start
     (2, 1, 350, 300, 7, True),       # Np = 384
-    (2, 1, 500, 2000, 4, False),     # Np = 512, 125 groups x 2 outputs: two launches
-    (4, 1, 150, 1000, 6, True),      # cart-pole: 63 groups x 4 outputs: two launches
+    (2, 1, 500, 480, 4, False),      # Np = 512: 30 groups x 2 outputs x 4 parts fill the launch
+    (2, 1, 200, 1900, 3, False),     # 119 groups x 2 outputs x 2 parts: two launches
+    (4, 1, 150, 470, 6, True),       # cart-pole: 30 groups x 4 outputs x 2 parts
     (3, 1, 120, 40, 9, False),
     (1, 1, 90, 33, 5, True),         # one output: no hand-off between workgroups
     (2, 2, 180, 100, 5, True),
@@ -1287,7 +1288,8 @@ def test_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
 ])
 def test_persistent_chain_matches_per_step_launches(n_s, n_u, N, T, H, with_q0):
     """(Tolerances: the per-step route of the larger cases takes other posterior kernels -- another order of
-    summation, compounded over H steps; where both routes run the same arithmetic the results agree to the bit.)
+    summation, compounded over H steps; the persistent kernel also adds the shares of |U^-T k*|^2 of its Np / 128
+    workgroups per output in its own order.)
     All H steps inside one launch (workgroups of a group of 16 rollouts hand their outputs round through L2)
     against the same chain launched step by step; and against the oracle's chain for a few rollouts."""
     from safe_exploration_amd import gp_reachability as reach
@@ -1311,16 +1313,22 @@ def test_persistent_chain_matches_per_step_launches(n_s, n_u, N, T, H, with_q0):
         p_all, q_all = reach.multistep_reachability_batch(*args)
         assert gp.last_chain
         assert np.all(np.isfinite(q_ref)) and np.all(np.isfinite(q_all))
-        np.testing.assert_allclose(p_all, p_ref, rtol=1e-9, atol=1e-12)
-        np.testing.assert_allclose(q_all, q_ref, rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(p_all, p_ref, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(q_all, q_ref, rtol=1e-7, atol=1e-14)
     # fewer rollouts after more (the tickets of the unused groups stay behind), then more again
-    if T > 40:
+    if T > 40 and T < 1024:
         sub = tuple(x[:20] if isinstance(x, np.ndarray) and x.shape[:1] == (T,) else x for x in args)
         p_s, q_s = reach.multistep_reachability_batch(*sub)
-        np.testing.assert_allclose(p_s, p_ref[:20], rtol=1e-9, atol=1e-12)
-        np.testing.assert_allclose(q_s, q_ref[:20], rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(p_s, p_ref[:20], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(q_s, q_ref[:20], rtol=1e-7, atol=1e-14)
         p_all, q_all = reach.multistep_reachability_batch(*args)
-        np.testing.assert_allclose(q_all, q_ref, rtol=1e-8, atol=1e-14)
+        np.testing.assert_allclose(q_all, q_ref, rtol=1e-7, atol=1e-14)
+    # more rollouts than one launch holds: the per-step route takes over (same results, checked above)
+    if T == 470:
+        big = tuple(np.concatenate([x, x]) if isinstance(x, np.ndarray) and x.shape[:1] == (T,) else x for x in args)
+        p_b, q_b = reach.multistep_reachability_batch(*big)
+        assert not gp.last_chain
+        np.testing.assert_allclose(p_b[:T], p_ref, rtol=1e-8, atol=1e-11)
     om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
     n = min(T, 24)
     rp, rq = orc.multistep_reachability_batch(om, syn["p"][:n], k_fb[:n], k_ff[:n], l_mu, l_sg,
