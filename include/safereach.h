@@ -241,6 +241,16 @@ int sr_gp_set_chain(sr_gp_t h, int on);
  * third of the device's memory, so that refits allocate nothing (40 GB at N = 50000); the row append keeps a strip and
  * the previous U^-1 buffer.  A host that will only evaluate the model from here on hands them back with this call. */
 int sr_gp_release_scratch(sr_gp_t h);
+
+/* ---- completion mailbox for a host that blocks on ONE small result --------------------------------
+ * (the CasADi / IPOPT callback: CasadiSSMEvaluator.eval, state_space_models.py:271-303, calls the model, waits, and
+ * hands NumPy arrays back).  sr_publish enqueues, behind the work already on `stream`, a copy of n doubles from device
+ * memory into PINNED host memory followed by a store of `seq` to *flag_host (pinned as well); sr_wait_flag spins on the
+ * host until *flag_host == seq (SR_ESTATE after timeout_s).  The result is visible a PCIe write after the producing
+ * kernel ends; a D2H copy + hipStreamSynchronize takes ~4 us longer (N = 200: 33.7 -> 29.4 us per blocking call). */
+int sr_publish(int device, const double* src_dev, int n, double* dst_host, unsigned long long* flag_host,
+               unsigned long long seq, void* stream);
+int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s);
 int sr_gp_last_chain(sr_gp_t h);
 /* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
  * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.

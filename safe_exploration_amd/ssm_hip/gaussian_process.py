@@ -50,8 +50,9 @@ class _Handle(object):
 
     def single_io(self):
         """Staging of the single-query (CasADi/IPOPT callback) entry points: one pinned host block in, one
-        packed device block [mu | var | jac_mu | jac_var | hess_mu] out, one pinned host block back -- two
-        async copies and one stream sync per call instead of a pageable copy per array."""
+        packed device block [mu | var | jac_mu | jac_var | hess_mu] out, one pinned host block back.  The way back is
+        ``sr_publish`` + ``sr_wait_flag`` (results and a sequence number written into pinned memory by a kernel, the
+        host spins on the number): ~4 us less per blocking call than a D2H copy + stream sync."""
         io = getattr(self, "_single_io", None)
         if io is None:
             n, D = self.n_out, self.D
@@ -59,7 +60,8 @@ class _Handle(object):
             io = {"h_in": torch.empty(D, dtype=torch.float64).pin_memory(),
                   "d_in": torch.empty((1, D), dtype=torch.float64, device=self.device),
                   "d_out": torch.empty(total, dtype=torch.float64, device=self.device),
-                  "h_out": torch.empty(total, dtype=torch.float64).pin_memory()}
+                  "h_out": torch.empty(total, dtype=torch.float64).pin_memory(),
+                  "h_flag": torch.zeros(1, dtype=torch.int64).pin_memory(), "seq": 0, "mailbox": True}
             o = io["d_out"]
             io["mu"], io["var"] = o[:n], o[n:2 * n]
             io["jm"] = o[2 * n:2 * n + n * D]
@@ -68,6 +70,24 @@ class _Handle(object):
             io["h_in_np"], io["h_out_np"] = io["h_in"].numpy(), io["h_out"].numpy()
             self._single_io = io
         return io
+
+    def fetch(self, k, stream):
+        """first k doubles of the packed device block -> NumPy (copy), blocking."""
+        io = self._single_io
+        if io["mailbox"]:
+            io["seq"] += 1
+            rc = lib.sr_publish(self.device.index or 0, B.ptr(io["d_out"]), int(k), B.ptr(io["h_out"]),
+                                B.ptr(io["h_flag"]), io["seq"], ctypes.c_void_p(stream.cuda_stream))
+            if rc == 0:
+                rc = lib.sr_wait_flag(B.ptr(io["h_flag"]), io["seq"], 5.0)
+                if rc == 0:
+                    return io["h_out_np"][:k].copy()
+                stream.synchronize()           # surfaces a failed kernel as the HIP error it is
+                check(rc)
+            io["mailbox"] = False              # the host block is not device-visible here: plain copies from now on
+        io["h_out"][:k].copy_(io["d_out"][:k], non_blocking=True)
+        stream.synchronize()
+        return io["h_out_np"][:k].copy()
 
 
 class SimpleGPModel(StateSpaceModel):
@@ -622,10 +642,7 @@ class SimpleGPModel(StateSpaceModel):
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
         check(lib.sr_gp_predict(hd.h, B.ptr(io["d_in"]), 1, B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
                                 ctypes.c_void_p(stream.cuda_stream)))
-        k = 2 * n + n * D
-        io["h_out"][:k].copy_(io["d_out"][:k], non_blocking=True)
-        stream.synchronize()
-        o = io["h_out_np"][:k].copy()
+        o = hd.fetch(2 * n + n * D, stream)
         return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
 
     def linearize_device(self, x):
@@ -677,9 +694,7 @@ class SimpleGPModel(StateSpaceModel):
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
         check(lib.sr_gp_linearize(hd.h, B.ptr(io["d_in"]), B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
                                   B.ptr(io["jv"]), B.ptr(io["hm"]), ctypes.c_void_p(stream.cuda_stream)))
-        io["h_out"].copy_(io["d_out"], non_blocking=True)
-        stream.synchronize()
-        o = io["h_out_np"].copy()
+        o = hd.fetch(io["d_out"].numel(), stream)
         a, b, c = 2 * n, 2 * n + n * D, 2 * n + 2 * n * D
         return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
 

@@ -1336,3 +1336,35 @@ def test_persistent_chain_matches_per_step_launches(n_s, n_u, N, T, H, with_q0):
                                               None if kfb0 is None else kfb0[:n])
     np.testing.assert_allclose(p_all[:n], rp, rtol=1e-7, atol=1e-10)
     np.testing.assert_allclose(q_all[:n], rq, rtol=1e-6, atol=1e-12)
+
+
+def test_single_query_mailbox_and_fallback_agree():
+    """__call__ / linearize_predict hand their results back through sr_publish + sr_wait_flag (pinned mailbox, host
+    spin); the plain copy + stream sync route must give the same arrays, call after call."""
+    syn = orc.make_synthetic(17, 300, 2, 1, 8)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    io = gp._handle.single_io()
+    assert io["mailbox"]
+    outs = []
+    for t in range(8):
+        outs.append(gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1]))
+    assert io["mailbox"] and io["seq"] == 8            # the fast route stayed on
+    lin = gp.linearize_predict(syn["p"][:1], syn["k_ff"][:1], True)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    mu, var = gp.predict(x)
+    for t in range(8):
+        np.testing.assert_array_equal(outs[t][0][:, 0], mu[t])
+        np.testing.assert_array_equal(outs[t][1][:, 0], var[t])
+    io["mailbox"] = False
+    for t in range(8):
+        o = gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1])
+        for a, b in zip(o, outs[t]):
+            np.testing.assert_array_equal(a, b)
+    lin2 = gp.linearize_predict(syn["p"][:1], syn["k_ff"][:1], True)
+    for a, b in zip(lin, lin2):
+        np.testing.assert_array_equal(a, b)
+    io["mailbox"] = True
+    # a flag that never comes is an error, not a hang
+    from safe_exploration_amd._lib import lib
+    from safe_exploration_amd import _buffers as B
+    assert lib.sr_wait_flag(B.ptr(io["h_flag"]), io["seq"] + 12345, 0.05) != 0
