@@ -251,6 +251,16 @@ int sr_gp_release_scratch(sr_gp_t h);
 int sr_publish(int device, const double* src_dev, int n, double* dst_host, unsigned long long* flag_host,
                unsigned long long seq, void* stream);
 int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s);
+/* One blocking single query as ONE command: the D coordinates x_host (host memory, read at call time) travel in the
+ * kernel arguments, the results go straight to the pinned host block
+ *   out_host = [mu n | var n | jac_mu n x D]                      (second_order == 0)
+ *              [... | jac_var n x D | hess_mu n x D x D]          (second_order != 0)
+ * and the last workgroup stores seq to *flag_host (pinned; wait with sr_wait_flag).  Available where the one-launch
+ * posterior applies (ARD-RBF, Np <= 384; Np = 512 for second order); SR_EUNSUPPORTED otherwise: use sr_gp_predict /
+ * sr_gp_linearize.  replaces SimpleGPModel.__call__ (ssm_gpy/gaussian_process.py:135-144) and
+ * linearize_predict(jacobians=True) as CasadiSSMEvaluator drives them (state_space_models.py:271-303, 384-417). */
+int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, double* out_host,
+                unsigned long long* flag_host, unsigned long long seq, void* stream);
 int sr_gp_last_chain(sr_gp_t h);
 /* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
  * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.

@@ -30,6 +30,7 @@ struct sr_gp {
     // groups stand at chain_base), switch
     double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;
     unsigned long long chain_base = 0; int chain_valid = 0; int chain = 1; int last_chain = 0;
+    unsigned* call_ticket = nullptr;        // sr_gp_call1: workgroups done (reset by the last one)
     int general = 0;
     int have_data = 0, factorized = 0;
     // per-chunk workspace (grow-only)
@@ -146,7 +147,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
-    dev_free(h->chain_xch); dev_free(h->chain_tickets);
+    dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->call_ticket);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (int d = 0; d < SR_FACT_SLOTS; ++d) {
@@ -1391,6 +1392,47 @@ extern "C" int sr_wait_flag(const unsigned long long* flag_host, unsigned long l
     }
     sr_set_error("sr_wait_flag: sequence %llu not seen within %.3f s (flag = %llu)", seq, timeout_s, *f);
     return SR_ESTATE;
+}
+
+// One blocking single query in ONE command: x (host memory, D doubles, read NOW) travels in the kernel arguments, the
+// results go straight to the pinned host block out_host = [mu n | var n | jac_mu n x D (| jac_var n x D | hess n x D x D)]
+// and the last workgroup writes `seq` to *flag_host (both pinned; wait with sr_wait_flag).  Only where the one-launch
+// posterior of sr_small.hip applies (ARD-RBF, Np <= 384, and 512 with second order); SR_EUNSUPPORTED otherwise -- the
+// caller then takes sr_gp_predict / sr_gp_linearize with its own copies.
+// replaces the body of SimpleGPModel.__call__ / linearize_predict as CasadiSSMEvaluator drives them
+// (/root/reference/safe_exploration/state_space_models.py:271-303, 384-417; ssm_gpy/gaussian_process.py:135-144).
+extern "C" int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, double* out_host,
+                           unsigned long long* flag_host, unsigned long long seq, void* stream) {
+    SR_CHECK(h != nullptr && x_host && out_host && flag_host, SR_EINVAL, "sr_gp_call1: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_call1: model not factorized");
+    if (!(h->small_path == 1 && !h->general && h->n_xin == 0 &&
+          sr_gp_small_wanted(h->Np, second_order ? SR_SMALL_T : 1, h->D, false))) {
+        sr_set_error("sr_gp_call1: no one-launch posterior for this model (Np=%d, general=%d)", h->Np, h->general);
+        return SR_EUNSUPPORTED;
+    }
+    SR_DEVICE(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (!h->call_ticket) {
+        SR_TRY(dev_alloc(&h->call_ticket, 1));
+        SR_HIP(hipMemset(h->call_ticket, 0, sizeof(unsigned)));
+    }
+    double* out = nullptr;
+    unsigned long long* flag = nullptr;
+    SR_HIP(hipHostGetDevicePointer((void**)&out, out_host, 0));
+    SR_HIP(hipHostGetDevicePointer((void**)&flag, flag_host, 0));
+    const int n = h->n_out, D = h->D;
+    sr_kstar_args ka{};
+    ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.xa = nullptr; ka.lda = D; ka.na = D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
+    ka.N = h->N; ka.Np = h->Np; ka.D = D; ka.n_out = n; ka.nsplit = 1; ka.T = 1; ka.Tp = 1;
+    ka.xv_on = 1;
+    for (int j = 0; j < D; ++j) ka.xv[j] = x_host[j];
+    ka.done_ticket = h->call_ticket; ka.host_flag = flag; ka.host_seq = seq;
+    h->last_streamed = 0;
+    sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
+    if (second_order)
+        return sr_launch_gp_small_lin(ka, h->Wt, out, out + n, out + 2 * n, out + 2 * n + n * D, out + 2 * n + 2 * n * D, s);
+    return sr_launch_gp_small(ka, h->Wt, out, out + n, out + 2 * n, s);
 }
 
 extern "C" int sr_gp_release_scratch(sr_gp_t h) {

@@ -162,6 +162,10 @@ struct sr_kstar_args {
     double* jac_part;       // nsplit x n_out x D x Tp
     int N, Np, D, n_out, nsplit;
     long T, Tp;
+    // one-launch blocking single query (sr_gp_call1; K0 only): the query travels in the kernel arguments, the results
+    // go straight to pinned host memory and the last workgroup writes the sequence number the host spins on
+    int xv_on = 0; double xv[SR_MAX_D] = {};
+    unsigned* done_ticket = nullptr; unsigned long long* host_flag = nullptr; unsigned long long host_seq = 0;
 };
 int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 

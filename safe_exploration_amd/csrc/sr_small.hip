@@ -185,7 +185,7 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
         for (int j = 0; j < DT; ++j) {
             il[j] = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
             xs[j] = 0.0;
-            if (live && j < a.D) xs[j] = (j < a.na) ? xa[qt * lda + j] : xb[qt * ldb + (j - a.na)];
+            if (live && j < a.D) xs[j] = a.xv_on ? a.xv[j] : ((j < a.na) ? xa[qt * lda + j] : xb[qt * ldb + (j - a.na)]);
         }
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
@@ -315,6 +315,20 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         double v = sf2 - qn;
         if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
         var[(t0 + tid) * a.n_out + d] = v;
+    }
+
+    if (a.host_flag) {
+        // blocking single query: the outputs above went to pinned host memory; once every workgroup's stores are
+        // out (system-scope fence), the last one to arrive publishes the sequence number
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == gridDim.x * gridDim.y - 1u) {
+                __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 

@@ -61,7 +61,8 @@ class _Handle(object):
                   "d_in": torch.empty((1, D), dtype=torch.float64, device=self.device),
                   "d_out": torch.empty(total, dtype=torch.float64, device=self.device),
                   "h_out": torch.empty(total, dtype=torch.float64).pin_memory(),
-                  "h_flag": torch.zeros(1, dtype=torch.int64).pin_memory(), "seq": 0, "mailbox": True}
+                  "h_flag": torch.zeros(1, dtype=torch.int64).pin_memory(), "seq": 0, "mailbox": True,
+                  "direct": True}
             o = io["d_out"]
             io["mu"], io["var"] = o[:n], o[n:2 * n]
             io["jm"] = o[2 * n:2 * n + n * D]
@@ -70,6 +71,26 @@ class _Handle(object):
             io["h_in_np"], io["h_out_np"] = io["h_in"].numpy(), io["h_out"].numpy()
             self._single_io = io
         return io
+
+    def call1(self, x, second_order, k, stream):
+        """One blocking single query as ONE command (sr_gp_call1: query in the kernel arguments, results and sequence
+        number written to the pinned block by the posterior kernel itself).  Returns the first k doubles of the
+        packed result, or None where the library has no one-launch posterior for this model."""
+        io = self._single_io
+        if not (io["direct"] and io["mailbox"]):
+            return None
+        io["h_in_np"][:] = x
+        io["seq"] += 1
+        rc = lib.sr_gp_call1(self.h, B.ptr(io["h_in"]), int(second_order), B.ptr(io["h_out"]), B.ptr(io["h_flag"]),
+                             io["seq"], ctypes.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            io["direct"] = False               # SR_EUNSUPPORTED (model too large / general kernel) or unpinned block
+            return None
+        rc = lib.sr_wait_flag(B.ptr(io["h_flag"]), io["seq"], 5.0)
+        if rc != 0:
+            stream.synchronize()
+            check(rc)
+        return io["h_out_np"][:k].copy()
 
     def fetch(self, k, stream):
         """first k doubles of the packed device block -> NumPy (copy), blocking."""
@@ -636,9 +657,12 @@ class SimpleGPModel(StateSpaceModel):
         if states.shape[1] + actions.shape[1] != D:
             raise ValueError("states and actions must have {} columns together".format(D))
         io = hd.single_io()
+        stream = torch.cuda.current_stream(hd.device)
+        o = hd.call1(np.concatenate((states[0], actions[0])), False, 2 * n + n * D, stream)
+        if o is not None:
+            return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
         io["h_in_np"][:states.shape[1]] = states[0]
         io["h_in_np"][states.shape[1]:] = actions[0]
-        stream = torch.cuda.current_stream(hd.device)
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
         check(lib.sr_gp_predict(hd.h, B.ptr(io["d_in"]), 1, B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
                                 ctypes.c_void_p(stream.cuda_stream)))
@@ -689,13 +713,16 @@ class SimpleGPModel(StateSpaceModel):
         if x.size != D:
             raise ValueError("x must have {} entries".format(D))
         io = hd.single_io()
-        io["h_in_np"][:] = x
         stream = torch.cuda.current_stream(hd.device)
+        a, b, c = 2 * n, 2 * n + n * D, 2 * n + 2 * n * D
+        o = hd.call1(x, True, io["d_out"].numel(), stream)
+        if o is not None:
+            return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
+        io["h_in_np"][:] = x
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
         check(lib.sr_gp_linearize(hd.h, B.ptr(io["d_in"]), B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
                                   B.ptr(io["jv"]), B.ptr(io["hm"]), ctypes.c_void_p(stream.cuda_stream)))
         o = hd.fetch(io["d_out"].numel(), stream)
-        a, b, c = 2 * n, 2 * n + n * D, 2 * n + 2 * n * D
         return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
 
     def predict_with_jacobians(self, states, actions):

@@ -31,13 +31,16 @@ def main():
         io = gp._handle.single_io()
         x = B.as_dev(np.hstack((prob["p"][:1], prob["k_ff"][:1])), gp.device)
         row = {}
-        for mb in (False, True):
-            io["mailbox"] = mb
-            row[mb] = (t(lambda: gp(prob["p"][:1], prob["k_ff"][:1])),
-                       t(lambda: gp.linearize_predict(prob["p"][:1], prob["k_ff"][:1], True)))
-        print("n_s=%d N=%5d  __call__: copy+sync %.1f us, mailbox %.1f us | linearize_predict(jacobians=True): %.1f -> %.1f us"
-              " | kernel alone (async) %.1f us" % (n_s, N, row[False][0], row[True][0], row[False][1], row[True][1],
-                                                   t(lambda: gp.predict_device(x, True))), flush=True)
+        for mode, (mb, di) in (("sync", (False, False)), ("mailbox", (True, False)), ("direct", (True, True))):
+            io["mailbox"], io["direct"] = mb, di
+            row[mode] = (t(lambda: gp(prob["p"][:1], prob["k_ff"][:1])),
+                         t(lambda: gp.linearize_predict(prob["p"][:1], prob["k_ff"][:1], True)))
+            if mode == "direct" and not io["direct"]:
+                row[mode] = (float("nan"), float("nan"))
+        print("n_s=%d N=%5d  __call__: copy+sync %.1f us, mailbox %.1f, one command %.1f | linearize_predict(jacobians=True): "
+              "%.1f, %.1f, %.1f us | kernel alone (async) %.1f us" % (
+                  n_s, N, row["sync"][0], row["mailbox"][0], row["direct"][0], row["sync"][1], row["mailbox"][1],
+                  row["direct"][1], t(lambda: gp.predict_device(x, True))), flush=True)
         del gp
 
 

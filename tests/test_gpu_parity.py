@@ -1344,12 +1344,23 @@ def test_single_query_mailbox_and_fallback_agree():
     syn = orc.make_synthetic(17, 300, 2, 1, 8)
     gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
     io = gp._handle.single_io()
-    assert io["mailbox"]
+    assert io["mailbox"] and io["direct"]
+    # (a) one command per call: query in the kernel arguments, results + sequence number written by the posterior kernel
+    direct = [gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1]) for t in range(8)]
+    lin_direct = gp.linearize_predict(syn["p"][:1], syn["k_ff"][:1], True)
+    assert io["direct"] and io["seq"] == 9
+    # (b) copy in, kernel, sr_publish: what a model without a one-launch posterior takes
+    io["direct"] = False
     outs = []
     for t in range(8):
         outs.append(gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1]))
-    assert io["mailbox"] and io["seq"] == 8            # the fast route stayed on
+    assert io["mailbox"] and io["seq"] == 17           # the mailbox route stayed on
     lin = gp.linearize_predict(syn["p"][:1], syn["k_ff"][:1], True)
+    for t in range(8):
+        for a, b in zip(direct[t], outs[t]):
+            np.testing.assert_array_equal(a, b)
+    for a, b in zip(lin_direct, lin):
+        np.testing.assert_array_equal(a, b)
     x = np.hstack((syn["p"], syn["k_ff"]))
     mu, var = gp.predict(x)
     for t in range(8):
@@ -1364,6 +1375,14 @@ def test_single_query_mailbox_and_fallback_agree():
     for a, b in zip(lin, lin2):
         np.testing.assert_array_equal(a, b)
     io["mailbox"] = True
+    # a model beyond the one-launch sizes declines the direct route and stays correct
+    syn2 = orc.make_synthetic(18, 900, 2, 1, 4)
+    gp2 = hip_model(syn2["Z"], syn2["Y"], syn2["lengthscale"], syn2["signal_var"], syn2["noise_var"], 2, 1)
+    o2 = gp2(syn2["p"][:1], syn2["k_ff"][:1])
+    assert not gp2._handle.single_io()["direct"]
+    mu2, var2 = gp2.predict(np.hstack((syn2["p"][:1], syn2["k_ff"][:1])))
+    np.testing.assert_array_equal(o2[0][:, 0], mu2[0])
+    np.testing.assert_array_equal(o2[1][:, 0], var2[0])
     # a flag that never comes is an error, not a hang
     from safe_exploration_amd._lib import lib
     from safe_exploration_amd import _buffers as B
