@@ -69,24 +69,24 @@ class _Handle(object):
             io["jv"] = o[2 * n + n * D:2 * n + 2 * n * D]
             io["hm"] = o[2 * n + 2 * n * D:]
             io["h_in_np"], io["h_out_np"] = io["h_in"].numpy(), io["h_out"].numpy()
+            io["p_in"], io["p_out"], io["p_flag"] = B.ptr(io["h_in"]), B.ptr(io["h_out"]), B.ptr(io["h_flag"])
             self._single_io = io
         return io
 
-    def call1(self, x, second_order, k, stream):
-        """One blocking single query as ONE command (sr_gp_call1: query in the kernel arguments, results and sequence
-        number written to the pinned block by the posterior kernel itself).  Returns the first k doubles of the
-        packed result, or None where the library has no one-launch posterior for this model."""
+    def call1(self, second_order, k, stream):
+        """One blocking single query as ONE command (sr_gp_call1: the query, already in the pinned input block, travels
+        in the kernel arguments; results and sequence number are written to the pinned block by the posterior kernel
+        itself).  Returns the first k doubles of the packed result, or None where the library has no one-launch
+        posterior for this model."""
         io = self._single_io
         if not (io["direct"] and io["mailbox"]):
             return None
-        io["h_in_np"][:] = x
-        io["seq"] += 1
-        rc = lib.sr_gp_call1(self.h, B.ptr(io["h_in"]), int(second_order), B.ptr(io["h_out"]), B.ptr(io["h_flag"]),
-                             io["seq"], ctypes.c_void_p(stream.cuda_stream))
+        io["seq"] = seq = io["seq"] + 1
+        rc = lib.sr_gp_call1(self.h, io["p_in"], second_order, io["p_out"], io["p_flag"], seq, stream.cuda_stream)
         if rc != 0:
             io["direct"] = False               # SR_EUNSUPPORTED (model too large / general kernel) or unpinned block
             return None
-        rc = lib.sr_wait_flag(B.ptr(io["h_flag"]), io["seq"], 5.0)
+        rc = lib.sr_wait_flag(io["p_flag"], seq, 5.0)
         if rc != 0:
             stream.synchronize()
             check(rc)
@@ -658,11 +658,11 @@ class SimpleGPModel(StateSpaceModel):
             raise ValueError("states and actions must have {} columns together".format(D))
         io = hd.single_io()
         stream = torch.cuda.current_stream(hd.device)
-        o = hd.call1(np.concatenate((states[0], actions[0])), False, 2 * n + n * D, stream)
-        if o is not None:
-            return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
         io["h_in_np"][:states.shape[1]] = states[0]
         io["h_in_np"][states.shape[1]:] = actions[0]
+        o = hd.call1(0, 2 * n + n * D, stream)
+        if o is not None:
+            return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
         check(lib.sr_gp_predict(hd.h, B.ptr(io["d_in"]), 1, B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
                                 ctypes.c_void_p(stream.cuda_stream)))
@@ -715,10 +715,10 @@ class SimpleGPModel(StateSpaceModel):
         io = hd.single_io()
         stream = torch.cuda.current_stream(hd.device)
         a, b, c = 2 * n, 2 * n + n * D, 2 * n + 2 * n * D
-        o = hd.call1(x, True, io["d_out"].numel(), stream)
+        io["h_in_np"][:] = x
+        o = hd.call1(1, io["d_out"].numel(), stream)
         if o is not None:
             return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
-        io["h_in_np"][:] = x
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
         check(lib.sr_gp_linearize(hd.h, B.ptr(io["d_in"]), B.ptr(io["mu"]), B.ptr(io["var"]), B.ptr(io["jm"]),
                                   B.ptr(io["jv"]), B.ptr(io["hm"]), ctypes.c_void_p(stream.cuda_stream)))
