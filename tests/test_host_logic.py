@@ -358,3 +358,26 @@ def test_dlqr_and_name_aliases_vs_reference_golden():
         assert np.abs(ev).max() < 1.0
     from safe_exploration_amd import uncertainty_propagation_casadi as upc, uncertainty_propagation as up
     assert upc.multi_step_taylor_symbolic is up.multi_step_taylor and upc.mean_equivalent_multistep is up.mean_equivalent_multistep
+
+
+def test_wait_flag_is_host_code_and_times_out():
+    """sr_wait_flag is the host half of the completion mailbox: it returns at once when the sequence number is there,
+    sees a store from another thread, and gives up after its timeout instead of hanging a CasADi callback."""
+    import ctypes
+    import threading
+    import time
+    from safe_exploration_amd._lib import lib, SR_OK
+    flag = (ctypes.c_ulonglong * 1)(41)
+    assert lib.sr_wait_flag(ctypes.cast(flag, ctypes.c_void_p), 41, 0.01) == SR_OK
+    t0 = time.perf_counter()
+    assert lib.sr_wait_flag(ctypes.cast(flag, ctypes.c_void_p), 42, 0.05) != SR_OK
+    assert 0.04 < time.perf_counter() - t0 < 2.0
+    assert b"42" in lib.sr_last_error()
+
+    def later():
+        time.sleep(0.02)
+        flag[0] = 42
+    th = threading.Thread(target=later)
+    th.start()
+    assert lib.sr_wait_flag(ctypes.cast(flag, ctypes.c_void_p), 42, 5.0) == SR_OK
+    th.join()
