@@ -1086,6 +1086,11 @@ static int check_reach_dims(const sr_gp* h, int* n_s, int* n_u) {
     return SR_OK;
 }
 
+static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const double* q0, const double* k_fb0,
+                     const double* k_ff, const double* k_fb, const double* a, const double* b, const double* l_mu,
+                     const double* l_sigma, double c_safety, double* p_all, double* q_all, double* gp_var_all,
+                     int* n_bad, int n_s, int n_u, hipStream_t s, bool* taken);
+
 extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double* q,
                                 const double* k_ff, const double* k_fb, const double* a,
                                 const double* b, const double* l_mu, const double* l_sigma,
@@ -1102,6 +1107,16 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
     SR_TRY(check_reach_dims(h, &n_s, &n_u));
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
+    h->last_chain = 0;
+    if (n_s <= 2) {
+        // small model, few states: posterior and ellipsoid step in one launch (the chain kernel with H = 1): 24.5 ->
+        // 21.5 us per call at N = 200 (host-bound from there).  Not for n_s >= 3: the Jacobi rotations of the
+        // eigenvalue bound run on one lane per state inside a 512-thread workgroup there (cart-pole: 25 -> 35 us).
+        bool chained = false;
+        SR_TRY(try_chain(h, T, 1, 0, p, q, k_fb, k_ff, nullptr, a, b, l_mu, l_sigma, c_safety, p_out, q_out, var_out,
+                         n_bad, n_s, n_u, s, &chained));
+        if (chained) return SR_OK;
+    }
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
         double* var_dst = var_out ? var_out + t0 * n_s : nullptr;
@@ -1127,17 +1142,13 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
     return SR_OK;
 }
 
-// shared H-step chain: mode 0 = robust ellipsoids (gp_reachability.py:159-212),
-// mode 1/2 = Taylor / mean-equivalent Gaussian moments (uncertainty_propagation_casadi.py:88-190)
-static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, const double* q0,
-                          const double* k_fb0, const double* k_ff, const double* k_fb, const double* a,
-                          const double* b, const double* l_mu, const double* l_sigma, double c_safety,
-                          double* p_all, double* q_all, double* gp_var_all, int* n_bad, hipStream_t s) {
-    int n_s, n_u;
-    SR_TRY(check_reach_dims(h, &n_s, &n_u));
-    SR_DEVICE(h->device);
+// The persistent kernel of sr_small.hip (K0c) for a chain of H >= 1 steps, where it applies; *taken says whether it ran.
+static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const double* q0, const double* k_fb0,
+                     const double* k_ff, const double* k_fb, const double* a, const double* b, const double* l_mu,
+                     const double* l_sigma, double c_safety, double* p_all, double* q_all, double* gp_var_all,
+                     int* n_bad, int n_s, int n_u, hipStream_t s, bool* taken) {
+    *taken = false;
     const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
-    h->last_chain = 0;
     // small model, few rollouts: the whole chain in one launch (sr_small.hip K0c).  One launch holds SR_CHAIN_GROUPS
     // workgroups = gmax groups of 16 rollouts; a second launch costs as much again, which only pays where the per-step
     // route has left its one-launch posterior (T > SR_FUSED_T).  Measured at N = 200, H = 15: 256 rollouts 241 -> 148 us,
@@ -1145,7 +1156,7 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
     const int parts = h->Np / 128;                                      // workgroups sharing one (group, output)
     const int gmax = std::max(1, SR_CHAIN_GROUPS / (n_s * std::max(parts, 1)));   // groups of 16 rollouts per launch
     const long chain_launches = ((T + SR_SMALL_T - 1) / SR_SMALL_T + gmax - 1) / gmax;
-    if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 && H >= 2 &&
+    if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 &&
         (chain_launches == 1 || (chain_launches == 2 && T > SR_FUSED_T)) &&
         sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
         if (!h->chain_xch) {
@@ -1176,8 +1187,27 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
             h->chain_valid = groups;
         }
         h->last_chain = 1;
+        *taken = true;
         return SR_OK;
     }
+    return SR_OK;
+}
+
+// shared H-step chain: mode 0 = robust ellipsoids (gp_reachability.py:159-212),
+// mode 1/2 = Taylor / mean-equivalent Gaussian moments (uncertainty_propagation_casadi.py:88-190)
+static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, const double* q0,
+                          const double* k_fb0, const double* k_ff, const double* k_fb, const double* a,
+                          const double* b, const double* l_mu, const double* l_sigma, double c_safety,
+                          double* p_all, double* q_all, double* gp_var_all, int* n_bad, hipStream_t s) {
+    int n_s, n_u;
+    SR_TRY(check_reach_dims(h, &n_s, &n_u));
+    SR_DEVICE(h->device);
+    const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
+    h->last_chain = 0;
+    bool chained = false;
+    SR_TRY(try_chain(h, T, H, mode, p0, q0, k_fb0, k_ff, k_fb, a, b, l_mu, l_sigma, c_safety, p_all, q_all, gp_var_all,
+                     n_bad, n_s, n_u, s, &chained));
+    if (chained) return SR_OK;
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
         SR_TRY(ensure_ws(h, round_up(Tc, srt::BN), pick_nsplit(h, round_up(Tc, srt::BN))));
