@@ -82,7 +82,12 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
         const double df = M[0][0] - M[1][1];
         return 0.5 * (tr + sqrt(fma(df, df, 4.0 * M[0][1] * M[0][1])));
     }
-    // cyclic Jacobi (eigenvalues only)
+    // cyclic Jacobi (eigenvalues only).  Stops when the squared off-diagonal norm is below 1e-26 of the squared
+    // diagonal norm: the eigenvalue error is bounded by off^2 / (2 gap), i.e. far below one ulp unless two eigenvalues
+    // agree to 13 digits -- and then by their difference.  One rotation costs one sqrt, one division and one rsqrt:
+    //   t = sgn(d) 2 a / (|d| + sqrt(d^2 + 4 a^2)),  d = M_rr - M_pp, a = M_pr;   c = 1 / sqrt(1 + t^2),  s = t c
+    // (the textbook form through theta = d / 2a takes two square roots and three divisions; on one lane per query the
+    // rotations are the whole cost of the step for n_s >= 3: 10 us per step inside the persistent chain kernel).
     for (int sweep = 0; sweep < 24; ++sweep) {
         double off = 0.0, dia = 0.0;
 #pragma unroll
@@ -92,7 +97,7 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
             for (int j = 0; j < NS; ++j)
                 if (j > i) off = fma(M[i][j], M[i][j], off);
         }
-        if (off <= 1e-34 * dia || off == 0.0) break;
+        if (off <= 1e-26 * dia || off == 0.0) break;
 #pragma unroll
         for (int p = 0; p < NS; ++p)
 #pragma unroll
@@ -100,10 +105,11 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
                 if (r > p) {
                     const double apr = M[p][r];
                     if (apr != 0.0) {
-                        const double theta = (M[r][r] - M[p][p]) / (2.0 * apr);
-                        const double tt = ((theta >= 0.0) ? 1.0 : -1.0) /
-                                          (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-                        const double c = 1.0 / sqrt(fma(tt, tt, 1.0));
+                        const double dd = M[r][r] - M[p][p];
+                        const double two_a = 2.0 * apr;
+                        const double den = fabs(dd) + sqrt(fma(dd, dd, two_a * two_a));
+                        const double tt = ((dd >= 0.0) ? two_a : -two_a) / den;
+                        const double c = rsqrt(fma(tt, tt, 1.0));
                         const double s = tt * c;
 #pragma unroll
                         for (int k = 0; k < NS; ++k) {   // columns p, r
