@@ -1588,8 +1588,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         h->app_cap = need;
     }
     double* ws = h->app_ws;
-    double *U12t = ws + o_u12, *Xt = ws + o_xt, *Y2 = ws + o_y2, *G = ws + o_g, *Sb = ws + o_sb, *invS = ws + o_inv,
-           *wdm = ws + o_wdm;
+    double *U12t = ws + o_u12, *Xt = ws + o_xt, *Y2 = ws + o_y2, *G = ws + o_g, *Sb = ws + o_sb, *invS = ws + o_inv;
     int* info_dev = reinterpret_cast<int*>(ws + o_info);
     double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;
     const bool reuse_alt = (Np1 == Np0) && h->Wt_alt && h->wt_alt_cap >= (size_t)n_out * NN1;
@@ -1638,7 +1637,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], Sb, m, SR_NB, D, s));
         else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], Sb, m, SR_NB, D, s));
         SR_A(sr_launch_sub_block(Sb, G, pf, s));                                                   // S = C - G
-        SR_A(sr_launch_potrf_diag(Sb, SR_NB, invS, wdm, SR_NB, 0, info_dev + d, s));               // invS = U22^-1
+        SR_A(sr_launch_potrf_corner16(Sb, SR_NB, invS, SR_NB, info_dev + d, s));                   // invS = U22^-1 (m <= 16: last pivot)
         SR_A(sr_launch_append_small(u12, Wt0, Np0, m, 1, nullptr, invS, Xt, Y2, s));               // Y2 = -U^-1 U12 U22^-1
         SR_A(sr_launch_append_assemble(Wt0, Np0, off0, N0, Y2, invS, m, Wt1 + (size_t)d * NN1, Np1, off1, s));
         // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1

@@ -122,6 +122,7 @@ int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, 
                    int Np, int D, hipStream_t s);
 // factor the diagonal block kb of the Np x Np matrix A (upper), write U_kk in place, U_kk^-1 to
 // wt_diag (into Wt's diagonal block) and U_kk^-T to w_diag (into W's diagonal block).
+int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s);
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
                          int kb, int* info_dev, hipStream_t s, int skip = 0);
 int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s);

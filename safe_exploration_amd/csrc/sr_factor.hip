@@ -570,6 +570,42 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
     }
 }
 
+// The Schur complement of a row append of m <= 16 points lives in the LAST 16 x 16 pivot of an otherwise identity
+// 128 x 128 block: one wavefront factors and inverts that corner (3 us; the full kernel takes 62 us on the way of every
+// appended point).  Writes rows / columns 112 .. 127 of wt_diag (= U22^-1, upper) only.
+__global__ __launch_bounds__(64) void sr_potrf_corner16_kernel(double* A, long lda, double* wt_diag, long ldw,
+                                                               int* info) {
+    __shared__ double S[16 * SR_PD_LD];
+    __shared__ double X[16 * SR_PD_XLD];
+    __shared__ double invd[16];
+    __shared__ int fail;
+    const int lane = threadIdx.x, c0 = SR_NB - 16;
+    if (lane == 0) fail = 0;
+    for (int idx = lane; idx < 256; idx += 64) {
+        const int r = idx >> 4, c = idx & 15;
+        S[r * SR_PD_LD + c] = (c >= r) ? A[(long)(c0 + r) * lda + c0 + c] : 0.0;
+    }
+    __syncthreads();
+    sr_factor16(S, 0, invd, &fail, lane);
+    __syncthreads();
+    sr_invert16(S, 0, invd, X, lane);
+    __syncthreads();
+    const bool bad = fail != 0;
+    if (bad && lane == 0 && *info == 0) *info = c0 + fail;
+    for (int idx = lane; idx < 256; idx += 64) {
+        const int r = idx >> 4, c = idx & 15;
+        const double eye = (r == c) ? 1.0 : 0.0;
+        A[(long)(c0 + r) * lda + c0 + c] = bad ? eye : ((c >= r) ? S[r * SR_PD_LD + c] : 0.0);
+        wt_diag[(long)(c0 + r) * ldw + c0 + c] = bad ? eye : X[r * SR_PD_XLD + c];
+    }
+}
+
+int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s) {
+    hipLaunchKernelGGL(sr_potrf_corner16_kernel, dim3(1), dim3(64), 0, s, A, lda, wt_diag, ldw, info_dev);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw, int kb,
                          int* info_dev, hipStream_t s, int skip) {
     hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
@@ -715,14 +751,34 @@ __global__ __launch_bounds__(256) void sr_append_alpha_kernel(const double* __re
                                                               const double* __restrict__ Ynew, int m,
                                                               double* __restrict__ alpha1, int Np1, int qoff) {
     // qoff: position of the first new point among the queries of the K* pass (front-padded query block: 128 - m)
-    __shared__ double r[SR_NB], v2[SR_NB];
+    __shared__ double r[SR_NB], v2[SR_NB], red[4][16];
     const int pf = SR_NB - m, off0 = Np0 - N0, off1 = Np1 - (N0 + m);
-    if (threadIdx.x < m) {
-        double mu = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) mu += mu_part[((long)sp * n_out + d) * Tp + qoff + threadIdx.x];
-        r[threadIdx.x] = Ynew[(long)threadIdx.x * n_out + d] - mu;
+    // mean of the old model at the new points: the N-split partials of the K* pass, summed by the whole workgroup
+    // (one thread per point walking up to Np / 16 partials was 119 us of dependent-latency at N = 5000)
+    for (int q0 = 0; q0 < m; q0 += 16) {
+        double acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+        for (int sp = threadIdx.x; sp < nsplit; sp += 256) {
+            const double* src = mu_part + ((long)sp * n_out + d) * Tp + qoff + q0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q0 + q < m) acc[q] += src[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            double v = acc[q];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 && q0 + threadIdx.x < m) {
+            const int q = q0 + threadIdx.x;
+            const double mu = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            r[q] = Ynew[(long)q * n_out + d] - mu;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x < m) {
         double v = 0.0;
         for (int b = 0; b <= (int)threadIdx.x; ++b) v = fma(invS[(pf + b) * SR_NB + pf + threadIdx.x], r[b], v);
