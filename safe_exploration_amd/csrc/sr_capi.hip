@@ -56,6 +56,10 @@ struct sr_gp {
     // (kept while the padded size does not change: appends then allocate nothing big)
     double* app_ws = nullptr; size_t app_cap = 0;
     double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
+    int wt_alt_off = -1;     // front padding of the (complete, well-formed) factor Wt_alt last held; -1 unknown
+    // small appends allocate nothing while the padded size stays: Z has room for z_cap points, yT / alpha ping-pong
+    long z_cap = 0; double *yT_alt = nullptr, *alpha_alt = nullptr; int vec_alt_np = 0;
+    std::vector<double> sf2_host, noise_host;    // host copies of sf2 / noise (filled on first use after set_data)
     // up to SR_FACT_SLOTS outputs are in flight at once (output d uses slot d % n_par); every slot has a CRITICAL
     // stream (diagonal blocks, panel rows, look-ahead rows, inversion; slot 0: the caller's stream) and a BULK
     // stream (the trailing update behind the look-ahead rows)
@@ -122,7 +126,8 @@ extern "C" int sr_gp_create(sr_gp_t* out, int device, int N, int D, int n_out) {
     h->device = device; h->N = N; h->D = D; h->n_out = n_out;
     h->Np = (int)round_up(N, SR_NB);
     int rc = SR_OK;
-    if ((rc = dev_alloc(&h->Z, (size_t)N * D)) || (rc = dev_alloc(&h->yT, (size_t)n_out * h->Np)) ||
+    h->z_cap = h->Np;
+    if ((rc = dev_alloc(&h->Z, (size_t)h->Np * D)) || (rc = dev_alloc(&h->yT, (size_t)n_out * h->Np)) ||
         (rc = dev_alloc(&h->ls, (size_t)n_out * D)) || (rc = dev_alloc(&h->sf2, n_out)) ||
         (rc = dev_alloc(&h->noise, n_out)) || (rc = dev_alloc(&h->alpha, (size_t)n_out * h->Np))) {
         sr_gp_destroy(h);
@@ -148,6 +153,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
     dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->call_ticket);
+    dev_free(h->yT_alt); dev_free(h->alpha_alt);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (int d = 0; d < SR_FACT_SLOTS; ++d) {
@@ -191,6 +197,7 @@ extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const
     h->general = 0;
     h->have_data = 1;
     h->factorized = 0;
+    h->sf2_host.clear(); h->noise_host.clear();
     return SR_OK;
 }
 
@@ -207,6 +214,7 @@ extern "C" int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* 
                        h->yT, h->N, h->Np, h->n_out);
     SR_HIP(hipGetLastError());
     h->general = 1;
+    h->sf2_host.clear(); h->noise_host.clear();
     h->have_data = 1;
     h->factorized = 0;
     return SR_OK;
@@ -1472,8 +1480,9 @@ extern "C" int sr_gp_release_scratch(sr_gp_t h) {
     SR_DEVICE(h->device);
     SR_HIP(hipDeviceSynchronize());
     dev_free(h->fact_ws); h->fact_ws = nullptr; h->fact_cap = 0;
-    dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0;
+    dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1;
     dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
+    dev_free(h->yT_alt); dev_free(h->alpha_alt); h->yT_alt = h->alpha_alt = nullptr; h->vec_alt_np = 0;
     return SR_OK;
 }
 
@@ -1592,29 +1601,43 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     int* info_dev = reinterpret_cast<int*>(ws + o_info);
     double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;
     const bool reuse_alt = (Np1 == Np0) && h->Wt_alt && h->wt_alt_cap >= (size_t)n_out * NN1;
-    std::vector<double> sf2(n_out), noise(n_out);
+    // while the padded size stays, nothing is allocated: the new points go behind the old ones in Z (room for Np
+    // points), yT / alpha / U^-1 are written into the buffers the state before the previous append lived in
+    const bool z_inplace = N1 <= h->z_cap;
+    const bool vec_alt = (Np1 == Np0) && h->yT_alt && h->alpha_alt && h->vec_alt_np == Np1;
     int rc = SR_OK;
     auto drop_new = [&]() {
-        dev_free(Z1); dev_free(yT1); dev_free(alpha1);
+        if (!z_inplace) dev_free(Z1);
+        if (!vec_alt) { dev_free(yT1); dev_free(alpha1); }
         if (!reuse_alt) dev_free(Wt1);
     };
 #define SR_A(expr) do { rc = (expr); if (rc != SR_OK) { drop_new(); return rc; } } while (0)
 #define SR_AH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); drop_new(); return SR_EHIP; } } while (0)
-    SR_A(dev_alloc(&Z1, (size_t)N1 * D));
-    SR_A(dev_alloc(&yT1, (size_t)n_out * Np1));
-    SR_A(dev_alloc(&alpha1, (size_t)n_out * Np1));
+    if (z_inplace) Z1 = h->Z;
+    else SR_A(dev_alloc(&Z1, (size_t)Np1 * D));
+    if (vec_alt) { yT1 = h->yT_alt; alpha1 = h->alpha_alt; }
+    else {
+        SR_A(dev_alloc(&yT1, (size_t)n_out * Np1));
+        SR_A(dev_alloc(&alpha1, (size_t)n_out * Np1));
+    }
     if (reuse_alt) Wt1 = h->Wt_alt;
     else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
+    if ((int)h->sf2_host.size() != n_out) {              // first append after set_data: one blocking read
+        h->sf2_host.assign(n_out, 0.0); h->noise_host.assign(n_out, 0.0);
+        SR_AH(hipMemcpyAsync(h->sf2_host.data(), h->sf2, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+        SR_AH(hipMemcpyAsync(h->noise_host.data(), h->noise, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
+        SR_AH(hipStreamSynchronize(s));
+    }
+    const std::vector<double>& sf2 = h->sf2_host;
+    const std::vector<double>& noise = h->noise_host;
     SR_AH(hipMemsetAsync(info_dev, 0, sizeof(int) * n_out, s));
-    SR_AH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
-    SR_AH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
-    SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
+    if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
+    // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
     SR_AH(hipMemcpyAsync(Z1 + (size_t)N0 * D, Znew, sizeof(double) * m * D, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(sr_append_y_kernel, dim3((Np1 + 255) / 256, n_out), dim3(256), 0, s, h->yT, Np0, N0, Ynew, m,
                        yT1, Np1, n_out);
     SR_AH(hipGetLastError());
-    SR_AH(hipStreamSynchronize(s));
     // B = K(Z_old, Z_new) with the new points as queries, then U12 = U^-T B by streaming U^-1 once
     const long Tp = srt::BN;
     const int nsplit = pick_nsplit(h, Tp);
@@ -1638,8 +1661,13 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], Sb, m, SR_NB, D, s));
         SR_A(sr_launch_sub_block(Sb, G, pf, s));                                                   // S = C - G
         SR_A(sr_launch_potrf_corner16(Sb, SR_NB, invS, SR_NB, info_dev + d, s));                   // invS = U22^-1 (m <= 16: last pivot)
-        SR_A(sr_launch_append_small(u12, Wt0, Np0, m, 1, nullptr, invS, Xt, Y2, s));               // Y2 = -U^-1 U12 U22^-1
-        SR_A(sr_launch_append_assemble(Wt0, Np0, off0, N0, Y2, invS, m, Wt1 + (size_t)d * NN1, Np1, off1, s));
+        // Y2 = -U^-1 U12 U22^-1 and the move of the old factor to its new place in one pass over it; a buffer that
+        // did not hold an earlier state of this model is zeroed first (lower triangle, identity padding)
+        if (!(reuse_alt && h->wt_alt_off >= off1)) {
+            SR_AH(hipMemsetAsync(Wt1 + (size_t)d * NN1, 0, NN1 * sizeof(double), s));
+            SR_A(sr_launch_eye_front(Wt1 + (size_t)d * NN1, Np1, off1, s));
+        }
+        SR_A(sr_launch_append_move(Wt0, Np0, off0, N0, u12, invS, m, Xt, Y2, Wt1 + (size_t)d * NN1, Np1, off1, s));
         // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1
         SR_A(sr_launch_append_alpha(h->alpha + (size_t)d * Np0, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, d, Tp,
                                     Ynew, m, alpha1 + (size_t)d * Np1, Np1, s));
@@ -1656,22 +1684,28 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         if (info_h[d] != 0 && !bad) bad = d + 1;
     }
     if (bad) {
+        if (reuse_alt) h->wt_alt_off = -1;     // the spare factor buffer holds a half-written state now
         drop_new();
         sr_set_error("sr_gp_append: Schur complement not positive definite (output %d, point %d)", bad - 1, info_h[bad - 1]);
         return SR_ENOTPD;
     }
     double* old_wt = h->Wt;
-    dev_free(h->Z); dev_free(h->yT); dev_free(h->alpha);
-    h->Z = Z1; h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
+    double *old_yT = h->yT, *old_alpha = h->alpha;
+    if (!z_inplace) { dev_free(h->Z); h->Z = Z1; h->z_cap = Np1; }
+    h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
     h->N = N1;
     if (Np1 == Np0) {
+        if (!vec_alt) { dev_free(h->yT_alt); dev_free(h->alpha_alt); }
+        h->yT_alt = old_yT; h->alpha_alt = old_alpha; h->vec_alt_np = Np0;
         // keep the previous buffer for the next append (bounded: not for huge factors)
         if (!reuse_alt) dev_free(h->Wt_alt);
-        if ((size_t)n_out * NN0 * sizeof(double) <= SR_FACT_PAR_BYTES * 2) { h->Wt_alt = old_wt; h->wt_alt_cap = (size_t)n_out * NN0; }
-        else { dev_free(old_wt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; }
+        if ((size_t)n_out * NN0 * sizeof(double) <= SR_FACT_PAR_BYTES * 2) { h->Wt_alt = old_wt; h->wt_alt_cap = (size_t)n_out * NN0; h->wt_alt_off = off0; }
+        else { dev_free(old_wt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1; }
     } else {
         dev_free(old_wt);
-        dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0;
+        dev_free(old_yT); dev_free(old_alpha);
+        dev_free(h->yT_alt); dev_free(h->alpha_alt); h->yT_alt = h->alpha_alt = nullptr; h->vec_alt_np = 0;
+        dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1;
         h->Np = Np1;
         free_ws(h);
         dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
@@ -1792,16 +1826,17 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     double* old_wt = h->Wt;
     dev_free(h->Z); dev_free(h->yT); dev_free(h->alpha);
     h->Z = Z1; h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
+    h->z_cap = N1;
     h->N = N1;
     if (Np1 == Np0) {
         // keep the previous buffer for the next append (bounded: not for huge factors)
         if (!reuse_alt) dev_free(h->Wt_alt);
-        if ((size_t)n_out * NN0 * sizeof(double) <= SR_FACT_PAR_BYTES * 2) { h->Wt_alt = old_wt; h->wt_alt_cap = (size_t)n_out * NN0; }
-        else { dev_free(old_wt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; }
+        if ((size_t)n_out * NN0 * sizeof(double) <= SR_FACT_PAR_BYTES * 2) { h->Wt_alt = old_wt; h->wt_alt_cap = (size_t)n_out * NN0; h->wt_alt_off = off0; }
+        else { dev_free(old_wt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1; }
     } else {
         // everything sized by Np is dropped and re-created lazily
         dev_free(old_wt);
-        dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0;
+        dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1;
         h->Np = Np1;
         free_ws(h);
         dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);

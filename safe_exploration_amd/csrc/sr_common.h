@@ -122,6 +122,9 @@ int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, 
                    int Np, int D, hipStream_t s);
 // factor the diagonal block kb of the Np x Np matrix A (upper), write U_kk in place, U_kk^-1 to
 // wt_diag (into Wt's diagonal block) and U_kk^-T to w_diag (into W's diagonal block).
+int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const double* U12t, const double* invS, int m,
+                          double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s);
+int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s);
 int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s);
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
                          int kb, int* info_dev, hipStream_t s, int skip = 0);

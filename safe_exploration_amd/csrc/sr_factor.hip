@@ -740,6 +740,82 @@ __global__ __launch_bounds__(256) void sr_append_y2_kernel(const double* __restr
     }
 }
 
+// The new columns and the move of the old factor in ONE pass: wavefront per OLD padded row `row` (real index i):
+//   acc[c]      = sum_{k >= row} Wt0[row][k] Xt[c][k]                       (Y2 = -U^-1 X, as sr_append_y2_kernel)
+//   Wt1[r][..]  = the same row, shifted to the new padding (r = off1 + i), upper part only, + the m new entries -acc
+// and one extra workgroup writes the rows of the new points (U22^-1).  Everything below the diagonal of Wt1 and its
+// identity padding must already be in place (a buffer that held an earlier state of the same model, or zeroed +
+// sr_launch_eye_front): the copy through sr_append_assemble_kernel read and wrote the full square, zeros included --
+// 525 MB per output and append at N = 5000 against 210 MB here.
+template <int MC>
+__global__ __launch_bounds__(256) void sr_append_move_kernel(const double* __restrict__ Wt0, int Np0, int off0, int N0,
+                                                             const double* __restrict__ Xt,
+                                                             const double* __restrict__ invS, int m,
+                                                             double* __restrict__ Y2, double* __restrict__ Wt1,
+                                                             int Np1, int off1) {
+    const int lane = threadIdx.x & 63, pf = SR_NB - m;
+    const int nrow_blocks = (Np0 + 3) / 4;
+    if ((int)blockIdx.x >= nrow_blocks) {
+        // rows of the new points: Wt1[off1 + N0 + q][off1 + N0 + c] = U22^-1[q][c]
+        for (int e = threadIdx.x; e < m * m; e += 256) {
+            const int q = e / m, c = e % m;
+            if (c >= q) Wt1[(long)(off1 + N0 + q) * Np1 + off1 + N0 + c] = invS[(pf + q) * SR_NB + pf + c];
+        }
+        return;
+    }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Np0 || row < off0) return;                   // old padding rows carry nothing
+    const int shift = off1 - off0;                          // new column index = old + shift
+    double* dst = Wt1 + (long)(row + shift) * Np1 + shift;
+    double acc[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) acc[c] = 0.0;
+    for (int k = row + lane; k < Np0; k += 64) {
+        const double w = Wt0[(long)row * Np0 + k];
+        dst[k] = w;
+#pragma unroll
+        for (int c = 0; c < MC; ++c)
+            if (c < m) acc[c] = fma(w, Xt[(long)c * Np0 + k], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        double v = acc[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && c < m) {
+            Y2[(long)row * SR_NB + pf + c] = -v;
+            dst[Np0 + c] = -v;                               // column off1 + N0 + c of the new matrix
+        }
+    }
+}
+
+// ones on the first n diagonal entries (identity padding of a zeroed matrix)
+__global__ __launch_bounds__(256) void sr_eye_front_kernel(double* __restrict__ W, int ld, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) W[(long)i * ld + i] = 1.0;
+}
+
+int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s) {
+    if (n <= 0) return SR_OK;
+    hipLaunchKernelGGL(sr_eye_front_kernel, dim3((n + 255) / 256), dim3(256), 0, s, W, ld, n);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const double* U12t, const double* invS, int m,
+                          double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s) {
+    hipLaunchKernelGGL(sr_append_xt_kernel, dim3((Np0 + 255) / 256, m), dim3(256), 0, s, U12t, invS, Np0, m, Xt);
+    SR_HIP(hipGetLastError());
+    const dim3 grid((Np0 + 3) / 4 + 1);
+    if (m <= 1)
+        hipLaunchKernelGGL(sr_append_move_kernel<1>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1);
+    else if (m <= 4)
+        hipLaunchKernelGGL(sr_append_move_kernel<4>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1);
+    else
+        hipLaunchKernelGGL(sr_append_move_kernel<16>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 // alpha of the grown model without another pass over U^-1:  with r = y_new - mu_old(z_new) (the old model's
 // mean at the new points, which the K* pass has just produced) and v2 = U22^-T r,
 //   alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2].     One workgroup recomputes v2 (m <= 16), grid over the rows.

@@ -628,6 +628,50 @@ def test_row_append_update_equals_refit(N0, adds):
     # single-query latency path and explicit inverse after an append
     np.testing.assert_allclose(gp.predict(x[:1])[1], var_f[:1], rtol=0, atol=1e-9)
     np.testing.assert_allclose(gp.inv_K[0], om["inv_K"][0], rtol=1e-6, atol=1e-8 * np.abs(om["inv_K"][0]).max())
+    # the factor itself is complete after any sequence of appends (the one-pass move of small appends relies on the
+    # zeros below the diagonal and on the identity padding of the buffer it writes into): equal to the refit's, entry
+    # by entry, lower triangle and padding included
+    _, wt_a = gp.export_state()
+    _, wt_f = full.export_state()
+    wa, wf = wt_a.cpu().numpy(), wt_f.cpu().numpy()
+    off = gp._handle.Np - ntot
+    for d in range(2):
+        assert np.all(np.tril(wa[d], -1) == 0.0)
+        assert np.all(wa[d][:off, :off] == np.eye(off)) and np.all(wa[d][:off, off:] == 0.0)
+        np.testing.assert_allclose(wa[d], wf[d], rtol=1e-6, atol=1e-9 * np.abs(wf[d]).max())
+
+
+def test_small_appends_after_refit_and_release():
+    """The buffer a small append writes into may hold an older state of the model (ping-pong), a released or a fresh
+    allocation: always a complete factor afterwards."""
+    syn = orc.make_synthetic(321, 420, 2, 1, 16)
+    Z, Y = syn["Z"], syn["Y"]
+    gp = hip_model(Z[:400], Y[:400], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    gp.update_model(Z[400:403], Y[400:403], opt_hyp=False, replace_old=False)      # fresh buffer
+    gp.update_model(Z[403:404], Y[403:404], opt_hyp=False, replace_old=False)      # ping
+    gp.update_model(Z[404:410], Y[404:410], opt_hyp=False, replace_old=False)      # pong
+    gp.release_scratch()
+    gp.update_model(Z[410:411], Y[410:411], opt_hyp=False, replace_old=False)      # fresh again
+    # an append that breaks down (NaN inputs: the Schur complement is not positive) leaves the model as it was ...
+    before = gp.predict(np.hstack((syn["p"], syn["k_ff"])))
+    bad = Z[411:415].copy()
+    bad[2, 0] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.update_model(bad, Y[411:415], opt_hyp=False, replace_old=False)
+    assert gp._handle.N == 411 and gp.x_train.shape[0] == 411
+    after = gp.predict(np.hstack((syn["p"], syn["k_ff"])))
+    np.testing.assert_array_equal(before[0], after[0])
+    np.testing.assert_array_equal(before[1], after[1])
+    # ... and the next (smaller) one does not inherit the half-written spare buffer
+    gp.update_model(Z[411:413], Y[411:413], opt_hyp=False, replace_old=False)
+    gp.update_model(Z[413:420], Y[413:420], opt_hyp=False, replace_old=False)
+    full = hip_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    wa, wf = gp.export_state()[1].cpu().numpy(), full.export_state()[1].cpu().numpy()
+    for d in range(2):
+        assert np.all(np.tril(wa[d], -1) == 0.0)
+        np.testing.assert_allclose(wa[d], wf[d], rtol=1e-6, atol=1e-9 * np.abs(wf[d]).max())
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    np.testing.assert_allclose(gp.predict(x)[1], full.predict(x)[1], rtol=0, atol=1e-9)
 
 
 def test_distance_to_center_batch_vs_reference_golden():
