@@ -1735,9 +1735,11 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1;
     const int pf = SR_NB - m;
     const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB, PB = (size_t)Np0 * SR_NB;
+    constexpr int APP_KS = 512;          // K-slice of the thin products (sr_launch_gemm_tn_splitk)
     const size_t o_xq = 0, o_ks = o_xq + (size_t)SR_NB * D, o_u12 = o_ks + (size_t)n_out * PB, o_u12t = o_u12 + PB,
                  o_x = o_u12t + PB, o_y2 = o_x + PB, o_g = o_y2 + PB, o_sb = o_g + BB, o_inv = o_sb + BB, o_wdm = o_inv + BB,
-                 o_wtr = o_wdm + BB, o_info = o_wtr + NN0, need = o_info + (size_t)n_out;
+                 o_wtr = o_wdm + BB, o_part = o_wtr + NN0, o_info = o_part + (size_t)((Np0 + APP_KS - 1) / APP_KS) * PB,
+                 need = o_info + (size_t)n_out;
     if (h->app_cap < need) {
         (void)hipDeviceSynchronize();
         dev_free(h->app_ws);
@@ -1747,7 +1749,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     }
     double* ws = h->app_ws;
     double *Xq = ws + o_xq, *Ks = ws + o_ks, *U12 = ws + o_u12, *U12t = ws + o_u12t, *X = ws + o_x, *Y2 = ws + o_y2,
-           *G = ws + o_g, *Sb = ws + o_sb, *invS = ws + o_inv, *wdm = ws + o_wdm, *Wtr = ws + o_wtr;
+           *G = ws + o_g, *Sb = ws + o_sb, *invS = ws + o_inv, *wdm = ws + o_wdm, *Wtr = ws + o_wtr, *part = ws + o_part;
     int* info_dev = reinterpret_cast<int*>(ws + o_info);
     double *Z1 = nullptr, *yT1 = nullptr, *alpha1 = nullptr, *Wt1 = nullptr;                 // new persistent state
     const bool reuse_alt = (Np1 == Np0) && h->Wt_alt && h->wt_alt_cap >= (size_t)n_out * NN1;
@@ -1789,8 +1791,9 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     for (int d = 0; d < n_out; ++d) {
         const double* Wt0 = h->Wt + (size_t)d * NN0;
         // U12 = U^-T B  (A = U^-1 k-major, upper block triangular)
-        SR_A(sr_launch_gemm_tn(Wt0, Np0, Ks + (size_t)d * PB, SR_NB, U12, SR_NB, Np0, SR_NB, Np0, 1.0, 0.0, 3, s));
-        SR_A(sr_launch_gemm_tn(U12, SR_NB, U12, SR_NB, G, SR_NB, SR_NB, SR_NB, Np0, 1.0, 0.0, 0, s));
+        // (thin products -- 128 columns, K up to Np -- in K-slices: 227 -> ~50 us, G = U12^T U12 209 -> ~15 us at N = 5000)
+        SR_A(sr_launch_gemm_tn_splitk(Wt0, Np0, Ks + (size_t)d * PB, SR_NB, U12, Np0, SR_NB, Np0, APP_KS, 1.0, 3, part, s));
+        SR_A(sr_launch_gemm_tn_splitk(U12, SR_NB, U12, SR_NB, G, SR_NB, SR_NB, Np0, APP_KS, 1.0, 0, part, s));
         // S = C - U12^T U12 on the real (front padded) block, C = k(Znew, Znew) + noise I
         if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], Sb, m, SR_NB, D, s));
         else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], Sb, m, SR_NB, D, s));
@@ -1801,7 +1804,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
         SR_A(sr_launch_gemm_tn(U12t, Np0, invS, SR_NB, X, SR_NB, Np0, SR_NB, SR_NB, 1.0, 0.0, 0, s));
         // Y2 = -U^-1 X   (A = U^-T = transpose of U^-1, k-major, lower block triangular)
         SR_A(sr_launch_transpose(Wt0, Wtr, Np0, s));
-        SR_A(sr_launch_gemm_tn(Wtr, Np0, X, SR_NB, Y2, SR_NB, Np0, SR_NB, Np0, -1.0, 0.0, 4, s));
+        SR_A(sr_launch_gemm_tn_splitk(Wtr, Np0, X, SR_NB, Y2, Np0, SR_NB, Np0, APP_KS, -1.0, 4, part, s));
         SR_A(sr_launch_append_assemble(Wt0, Np0, off0, N0, Y2, invS, m, Wt1 + (size_t)d * NN1, Np1, off1, s));
         // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1
         SR_A(sr_launch_append_alpha(h->alpha + (size_t)d * Np0, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, d, SR_NB, Ynew,

@@ -107,6 +107,10 @@ int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, doub
 int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                             int M, int N, int K, double alpha, double beta, hipStream_t s, int prio = 0,
                             int order = -1);   // order: 0 row-major tiles, 1 XCD-aware super-tiles, -1 by size
+// thin products (N a few tiles, K long): K-slices of ks rows as grid.z into `part` (ceil(K / ks) x M x N doubles), then
+// summed in order into C (M x N contiguous).  modes as sr_launch_gemm_tn.
+int sr_launch_gemm_tn_splitk(const double* A, long lda, const double* B, long ldb, double* C, int M, int N, int K,
+                             int ks, double alpha, int mode, double* part, hipStream_t s);
 // a list of independent TN products in one launch (one level of the recursive triangular inversion):
 // C_j = alpha A_j^T B_j, optionally also CT_j = C_j^T; operands at offsets (doubles) of common base pointers,
 // common leading dimension.  mode 2 / 3 as above.

@@ -89,6 +89,51 @@ int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, doub
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K form for THIN products (the row append: M = Np rows, N = 128 columns, K up to Np): the plain kernel has
+// Np / 64 * 2 workgroups there, the longest of which walks all of K (227 us at Np = 5120); G = U12^T U12 is ONE
+// 128 x 128 tile with K = Np (209 us).  grid.z = K-slices of `ks` rows; slice z writes its (possibly empty: zeros)
+// contribution to part + z * M * ldc, sr_sum_slices_kernel adds the slices in order (deterministic).
+// ------------------------------------------------------------------------------------------------
+template <class TL>
+__global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_splitk_kernel(
+    const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* part, long ldc, int M, int K,
+    int ks, double alpha, int mode) {
+    __shared__ double smem[TL::SMEM];
+    const int m0 = blockIdx.y * TL::T;
+    const int n0 = blockIdx.x * TL::T;
+    int k_beg = (mode == 2) ? (n0 & ~127) : ((mode == 4) ? (m0 & ~127) : 0);
+    int k_end = (mode == 3) ? min(K, (m0 & ~127) + 128) : K;
+    k_beg = max(k_beg, (int)blockIdx.z * ks);
+    k_end = min(k_end, ((int)blockIdx.z + 1) * ks);
+    if (k_end < k_beg) k_end = k_beg;
+    sr_gemm_tile<TL>(A, lda, B, ldb, part + (long)blockIdx.z * M * ldc, ldc, m0, n0, k_beg, k_end, alpha, 0.0, smem);
+}
+
+__global__ __launch_bounds__(256) void sr_sum_slices_kernel(const double* __restrict__ part, long stride, int nsl,
+                                                            double* __restrict__ out, long n) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    double v = 0.0;
+    for (int z = 0; z < nsl; ++z) v += part[(long)z * stride + e];
+    out[e] = v;
+}
+
+// C (M x N, ldc == N: the slices are contiguous copies of it) = alpha A^T B restricted by `mode` as in sr_launch_gemm_tn
+int sr_launch_gemm_tn_splitk(const double* A, long lda, const double* B, long ldb, double* C, int M, int N, int K,
+                             int ks, double alpha, int mode, double* part, hipStream_t s) {
+    SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && ks % 128 == 0 && ks > 0, SR_EINVAL,
+             "gemm_tn_splitk: M=%d N=%d K=%d ks=%d", M, N, K, ks);
+    const int nsl = (K + ks - 1) / ks;
+    hipLaunchKernelGGL(sr_gemm_tn_splitk_kernel<sr_tile64>, dim3(N / 64, M / 64, nsl), dim3(256), 0, s, A, lda, B, ldb,
+                       part, (long)N, M, K, ks, alpha, mode);
+    SR_HIP(hipGetLastError());
+    const long n = (long)M * N;
+    hipLaunchKernelGGL(sr_sum_slices_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, n, nsl, C, n);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Upper block triangle only (mode 1 above) on a LINEAR grid: tile b -> (m, n >= m), rows of tn - m tiles.
 // The rectangular grid of the trailing update starts (and retires) tm*tn/2 empty workgroups; at N = 50000
 // that is 47 000 of them per panel.  C (op)= alpha A^T B + beta C on the tiles n0 >= m0.
