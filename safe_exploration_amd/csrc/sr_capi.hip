@@ -538,7 +538,11 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                 double* Cnext = U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB;
                 const int la = std::min(P * SR_NB, rest);         // rows of the next panel
                 const int bulk = rest - la;
-                if (bulk > 0) SR_FH(hipEventRecord(h->ev_panel[sl][pi & 1], sc));     // the panel's rows are final
+                // regime 1 (chain-bound sizes): the bulk update starts only AFTER the look-ahead rows are done -- started
+                // together, its workgroups fill the CUs first and the look-ahead (on the critical path) takes 60 - 70 us
+                // instead of 20; regime 2: when the panel's rows are final
+                const bool bulk_after_la = (regime == 1);
+                if (bulk > 0 && !bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[sl][pi & 1], sc));
                 // the previous bulk update wrote the look-ahead rows too: it has to be through
                 if (n_bulk[sl] > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[sl][(n_bulk[sl] - 1) & 1], 0));
                 if (h->diag_stream[sl]) {
@@ -558,6 +562,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                     SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1));
                 }
                 if (bulk > 0) {
+                    if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[sl][pi & 1], sc));
                     SR_FH(hipStreamWaitEvent(sb, h->ev_panel[sl][pi & 1], 0));
                     {
                         sr_prof_scope ps(&h->prof, SR_K_GEMM, sb);
