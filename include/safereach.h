@@ -220,7 +220,7 @@ int sr_gp_sample(int device, long T, int size, int n_out, int n_u, const double*
 /* ---- tuning / measurement -------------------------------------------------------------------- */
 /* max queries processed per internal pass (workspace = n_out * Np * chunk * 8 B); default 65536. */
 int sr_gp_set_chunk(sr_gp_t h, long chunk);
-/* query tiles per scheduling group of the variance kernel (L2/XCD locality knob); default 32. */
+/* query tiles per scheduling group of the variance kernel (L2/XCD locality knob); default 64. */
 int sr_gp_set_var_group(sr_gp_t h, int group);
 /* main loop of the variance kernel: 0 = register-staged tiles (global->VGPR->LDS), 1 = LDS-DMA tiles
  * (global_load_lds_dwordx4; same results as 0 bit for bit), 2 = 1 with the structural zeros of the diagonal blocks

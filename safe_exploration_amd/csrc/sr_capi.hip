@@ -43,7 +43,9 @@ struct sr_gp {
     unsigned* stream_tickets = nullptr;
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
-    int var_group = 32;
+    int var_group = 64;      // query tiles per scheduling group of the variance kernel.  With the diagonal blocks cut short
+                             // (variant 2) 64 beats 32: 70.7 against 70.0 TF at C2', fabric-side fetches 61.3 -> 42.9 M KiB per launch
+                             // (scripts/pmc_groups.sh); 256 and more lose the sharing of the K* tiles (68.7 TF)
     int small_path = 1;      // latency paths (streaming T <= 16, 64-tiles, split-K) instead of the plain MFMA tiles
     int last_streamed = 0;   // the last gp_pass went through the streaming kernels (their partials hold U^-T k*)
     int force_stream = 0;    // sr_gp_linearize wants those partials whatever the model size
