@@ -319,7 +319,8 @@ static int pick_fact_panel(const sr_gp* h) {
     const int nb = h->Np / SR_NB;
     // measured (scripts/factor_bench.py, n_out = 2): N = 3000 .. 6000 panels of 2 are 2 - 4 % ahead of 4 (3.33 / 3.49,
     // 4.91 / 5.01, 6.82 / 7.01, 9.24 / 9.41 ms), N = 7000 and 10000 panels of 4 (12.99 / 13.04, 28.3 / 30.2 ms)
-    return nb <= 48 ? 2 : (nb <= 160 ? 4 : 8);
+    // N = 50000 (391 blocks): panels of 4 / 8 / 16 / 32 blocks 2.735 / 2.655 / 2.625 / 2.642 s; N = 30000: 8 and 16 alike
+    return nb <= 48 ? 2 : (nb <= 160 ? 4 : (nb <= 300 ? 8 : 16));
 }
 
 // Streams of the factorisation.  The chain of diagonal blocks is latency-bound and must never queue behind the
