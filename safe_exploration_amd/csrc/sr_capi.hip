@@ -26,10 +26,10 @@ struct sr_gp {
     // GP input transform of the reachability / moment entry points: x_gp = Tz x (Tz n_xin x n_s), NULL = identity
     double* Tz = nullptr; int n_xin = 0;
     double *tz_x = nullptr, *tz_jac = nullptr; long tz_cap = 0;   // transformed inputs / chain-ruled Jacobians (per chunk)
-    // persistent multi-step kernel (sr_small.hip K0c): exchange buffer, group tickets (all of the first chain_valid
-    // groups stand at chain_base), switch
-    double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;
-    unsigned long long chain_base = 0; int chain_valid = 0; int chain = 1; int last_chain = 0;
+    // persistent multi-step kernel (sr_small.hip K0c): exchange buffer, per group ticket + epoch + done counter (all of
+    // the hand-off state lives on the device), switch
+    double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // tickets, then epochs
+    unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0;
     unsigned* call_ticket = nullptr;        // sr_gp_call1: workgroups done (reset by the last one)
     int general = 0;
     int have_data = 0, factorized = 0;
@@ -154,7 +154,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
-    dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->call_ticket);
+    dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->chain_done); dev_free(h->call_ticket);
     dev_free(h->yT_alt); dev_free(h->alpha_alt);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
@@ -1176,18 +1176,17 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
         (chain_launches == 1 || (chain_launches == 2 && T > SR_FUSED_T)) &&
         sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
         if (!h->chain_xch) {
+            // (first use only: a blocking memset -- not inside a stream capture)
             SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_GROUPS * 2 * SR_SMALL_T * (SR_MAX_D + 2)));
-            SR_TRY(dev_alloc(&h->chain_tickets, (size_t)SR_CHAIN_GROUPS));
-            h->chain_valid = 0;
+            SR_TRY(dev_alloc(&h->chain_tickets, (size_t)2 * SR_CHAIN_GROUPS));
+            SR_TRY(dev_alloc(&h->chain_done, (size_t)SR_CHAIN_GROUPS));
+            SR_HIP(hipMemset(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
+            SR_HIP(hipMemset(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS));
         }
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         for (long t0 = 0; t0 < T; t0 += (long)gmax * SR_SMALL_T) {
             const long Tc = std::min((long)gmax * SR_SMALL_T, T - t0);
             const int groups = (int)((Tc + SR_SMALL_T - 1) / SR_SMALL_T);
-            if (groups > h->chain_valid) {
-                SR_HIP(hipMemsetAsync(h->chain_tickets, 0, sizeof(unsigned long long) * SR_CHAIN_GROUPS, s));
-                h->chain_base = 0; h->chain_valid = SR_CHAIN_GROUPS;
-            }
             sr_chain_args ca{};
             ca.k.Z = h->Z; ca.k.alpha = h->alpha; ca.k.ls = h->ls; ca.k.sf2 = h->sf2;
             ca.k.N = h->N; ca.k.Np = h->Np; ca.k.D = h->D; ca.k.n_out = h->n_out; ca.k.na = n_s; ca.k.nb = n_u;
@@ -1197,10 +1196,10 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
             ca.a = a; ca.b = b; ca.l_mu = l_mu; ca.l_sigma = l_sigma; ca.c_safety = c_safety;
             ca.p_all = p_all + t0 * H * n_s; ca.q_all = q_all + t0 * H * nss;
             ca.gp_var_all = gp_var_all ? gp_var_all + t0 * H * n_s : nullptr;
-            ca.n_bad = n_bad; ca.xch = h->chain_xch; ca.tickets = h->chain_tickets; ca.base = h->chain_base;
+            ca.n_bad = n_bad; ca.xch = h->chain_xch; ca.tickets = h->chain_tickets;
+            ca.epoch = h->chain_tickets + SR_CHAIN_GROUPS; ca.done = h->chain_done;
             SR_TRY(sr_launch_chain(ca, s));
-            h->chain_base += (unsigned long long)n_s * parts * H;
-            h->chain_valid = groups;
+            (void)groups;
         }
         h->last_chain = 1;
         *taken = true;

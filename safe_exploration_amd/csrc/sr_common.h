@@ -197,8 +197,9 @@ struct sr_chain_args {
     int* n_bad;
     double* xch;                      // groups x 2 x n_out x parts x 16 x (D + 2): per-step results handed between
                                       // the n_out x Np / 128 workgroups of a group of 16 rollouts
-    unsigned long long* tickets;      // one per group; all equal `base` at launch
-    unsigned long long base;
+    // per group: arrivals so far (monotonic), the value it had when the previous launch ended (written by that launch's
+    // last workgroup: nothing of the protocol lives on the host, so a captured launch can be replayed), workgroups done
+    unsigned long long* tickets; unsigned long long* epoch; unsigned* done;
 };
 #define SR_CHAIN_GROUPS 240          /* workgroups of one launch: all must be resident (they wait for each other) */
 bool sr_chain_supported(int Np, int D, int n_s, int n_u, int H);

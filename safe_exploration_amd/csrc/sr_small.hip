@@ -476,6 +476,7 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
     __shared__ double cst[NS * NS + NS * NU + 3 * NS];     // a, b, l_mu, l_sigma, sf2
     extern __shared__ double ctl[];                        // k_ff [16][H][NU], then k_fb [16][H-1][NU][NS] of the group
     __shared__ int fail;
+    __shared__ unsigned long long base_s;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -485,7 +486,11 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
     const long nq = c.T - t0 < SR_FQ ? c.T - t0 : SR_FQ;
     const long nss = NS * NS, nus = NU * NS;
     const bool writer = (d == 0 && part == 0);
-    if (tid == 0) fail = 0;
+    if (tid == 0) {
+        fail = 0;
+        // where the group's ticket stood when the previous launch ended (its last workgroup wrote it down)
+        base_s = (NS > 1 || P > 1) ? __hip_atomic_load(c.epoch + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
 
     // everything that does not change from step to step is fetched once
     double wreg[TOT];
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_fetch_add(c.tickets + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long want = c.base + (unsigned long long)(n_out * P) * (i + 1);
+                const unsigned long long want = base_s + (unsigned long long)(n_out * P) * (i + 1);
                 const unsigned long long t_start = wall_clock64();          // 100 MHz
                 while (__hip_atomic_load(c.tickets + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
@@ -614,6 +619,16 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
         const double nan = __builtin_nan("");
         for (long e = tid; e < nq * c.H * NS; e += NT) c.p_all[t0 * c.H * NS + e] = nan;
         for (long e = tid; e < nq * c.H * nss; e += NT) c.q_all[t0 * c.H * nss + e] = nan;
+    }
+    if ((NS > 1 || P > 1) && tid == 0) {
+        // the last workgroup of the group to leave notes where the ticket stands: the next launch starts from there
+        // (whatever happened in this one -- a timed-out group resynchronises itself this way)
+        const unsigned old = __hip_atomic_fetch_add(c.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(n_out * P) - 1u) {
+            __hip_atomic_store(c.done + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long now = __hip_atomic_load(c.tickets + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.epoch + g, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

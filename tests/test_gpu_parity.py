@@ -849,6 +849,22 @@ def test_entry_points_are_graph_capturable():
     got_p, got_q = out[0].clone(), out[1].clone()
     ref_p, ref_q = f()
     assert torch.equal(got_p, ref_p) and torch.equal(got_q, ref_q)
+    # replayed again and again (eager calls in between): the hand-off state of the persistent kernel lives on the
+    # device, a captured launch carries nothing that goes stale
+    assert gp.last_chain
+    for seed in (5, 6, 7):
+        roll3 = workload.random_rollout_controls(seed, 256, 6, 2, 1)
+        for k in tr:
+            tr[k].copy_(B.as_dev(roll3[k], dev))
+        g.replay()
+        torch.cuda.synchronize()
+        got_p, got_q = out[0].clone(), out[1].clone()
+        ref_p, ref_q = f()
+        assert torch.equal(got_p, ref_p) and torch.equal(got_q, ref_q)
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], ref_p) and torch.equal(out[1], ref_q)
 
 
 @pytest.mark.gpu
