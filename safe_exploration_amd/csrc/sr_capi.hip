@@ -29,7 +29,7 @@ struct sr_gp {
     // persistent multi-step kernel (sr_small.hip K0c): exchange buffer, per group ticket + epoch + done counter (all of
     // the hand-off state lives on the device), switch
     double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // tickets, then epochs
-    unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0;
+    unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0; int chain_cap = -1;
     unsigned* call_ticket = nullptr;        // sr_gp_call1: workgroups done (reset by the last one)
     int general = 0;
     int have_data = 0, factorized = 0;
@@ -1170,7 +1170,15 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
     // route has left its one-launch posterior (T > SR_FUSED_T).  Measured at N = 200, H = 15: 256 rollouts 241 -> 148 us,
     // 1024 rollouts (two launches) 292 against 247 us per step, 1920 rollouts (two launches) 304 against 544 us.
     const int parts = h->Np / 128;                                      // workgroups sharing one (group, output)
-    const int gmax = std::max(1, SR_CHAIN_GROUPS / (n_s * std::max(parts, 1)));   // groups of 16 rollouts per launch
+    // every workgroup of a launch must be resident (one per CU): leave 16 CUs of whatever this device (or partition of
+    // a device) has to other work
+    if (h->chain_cap < 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 0;
+        h->chain_cap = std::max(0, std::min(SR_CHAIN_GROUPS, cus - 16));
+    }
+    if (h->chain_cap < n_s * std::max(parts, 1)) return SR_OK;          // not even one group fits: per-step launches
+    const int gmax = std::max(1, h->chain_cap / (n_s * std::max(parts, 1)));      // groups of 16 rollouts per launch
     const long chain_launches = ((T + SR_SMALL_T - 1) / SR_SMALL_T + gmax - 1) / gmax;
     if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 &&
         (chain_launches == 1 || (chain_launches == 2 && T > SR_FUSED_T)) &&
