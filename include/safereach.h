@@ -237,6 +237,9 @@ int sr_gp_set_small_path(sr_gp_t h, int on);
  * the reference's systems n_s <= 4) run all H steps inside ONE persistent launch; on = 0 forces the per-step launches.
  * Default on; results agree to rounding.  sr_gp_last_chain: 1 if the last chain took the persistent kernel. */
 int sr_gp_set_chain(sr_gp_t h, int on);
+/* big batches on the plain MFMA path (>= 8192 queries per range): the K* pass of column ranges 1 .. nsub-1 runs on a side
+ * stream beside the contraction of the ranges before them; nsub = 1 switches it off.  Results are identical bit for bit. */
+int sr_gp_set_pipeline(sr_gp_t h, int nsub);
 /* The model update keeps its scratch (two Np x Np matrices per output in flight) with the handle while that is at most a
  * third of the device's memory, so that refits allocate nothing (40 GB at N = 50000); the row append keeps a strip and
  * the previous U^-1 buffer.  A host that will only evaluate the model from here on hands them back with this call. */

@@ -31,6 +31,8 @@ struct sr_gp {
     double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // tickets, then epochs
     unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0; int chain_cap = -1;
     unsigned* call_ticket = nullptr;        // sr_gp_call1: workgroups done (reset by the last one)
+    // big batches: the K* pass of the later sub-chunks runs on aux_stream beside the contraction of the earlier ones
+    int pipe_sub = 1; hipStream_t aux_stream = nullptr; hipEvent_t ev_pipe_fork = nullptr; hipEvent_t ev_pipe_k[8] = {};
     int general = 0;
     int have_data = 0, factorized = 0;
     // per-chunk workspace (grow-only)
@@ -156,6 +158,9 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
     dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->chain_done); dev_free(h->call_ticket);
     dev_free(h->yT_alt); dev_free(h->alpha_alt);
+    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+    if (h->ev_pipe_fork) (void)hipEventDestroy(h->ev_pipe_fork);
+    for (hipEvent_t e : h->ev_pipe_k) if (e) (void)hipEventDestroy(e);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (int d = 0; d < SR_FACT_SLOTS; ++d) {
@@ -901,6 +906,57 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     ka.Ks = h->Ks; ka.mu_part = h->mu_part; ka.jac_part = h->jac_part;
     ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = nsplit;
     ka.T = Tc; ka.Tp = Tp;
+    const bool small_var = h->small_path && ((Tc <= SR_SMALL_T && (h->Np > SR_STREAM_MIN_NP || h->force_stream)) ||
+                                             (h->small_path == 1 && h->Np > SR_STREAM_MIN_NP &&
+                                              Tc <= (long)SR_SMALL_T * sr_var_small_groups_max(h->Np, h->n_out)));
+    const bool plain_var = !small_var && !(h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) &&
+                           !(h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out));
+    // Big batch on the plain MFMA path: the K* pass is bound by its HBM writes (n_out Np Tp 8 B: 5.4 GB, 1.3 ms at
+    // C2'), the contraction by the MFMA pipe.  In pipe_sub column ranges the K* pass of ranges 1.. runs on a side
+    // stream beside the contraction of range 0; only the first range's K* pass stays exposed.
+    const int nsub = (plain_var && h->pipe_sub > 1 && Tp >= (long)h->pipe_sub * 8192) ? std::min(h->pipe_sub, 8) : 1;
+    if (nsub > 1) {
+        if (!h->aux_stream) {
+            SR_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+            SR_HIP(hipEventCreateWithFlags(&h->ev_pipe_fork, hipEventDisableTiming));
+            for (hipEvent_t& e : h->ev_pipe_k) SR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const long W = round_up((Tp + nsub - 1) / nsub, 256);      // columns per range (K* blocks hold 256 queries)
+        SR_HIP(hipEventRecord(h->ev_pipe_fork, s));                 // inputs ready, workspace free
+        SR_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_pipe_fork, 0));
+        h->last_streamed = 0;
+        for (int i = 0; i < nsub; ++i) {
+            const long c0 = (long)i * W;
+            if (c0 >= Tp) break;
+            const long w = std::min(W, Tp - c0);
+            sr_kstar_args kr = ka;
+            kr.xa = xa + c0 * lda; kr.xb = xb ? xb + c0 * ldb : nullptr;
+            kr.Ks = h->Ks + c0; kr.mu_part = h->mu_part + c0; kr.jac_part = h->jac_part + c0;
+            kr.kxx = h->kxx ? h->kxx + c0 : nullptr;
+            kr.T = std::max(0L, std::min(Tc - c0, w)); kr.Tw = w;
+            hipStream_t sk = (i == 0) ? s : h->aux_stream;
+            {
+                sr_prof_scope ps(&h->prof, SR_K_KSTAR, sk);
+                SR_TRY(sr_launch_kstar(kr, sk));
+            }
+            if (i > 0) SR_HIP(hipEventRecord(h->ev_pipe_k[i], h->aux_stream));
+        }
+        for (int i = 0; i < nsub; ++i) {
+            const long c0 = (long)i * W;
+            if (c0 >= Tp) break;
+            const long w = std::min(W, Tp - c0);
+            if (i > 0) SR_HIP(hipStreamWaitEvent(s, h->ev_pipe_k[i], 0));
+            sr_prof_scope ps(&h->prof, SR_K_VAR, s);
+            SR_TRY(sr_launch_var(h->Wt, h->Ks + c0, h->var_part + c0, h->N, h->Np, Tp, h->n_out, h->var_group,
+                                 h->var_variant, s, w));
+        }
+        sr_final_args fp;
+        fp.mu_part = h->mu_part; fp.jac_part = h->jac_part; fp.var_part = h->var_part; fp.sf2 = h->sf2;
+        fp.ls = h->ls; fp.kxx = h->general ? h->kxx : nullptr; fp.mu = mu; fp.var = var; fp.jac = jac;
+        fp.n_out = h->n_out; fp.D = h->D; fp.nsplit = nsplit; fp.nrb = h->Np / SR_NB; fp.T = Tc; fp.Tp = Tp;
+        sr_prof_scope ps(&h->prof, SR_K_FINAL, s);
+        return sr_launch_finalize(fp, s);
+    }
     {
         sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
         SR_TRY(sr_launch_kstar(ka, s));
@@ -908,9 +964,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     int nrb = h->Np / SR_NB;
     const double* var_part = h->var_part;
     h->last_streamed = 0;
-    if (h->small_path && ((Tc <= SR_SMALL_T && (h->Np > SR_STREAM_MIN_NP || h->force_stream)) ||
-                          (h->small_path == 1 && h->Np > SR_STREAM_MIN_NP &&
-                           Tc <= (long)SR_SMALL_T * sr_var_small_groups_max(h->Np, h->n_out)))) {
+    if (small_var) {
         h->last_streamed = 1;
         // latency regime: stream U^-1 once (HBM-bound) instead of the MFMA tiles
         if (!h->small_vp) SR_TRY(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(h->Np, h->n_out)));
@@ -1498,6 +1552,12 @@ extern "C" int sr_gp_release_scratch(sr_gp_t h) {
     dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1;
     dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
     dev_free(h->yT_alt); dev_free(h->alpha_alt); h->yT_alt = h->alpha_alt = nullptr; h->vec_alt_np = 0;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_set_pipeline(sr_gp_t h, int nsub) {
+    SR_CHECK(h != nullptr && nsub >= 1 && nsub <= 8, SR_EINVAL, "sr_gp_set_pipeline: nsub=%d outside 1..8", nsub);
+    h->pipe_sub = nsub;
     return SR_OK;
 }
 

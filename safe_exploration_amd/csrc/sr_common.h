@@ -172,6 +172,8 @@ struct sr_kstar_args {
     long T, Tp;
     // one-launch blocking single query (sr_gp_call1; K0 only): the query travels in the kernel arguments, the results
     // go straight to pinned host memory and the last workgroup writes the sequence number the host spins on
+    long Tw = 0;            // width (padded queries) of THIS launch when it covers a column range of the buffers only;
+                            // 0: all Tp columns.  Pointers (xa, xb, Ks, mu_part, jac_part, kxx) are then pre-offset.
     int xv_on = 0; double xv[SR_MAX_D] = {};
     unsigned* done_ticket = nullptr; unsigned long long* host_flag = nullptr; unsigned long long host_seq = 0;
 };
@@ -207,7 +209,7 @@ int sr_launch_chain(const sr_chain_args& a, hipStream_t s);
 
 // part[d][rb][t] = sum_{i in row block rb} ( sum_k Wt[d][k][i] Ks[d][k][t] )^2
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
-                  int group, int variant, hipStream_t s);
+                  int group, int variant, hipStream_t s, long Tw = 0);
 
 // 64 x 64 tile variant for small models (sr_predict.hip, K2m): part layout [d][Np/64][Tp]
 bool sr_var64_wanted(int Np, long Tp, int n_out);

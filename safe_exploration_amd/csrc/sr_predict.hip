@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
     const int d = blockIdx.y, sp = blockIdx.z;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = t < a.T;
-    const bool inpad = t < a.Tp;
+    const bool inpad = t < (a.Tw ? a.Tw : a.Tp);
 
     double inv_l[DT], xs[DT], g[DT];
 #pragma unroll
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void sr_kstar_general_kernel(sr_kstar_args a) 
     const int d = blockIdx.y, sp = blockIdx.z;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = t < a.T;
-    const bool inpad = t < a.Tp;
+    const bool inpad = t < (a.Tw ? a.Tw : a.Tp);
     const double* kp = a.kp + (long)d * SR_KP(a.D);
     const int kind = (int)kp[0];
     const double var = kp[1], c0 = kp[2];
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void sr_kstar_general_kernel(sr_kstar_args a) 
 }
 
 int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s) {
-    dim3 grid((unsigned)((a.Tp + 255) / 256), a.n_out, a.nsplit);
+    dim3 grid((unsigned)(((a.Tw ? a.Tw : a.Tp) + 255) / 256), a.n_out, a.nsplit);
     if (a.kp) {
 #define SR_KSTARG_CASE(DT) hipLaunchKernelGGL(sr_kstar_general_kernel<DT>, grid, dim3(256), 0, s, a)
         if (a.D <= 3) SR_KSTARG_CASE(3);
@@ -277,10 +277,11 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
 }
 
 int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
-                  int group, int variant, hipStream_t s) {
+                  int group, int variant, hipStream_t s, long Tw) {
+    // Tw != 0: only the first Tw columns behind the (pre-offset) Ks / part pointers; Tp stays the row stride
     const int k_beg = ((Np - N) / srt::BK) * srt::BK;     // rows k < Np-N are padding: K* is zero there
     const int nrb = Np / srt::BM;
-    const int ntq = (int)(Tp / srt::BN);
+    const int ntq = (int)((Tw ? Tw : Tp) / srt::BN);
     if (group < 1) group = 1;
     if (group > ntq) group = ntq;
     const int ngrp = (ntq + group - 1) / group;

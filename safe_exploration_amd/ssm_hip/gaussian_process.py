@@ -846,6 +846,11 @@ class SimpleGPModel(StateSpaceModel):
         self._need_trained()
         check(lib.sr_gp_release_scratch(self._handle.h))
 
+    def set_pipeline(self, nsub):
+        """column ranges of a big batch whose K* passes overlap with the contraction of the ranges before (1 = off)"""
+        self._need_trained()
+        check(lib.sr_gp_set_pipeline(self._handle.h, int(nsub)))
+
     def set_chain(self, on):
         """multi-step chains of small models inside one persistent launch (default) or step by step"""
         self._need_trained()
