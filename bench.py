@@ -7,7 +7,10 @@
 
 ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks
 (torch.multiprocessing.spawn, one per GPU, rendezvous on 127.0.0.1); under torch.distributed.run the
-ranks it finds are used as they are.  Either way the backend is "nccl" (= RCCL on ROCm).
+ranks it finds are used as they are.  Either way the backend is "nccl" (= RCCL on ROCm).  Two environment
+overrides exist so that the N > 1 branch can be exercised on a ONE-GPU box (RCCL itself refuses two ranks on one
+device): SR_DIST_BACKEND=gloo picks the process-group backend, SR_SHARE_DEVICE=1 puts every rank on cuda:0.  The
+JSON line names the backend and device placement that really ran (`config.parallelism`).
 
 One *step* = one pass of the hot path over one batch of T synthetic query states per GPU:
 GP posterior (mu, var, d mu/dx at z=[p;k_ff]) + ellipsoid branch of onestep_reachability, through
@@ -35,6 +38,7 @@ if ROOT not in sys.path:
 
 METRIC = "one-step reachability evals/sec (batched query states), N=5k train pts"
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (v_mfma_f64_16x16x4_f64) dense peak, vendor spec
+FP64_MFMA_MEASURED_TFLOPS = 77.4 # what scripts/mfma_f64_peak.hip reaches on this part (2 waves/SIMD, no operands from memory)
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -100,6 +104,35 @@ def cpu_baseline(prob, l_mu, l_sigma, budget_s=12.0):
                                    "BLAS threads as above)" % nq}
 
 
+def cpu_baseline_chain(prob, roll, l_mu, l_sigma, a, b, H, budget_s=12.0):
+    """C3: the oracle's H-step chain (one reference-style onestep call per rollout and step, gp_reachability.py:195-210)
+    on a bounded number of rollouts; value in step-evals/s like the GPU line.  Model fit excluded."""
+    from oracle import oracle_np as orc
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    t0 = time.time()
+    beta, inv_K, _ = orc.gp_fit(prob["Z"], prob["Y"], prob["lengthscale"], prob["signal_var"], prob["noise_var"] + 1e-5)
+    fit_s = time.time() - t0
+    model = dict(Z=prob["Z"], beta=beta, inv_K=inv_K, lengthscale=prob["lengthscale"], signal_var=prob["signal_var"])
+    n, done, spent = 2, 0, 0.0
+    while True:
+        t0 = time.time()
+        orc.multistep_reachability_batch(model, roll["p0"][:n], roll["k_fb"][:n], roll["k_ff"][:n], l_mu, l_sigma, None,
+                                         C_SAFETY, a, b)
+        dt = time.time() - t0
+        done, spent = n, dt
+        if dt > budget_s / 3 or n * 2 > roll["p0"].shape[0]:
+            break
+        n *= 2
+    return {"value": done * H / spent, "unit": "evals/s", "cores": int(thr), "kind": "port",
+            "sample": "first %d of the same rollouts x H=%d, N=%d; NumPy/SciPy oracle, one onestep call per rollout "
+                      "and step as the reference drives it; %.1f s timed; model fit (%.1f s) excluded"
+                      % (done, H, prob["Z"].shape[0], spent, fit_s)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,7 +145,17 @@ def parse_args(argv=None):
     ap.add_argument("--var-variant", type=int, default=-1)
     ap.add_argument("--pipeline", type=int, default=0, help="column ranges of the K* / contraction pipeline (0: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-shards", default="", help="directory: every rank stores its query seed and the head of its "
+                    "outputs of the last step there (shard_rank<r>.npz) -- for tests of the sharded path")
     return ap.parse_args(argv)
+
+
+def dist_backend():
+    return os.environ.get("SR_DIST_BACKEND", "nccl")
+
+
+def share_device():
+    return os.environ.get("SR_SHARE_DEVICE", "0") not in ("", "0")
 
 
 def _free_port():
@@ -141,7 +184,7 @@ def main(argv=None):
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not share_device():
             raise SystemExit("--gpus %d but only %d device(s) visible" % (args.gpus, have))
         mp.spawn(_spawned_rank, args=(list(sys.argv[1:] if argv is None else argv), args.gpus, _free_port()),
                  nprocs=args.gpus, join=True)
@@ -240,13 +283,19 @@ def run(args):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if share_device() else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     backend = "single process"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        backend = "%s world=%d" % (dist.get_backend(), dist.get_world_size())   # what RCCL itself reports
+        if dist_backend() == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(dist_backend(), rank=rank, world_size=world)
+        # what the process group itself reports, and where the ranks sit
+        backend = "%s world=%d%s" % (dist.get_backend(), dist.get_world_size(),
+                                     ", all ranks on cuda:0" if share_device() else ", one GPU per rank")
 
     if args.workload == "c4":
         return run_model_update(args, dev, world, rank)
@@ -268,14 +317,15 @@ def run(args):
         gp.train(prob["Z"], prob["Y"], opt_hyp=False)
         torch.cuda.synchronize(dev)
     fit_s = time.time() - t0
-    bcast_s = 0.0
+    bcast_s, bcast = 0.0, {}
     if world > 1:
         dist.barrier()
         t0 = time.time()
-        gp = parallel.replicate_model(gp, prob, src=0)
+        gp = parallel.replicate_model(gp, prob, src=0, device=dev)
         torch.cuda.synchronize(dev)
         dist.barrier()
         bcast_s = time.time() - t0
+        bcast = dict(parallel.LAST_REPLICATION)
     if args.var_group:
         gp.set_var_group(args.var_group)
     if args.var_variant >= 0:
@@ -284,7 +334,8 @@ def run(args):
         gp.set_pipeline(args.pipeline)
 
     # ---- this rank's shard of the (world * T) query states, resident in HBM ------------------------
-    q = workload.make_queries(seed + 7919 + 104729 * rank, n_s, n_u, T) if rank else prob
+    q_seed = seed + 7919 + 104729 * rank
+    q = workload.make_queries(q_seed, n_s, n_u, T) if rank else prob
     tp, tq, tkff, tkfb = (B.as_dev(q[k], dev) for k in ("p", "Q", "k_ff", "k_fb"))
     if H > 1:
         roll = workload.random_rollout_controls(seed + 31 * rank, T, H, n_s, n_u)
@@ -315,6 +366,13 @@ def run(args):
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     assert bool(torch.isfinite(out[1]).all()), "non-finite result in the timed region"
+    if args.dump_shards:
+        os.makedirs(args.dump_shards, exist_ok=True)
+        head = min(T, 4096)
+        np.savez(os.path.join(args.dump_shards, "shard_rank%d.npz" % rank), rank=rank, world=world, T=T, H=H,
+                 query_seed=(-1 if rank == 0 else q_seed), roll_seed=seed + 31 * rank,
+                 p_head=out[0][:head].cpu().numpy(), q_head=out[1][:head].cpu().numpy(),
+                 p_sum=out[0].sum(0).cpu().numpy(), q_sum=out[1].sum(0).cpu().numpy())
 
     if rank == 0:
         evals = float(world) * T * H * args.steps
@@ -340,6 +398,18 @@ def run(args):
                 traffic_src = "committed PMC pass: %s (not measured in this run)" % pj.get("source", "profiles/pmc_%s.json" % args.workload)
             except Exception:
                 traffic = None
+        # SURVEY 8(d) asks for BOTH rates: the algorithmic HBM bytes of a step over the step time (far below the roof
+        # here: the batch is MFMA-bound from ~40 queries on) next to the MFMA fraction.  Per 65536-query pass the
+        # factor is read once (n_out N (N+1)/2 doubles) plus Z and alpha; per query the API arrays in and out.
+        D = n_s + n_u
+        passes = H * -(-T // 65536)
+        bytes_step = 8.0 * (passes * (n_s * N * (N + 1) / 2 + N * D + n_s * N)
+                            + T * H * (n_s + n_u + n_s * n_s + n_u * n_s + n_s + n_s * n_s))
+        step_s = elapsed / args.steps
+        # the K* pass: bound by its HBM writes (n_out N T doubles per pass: the cross-covariance the contraction reads)
+        ks_avg_ms = ks_ms / max(ks_n, 1)
+        ks_bytes = 8.0 * n_s * N * T * H * args.steps / max(ks_n, 1)
+        ks_gbs = ks_bytes / (ks_avg_ms * 1e-3) / 1e9 if ks_avg_ms > 0 else 0.0
         line = {
             "metric": METRIC, "value": evals / elapsed, "unit": "evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -347,21 +417,38 @@ def run(args):
             "data": "synthetic",
             "config": {"workload": desc, "N": N, "queries_per_gpu_per_step": T, "horizon": H,
                        "n_s": n_s, "n_u": n_u,
-                       "parallelism": "query-shard x%d (%s), one-time RCCL broadcast of Z/alpha/U^-1, no "
-                                      "data-path collective" % (world, backend),
+                       "parallelism": "query-shard x%d (%s), one-time broadcast of Z/alpha and the packed upper "
+                                      "triangle of U^-1, no data-path collective" % (world, backend),
                        "model_fit_s": round(fit_s, 3), "broadcast_s": round(bcast_s, 3)},
             "roofline": {"kernel": "sr_var_kernel", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "frac_of_measured_ceiling": achieved / FP64_MFMA_MEASURED_TFLOPS,
+                         "measured_ceiling": FP64_MFMA_MEASURED_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops_launch, "avg_launch_ms": avg_ms,
-                         "launches": var_n},
+                         "launches": var_n,
+                         "hbm_gbps_achieved": bytes_step / step_s / 1e9,
+                         "hbm_frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS,
+                         "hbm_bytes_per_step_algorithmic": bytes_step},
+            "roofline_kstar": {"kernel": "sr_kstar_kernel", "bound": "hbm-write", "achieved": ks_gbs,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks_gbs / HBM_PEAK_GBS,
+                               "bytes_per_launch": ks_bytes, "avg_launch_ms": ks_avg_ms, "launches": ks_n,
+                               "traffic": None},
             "kernel_ms_per_step": {"sr_kstar_kernel": ks_ms / args.steps, "sr_var_kernel": var_ms / args.steps,
                                    "sr_finalize_kernel": fin_ms / args.steps,
                                    "sr_ellipsoid_kernel": ell_ms / args.steps},
         }
+        if world > 1:
+            fb = bcast.get("factor_bytes", 0) + bcast.get("other_bytes", 0)
+            line["config"].update({"broadcast_bytes": fb, "broadcast_dense_factor_bytes": bcast.get("dense_factor_bytes"),
+                                   "broadcast_pieces": bcast.get("pieces"),
+                                   "broadcast_GBps": fb / bcast_s / 1e9 if bcast_s > 0 else None})
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(prob, l_mu, l_sigma)
+            if H == 1:
+                line["cpu_baseline"] = cpu_baseline(prob, l_mu, l_sigma)
+            else:
+                line["cpu_baseline"] = cpu_baseline_chain(prob, roll, l_mu, l_sigma, a_lin, b_lin, H)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -97,6 +97,19 @@ int sr_gp_dims(sr_gp_t h, int* N, int* D, int* n_out, long* Np);
 int sr_gp_export(sr_gp_t h, double* alpha, double* Wt, void* stream);
 int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, void* stream);
 
+/* The same state PACKED for the one-time replication to the other GPUs (the reference has no multi-GPU
+ * path, so nothing of it is replaced): of U^-1 only the N (N + 1) / 2 entries on and above the diagonal of the real
+ * rows travel -- 100 MB instead of 210 MB per output at N = 5000.  Training row i (0 <= i < N) contributes
+ * U^-1[i][i .. N-1]; the rows [row0, row1) of output d are packed back to back into buf (sr_gp_packed_count doubles;
+ * -1 for a bad range), so a sender can move the factor in bounded pieces through a staging buffer of any size.
+ * Receiver: sr_gp_import_begin(alpha n_out x N) after sr_gp_set_data, sr_gp_import_packed for every piece of every
+ * output (any order), sr_gp_import_end -> factorized.  Predictions are bit-identical to the sender's. */
+long sr_gp_packed_count(sr_gp_t h, long row0, long row1);
+int sr_gp_export_packed(sr_gp_t h, int d, long row0, long row1, double* buf, void* stream);
+int sr_gp_import_begin(sr_gp_t h, const double* alpha, void* stream);
+int sr_gp_import_packed(sr_gp_t h, int d, long row0, long row1, const double* buf, void* stream);
+int sr_gp_import_end(sr_gp_t h);
+
 /* explicit (K + noise I)^-1 of output d, N x N -- the reference's `inv_K[d]` attribute
  * (ssm_gpy/gaussian_process.py:258-262).  Cold path; needs factorize() on this handle. */
 int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream);

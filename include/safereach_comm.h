@@ -19,8 +19,9 @@ extern "C" {
 /* one RCCL communicator (and one stream) per device, single process (ncclCommInitAll) */
 int         sr_comm_init_all(int ndev, const int* devices);
 /* handles[i] lives on devices[i]; all of the same shape (sr_gp_dims); handles[root] is factorised, the others have their
- * data set (sr_gp_set_data[_general]: Z, targets, hyper-parameters).  ONE broadcast of n_out * (N + Np^2) doubles, then
- * sr_gp_import on the receivers: every handle is ready to predict. */
+ * data set (sr_gp_set_data[_general]: Z, targets, hyper-parameters).  alpha and the PACKED upper triangle of U^-1 travel
+ * (n_out * (N + N (N + 1) / 2) doubles, pieces of <= 64 MB through one staging buffer per device; sr_gp_export_packed /
+ * sr_gp_import_packed of safereach.h): every handle is ready to predict, no copy of the factor's size is staged. */
 int         sr_comm_bcast(sr_gp_t* handles, int ndev, int root);
 int         sr_comm_destroy(void);
 const char* sr_comm_last_error(void);

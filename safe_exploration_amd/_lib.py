@@ -50,6 +50,11 @@ SIGNATURES = {
     "sr_gp_dims": (_I, [_H, _PI, _PI, _PI, _PL]),
     "sr_gp_export": (_I, [_H, _P, _P, _P]),
     "sr_gp_import": (_I, [_H, _P, _P, _P]),
+    "sr_gp_packed_count": (_L, [_H, _L, _L]),
+    "sr_gp_export_packed": (_I, [_H, _I, _L, _L, _P, _P]),
+    "sr_gp_import_begin": (_I, [_H, _P, _P]),
+    "sr_gp_import_packed": (_I, [_H, _I, _L, _L, _P, _P]),
+    "sr_gp_import_end": (_I, [_H]),
     "sr_gp_inv_k": (_I, [_H, _I, _P, _P]),
     "sr_gp_predict": (_I, [_H, _P, _L, _P, _P, _P, _P]),
     "sr_gp_linearize": (_I, [_H, _P, _P, _P, _P, _P, _P, _P]),

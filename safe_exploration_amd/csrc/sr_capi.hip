@@ -35,8 +35,10 @@ struct sr_gp {
     int pipe_sub = 1; hipStream_t aux_stream = nullptr; hipEvent_t ev_pipe_fork = nullptr; hipEvent_t ev_pipe_k[8] = {};
     int general = 0;
     int have_data = 0, factorized = 0;
+    int import_open = 0;     // between sr_gp_import_begin and sr_gp_import_end
     // per-chunk workspace (grow-only)
     long chunk = 65536, ws_Tp = 0, ws_part = 0;     // ws_part: capacity of mu_part in units of n_out doubles
+    int ws_locked = 0;       // internal buffers (mu / var / jac) are referenced by an entry point: growing now is a bug
     double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
            *mu = nullptr, *var = nullptr, *jac = nullptr, *kxx = nullptr;
     double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch
@@ -672,6 +674,88 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
     return SR_OK;
 }
 
+// ---- packed posterior state for the one-time replication ------------------------------------------
+// U^-1 is upper triangular: of the Np^2 doubles sr_gp_export hands out only the N (N + 1) / 2 on and above the
+// diagonal of the real (unpadded) rows carry information -- 100 MB instead of 210 MB per output at N = 5000, 10 GB
+// instead of 20 GB at N = 50000.  Training row i (0 <= i < N) contributes its N - i entries U^-1[i][i..N-1]; rows
+// [row0, row1) are packed back to back, so a replication can travel in bounded pieces through a small staging buffer.
+static inline long packed_rows_count(long N, long row0, long row1) {
+    return (row1 - row0) * N - (row1 * (row1 - 1) - row0 * (row0 - 1)) / 2;
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void sr_pack_rows_kernel(double* __restrict__ Wt, double* __restrict__ buf, int N,
+                                                           int Np, long row0) {
+    const long i = row0 + blockIdx.x;                                    // training row
+    const long off = Np - N;
+    const long base = (i - row0) * N - (i * (i - 1) - row0 * (row0 - 1)) / 2;   // packed offset of row i's first entry
+    double* row = Wt + (i + off) * Np + off + i;
+    const int len = N - (int)i;
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < len; c += gridDim.y * 256) {
+        if (PACK) buf[base + c] = row[c];
+        else row[c] = buf[base + c];
+    }
+}
+
+extern "C" long sr_gp_packed_count(sr_gp_t h, long row0, long row1) {
+    if (!h || row0 < 0 || row1 < row0 || row1 > h->N) return -1;
+    return packed_rows_count(h->N, row0, row1);
+}
+
+extern "C" int sr_gp_export_packed(sr_gp_t h, int d, long row0, long row1, double* buf, void* stream) {
+    SR_CHECK(h != nullptr && buf != nullptr, SR_EINVAL, "sr_gp_export_packed: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_export_packed: model not factorized");
+    SR_CHECK(d >= 0 && d < h->n_out && row0 >= 0 && row0 <= row1 && row1 <= h->N, SR_EINVAL,
+             "sr_gp_export_packed: d=%d rows [%ld, %ld) outside the model (n_out=%d, N=%d)", d, row0, row1, h->n_out, h->N);
+    if (row1 == row0) return SR_OK;
+    SR_DEVICE(h->device);
+    const int gy = std::max(1, std::min(8, (h->N - (int)row0 + 2047) / 2048));
+    hipLaunchKernelGGL(sr_pack_rows_kernel<true>, dim3((unsigned)(row1 - row0), gy), dim3(256), 0, (hipStream_t)stream,
+                       h->Wt + (size_t)d * h->Np * h->Np, buf, h->N, h->Np, row0);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// Receiver side: sr_gp_import_begin (alpha, identity padding, structural zeros), then the packed rows of every output
+// in any order and in any number of pieces (sr_gp_import_packed), then sr_gp_import_end marks the handle factorized.
+extern "C" int sr_gp_import_begin(sr_gp_t h, const double* alpha, void* stream) {
+    SR_CHECK(h != nullptr && alpha != nullptr, SR_EINVAL, "sr_gp_import_begin: NULL argument");
+    SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_import_begin: call sr_gp_set_data first (Z and hyper-parameters)");
+    hipStream_t s = (hipStream_t)stream;
+    SR_DEVICE(h->device);
+    SR_TRY(ensure_wt(h));             // zero below the diagonal from allocation on; nothing ever writes there
+    h->factorized = 0;
+    h->import_open = 1;
+    SR_HIP(hipMemsetAsync(h->alpha, 0, sizeof(double) * h->n_out * h->Np, s));
+    SR_HIP(hipMemcpy2DAsync(h->alpha + (h->Np - h->N), sizeof(double) * h->Np, alpha, sizeof(double) * h->N,
+                            sizeof(double) * h->N, h->n_out, hipMemcpyDeviceToDevice, s));
+    for (int d = 0; d < h->n_out; ++d)
+        SR_TRY(sr_launch_eye_front(h->Wt + (size_t)d * h->Np * h->Np, h->Np, h->Np - h->N, s));
+    return SR_OK;
+}
+
+extern "C" int sr_gp_import_packed(sr_gp_t h, int d, long row0, long row1, const double* buf, void* stream) {
+    SR_CHECK(h != nullptr && buf != nullptr, SR_EINVAL, "sr_gp_import_packed: NULL argument");
+    SR_CHECK(h->import_open, SR_ESTATE, "sr_gp_import_packed: call sr_gp_import_begin first");
+    SR_CHECK(d >= 0 && d < h->n_out && row0 >= 0 && row0 <= row1 && row1 <= h->N, SR_EINVAL,
+             "sr_gp_import_packed: d=%d rows [%ld, %ld) outside the model (n_out=%d, N=%d)", d, row0, row1, h->n_out, h->N);
+    if (row1 == row0) return SR_OK;
+    SR_DEVICE(h->device);
+    const int gy = std::max(1, std::min(8, (h->N - (int)row0 + 2047) / 2048));
+    hipLaunchKernelGGL(sr_pack_rows_kernel<false>, dim3((unsigned)(row1 - row0), gy), dim3(256), 0, (hipStream_t)stream,
+                       h->Wt + (size_t)d * h->Np * h->Np, const_cast<double*>(buf), h->N, h->Np, row0);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+extern "C" int sr_gp_import_end(sr_gp_t h) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_import_end: NULL handle");
+    SR_CHECK(h->import_open, SR_ESTATE, "sr_gp_import_end: no import in progress");
+    h->import_open = 0;
+    h->factorized = 1;
+    return SR_OK;
+}
+
 extern "C" int sr_gp_mll(sr_gp_t h, double* nll, double* grad, void* stream) {
     SR_CHECK(h && nll && grad, SR_EINVAL, "sr_gp_mll: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_mll: model not factorized");
@@ -757,6 +841,9 @@ static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
     // big ones: sizing by max(nsplit) x max(Tp) would hold GBs of dead workspace)
     const long need_part = (long)nsplit * Tp;
     if (Tp <= h->ws_Tp && need_part <= h->ws_part) return SR_OK;
+    // a caller that has already handed h->mu / h->var / h->jac on (prepare_ws) must have sized for every route
+    SR_CHECK(!h->ws_locked, SR_ESTATE, "internal: workspace of %ld x %ld needs %ld x %d while its buffers are in use",
+             h->ws_Tp, h->ws_part, Tp, nsplit);
     const long nTp = std::max(Tp, h->ws_Tp);
     const long npart = std::max(need_part, h->ws_part);
     (void)hipDeviceSynchronize();
@@ -778,6 +865,22 @@ static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
     h->ws_part = npart;
     return SR_OK;
 }
+
+// Size the workspace for WHATEVER route gp_pass takes with Tc queries, before an entry point resolves h->mu / h->var /
+// h->jac: the fused small-batch route wants 2 * ceil(Np / 256) mean partials per query, which exceeds pick_nsplit for
+// big models (n_out = 2: Np > 49152) -- sized by pick_nsplit alone, the first T <= 64 reachability call on such a
+// model reallocated the workspace under the pointers its caller held.  The lock turns any such growth into an error.
+static int prepare_ws(sr_gp* h, long Tc) {
+    const long Tp = round_up(Tc, srt::BN);
+    int ns = pick_nsplit(h, Tp);
+    if (Tc <= SR_STREAM_MAX_T) ns = std::max(ns, std::max(pick_nsplit(h, srt::BN), 2 * ((h->Np + 255) / 256)));
+    return ensure_ws(h, Tp, ns);
+}
+struct sr_ws_lock {
+    sr_gp* h;
+    explicit sr_ws_lock(sr_gp* h_) : h(h_) { h->ws_locked = 1; }
+    ~sr_ws_lock() { h->ws_locked = 0; }
+};
 
 // ---- fused small-batch route (sr_stream.hip) ----------------------------------------------------------------
 // Models beyond the one-launch sizes, up to 128 columns (queries, or [k*, dk*/dx] of one query): U^-1 is streamed
@@ -1121,7 +1224,8 @@ static int ensure_tz(sr_gp* h, long Tc, int n_s, int n_u) {
     dev_free(h->tz_x); dev_free(h->tz_jac);
     h->tz_x = h->tz_jac = nullptr; h->tz_cap = 0;
     SR_TRY(dev_alloc(&h->tz_x, (size_t)Tc * SR_MAX_D));
-    SR_TRY(dev_alloc(&h->tz_jac, (size_t)Tc * n_s * (n_s + n_u)));
+    // (sized for any later transform of this handle: a smaller n_x_in means a larger n_u = D - n_x_in)
+    SR_TRY(dev_alloc(&h->tz_jac, (size_t)Tc * SR_MAX_NS * (SR_MAX_NS + SR_MAX_D)));
     h->tz_cap = Tc;
     return SR_OK;
 }
@@ -1190,8 +1294,9 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
         double* var_dst = var_out ? var_out + t0 * n_s : nullptr;
-        // gp_pass may (re)allocate the workspace: resolve internal pointers after it
-        SR_TRY(ensure_ws(h, round_up(Tc, srt::BN), pick_nsplit(h, round_up(Tc, srt::BN))));
+        // gp_pass must not (re)allocate the workspace once internal pointers are resolved
+        SR_TRY(prepare_ws(h, Tc));
+        sr_ws_lock lock(h);
         if (!var_dst) var_dst = h->var;
         const double* jac_su = nullptr;
         SR_TRY(gp_pass_states(h, Tc, p + t0 * n_s, n_s, n_s, k_ff + t0 * n_u, n_u, n_u, h->mu, var_dst, &jac_su, s));
@@ -1287,7 +1392,8 @@ static int multistep_impl(sr_gp* h, long T, int H, int mode, const double* p0, c
     if (chained) return SR_OK;
     for (long t0 = 0; t0 < T; t0 += h->chunk) {
         const long Tc = std::min(h->chunk, T - t0);
-        SR_TRY(ensure_ws(h, round_up(Tc, srt::BN), pick_nsplit(h, round_up(Tc, srt::BN))));
+        SR_TRY(prepare_ws(h, Tc));
+        sr_ws_lock lock(h);
         for (int i = 0; i < H; ++i) {
             // inputs of step i (gp_reachability.py:195-210)
             const double* p_in; long ldp; const double* q_in; long ldq; const double* kfb_in; long ldkfb;
@@ -1685,6 +1791,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         if (!z_inplace) dev_free(Z1);
         if (!vec_alt) { dev_free(yT1); dev_free(alpha1); }
         if (!reuse_alt) dev_free(Wt1);
+        else h->wt_alt_off = -1;       // the spare factor buffer may hold a half-written state now
     };
 #define SR_A(expr) do { rc = (expr); if (rc != SR_OK) { drop_new(); return rc; } } while (0)
 #define SR_AH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -1833,6 +1940,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     auto drop_new = [&]() {
         dev_free(Z1); dev_free(yT1); dev_free(alpha1);
         if (!reuse_alt) dev_free(Wt1);
+        else h->wt_alt_off = -1;       // the spare factor buffer may hold a half-written state now
     };
 #define SR_A(expr) do { rc = (expr); if (rc != SR_OK) { drop_new(); return rc; } } while (0)
 #define SR_AH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \

@@ -61,7 +61,12 @@ extern "C" int sr_comm_init_all(int ndev, const int* devices) {
 
 // handles[i] lives on the i-th device of sr_comm_init_all; handles[root] is factorised, the others have their data
 // set (sr_gp_set_data[_general]: Z, targets, hyper-parameters -- a few KB the host has anyway).  On return every handle
-// holds the root's posterior (alpha, U^-1) and is ready to predict: ONE broadcast of n_out * (Np^2 + N) doubles.
+// holds the root's posterior (alpha, U^-1) and is ready to predict.  What travels: alpha and the PACKED upper triangle
+// of U^-1 -- n_out * (N + N (N + 1) / 2) doubles, half of the dense buffer -- in pieces of <= 64 MB through ONE staging
+// buffer per device (pack on the root, broadcast, unpack on the receivers, all in order on the device's stream): no
+// copy of the factor's size anywhere (the first version staged the dense n_out * Np^2 buffer on every device).
+static const long SR_COMM_PIECE = 8L << 20;       // doubles per staging piece
+
 extern "C" int sr_comm_bcast(sr_gp_t* handles, int ndev, int root) {
     if ((int)g_comms.size() != ndev || ndev < 1) return fail(SR_ESTATE, "sr_comm_bcast: call sr_comm_init_all(%d, ...) first", ndev);
     if (handles == nullptr || root < 0 || root >= ndev) return fail(SR_EINVAL, "sr_comm_bcast: bad argument");
@@ -76,30 +81,57 @@ extern "C" int sr_comm_bcast(sr_gp_t* handles, int ndev, int root) {
     }
     int prev = 0;
     (void)hipGetDevice(&prev);
-    const size_t na = (size_t)n_out * N, nw = (size_t)n_out * Np * Np;
-    std::vector<double*> buf(ndev, nullptr);
+    // row ranges of the packed triangle, each at most SR_COMM_PIECE doubles (a single row may exceed it)
+    struct piece { long r0, r1, cnt; };
+    std::vector<piece> pieces;
+    long cap = 0;
+    for (long r0 = 0; r0 < N;) {
+        long r1 = r0 + 1, cnt = N - r0;
+        while (r1 < N && cnt + (N - r1) <= SR_COMM_PIECE) { cnt += N - r1; ++r1; }
+        pieces.push_back({r0, r1, cnt});
+        cap = cnt > cap ? cnt : cap;
+        r0 = r1;
+    }
+    const size_t na = (size_t)n_out * N;
+    std::vector<double*> buf(ndev, nullptr);                  // [alpha | one staging piece]
     int rc = SR_OK;
     for (int i = 0; i < ndev && rc == SR_OK; ++i) {
-        if (hipSetDevice(g_devs[i]) != hipSuccess || hipMalloc((void**)&buf[i], (na + nw) * sizeof(double)) != hipSuccess)
-            rc = fail(SR_EHIP, "sr_comm_bcast: allocation of %zu bytes on device %d failed", (na + nw) * sizeof(double), g_devs[i]);
+        if (hipSetDevice(g_devs[i]) != hipSuccess || hipMalloc((void**)&buf[i], (na + (size_t)cap) * sizeof(double)) != hipSuccess)
+            rc = fail(SR_EHIP, "sr_comm_bcast: allocation of %zu bytes on device %d failed", (na + (size_t)cap) * sizeof(double), g_devs[i]);
     }
-    if (rc == SR_OK && sr_gp_export(handles[root], buf[root], buf[root] + na, g_streams[root]) != SR_OK)
-        rc = fail(SR_ESTATE, "sr_comm_bcast: %s", sr_last_error());
-    if (rc == SR_OK) {
+    auto bcast = [&](size_t off, size_t count) -> int {
         ncclResult_t r = ncclGroupStart();
         for (int i = 0; i < ndev && r == ncclSuccess; ++i)
-            r = ncclBroadcast(buf[i], buf[i], na + nw, ncclDouble, root, g_comms[i], g_streams[i]);
+            r = ncclBroadcast(buf[i] + off, buf[i] + off, count, ncclDouble, root, g_comms[i], g_streams[i]);
         const ncclResult_t r2 = ncclGroupEnd();
         if (r != ncclSuccess || r2 != ncclSuccess)
-            rc = fail(SR_EHIP, "sr_comm_bcast: RCCL broadcast failed: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
-    }
-    for (int i = 0; i < ndev && rc == SR_OK; ++i) {
-        if (i != root && sr_gp_import(handles[i], buf[i], buf[i] + na, g_streams[i]) != SR_OK)
+            return fail(SR_EHIP, "sr_comm_bcast: RCCL broadcast failed: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
+        return SR_OK;
+    };
+    if (rc == SR_OK && sr_gp_export(handles[root], buf[root], nullptr, g_streams[root]) != SR_OK)
+        rc = fail(SR_ESTATE, "sr_comm_bcast: %s", sr_last_error());
+    if (rc == SR_OK) rc = bcast(0, na);
+    for (int i = 0; i < ndev && rc == SR_OK; ++i)
+        if (i != root && sr_gp_import_begin(handles[i], buf[i], g_streams[i]) != SR_OK)
             rc = fail(SR_ESTATE, "sr_comm_bcast: %s", sr_last_error());
+    for (int d = 0; d < n_out && rc == SR_OK; ++d) {
+        for (const piece& pc : pieces) {
+            if (sr_gp_export_packed(handles[root], d, pc.r0, pc.r1, buf[root] + na, g_streams[root]) != SR_OK) {
+                rc = fail(SR_ESTATE, "sr_comm_bcast: %s", sr_last_error());
+                break;
+            }
+            if ((rc = bcast(na, (size_t)pc.cnt)) != SR_OK) break;
+            for (int i = 0; i < ndev && rc == SR_OK; ++i)
+                if (i != root && sr_gp_import_packed(handles[i], d, pc.r0, pc.r1, buf[i] + na, g_streams[i]) != SR_OK)
+                    rc = fail(SR_ESTATE, "sr_comm_bcast: %s", sr_last_error());
+            if (rc != SR_OK) break;
+        }
     }
     for (int i = 0; i < ndev; ++i) {
         (void)hipSetDevice(g_devs[i]);
         if (g_streams[i]) (void)hipStreamSynchronize(g_streams[i]);
+        if (rc == SR_OK && i != root && sr_gp_import_end(handles[i]) != SR_OK)
+            rc = fail(SR_ESTATE, "sr_comm_bcast: %s", sr_last_error());
         if (buf[i]) (void)hipFree(buf[i]);
     }
     (void)hipSetDevice(prev);

@@ -69,20 +69,103 @@ def broadcast_model_state(gp, src=0, device=None):
     return spec[0], broadcast_tensors(payload, src=src, device=device)
 
 
-def replicate_model(gp, prob=None, src=0, device=None):
+PIECE_DOUBLES = 8 << 20       # staging piece of the packed factor: 64 MB (two of them live on every rank)
+
+
+def packed_pieces(N, max_doubles=PIECE_DOUBLES):
+    """Row ranges [(row0, row1, count)] of the packed upper triangle (row i carries N - i doubles), each at most
+    ``max_doubles`` long (a single row may exceed it)."""
+    out, r0, N = [], 0, int(N)
+    while r0 < N:
+        # largest r1 with (r1 - r0) N - (r1 (r1 - 1) - r0 (r0 - 1)) / 2 <= max_doubles
+        lo, hi = r0 + 1, N
+        cnt = lambda r1: (r1 - r0) * N - (r1 * (r1 - 1) - r0 * (r0 - 1)) // 2
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            if cnt(mid) <= max_doubles:
+                lo = mid
+            else:
+                hi = mid - 1
+        out.append((r0, lo, cnt(lo)))
+        r0 = lo
+    return out
+
+
+LAST_REPLICATION = {}         # statistics of the last replicate_model on this rank (bytes moved, pieces)
+
+
+def broadcast_packed_factor(N, n_out, export_piece, import_piece, src=0, device=None, piece_doubles=PIECE_DOUBLES):
+    """The packed upper triangle of U^-1 of every output from rank ``src`` to all others, in pieces of at most
+    ``piece_doubles`` through TWO staging buffers: while piece k travels, piece k+1 is packed on the sender and piece
+    k-1 unpacked on the receivers.  ``export_piece(d, row0, row1, buf)`` fills ``buf`` on the sender,
+    ``import_piece(d, row0, row1, buf)`` consumes it on a receiver (either may be None on the ranks that do not need
+    it).  Returns (bytes moved, pieces)."""
+    rank = dist.get_rank()
+    pieces = packed_pieces(N, piece_doubles)
+    cap = max(c for _, _, c in pieces)
+    stage = [torch.empty(cap, dtype=torch.float64, device=device) for _ in range(2)]
+    inflight = [None, None]
+
+    def retire(b):
+        if inflight[b] is not None:
+            work, args = inflight[b]
+            work.wait()
+            if rank != src:
+                import_piece(*args)
+            inflight[b] = None
+
+    moved = k = 0
+    for d in range(n_out):
+        for (r0, r1, cnt) in pieces:
+            b = k & 1
+            retire(b)                              # the broadcast that last used this staging buffer
+            buf = stage[b][:cnt]
+            if rank == src:
+                export_piece(d, r0, r1, buf)
+            inflight[b] = (dist.broadcast(buf, src=src, async_op=True), (d, r0, r1, buf))
+            moved += cnt * 8
+            k += 1
+    retire(k & 1)
+    retire((k + 1) & 1)
+    return moved, k
+
+
+def replicate_model(gp, prob=None, src=0, device=None, piece_doubles=PIECE_DOUBLES):
     """Rank `src` holds a trained HIP SimpleGPModel; every other rank receives the model description (object
-    broadcast: dimensions, kernels, hyper-parameters, noise), then Z, the targets that belong to Z, alpha and
-    U^-1 over RCCL, and adopts them without factorising (sr_gp_import).  ``prob`` is accepted for backward
-    compatibility and ignored: the source model is the single source of truth.  Returns the rank-local model."""
+    broadcast: dimensions, kernels, hyper-parameters, noise), then Z, the targets that belong to Z and alpha, then
+    the PACKED upper triangle of U^-1 -- N (N + 1) / 2 doubles per output instead of the Np^2 of the dense buffer, in
+    pieces of <= 64 MB through two staging buffers (no copy of the factor's size on either side) -- and adopts it
+    without factorising (sr_gp_import_begin / _packed / _end).  RCCL over xGMI with backend "nccl", gloo in the tests.
+    ``prob`` is accepted for backward compatibility and ignored: the source model is the single source of truth.
+    Returns the rank-local model."""
     from .ssm_hip.gaussian_process import SimpleGPModel
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    spec, got = broadcast_model_state(gp, src=src, device=dev)
-    if dist.get_rank() == src:
-        return gp
-    local = SimpleGPModel(spec["n_s_out"], spec["n_s_in"], spec["n_u"], kern_types=spec["kern_types"],
-                          hyp=spec["hyp"], device=dev)
-    local.import_state(got["Z"].cpu().numpy(), got["Y"].cpu().numpy(), got["alpha"], got["wt"],
-                       noise_diag=spec["noise_diag"])
+    rank = dist.get_rank()
+    spec = [model_spec(gp) if rank == src else None]
+    dist.broadcast_object_list(spec, src=src)
+    spec = spec[0]
+    payload = None
+    if rank == src:
+        payload = {"Z": torch.from_numpy(np.ascontiguousarray(gp.z_fit)),
+                   "Y": torch.from_numpy(np.ascontiguousarray(gp.y_z)), "alpha": gp.export_alpha()}
+    got = broadcast_tensors(payload, src=src, device=dev)
+    N, n_out = got["Z"].shape[0], spec["n_s_out"]
+    if rank == src:
+        local = gp
+    else:
+        local = SimpleGPModel(spec["n_s_out"], spec["n_s_in"], spec["n_u"], kern_types=spec["kern_types"],
+                              hyp=spec["hyp"], device=dev)
+        local.begin_import(got["Z"].cpu().numpy(), got["Y"].cpu().numpy(), got["alpha"],
+                           noise_diag=spec["noise_diag"])
+    moved, k = broadcast_packed_factor(N, n_out, local.export_packed if rank == src else None,
+                                       local.import_packed if rank != src else None, src=src, device=dev,
+                                       piece_doubles=piece_doubles)
+    if rank != src:
+        local.end_import()
+    torch.cuda.current_stream(dev).synchronize()
+    LAST_REPLICATION.clear()
+    LAST_REPLICATION.update({"factor_bytes": moved, "other_bytes": sum(int(t.numel()) * 8 for t in got.values()),
+                             "pieces": k, "dense_factor_bytes": n_out * (-(-N // 128) * 128) ** 2 * 8})
     return local
 
 

@@ -549,6 +549,64 @@ class SimpleGPModel(StateSpaceModel):
         check(lib.sr_gp_export(hd.h, B.ptr(alpha), B.ptr(wt), B.stream_ptr(hd.device)))
         return alpha, wt
 
+    # ---- packed replication (one-time broadcast to the other GPUs; parallel.replicate_model) ----------------------
+    def export_alpha(self):
+        """alpha (n_out, N) as a device tensor."""
+        self._need_trained()
+        hd = self._handle
+        alpha = B.empty((hd.n_out, hd.N), hd.device)
+        check(lib.sr_gp_export(hd.h, B.ptr(alpha), None, B.stream_ptr(hd.device)))
+        return alpha
+
+    def packed_count(self, row0, row1):
+        n = lib.sr_gp_packed_count(self._handle.h, int(row0), int(row1))
+        if n < 0:
+            raise ValueError("rows [%d, %d) outside the model" % (row0, row1))
+        return int(n)
+
+    def export_packed(self, d, row0, row1, buf):
+        """Rows [row0, row1) of the upper triangle of U^-1 of output d, packed back to back into ``buf`` (device
+        tensor with room for ``packed_count(row0, row1)`` doubles), on the current stream."""
+        self._need_trained()
+        hd = self._handle
+        assert buf.is_cuda and buf.dtype == torch.float64 and buf.numel() >= self.packed_count(row0, row1)
+        check(lib.sr_gp_export_packed(hd.h, int(d), int(row0), int(row1), B.ptr(buf), B.stream_ptr(hd.device)))
+
+    def begin_import(self, Z, Y, alpha, noise_diag=1e-5):
+        """Receiver side of the packed replication: data + alpha now, then ``import_packed`` for every piece of every
+        output, then ``end_import``.  No factorisation here."""
+        dev = B.resolve_device(self._device_arg)
+        Z = np.asarray(Z, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64)
+        N, D = Z.shape
+        handle = _Handle(dev, N, D, self.n_s_out)
+        noise = self._noise + float(noise_diag) + GPY_JITTER
+        s = B.stream_ptr(dev)
+        self._set_data(handle, Z, Y, noise, dev, s)
+        ta = B.as_dev(alpha, dev, (self.n_s_out, N))
+        check(lib.sr_gp_import_begin(handle.h, B.ptr(ta), s))
+        torch.cuda.current_stream(dev).synchronize()        # ta may go
+        self._import = (handle, Z, Y, noise_diag)
+
+    def import_packed(self, d, row0, row1, buf):
+        handle = self._import[0]
+        check(lib.sr_gp_import_packed(handle.h, int(d), int(row0), int(row1), B.ptr(buf), B.stream_ptr(handle.device)))
+
+    def end_import(self):
+        handle, Z, Y, noise_diag = self._import
+        check(lib.sr_gp_import_end(handle.h))
+        torch.cuda.current_stream(handle.device).synchronize()
+        self._import = None
+        self._handle = handle
+        self._noise_diag = noise_diag
+        self._beta = None
+        self._inv_K = None
+        self.z = Z
+        self.x_train = Z
+        self.y_train = Y
+        self._z_fit, self._y_z = Z, Y
+        self.gp_trained = True
+
     def import_state(self, Z, Y, alpha, wt, noise_diag=1e-5):
         """Adopt a posterior factorised elsewhere (rank-0 broadcast): no factorisation here."""
         dev = B.resolve_device(self._device_arg)

@@ -107,6 +107,66 @@ def test_model_state_broadcast_world2():
         np.testing.assert_array_equal(ret["ls1"], [1.5, 1.0, 0.5])
 
 
+def _packed_worker(rank, world, port, N, n_out, piece, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # host stand-ins of sr_gp_export_packed / sr_gp_import_packed: row i contributes U[i, i:]
+        rng = np.random.default_rng(5)
+        U = np.triu(rng.standard_normal((n_out, N, N)))
+        recv = np.zeros_like(U)
+        calls = []
+
+        def export_piece(d, r0, r1, buf):
+            buf.copy_(torch.from_numpy(np.concatenate([U[d, i, i:] for i in range(r0, r1)])))
+
+        def import_piece(d, r0, r1, buf):
+            calls.append((d, r0, r1))
+            flat, o = buf.numpy(), 0
+            for i in range(r0, r1):
+                recv[d, i, i:] = flat[o:o + N - i]
+                o += N - i
+            assert o == flat.size
+
+        moved, k = parallel.broadcast_packed_factor(N, n_out, export_piece if rank == 0 else None,
+                                                    import_piece if rank != 0 else None, src=0,
+                                                    device=torch.device("cpu"), piece_doubles=piece)
+        if rank == 1:
+            ret["equal"] = bool(np.array_equal(recv, U))
+            ret["moved"], ret["pieces"], ret["calls"] = moved, k, calls
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_factor_broadcast_world2():
+    """the chunked, double-buffered broadcast of the packed triangle: every piece arrives once, in order, and the
+    receiver rebuilds exactly the sender's upper triangle; N (N + 1) / 2 doubles per output travel."""
+    N, n_out, piece = 37, 2, 100
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_packed_worker, args=(2, _free_port(), N, n_out, piece, ret), nprocs=2, join=True)
+        assert ret["equal"]
+        assert ret["moved"] == n_out * N * (N + 1) // 2 * 8
+        pcs = parallel.packed_pieces(N, piece)
+        assert ret["pieces"] == n_out * len(pcs) and len(pcs) > 3
+        assert ret["calls"] == [(d, r0, r1) for d in range(n_out) for (r0, r1, _) in pcs]
+
+
+def test_packed_pieces_cover_the_triangle():
+    for N in (1, 2, 127, 128, 5000, 50000):
+        for cap in (1, 1000, 8 << 20):
+            if N > 5000 and cap < 1000:
+                continue
+            pcs = parallel.packed_pieces(N, cap)
+            assert pcs[0][0] == 0 and pcs[-1][1] == N
+            assert all(a[1] == b[0] for a, b in zip(pcs[:-1], pcs[1:]))
+            assert sum(c for _, _, c in pcs) == N * (N + 1) // 2
+            # a piece only exceeds the cap when it is a single row
+            assert all(c <= cap or r1 - r0 == 1 for r0, r1, c in pcs)
+
+
 def test_shard_bounds_partition():
     for T in (0, 1, 7, 64, 65536, 8388608 + 3):
         for world in (1, 2, 3, 8):

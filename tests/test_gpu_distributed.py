@@ -76,3 +76,59 @@ def test_two_ranks_share_one_gpu(lib_built):
         assert ret["shape"] == (1001, 2, 2)
         assert ret["dp"] < 1e-13 and ret["dq"] < 1e-12
         assert ret["d_mu_sharded_fit"] == 0.0 and ret["d_var_sharded_fit"] == 0.0
+
+
+def _run_bench(argv, env_extra=None, timeout=1500):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, cwd=root,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, "bench.py failed:\n%s\n%s" % (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line expected, got %d:\n%s" % (len(lines), r.stdout[-2000:])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_c5_on_one_gpu(lib_built, tmp_path):
+    """bench.py's N > 1 branch, executed: two self-spawned ranks share cuda:0 over gloo (SR_DIST_BACKEND /
+    SR_SHARE_DEVICE; RCCL refuses two ranks on one device), workload c5 (N = 5000, 131072 queries per rank in two
+    chunks), packed-triangle replication.  The parsed line must describe what ran, and rank 1's shard must equal a
+    single-process evaluation of the same query rows on a model factorised HERE (the replica was never factorised)."""
+    T = 131072
+    line = _run_bench(["--gpus", "2", "--workload", "c5", "--queries", str(T), "--steps", "2", "--warmup", "1",
+                       "--dump-shards", str(tmp_path)],
+                      {"SR_DIST_BACKEND": "gloo", "SR_SHARE_DEVICE": "1"})
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    par = line["config"]["parallelism"]
+    assert "gloo" in par and "world=2" in par and "all ranks on cuda:0" in par
+    assert line["config"]["broadcast_s"] > 0
+    N, n_out = 5000, 2
+    packed = n_out * N * (N + 1) // 2 * 8
+    assert line["config"]["broadcast_bytes"] == packed + (N * 3 + N * n_out + n_out * N) * 8
+    assert line["config"]["broadcast_dense_factor_bytes"] == n_out * 5120 * 5120 * 8
+    assert line["config"]["broadcast_bytes"] < 0.51 * line["config"]["broadcast_dense_factor_bytes"]
+    assert line["config"]["broadcast_GBps"] > 0
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert abs(line["value"] - 2 * T * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    # rank 1's shard against a single-process evaluation
+    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload
+    d1 = np.load(os.path.join(str(tmp_path), "shard_rank1.npz"))
+    assert int(d1["rank"]) == 1 and int(d1["world"]) == 2 and int(d1["T"]) == T
+    prob = workload.make_problem(5, N, 2, 1, 16)
+    gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob))
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+    q = workload.make_queries(int(d1["query_seed"]), 2, 1, T)
+    l = np.array([0.05, 0.02])
+    head = d1["p_head"].shape[0]
+    p1, q1 = reach.onestep_reachability_batch(q["p"], gp, q["k_ff"], l, l, q["Q"], q["k_fb"], 2.0,
+                                              np.eye(2), np.zeros((2, 1)))
+    np.testing.assert_allclose(d1["p_head"], p1[:head], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(d1["q_head"], q1[:head], rtol=1e-12, atol=1e-16)
+    np.testing.assert_allclose(d1["p_sum"], p1.sum(0), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(d1["q_sum"], q1.sum(0), rtol=1e-10)
+    d0 = np.load(os.path.join(str(tmp_path), "shard_rank0.npz"))
+    assert int(d0["query_seed"]) == -1 and not np.array_equal(d0["p_head"], d1["p_head"])

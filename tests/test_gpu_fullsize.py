@@ -245,3 +245,77 @@ def test_casadi_evaluator_callbacks_on_the_hip_model(kt, N, n_s, n_u, monkeypatc
     ax2, au2 = (np.array(o) for o in ev2.get_reverse(1, "adj2", [], [], {})(x, u, m2, v2, s_mu, s_var))
     g2 = np.concatenate((s_mu.ravel(), s_var.ravel())).dot(st2)
     np.testing.assert_allclose(np.concatenate((ax2.ravel(), au2.ravel())), g2, rtol=1e-12, atol=1e-13 * np.abs(g2).max())
+
+
+def test_packed_export_import_round_trip():
+    """The replication format (sr_gp_export_packed / sr_gp_import_begin / _packed / _end): pieces of the packed upper
+    triangle into a fresh handle, in shuffled order, must reproduce the sender's dense U^-1 and alpha bit for bit --
+    and with them every prediction.  N not a multiple of 128 (front padding in play)."""
+    import torch
+    from safe_exploration_amd import SimpleGPModel, parallel
+    for N, n_s, n_u in ((333, 2, 1), (1500, 3, 2)):
+        syn = orc.make_synthetic(40 + N, N, n_s, n_u, 300)
+        gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+        alpha, wt = gp.export_state()
+        pieces = parallel.packed_pieces(N, 40000)
+        assert len(pieces) >= 3
+        assert gp.packed_count(0, N) == N * (N + 1) // 2
+        other = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s,
+                              hyp=hyp_from(syn["lengthscale"], syn["signal_var"], syn["noise_var"]))
+        other.begin_import(syn["Z"], syn["Y"], gp.export_alpha())
+        jobs = [(d, r0, r1, c) for d in range(n_s) for (r0, r1, c) in pieces]
+        np.random.default_rng(0).shuffle(jobs)
+        for d, r0, r1, c in jobs:
+            buf = torch.empty(c, dtype=torch.float64, device=gp.device)
+            gp.export_packed(d, r0, r1, buf)
+            # the packed piece is exactly rows r0..r1-1 of the upper triangle of the real block
+            off = wt.shape[1] - N
+            want = torch.cat([wt[d, off + i, off + i:] for i in range(r0, min(r1, r0 + 3))])
+            assert torch.equal(buf[:want.numel()], want)
+            other.import_packed(d, r0, r1, buf)
+        other.end_import()
+        a2, w2 = other.export_state()
+        assert torch.equal(a2, alpha) and torch.equal(w2, wt)
+        x = np.hstack((syn["p"], syn["k_ff"]))
+        m1, v1 = gp.predict(x)
+        m2, v2 = other.predict(x)
+        assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+    with pytest.raises(ValueError):
+        gp.packed_count(5, 3)
+
+
+def test_first_small_batch_reach_call_on_a_big_model():
+    """on a model with 2 ceil(Np / 256) > pick_nsplit (n_out = 8: Np > 12288) the fused T <= 64 route needs
+    more mean partials than the reachability entry points used to size the workspace for -- the first such call on a
+    fresh handle reallocated the workspace under the pointers its caller held.  First call on the handle: T = 8
+    one-step reachability; then the same rows through the plain three-kernel route and a 3-step chain."""
+    import torch
+    from safe_exploration_amd import gp_reachability as reach
+    n_s, n_u, N, T = 8, 1, 12400, 8
+    syn = orc.make_synthetic(77, N, n_s, n_u, T, sf2=0.01)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    l = np.full(n_s, 0.05)
+    a, b = 0.5 * np.eye(n_s), np.zeros((n_s, n_u))
+    p1, q1, v1 = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0, a, b,
+                                                  return_var=True)
+    assert np.isfinite(q1).all() and (v1 > 0).all()
+    gp.set_small_path(0)
+    p0, q0, v0 = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0, a, b,
+                                                  return_var=True)
+    gp.set_small_path(1)
+    np.testing.assert_allclose(p1, p0, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(v1, v0, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(q1, q0, rtol=1e-8, atol=1e-14)
+    # the posterior itself against predict() on the same inputs (a different entry point, its own buffers)
+    mu, var = gp.predict(np.hstack((syn["p"], syn["k_ff"])))
+    np.testing.assert_allclose(v1, var, rtol=0, atol=1e-11)
+    # a short chain as the first multi-step call (T <= 64 per step)
+    gp2 = hip_model(syn["Z"][:12300], syn["Y"][:12300], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    rng = np.random.default_rng(3)
+    k_ff = 0.1 * rng.standard_normal((T, 3, n_u))
+    k_fb = 0.1 * rng.standard_normal((T, 2, n_u, n_s))
+    pa, qa = reach.multistep_reachability_batch(syn["p"], gp2, k_fb, k_ff, l, l, None, 2.0, a, b)
+    gp2.set_small_path(0)
+    pb, qb = reach.multistep_reachability_batch(syn["p"], gp2, k_fb, k_ff, l, l, None, 2.0, a, b)
+    np.testing.assert_allclose(pa, pb, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(qa, qb, rtol=1e-7, atol=1e-13)
