@@ -430,7 +430,10 @@ def run(args):
                          "launches": var_n,
                          "hbm_gbps_achieved": bytes_step / step_s / 1e9,
                          "hbm_frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS,
-                         "hbm_bytes_per_step_algorithmic": bytes_step},
+                         "hbm_bytes_per_step_algorithmic": bytes_step,
+                         "hbm_note": "SURVEY 8(d) B = factor once per 65536-query pass + Z + alpha + the API arrays; the "
+                                     "K* workspace round trip of this design (roofline_kstar.bytes_per_launch written, "
+                                     "then read by sr_var_kernel) is extra and still far below the roof"},
             "roofline_kstar": {"kernel": "sr_kstar_kernel", "bound": "hbm-write", "achieved": ks_gbs,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ks_gbs / HBM_PEAK_GBS,
                                "bytes_per_launch": ks_bytes, "avg_launch_ms": ks_avg_ms, "launches": ks_n,

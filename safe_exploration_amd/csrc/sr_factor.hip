@@ -474,7 +474,7 @@ __device__ __forceinline__ void sr_invert16(const double* S, int j0, const doubl
     }
 }
 
-__global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
+__global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_v2_kernel(double* A, long lda,
                                                                          double* wt_diag, double* w_diag,
                                                                          long ldw, int kb, int* info, int skip) {
     // skip: ablation bits of sr_test_potrf_diag (0 in production): 1 pivots, 2 panel rows, 4 trailing update,
@@ -651,10 +651,228 @@ int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int
     return SR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Diagonal block, round 3: factor AND inverse in ONE sweep over the 8 panels of 16 columns.
+// The elimination that turns A_kk into U_kk (U^-T A = U) is applied to an augmented identity at the same time, so that
+// V = U_kk^-T is complete the moment the factor is -- the separate inversion phase of the kernel above (sub-block
+// inverses + three combination levels, 5 more barriers) is gone, and so are the VALU forward substitutions:
+//   * sr_factor16_aug: the 16 x 16 pivot block in registers as before; lanes 16..31, which only mirrored lanes 0..15,
+//     now carry the columns of the identity through the same row operations: T_p = U_pp^-T at no extra instruction;
+//   * phase 1 of panel p: the panel row  U[p][c] = T_p A[p][c] (c > p)  and  V[p][c'] = T_p V[p][c'] (c' < p): seven
+//     16 x 16 tiles, 4 MFMAs each, one wavefront per tile, in place in LDS and straight to global memory;
+//   * phase 2: trailing updates  A[r][c] -= U[p][r]^T U[p][c]  (p < r <= c)  and  V[r][c'] -= U[p][r]^T V[p][c']
+//     (c' <= p < r) as independent tile jobs; wavefront 0 updates the next pivot tile from the panel tile it still
+//     holds in registers (the MFMA result layout IS the operand layout of the next product: row (lane>>4) + 4 reg,
+//     column lane & 15) and factors it at once.
+//   V lives in the strict lower block triangle of S (A needs the upper one only): no second LDS matrix.
+// fp64 MFMA and fp64 VALU share the DP pipe of a SIMD: the wavefronts that sit on wavefront 0's SIMD (4, 8, 12) take no
+// MFMA job in phase 2 -- they copy the pivot stage to global memory and write the structural zeros of the outputs --,
+// else the pivot chain (the critical path: 16 dependent rsqrt / FMA sequences per panel) stalls behind their MFMAs
+// (first version of this kernel, every wavefront computing the panel tiles it needs itself: 43 us).
+// Two barriers per panel.
+// ------------------------------------------------------------------------------------------------
+#define SR_PD_TLD 33      // pivot stage: 16 rows of [U_pp (16 columns) | T_p = U_pp^-T (16 columns)], padded
+
+// upper Cholesky of the 16 x 16 tile at (j0, j0) of S by one wavefront in registers.  X (LDS, 16 x SR_PD_TLD) receives
+// [U | T], T = U^-T (lower triangular, exact zeros above; the part of U below its diagonal is scratch).
+// *fail: 1-based index of the first non-positive pivot.  Nothing but the 16 LDS writes follows the pivot chain: the
+// copies to global memory are another wavefront's job.
+__device__ __forceinline__ void sr_factor16_aug(const double* S, int j0, double* X, int* fail, int lane) {
+    const int c = lane & 15;
+    const bool aug = (lane & 16) != 0;              // lanes 16..31 (and their mirrors 48..63): columns of the identity
+    double a[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = aug ? ((r == c) ? 1.0 : 0.0) : S[(j0 + r) * SR_PD_LD + j0 + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double d = sr_readlane_f64(a[j], j);       // pivot: wavefront-uniform
+        if (!(d > 0.0)) {                          // also catches NaN
+            if (lane == 0 && *fail == 0) *fail = j0 + j + 1;
+            d = 1.0;
+        }
+        double sd, inv;
+        sr_sqrt_rsqrt(d, sd, inv);
+        a[j] = (!aug && c == j) ? sd : a[j] * inv; // row j of [U | U^-T]
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) {
+            const double ujr = sr_readlane_f64(a[j], r);     // U[j][r]: wavefront-uniform
+            a[r] = fma(-ujr, a[j], a[r]);
+        }
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[r * SR_PD_TLD + lane] = a[r];
+    }
+}
+
+// P = T X for the 16 x 16 tile X at rows j0.., columns c0.. of S: result in the MFMA layout (reg q: row (lane>>4) + 4 q,
+// column lane & 15), which is also the A- and B-operand layout of a product that contracts over P's rows
+__device__ __forceinline__ d4_t sr_pd_panel_tile(const double* S, const double* X, int j0, int c0, int lk, int ln) {
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double af = X[ln * SR_PD_TLD + 16 + 4 * kk + lk];
+        const double bf = S[(j0 + 4 * kk + lk) * SR_PD_LD + c0 + ln];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
+                                                                         double* wt_diag, double* w_diag,
+                                                                         long ldw, int kb, int* info, int skip) {
+    // skip (sr_test_potrf_diag; 0 in production): 64 = leave A untouched (back-to-back timing on one input)
+    __shared__ double S[SR_NB * SR_PD_LD];
+    __shared__ double Xb[2][16 * SR_PD_TLD];
+    __shared__ int fail;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
+    const long k0 = (long)kb * SR_NB;
+    const bool storeA = !(skip & 64);
+    double* Ag = A + k0 * lda + k0;
+    __builtin_amdgcn_s_setprio(3);
+    if (tid == 0) fail = 0;
+    for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
+        const int r = idx >> 7, c = idx & 127;
+        S[r * SR_PD_LD + c] = (c >= r) ? Ag[(long)r * lda + c] : 0.0;       // strict lower triangle: V = 0 off its diagonal
+    }
+    __syncthreads();
+    if (wave == 0) sr_factor16_aug(S, 0, Xb[0], &fail, lane);
+    __syncthreads();
+    // wavefront -> role in phase 2: 0 pivots; 4, 8, 12 (same SIMD as 0) stores only; the other 12 the MFMA jobs
+    const bool simd0 = (wave & 3) == 0;
+    const int worker = wave - 1 - (wave >> 2);             // 0 .. 11 for the MFMA wavefronts
+    constexpr int NWORK = 12;
+    for (int p = 0; p < SR_NB / 16; ++p) {
+        const int j0 = 16 * p;
+        const double* X = Xb[p & 1];
+        const int nbt = SR_NB / 16 - 1 - p;
+        // ---- phase 1: the seven tiles of panel row p, in place: wavefront w takes tile w (0: the next pivot's column)
+        d4_t mine = {0.0, 0.0, 0.0, 0.0};
+        if (wave < SR_NB / 16 - 1) {
+            const int ct = (wave < nbt) ? p + 1 + wave : wave - nbt;         // tile column: A part c > p, then V part c' < p
+            const int c0 = 16 * ct;
+            mine = sr_pd_panel_tile(S, X, j0, c0, lk, ln);
+            if (wave != 0 || nbt == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[(j0 + lk + 4 * q) * SR_PD_LD + c0 + ln] = mine[q];
+            }
+            if (ct > p) {
+                if (storeA && wave != 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Ag[(long)(j0 + lk + 4 * q) * lda + c0 + ln] = mine[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w_diag[(long)(j0 + lk + 4 * q) * ldw + c0 + ln] = mine[q];
+                    wt_diag[(long)(c0 + ln) * ldw + j0 + lk + 4 * q] = mine[q];
+                }
+            }
+        }
+        if (wave == 0 && nbt > 0) {
+            // the panel tile of the next pivot's column is needed by the others too (row p + 1 of the trailing update)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[(j0 + lk + 4 * q) * SR_PD_LD + j0 + 16 + ln] = mine[q];
+        }
+        __syncthreads();
+        // ---- phase 2
+        if (wave == 0) {
+            if (nbt > 0) {
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mine[kk], mine[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[(j0 + 16 + lk + 4 * q) * SR_PD_LD + j0 + 16 + ln] -= acc[q];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // the tile update above, then its reads below
+                sr_factor16_aug(S, j0 + 16, Xb[(p + 1) & 1], &fail, lane);
+            }
+        } else if (!simd0) {
+            const int nA = nbt * (nbt + 1) / 2;        // trailing tiles of A; tile 0 is wavefront 0's
+            const int nV = nbt * (p + 1);              // trailing tiles of V
+            for (int e = 1 + worker; e < nA + nV; e += NWORK) {
+                int r0, c0;
+                bool useT = false;
+                if (e < nA) {
+                    int ti = 0, rem = e;
+                    while (rem >= nbt - ti) { rem -= nbt - ti; ++ti; }
+                    r0 = 16 * (p + 1 + ti);
+                    c0 = r0 + 16 * rem;
+                } else {
+                    const int v = e - nA, ti = v / (p + 1), cq = v % (p + 1);
+                    r0 = 16 * (p + 1 + ti);
+                    c0 = 16 * cq;
+                    useT = (cq == p);                   // V[p][p] after the panel step is T itself (kept in the pivot stage)
+                }
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double af = S[(j0 + 4 * kk + lk) * SR_PD_LD + r0 + ln];
+                    const double bf = useT ? X[(4 * kk + lk) * SR_PD_TLD + 16 + ln] : S[(j0 + 4 * kk + lk) * SR_PD_LD + c0 + ln];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[(r0 + lk + 4 * q) * SR_PD_LD + c0 + ln] -= acc[q];
+            }
+        } else {
+            const int sw = (wave >> 2) - 1;            // 0, 1, 2
+            if (sw == 0) {
+                // the pivot stage of this panel: U_pp (zeros below its diagonal), T_p (lower) and T_p^T (upper)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = lk + 4 * q;
+                    const double u = X[r * SR_PD_TLD + ln], t = X[r * SR_PD_TLD + 16 + ln];
+                    if (storeA) Ag[(long)(j0 + r) * lda + j0 + ln] = (r <= ln) ? u : 0.0;
+                    w_diag[(long)(j0 + r) * ldw + j0 + ln] = t;
+                    wt_diag[(long)(j0 + ln) * ldw + j0 + r] = t;
+                }
+                if (nbt > 0 && storeA) {                // wavefront 0 left the store of U[p][p+1] to us
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        Ag[(long)(j0 + lk + 4 * q) * lda + j0 + 16 + ln] = S[(j0 + lk + 4 * q) * SR_PD_LD + j0 + 16 + ln];
+                }
+            }
+            // structural zeros: 28 pairs (strictly-lower tile (zr, zc) of A and U^-1, its mirror of U^-T), 4 per panel,
+            // wavefronts 8 and 12 two each (wavefront 4 has the pivot stage)
+            if (sw > 0 && p < 7) {
+                for (int i = 0; i < 2; ++i) {
+                    int z = 4 * p + 2 * (sw - 1) + i, zr = 1;
+                    while (z >= zr) { z -= zr; ++zr; }
+                    const int zc = z;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const long rr = 16 * zr + lk + 4 * q, cc = 16 * zc + ln;
+                        if (storeA) Ag[rr * lda + cc] = 0.0;
+                        wt_diag[rr * ldw + cc] = 0.0;
+                        w_diag[(long)(16 * zc + lk + 4 * q) * ldw + 16 * zr + ln] = 0.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (fail) {
+        if (tid == 0 && *info == 0) *info = (int)k0 + fail;
+        // keep downstream kernels finite: identity block
+        for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
+            const int r = idx >> 7, c = idx & 127;
+            const double v = (r == c) ? 1.0 : 0.0;
+            if (storeA) Ag[(long)r * lda + c] = v;
+            wt_diag[(long)r * ldw + c] = v;
+            w_diag[(long)r * ldw + c] = v;
+        }
+    }
+}
+
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw, int kb,
                          int* info_dev, hipStream_t s, int skip) {
-    hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
-                       kb, info_dev, skip);
+    if (skip & 128)      // the round-2 kernel (A/B timing through sr_test_potrf_diag only)
+        hipLaunchKernelGGL(sr_potrf_diag_v2_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
+                           kb, info_dev, skip & 63);
+    else
+        hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
+                           kb, info_dev, skip);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time the diagonal-block kernel of the factorisation alone (200 back-to-back launches) and its phases by ablation;
-check factor and inverse against NumPy.  GPU box:  python scripts/diag_bench.py"""
+"""Time the diagonal-block kernel of the factorisation alone (200 back-to-back launches on one input) against the
+round-2 kernel, and check factor and inverse against NumPy.  GPU box:  python scripts/diag_bench.py"""
 import os
 import sys
 
@@ -17,23 +17,23 @@ def main():
     rng = np.random.default_rng(0)
     M = rng.standard_normal((128, 160))
     A = M.dot(M.T) / 160 + 0.5 * np.eye(128)
-    tA = B.as_dev(A.copy(), dev)
-    wt, w = B.empty((128, 128), dev), B.empty((128, 128), dev)
-    info = torch.zeros(1, dtype=torch.int32, device=dev)
-    s = B.stream_ptr(dev)
-    check(lib.sr_test_potrf_diag(0, B.ptr(tA), 128, B.ptr(wt), B.ptr(w), 128, B.ptr(info), 0, s))
-    U = np.triu(B.to_numpy(tA))
     R = np.linalg.cholesky(A).T
-    print("max|U - chol| = %.3e   max|U^-1 - inv| = %.3e   max|w - wt^T| = %.3e  info=%d" % (
-        np.abs(U - R).max(), np.abs(B.to_numpy(wt) - np.linalg.inv(R)).max(),
-        np.abs(B.to_numpy(w) - B.to_numpy(wt).T).max(), int(info.item())))
-    names = {0: "full", 1: "no pivots", 2: "no panel rows", 4: "no trailing update", 8: "no sub-block inverses",
-             16: "no inverse combination", 32: "no global load/store", 63: "skeleton (barriers only)",
-             62: "pivots only", 61: "panel rows only", 59: "trailing only", 55: "sub-block inverses only",
-             47: "combination only", 31: "global load/store only"}
-    for skip, name in names.items():
+    s = B.stream_ptr(dev)
+    for skip, name in ((0, "round 3 (factor + inverse in one sweep)"), (128, "round 2")):
+        tA = B.as_dev(A.copy(), dev)
+        wt, w = B.empty((128, 128), dev).fill_(7.0), B.empty((128, 128), dev).fill_(7.0)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.sr_test_potrf_diag(0, B.ptr(tA), 128, B.ptr(wt), B.ptr(w), 128, B.ptr(info), skip, s))
+        U = B.to_numpy(tA)
+        print("%-42s max|U - chol| = %.3e   max|U^-1 - inv| = %.3e   max|w - wt^T| = %.3e  info=%d" % (
+            name, np.abs(U - R).max(), np.abs(B.to_numpy(wt) - np.linalg.inv(R)).max(),
+            np.abs(B.to_numpy(w) - B.to_numpy(wt).T).max(), int(info.item())))
+    for skip, name in ((64, "round 3, input untouched"), (0, "round 3 (refactors its own output)"),
+                       (128, "round 2 (refactors its own output)")):
+        tA = B.as_dev(A.copy(), dev)
+        wt, w = B.empty((128, 128), dev), B.empty((128, 128), dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
         for _ in range(5):
-            tA.copy_(torch.from_numpy(A).to(dev))
             lib.sr_test_potrf_diag(0, B.ptr(tA), 128, B.ptr(wt), B.ptr(w), 128, B.ptr(info), skip, s)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,7 +43,7 @@ def main():
             lib.sr_test_potrf_diag(0, B.ptr(tA), 128, B.ptr(wt), B.ptr(w), 128, B.ptr(info), skip, s)
         e1.record()
         torch.cuda.synchronize()
-        print("skip=%2d  %-28s %7.2f us / launch" % (skip, name, 1e3 * e0.elapsed_time(e1) / n))
+        print("skip=%3d  %-40s %7.2f us / launch   (info=%d)" % (skip, name, 1e3 * e0.elapsed_time(e1) / n, int(info.item())))
 
 
 if __name__ == "__main__":

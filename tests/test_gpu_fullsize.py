@@ -257,7 +257,7 @@ def test_packed_export_import_round_trip():
         syn = orc.make_synthetic(40 + N, N, n_s, n_u, 300)
         gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
         alpha, wt = gp.export_state()
-        pieces = parallel.packed_pieces(N, 40000)
+        pieces = parallel.packed_pieces(N, 15000)
         assert len(pieces) >= 3
         assert gp.packed_count(0, N) == N * (N + 1) // 2
         other = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s,

@@ -49,6 +49,50 @@ def test_gemm_tn_matches_numpy(M, N, K, mode):
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("seed,cond", [(0, 1.0), (1, 1e-6), (2, 1e3)])
+def test_potrf_diag_block_matches_numpy(seed, cond):
+    """The diagonal-block kernel of the model update (factor and inverse of one 128 x 128 block in one sweep): U against
+    numpy's Cholesky, U^-1 and U^-T against the inverse of numpy's factor, the structural zeros of all three outputs
+    (the blocks are read as full tiles by the GEMMs behind), and the first bad pivot of a matrix that is not positive
+    definite.  The block sits inside a larger matrix (leading dimensions != 128, kb offset)."""
+    import torch
+    from safe_exploration_amd import _buffers as B
+    from safe_exploration_amd._lib import lib, check
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((128, 160))
+    A = M.dot(M.T) / 160 + cond * np.eye(128)
+    dev = torch.device("cuda", 0)
+    big = rng.standard_normal((128, 200))                   # lda = 200: the kernel must honour the leading dimension
+    big[:, :128] = A
+    tA = B.as_dev(big.copy(), dev)
+    wt, w = B.empty((128, 136), dev).fill_(7.0), B.empty((128, 136), dev).fill_(7.0)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.sr_test_potrf_diag(0, B.ptr(tA), 200, B.ptr(wt), B.ptr(w), 136, B.ptr(info), 0, B.stream_ptr(dev)))
+    assert int(info.item()) == 0
+    got = B.to_numpy(tA)
+    R = np.linalg.cholesky(A).T
+    Ri = np.linalg.inv(R)
+    scale = np.abs(Ri).max()
+    np.testing.assert_allclose(got[:, :128], R, rtol=0, atol=2e-15 * np.abs(R).max() * max(1.0, 1.0 / np.sqrt(cond)))
+    np.testing.assert_array_equal(got[:, 128:], big[:, 128:])                  # nothing outside the block touched
+    gwt, gw = B.to_numpy(wt), B.to_numpy(w)
+    np.testing.assert_allclose(gwt[:, :128], Ri, rtol=0, atol=1e-13 * scale * max(1.0, 1.0 / cond))
+    np.testing.assert_array_equal(gw[:, :128], gwt[:, :128].T)
+    assert np.all(np.tril(gwt[:, :128], -1) == 0) and np.all(np.triu(gw[:, :128], 1) == 0)
+    assert np.all(gwt[:, 128:] == 7.0) and np.all(gw[:, 128:] == 7.0)
+    # U^-1 U = I to rounding
+    np.testing.assert_allclose(gwt[:, :128].dot(got[:, :128]), np.eye(128), rtol=0, atol=1e-12 * max(1.0, 1.0 / cond))
+    # not positive definite from pivot 70 on: info = 70 (1-based), outputs stay finite (identity block)
+    bad = A.copy()
+    bad[69, 69] = -1.0
+    tA = B.as_dev(bad, dev)
+    info.zero_()
+    wt2, w2 = B.empty((128, 128), dev), B.empty((128, 128), dev)
+    check(lib.sr_test_potrf_diag(0, B.ptr(tA), 128, B.ptr(wt2), B.ptr(w2), 128, B.ptr(info), 0, B.stream_ptr(dev)))
+    assert int(info.item()) == 70
+    assert np.array_equal(B.to_numpy(wt2), np.eye(128)) and np.array_equal(B.to_numpy(w2), np.eye(128))
+
+
 # ------------------------------------------------------------------ GP fit + predict
 @pytest.mark.parametrize("name,n_s,n_u", [("gp_pend.npz", 2, 1), ("gp_cart.npz", 4, 1)])
 def test_predict_matches_golden_and_oracle(name, n_s, n_u):
