@@ -66,19 +66,21 @@ struct sr_gp {
     // small appends allocate nothing while the padded size stays: Z has room for z_cap points, yT / alpha ping-pong
     long z_cap = 0; double *yT_alt = nullptr, *alpha_alt = nullptr; int vec_alt_np = 0;
     std::vector<double> sf2_host, noise_host;    // host copies of sf2 / noise (filled on first use after set_data)
-    // up to SR_FACT_SLOTS outputs are in flight at once (output d uses slot d % n_par); every slot has a CRITICAL
-    // stream (diagonal blocks, panel rows, look-ahead rows, inversion; slot 0: the caller's stream) and a BULK
-    // stream (the trailing update behind the look-ahead rows)
-    hipStream_t fact_stream[SR_FACT_SLOTS] = {nullptr}, bulk_stream[SR_FACT_SLOTS] = {nullptr};
-    hipEvent_t fact_fork = nullptr, fact_join[SR_FACT_SLOTS] = {nullptr};
-    hipEvent_t ev_panel[SR_FACT_SLOTS][2] = {{nullptr}}, ev_bulk[SR_FACT_SLOTS][2] = {{nullptr}};
+    // up to SR_FACT_SLOTS outputs are factorised at once as a BATCH (every launch covers all of them).  Streams:
+    // CRITICAL (diagonal blocks, panel rows, look-ahead rows, late inversion), BULK (the trailing update behind the
+    // look-ahead rows) and INVERSION (the early part of the triangular inversion); the caller's stream waits for them
+    hipStream_t fact_stream = nullptr, bulk_stream = nullptr, inv_stream = nullptr;
+    hipEvent_t fact_fork = nullptr, fact_join = nullptr;
+    hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_bulk[2] = {nullptr, nullptr};
+    hipEvent_t ev_inv[2] = {nullptr, nullptr};            // critical -> inversion stream, back
     int fact_panel = 0;                                  // blocks per Cholesky panel; 0 = by size
     int fact_regime = 0;                                 // how the streams below were made: 0 none, 1 chain-bound, 2 GEMM-bound
-    hipStream_t diag_stream[SR_FACT_SLOTS] = {nullptr};   // regime 2: diagonal blocks on their own (reserved) CUs
-    hipEvent_t ev_diag[SR_FACT_SLOTS][2] = {{nullptr}};   // critical -> diag, diag -> critical
+    int ncu = 0;                                         // compute units of the device (cached)
     // job lists of the level-batched triangular inversion (depend on Np only)
+    int* fact_info = nullptr;                            // status words of the factorisation (64 ints)
+    size_t mem_total = 0;                                // device memory (cached)
     sr_gemm_job* inv_jobs = nullptr; int inv_jobs_np = 0;
-    struct inv_level { int off1, off2, count, maxM, maxN; long tiles; };
+    struct inv_level { int off1, off2, count, maxM, maxN; long tiles; int depth, n_left; long tiles_left; };   // jobs of the root's left subtree first
     std::vector<inv_level> inv_levels;
     sr_prof prof;
 };
@@ -165,19 +167,11 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     for (hipEvent_t e : h->ev_pipe_k) if (e) (void)hipEventDestroy(e);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
-    for (int d = 0; d < SR_FACT_SLOTS; ++d) {
-        if (h->fact_stream[d]) (void)hipStreamDestroy(h->fact_stream[d]);
-        if (h->bulk_stream[d]) (void)hipStreamDestroy(h->bulk_stream[d]);
-        if (h->diag_stream[d]) (void)hipStreamDestroy(h->diag_stream[d]);
-        if (h->fact_join[d]) (void)hipEventDestroy(h->fact_join[d]);
-        for (int e = 0; e < 2; ++e) {
-            if (h->ev_panel[d][e]) (void)hipEventDestroy(h->ev_panel[d][e]);
-            if (h->ev_bulk[d][e]) (void)hipEventDestroy(h->ev_bulk[d][e]);
-            if (h->ev_diag[d][e]) (void)hipEventDestroy(h->ev_diag[d][e]);
-        }
-    }
+    for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream}) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : {h->fact_join, h->ev_panel[0], h->ev_panel[1], h->ev_bulk[0], h->ev_bulk[1], h->ev_inv[0], h->ev_inv[1]})
+        if (e) (void)hipEventDestroy(e);
     if (h->fact_fork) (void)hipEventDestroy(h->fact_fork);
-    dev_free(h->inv_jobs);
+    dev_free(h->inv_jobs); dev_free(h->fact_info);
     h->prof.destroy();
     delete h;
     return SR_OK;
@@ -282,11 +276,16 @@ static int ensure_inv_jobs(sr_gp* h) {
     }
     std::vector<sr_gemm_job> jobs;
     h->inv_levels.clear();
+    const int root_mid = nb / 2;
     for (int depth = max_depth; depth >= 0; --depth) {
         sr_gp::inv_level lv{};
+        lv.depth = depth;
         std::vector<sr_gemm_job> j1, j2;
+        for (int side = 0; side < 2; ++side)
         for (const Node& r : nodes) {
             if (r.depth != depth) continue;
+            const bool left = depth > 0 && r.hi <= root_mid;          // inside the root's left half
+            if (left != (side == 0)) continue;
             const int mid = (r.lo + r.hi) / 2;
             const int n1 = (mid - r.lo) * SR_NB, n2 = (r.hi - mid) * SR_NB;
             const long o11 = (long)r.lo * SR_NB * Np + (long)r.lo * SR_NB;
@@ -298,6 +297,7 @@ static int ensure_inv_jobs(sr_gp* h) {
             lv.maxM = std::max(lv.maxM, n2);
             lv.maxN = std::max(lv.maxN, n1);
             lv.tiles += (long)(n2 / SR_NB) * (n1 / SR_NB);
+            if (left) { ++lv.n_left; lv.tiles_left += (long)(n2 / SR_NB) * (n1 / SR_NB); }
         }
         lv.count = (int)j1.size();
         if (lv.count == 0) continue;
@@ -357,35 +357,39 @@ static int make_masked_stream(hipStream_t* st, int ncu, int first_bit, int last_
 }
 
 static void drop_fact_streams(sr_gp* h) {
-    for (int sl = 0; sl < SR_FACT_SLOTS; ++sl) {
-        hipStream_t* all[3] = {&h->fact_stream[sl], &h->bulk_stream[sl], &h->diag_stream[sl]};
-        for (hipStream_t* st : all)
-            if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
-    }
+    for (hipStream_t* st : {&h->fact_stream, &h->bulk_stream, &h->inv_stream})
+        if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
     h->fact_regime = 0;
 }
 
-static int ensure_fact_streams(sr_gp* h, int n_par, int regime) {
+static int ensure_fact_streams(sr_gp* h, int regime) {
+    if (h->ncu == 0) {
+        int cus = 0;
+        SR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        h->ncu = cus;
+    }
+    const int ncu = h->ncu;
+    const bool can_mask = ncu >= 64;
+    // (giving each output's chain one half of the XCDs through CU masks on ALL of its streams was measured and lost:
+    //  N = 5000, two outputs 5.6 -> 8.7 ms -- kernels on a CU-masked queue start late, and the mask costs the priority)
     if (h->fact_regime != regime) drop_fact_streams(h);
     int prio_lo = 0, prio_hi = 0;
     SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    hipDeviceProp_t prop;
-    SR_HIP(hipGetDeviceProperties(&prop, h->device));
-    const int ncu = prop.multiProcessorCount;
-    const bool can_mask = ncu >= 64;
-    for (int sl = 0; sl < n_par; ++sl) {
-        if (!h->fact_stream[sl]) SR_HIP(hipStreamCreateWithPriority(&h->fact_stream[sl], hipStreamNonBlocking, prio_hi));
-        if (!h->bulk_stream[sl]) {
-            if (can_mask) SR_TRY(make_masked_stream(&h->bulk_stream[sl], ncu, regime == 2 ? 8 : SR_FACT_RESERVED_CUS, ncu));
-            else SR_HIP(hipStreamCreateWithPriority(&h->bulk_stream[sl], hipStreamNonBlocking, prio_lo));
-        }
-        if (regime == 2 && can_mask && !h->diag_stream[sl]) SR_TRY(make_masked_stream(&h->diag_stream[sl], ncu, 0, 8));
-        if (!h->fact_join[sl]) SR_HIP(hipEventCreateWithFlags(&h->fact_join[sl], hipEventDisableTiming));
-        for (int e = 0; e < 2; ++e) {
-            if (!h->ev_panel[sl][e]) SR_HIP(hipEventCreateWithFlags(&h->ev_panel[sl][e], hipEventDisableTiming));
-            if (!h->ev_bulk[sl][e]) SR_HIP(hipEventCreateWithFlags(&h->ev_bulk[sl][e], hipEventDisableTiming));
-            if (!h->ev_diag[sl][e]) SR_HIP(hipEventCreateWithFlags(&h->ev_diag[sl][e], hipEventDisableTiming));
-        }
+    if (!h->fact_stream) SR_HIP(hipStreamCreateWithPriority(&h->fact_stream, hipStreamNonBlocking, prio_hi));
+    const int reserve = regime == 2 ? 8 : SR_FACT_RESERVED_CUS;
+    if (!h->bulk_stream) {
+        if (can_mask) SR_TRY(make_masked_stream(&h->bulk_stream, ncu, reserve, ncu));
+        else SR_HIP(hipStreamCreateWithPriority(&h->bulk_stream, hipStreamNonBlocking, prio_lo));
+    }
+    if (regime == 1 && !h->inv_stream) {
+        if (can_mask) SR_TRY(make_masked_stream(&h->inv_stream, ncu, reserve, ncu));
+        else SR_HIP(hipStreamCreateWithPriority(&h->inv_stream, hipStreamNonBlocking, prio_lo));
+    }
+    if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
+    for (int e = 0; e < 2; ++e) {
+        if (!h->ev_panel[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_panel[e], hipEventDisableTiming));
+        if (!h->ev_bulk[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_bulk[e], hipEventDisableTiming));
+        if (!h->ev_inv[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_inv[e], hipEventDisableTiming));
     }
     h->fact_regime = regime;
     return SR_OK;
@@ -395,6 +399,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_factorize: NULL handle");
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
     SR_DEVICE(h->device);
+    const auto t_begin = std::chrono::steady_clock::now();
     SR_TRY(ensure_wt(h));
     SR_TRY(ensure_inv_jobs(h));
     const int Np = h->Np, nb = Np / SR_NB;
@@ -407,22 +412,18 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     // The scratch stays with the handle (refits allocate nothing) up to a third of the device's memory: at N = 50000
     // a hipMalloc / hipFree of 40 GB per update made the first updates of a process take 4.0 - 4.8 s instead of 2.67 s
     // (page-table work inside the timed call).  sr_gp_release_scratch hands it back.
-    size_t mem_free = 0, mem_total = 0;
-    (void)hipMemGetInfo(&mem_free, &mem_total);
-    const bool keep = per * n_par * sizeof(double) <= std::max<size_t>(SR_FACT_PAR_BYTES, mem_total / 3);
+    if (h->mem_total == 0) {
+        size_t mem_free = 0;
+        (void)hipMemGetInfo(&mem_free, &h->mem_total);
+    }
+    const bool keep = per * n_par * sizeof(double) <= std::max<size_t>(SR_FACT_PAR_BYTES, h->mem_total / 3);
     double* scratch = nullptr;                           // owned here only when it is not kept in the handle
-    int* info_dev = nullptr;
-    std::vector<double> sf2(h->n_out), noise(h->n_out);
     int rc = SR_OK;
     hipStream_t s0 = (hipStream_t)stream;
     auto cleanup = [&]() {
         // never return with work in flight on the side streams
-        for (int sl = 0; sl < SR_FACT_SLOTS; ++sl) {
-            if (h->fact_stream[sl]) (void)hipStreamSynchronize(h->fact_stream[sl]);
-            if (h->bulk_stream[sl]) (void)hipStreamSynchronize(h->bulk_stream[sl]);
-            if (h->diag_stream[sl]) (void)hipStreamSynchronize(h->diag_stream[sl]);
-        }
-        dev_free(scratch); dev_free(info_dev);
+        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream}) if (st) (void)hipStreamSynchronize(st);
+        dev_free(scratch);
     };
 #define SR_F(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(); return rc; } } while (0)
 #define SR_FH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
@@ -441,20 +442,25 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         SR_F(dev_alloc(&scratch, per));
         ws = scratch;
     }
-    SR_F(dev_alloc(&info_dev, (size_t)h->n_out));
+    // (nothing is read back or allocated before the first launch: the Gram kernels take the signal variance and the
+    //  noise from device memory, the status words live with the handle -- round 2 paid a D2H copy, a stream
+    //  synchronisation, a hipMalloc and a hipMemGetInfo here, 0.1 ms before the first kernel started)
+    if (!h->fact_info) SR_F(dev_alloc(&h->fact_info, (size_t)64));
+    int* info_dev = h->fact_info;
     SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s0));
-    SR_FH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0));
-    SR_FH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0));
-    SR_FH(hipStreamSynchronize(s0));
     if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
     SR_FH(hipEventRecord(h->fact_fork, s0));
     const int regime = nb <= 128 ? 1 : 2;
-    SR_F(ensure_fact_streams(h, n_par, regime));
-    for (int sl = 0; sl < n_par; ++sl) SR_FH(hipStreamWaitEvent(h->fact_stream[sl], h->fact_fork, 0));
+    SR_F(ensure_fact_streams(h, regime));
+    static const bool no_early_inv = getenv("SR_FACT_NO_EARLY_INV") != nullptr;
+    hipStream_t sc = h->fact_stream, sb = h->bulk_stream, si = h->inv_stream;
+    SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));
 
-    // Outputs are processed in rounds of n_par; inside a round the host walks the panels in the OUTER loop and the
-    // outputs in the inner one, so that all chains advance together (enqueueing one output's 200 launches before
-    // the next one's would serialise them at the host's launch rate).
+    // Outputs are processed in rounds of n_par as a BATCH: one chain of launches, every kernel works on the n_par
+    // problems at once (grid dimension = output; operands `per` resp. NN doubles apart).  Round 2 ran one chain of
+    // launches per output on streams of their own; the chains got in each other's way -- a diagonal-block kernel needs
+    // a CU to itself (136 KB of LDS) and waited for the other chain's GEMM workgroups to drain, every GEMM of one chain
+    // slowed the other's: N = 5000, one output alone 4.0 ms, two outputs 5.6 ms.
     // Buffers per output in flight:
     //   U  = Gram matrix, updated in place; its diagonal blocks end up factored; its strict lower block triangle
     //        is scratch of the inversion (Y).
@@ -466,17 +472,32 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     //        lower triangle is zero from allocation and never written).
     for (int d0 = 0; d0 < h->n_out; d0 += n_par) {
         const int nd = std::min(n_par, h->n_out - d0);
-        int n_bulk[SR_FACT_SLOTS] = {0};                  // bulk updates issued so far (event ping-pong)
-        bool diag_ready[SR_FACT_SLOTS] = {false};         // "diagonal tile of the next block is final" already recorded
-        for (int sl = 0; sl < nd; ++sl) {
-            const int d = d0 + sl;
-            hipStream_t sc = h->fact_stream[sl];
-            double* U = ws + (size_t)sl * per;
+        double* U = ws;                                   // batch member b: + b * per
+        double* W = U + NN;
+        double* Wt = h->Wt + (size_t)d0 * NN;             // batch member b: + b * NN
+        const long sP = (long)per, sN = (long)NN;
+        const sr_batch b_ppp{nd, sP, sP, sP, 0};          // all operands in the scratch
+        const sr_batch b_diag{nd, sP, sN, sP, 0};         // A = U, wt = Wt, w = W
+        const sr_batch b_solve{nd, sN, sP, sP, 0};        // A = Wt (U_kk^-1), B = U, C = W
+        const sr_batch b_inv1{nd, sP, sP, sP, 0};         // inversion, product 1: (W, W) -> U
+        const sr_batch b_inv2{nd, sN, sP, sP, sN};        // inversion, product 2: (Wt, U) -> W, Wt
+        int n_bulk = 0;                                   // bulk updates issued so far (event ping-pong)
+        // Early inversion (chain-bound sizes): once the chain has passed the middle block, the root's LEFT subtree of the
+        // inversion and the root's first product need nothing the Cholesky still writes (factor rows above the middle,
+        // their diagonal-block inverses; results go to W / Wt inside the left half and to U's unused lower-left block).
+        // They run on a low-priority stream of their own beside the second half of the chain, which leaves most of the
+        // chip idle -- 5/8 of the inversion's flops.  Afterwards: right subtree, root's second product.
+        const int root_mid = nb / 2;
+        const bool early_inv = regime == 1 && si != nullptr && nb >= 8 && !no_early_inv;
+        bool early_done = false;
+        {
             sr_prof_scope ps(&h->prof, SR_K_GRAM, sc);
             if (h->general)
-                SR_F(sr_launch_gram_general(h->Z, h->kp + (size_t)d * SR_KP(h->D), noise[d], U, h->N, Np, h->D, sc));
+                SR_F(sr_launch_gram_general(h->Z, h->kp + (size_t)d0 * SR_KP(h->D), 0.0, h->noise + d0, U, h->N, Np, h->D, sc,
+                                            nd, sP));
             else
-                SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d * h->D, sf2[d], noise[d], U, h->N, Np, h->D, sc));
+                SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d0 * h->D, 0.0, 0.0, h->sf2 + d0, h->noise + d0, U, h->N, Np, h->D,
+                                    sc, nd, sP));
         }
         // --- Cholesky K = U^T U, right-looking in panels of P blocks with look-ahead: after a panel is factored
         // (critical stream, per block: update of its row by the panel's rows above, diagonal block, block row solve),
@@ -486,138 +507,116 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         for (int p0 = 0; p0 < nb; p0 += P, ++pi) {
             const int p1 = std::min(nb, p0 + P);
             for (int kb = p0; kb < p1; ++kb) {
-                for (int sl = 0; sl < nd; ++sl) {
-                    const int d = d0 + sl;
-                    hipStream_t sc = h->fact_stream[sl];
-                    double* U = ws + (size_t)sl * per;
-                    double* W = U + NN;
-                    double* Wt = h->Wt + (size_t)d * NN;
-                    const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
-                    const int ncols = Np - (kb + 1) * SR_NB;
-                    hipStream_t sd = h->diag_stream[sl];
-                    // left-looking INSIDE the panel: block row kb takes the updates of the panel's rows above it in
-                    // one product with K = (kb - p0) * 128, right before it is needed -- each row block of the
-                    // panel is read-modify-written once (eager rank-128 updates of all remaining panel rows
-                    // touched it up to P - 1 times with K = 128, where prologue and epilogue dominate a tile).
-                    // With a stream of its own for the diagonal blocks the update is split: the diagonal tile first,
-                    // then the diagonal block (62 us on its reserved CU) BESIDE the rest of the row's update.
-                    const double* Upr = W + (size_t)p0 * SR_NB * Np + (size_t)kb * SR_NB;       // rows p0..kb-1, cols >= kb
-                    const int Kin = (kb - p0) * SR_NB;
-                    if (kb > p0) {
-                        sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
-                        SR_F(sr_launch_gemm_tn_upper(Upr, Np, Upr, Np, U + dg, Np, SR_NB, sd ? SR_NB : Np - kb * SR_NB, Kin,
-                                                     -1.0, 1.0, sc, 1));
-                    }
-                    if (sd) {
-                        // hand the block over (unless the look-ahead already recorded "tile ready"), factor it there
-                        if (!diag_ready[sl]) SR_FH(hipEventRecord(h->ev_diag[sl][0], sc));
-                        diag_ready[sl] = false;
-                        SR_FH(hipStreamWaitEvent(sd, h->ev_diag[sl][0], 0));
-                        {
-                            sr_prof_scope ps(&h->prof, SR_K_POTRF, sd);
-                            SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, sd));
-                        }
-                        SR_FH(hipEventRecord(h->ev_diag[sl][1], sd));
-                        if (kb > p0 && ncols > 0) {               // rest of row kb: A[kb][kb+1:] -= Upr[:, kb]^T Upr[:, kb+1:]
-                            sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
-                            SR_F(sr_launch_gemm_tn(Upr, Np, Upr + SR_NB, Np, U + dg + SR_NB, Np, SR_NB, ncols, Kin, -1.0, 1.0, 0,
-                                                   sc, 1));
-                        }
-                        SR_FH(hipStreamWaitEvent(sc, h->ev_diag[sl][1], 0));
-                    } else {
-                        sr_prof_scope ps(&h->prof, SR_K_POTRF, sc);
-                        SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d, sc));
-                    }
-                    if (ncols > 0) {
-                        const double* Arow = U + dg + SR_NB;          // updated Gram rows right of the block
-                        double* Urow = W + dg + SR_NB;                // factor rows U[kb][cols right of the block]
-                        sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
-                        // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major)
-                        SR_F(sr_launch_gemm_tn(Wt + dg, Np, Arow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, sc, 1));
+                const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
+                const int ncols = Np - (kb + 1) * SR_NB;
+                // left-looking INSIDE the panel: block row kb takes the updates of the panel's rows above it in
+                // one product with K = (kb - p0) * 128, right before it is needed -- each row block of the
+                // panel is read-modify-written once (eager rank-128 updates of all remaining panel rows
+                // touched it up to P - 1 times with K = 128, where prologue and epilogue dominate a tile).
+                // (Round 2 ran the diagonal block of the big sizes on a stream of its own beside the rest of its row's
+                // update; with the block down from 62 - 180 us to 35 the two event hand-offs per block cost more than the
+                // overlap bought: N = 50000 2.616 -> 2.594 s, N = 20000 193 -> 189 ms without it.)
+                const double* Upr = W + (size_t)p0 * SR_NB * Np + (size_t)kb * SR_NB;       // rows p0..kb-1, cols >= kb
+                const int Kin = (kb - p0) * SR_NB;
+                if (kb > p0) {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    SR_F(sr_launch_gemm_tn_upper(Upr, Np, Upr, Np, U + dg, Np, SR_NB, Np - kb * SR_NB, Kin, -1.0, 1.0, sc, 1, -1,
+                                                 &b_ppp));
+                }
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_POTRF, sc);
+                    SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d0, sc, 0, &b_diag));
+                }
+                if (ncols > 0) {
+                    const double* Arow = U + dg + SR_NB;          // updated Gram rows right of the block
+                    double* Urow = W + dg + SR_NB;                // factor rows U[kb][cols right of the block]
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major)
+                    SR_F(sr_launch_gemm_tn(Wt + dg, Np, Arow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, sc, 1, &b_solve));
+                }
+            }
+            if (early_inv && !early_done && p1 >= root_mid && p1 < nb) {
+                // every factor row above the middle is final (and its diagonal block inverted): left subtree + root product 1
+                early_done = true;
+                SR_FH(hipEventRecord(h->ev_inv[0], sc));
+                SR_FH(hipStreamWaitEvent(si, h->ev_inv[0], 0));
+                for (const sr_gp::inv_level& lv : h->inv_levels) {
+                    sr_prof_scope ps(&h->prof, SR_K_TRINV, si);
+                    if (lv.depth == 0) {
+                        SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, 1, lv.maxM, lv.maxN, lv.tiles, 1.0, 2,
+                                                    si, &b_inv1));
+                    } else if (lv.n_left > 0) {
+                        SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, lv.n_left, lv.maxM, lv.maxN,
+                                                    lv.tiles_left, 1.0, 2, si, &b_inv1));
+                        SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2, lv.n_left, lv.maxM, lv.maxN,
+                                                    lv.tiles_left, -1.0, 3, si, &b_inv2));
                     }
                 }
+                SR_FH(hipEventRecord(h->ev_inv[1], si));
             }
             const int rest = Np - p1 * SR_NB;
             if (rest <= 0) continue;
-            for (int sl = 0; sl < nd; ++sl) {
-                hipStream_t sc = h->fact_stream[sl], sb = h->bulk_stream[sl];
-                double* U = ws + (size_t)sl * per;
-                double* W = U + NN;
-                const int Kp = (p1 - p0) * SR_NB;
-                const double* Upan = W + (size_t)p0 * SR_NB * Np + (size_t)p1 * SR_NB;    // factor rows of the panel
-                double* Cnext = U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB;
-                const int la = std::min(P * SR_NB, rest);         // rows of the next panel
-                const int bulk = rest - la;
-                // regime 1 (chain-bound sizes): the bulk update starts only AFTER the look-ahead rows are done -- started
-                // together, its workgroups fill the CUs first and the look-ahead (on the critical path) takes 60 - 70 us
-                // instead of 20; regime 2: when the panel's rows are final
-                const bool bulk_after_la = (regime == 1);
-                if (bulk > 0 && !bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[sl][pi & 1], sc));
-                // the previous bulk update wrote the look-ahead rows too: it has to be through
-                if (n_bulk[sl] > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[sl][(n_bulk[sl] - 1) & 1], 0));
-                if (h->diag_stream[sl]) {
-                    // the next panel's first diagonal tile first: its diagonal block then runs beside the rest
-                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
-                    SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, SR_NB, SR_NB, Kp, -1.0, 1.0, sc, 1));
-                    SR_FH(hipEventRecord(h->ev_diag[sl][0], sc));
-                    diag_ready[sl] = true;
-                    if (rest > SR_NB)          // row p1 right of its diagonal tile
-                        SR_F(sr_launch_gemm_tn(Upan, Np, Upan + SR_NB, Np, Cnext + SR_NB, Np, SR_NB, rest - SR_NB, Kp, -1.0, 1.0, 0,
-                                               sc, 1));
-                    if (la > SR_NB)            // the other rows of the next panel
-                        SR_F(sr_launch_gemm_tn_upper(Upan + SR_NB, Np, Upan + SR_NB, Np, Cnext + (size_t)SR_NB * Np + SR_NB, Np,
-                                                     la - SR_NB, rest - SR_NB, Kp, -1.0, 1.0, sc, 1));
-                } else {
-                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
-                    SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1));
+            const int Kp = (p1 - p0) * SR_NB;
+            const double* Upan = W + (size_t)p0 * SR_NB * Np + (size_t)p1 * SR_NB;    // factor rows of the panel
+            double* Cnext = U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB;
+            const int la = std::min(P * SR_NB, rest);         // rows of the next panel
+            const int bulk = rest - la;
+            // regime 1 (chain-bound sizes): the bulk update starts only AFTER the look-ahead rows are done -- started
+            // together, its workgroups fill the CUs first and the look-ahead (on the critical path) takes 60 - 70 us
+            // instead of 20; regime 2: when the panel's rows are final
+            const bool bulk_after_la = (regime == 1);
+            if (bulk > 0 && !bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
+            // the previous bulk update wrote the look-ahead rows too: it has to be through
+            if (n_bulk > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
+            {
+                sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1, -1, &b_ppp));
+            }
+            if (bulk > 0) {
+                if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
+                SR_FH(hipStreamWaitEvent(sb, h->ev_panel[pi & 1], 0));
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sb);
+                    SR_F(sr_launch_gemm_tn_upper(Upan + la, Np, Upan + la, Np, Cnext + (size_t)la * Np + la, Np,
+                                                 bulk, bulk, Kp, -1.0, 1.0, sb, 0, -1, &b_ppp));
                 }
-                if (bulk > 0) {
-                    if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[sl][pi & 1], sc));
-                    SR_FH(hipStreamWaitEvent(sb, h->ev_panel[sl][pi & 1], 0));
-                    {
-                        sr_prof_scope ps(&h->prof, SR_K_GEMM, sb);
-                        SR_F(sr_launch_gemm_tn_upper(Upan + la, Np, Upan + la, Np, Cnext + (size_t)la * Np + la, Np,
-                                                     bulk, bulk, Kp, -1.0, 1.0, sb));
-                    }
-                    SR_FH(hipEventRecord(h->ev_bulk[sl][n_bulk[sl] & 1], sb));
-                    ++n_bulk[sl];
-                }
+                SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sb));
+                ++n_bulk;
             }
         }
-        for (int sl = 0; sl < nd; ++sl)
-            if (n_bulk[sl] > 0) SR_FH(hipStreamWaitEvent(h->fact_stream[sl], h->ev_bulk[sl][(n_bulk[sl] - 1) & 1], 0));
+        if (n_bulk > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
         // --- W = U^-T (lower) and Wt = U^-1 (upper) by recursive halving of the block range, level by level
         // (ensure_inv_jobs).  The diagonal blocks of W / Wt were written by sr_potrf_diag_kernel.
+        if (early_done) SR_FH(hipStreamWaitEvent(sc, h->ev_inv[1], 0));
         for (const sr_gp::inv_level& lv : h->inv_levels) {
-            for (int sl = 0; sl < nd; ++sl) {
-                hipStream_t sc = h->fact_stream[sl];
-                double* U = ws + (size_t)sl * per;
-                double* W = U + NN;
-                double* Wt = h->Wt + (size_t)(d0 + sl) * NN;
-                sr_prof_scope ps(&h->prof, SR_K_TRINV, sc);
-                SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, lv.count, lv.maxM, lv.maxN, lv.tiles, 1.0, 2, sc));
-                SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2, lv.count, lv.maxM, lv.maxN, lv.tiles, -1.0, 3, sc));
-            }
+            sr_prof_scope ps(&h->prof, SR_K_TRINV, sc);
+            const int skip = early_done ? lv.n_left : 0;          // jobs of the left subtree already ran
+            const int cnt = lv.count - skip;
+            const long tiles = lv.tiles - (early_done ? lv.tiles_left : 0);
+            if (cnt > 0 && !(early_done && lv.depth == 0))
+                SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1 + skip, cnt, lv.maxM, lv.maxN, tiles, 1.0, 2,
+                                            sc, &b_inv1));
+            if (cnt > 0)
+                SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2 + skip, cnt, lv.maxM, lv.maxN, tiles, -1.0, 3,
+                                            sc, &b_inv2));
         }
-        // alpha = Wt (W y)
-        for (int sl = 0; sl < nd; ++sl) {
-            const int d = d0 + sl;
-            hipStream_t sc = h->fact_stream[sl];
-            double* U = ws + (size_t)sl * per;
-            double* W = U + NN;
-            double* v = W + NN;
-            double* Wt = h->Wt + (size_t)d * NN;
-            SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d * Np, v, Np, 1, sc));
-            SR_F(sr_launch_trmv(Wt, Np, v, h->alpha + (size_t)d * Np, Np, 0, sc));
-        }
+        // alpha = Wt (W y)   (v behind W in the scratch)
+        SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d0 * Np, W + NN, Np, 1, sc, nd, sP, Np, sP));
+        SR_F(sr_launch_trmv(Wt, Np, W + NN, h->alpha + (size_t)d0 * Np, Np, 0, sc, nd, sN, sP, Np));
     }
-    for (int sl = 0; sl < n_par; ++sl) {
-        SR_FH(hipEventRecord(h->fact_join[sl], h->fact_stream[sl]));
-        SR_FH(hipStreamWaitEvent(s0, h->fact_join[sl], 0));
-    }
+    SR_FH(hipEventRecord(h->fact_join, sc));
+    SR_FH(hipStreamWaitEvent(s0, h->fact_join, 0));
+    static const bool trace = getenv("SR_FACT_TRACE") != nullptr;
+    const auto t_enq = std::chrono::steady_clock::now();
     std::vector<int> info_h(h->n_out, 0);
     SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s0));
     SR_FH(hipStreamSynchronize(s0));
+    if (trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "sr_gp_factorize: Np=%d enqueue %.3f ms, total %.3f ms\n", Np,
+                std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_begin).count());
+    }
     cleanup();
 #undef SR_F
 #undef SR_FH
@@ -1839,8 +1838,8 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         const double* u12 = U12t + (size_t)d * m * Np0;
         SR_AH(hipMemsetAsync(G, 0, BB * sizeof(double), s));
         SR_A(sr_launch_append_small(u12, Wt0, Np0, m, 0, G, nullptr, nullptr, nullptr, s));      // G = U12^T U12
-        if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], Sb, m, SR_NB, D, s));
-        else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], Sb, m, SR_NB, D, s));
+        if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], nullptr, Sb, m, SR_NB, D, s));
+        else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], nullptr, nullptr, Sb, m, SR_NB, D, s));
         SR_A(sr_launch_sub_block(Sb, G, pf, s));                                                   // S = C - G
         SR_A(sr_launch_potrf_corner16(Sb, SR_NB, invS, SR_NB, info_dev + d, s));                   // invS = U22^-1 (m <= 16: last pivot)
         // Y2 = -U^-1 U12 U22^-1 and the move of the old factor to its new place in one pass over it; a buffer that
@@ -1978,8 +1977,8 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
         SR_A(sr_launch_gemm_tn_splitk(Wt0, Np0, Ks + (size_t)d * PB, SR_NB, U12, Np0, SR_NB, Np0, APP_KS, 1.0, 3, part, s));
         SR_A(sr_launch_gemm_tn_splitk(U12, SR_NB, U12, SR_NB, G, SR_NB, SR_NB, Np0, APP_KS, 1.0, 0, part, s));
         // S = C - U12^T U12 on the real (front padded) block, C = k(Znew, Znew) + noise I
-        if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], Sb, m, SR_NB, D, s));
-        else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], Sb, m, SR_NB, D, s));
+        if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], nullptr, Sb, m, SR_NB, D, s));
+        else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], nullptr, nullptr, Sb, m, SR_NB, D, s));
         SR_A(sr_launch_sub_block(Sb, G, pf, s));
         SR_A(sr_launch_potrf_diag(Sb, SR_NB, invS, wdm, SR_NB, 0, info_dev + d, s));       // invS = U22^-1
         // X = U12 U22^-1

@@ -100,13 +100,18 @@ struct sr_prof_scope {
 //   mode 4: A block-lower-triangular (A[k][m] == 0 for k < m0): per tile k starts at m0.
 //   mode 3: A block-upper-triangular (A[k][m] == 0 for k >= m0 + 128): per tile k ends at m0 + 128.
 // prio != 0: the workgroups raise their wavefront priority (critical-path products that share CUs with bulk work)
+// Batch of independent, equally shaped problems in ONE launch (the outputs of a model: the same product on n operand
+// sets `stride` doubles apart): every launcher below takes an optional sr_batch; n = 1 / NULL = the plain call.
+struct sr_batch { int n = 1; long sA = 0, sB = 0, sC = 0, sCT = 0; };
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s, int prio = 0);
+                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s, int prio = 0,
+                      const sr_batch* bt = nullptr);
 
 // upper block triangle only (tiles n0 >= m0; M <= N) on a linear grid -- the trailing updates of the Cholesky
 int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                             int M, int N, int K, double alpha, double beta, hipStream_t s, int prio = 0,
-                            int order = -1);   // order: 0 row-major tiles, 1 XCD-aware super-tiles, -1 by size
+                            int order = -1,    // order: 0 row-major tiles, 1 XCD-aware super-tiles, -1 by size
+                            const sr_batch* bt = nullptr);
 // thin products (N a few tiles, K long): K-slices of ks rows as grid.z into `part` (ceil(K / ks) x M x N doubles), then
 // summed in order into C (M x N contiguous).  modes as sr_launch_gemm_tn.
 int sr_launch_gemm_tn_splitk(const double* A, long lda, const double* B, long ldb, double* C, int M, int N, int K,
@@ -118,26 +123,31 @@ struct sr_gemm_job { long a, b, c, ct; int M, N, K, pad; };
 // tiles128: 128 x 128 tiles of the whole list (picks the workgroup tile)
 int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, double* CTb, long ld,
                            const sr_gemm_job* jobs_dev, int njobs, int maxM, int maxN, long tiles128, double alpha,
-                           int mode, hipStream_t s);
+                           int mode, hipStream_t s, const sr_batch* bt = nullptr);
 
 // padded index space: the Np - N padding rows/cols sit at the FRONT (identity), training point i lives
 // at padded index i + (Np - N); the contraction kernels simply start at k = 16*floor((Np-N)/16).
-int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, double* K, int N,
-                   int Np, int D, hipStream_t s);
+// sf2_dev / noise_dev: device scalars that take precedence over the by-value arguments when not NULL
+// nbatch > 1: outputs b = 0 .. nbatch-1 in one launch (ls + b D, sf2_dev + b, noise_dev + b, K + b strideK)
+int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, const double* sf2_dev,
+                   const double* noise_dev, double* K, int N, int Np, int D, hipStream_t s, int nbatch = 1,
+                   long strideK = 0);
 // factor the diagonal block kb of the Np x Np matrix A (upper), write U_kk in place, U_kk^-1 to
 // wt_diag (into Wt's diagonal block) and U_kk^-T to w_diag (into W's diagonal block).
 int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const double* U12t, const double* invS, int m,
                           double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s);
 int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s);
 int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s);
+// bt: batch of blocks (sA: stride of A, sB: of wt_diag, sC: of w_diag; info_dev + b)
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
-                         int kb, int* info_dev, hipStream_t s, int skip = 0);
+                         int kb, int* info_dev, hipStream_t s, int skip = 0, const sr_batch* bt = nullptr);
 int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s);
 int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd, int rows, int cols,
                              hipStream_t s);
 // y[r] = sum_c M[r][c] x[c], c in [0..r] (lower=1) or [r..n) (lower=0)
+// nbatch members, matrix / x / y sM / sx / sy doubles apart
 int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
-                   hipStream_t s);
+                   hipStream_t s, int nbatch = 1, long sM = 0, long sx = 0, long sy = 0);
 long sr_mll_ws(int N);
 int sr_launch_mll(const double* Kinv, int Np, int N, const double* alpha, const double* yT, const double* Z,
                   const double* kp, int D, const double* logdet, double* partial, double* nll, double* grad,
@@ -153,8 +163,8 @@ int sr_launch_append_assemble(const double* Wt0, int Np0, int off0, int N0, cons
 //   kappa = exp(-r^2/2) (RBF, 0) or (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r) (Matern-5/2, 1)
 // packed per output as SR_KP(D) doubles: [kappa, v, c0, s[D], a[D], b[D]]
 #define SR_KP(D) (3 + 3 * (D))
-int sr_launch_gram_general(const double* Z, const double* kp, double noise, double* K, int N, int Np,
-                           int D, hipStream_t s);
+int sr_launch_gram_general(const double* Z, const double* kp, double noise, const double* noise_dev, double* K, int N,
+                           int Np, int D, hipStream_t s, int nbatch = 1, long strideK = 0);
 
 struct sr_kstar_args {
     const double* Z;        // N x D

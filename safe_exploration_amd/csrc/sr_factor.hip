@@ -13,14 +13,17 @@ struct sr_tile128 {
     static constexpr int T = 128, NI = 4, SMEM = srt::SMEM_DOUBLES, WPS = 2;
     static __device__ __forceinline__ void mainloop(const double* A, long lda, const double* B, long ldb, int k0,
                                                     int k1, double* smem, Acc& acc) {
-        srt::mainloop_tn_glds<16>(A, lda, B, ldb, k0, k1, smem, acc);   // LDS-DMA staging (+5 % over register staging)
+        // LDS-DMA staging (+5 % over register staging).  (Four stages of 8 k-rows in the same LDS -- three k-tiles in
+        // flight, hand-placed vmcnt -- measured the same: 42.9 TF at K = 256, 51.4 at K = 1024, C4 63.2 against 64.2.
+        // What these products lose, they lose to the tail of the grid, not to the pipeline of a tile.)
+        srt::mainloop_tn_glds<16>(A, lda, B, ldb, k0, k1, smem, acc);
     }
     static __device__ __forceinline__ int row(int wm, int mi, int lane, int r) { return srt::acc_row(wm, mi, lane, r); }
     static __device__ __forceinline__ int col(int wn, int ni, int lane) { return srt::acc_col(wn, ni, lane); }
 };
 struct sr_tile64 {
     using Acc = srt64::Acc;
-    static constexpr int T = 64, NI = 2, SMEM = srt64::SMEM_DOUBLES, WPS = 4;
+    static constexpr int T = 64, NI = 2, SMEM = srt64::SMEM_DOUBLES, WPS = 2;
     static __device__ __forceinline__ void mainloop(const double* A, long lda, const double* B, long ldb, int k0,
                                                     int k1, double* smem, Acc& acc) {
         srt64::mainloop_tn(A, lda, B, ldb, k0, k1, smem, acc);
@@ -39,28 +42,44 @@ __device__ __forceinline__ void sr_gemm_tile(const double* __restrict__ A, long 
     TL::mainloop(A + m0, lda, B + n0, ldb, k_beg, k_end, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    if (beta != 0.0) {
+        // read-modify-write: all loads of a row of MFMA tiles first, then the arithmetic and the stores (with the
+        // test on beta inside the element loop every element was a load -> s_waitcnt vmcnt(0) -> store round trip of
+        // its own: 16 resp. 64 dependent global-memory latencies per tile)
 #pragma unroll
-    for (int mi = 0; mi < TL::NI; ++mi)
+        for (int mi = 0; mi < TL::NI; ++mi) {
+            double old[TL::NI][4];
 #pragma unroll
-        for (int ni = 0; ni < TL::NI; ++ni)
+            for (int ni = 0; ni < TL::NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = m0 + TL::row(wm, mi, lane, r);
-                const long col = n0 + TL::col(wn, ni, lane);
-                double* c = C + row * ldc + col;
-                double v = alpha * acc.v[mi][ni][r];
-                if (beta != 0.0) v += beta * (*c);
-                *c = v;
-            }
+                for (int r = 0; r < 4; ++r)
+                    old[ni][r] = C[(m0 + TL::row(wm, mi, lane, r)) * ldc + n0 + TL::col(wn, ni, lane)];
+#pragma unroll
+            for (int ni = 0; ni < TL::NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    C[(m0 + TL::row(wm, mi, lane, r)) * ldc + n0 + TL::col(wn, ni, lane)] =
+                        fma(alpha, acc.v[mi][ni][r], beta * old[ni][r]);
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TL::NI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TL::NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    C[(m0 + TL::row(wm, mi, lane, r)) * ldc + n0 + TL::col(wn, ni, lane)] = alpha * acc.v[mi][ni][r];
+    }
 }
 
 // rectangular grid; mode as documented in sr_common.h (k ranges at the tile's own granularity)
 template <class TL>
 __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_kernel(
     const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* C, long ldc, int K,
-    double alpha, double beta, int mode, int prio) {
+    double alpha, double beta, int mode, int prio, sr_batch bt) {
     __shared__ double smem[TL::SMEM];
     if (prio) __builtin_amdgcn_s_setprio(3);       // critical-path product: win the issue arbitration on a shared SIMD
+    A += (long)blockIdx.z * bt.sA; B += (long)blockIdx.z * bt.sB; C += (long)blockIdx.z * bt.sC;
     const int m0 = blockIdx.y * TL::T;
     const int n0 = blockIdx.x * TL::T;
     if (mode == 1 && (n0 & ~127) < (m0 & ~127)) return;        // triangular structure is defined on 128-blocks
@@ -73,17 +92,35 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_kernel(
 // happens.  Products of few tiles are therefore latency-bound (the block row and the look-ahead row of the
 // Cholesky sit on its critical path) or balance-bound (triangular k ranges); they take the 64 x 64 tile.
 static inline bool sr_use_tile64(long tiles128) { return tiles128 < 1024; }
+// ... but a 64 x 64 tile moves 8 bytes of operands per 8 flop (K-independent): a grid of them that fills the chip is
+// bound by L2 / fabric bandwidth (N = 5000, K = 256 bulk update of two outputs: 1.7 GB in 254 us = 6.8 TB/s, 21 TF per
+// output).  THROUGHPUT-bound products (bulk trailing update, the big levels of the inversion) therefore take the
+// 128-tile (16 flop per byte) as soon as there are enough of them to occupy the chip once.
+static int sr_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static inline bool sr_use_tile64_bulk(long tiles128) {
+    static const int below = sr_env_int("SR_T64_BULK_BELOW", 192);
+    return tiles128 < below;
+}
+static inline bool sr_use_tile64_jobs(long tiles128) {
+    static const int below = sr_env_int("SR_T64_JOBS_BELOW", 1024);
+    return tiles128 < below;
+}
 
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s, int prio) {
+                      int M, int N, int K, double alpha, double beta, int mode, hipStream_t s, int prio,
+                      const sr_batch* btp) {
     SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && M > 0 && N > 0, SR_EINVAL,
              "gemm_tn: M=%d N=%d K=%d must be tile multiples", M, N, K);
-    if (sr_use_tile64((long)(M / 128) * (N / 128)))
-        hipLaunchKernelGGL(sr_gemm_tn_kernel<sr_tile64>, dim3(N / 64, M / 64), dim3(256), 0, s, A, lda, B, ldb, C, ldc,
-                           K, alpha, beta, mode, prio);
+    const sr_batch bt = btp ? *btp : sr_batch{};
+    if (sr_use_tile64((long)(M / 128) * (N / 128) * bt.n))
+        hipLaunchKernelGGL(sr_gemm_tn_kernel<sr_tile64>, dim3(N / 64, M / 64, bt.n), dim3(256), 0, s, A, lda, B, ldb, C, ldc,
+                           K, alpha, beta, mode, prio, bt);
     else
-        hipLaunchKernelGGL(sr_gemm_tn_kernel<sr_tile128>, dim3(N / 128, M / 128), dim3(256), 0, s, A, lda, B, ldb, C,
-                           ldc, K, alpha, beta, mode, prio);
+        hipLaunchKernelGGL(sr_gemm_tn_kernel<sr_tile128>, dim3(N / 128, M / 128, bt.n), dim3(256), 0, s, A, lda, B, ldb, C,
+                           ldc, K, alpha, beta, mode, prio, bt);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -159,9 +196,10 @@ __device__ __forceinline__ void sr_upper_index(long b, int tn, int& m, int& n) {
 template <class TL>
 __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_upper_kernel(
     const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, double* C, long ldc,
-    int K, int tm, int tn, double alpha, double beta, int prio, int order) {
+    int K, int tm, int tn, double alpha, double beta, int prio, int order, sr_batch bt) {
     __shared__ double smem[TL::SMEM];
     if (prio) __builtin_amdgcn_s_setprio(3);
+    A += (long)blockIdx.y * bt.sA; B += (long)blockIdx.y * bt.sB; C += (long)blockIdx.y * bt.sC;
     int m, n;
     if (order == 0) {
         sr_upper_index(blockIdx.x, tn, m, n);
@@ -185,14 +223,17 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_upper_kernel(
 // lower-left quarter of every diagonal 128-block stays untouched as well: nothing reads it (the diagonal-block
 // kernel loads the upper triangle only).
 int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio, int order) {
+                            int M, int N, int K, double alpha, double beta, hipStream_t s, int prio, int order,
+                            const sr_batch* btp) {
+    const sr_batch bt = btp ? *btp : sr_batch{};
     SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && M > 0 && N >= M, SR_EINVAL,
              "gemm_tn_upper: M=%d N=%d K=%d", M, N, K);
     const long tm128 = M / 128, tn128 = N / 128;
-    const long tiles128 = tm128 * tn128 - tm128 * (tm128 - 1) / 2;
-    const bool t64 = sr_use_tile64(tiles128);
+    const long tiles128 = (tm128 * tn128 - tm128 * (tm128 - 1) / 2) * bt.n;
+    const bool t64 = prio ? sr_use_tile64(tiles128) : sr_use_tile64_bulk(tiles128);
     const long tm = t64 ? M / 64 : tm128, tn = t64 ? N / 64 : tn128;
-    if (order < 0) order = tiles128 >= 4096 ? 1 : 0;     // super-tiles pay once the grid is many times the chip
+    static const int order1_from = sr_env_int("SR_ORDER1_FROM", 4096);
+    if (order < 0) order = tiles128 >= order1_from ? 1 : 0;     // super-tiles pay once the grid is many times the chip
     long blocks;
     if (order == 0) {
         blocks = tm * tn - tm * (tm - 1) / 2;
@@ -203,11 +244,11 @@ int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb
     }
     SR_CHECK(blocks < 2147483647L, SR_EINVAL, "gemm_tn_upper: grid too large");
     if (t64)
-        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile64>, dim3((unsigned)blocks), dim3(256), 0, s, A, lda, B, ldb,
-                           C, ldc, K, (int)tm, (int)tn, alpha, beta, prio, order);
+        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile64>, dim3((unsigned)blocks, bt.n), dim3(256), 0, s, A, lda, B, ldb,
+                           C, ldc, K, (int)tm, (int)tn, alpha, beta, prio, order, bt);
     else
-        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile128>, dim3((unsigned)blocks), dim3(256), 0, s, A, lda, B, ldb,
-                           C, ldc, K, (int)tm, (int)tn, alpha, beta, prio, order);
+        hipLaunchKernelGGL(sr_gemm_tn_upper_kernel<sr_tile128>, dim3((unsigned)blocks, bt.n), dim3(256), 0, s, A, lda, B, ldb,
+                           C, ldc, K, (int)tm, (int)tn, alpha, beta, prio, order, bt);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -224,9 +265,12 @@ int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb
 template <class TL>
 __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_jobs_kernel(
     const double* __restrict__ Ab, const double* __restrict__ Bb, double* Cb, double* CTb, long ld,
-    const sr_gemm_job* __restrict__ jobs, double alpha, int mode) {
+    const sr_gemm_job* __restrict__ jobs, double alpha, int mode, int njobs, sr_batch bt) {
     __shared__ double smem[TL::SMEM];
-    const sr_gemm_job jb = jobs[blockIdx.z];
+    const int bz = (int)blockIdx.z / njobs;               // batch member, job
+    const sr_gemm_job jb = jobs[(int)blockIdx.z - bz * njobs];
+    Ab += (long)bz * bt.sA; Bb += (long)bz * bt.sB; Cb += (long)bz * bt.sC;
+    if (CTb) CTb += (long)bz * bt.sCT;
     const int tm = jb.M / TL::T;
     // heavy tiles first, so that the tail of the grid consists of the SHORT k ranges: the slow grid index (y) walks
     // the dimension that sets the k range -- mode 2: n ascending (k starts at n0), mode 3: m descending (k ends at m0 + T)
@@ -280,17 +324,18 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_jobs_kernel(
 
 int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, double* CTb, long ld,
                            const sr_gemm_job* jobs_dev, int njobs, int maxM, int maxN, long tiles128, double alpha,
-                           int mode, hipStream_t s) {
-    SR_CHECK(njobs > 0 && njobs <= 65535 && maxM % srt::BM == 0 && maxN % srt::BN == 0 && (mode == 2 || mode == 3),
+                           int mode, hipStream_t s, const sr_batch* btp) {
+    const sr_batch bt = btp ? *btp : sr_batch{};
+    SR_CHECK(njobs > 0 && (long)njobs * bt.n <= 65535 && maxM % srt::BM == 0 && maxN % srt::BN == 0 && (mode == 2 || mode == 3),
              SR_EINVAL, "gemm_tn_jobs: njobs=%d maxM=%d maxN=%d mode=%d", njobs, maxM, maxN, mode);
-    const int T = sr_use_tile64(tiles128) ? 64 : 128;
-    const dim3 grid = (mode == 2) ? dim3(maxM / T, maxN / T, njobs) : dim3(maxN / T, maxM / T, njobs);
+    const int T = sr_use_tile64_jobs(tiles128 * bt.n) ? 64 : 128;
+    const dim3 grid = (mode == 2) ? dim3(maxM / T, maxN / T, njobs * bt.n) : dim3(maxN / T, maxM / T, njobs * bt.n);
     if (T == 64)
         hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile64>, grid, dim3(256), 0, s, Ab, Bb, Cb, CTb, ld, jobs_dev, alpha,
-                           mode);
+                           mode, njobs, bt);
     else
         hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile128>, grid, dim3(256), 0, s, Ab, Bb, Cb, CTb, ld, jobs_dev,
-                           alpha, mode);
+                           alpha, mode, njobs, bt);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -300,35 +345,55 @@ int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, doubl
 // (kernel spec: ssm_gpy/gp_models_utils_casadi.py:17-40; noise on the diagonal:
 //  ssm_gpy/gaussian_process.py:252-253)
 // ------------------------------------------------------------------------------------------------
+// sf2_dev / noise_dev (device scalars) take precedence over the by-value arguments when not NULL: the model update
+// then needs no host copy of the hyper-parameters before its first launch.  Thread = 4 rows x 1 column: the column's
+// scaled coordinates are loaded once per 4 entries, and the scaling is a multiplication by 1 / l (computed once per
+// thread; the division per entry and dimension was a third of the kernel's time).
 __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__ Z,
                                                       const double* __restrict__ ls, double sf2,
-                                                      double noise, double* __restrict__ K, int N,
-                                                      int Np, int D) {
-    const int i = blockIdx.y;
+                                                      double noise, const double* __restrict__ sf2_dev,
+                                                      const double* __restrict__ noise_dev,
+                                                      double* __restrict__ K, int N, int Np, int D, long strideK) {
+    const int i0 = blockIdx.y * 4;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= Np) return;
-    if ((j | 127) < i) return;               // blocks left of the diagonal are never read (upper factorisation)
+    if ((j | 127) < i0) return;              // blocks left of the diagonal are never read (upper factorisation)
+    const int b = blockIdx.z;                // batch member (output)
+    ls += (long)b * D;
+    K += (long)b * strideK;
+    if (sf2_dev) sf2 = sf2_dev[b];
+    if (noise_dev) noise = noise_dev[b];
     const int off = Np - N;                  // front padding
-    double v;
-    if (i < off || j < off) {
-        v = (i == j) ? 1.0 : 0.0;
-    } else {
-        const int zi = i - off, zj = j - off;
-        double r2 = 0.0;
-        for (int c = 0; c < D; ++c) {
-            const double t = (Z[(long)zi * D + c] - Z[(long)zj * D + c]) / ls[c];
-            r2 += t * t;
-        }
-        v = sf2 * exp(-0.5 * r2);
-        if (i == j) v = sf2 + noise;
+    double il[SR_MAX_D], zj[SR_MAX_D];
+    for (int c = 0; c < D; ++c) {
+        il[c] = 1.0 / ls[c];
+        zj[c] = (j >= off) ? Z[(long)(j - off) * D + c] * il[c] : 0.0;
     }
-    K[(long)i * Np + j] = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u;
+        if (i >= Np) break;
+        double v;
+        if (i < off || j < off) {
+            v = (i == j) ? 1.0 : 0.0;
+        } else if (i == j) {
+            v = sf2 + noise;
+        } else {
+            double r2 = 0.0;
+            for (int c = 0; c < D; ++c) {
+                const double t = fma(Z[(long)(i - off) * D + c], il[c], -zj[c]);
+                r2 = fma(t, t, r2);
+            }
+            v = sf2 * exp(-0.5 * r2);
+        }
+        K[(long)i * Np + j] = v;
+    }
 }
 
-int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, double* K, int N,
-                   int Np, int D, hipStream_t s) {
-    dim3 grid((Np + 255) / 256, Np);
-    hipLaunchKernelGGL(sr_gram_kernel, grid, dim3(256), 0, s, Z, ls, sf2, noise, K, N, Np, D);
+int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, const double* sf2_dev,
+                   const double* noise_dev, double* K, int N, int Np, int D, hipStream_t s, int nbatch, long strideK) {
+    dim3 grid((Np + 255) / 256, (Np + 3) / 4, nbatch);
+    hipLaunchKernelGGL(sr_gram_kernel, grid, dim3(256), 0, s, Z, ls, sf2, noise, sf2_dev, noise_dev, K, N, Np, D, strideK);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -342,11 +407,17 @@ __device__ __forceinline__ double sr_kappa(int kind, double r2) {
 
 __global__ __launch_bounds__(256) void sr_gram_general_kernel(const double* __restrict__ Z,
                                                               const double* __restrict__ kp, double noise,
-                                                              double* __restrict__ K, int N, int Np, int D) {
+                                                              const double* __restrict__ noise_dev,
+                                                              double* __restrict__ K, int N, int Np, int D,
+                                                              long strideK) {
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= Np) return;
     if ((j | 127) < i) return;               // blocks left of the diagonal are never read (upper factorisation)
+    const int b = blockIdx.z;                // batch member (output)
+    kp += (long)b * SR_KP(D);
+    K += (long)b * strideK;
+    if (noise_dev) noise = noise_dev[b];
     const int off = Np - N;
     double v;
     if (i < off || j < off) {
@@ -370,10 +441,10 @@ __global__ __launch_bounds__(256) void sr_gram_general_kernel(const double* __re
     K[(long)i * Np + j] = v;
 }
 
-int sr_launch_gram_general(const double* Z, const double* kp, double noise, double* K, int N, int Np,
-                           int D, hipStream_t s) {
-    dim3 grid((Np + 255) / 256, Np);
-    hipLaunchKernelGGL(sr_gram_general_kernel, grid, dim3(256), 0, s, Z, kp, noise, K, N, Np, D);
+int sr_launch_gram_general(const double* Z, const double* kp, double noise, const double* noise_dev, double* K, int N,
+                           int Np, int D, hipStream_t s, int nbatch, long strideK) {
+    dim3 grid((Np + 255) / 256, Np, nbatch);
+    hipLaunchKernelGGL(sr_gram_general_kernel, grid, dim3(256), 0, s, Z, kp, noise, noise_dev, K, N, Np, D, strideK);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -673,6 +744,10 @@ int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int
 // ------------------------------------------------------------------------------------------------
 #define SR_PD_TLD 33      // pivot stage: 16 rows of [U_pp (16 columns) | T_p = U_pp^-T (16 columns)], padded
 
+// (A square-root-free variant that takes R_j[r] from lane r with the DPP row broadcast of the fp64 ALU -- one
+//  v_fmac_f64_dpp ... row_newbcast:r per updated entry, reciprocal instead of rsqrt on the chain, the 16 square roots
+//  at the end -- was built and measured: 38 us per block against 30 with the v_readlane form below, software-pipelined
+//  or not.  DPP on the fp64 ALU is slow on this part.)
 // upper Cholesky of the 16 x 16 tile at (j0, j0) of S by one wavefront in registers.  X (LDS, 16 x SR_PD_TLD) receives
 // [U | T], T = U^-T (lower triangular, exact zeros above; the part of U below its diagonal is scratch).
 // *fail: 1-based index of the first non-positive pivot.  Nothing but the 16 LDS writes follows the pivot chain: the
@@ -720,11 +795,14 @@ __device__ __forceinline__ d4_t sr_pd_panel_tile(const double* S, const double* 
 
 __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
                                                                          double* wt_diag, double* w_diag,
-                                                                         long ldw, int kb, int* info, int skip) {
+                                                                         long ldw, int kb, int* info, int skip,
+                                                                         sr_batch bt) {
     // skip (sr_test_potrf_diag; 0 in production): 64 = leave A untouched (back-to-back timing on one input)
     __shared__ double S[SR_NB * SR_PD_LD];
     __shared__ double Xb[2][16 * SR_PD_TLD];
     __shared__ int fail;
+    A += (long)blockIdx.x * bt.sA; wt_diag += (long)blockIdx.x * bt.sB; w_diag += (long)blockIdx.x * bt.sC;
+    info += blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, ln = lane & 15;
@@ -866,13 +944,14 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
 }
 
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw, int kb,
-                         int* info_dev, hipStream_t s, int skip) {
+                         int* info_dev, hipStream_t s, int skip, const sr_batch* btp) {
+    const sr_batch bt = btp ? *btp : sr_batch{};
     if (skip & 128)      // the round-2 kernel (A/B timing through sr_test_potrf_diag only)
         hipLaunchKernelGGL(sr_potrf_diag_v2_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
                            kb, info_dev, skip & 63);
     else
-        hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(1), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
-                           kb, info_dev, skip);
+        hipLaunchKernelGGL(sr_potrf_diag_kernel, dim3(bt.n), dim3(SR_PD_THREADS), 0, s, A, lda, wt_diag, w_diag, ldw,
+                           kb, info_dev, skip, bt);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -1167,23 +1246,39 @@ int sr_launch_append_small(const double* U12t, const double* Wt0, int Np0, int m
     return SR_OK;
 }
 
-// one wavefront per row; shuffle reduction
+// one wavefront per row, eight independent loads per lane in flight; shuffle reduction.  blockIdx.y = batch member
+// (matrix, x and y `sM`, `sx`, `sy` doubles apart).  (One load per lane and iteration: 46 us per 105 MB triangle; the four
+// products behind a model update with two outputs were 0.18 ms at its very end.)
 __global__ __launch_bounds__(256) void sr_trmv_kernel(const double* __restrict__ M, long ld,
                                                       const double* __restrict__ x,
-                                                      double* __restrict__ y, int n, int lower) {
+                                                      double* __restrict__ y, int n, int lower, long sM, long sx,
+                                                      long sy) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
+    M += (long)blockIdx.y * sM; x += (long)blockIdx.y * sx; y += (long)blockIdx.y * sy;
     const int c0 = lower ? 0 : row, c1 = lower ? row + 1 : n;
-    double s = 0.0;
-    for (int c = c0 + lane; c < c1; c += 64) s += M[(long)row * ld + c] * x[c];
+    const double* m = M + (long)row * ld;
+    double acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+    int c = c0 + lane;
+    for (; c + 7 * 64 < c1; c += 8 * 64) {
+        double mv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { mv[u] = m[c + 64 * u]; xv[u] = x[c + 64 * u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = fma(mv[u], xv[u], acc[u]);
+    }
+    for (; c < c1; c += 64) acc[0] = fma(m[c], x[c], acc[0]);
+    double s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) y[row] = s;
 }
 
 int sr_launch_trmv(const double* M, long ld, const double* x, double* y, int n, int lower,
-                   hipStream_t s) {
-    hipLaunchKernelGGL(sr_trmv_kernel, dim3((n + 3) / 4), dim3(256), 0, s, M, ld, x, y, n, lower);
+                   hipStream_t s, int nbatch, long sM, long sx, long sy) {
+    hipLaunchKernelGGL(sr_trmv_kernel, dim3((n + 3) / 4, nbatch), dim3(256), 0, s, M, ld, x, y, n, lower, sM, sx, sy);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

@@ -264,7 +264,13 @@ namespace srt64 {
 constexpr int BM = 64, BN = 64, BK = 16;
 constexpr int LDP = 144;                     // doubles between row pairs
 constexpr int STAGE = (BK / 2) * LDP;        // doubles per operand per stage
-constexpr int SMEM_DOUBLES = 4 * STAGE;      // A, B x 2 stages (36,864 B)
+// Round 3: FOUR stages, three k-tiles in flight.  A k-tile of this tile is 16 MFMAs per wavefront (0.43 us); with two
+// stages the single DMA in flight exposed the whole global -> LDS latency on every k-step (1.5 us per step measured:
+// the K = 128 block-row solve of the Cholesky took 14 us for 3.4 us of MFMAs).  The barrier of a k-step waits for
+// exactly the DMAs of the stage about to be read (s_waitcnt vmcnt(4 x stages still in flight), by hand: the
+// __syncthreads() of the two-stage loop carries a vmcnt(0)).  72 KiB of LDS: 2 workgroups per CU.
+constexpr int NS = 4;
+constexpr int SMEM_DOUBLES = 2 * NS * STAGE; // A, B x NS stages (73,728 B)
 
 struct Acc {
     d4_t v[2][2];
@@ -282,6 +288,14 @@ __device__ __forceinline__ int acc_col(int wn, int ni, int lane) { return wn * 3
 // LDS offset (doubles) of tile row r inside a stage: rows (r, r + 2) share a pair
 __device__ __forceinline__ int row_off(int r) { return (((r >> 2) << 1) + (r & 1)) * LDP + ((r >> 1) & 1) * 64; }
 
+// wait until at most `stages` stages' DMAs (4 instructions per wavefront each) are still in flight, then the barrier;
+// "memory": LDS reads stay behind it, the DMA of the stage it frees stays behind it too
+__device__ __forceinline__ void wait_stage_barrier(int stages) {
+    if (stages >= 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (stages == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long lda, const double* __restrict__ B,
                                             long ldb, int k_beg, int k_end, double* smem, Acc& acc) {
     const int tid = threadIdx.x;
@@ -289,7 +303,7 @@ __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     double* As = smem;
-    double* Bs = smem + 2 * STAGE;
+    double* Bs = smem + NS * STAGE;
     if (k_beg >= k_end) return;
     // wavefront w moves pairs w and w + 4 of each operand: pair q = rows (4 (q >> 1) + (q & 1), that + 2)
     const int half = lane >> 5, l32 = lane & 31;
@@ -308,12 +322,19 @@ __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long l
         __builtin_amdgcn_global_load_lds(SRT_AS1(pa_ + 8 * lda), SRT_AS3(sa_ + 4 * LDP), 16, 0, 0);    \
         __builtin_amdgcn_global_load_lds(SRT_AS1(pb_ + 8 * ldb), SRT_AS3(sb_ + 4 * LDP), 16, 0, 0);    \
     } while (0)
-    SRT64_DMA(k_beg, 0);
+    const int nsteps = (k_end - k_beg) / BK;
+    // everything of this wavefront that is older than the DMAs below (a caller's loads) must not count against them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+        if (s_ < nsteps) SRT64_DMA(k_beg + s_ * BK, s_);
     const int lk = lane >> 4, ln = lane & 15;
-    int buf = 0;
-    for (int k0 = k_beg; k0 < k_end; k0 += BK) {
-        __syncthreads();                       // vmcnt(0) + s_barrier: tile k0 landed, the other stage is free
-        if (k0 + BK < k_end) SRT64_DMA(k0 + BK, buf ^ 1);
+    int buf = 0, nbuf = NS - 1;                // stage read by step t, stage filled by step t (t + NS - 1's data)
+    for (int t = 0; t < nsteps; ++t) {
+        // issued so far: min(nsteps, t + NS - 1) stages; stage t must have landed
+        const int issued = (t + NS - 1 < nsteps) ? t + NS - 1 : nsteps;
+        wait_stage_barrier(issued - (t + 1));
+        if (t + NS - 1 < nsteps) SRT64_DMA(k_beg + (t + NS - 1) * BK, nbuf);
         const double* as = As + buf * STAGE + wm * 32 + ln;
         const double* bs = Bs + buf * STAGE + wn * 32 + ln;
 #pragma unroll
@@ -331,7 +352,8 @@ __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long l
                 for (int j = 0; j < 2; ++j)
                     acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0);
         }
-        buf ^= 1;
+        buf = (buf + 1 == NS) ? 0 : buf + 1;
+        nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;
     }
     __syncthreads();                           // callers reuse smem after the main loop
 #undef SRT64_DMA
