@@ -327,7 +327,11 @@ static int pick_fact_panel(const sr_gp* h) {
     // measured (scripts/factor_bench.py, n_out = 2): N = 3000 .. 6000 panels of 2 are 2 - 4 % ahead of 4 (3.33 / 3.49,
     // 4.91 / 5.01, 6.82 / 7.01, 9.24 / 9.41 ms), N = 7000 and 10000 panels of 4 (12.99 / 13.04, 28.3 / 30.2 ms)
     // N = 50000 (391 blocks): panels of 4 / 8 / 16 / 32 blocks 2.735 / 2.655 / 2.625 / 2.642 s; N = 30000: 8 and 16 alike
-    return nb <= 48 ? 2 : (nb <= 160 ? 4 : (nb <= 300 ? 8 : 16));
+    // round 3 (diagonal block 62 -> 30 us, batched outputs), n_out = 2, panels of 2 / 3 / 4 / 6 / 8 blocks: N = 3000 2.22 / 2.26 /
+    // 2.34 / 2.41 / 2.52 ms; N = 5000 5.26 / 5.15 / 5.15 / 5.29 / 5.64; N = 7000 11.0 / 10.5 / 10.2 / 10.3 / 10.5; N = 10000
+    // 28.3 / 26.7 / 25.8 / 25.5 / 25.0; N = 20000 (4 / 8 / 12 / 16) 186.8 / 184.3 / 187.4 / 188.6; N = 30000 592 / 578 / 575 /
+    // 574; N = 50000 (8 / 12 / 16 / 24) 2.599 / 2.580 / 2.570 / 2.555 s
+    return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 16 : 24))));
 }
 
 // Streams of the factorisation.  The chain of diagonal blocks is latency-bound and must never queue behind the
@@ -406,17 +410,22 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     const int P = pick_fact_panel(h);
     const size_t NN = (size_t)Np * Np;
     const size_t per = 2 * NN + (size_t)Np;              // scratch doubles per output in flight: U, W, v
-    // outputs in flight: as many as fit SR_FACT_PAR_BYTES of scratch, at most SR_FACT_SLOTS
-    int n_par = (int)std::min<size_t>((size_t)std::min(h->n_out, SR_FACT_SLOTS),
-                                      std::max<size_t>(1, SR_FACT_PAR_BYTES / (per * sizeof(double))));
-    // The scratch stays with the handle (refits allocate nothing) up to a third of the device's memory: at N = 50000
-    // a hipMalloc / hipFree of 40 GB per update made the first updates of a process take 4.0 - 4.8 s instead of 2.67 s
-    // (page-table work inside the timed call).  sr_gp_release_scratch hands it back.
+    // outputs in a batch: as many as fit a third of the device's memory in scratch (8 GB at least), at most SR_FACT_SLOTS.
+    // (Round 2 capped the scratch at 8 GB, so the outputs of a big model went one after the other; batched, the latency
+    // of one output's chain of panel steps is filled with the other's tiles: N = 50000, n_out = 2 -- 80 GB of scratch
+    // beside 40 GB of factors.)
+    // The scratch stays with the handle (refits allocate nothing): at N = 50000 a hipMalloc / hipFree of 40 GB per update
+    // made the first updates of a process take 4.0 - 4.8 s instead of 2.67 s (page-table work inside the timed call).
+    // sr_gp_release_scratch hands it back.
     if (h->mem_total == 0) {
         size_t mem_free = 0;
         (void)hipMemGetInfo(&mem_free, &h->mem_total);
     }
-    const bool keep = per * n_par * sizeof(double) <= std::max<size_t>(SR_FACT_PAR_BYTES, h->mem_total / 3);
+    static const size_t par_cap_env = getenv("SR_FACT_PAR_GB") ? (size_t)atol(getenv("SR_FACT_PAR_GB")) << 30 : 0;
+    const size_t par_bytes = par_cap_env ? par_cap_env : std::max<size_t>(SR_FACT_PAR_BYTES, h->mem_total / 3);
+    int n_par = (int)std::min<size_t>((size_t)std::min(h->n_out, SR_FACT_SLOTS),
+                                      std::max<size_t>(1, par_bytes / (per * sizeof(double))));
+    const bool keep = per * n_par * sizeof(double) <= par_bytes;
     double* scratch = nullptr;                           // owned here only when it is not kept in the handle
     int rc = SR_OK;
     hipStream_t s0 = (hipStream_t)stream;
