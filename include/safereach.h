@@ -250,6 +250,14 @@ int sr_gp_set_small_path(sr_gp_t h, int on);
  * the reference's systems n_s <= 4) run all H steps inside ONE persistent launch; on = 0 forces the per-step launches.
  * Default on; results agree to rounding.  sr_gp_last_chain: 1 if the last chain took the persistent kernel. */
 int sr_gp_set_chain(sr_gp_t h, int on);
+/* The workgroups of the persistent kernel wait for each other; they are launched only when the kernel's occupancy
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor) and the device's CU count say they can all be resident.  Should the
+ * hand-off of a group still not complete within 100 ms (the CUs were held by other work for that long), the group fills
+ * its outputs with NaN AND raises a status word in pinned host memory.  sr_gp_chain_status: call after synchronising the
+ * stream; *timed_out = 1 if a launch since the last query failed that way (the word is cleared, and the handle takes the
+ * per-step launches from then on).  A caller that does not ask is told by the next reachability entry point, which
+ * returns SR_ESTATE once. */
+int sr_gp_chain_status(sr_gp_t h, int* timed_out);
 /* big batches on the plain MFMA path (>= 8192 queries per range): the K* pass of column ranges 1 .. nsub-1 runs on a side
  * stream beside the contraction of the ranges before them; nsub = 1 switches it off.  Results are identical bit for bit. */
 int sr_gp_set_pipeline(sr_gp_t h, int nsub);
@@ -290,9 +298,14 @@ int sr_test_gemm_tn_upper(int device, const double* A, long lda, const double* B
                           int M, int N, int K, double alpha, double beta, int order, void* stream);
 /* diagnostic: the diagonal-block kernel of the factorisation alone: A (128 x 128 SPD, upper triangle read, leading
  * dimension lda) -> upper Cholesky factor in place, wt = its inverse, w = the inverse transposed (leading dimension
- * ldw); info: device int, 0 or the 1-based first non-positive pivot.  skip != 0 leaves phases out (timing ablation). */
+ * ldw); info: device int, 0 or the 1-based first non-positive pivot.  skip: 0 in production; 64 leaves A untouched
+ * (back-to-back timing on one input), 128 runs the round-2 kernel (A/B timing). */
 int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, long ldw, int* info, int skip,
                        void* stream);
+/* diagnostic: the following persistent multi-step launches of the handle are `drop` workgroups short, so that the last
+ * group of rollouts waits for partners that never come: the deterministic way into the time-out path (the tests check
+ * that it is reported -- sr_gp_chain_status -- and not silent).  0 restores normal launches. */
+int sr_test_chain_drop(sr_gp_t h, int drop);
 /* per-kernel hipEvent timing inside the library (adds an event pair per launch while enabled). */
 int sr_prof_enable(sr_gp_t h, int on);
 int sr_prof_reset (sr_gp_t h);

@@ -81,11 +81,13 @@ SIGNATURES = {
     "sr_wait_flag": (_I, [_P, ctypes.c_ulonglong, ctypes.c_double]),
     "sr_gp_call1": (_I, [_H, _P, _I, _P, _P, ctypes.c_ulonglong, _P]),
     "sr_gp_last_chain": (_I, [_H]),
+    "sr_gp_chain_status": (_I, [_H, _PI]),
     "sr_gp_set_small_path": (_I, [_H, _I]),
     "sr_gp_set_fact_panel": (_I, [_H, _I]),
     "sr_test_gemm_tn": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_gemm_tn_upper": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_potrf_diag": (_I, [_I, _P, _L, _P, _P, _L, _P, _I, _P]),
+    "sr_test_chain_drop": (_I, [_H, _I]),
     "sr_prof_enable": (_I, [_H, _I]),
     "sr_prof_reset": (_I, [_H]),
     "sr_prof_get": (_I, [_H, _I, _PD, _PL]),

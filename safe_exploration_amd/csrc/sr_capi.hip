@@ -30,6 +30,9 @@ struct sr_gp {
     // the hand-off state lives on the device), switch
     double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // tickets, then epochs
     unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0; int chain_cap = -1;
+    int* chain_status_host = nullptr; int* chain_status_dev = nullptr;   // pinned: set by a chain launch that timed out
+    int chain_occ_key = -1, chain_occ_blocks = 0;                         // occupancy of the kernel last asked about
+    int chain_test_drop = 0;                                              // sr_test_chain_drop
     unsigned* call_ticket = nullptr;        // sr_gp_call1: workgroups done (reset by the last one)
     // big batches: the K* pass of the later sub-chunks runs on aux_stream beside the contraction of the earlier ones
     int pipe_sub = 1; hipStream_t aux_stream = nullptr; hipEvent_t ev_pipe_fork = nullptr; hipEvent_t ev_pipe_k[8] = {};
@@ -161,6 +164,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
     dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->chain_done); dev_free(h->call_ticket);
+    if (h->chain_status_host) (void)hipHostFree(h->chain_status_host);
     dev_free(h->yT_alt); dev_free(h->alpha_alt);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->ev_pipe_fork) (void)hipEventDestroy(h->ev_pipe_fork);
@@ -1345,12 +1349,34 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
         h->chain_cap = std::max(0, std::min(SR_CHAIN_GROUPS, cus - 16));
     }
     if (h->chain_cap < n_s * std::max(parts, 1)) return SR_OK;          // not even one group fits: per-step launches
+    // A chain launch whose hand-off timed out (SR_CHAIN_TIMEOUT_TICKS: its workgroups were not co-resident in time) has
+    // poisoned its outputs with NaN and raised the pinned status word.  The first entry after that reports it -- a
+    // caller that never looked at the outputs must not go on with them -- and the handle takes the per-step launches
+    // from here on (sr_gp_set_chain(h, 1) re-arms the persistent kernel).
+    if (h->chain_status_host && *(volatile int*)h->chain_status_host != 0) {
+        *(volatile int*)h->chain_status_host = 0;
+        h->chain = 0;
+        sr_set_error("a previous persistent multi-step launch timed out (its workgroups did not become co-resident within "
+                     "100 ms); its outputs were filled with NaN.  The handle now uses per-step launches; repeat the call.");
+        return SR_ESTATE;
+    }
     const int gmax = std::max(1, h->chain_cap / (n_s * std::max(parts, 1)));      // groups of 16 rollouts per launch
     const long chain_launches = ((T + SR_SMALL_T - 1) / SR_SMALL_T + gmax - 1) / gmax;
     if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 &&
         (chain_launches == 1 || (chain_launches == 2 && T > SR_FUSED_T)) &&
         sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
+        // the kernel must be able to run at all: at least one workgroup per CU (registers, static + dynamic LDS)
+        const int occ_key = ((h->Np * 8 + n_s) * 8 + n_u) * 64 + std::min(H, 63);
+        if (h->chain_occ_key != occ_key) {
+            h->chain_occ_blocks = 0;
+            SR_TRY(sr_chain_blocks_per_cu(h->Np, n_s, n_u, H, &h->chain_occ_blocks));
+            h->chain_occ_key = occ_key;
+        }
+        if (h->chain_occ_blocks < 1) return SR_OK;                       // per-step launches
         if (!h->chain_xch) {
+            SR_HIP(hipHostMalloc((void**)&h->chain_status_host, sizeof(int), hipHostMallocMapped));
+            *h->chain_status_host = 0;
+            SR_HIP(hipHostGetDevicePointer((void**)&h->chain_status_dev, h->chain_status_host, 0));
             // (first use only: a blocking memset -- not inside a stream capture)
             SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_GROUPS * 2 * SR_SMALL_T * (SR_MAX_D + 2)));
             SR_TRY(dev_alloc(&h->chain_tickets, (size_t)2 * SR_CHAIN_GROUPS));
@@ -1373,6 +1399,8 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
             ca.gp_var_all = gp_var_all ? gp_var_all + t0 * H * n_s : nullptr;
             ca.n_bad = n_bad; ca.xch = h->chain_xch; ca.tickets = h->chain_tickets;
             ca.epoch = h->chain_tickets + SR_CHAIN_GROUPS; ca.done = h->chain_done;
+            ca.status = h->chain_status_dev;
+            ca.test_drop = h->chain_test_drop;
             SR_TRY(sr_launch_chain(ca, s));
             (void)groups;
         }
@@ -1683,6 +1711,17 @@ extern "C" int sr_gp_set_chain(sr_gp_t h, int on) {
 
 extern "C" int sr_gp_last_chain(sr_gp_t h) { return h ? h->last_chain : 0; }
 
+extern "C" int sr_gp_chain_status(sr_gp_t h, int* timed_out) {
+    SR_CHECK(h != nullptr && timed_out != nullptr, SR_EINVAL, "sr_gp_chain_status: NULL argument");
+    *timed_out = 0;
+    if (h->chain_status_host && *(volatile int*)h->chain_status_host != 0) {
+        *timed_out = 1;
+        *(volatile int*)h->chain_status_host = 0;
+        h->chain = 0;                        // per-step launches from here on (sr_gp_set_chain re-arms)
+    }
+    return SR_OK;
+}
+
 extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_small_path: NULL handle");
     h->small_path = on;      // 0: plain three-kernel pass only; 1: all latency paths; 2: all but the fused K0
@@ -1715,6 +1754,23 @@ extern "C" int sr_test_potrf_diag(int device, double* A, long lda, double* wt, d
     SR_CHECK(A && wt && w && info, SR_EINVAL, "sr_test_potrf_diag: NULL argument");
     SR_DEVICE(device);
     return sr_launch_potrf_diag(A, lda, wt, w, ldw, 0, info, (hipStream_t)stream, skip);
+}
+
+// tests: the next persistent multi-step launches are short of `drop` workgroups, i.e. the last group waits for partners
+// that never come -- the deterministic way to reach the time-out path (a CU mask of one or two bits does not do it: the
+// driver widens such masks, the chain completed on "1 CU")
+extern "C" int sr_test_chain_drop(sr_gp_t h, int drop) {
+    SR_CHECK(h != nullptr && drop >= 0, SR_EINVAL, "sr_test_chain_drop: bad argument");
+    h->chain_test_drop = drop;
+    if (drop == 0 && h->chain_tickets) {
+        // a launch that was short of a workgroup leaves its group's counters in a state no real launch can produce
+        // (in the field every workgroup runs, however late, and the last one to leave resynchronises the group)
+        SR_DEVICE(h->device);
+        SR_HIP(hipDeviceSynchronize());
+        SR_HIP(hipMemset(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
+        SR_HIP(hipMemset(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS));
+    }
+    return SR_OK;
 }
 
 extern "C" int sr_prof_enable(sr_gp_t h, int on) {

@@ -212,9 +212,18 @@ struct sr_chain_args {
     // per group: arrivals so far (monotonic), the value it had when the previous launch ended (written by that launch's
     // last workgroup: nothing of the protocol lives on the host, so a captured launch can be replayed), workgroups done
     unsigned long long* tickets; unsigned long long* epoch; unsigned* done;
+    // status word in PINNED HOST memory (device-visible address): a group whose hand-off did not complete within
+    // SR_CHAIN_TIMEOUT_TICKS ORs 1 into it with a system-scope atomic (and poisons its outputs with NaN).  The host
+    // reads it without a copy: after the stream has been synchronised it says whether this launch failed.
+    int* status;
+    int test_drop = 0;                // tests only: launch this many workgroups fewer than the chain needs
 };
 #define SR_CHAIN_GROUPS 240          /* workgroups of one launch: all must be resident (they wait for each other) */
+#define SR_CHAIN_TIMEOUT_TICKS 10000000ull   /* 100 ms of the 100 MHz wall clock (a step takes ~10 us) */
 bool sr_chain_supported(int Np, int D, int n_s, int n_u, int H);
+// workgroups of the chain kernel for this model that one CU can hold (hipOccupancyMaxActiveBlocksPerMultiprocessor of
+// the instantiation the dispatcher would pick; 0 = it cannot run at all); H sizes the dynamic LDS
+int sr_chain_blocks_per_cu(int Np, int n_s, int n_u, int H, int* blocks);
 int sr_launch_chain(const sr_chain_args& a, hipStream_t s);
 
 // part[d][rb][t] = sum_{i in row block rb} ( sum_k Wt[d][k][i] Ks[d][k][t] )^2

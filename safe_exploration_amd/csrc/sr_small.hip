@@ -552,9 +552,9 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
                 const unsigned long long t_start = wall_clock64();          // 100 MHz
                 while (__hip_atomic_load(c.tickets + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(2);
-                    // 10 s: a workgroup of the group never came (a launch on a stream whose CU mask holds fewer
-                    // CUs than the grid has workgroups would wait for ever)
-                    if (wall_clock64() - t_start > 1000000000ull) { fail = 1; break; }
+                    // 100 ms: a workgroup of the group never came (a launch on a stream whose CU mask holds fewer
+                    // CUs than the grid has workgroups would wait for ever; other work on the device only delays it)
+                    if (wall_clock64() - t_start > SR_CHAIN_TIMEOUT_TICKS) { fail = 1; break; }
                 }
             }
             __syncthreads();
@@ -615,6 +615,8 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
         }
         // (the next phase A starts by reading ps and writes none of the arrays read above before its first barrier)
     }
+    if (fail && tid == 0 && c.status)     // not silent: the host finds this after synchronising (sr_gp_chain_status)
+        __hip_atomic_fetch_or(c.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (fail && writer) {
         const double nan = __builtin_nan("");
         for (long e = tid; e < nq * c.H * NS; e += NT) c.p_all[t0 * c.H * NS + e] = nan;
@@ -637,8 +639,40 @@ static int launch_chain_np(const sr_chain_args& a, hipStream_t s) {
     constexpr int DT = (NS + NU <= 3) ? 3 : (NS + NU <= 5 ? 5 : 8);
     const unsigned groups = (unsigned)((a.T + SR_FQ - 1) / SR_FQ);
     const size_t ctl_bytes = sizeof(double) * SR_FQ * ((size_t)a.H * NU + (size_t)(a.H - 1) * NU * NS);
-    hipLaunchKernelGGL((sr_chain_kernel<NP, DT, NS, NU>), dim3(groups * NS * SR_CHAIN_PARTS(NP)), dim3(64 * SR_CHAIN_NW), ctl_bytes, s, a);
+    hipLaunchKernelGGL((sr_chain_kernel<NP, DT, NS, NU>), dim3(groups * NS * SR_CHAIN_PARTS(NP) - a.test_drop), dim3(64 * SR_CHAIN_NW), ctl_bytes, s, a);
     SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+template <int NP, int NS, int NU>
+static int chain_occupancy_np(int H, int* blocks) {
+    constexpr int DT = (NS + NU <= 3) ? 3 : (NS + NU <= 5 ? 5 : 8);
+    const size_t ctl_bytes = sizeof(double) * SR_FQ * ((size_t)H * NU + (size_t)(H - 1) * NU * NS);
+    SR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sr_chain_kernel<NP, DT, NS, NU>, 64 * SR_CHAIN_NW, ctl_bytes));
+    return SR_OK;
+}
+template <int NS, int NU>
+static int chain_occupancy_su(int Np, int H, int* blocks) {
+    switch (Np) {
+        case 128: return chain_occupancy_np<128, NS, NU>(H, blocks);
+        case 256: return chain_occupancy_np<256, NS, NU>(H, blocks);
+        case 384: return chain_occupancy_np<384, NS, NU>(H, blocks);
+        case 512: return chain_occupancy_np<512, NS, NU>(H, blocks);
+    }
+    *blocks = 0;
+    return SR_OK;
+}
+int sr_chain_blocks_per_cu(int Np, int n_s, int n_u, int H, int* blocks) {
+    *blocks = 0;
+    if (n_u == 1) {
+        if (n_s == 1) return chain_occupancy_su<1, 1>(Np, H, blocks);
+        if (n_s == 2) return chain_occupancy_su<2, 1>(Np, H, blocks);
+        if (n_s == 3) return chain_occupancy_su<3, 1>(Np, H, blocks);
+        if (n_s == 4) return chain_occupancy_su<4, 1>(Np, H, blocks);
+    } else if (n_u == 2) {
+        if (n_s == 2) return chain_occupancy_su<2, 2>(Np, H, blocks);
+        if (n_s == 3) return chain_occupancy_su<3, 2>(Np, H, blocks);
+    }
     return SR_OK;
 }
 

@@ -10,7 +10,10 @@ All arithmetic happens in the HIP kernels behind include/safereach.h:
   * any other StateSpaceModel     -> its ``ssm(x, u)`` is called on the host exactly like the
     reference does (gp_reachability.py:74,101) and the ellipsoid algebra runs in sr_ellipsoid_step.
 """
+import ctypes
+
 import numpy as np
+import torch
 
 from . import _buffers as B
 from ._lib import lib, check
@@ -64,6 +67,25 @@ def _raise_if_bad(n_bad):
                              "({} query state(s) affected)".format(int(n_bad.item())))
 
 
+def chain_timed_out(hd, sync_device=None):
+    """True if a persistent multi-step launch of this handle failed since the last query: its workgroups did not become
+    co-resident within 100 ms and it filled its outputs with NaN (``sr_gp_chain_status``).  Synchronises the current
+    stream first when a device is given -- the status word is only final once the launch has ended."""
+    if sync_device is not None:
+        torch.cuda.current_stream(sync_device).synchronize()
+    flag = ctypes.c_int(0)
+    check(lib.sr_gp_chain_status(hd.h, ctypes.byref(flag)))
+    return bool(flag.value)
+
+
+def _raise_if_chain_failed(hd, dev, synced):
+    """After a call whose results the caller is about to read on the host: never hand NaN ellipsoids back silently."""
+    if lib.sr_gp_last_chain(hd.h) and chain_timed_out(hd, None if synced else dev):
+        raise RuntimeError("libsafereach: the persistent multi-step kernel timed out (its workgroups were not co-resident "
+                           "within 100 ms: the device was busy with other work); the model now uses per-step launches -- "
+                           "repeat the call")
+
+
 def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None, k_fb=None,
                                c_safety=1., a=None, b=None, check_bounds=False, return_var=False, t_z_gp=None):
     """Batched ``onestep_reachability``.
@@ -103,7 +125,10 @@ def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None,
                                    B.ptr(q_out), B.ptr(var), B.ptr(n_bad), B.stream_ptr(dev)))
     _raise_if_bad(n_bad)
     outs = (p_out, q_out, var) if return_var else (p_out, q_out)
-    return outs if as_t else tuple(B.to_numpy(o) for o in outs)
+    if as_t:
+        return outs          # device tensors, nothing synchronised: a failed chain is reported by the next entry point
+    _raise_if_chain_failed(hd, dev, n_bad is not None)
+    return tuple(B.to_numpy(o) for o in outs)
 
 
 def ellipsoid_step_batch(p_center, k_ff, mu, var, jac, l_mu, l_sigma, q_shape=None, k_fb=None,
@@ -212,7 +237,10 @@ def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_
                                      B.ptr(ta), B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety),
                                      B.ptr(p_all), B.ptr(q_all), B.ptr(n_bad), B.stream_ptr(dev)))
     _raise_if_bad(n_bad)
-    return (p_all, q_all) if as_t else (B.to_numpy(p_all), B.to_numpy(q_all))
+    if as_t:
+        return p_all, q_all
+    _raise_if_chain_failed(hd, dev, n_bad is not None)
+    return B.to_numpy(p_all), B.to_numpy(q_all)
 
 
 def multistep_reachability(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_safety=1., verbose=1,

@@ -50,7 +50,11 @@ def multistep_moments_batch(mu_0, ssm, k_ff, k_fb, a=None, b=None, mode=TAYLOR, 
         check(lib.sr_multistep_moments(hd.h, T, H, int(mode), B.ptr(m0), B.ptr(kff), B.ptr(kfb), B.ptr(ta), B.ptr(tb),
                                        B.ptr(mu_all), B.ptr(sigma_all), B.ptr(var_all), B.stream_ptr(dev)))
     outs = (mu_all, sigma_all, var_all)
-    return outs if as_t else tuple(B.to_numpy(o) for o in outs)
+    if as_t:
+        return outs
+    from .gp_reachability import _raise_if_chain_failed
+    _raise_if_chain_failed(hd, dev, False)
+    return tuple(B.to_numpy(o) for o in outs)
 
 
 def moment_step_batch(mu_x, k_ff, mu_g, var_g, jac_g, sigma_x=None, k_fb=None, a=None, b=None, mode=TAYLOR,

@@ -1442,6 +1442,110 @@ def test_persistent_chain_matches_per_step_launches(n_s, n_u, N, T, H, with_q0):
     np.testing.assert_allclose(q_all[:n], rq, rtol=1e-6, atol=1e-12)
 
 
+def test_persistent_chain_timeout_is_reported_not_silent():
+    """A persistent multi-step launch one of whose groups cannot complete its hand-offs (here: the launch is one workgroup
+    short, sr_test_chain_drop -- in the field: the CUs were held by other work).  Within 100 ms the group gives up, fills
+    its outputs with NaN AND raises the pinned status word: the NumPy entry point raises instead of returning NaN
+    ellipsoids, sr_gp_chain_status reports it to device-tensor callers, the next entry point reports it to callers that
+    never ask, the handle falls back to per-step launches, and the same call then succeeds."""
+    import time
+    import torch
+    from safe_exploration_amd import gp_reachability as reach
+    from safe_exploration_amd._lib import lib, check
+    n_s, n_u, N, T, H = 2, 1, 200, 240, 6            # 15 groups x 2 outputs x 2 parts = 60 workgroups
+    syn = orc.make_synthetic(4242, N, n_s, n_u, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    rng = np.random.default_rng(5)
+    k_ff = 0.3 * rng.standard_normal((T, H, n_u))
+    k_fb = 0.1 * rng.standard_normal((T, H - 1, n_u, n_s))
+    l = np.array([0.005, 0.008])
+    a, b = 0.6 * np.eye(n_s), 0.1 * rng.standard_normal((n_s, n_u))
+    args = (syn["p"], gp, k_fb, k_ff, l, l, None, 2.0, a, b)
+    p_ref, q_ref = reach.multistep_reachability_batch(*args)
+    assert gp.last_chain and not reach.chain_timed_out(gp._handle)
+    check(lib.sr_test_chain_drop(gp._handle.h, 1))
+    try:
+        # (1) NumPy in / out: the call itself must raise
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="timed out"):
+            reach.multistep_reachability_batch(*args)
+        assert time.time() - t0 < 5.0                      # 100 ms, not 10 s
+        # the handle now takes per-step launches: the same call works
+        p2, q2 = reach.multistep_reachability_batch(*args)
+        assert not gp.last_chain
+        np.testing.assert_allclose(p2, p_ref, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(q2, q_ref, rtol=1e-7, atol=1e-14)
+        # (2) device tensors in / out, nothing synchronises: NaN in the failed group only, status word set, and the
+        # first entry after the failure reports it
+        gp.set_chain(True)
+        targs = tuple(torch.from_numpy(x).to(gp.device) if isinstance(x, np.ndarray) and x.shape[:1] == (T,) else x
+                      for x in args)
+        tp, tq = reach.multistep_reachability_batch(*targs)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(tq[-16:]).all()) and bool(torch.isfinite(tq[:-16]).all())
+        np.testing.assert_allclose(tq[:-16].cpu().numpy(), q_ref[:-16], rtol=1e-7, atol=1e-14)
+        with pytest.raises(RuntimeError, match="timed out"):
+            reach.multistep_reachability_batch(*targs)
+        tp, tq = reach.multistep_reachability_batch(*targs)       # per-step launches now
+        torch.cuda.synchronize()
+        assert not gp.last_chain
+        np.testing.assert_allclose(tq.cpu().numpy(), q_ref, rtol=1e-7, atol=1e-14)
+        # (3) a caller that asks: sr_gp_chain_status
+        gp.set_chain(True)
+        reach.multistep_reachability_batch(*targs)
+        assert reach.chain_timed_out(gp._handle, gp.device)
+        assert not reach.chain_timed_out(gp._handle, gp.device)          # cleared by the query
+    finally:
+        check(lib.sr_test_chain_drop(gp._handle.h, 0))
+    # complete launches again: the persistent kernel can be re-armed, the groups resynchronise themselves
+    gp.set_chain(True)
+    for _ in range(2):
+        p3, q3 = reach.multistep_reachability_batch(*args)
+        assert gp.last_chain
+        np.testing.assert_allclose(q3, q_ref, rtol=1e-7, atol=1e-14)
+
+
+def test_persistent_chain_beside_a_saturating_stream():
+    """The chain kernel's workgroups wait for each other; while another stream keeps every CU busy (the 47 ms contraction
+    of a 65536-query batch on an N = 5000 model) they may become resident late.  Whatever happens must be either the right
+    answer or a reported failure followed by the right answer from the per-step route -- never silent NaN."""
+    import torch
+    from safe_exploration_amd import gp_reachability as reach, workload
+    big = orc.make_synthetic(5, 5000, 2, 1, 4)
+    gbig = hip_model(big["Z"], big["Y"], big["lengthscale"], big["signal_var"], big["noise_var"], 2, 1)
+    qb = workload.make_queries(9, 2, 1, 65536)
+    xb = torch.from_numpy(np.hstack((qb["p"], qb["k_ff"]))).to(gbig.device)
+    n_s, n_u, N, T, H = 2, 1, 200, 256, 15
+    syn = orc.make_synthetic(777, N, n_s, n_u, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    rng = np.random.default_rng(6)
+    k_ff = 0.3 * rng.standard_normal((T, H, n_u))
+    k_fb = 0.1 * rng.standard_normal((T, H - 1, n_u, n_s))
+    l = np.array([0.005, 0.008])
+    a, b = 0.6 * np.eye(n_s), 0.1 * rng.standard_normal((n_s, n_u))
+    args = (syn["p"], gp, k_fb, k_ff, l, l, None, 2.0, a, b)
+    p_ref, q_ref = reach.multistep_reachability_batch(*args)
+    assert gp.last_chain
+    side = torch.cuda.Stream(device=gbig.device)
+    failures = 0
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                gbig.predict_device(xb)                       # ~3 x 48 ms of MFMA work on every CU
+        try:
+            p_all, q_all = reach.multistep_reachability_batch(*args)
+        except RuntimeError as e:
+            assert "timed out" in str(e)
+            failures += 1
+            p_all, q_all = reach.multistep_reachability_batch(*args)      # per-step launches
+            gp.set_chain(True)
+        assert np.all(np.isfinite(q_all))
+        np.testing.assert_allclose(p_all, p_ref, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(q_all, q_ref, rtol=1e-7, atol=1e-14)
+        side.synchronize()
+    print("chain launches that timed out beside the saturating stream: %d of 4" % failures)
+
+
 def test_single_query_mailbox_and_fallback_agree():
     """__call__ / linearize_predict hand their results back through sr_publish + sr_wait_flag (pinned mailbox, host
     spin); the plain copy + stream sync route must give the same arrays, call after call."""
