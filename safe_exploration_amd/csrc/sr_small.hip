@@ -126,29 +126,32 @@ struct sr_small_lds {
 // Phases A - C for output d and the (up to) SR_FQ queries x_t = [xa[t*lda ..], xb[t*ldb ..]], t < nq, whose pointers
 // may be global or LDS.  Leaves R in L.Rs, the scaled queries in L.xq and the strip sums in L.redC; ends with a
 // barrier.  Must be called by all 1024 threads.
-// The training rows of a lane's phase-A fragments: KEEP = all NP/64 k-steps loaded once by sr_small_rows_load and
-// kept in registers by the caller (the persistent chain kernel); otherwise phase A loads them itself, HC steps at a time.
-template <int NP, int DT, int NW = 16>
+// The training rows of a lane's phase-A fragments: phase A loads them itself, HC steps at a time, unless KEEP:
+// The persistent chain kernel keeps them in LDS for all its steps (sr_small_rows: Np x (DT + 1) doubles, z_ij / l_j and
+// alpha_i; round 2 kept them in registers where they fit -- 64 to 96 VGPRs beside the U^-1 fragments, the main reason
+// for the kernel's scratch use -- and re-read them from L2 every step where they did not).
+template <int NP, int DT>
 struct sr_small_rows {
-    double zs[NP / (4 * NW)][DT];     // z_ij / l_j
-    double al[NP / (4 * NW)];         // alpha_i (0 on padding rows)
+    const double (*r)[DT + 1];        // [NP]: z_i0 / l_0 .. , alpha_i (0 on padding rows)
+    const double* il;                 // [DT]: 1 / l_j (0 beyond D) -- read per step, not held in registers across steps
 };
 
-template <int NP, int DT, int NW>
-__device__ __forceinline__ void sr_small_rows_load(const sr_kstar_args& a, int d, sr_small_rows<NP, DT, NW>& rows) {
-    constexpr int RPW = NP / NW, KSA = RPW / 4;
-    const int lane = threadIdx.x & 63, lk = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// all threads of the workgroup; the caller's barrier publishes the rows
+template <int NP, int DT>
+__device__ __forceinline__ void sr_small_rows_fill(const sr_kstar_args& a, int d, double (*dst)[DT + 1], int nthreads) {
     const int off = NP - a.N;
-#pragma unroll
-    for (int st = 0; st < KSA; ++st) {
-        const int i = wave * RPW + 4 * st + lk;
+    for (int e = threadIdx.x; e < NP * (DT + 1); e += nthreads) {
+        const int i = e / (DT + 1), j = e % (DT + 1);
         const bool valid = i >= off;
-        rows.al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
-#pragma unroll
-        for (int j = 0; j < DT; ++j)      // z * (1 / l) as phase A forms it: the same bits with and without KEEP
-            rows.zs[st][j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] * (1.0 / a.ls[d * a.D + j]) : 0.0;
+        double v = 0.0;
+        if (valid && j == DT) v = a.alpha[(long)d * NP + i];
+        else if (valid && j < a.D) v = a.Z[(long)(i - off) * a.D + j] * (1.0 / a.ls[d * a.D + j]);   // as phase A forms it
+        dst[i][j] = v;
     }
+}
+template <int DT>
+__device__ __forceinline__ void sr_small_il_fill(const sr_kstar_args& a, int d, double* il) {
+    if (threadIdx.x < DT) il[threadIdx.x] = (threadIdx.x < a.D) ? 1.0 / a.ls[d * a.D + threadIdx.x] : 0.0;
 }
 
 // Phase A alone: k* into L.ks, R = k*^T M into L.Rs (valid for threads < 256 right away, for everybody after the next
@@ -157,10 +160,17 @@ template <int NP, int DT, bool LIN, bool KEEP = false, int NW = 16>
 __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
                                                  const double* xa, long lda, const double* xb, long ldb, long nq,
                                                  const sr_small_lds<NP, DT>& L,
-                                                 const sr_small_rows<NP, DT, NW>* rows = nullptr) {
+                                                 const sr_small_rows<NP, DT>* rows = nullptr) {
     constexpr int RPW = NP / NW;             // training rows per wavefront in phase A
     constexpr int KSA = RPW / 4;             // phase-A k-steps per wavefront
-    constexpr int HC = KSA <= 4 ? KSA : KSA / 2;     // k-steps whose global loads are hoisted together
+#ifndef SR_CHAIN_HC
+#define SR_CHAIN_HC 2
+#endif
+    // k-steps whose global loads are hoisted together.  The persistent kernel (NW = 8) holds its U^-1 fragments in
+    // registers throughout: there at most SR_CHAIN_HC steps (HC (DT + 1) doubles per lane) -- with half of the 16 steps
+    // of Np = 512 hoisted the kernel needed 184 - 520 B of scratch per lane
+    constexpr int HC0 = KSA <= 4 ? KSA : KSA / 2;
+    constexpr int HC = (NW == 16 || HC0 <= SR_CHAIN_HC) ? HC0 : ((KSA % SR_CHAIN_HC == 0) ? SR_CHAIN_HC : (KSA % 3 == 0 ? 3 : 2));
     static_assert(DT + 1 <= 16, "the mean/Jacobian right-hand side must fit the 16 MFMA columns");
     static_assert(NP % 128 == 0 && NP <= 512 && KSA % HC == 0 && KSA >= 1, "Np in {128, 256, 384, 512}");
     double (*ks)[SR_FQ] = L.ks;
@@ -183,13 +193,13 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
         double xs[DT], il[DT];
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
-            il[j] = (j < a.D) ? a.ls[d * a.D + j] : 1.0;
+            il[j] = (!KEEP && j < a.D) ? a.ls[d * a.D + j] : 1.0;
             xs[j] = 0.0;
             if (live && j < a.D) xs[j] = a.xv_on ? a.xv[j] : ((j < a.na) ? xa[qt * lda + j] : xb[qt * ldb + (j - a.na)]);
         }
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
-            il[j] = (j < a.D) ? 1.0 / il[j] : 0.0;
+            il[j] = KEEP ? rows->il[j] : ((j < a.D) ? 1.0 / il[j] : 0.0);
             xs[j] *= il[j];
         }
         sr_d4 accA = {0.0, 0.0, 0.0, 0.0};
@@ -201,9 +211,9 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
                 const int i = wave * RPW + 4 * (c0 + st) + lk;
                 const bool valid = i >= off;
                 if (KEEP) {
-                    al[st] = rows->al[c0 + st];
+                    al[st] = rows->r[i][DT];
 #pragma unroll
-                    for (int j = 0; j < DT; ++j) zv[st][j] = rows->zs[c0 + st][j];
+                    for (int j = 0; j < DT; ++j) zv[st][j] = rows->r[i][j];
                 } else {
                     al[st] = valid ? a.alpha[(long)d * NP + i] : 0.0;
 #pragma unroll
@@ -251,7 +261,7 @@ template <int NP, int DT, bool LIN, bool KEEP = false>
 __device__ __forceinline__ void sr_small_posterior(const sr_kstar_args& a, const double* __restrict__ Wt, int d,
                                                    const double* xa, long lda, const double* xb, long ldb, long nq,
                                                    const sr_small_lds<NP, DT>& L,
-                                                   const sr_small_rows<NP, DT, 16>* rows = nullptr) {
+                                                   const sr_small_rows<NP, DT>* rows = nullptr) {
     sr_small_phase_a<NP, DT, LIN, KEEP, 16>(a, d, xa, lda, xb, ldb, nq, L, rows);
     // ---- phases B, C ---------------------------------------------------------------------------
     sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, L.ks, L.pB, L.redC, threadIdx.x >> 6, threadIdx.x & 63);
@@ -474,6 +484,8 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
     __shared__ double qs[SR_FQ][NS * NS];          // shape matrices
     __shared__ double mus[SR_FQ][NS], vars_[SR_FQ][NS], jacs[SR_FQ][NS * D];
     __shared__ double cst[NS * NS + NS * NU + 3 * NS];     // a, b, l_mu, l_sigma, sf2
+    __shared__ double rows_[NP][DT + 1];                   // training rows of output d: z_i / l, alpha_i
+    __shared__ double il_[DT];                             // 1 / lengthscale of output d
     extern __shared__ double ctl[];                        // k_ff [16][H][NU], then k_fb [16][H-1][NU][NS] of the group
     __shared__ int fail;
     __shared__ unsigned long long base_s;
@@ -495,10 +507,11 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
     // everything that does not change from step to step is fetched once
     double wreg[TOT];
     sr_flat_load<NP>(c.Wt + (long)d * NP * NP, part, wave, lane, wreg);
-    // training rows of phase A in registers too while fragments + rows stay below ~180 of the 256 VGPRs
-    constexpr bool KEEP = (NP / (4 * NW)) * (DT + 1) + TOT <= 90;
-    sr_small_rows<NP, DT, NW> rows;
-    if (KEEP) sr_small_rows_load<NP, DT, NW>(c.k, d, rows);
+    // training rows of phase A (pre-scaled) in LDS
+    constexpr bool KEEP = true;
+    sr_small_rows_fill<NP, DT>(c.k, d, rows_, NT);
+    sr_small_il_fill<DT>(c.k, d, il_);
+    const sr_small_rows<NP, DT> rows{rows_, il_};
     double* kffs = ctl;
     double* kfbs = ctl + (long)SR_FQ * c.H * NU;
     for (long e = tid; e < nq * c.H * NU; e += NT) kffs[e] = c.k_ff[t0 * c.H * NU + e];
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
             double v = 0.0;
             bool mine = true;
             if (j < D) {
-                v = (Rs_[t][1 + j] - xq_[t][j] * Rs_[t][0]) / c.k.ls[d * D + j];
+                v = (Rs_[t][1 + j] - xq_[t][j] * Rs_[t][0]) * il_[j];
                 mine = (part == 0);
             } else if (j == D) {
                 v = Rs_[t][0];
@@ -579,6 +592,10 @@ __global__ __launch_bounds__(64 * SR_CHAIN_NW) void sr_chain_kernel(sr_chain_arg
         __syncthreads();
 
         // ---- ellipsoid step, in place in LDS ------------------------------------------------------
+        // (A cooperative form -- 16 lanes per rollout, one matrix entry each, every matrix in LDS, parallel-ordered
+        //  Jacobi sweeps -- was built and measured: it removes no scratch (the ellipsoid step is not where the
+        //  registers go) and is slower: pendulum N = 200 148 -> 183 us, cart-pole N = 150 335 -> 340 us per 15-step
+        //  chain; the LDS round trips between its many small phases cost what the parallelism buys.)
         if (tid < nq) {
             sr_ell_args ea;
             ea.T = nq; ea.n_s = NS; ea.n_u = NU;
@@ -690,10 +707,23 @@ static int launch_chain_su(const sr_chain_args& a, hipStream_t s) {
 
 // the systems of the reference's experiments (pendulum 2 + 1, cart-pole 4 + 1) and their neighbours; anything else
 // runs the per-step launches
+// Which instantiations are dispatched (profiles/r03_kernel_resources.txt; the workgroup has 8 wavefronts, i.e. 256
+// registers per lane, of which the U^-1 fragments take 36 .. 132).  Scratch-free: everything at Np <= 128, n_s <= 3 at
+// Np = 256, n_s <= 2 at Np = 384, one output at Np = 512.  Also taken, because they still beat the per-step launches
+// by 1.3 - 1.9 x: instantiations whose scratch is at most 96 B per lane -- two dozen loop-invariant dwords (addresses,
+// constants) that the prologue writes ONCE and every step re-reads (15 scratch loads per step in the n_s = 4, Np = 256
+// cart-pole kernel: 80 B; Np = 512 pendulum: 20 B).  Beyond that (116 .. 328 B) the per-step launches run.
+static bool sr_chain_dispatched(int Np, int n_s, int n_u) {
+    if (Np <= 256) return true;                                   // scratch 0, except (4, 1) at 256: 80 B
+    if (Np == 384) return n_s <= 3;                               // (3, 1) 12 B, (3, 2) 88 B; (4, 1): 188 B -> no
+    return n_s <= 2;                                              // 512: (1, 1) 0, (2, 1) 20 B, (2, 2) 68 B; others 116+ -> no
+}
+
 bool sr_chain_supported(int Np, int D, int n_s, int n_u, int H) {
     if (!(Np % 128 == 0 && Np <= SR_FUSED_NP && D == n_s + n_u)) return false;
     if ((long)H * (n_u + n_u * n_s) * SR_FQ * 8 > 24576) return false;      // the group's control sequence lives in LDS
-    return (n_u == 1 && n_s >= 1 && n_s <= 4) || (n_u == 2 && (n_s == 2 || n_s == 3));
+    if (!((n_u == 1 && n_s >= 1 && n_s <= 4) || (n_u == 2 && (n_s == 2 || n_s == 3)))) return false;
+    return sr_chain_dispatched(Np, n_s, n_u);
 }
 
 int sr_launch_chain(const sr_chain_args& a, hipStream_t s) {
