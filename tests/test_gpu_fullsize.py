@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from _helpers import hip_model, mu_atol, cached_oracle_model, hyp_from
+from _helpers import hip_model, mu_atol, cached_oracle_model, hyp_from, oracle_model
 from oracle import oracle_np as orc
 
 pytestmark = pytest.mark.gpu
@@ -319,3 +319,149 @@ def test_first_small_batch_reach_call_on_a_big_model():
     pb, qb = reach.multistep_reachability_batch(syn["p"], gp2, k_fb, k_ff, l, l, None, 2.0, a, b)
     np.testing.assert_allclose(pa, pb, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(qa, qb, rtol=1e-7, atol=1e-13)
+
+
+def test_config3_at_the_rollout_count_the_bench_times():
+    """BASELINE configs[2] at the size `bench.py --workload c3` times: cart-pole dims (n_s = 4, n_u = 1), N = 5000, H = 15,
+    65536 rollouts (983040 step evaluations).  Properties on ALL rows (finite, symmetric, positive definite shape
+    matrices, positive GP variances implied by them), the one-call chain against H one-step calls on a strided sample of
+    512 rollouts, three rollouts against the oracle chain (factorised on the CPU), and bit-equality of a slice evaluated
+    on its own (same kernels, same tile positions)."""
+    import torch
+    from safe_exploration_amd import gp_reachability as reach, workload
+    N, T, H, n_s, n_u = 5000, 65536, 15, 4, 1
+    syn = orc.make_synthetic(3, N, n_s, n_u, 8, sf2=0.01)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    roll = workload.random_rollout_controls(34, T, H, n_s, n_u)
+    dev = gp.device
+    tp0, tkff, tkfb = (torch.from_numpy(roll[k]).to(dev) for k in ("p0", "k_ff", "k_fb"))
+    l = np.full(n_s, 0.05)
+    a, b = 0.5 * np.eye(n_s), np.zeros((n_s, n_u))
+    p_all, q_all = reach.multistep_reachability_batch(tp0, gp, tkfb, tkff, l, l, None, 2.0, a, b)
+    assert p_all.shape == (T, H, n_s) and q_all.shape == (T, H, n_s, n_s)
+    assert bool(torch.isfinite(p_all).all()) and bool(torch.isfinite(q_all).all())
+    assert float((q_all - q_all.transpose(-1, -2)).abs().max()) <= 1e-14 * float(q_all.abs().max())
+    # positive definite everywhere: batched Cholesky of all 983040 shape matrices succeeds
+    _, info = torch.linalg.cholesky_ex(q_all.reshape(-1, n_s, n_s))
+    assert int(info.abs().max()) == 0
+    # the chain == repeated one-step calls, on every 128th rollout
+    idx = torch.arange(0, T, 128, device=dev)
+    sp, skff, skfb = tp0[idx], tkff[idx], tkfb[idx]
+    p, q = reach.onestep_reachability_batch(sp, gp, skff[:, 0], l, l, None, None, 2.0, a, b)
+    # (the 512-query calls take the split-K posterior kernels, the 65536-query chain the plain tiles: another order of
+    #  summation, compounded over the steps)
+    np.testing.assert_allclose(p.cpu().numpy(), p_all[idx, 0].cpu().numpy(), rtol=1e-9, atol=1e-12)
+    for i in range(1, H):
+        p, q = reach.onestep_reachability_batch(p, gp, skff[:, i], l, l, q, skfb[:, i - 1], 2.0, a, b)
+        np.testing.assert_allclose(p.cpu().numpy(), p_all[idx, i].cpu().numpy(), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(q.cpu().numpy(), q_all[idx, i].cpu().numpy(), rtol=1e-7, atol=1e-14)
+    # a tile-aligned slice on its own: bit-equal
+    sl = slice(128 * 100, 128 * 108)
+    ps, qs = reach.multistep_reachability_batch(tp0[sl], gp, tkfb[sl], tkff[sl], l, l, None, 2.0, a, b)
+    np.testing.assert_allclose(qs.cpu().numpy(), q_all[sl].cpu().numpy(), rtol=1e-9, atol=1e-15)
+    # oracle chain on three rollouts
+    om = cached_oracle_model(3, N, n_s, n_u, sf2=0.01)
+    pick = [0, 31337, T - 1]
+    rp, rq = orc.multistep_reachability_batch(om, roll["p0"][pick], roll["k_fb"][pick], roll["k_ff"][pick], l, l, None,
+                                              2.0, a, b)
+    ti = torch.tensor(pick, device=dev)
+    np.testing.assert_allclose(p_all[ti].cpu().numpy(), rp, rtol=1e-8, atol=max(mu_atol(om), 1e-11))
+    np.testing.assert_allclose(q_all[ti].cpu().numpy(), rq, rtol=1e-6, atol=1e-13)
+
+
+@pytest.mark.parametrize("adds", [[1], [16], [50], [128], [1, 16, 50, 128, 3]])
+def test_row_append_at_the_headline_model_size(adds):
+    """update_model(replace_old=False) at N = 5000 (where DESIGN quotes 0.40 / 0.73 / 1.2 / 2.25 ms): + 1, + 16, + 50, + 128
+    points and a sequence that crosses the 128-padding boundary, against a refit on all the data (posterior AND factor)
+    and the oracle's variance on the same data."""
+    N0 = 5000
+    ntot = N0 + sum(adds)
+    syn = orc.make_synthetic(50 + ntot, ntot, 2, 1, 256)
+    Z, Y = syn["Z"], syn["Y"]
+    gp = hip_model(Z[:N0], Y[:N0], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    lo = N0
+    for m in adds:
+        gp.update_model(Z[lo:lo + m], Y[lo:lo + m], opt_hyp=False, replace_old=False)
+        lo += m
+    assert gp._handle.N == ntot
+    full = hip_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    mu_a, var_a, jac_a = gp.predict(x, None, True)
+    mu_f, var_f, jac_f = full.predict(x, None, True)
+    scale = np.abs(full.beta).sum(0).max()
+    np.testing.assert_allclose(gp.beta, full.beta, rtol=1e-6, atol=1e-8 * np.abs(full.beta).max())
+    np.testing.assert_allclose(mu_a, mu_f, rtol=1e-8, atol=1e-10 * scale)
+    np.testing.assert_allclose(jac_a, jac_f, rtol=1e-8, atol=1e-9 * scale)
+    np.testing.assert_allclose(var_a, var_f, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gp.predict(x[:1])[1], var_f[:1], rtol=0, atol=1e-9)     # streaming single-query path
+    _, wt_a = gp.export_state()
+    _, wt_f = full.export_state()
+    assert wt_a.shape == wt_f.shape
+    den = float(wt_f.abs().max())
+    assert float((wt_a - wt_f).abs().max()) <= 1e-8 * den
+    assert float(torch_tril_abs_max(wt_a)) == 0.0
+    if len(adds) == 1:          # one oracle fit (N^3 on the CPU) per size is enough
+        om = oracle_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+        _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
+        np.testing.assert_allclose(var_a, rvar, rtol=0, atol=1e-9)
+
+
+def torch_tril_abs_max(w):
+    import torch
+    return torch.tril(w, -1).abs().max()
+
+
+def _bench_line(argv, timeout=1500):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, cwd=root, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, "bench.py %s failed:\n%s\n%s" % (argv, r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("argv,N,T,H,n_s", [
+    (["--workload", "c2"], 2000, 65536, 1, 2),
+    (["--workload", "c2p"], 5000, 65536, 1, 2),
+    (["--workload", "c3"], 5000, 65536, 15, 4),
+    (["--workload", "c5", "--queries", "196608"], 5000, 196608, 1, 2),
+])
+def test_bench_lines_are_self_consistent(argv, N, T, H, n_s):
+    """`bench.py --workload ...` with one timed step: the JSON line carries the contract's fields and its roofline is
+    arithmetic on what was measured -- achieved x avg_launch_ms == flops_per_launch, launches x flops_per_launch == the
+    algorithmic flops of the step (n_out N^2 T H), value == evals / time, dominant kernel <= step time."""
+    line = _bench_line(argv + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_kstar"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 1 and line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert line["config"]["N"] == N and line["config"]["queries_per_gpu_per_step"] == T and line["config"]["horizon"] == H
+    rf = line["roofline"]
+    assert rf["kernel"] == "sr_var_kernel" and rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s"
+    flops_step = float(n_s) * N * N * T * H
+    assert abs(rf["flops_per_launch"] * rf["launches"] - flops_step) <= 1e-9 * flops_step
+    assert abs(rf["achieved"] * 1e12 * rf["avg_launch_ms"] * 1e-3 - rf["flops_per_launch"]) <= 1e-6 * rf["flops_per_launch"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.5 < rf["frac"] < 1.0
+    assert abs(rf["frac_of_measured_ceiling"] - rf["achieved"] / rf["measured_ceiling"]) < 1e-12
+    assert rf["avg_launch_ms"] * rf["launches"] <= line["ms_per_step"] * 1.001
+    assert abs(line["value"] - T * H / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert abs(rf["hbm_gbps_achieved"] - rf["hbm_bytes_per_step_algorithmic"] / (line["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * rf["hbm_gbps_achieved"]
+    rk = line["roofline_kstar"]
+    assert rk["bound"] == "hbm-write" and 0.2 < rk["frac"] < 1.0
+    assert abs(rk["achieved"] * 1e9 * rk["avg_launch_ms"] * 1e-3 - rk["bytes_per_launch"]) <= 1e-6 * rk["bytes_per_launch"]
+
+
+def test_bench_model_update_line_is_self_consistent():
+    """`bench.py --workload c4 --n-train 5000`: value == (2/3) N^3 n_out / step time; per-kernel sums present."""
+    line = _bench_line(["--workload", "c4", "--n-train", "5000", "--steps", "3", "--warmup", "2"])
+    N, n_out = 5000, 2
+    flops = n_out * (2.0 / 3.0) * float(N) ** 3
+    assert abs(line["roofline"]["flops_per_step"] - flops) <= 1e-9 * flops
+    assert abs(line["value"] - flops / (line["ms_per_step"] * 1e-3) / 1e12) <= 1e-6 * line["value"]
+    assert line["unit"] == "TFLOP/s" and 0.2 < line["roofline"]["frac"] < 1.0
+    assert line["config"]["max|mu(z)+s2n*alpha-y|"] < 1e-7
+    assert set(line["kernel_ms_per_step"]) == {"sr_gram_kernel", "sr_potrf_diag_kernel", "sr_gemm_tn_kernel[cholesky]",
+                                               "sr_gemm_tn_kernel[inverse]"}
