@@ -143,7 +143,6 @@ def parse_args(argv=None):
     ap.add_argument("--n-train", type=int, default=0, help="override the number of training points")
     ap.add_argument("--var-group", type=int, default=0)
     ap.add_argument("--var-variant", type=int, default=-1)
-    ap.add_argument("--pipeline", type=int, default=0, help="column ranges of the K* / contraction pipeline (0: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-shards", default="", help="directory: every rank stores its query seed and the head of its "
                     "outputs of the last step there (shard_rank<r>.npz) -- for tests of the sharded path")
@@ -330,8 +329,6 @@ def run(args):
         gp.set_var_group(args.var_group)
     if args.var_variant >= 0:
         gp.set_var_variant(args.var_variant)
-    if args.pipeline:
-        gp.set_pipeline(args.pipeline)
 
     # ---- this rank's shard of the (world * T) query states, resident in HBM ------------------------
     q_seed = seed + 7919 + 104729 * rank
@@ -382,8 +379,8 @@ def run(args):
         fin_ms, fin_n = gp.prof_get(_lib.K_FINAL)
         # algorithmic flops of one sr_var_kernel launch: n_out * N^2 * T  (N^2/2 MACs per query and
         # output through the triangular factor) -- true N, not the padded one
-        # (a launch covers whatever share of the queries the library gave it -- one chunk of <= 65536, or a column
-        #  range of a chunk with --pipeline: the launches of the timed region together cover T * H * steps queries)
+        # (a launch covers whatever share of the queries the library gave it -- one chunk of <= 65536: the launches of
+        #  the timed region together cover T * H * steps queries)
         flops_launch = float(n_s) * N * N * T * H * args.steps / max(var_n, 1)
         avg_ms = var_ms / max(var_n, 1)
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -391,7 +388,7 @@ def run(args):
         # inside the run); the committed summary is quoted and its source named, never presented as live
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-        if os.path.exists(pmc) and not args.n_train and not args.queries and not args.pipeline:
+        if os.path.exists(pmc) and not args.n_train and not args.queries:
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get("sr_var_kernel_hbm_bytes_per_launch")

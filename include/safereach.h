@@ -29,7 +29,10 @@ typedef struct sr_gp* sr_gp_t;
 #define SR_EHIP       -2   /* HIP runtime error (no device, OOM, launch)  */
 #define SR_ENOTPD     -3   /* Cholesky breakdown: matrix not positive definite */
 #define SR_ESTATE     -4   /* call order violated (e.g. predict before factorize) */
-#define SR_EUNSUPPORTED -5 /* dimension outside compiled range (n_s<=8, n_u<=4, D<=12) */
+#define SR_EUNSUPPORTED -5 /* dimension outside compiled range (n_s<=8, n_u<=4, D<=12).  The reference's systems (n_s <= 4,
+                            * D <= 5) run in registers; n_s = 5..8 (ellipsoid step) and D = 9..12 (sr_gp_linearize) are
+                            * compiled but spill 124 .. 980 B per lane to scratch (profiles/r03_kernel_resources.txt):
+                            * correct, tested, and several times slower per query than the small instantiations */
 
 /* kernel ids for sr_prof_get() */
 #define SR_K_GRAM      0
@@ -79,7 +82,7 @@ int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
  * replaces: update_model(x, y, opt_hyp=False, replace_old=False)  ssm_gpy/gaussian_process.py:347-419
  * (the reference refactorises; its own row-append sketch is ssm_pytorch/utilities.py:74-117).
  * info [host, n_out] like sr_gp_factorize.  On success N grows by m and Np may grow.
- * m <= 16 takes matrix-vector shaped passes (U12 through the streaming prediction kernels; 0.9 ms at N = 5000), larger m
+ * m <= 16 takes matrix-vector shaped passes (U12 through the streaming prediction kernels; 0.40 ms for one point, 0.73 ms for 16 at N = 5000), larger m
  * the same algebra on 64 x 64 MFMA tiles; either way alpha is updated from the old model's mean at the new points and no
  * buffer of the factor's size is allocated while the padded size stays the same. */
 int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info);
@@ -258,9 +261,6 @@ int sr_gp_set_chain(sr_gp_t h, int on);
  * per-step launches from then on).  A caller that does not ask is told by the next reachability entry point, which
  * returns SR_ESTATE once. */
 int sr_gp_chain_status(sr_gp_t h, int* timed_out);
-/* big batches on the plain MFMA path (>= 8192 queries per range): the K* pass of column ranges 1 .. nsub-1 runs on a side
- * stream beside the contraction of the ranges before them; nsub = 1 switches it off.  Results are identical bit for bit. */
-int sr_gp_set_pipeline(sr_gp_t h, int nsub);
 /* The model update keeps its scratch (two Np x Np matrices per output in flight) with the handle while that is at most a
  * third of the device's memory, so that refits allocate nothing (40 GB at N = 50000); the row append keeps a strip and
  * the previous U^-1 buffer.  A host that will only evaluate the model from here on hands them back with this call. */

@@ -34,8 +34,6 @@ struct sr_gp {
     int chain_occ_key = -1, chain_occ_blocks = 0;                         // occupancy of the kernel last asked about
     int chain_test_drop = 0;                                              // sr_test_chain_drop
     unsigned* call_ticket = nullptr;        // sr_gp_call1: workgroups done (reset by the last one)
-    // big batches: the K* pass of the later sub-chunks runs on aux_stream beside the contraction of the earlier ones
-    int pipe_sub = 1; hipStream_t aux_stream = nullptr; hipEvent_t ev_pipe_fork = nullptr; hipEvent_t ev_pipe_k[8] = {};
     int general = 0;
     int have_data = 0, factorized = 0;
     int import_open = 0;     // between sr_gp_import_begin and sr_gp_import_end
@@ -166,9 +164,6 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->chain_done); dev_free(h->call_ticket);
     if (h->chain_status_host) (void)hipHostFree(h->chain_status_host);
     dev_free(h->yT_alt); dev_free(h->alpha_alt);
-    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
-    if (h->ev_pipe_fork) (void)hipEventDestroy(h->ev_pipe_fork);
-    for (hipEvent_t e : h->ev_pipe_k) if (e) (void)hipEventDestroy(e);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
     for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream}) if (st) (void)hipStreamDestroy(st);
@@ -1024,54 +1019,10 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
     const bool small_var = h->small_path && ((Tc <= SR_SMALL_T && (h->Np > SR_STREAM_MIN_NP || h->force_stream)) ||
                                              (h->small_path == 1 && h->Np > SR_STREAM_MIN_NP &&
                                               Tc <= (long)SR_SMALL_T * sr_var_small_groups_max(h->Np, h->n_out)));
-    const bool plain_var = !small_var && !(h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) &&
-                           !(h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out));
-    // Big batch on the plain MFMA path: the K* pass is bound by its HBM writes (n_out Np Tp 8 B: 5.4 GB, 1.3 ms at
-    // C2'), the contraction by the MFMA pipe.  In pipe_sub column ranges the K* pass of ranges 1.. runs on a side
-    // stream beside the contraction of range 0; only the first range's K* pass stays exposed.
-    const int nsub = (plain_var && h->pipe_sub > 1 && Tp >= (long)h->pipe_sub * 8192) ? std::min(h->pipe_sub, 8) : 1;
-    if (nsub > 1) {
-        if (!h->aux_stream) {
-            SR_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-            SR_HIP(hipEventCreateWithFlags(&h->ev_pipe_fork, hipEventDisableTiming));
-            for (hipEvent_t& e : h->ev_pipe_k) SR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-        const long W = round_up((Tp + nsub - 1) / nsub, 256);      // columns per range (K* blocks hold 256 queries)
-        SR_HIP(hipEventRecord(h->ev_pipe_fork, s));                 // inputs ready, workspace free
-        SR_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_pipe_fork, 0));
-        h->last_streamed = 0;
-        for (int i = 0; i < nsub; ++i) {
-            const long c0 = (long)i * W;
-            if (c0 >= Tp) break;
-            const long w = std::min(W, Tp - c0);
-            sr_kstar_args kr = ka;
-            kr.xa = xa + c0 * lda; kr.xb = xb ? xb + c0 * ldb : nullptr;
-            kr.Ks = h->Ks + c0; kr.mu_part = h->mu_part + c0; kr.jac_part = h->jac_part + c0;
-            kr.kxx = h->kxx ? h->kxx + c0 : nullptr;
-            kr.T = std::max(0L, std::min(Tc - c0, w)); kr.Tw = w;
-            hipStream_t sk = (i == 0) ? s : h->aux_stream;
-            {
-                sr_prof_scope ps(&h->prof, SR_K_KSTAR, sk);
-                SR_TRY(sr_launch_kstar(kr, sk));
-            }
-            if (i > 0) SR_HIP(hipEventRecord(h->ev_pipe_k[i], h->aux_stream));
-        }
-        for (int i = 0; i < nsub; ++i) {
-            const long c0 = (long)i * W;
-            if (c0 >= Tp) break;
-            const long w = std::min(W, Tp - c0);
-            if (i > 0) SR_HIP(hipStreamWaitEvent(s, h->ev_pipe_k[i], 0));
-            sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-            SR_TRY(sr_launch_var(h->Wt, h->Ks + c0, h->var_part + c0, h->N, h->Np, Tp, h->n_out, h->var_group,
-                                 h->var_variant, s, w));
-        }
-        sr_final_args fp;
-        fp.mu_part = h->mu_part; fp.jac_part = h->jac_part; fp.var_part = h->var_part; fp.sf2 = h->sf2;
-        fp.ls = h->ls; fp.kxx = h->general ? h->kxx : nullptr; fp.mu = mu; fp.var = var; fp.jac = jac;
-        fp.n_out = h->n_out; fp.D = h->D; fp.nsplit = nsplit; fp.nrb = h->Np / SR_NB; fp.T = Tc; fp.Tp = Tp;
-        sr_prof_scope ps(&h->prof, SR_K_FINAL, s);
-        return sr_launch_finalize(fp, s);
-    }
+    // (Round 2 could run the K* pass of later column ranges of a big batch on a side stream beside the contraction of the
+    //  earlier ones -- the K* pass is bound by its HBM writes, the contraction by the MFMA pipe.  Measured again in round 3,
+    //  interleaved on one box, six runs each: 1.3672 +- 0.0012 M evals/s without, 1.3585 +- 0.0011 with 4 ranges: the
+    //  contraction's launches stretch by more than the 1.3 ms the overlap hides.  Removed.)
     {
         sr_prof_scope ps(&h->prof, SR_K_KSTAR, s);
         SR_TRY(sr_launch_kstar(ka, s));
@@ -1694,12 +1645,6 @@ extern "C" int sr_gp_release_scratch(sr_gp_t h) {
     dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1;
     dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
     dev_free(h->yT_alt); dev_free(h->alpha_alt); h->yT_alt = h->alpha_alt = nullptr; h->vec_alt_np = 0;
-    return SR_OK;
-}
-
-extern "C" int sr_gp_set_pipeline(sr_gp_t h, int nsub) {
-    SR_CHECK(h != nullptr && nsub >= 1 && nsub <= 8, SR_EINVAL, "sr_gp_set_pipeline: nsub=%d outside 1..8", nsub);
-    h->pipe_sub = nsub;
     return SR_OK;
 }
 

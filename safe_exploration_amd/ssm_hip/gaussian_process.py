@@ -450,7 +450,7 @@ class SimpleGPModel(StateSpaceModel):
             raise ValueError("x must be (n, n_s_in+n_u) and y (n, n_s_out)")
         hd = self._handle
         s = B.stream_ptr(hd.device)
-        # <= 16 rows per call take the matrix-vector shaped path of sr_gp_append (0.9-1.3 ms at N = 5000), more rows
+        # <= 16 rows per call take the matrix-vector shaped path of sr_gp_append (0.40-0.73 ms at N = 5000), more rows
         # go 128 at a time through its MFMA path
         step = 16 if x.shape[0] <= 16 else 128
         for lo in range(0, x.shape[0], step):
@@ -903,11 +903,6 @@ class SimpleGPModel(StateSpaceModel):
         """free what the model update / row append keep for their next call (two Np x Np matrices per output)"""
         self._need_trained()
         check(lib.sr_gp_release_scratch(self._handle.h))
-
-    def set_pipeline(self, nsub):
-        """column ranges of a big batch whose K* passes overlap with the contraction of the ranges before (1 = off)"""
-        self._need_trained()
-        check(lib.sr_gp_set_pipeline(self._handle.h, int(nsub)))
 
     def set_chain(self, on):
         """multi-step chains of small models inside one persistent launch (default) or step by step"""

@@ -1599,40 +1599,3 @@ def test_single_query_mailbox_and_fallback_agree():
     from safe_exploration_amd._lib import lib
     from safe_exploration_amd import _buffers as B
     assert lib.sr_wait_flag(B.ptr(io["h_flag"]), io["seq"] + 12345, 0.05) != 0
-
-
-@pytest.mark.parametrize("kern,T", [("rbf", 65536), ("rbf", 40001), ("mat52", 33000)])
-def test_kstar_contraction_pipeline_is_bitwise_invisible(kern, T):
-    """Big batches run the K* pass of the later column ranges on a side stream beside the contraction of the earlier
-    ones: same kernels on the same data, so every output must agree to the bit with the unpipelined pass -- also when
-    the ranges are ragged, for the general kernel family, and call after call (the ranges share one workspace)."""
-    from safe_exploration_amd import gp_reachability as reach
-    n_s, n_u, N = 2, 1, 700
-    syn = orc.make_synthetic(77, N, n_s, n_u, T)
-    if kern == "rbf":
-        gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
-    else:
-        from safe_exploration_amd import SimpleGPModel
-        hyp = [{"lengthscale": syn["lengthscale"][i], "variance": syn["signal_var"][i],
-                "noise_variance": syn["noise_var"][i]} for i in range(n_s)]
-        gp = SimpleGPModel(n_s, n_s, n_u, kern_types=[kern] * n_s, hyp=hyp)
-        gp.train(syn["Z"], syn["Y"], opt_hyp=False)
-    x = np.hstack((syn["p"], syn["k_ff"]))
-    gp.set_pipeline(1)
-    ref = gp.predict(x, None, True)
-    l = np.array([0.05, 0.02])
-    ref_r = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0)
-    for nsub in (2, 4, 3, 8):
-        gp.set_pipeline(nsub)
-        for _ in range(2):
-            got = gp.predict(x, None, True)
-            for a, b in zip(ref, got):
-                np.testing.assert_array_equal(a, b)
-        got_r = reach.onestep_reachability_batch(syn["p"], gp, syn["k_ff"], l, l, syn["Q"], syn["k_fb"], 2.0)
-        for a, b in zip(ref_r, got_r):
-            np.testing.assert_array_equal(a, b)
-    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"]) if kern == "rbf" else None
-    if om is not None:
-        idx = np.random.default_rng(0).choice(T, 2000, replace=False)
-        _, rvar = orc.gp_predict(x[idx], om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
-        np.testing.assert_allclose(got[1][idx], rvar, rtol=0, atol=1e-9)
