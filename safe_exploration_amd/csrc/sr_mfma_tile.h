@@ -247,6 +247,16 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
 #undef SRT_DMA
 }
 
+// Round 3, measured and NOT kept (scripts/mfma_lds_tile.hip, profiles/r03_mfma_lds_tile.txt): where the 9 % between this
+// loop (70.5 TF inside sr_var_kernel) and the matrix pipe (77.5 TF) go.  An LDS-fed loop of the same fragment reads and
+// MFMAs runs at 77.0 - 77.7 TF for EVERY wavefront tile from 32 x 32 to 96 x 64 at two wavefronts per SIMD: the LDS -> VGPR
+// traffic costs nothing, so a 96 x 64 wavefront tile has nothing to win (and its 41 KB stages would leave one workgroup per
+// CU: 58 TF).  A barrier per k-tile: 77.0.  The LDS-DMA of the next k-tile, no barrier: 74.5 (-3.5 %); DMA + barrier:
+// 72.0 (-3 % more), the same with one, two or three k-tiles in flight (s_waitcnt vmcnt(0 / 8 / 16)) -- it is not the DMA's
+// latency.  72.0 is what this skeleton can reach; the kernel is at 0.98 of it (the rest: structural zeros of the
+// diagonal blocks, prologue, epilogue).  Two rewrites of the loop confirmed it: four stages of 8 k-rows with three tiles
+// in flight (equal), and the barrier moved to the middle of a tile with the next tile's first fragments read across the
+// tile boundary (66.5 TF: twice the barriers, and hipcc hoists the barrier back to the top of the tile).
 }  // namespace srt
 
 // ------------------------------------------------------------------------------------------------
