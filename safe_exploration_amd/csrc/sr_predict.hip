@@ -513,6 +513,172 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2b: the same regime as K2k (few query tiles), BALANCED ("stream-K") and in ONE launch.  The work of the launch is the
+// list of k-blocks (128 k-rows of one 128 x 128 output tile), tiles ordered (output, query tile, row block DEScending:
+// heavy tiles first), blocks ascending inside a tile; workgroup g of G takes the contiguous share [g U / G, (g + 1) U / G)
+// of its U entries -- the same number of MFMAs for everybody, whatever the triangular k range of a tile (K2k cuts every
+// tile into chunks of 1 / 2 / 4 / 8 blocks: at N = 5000, T = 128 that is 440 workgroups of up to 4 blocks on 512 slots,
+// CUs with two of them take twice as long as CUs with one).  A share covers at most two partial tiles (its first and its
+// last) plus whole tiles in between.  A partial product goes to the workgroup's slot (accumulator layout, coalesced);
+// a ticket per tile elects the LAST arriver, which adds the tile's segments in ascending k order (its own from
+// registers: the sum does not depend on who is last), squares, reduces over the rows -- no second pass, no second launch.
+// Hand-off protocol of sr_stream.hip: agent-scope stores, s_waitcnt vmcnt(0), barrier, relaxed agent atomic; nobody waits
+// for anybody, so the workgroups need not be co-resident.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long sr_sk_bound(long g, long U, long G) { return (g * U) / G; }
+__device__ __forceinline__ long sr_sk_owner(long u, long U, long G) {        // the g with bound(g) <= u < bound(g + 1)
+    long g = (u * G) / U;
+    while (g + 1 <= G && sr_sk_bound(g + 1, U, G) <= u) ++g;
+    while (g > 0 && sr_sk_bound(g, U, G) > u) --g;
+    return g;
+}
+
+__global__ __launch_bounds__(256, 2) void sr_var_streamk_kernel(const double* __restrict__ Wt,
+                                                                const double* __restrict__ Ks,
+                                                                double* Vt, unsigned* tickets,
+                                                                double* __restrict__ part, int Np, long Tp,
+                                                                int nrb, int ntq, int k_beg, long U) {
+    __shared__ double smem[srt::SMEM_DOUBLES];
+    __shared__ int s_flag;
+    const long G = gridDim.x, g = blockIdx.x;
+    const long S = (long)nrb * (nrb + 1) / 2;                 // blocks of one (output, query tile)
+    long u = sr_sk_bound(g, U, G);
+    const long u1 = sr_sk_bound(g + 1, U, G);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    while (u < u1) {
+        // tile of entry u: (d, x) = u / S; inside: descending row blocks, tile j (rb = nrb - 1 - j) holds nrb - j blocks
+        const long dx = u / S;
+        const long r = u - dx * S;
+        int j = 0;
+        long c = 0;                                            // first entry of tile j
+        while (c + (nrb - j) <= r) { c += nrb - j; ++j; }
+        const int rb = nrb - 1 - j, n = nrb - j;
+        const int o = (int)(r - c);                            // first k-block of this segment
+        const int len = (int)((n - o < u1 - u) ? n - o : u1 - u);
+        const int d = (int)(dx / ntq), x = (int)(dx % ntq);
+        const int k0 = (o == 0) ? k_beg : o * srt::BM;
+        const int k1 = (o + len) * srt::BM;
+        const double* A = Wt + (long)d * Np * Np + (long)rb * srt::BM;
+        const double* B = Ks + (long)d * Np * Tp + (long)x * srt::BN;
+        srt::Acc acc;
+        acc.zero();
+        srt::mainloop_tn_glds<16>(A, Np, B, Tp, k0, k1, smem, acc);
+        bool finish = (len == n);                              // the whole tile was ours
+        if (!finish) {
+            const long t0 = dx * S + c;                        // the tile's first entry
+            const long g_first = sr_sk_owner(t0, U, G), g_last = sr_sk_owner(t0 + n - 1, U, G);
+            const int nseg = (int)(g_last - g_first + 1), mine = (int)(g - g_first);
+            // slot of segment sg of a tile: its workgroup's slot 1 if the tile starts in that workgroup's share, else 0
+            double* slot = Vt + ((g * 2) + (mine == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sr_st_agent(slot + ((mi * 4 + ni) * 4 + q) * 256 + tid, acc.v[mi][ni][q]);
+            unsigned* tk = tickets + (dx * nrb + rb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = (old == (unsigned)nseg - 1u);
+                if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_flag = last;
+            }
+            __syncthreads();
+            if (s_flag) {
+                // segments in ascending k order; ours comes from the registers.  One row of MFMA tiles (16 values per lane)
+                // at a time, the loads of a segment issued together (with the segment loop innermost every one of the
+                // 64 x nseg loads waited for its own L2 round trip: 430 us at N = 5000, T = 128)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    double v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = 0.0;
+                    for (int sg = 0; sg < nseg; ++sg) {
+                        if (sg == mine) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] += acc.v[mi][e >> 2][e & 3];
+                        } else {
+                            const double* src = Vt + (((g_first + sg) * 2) + (sg == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN) +
+                                                (long)(mi * 16) * 256 + tid;
+                            double w[16];
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) w[e] = sr_ld<true>(src + e * 256);
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] += w[e];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc.v[mi][e >> 2][e & 3] = v[e];
+                }
+                finish = true;
+            }
+            __syncthreads();                                   // s_flag and smem are reused
+        }
+        if (finish) {
+            double sq[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                double v = 0.0;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v = fma(acc.v[mi][ni][q], acc.v[mi][ni][q], v);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                sq[ni] = v;
+            }
+            double* red = smem;
+            if (lane < 16) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) red[wm * 128 + wn * 64 + ni * 16 + lane] = sq[ni];
+            }
+            __syncthreads();
+            if (tid < 128) part[((long)d * nrb + rb) * Tp + (long)x * srt::BN + tid] = red[tid] + red[128 + tid];
+            __syncthreads();
+        }
+        u += len;
+    }
+}
+
+// workgroups of the launch: two per CU of a 256-CU part (fewer when there is less work)
+// workgroups of the launch: two per CU once there are four blocks for each of them, one per CU below (fewer segments per
+// tile: the last arriver of a tile reads every other segment, 128 KB each, in batches that each wait for an L2 round trip)
+static long streamk_wgs(long U) {
+    const long g = U >= 2048 ? 512 : 256;
+    return g < U ? g : U;
+}
+
+// Measured against the two-launch split-K form (predict wall time in us, n_out = 2; profiles/r03_streamk.txt):
+//   N = 2000: T = 256 106 -> 98, 512 157 -> 131, 1024 239 -> 204;   N = 3000: T = 256 160 -> 134, 512 276 -> 210, 1024 480 -> 365;
+//   N = 5000: T = 512 533 -> 485, 1024 996 -> 907;  but T = 128 168 -> 192 and T = 256 287 -> 297 there: with 40 row blocks
+//   and one or two query tiles the heavy tiles are cut into a dozen segments and their reduction is the tail of the launch.
+bool sr_var_streamk_wanted(int Np, long Tp, int n_out) {
+    const long nrb = Np / srt::BM;
+    const long U = (long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2;
+    return U >= 512 && (nrb <= 28 || U >= 5000);
+}
+
+long sr_var_streamk_ws(int Np, long Tp, int n_out) {
+    const long nrb = Np / srt::BM;
+    return streamk_wgs((long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2) * 2 * (long)(srt::BM * srt::BN);
+}
+long sr_var_streamk_tickets(int Np, long Tp, int n_out) { return (long)n_out * (Tp / srt::BN) * (Np / srt::BM); }
+
+int sr_launch_var_streamk(const double* Wt, const double* Ks, double* Vt, unsigned* tickets, double* part, int N, int Np,
+                          long Tp, int n_out, hipStream_t s) {
+    const int k_beg = ((Np - N) / srt::BK) * srt::BK;
+    const int nrb = Np / srt::BM, ntq = (int)(Tp / srt::BN);
+    const long U = (long)n_out * ntq * nrb * (nrb + 1) / 2;
+    hipLaunchKernelGGL(sr_var_streamk_kernel, dim3((unsigned)streamk_wgs(U)), dim3(256), 0, s, Wt, Ks, Vt, tickets, part, Np,
+                       Tp, nrb, ntq, k_beg, U);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2s: small-batch variance (T <= SR_TS queries, the CasADi/IPOPT callback regime).  With one query
 // tile the MFMA kernel is serialised on its longest row block; here U^-1 is streamed exactly once at
 // HBM rate instead: thread = one column i of Wt, workgroup = 256 columns x 128 k-rows, K* rows
