@@ -331,7 +331,9 @@ static int pick_fact_panel(const sr_gp* h) {
     // 2.34 / 2.41 / 2.52 ms; N = 5000 5.26 / 5.15 / 5.15 / 5.29 / 5.64; N = 7000 11.0 / 10.5 / 10.2 / 10.3 / 10.5; N = 10000
     // 28.3 / 26.7 / 25.8 / 25.5 / 25.0; N = 20000 (4 / 8 / 12 / 16) 186.8 / 184.3 / 187.4 / 188.6; N = 30000 592 / 578 / 575 /
     // 574; N = 50000 (8 / 12 / 16 / 24) 2.599 / 2.580 / 2.570 / 2.555 s
-    return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 16 : 24))));
+    // with the in-panel updates of long K on 128-tiles (sr_use_tile64): N = 30000 panels of 12 / 16 / 24 / 32: 565 / 562 / 561 / 562 ms;
+    // N = 50000 panels of 24 / 32 / 48: 2.521 / 2.514 / 2.508 s
+    return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 24 : 48))));
 }
 
 // Streams of the factorisation.  The chain of diagonal blocks is latency-bound and must never queue behind the

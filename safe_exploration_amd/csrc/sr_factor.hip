@@ -4,6 +4,7 @@
 // replaces (numerically) what GPy computes for SimpleGPModel.train / update_model:
 //   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:238-275, 398-419
 #include "sr_mfma_tile.h"
+static int sr_env_int(const char* name, int dflt);
 
 // ------------------------------------------------------------------------------------------------
 // TN GEMMs on the fp64 matrix cores, on either workgroup tile of sr_mfma_tile.h
@@ -91,11 +92,19 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_kernel(
 // One fp64 MFMA holds its SIMD for 64 cycles: a 128 x 128 tile with K = 128 is 14 us of one CU, whatever else
 // happens.  Products of few tiles are therefore latency-bound (the block row and the look-ahead row of the
 // Cholesky sit on its critical path) or balance-bound (triangular k ranges); they take the 64 x 64 tile.
-static inline bool sr_use_tile64(long tiles128) { return tiles128 < 1024; }
+static inline bool sr_use_tile64(long tiles128, int K = 0) {
+    // ... unless K is long: then a grid that occupies the chip at least once is throughput-bound and the 64-tile's 8 flop
+    // per operand byte is the limit (the in-panel updates of the N = 50000 factorisation -- 128 rows x 50000 columns, K up
+    // to 2944: 21 TF on 64-tiles)
+    static const int klong = sr_env_int("SR_T64_KLONG", 768);
+    if (K >= klong && tiles128 >= 256) return false;
+    return tiles128 < 1024;
+}
 // ... but a 64 x 64 tile moves 8 bytes of operands per 8 flop (K-independent): a grid of them that fills the chip is
 // bound by L2 / fabric bandwidth (N = 5000, K = 256 bulk update of two outputs: 1.7 GB in 254 us = 6.8 TB/s, 21 TF per
 // output).  THROUGHPUT-bound products (bulk trailing update, the big levels of the inversion) therefore take the
 // 128-tile (16 flop per byte) as soon as there are enough of them to occupy the chip once.
+static int sr_env_int(const char* name, int dflt);
 static int sr_env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -115,7 +124,7 @@ int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, doub
     SR_CHECK(M % srt::BM == 0 && N % srt::BN == 0 && K % srt::BK == 0 && M > 0 && N > 0, SR_EINVAL,
              "gemm_tn: M=%d N=%d K=%d must be tile multiples", M, N, K);
     const sr_batch bt = btp ? *btp : sr_batch{};
-    if (sr_use_tile64((long)(M / 128) * (N / 128) * bt.n))
+    if (sr_use_tile64((long)(M / 128) * (N / 128) * bt.n, K))
         hipLaunchKernelGGL(sr_gemm_tn_kernel<sr_tile64>, dim3(N / 64, M / 64, bt.n), dim3(256), 0, s, A, lda, B, ldb, C, ldc,
                            K, alpha, beta, mode, prio, bt);
     else
@@ -230,7 +239,7 @@ int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb
              "gemm_tn_upper: M=%d N=%d K=%d", M, N, K);
     const long tm128 = M / 128, tn128 = N / 128;
     const long tiles128 = (tm128 * tn128 - tm128 * (tm128 - 1) / 2) * bt.n;
-    const bool t64 = prio ? sr_use_tile64(tiles128) : sr_use_tile64_bulk(tiles128);
+    const bool t64 = prio ? sr_use_tile64(tiles128, K) : sr_use_tile64_bulk(tiles128);
     const long tm = t64 ? M / 64 : tm128, tn = t64 ? N / 64 : tn128;
     static const int order1_from = sr_env_int("SR_ORDER1_FROM", 4096);
     if (order < 0) order = tiles128 >= order1_from ? 1 : 0;     // super-tiles pay once the grid is many times the chip
