@@ -90,6 +90,13 @@ def _evaluator_class(cas):
                 raise ValueError("Need to specify either has_jacobian or has_reverse")
             self.ssm = ssm
             self.linearize_mu = linearize_mu
+            # Row order of the d jac_mean/dz block of the stacked Jacobian.  "C" (default) is the reference's own
+            # convention, utils.reshape_derivatives_3d_to_2d (utils.py:357-380): row i*D + j <-> jac_mean[i, j].
+            # CasADi numbers the nonzeros of a dense output column by column, so an NLP whose objective depends
+            # on jac_mean through this Jacobian (rather than through get_reverse, whose seed arrives as a matrix
+            # and is unaffected) may want "F": row j*n + i <-> jac_mean[i, j].  The reference's only test of the
+            # block sums over it (test_state_space_models.py:103-139) and cannot tell the two apart.
+            self.jac_mu_order = "C"
             self.construct("CasadiModelEvaluator", opts)
 
         def get_n_in(self):
@@ -118,7 +125,9 @@ def _evaluator_class(cas):
             n, D = self.ssm.num_states, self.ssm.num_states + self.ssm.num_actions
             if self.linearize_mu:
                 _, _, jac_mu, jac_sigma, hess_mu = self.ssm.linearize_predict(state.T, action.T, True, False)
-                # (n, D, D) -> (n D, D): row i*D + j holds d jac_mu[i, j] / dz (utils.py:357-380)
+                # (n, D, D) -> (n D, D): row i*D + j holds d jac_mu[i, j] / dz (utils.py:357-380); see jac_mu_order
+                if self.jac_mu_order == "F":
+                    hess_mu = np.transpose(np.reshape(hess_mu, (n, D, D)), (1, 0, 2))
                 return [np.vstack((jac_mu, jac_sigma, np.reshape(hess_mu, (n * D, D))))]
             _, _, jac_mu, jac_sigma = self.ssm.predict(state.T, action.T, True, False)
             return [np.vstack((np.reshape(jac_mu, (n, D)), np.reshape(jac_sigma, (n, D))))]

@@ -236,6 +236,13 @@ def test_casadi_evaluator_callbacks_on_the_hip_model(kt, N, n_s, n_u, monkeypatc
     g = np.concatenate((s_mu.ravel(), s_var.ravel(), s_jac.ravel())).dot(stacked)
     np.testing.assert_allclose(adj_x[:, 0], g[:n_s], rtol=1e-12, atol=1e-13 * np.abs(g).max())
     np.testing.assert_allclose(adj_u[:, 0], g[n_s:], rtol=1e-12, atol=1e-13 * np.abs(g).max())
+    # column-major numbering of the jac_mean block (CasADi's own vec of a dense output): a row permutation only
+    ev.jac_mu_order = "F"
+    (stacked_f,) = (np.array(o) for o in jfun(x, u, mu, var, jac))
+    ev.jac_mu_order = "C"
+    perm = np.arange(n_s * D).reshape(n_s, D).T.reshape(-1)
+    np.testing.assert_array_equal(stacked_f[:2 * n_s], stacked[:2 * n_s])
+    np.testing.assert_array_equal(stacked_f[2 * n_s:], stacked[2 * n_s:][perm])
     # not linearised: two outputs, (2n) x D Jacobian from predict(states, actions, jacobians=True)
     ev2 = gp.get_forward_model_casadi(False)
     m2, v2 = (np.array(o) for o in ev2(x, u))
