@@ -28,7 +28,7 @@ struct sr_gp {
     double *tz_x = nullptr, *tz_jac = nullptr; long tz_cap = 0;   // transformed inputs / chain-ruled Jacobians (per chunk)
     // persistent multi-step kernel (sr_small.hip K0c): exchange buffer, per group ticket + epoch + done counter (all of
     // the hand-off state lives on the device), switch
-    double* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // tickets, then epochs
+    sr_xel* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // the groups' epochs
     unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0; int chain_cap = -1;
     int* chain_status_host = nullptr; int* chain_status_dev = nullptr;   // pinned: set by a chain launch that timed out
     int chain_occ_key = -1, chain_occ_blocks = 0;                         // occupancy of the kernel last asked about
@@ -1312,10 +1312,9 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
     *taken = false;
     const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
     // small model, few rollouts: the whole chain in one launch (sr_small.hip K0c).  One launch holds SR_CHAIN_GROUPS
-    // workgroups = gmax groups of 16 rollouts; a second launch costs as much again, which only pays where the per-step
-    // route has left its one-launch posterior (T > SR_FUSED_T).  Measured at N = 200, H = 15: 256 rollouts 241 -> 148 us,
-    // 1024 rollouts (two launches) 292 against 247 us per step, 1920 rollouts (two launches) 304 against 544 us.
-    const int parts = h->Np / 128;                                      // workgroups sharing one (group, output)
+    // workgroups = gmax groups of 16 rollouts (n_s Np / 128 posterior workgroups + the tail workgroup each): 768 rollouts
+    // of a pendulum model with N <= 256, 416 of a cart-pole model.  Measured at N = 200, H = 15: 256 rollouts 246
+    // (per-step launches) -> 102 us.
     // every workgroup of a launch must be resident (one per CU): leave 16 CUs of whatever this device (or partition of
     // a device) has to other work
     if (h->chain_cap < 0) {
@@ -1323,7 +1322,8 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 0;
         h->chain_cap = std::max(0, std::min(SR_CHAIN_GROUPS, cus - 16));
     }
-    if (h->chain_cap < n_s * std::max(parts, 1)) return SR_OK;          // not even one group fits: per-step launches
+    const int wpg = sr_chain_wgs_per_group(h->Np, n_s);                 // posterior workgroups + the tail workgroup
+    if (h->chain_cap < wpg) return SR_OK;                               // not even one group fits: per-step launches
     // A chain launch whose hand-off timed out (SR_CHAIN_TIMEOUT_TICKS: its workgroups were not co-resident in time) has
     // poisoned its outputs with NaN and raised the pinned status word.  The first entry after that reports it -- a
     // caller that never looked at the outputs must not go on with them -- and the handle takes the per-step launches
@@ -1335,10 +1335,16 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
                      "100 ms); its outputs were filled with NaN.  The handle now uses per-step launches; repeat the call.");
         return SR_ESTATE;
     }
-    const int gmax = std::max(1, h->chain_cap / (n_s * std::max(parts, 1)));      // groups of 16 rollouts per launch
+    const long xpg = std::max(1l, sr_chain_xels_per_group(h->Np, n_s, n_u, H));
+    const int gmax = (int)std::max(1l, std::min((long)(h->chain_cap / wpg), (long)SR_CHAIN_XELS / xpg));   // groups of 16 rollouts per launch
     const long chain_launches = ((T + SR_SMALL_T - 1) / SR_SMALL_T + gmax - 1) / gmax;
+    // Several launches in a row still beat the per-step route (N = 200, H = 15: 1024 rollouts 203 against 253 us, 4096
+    // rollouts in six launches 608 against 722 us; cart-pole N = 150: 832 rollouts 304 against 411 us) -- except where
+    // the per-step route still has its one-launch posterior (T <= SR_FUSED_T) and three launches are needed (cart-pole,
+    // 960 rollouts: 454 against 413 us).
+    const long chain_max_launches = T > SR_FUSED_T ? 6 : 2;
     if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 &&
-        (chain_launches == 1 || (chain_launches == 2 && T > SR_FUSED_T)) &&
+        chain_launches <= chain_max_launches &&
         sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
         // the kernel must be able to run at all: at least one workgroup per CU (registers, static + dynamic LDS)
         const int occ_key = ((h->Np * 8 + n_s) * 8 + n_u) * 64 + std::min(H, 63);
@@ -1353,9 +1359,10 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
             *h->chain_status_host = 0;
             SR_HIP(hipHostGetDevicePointer((void**)&h->chain_status_dev, h->chain_status_host, 0));
             // (first use only: a blocking memset -- not inside a stream capture)
-            SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_GROUPS * 2 * SR_SMALL_T * (SR_MAX_D + 2)));
+            SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_XELS));
             SR_TRY(dev_alloc(&h->chain_tickets, (size_t)2 * SR_CHAIN_GROUPS));
             SR_TRY(dev_alloc(&h->chain_done, (size_t)SR_CHAIN_GROUPS));
+            SR_HIP(hipMemset(h->chain_xch, 0, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS));     // tag 0 = never written
             SR_HIP(hipMemset(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
             SR_HIP(hipMemset(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS));
         }
@@ -1372,8 +1379,8 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
             ca.a = a; ca.b = b; ca.l_mu = l_mu; ca.l_sigma = l_sigma; ca.c_safety = c_safety;
             ca.p_all = p_all + t0 * H * n_s; ca.q_all = q_all + t0 * H * nss;
             ca.gp_var_all = gp_var_all ? gp_var_all + t0 * H * n_s : nullptr;
-            ca.n_bad = n_bad; ca.xch = h->chain_xch; ca.tickets = h->chain_tickets;
-            ca.epoch = h->chain_tickets + SR_CHAIN_GROUPS; ca.done = h->chain_done;
+            ca.n_bad = n_bad; ca.xch = h->chain_xch;
+            ca.epoch = h->chain_tickets; ca.alive = h->chain_tickets + SR_CHAIN_GROUPS; ca.done = h->chain_done;
             ca.status = h->chain_status_dev;
             ca.test_drop = h->chain_test_drop;
             SR_TRY(sr_launch_chain(ca, s));
@@ -1737,6 +1744,7 @@ extern "C" int sr_test_chain_drop(sr_gp_t h, int drop) {
         // (in the field every workgroup runs, however late, and the last one to leave resynchronises the group)
         SR_DEVICE(h->device);
         SR_HIP(hipDeviceSynchronize());
+        SR_HIP(hipMemset(h->chain_xch, 0, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS));
         SR_HIP(hipMemset(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
         SR_HIP(hipMemset(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS));
     }

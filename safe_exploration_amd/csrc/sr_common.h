@@ -198,6 +198,7 @@ int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu,
 
 // Persistent multi-step kernel (sr_small.hip): the whole H-step chain of up to SR_CHAIN_GROUPS / (n_out Np / 128) * 16
 // rollouts in ONE launch (the posterior of sr_gp_small_kernel and the step of sr_ellipsoid_kernel inside a loop over the steps).
+struct sr_xel { double v; unsigned long long chk; };      // 16 bytes, written and read by single instructions; chk = bits(v) ^ mix(tag)
 struct sr_chain_args {
     sr_kstar_args k;                  // model (Z, alpha, ls, sf2, N, Np, D, n_out, na = n_s, nb = n_u); queries unused
     const double* Wt;
@@ -207,11 +208,12 @@ struct sr_chain_args {
     const double* a; const double* b; const double* l_mu; const double* l_sigma; double c_safety;
     double* p_all; double* q_all; double* gp_var_all;             // T x H x n_s, T x H x n_s^2, T x H x n_s | NULL
     int* n_bad;
-    double* xch;                      // groups x 2 x n_out x parts x 16 x (D + 2): per-step results handed between
-                                      // the n_out x Np / 128 workgroups of a group of 16 rollouts
-    // per group: arrivals so far (monotonic), the value it had when the previous launch ended (written by that launch's
-    // last workgroup: nothing of the protocol lives on the host, so a captured launch can be replayed), workgroups done
-    unsigned long long* tickets; unsigned long long* epoch; unsigned* done;
+    sr_xel* xch;                      // groups x H x n_out x (16 (D + 1) + 16 parts) tagged values: every step's results
+                                      // of the n_out x Np / 128 posterior workgroups of a group of 16 rollouts (zeroed once)
+    // per group: the last tag used so far (the tags of a launch are epoch + 1 .. epoch + H; written by the launch's last
+    // workgroup to leave: nothing of the protocol lives on the host, so a captured launch can be replayed), workgroups
+    // done, and the tag with which the group's tail workgroup (the shape matrices) reported for this launch
+    unsigned long long* epoch; unsigned* done; unsigned long long* alive;
     // status word in PINNED HOST memory (device-visible address): a group whose hand-off did not complete within
     // SR_CHAIN_TIMEOUT_TICKS ORs 1 into it with a system-scope atomic (and poisons its outputs with NaN).  The host
     // reads it without a copy: after the stream has been synchronised it says whether this launch failed.
@@ -219,6 +221,9 @@ struct sr_chain_args {
     int test_drop = 0;                // tests only: launch this many workgroups fewer than the chain needs
 };
 #define SR_CHAIN_GROUPS 240          /* workgroups of one launch: all must be resident (they wait for each other) */
+#define SR_CHAIN_XELS (240ul * 112 * 96)      /* exchange elements (16 B): 240 posterior workgroups x 96 steps at most */
+int sr_chain_wgs_per_group(int Np, int n_s);                    // posterior workgroups + the tail workgroup
+long sr_chain_xels_per_group(int Np, int n_s, int n_u, int H);  // exchange elements one group of 16 rollouts needs
 #define SR_CHAIN_TIMEOUT_TICKS 10000000ull   /* 100 ms of the 100 MHz wall clock (a step takes ~10 us) */
 bool sr_chain_supported(int Np, int D, int n_s, int n_u, int H);
 // workgroups of the chain kernel for this model that one CU can hold (hipOccupancyMaxActiveBlocksPerMultiprocessor of

@@ -27,7 +27,9 @@ def main():
     print("%5s %4s %6s %4s %12s %12s" % ("N", "n_s", "T", "H", "per-step us", "one launch us"))
     for n_s, n_u, N, T, H in ((2, 1, 200, 256, 15), (2, 1, 200, 16, 15), (2, 1, 200, 1024, 15), (2, 1, 100, 256, 15),
                               (2, 1, 350, 256, 15), (2, 1, 500, 256, 15), (4, 1, 150, 256, 15), (4, 1, 150, 960, 15),
-                              (2, 1, 200, 256, 5), (2, 1, 200, 1920, 15), (2, 1, 200, 4096, 15)):
+                              (2, 1, 200, 256, 5), (2, 1, 200, 768, 15), (2, 1, 200, 1536, 15), (2, 1, 200, 1920, 15),
+                              (2, 1, 200, 2304, 15), (2, 1, 200, 3072, 15), (2, 1, 200, 4096, 15), (4, 1, 150, 416, 15),
+                              (4, 1, 150, 832, 15), (4, 1, 150, 1248, 15), (2, 1, 500, 416, 15), (2, 1, 500, 832, 15)):
         prob = workload.make_problem(9, N, n_s, n_u, T, sf2=0.01)
         gp = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device="cuda:0")
         gp.train(prob["Z"], prob["Y"], opt_hyp=False)
@@ -41,7 +43,8 @@ def main():
         for on in (False, True):
             gp.set_chain(on)
             out.append(timeit(fn))
-        print("%5d %4d %6d %4d %12.1f %12.1f" % (N, n_s, T, H, out[0], out[1]), flush=True)
+        print("%5d %4d %6d %4d %12.1f %12.1f%s" % (N, n_s, T, H, out[0], out[1], "" if gp.last_chain else "   (per-step launches)"),
+              flush=True)
         del gp
 
 

@@ -1392,10 +1392,12 @@ def test_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
     (2, 1, 200, 256, 15, False),     # the regime of the reference's experiments
     (2, 1, 200, 17, 5, True),        # ragged last group, ellipsoid start
     (2, 1, 350, 300, 7, True),       # Np = 384
-    (2, 1, 500, 480, 4, False),      # Np = 512: 30 groups x 2 outputs x 4 parts fill the launch
-    (2, 1, 200, 1900, 3, False),     # 119 groups x 2 outputs x 2 parts: two launches
-    (4, 1, 150, 470, 6, True),       # cart-pole: 30 groups x 4 outputs x 2 parts
-    (4, 1, 300, 100, 4, True),       # Np = 384 with n_s = 4: the instantiation needs 188 B of scratch -> per-step launches
+    (2, 1, 500, 416, 4, False),      # Np = 512: 26 groups x (2 outputs x 4 parts + tail) fill the launch
+    (2, 1, 200, 1500, 3, False),     # 94 groups x (2 outputs x 2 parts + tail): two launches
+    (4, 1, 150, 410, 6, True),       # cart-pole: 26 groups x (4 outputs x 2 parts + tail)
+    (4, 1, 300, 100, 4, True),       # Np = 384 with n_s = 4
+    (1, 1, 256, 481, 2, True),       # one output, two parts: exchange without a second output
+    (1, 1, 200, 64, 3, False),
     (3, 1, 120, 40, 9, False),
     (1, 1, 90, 33, 5, True),         # one output: no hand-off between workgroups
     (2, 2, 180, 100, 5, True),
@@ -1424,9 +1426,7 @@ def test_persistent_chain_matches_per_step_launches(n_s, n_u, N, T, H, with_q0):
     p_ref, q_ref = reach.multistep_reachability_batch(*args)
     assert not gp.last_chain
     gp.set_chain(True)
-    # the persistent kernel is dispatched only where its instantiation needs (next to) no scratch memory (sr_chain_supported)
-    Np = -(-N // 128) * 128
-    chain_ok = Np <= 256 or (Np == 384 and n_s <= 3) or (Np == 512 and n_s <= 2)
+    chain_ok = True                  # every instantiation is scratch-free and dispatched (sr_chain_supported)
     for _ in range(3):               # tickets carry on from launch to launch
         p_all, q_all = reach.multistep_reachability_batch(*args)
         assert gp.last_chain == chain_ok
@@ -1441,12 +1441,16 @@ def test_persistent_chain_matches_per_step_launches(n_s, n_u, N, T, H, with_q0):
         np.testing.assert_allclose(q_s, q_ref[:20], rtol=1e-7, atol=1e-14)
         p_all, q_all = reach.multistep_reachability_batch(*args)
         np.testing.assert_allclose(q_all, q_ref, rtol=1e-7, atol=1e-14)
-    # more rollouts than one launch holds: the per-step route takes over (same results, checked above)
-    if T == 470:
-        big = tuple(np.concatenate([x, x]) if isinstance(x, np.ndarray) and x.shape[:1] == (T,) else x for x in args)
-        p_b, q_b = reach.multistep_reachability_batch(*big)
-        assert not gp.last_chain
-        np.testing.assert_allclose(p_b[:T], p_ref, rtol=1e-8, atol=1e-11)
+    # more rollouts than two launches hold (26 groups each here) while the per-step route still has its one-launch
+    # posterior: the per-step route takes over (same results, checked above); two launches are still taken
+    if T == 410:
+        for reps, want_chain in ((2, True), (3, False)):
+            big = tuple(np.concatenate([x] * reps)[:1000] if isinstance(x, np.ndarray) and x.shape[:1] == (T,) else x
+                        for x in args)
+            p_b, q_b = reach.multistep_reachability_batch(*big)
+            assert gp.last_chain == want_chain
+            np.testing.assert_allclose(p_b[:T], p_ref, rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(q_b[T:2 * T], q_ref, rtol=1e-7, atol=1e-14)
     om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
     n = min(T, 24)
     rp, rq = orc.multistep_reachability_batch(om, syn["p"][:n], k_fb[:n], k_ff[:n], l_mu, l_sg,
