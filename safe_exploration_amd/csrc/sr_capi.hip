@@ -880,10 +880,13 @@ static int ensure_ws(sr_gp* h, long Tp, int nsplit) {
 // h->jac: the fused small-batch route wants 2 * ceil(Np / 256) mean partials per query, which exceeds pick_nsplit for
 // big models (n_out = 2: Np > 49152) -- sized by pick_nsplit alone, the first T <= 64 reachability call on such a
 // model reallocated the workspace under the pointers its caller held.  The lock turns any such growth into an error.
+// (65 .. 128 queries also fit the streamed route's 128 columns; measured at N = 5000, T = 128: 188 us against 165 us on
+//  the split-K tiles -- the 16-wavefront MFMA kernel reaches 64 % of the matrix pipe there)
+static int stream_max_t() { return SR_STREAM_MAX_T; }
 static int prepare_ws(sr_gp* h, long Tc) {
     const long Tp = round_up(Tc, srt::BN);
     int ns = pick_nsplit(h, Tp);
-    if (Tc <= SR_STREAM_MAX_T) ns = std::max(ns, std::max(pick_nsplit(h, srt::BN), 2 * ((h->Np + 255) / 256)));
+    if (Tc <= stream_max_t()) ns = std::max(ns, std::max(pick_nsplit(h, srt::BN), 2 * ((h->Np + 255) / 256)));
     return ensure_ws(h, Tp, ns);
 }
 struct sr_ws_lock {
@@ -1007,7 +1010,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         return sr_launch_gp_small(ka, h->Wt, mu, var, jac, s);
     }
-    if (h->small_path != 0 && !h->force_stream && h->Np > SR_STREAM_MIN_NP && Tc <= SR_STREAM_MAX_T)
+    if (h->small_path != 0 && !h->force_stream && h->Np > SR_STREAM_MIN_NP && Tc <= stream_max_t())
         return stream_predict(h, Tc, xa, lda, na, xb, ldb, nb, mu, var, jac, s);   // U^-1 streamed once, 1-3 launches
     const long Tp = round_up(Tc, srt::BN);
     const int nsplit = pick_nsplit(h, Tp);

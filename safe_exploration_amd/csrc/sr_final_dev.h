@@ -52,11 +52,23 @@ __device__ __forceinline__ void sr_final_query_wave(const sr_final_args& a, long
         }
         return;
     }
-    double m = 0.0;
-    for (int s = lane; s < a.nsplit; s += 64) m += sr_ld<AG>(a.mu_part + ((long)s * a.n_out + d) * a.Tp + t);
+    // many partial sums (the K* pass splits the training points down to 16 rows per workgroup for small batches: 320
+    // partials per quantity at N = 5000): lanes stride over them, EIGHT loads per lane and quantity in flight, mean and
+    // variance together, then the Jacobian three components at a time -- a plain strided loop pays one memory latency
+    // per partial and quantity (20 dependent round trips = 9 us of the 12 us this stage took at N = 5000).
+    double m = 0.0, q = 0.0;
+    for (int s0 = 0; s0 < a.nsplit || s0 < a.nrb; s0 += 512) {
+        double xm[8], xq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + lane + 64 * u;
+            xm[u] = (s < a.nsplit) ? sr_ld<AG>(a.mu_part + ((long)s * a.n_out + d) * a.Tp + t) : 0.0;
+            xq[u] = (s < a.nrb) ? sr_ld<AG>(a.var_part + ((long)d * a.nrb + s) * a.Tp + t) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { m += xm[u]; q += xq[u]; }
+    }
     m = sr_wave_sum(m);
-    double q = 0.0;
-    for (int rb = lane; rb < a.nrb; rb += 64) q += sr_ld<AG>(a.var_part + ((long)d * a.nrb + rb) * a.Tp + t);
     q = sr_wave_sum(q);
     double v = (a.kxx ? a.kxx[(long)d * a.Tp + t] : a.sf2[d]) - q;
     if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
@@ -65,12 +77,28 @@ __device__ __forceinline__ void sr_final_query_wave(const sr_final_args& a, long
         a.var[t * a.n_out + d] = v;
     }
     if (a.jac) {
-        for (int j = 0; j < a.D; ++j) {
-            double gj = 0.0;
-            for (int s = lane; s < a.nsplit; s += 64)
-                gj += sr_ld<AG>(a.jac_part + (((long)s * a.n_out + d) * a.D + j) * a.Tp + t);
-            gj = sr_wave_sum(gj);
-            if (lane == 0) a.jac[(t * a.n_out + d) * a.D + j] = gj;
+        for (int j0 = 0; j0 < a.D; j0 += 3) {
+            double g[3] = {0.0, 0.0, 0.0};
+            for (int s0 = 0; s0 < a.nsplit; s0 += 512) {
+                double x[3][8];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int s = s0 + lane + 64 * u;
+                        x[c][u] = (s < a.nsplit && j0 + c < a.D)
+                                      ? sr_ld<AG>(a.jac_part + (((long)s * a.n_out + d) * a.D + j0 + c) * a.Tp + t) : 0.0;
+                    }
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[c] += x[c][u];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double gj = sr_wave_sum(g[c]);
+                if (lane == 0 && j0 + c < a.D) a.jac[(t * a.n_out + d) * a.D + j0 + c] = gj;
+            }
         }
     }
 }

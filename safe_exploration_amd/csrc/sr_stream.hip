@@ -292,6 +292,9 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
 }
 
 // ------------------------------------------------------------------------------------------------
+// ONE 128-row k-chunk per workgroup (models whose grid would not cover the chip with longer runs: N < ~4000; there
+// this form is faster than the run kernel below with KC = 1 -- N = 3000, T = 32: 26.0 + 14.6 against 33.3 + 17.0 us for
+// kernel + reduction: its wavefronts skip the k-steps below their strip's diagonal).
 // 16 G columns per workgroup on the MFMA 16x16x4 tile.  The (column block, k-chunk) pair is one workgroup of 16
 // wavefronts, wavefront w owning the 16-column strip w: A-fragments straight from global (the 16 strips of a row are
 // one contiguous 2 KiB segment), B-fragments = the K* rows in LDS (row stride 16 G + 16 doubles for G > 1: the two
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
 // A-fragment.  Vp[(d, pair)][column][256].
 // ------------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) {
+__global__ __launch_bounds__(1024) void sr_stream_mfma1_kernel(sr_stream_args a) {
     constexpr int NC = 16 * G;
     constexpr int LDK = (G == 1) ? 16 : NC + 16;
     __shared__ double ks[SR_ST_ROWS * LDK];
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
 // part[d][cb][t] = sum_{i in column block cb} V_t[i] (dot0 ? V_0[i] : V_t[i]),  V_t = sum_chunks Vp;
 // grid (ncb, n_out, live columns).  The last workgroup of a COLUMN t (predict: query t) runs that query's final stage;
 // in linearize mode the last workgroup of the whole grid runs the single query's.
-__global__ __launch_bounds__(256) void sr_stream_reduce_kernel(sr_stream_args a, int nc) {
+__global__ __launch_bounds__(256) void sr_stream_reduce1_kernel(sr_stream_args a, int nc) {
     __shared__ double sh[4 * 120];
     __shared__ int s_flag;
     const int cb = blockIdx.x, d = blockIdx.y, t = blockIdx.z;
@@ -392,6 +395,201 @@ __global__ __launch_bounds__(256) void sr_stream_reduce_kernel(sr_stream_args a,
     } else {
         if (!sr_ticket_last(a.tickets, (unsigned)(a.n_out * a.ncb * gridDim.z), &s_flag)) return;
         sr_stream_final(a, sh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16 G columns per workgroup on the MFMA 16x16x4 tile.  A workgroup of 16 wavefronts owns a column block of 256
+// columns of U^-1 and a run of KC consecutive 128-row k-chunks of it (work item (cb, J), enumerated column block by
+// column block); wavefront w owns the 16-column strip w: A-fragments straight from global (the 16 strips of a row are one
+// contiguous 2 KiB segment), the next batch requested before the MFMAs of the current one are issued; B-fragments = the
+// K* rows, staged through LDS SUB rows at a time, double-buffered (row stride 16 G + 16 doubles for G > 1: the two k-rows
+// of a 32-lane ds_read_b64 group then sit on opposite bank halves), one ds_read_b64 per MFMA, G MFMAs per loaded
+// A-fragment.  The accumulators stay in registers over the whole run: one partial result per (work item, column).
+// (Round 2: one 128-row chunk per workgroup -- 840 workgroups of two load batches each at N = 5000, their prologues and
+// epilogues exposed, and four times the partial sums: T = 16 / 32 / 64: 41 + 21 / 55 + 26 / 96 + 38 us for this kernel
+// + its reduction.)
+// Vp[(d, work item)][column][256].
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int sr_st_items_of(int cb, int kc) { return (2 * cb + 2 + kc - 1) / kc; }
+__device__ __forceinline__ void sr_item_decode(int p, int kc, int& cb, int& J) {
+    cb = 0;
+    for (int n = sr_st_items_of(0, kc); p >= n; n = sr_st_items_of(cb, kc)) { p -= n; ++cb; }
+    J = p;
+}
+
+template <int G>
+__global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, int KC) {
+    constexpr int NC = 16 * G;
+    constexpr int LDK = (G == 1) ? 16 : NC + 16;
+    constexpr int SUB = (G <= 2) ? 128 : (G == 4 ? 64 : 32);      // K* rows per LDS stage
+    constexpr int UB = (G <= 2) ? 16 : (G == 4 ? 8 : 4);          // A-fragments (k-steps of 4 rows) per batch
+    constexpr int BPS = SUB / 4 / UB;                             // batches per stage: 2
+    constexpr int PF = SUB * NC / 1024;                           // K* doubles a thread moves per stage
+    static_assert(BPS == 2 && BPS * UB * 4 == SUB && PF * 1024 == SUB * NC, "stage geometry");
+    __shared__ double ks[2][SUB * LDK];
+    const int d = blockIdx.y, p = blockIdx.x;
+    int cb, J;
+    sr_item_decode(p, KC, cb, J);
+    const int j_hi = min(J * KC + KC, 2 * cb + 2);
+    const int k0 = J * KC * SR_ST_ROWS, k1 = min(j_hi * SR_ST_ROWS, a.Np);
+    const int nsub = (k1 - k0 + SUB - 1) / SUB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
+    const int c0 = blockIdx.z * NC;                      // first column of this workgroup (grid.z: column blocks)
+    const double* ksrc = a.Ks + (long)d * a.Np * a.Tp + (long)k0 * a.Tp + c0;
+
+    // K* rows of stage `sub` that this thread moves (element e = tid + 1024 m: row e / NC, column e % NC)
+    auto ks_fetch = [&](int sub, double (&pf)[PF]) {
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+            const int e = tid + 1024 * m, r = sub * SUB + e / NC, t = e % NC;
+            pf[m] = (c0 + t < a.ncols_pad) ? ksrc[(long)r * a.Tp + t] : 0.0;
+        }
+    };
+    auto ks_put = [&](int buf, const double (&pf)[PF]) {
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+            const int e = tid + 1024 * m;
+            ks[buf][(e / NC) * LDK + e % NC] = pf[m];
+        }
+    };
+
+    const int i0 = min(cb * SR_ST_COLS + 16 * wave, a.Np - 16);      // first column of this strip (Np is a multiple of 128)
+    // Every wavefront runs every batch of the work item -- uniform control flow, so that the requests of the next batch
+    // stay in flight under the MFMAs of the current one.  No masks: rows below a strip's diagonal hold the zeros of U^-1,
+    // rows in front of k_lo meet K* == 0.  (A per-wavefront range -- skipping the batches below the diagonal -- made the
+    // compiler wait for every single load: 116 against 71 us at N = 5000, T = 16.  What it would save is half of the
+    // two diagonal chunks of a column block: 5 % of the MFMAs at N = 5000.)
+    const double* w = a.Wt + (long)d * a.Np * a.Np + (long)(k0 + lk) * a.Np + i0 + ln;
+    d4_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double pf[PF];
+    ks_fetch(0, pf);
+    double A0[UB], A1[UB];
+#pragma unroll
+    for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * q) * a.Np];
+    ks_put(0, pf);
+    __syncthreads();
+    // BPS = 2: the even batch of a stage requests the next stage's K* rows, the odd one stores them and ends the stage
+    for (int sub = 0; sub < nsub; ++sub) {
+        const double* kb = ks[sub & 1] + lk * LDK + ln;
+        const bool more = sub + 1 < nsub;
+        if (more) ks_fetch(sub + 1, pf);
+#pragma unroll
+        for (int q = 0; q < UB; ++q) A1[q] = w[(long)(4 * ((2 * sub + 1) * UB + q)) * a.Np];
+#pragma unroll
+        for (int q = 0; q < UB; ++q)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[q], kb[4 * q * LDK + 16 * g], acc[g], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * ((2 * sub + 2) * UB + q)) * a.Np];
+        }
+#pragma unroll
+        for (int q = 0; q < UB; ++q)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[q], kb[4 * (UB + q) * LDK + 16 * g], acc[g], 0, 0, 0);
+        if (more) ks_put((sub + 1) & 1, pf);                  // (that buffer was last read in stage sub - 1)
+        __syncthreads();
+    }
+    // acc[g][r] = V[column i0 + lk + 4r][query 16 g + ln]; strips beyond the matrix (last column block) report zeros
+    const bool live = cb * SR_ST_COLS + 16 * wave < a.Np;
+    double* out = a.Vp + (((long)d * gridDim.x + p) * (NC * gridDim.z) + c0) * SR_ST_COLS;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(long)(16 * g + ln) * SR_ST_COLS + 16 * wave + lk + 4 * r] = live ? acc[g][r] : 0.0;
+}
+
+// Reduction + final stage of the MFMA kernel's partial results, ONE workgroup of 512 threads per (column t, output d) and
+// no hand-off between workgroups in predict mode: thread (sub, col) adds, for the column blocks cb = sub, sub + 2, ..,
+// the work items of column `col` of the block in their fixed order, squares (or multiplies with column 0 in linearize
+// mode) and accumulates; the workgroup sum is the query's |U^-T k*|^2, and its first wavefront runs the query's final
+// stage on the spot.  (Round 2: one workgroup of 256 threads per (column block, output, column) + a ticket per query:
+// 20 x n_out x T workgroups of two dependent round trips each -- 19 / 26 / 38 us for T = 16 / 32 / 64 at N = 5000,
+// whatever the amount of partial sums.)  Linearize mode: the last workgroup of the grid (ticket) runs the final stage.
+__global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a, int nc, int KC, int nitems) {
+    __shared__ double sh[4 * 120];
+    __shared__ double red[8];
+    __shared__ int s_flag;
+    const int t = blockIdx.x, d = blockIdx.y;
+    const int tid = threadIdx.x, sub = tid >> 8, col = tid & 255;
+    const long cs = (long)nc * SR_ST_COLS;               // item stride
+    const double* base = a.Vp + (long)d * nitems * cs + col;
+    const bool dot = a.dot0 && t != 0;
+    // first work item of this thread's first column block
+    int p0 = 0;
+    for (int c = 0; c < sub; ++c) p0 += sr_st_items_of(c, KC);
+    double acc = 0.0;
+    if (!dot && sr_st_items_of(a.ncb - 1, KC) <= 12) {
+        // at most 12 work items per column block (N = 5000: KC = 4, 1 .. 10): the items of FIVE column blocks are
+        // requested together -- the reduction is a chain of dependent round trips, not of bytes
+        for (int cb = sub; cb < a.ncb; cb += 10) {
+            double x[5][12];
+            int pp = p0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const int cbb = cb + 2 * b;
+                const int nch = cbb < a.ncb ? sr_st_items_of(cbb, KC) : 0;
+#pragma unroll
+                for (int u = 0; u < 12; ++u) x[b][u] = (u < nch) ? base[(long)(pp + u) * cs + (long)t * SR_ST_COLS] : 0.0;
+                for (int c = cbb; c < cbb + 2 && c < a.ncb; ++c) pp += sr_st_items_of(c, KC);
+            }
+            p0 = pp;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                double v = 0.0;
+#pragma unroll
+                for (int u = 0; u < 12; ++u) v += x[b][u];
+                acc = fma(v, v, acc);
+            }
+        }
+    } else {
+        for (int cb = sub; cb < a.ncb; cb += 2) {
+            const int nch = sr_st_items_of(cb, KC);
+            double v = 0.0, v0 = 0.0;
+            for (int c = 0; c < nch; c += 12) {               // (plain loads: Vp comes from the previous launch)
+                double x[12], y[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    x[u] = (c + u < nch) ? base[(long)(p0 + c + u) * cs + (long)t * SR_ST_COLS] : 0.0;
+                    y[u] = (dot && c + u < nch) ? base[(long)(p0 + c + u) * cs] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 12; ++u) { v += x[u]; v0 += y[u]; }
+            }
+            acc = fma(v, dot ? v0 : v, acc);
+            for (int c = cb; c < cb + 2 && c < a.ncb; ++c) p0 += sr_st_items_of(c, KC);
+        }
+    }
+    // sum over the workgroup in a fixed order: wavefront butterflies, then the 16 wavefront sums
+    const double wsum = sr_wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = wsum;
+    __syncthreads();
+    if (tid == 0) {
+        double q = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q += red[w];
+        // (agent scope: in linearize mode another workgroup reads it; the final stage below reads it back the same way)
+        sr_st_agent(a.part + (long)d * a.Tp + t, q);
+    }
+    if (a.mode == 0) {
+        if (tid < 64) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sr_final_args fa = a.fa;
+            fa.nrb = 1;                                   // part[d][0][t] holds the whole sum
+            sr_final_query_wave<true>(fa, t, d, tid);
+        }
+    } else {
+        if (!sr_ticket_last(a.tickets, (unsigned)(a.n_out * gridDim.x), &s_flag)) return;
+        sr_stream_args b = a;
+        b.ncb = 1;
+        sr_stream_final(b, sh);
     }
 }
 
@@ -442,14 +640,34 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     int g = nc / 16;
     while (g > 1 && (long)a.npairs * a.n_out * (nc / (16 * g)) < 256) g >>= 1;
     grid.z = nc / (16 * g);
+    // k-chunks per workgroup: as long a run as still leaves about one workgroup per CU (N = 5000, T = 16 / 64 / 128
+    // columns, whole call: runs of 1 / 2 / 3 / 4 chunks 79 / 70 / 81 / 66, 169 / 138 / 166 / 125, 288 / 245 / 300 / 218 us)
+    auto items = [&](int kc) { long n = 0; for (int cb = 0; cb < a.ncb; ++cb) n += sr_st_items_of(cb, kc); return n; };
+    int kc = 1;
+    for (int c : {2, 3, 4, 6, 8})
+        if (items(c) * a.n_out * grid.z >= 200) kc = c;
+    if (kc == 1) {
+        switch (g) {
+            case 1: hipLaunchKernelGGL(sr_stream_mfma1_kernel<1>, grid, dim3(1024), 0, s, a); break;
+            case 2: hipLaunchKernelGGL(sr_stream_mfma1_kernel<2>, grid, dim3(1024), 0, s, a); break;
+            case 4: hipLaunchKernelGGL(sr_stream_mfma1_kernel<4>, grid, dim3(1024), 0, s, a); break;
+            default: hipLaunchKernelGGL(sr_stream_mfma1_kernel<8>, grid, dim3(1024), 0, s, a); break;
+        }
+        SR_HIP(hipGetLastError());
+        hipLaunchKernelGGL(sr_stream_reduce1_kernel, dim3(a.ncb, a.n_out, a.ncols), dim3(256), 0, s, a, nc);
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
+    const int nitems = (int)items(kc);
+    grid.x = nitems;
     switch (g) {
-        case 1: hipLaunchKernelGGL(sr_stream_mfma_kernel<1>, grid, dim3(1024), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(sr_stream_mfma_kernel<2>, grid, dim3(1024), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(sr_stream_mfma_kernel<4>, grid, dim3(1024), 0, s, a); break;
-        default: hipLaunchKernelGGL(sr_stream_mfma_kernel<8>, grid, dim3(1024), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(sr_stream_mfma_kernel<1>, grid, dim3(1024), 0, s, a, kc); break;
+        case 2: hipLaunchKernelGGL(sr_stream_mfma_kernel<2>, grid, dim3(1024), 0, s, a, kc); break;
+        case 4: hipLaunchKernelGGL(sr_stream_mfma_kernel<4>, grid, dim3(1024), 0, s, a, kc); break;
+        default: hipLaunchKernelGGL(sr_stream_mfma_kernel<8>, grid, dim3(1024), 0, s, a, kc); break;
     }
     SR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(sr_stream_reduce_kernel, dim3(a.ncb, a.n_out, a.ncols), dim3(256), 0, s, a, nc);
+    hipLaunchKernelGGL(sr_stream_reduce_kernel, dim3(a.ncols, a.n_out), dim3(512), 0, s, a, nc, kc, nitems);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
