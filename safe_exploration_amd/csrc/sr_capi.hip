@@ -76,7 +76,7 @@ struct sr_gp {
     hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_bulk[2] = {nullptr, nullptr};
     hipEvent_t ev_inv[2] = {nullptr, nullptr};            // critical -> inversion stream, back
     int fact_panel = 0;                                  // blocks per Cholesky panel; 0 = by size
-    int fact_regime = 0;                                 // how the streams below were made: 0 none, 1 chain-bound, 2 GEMM-bound
+    int fact_regime = 0;                                 // how the streams below were made: 0 none, else 1000 x (1 chain-bound, 2 GEMM-bound) + reserved CUs
     int ncu = 0;                                         // compute units of the device (cached)
     // job lists of the level-batched triangular inversion (depend on Np only)
     int* fact_info = nullptr;                            // status words of the factorisation (64 ints)
@@ -378,11 +378,17 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
     const bool can_mask = ncu >= 64;
     // (giving each output's chain one half of the XCDs through CU masks on ALL of its streams was measured and lost:
     //  N = 5000, two outputs 5.6 -> 8.7 ms -- kernels on a CU-masked queue start late, and the mask costs the priority)
-    if (h->fact_regime != regime) drop_fact_streams(h);
+    // CUs the bulk streams leave to the critical chain: one per shader engine; two for 36 < Np / 128 <= 52, where the
+    // block-row solves and in-panel updates of the chain otherwise queue behind the trailing update's workgroups (50
+    // instead of 12 us each) and the trailing update has the slack (measured, reserve 32 / 64: N = 3500 2.79 / 2.80,
+    // N = 5000 5.14 / 4.99, N = 6500 8.79 / 8.74, N = 7500 12.17 / 12.45, N = 10000 25.1 / 26.7 ms)
+    const int nblk = h->Np / SR_NB;
+    const int reserve = regime == 2 ? 8 : ((nblk > 36 && nblk <= 52) ? 2 * SR_FACT_RESERVED_CUS : SR_FACT_RESERVED_CUS);
+    const int key = regime * 1000 + reserve;
+    if (h->fact_regime != key) drop_fact_streams(h);
     int prio_lo = 0, prio_hi = 0;
     SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     if (!h->fact_stream) SR_HIP(hipStreamCreateWithPriority(&h->fact_stream, hipStreamNonBlocking, prio_hi));
-    const int reserve = regime == 2 ? 8 : SR_FACT_RESERVED_CUS;
     if (!h->bulk_stream) {
         if (can_mask) SR_TRY(make_masked_stream(&h->bulk_stream, ncu, reserve, ncu));
         else SR_HIP(hipStreamCreateWithPriority(&h->bulk_stream, hipStreamNonBlocking, prio_lo));
@@ -397,7 +403,7 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
         if (!h->ev_bulk[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_bulk[e], hipEventDisableTiming));
         if (!h->ev_inv[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_inv[e], hipEventDisableTiming));
     }
-    h->fact_regime = regime;
+    h->fact_regime = key;
     return SR_OK;
 }
 
