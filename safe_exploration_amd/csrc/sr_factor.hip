@@ -4,7 +4,6 @@
 // replaces (numerically) what GPy computes for SimpleGPModel.train / update_model:
 //   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:238-275, 398-419
 #include "sr_mfma_tile.h"
-static int sr_env_int(const char* name, int dflt);
 
 // ------------------------------------------------------------------------------------------------
 // TN GEMMs on the fp64 matrix cores, on either workgroup tile of sr_mfma_tile.h
@@ -96,26 +95,18 @@ static inline bool sr_use_tile64(long tiles128, int K = 0) {
     // ... unless K is long: then a grid that occupies the chip at least once is throughput-bound and the 64-tile's 8 flop
     // per operand byte is the limit (the in-panel updates of the N = 50000 factorisation -- 128 rows x 50000 columns, K up
     // to 2944: 21 TF on 64-tiles)
-    static const int klong = sr_env_int("SR_T64_KLONG", 768);
-    if (K >= klong && tiles128 >= 256) return false;
+    if (K >= 768 && tiles128 >= 256) return false;
     return tiles128 < 1024;
 }
 // ... but a 64 x 64 tile moves 8 bytes of operands per 8 flop (K-independent): a grid of them that fills the chip is
 // bound by L2 / fabric bandwidth (N = 5000, K = 256 bulk update of two outputs: 1.7 GB in 254 us = 6.8 TB/s, 21 TF per
 // output).  THROUGHPUT-bound products (bulk trailing update, the big levels of the inversion) therefore take the
 // 128-tile (16 flop per byte) as soon as there are enough of them to occupy the chip once.
-static int sr_env_int(const char* name, int dflt);
-static int sr_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 static inline bool sr_use_tile64_bulk(long tiles128) {
-    static const int below = sr_env_int("SR_T64_BULK_BELOW", 192);
-    return tiles128 < below;
+    return tiles128 < 192;
 }
 static inline bool sr_use_tile64_jobs(long tiles128) {
-    static const int below = sr_env_int("SR_T64_JOBS_BELOW", 1024);
-    return tiles128 < below;
+    return tiles128 < 1024;
 }
 
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
@@ -241,8 +232,7 @@ int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb
     const long tiles128 = (tm128 * tn128 - tm128 * (tm128 - 1) / 2) * bt.n;
     const bool t64 = prio ? sr_use_tile64(tiles128, K) : sr_use_tile64_bulk(tiles128);
     const long tm = t64 ? M / 64 : tm128, tn = t64 ? N / 64 : tn128;
-    static const int order1_from = sr_env_int("SR_ORDER1_FROM", 4096);
-    if (order < 0) order = tiles128 >= order1_from ? 1 : 0;     // super-tiles pay once the grid is many times the chip
+    if (order < 0) order = tiles128 >= 4096 ? 1 : 0;     // super-tiles pay once the grid is many times the chip
     long blocks;
     if (order == 0) {
         blocks = tm * tn - tm * (tm - 1) / 2;
