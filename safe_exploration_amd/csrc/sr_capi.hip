@@ -5,6 +5,7 @@
 #include "sr_mfma_tile.h"
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 #include <algorithm>
 
@@ -1625,12 +1626,18 @@ extern "C" int sr_wait_flag(const unsigned long long* flag_host, unsigned long l
     SR_CHECK(flag_host != nullptr, SR_EINVAL, "sr_wait_flag: NULL flag");
     const volatile unsigned long long* f = flag_host;
     const auto t0 = std::chrono::steady_clock::now();
+    // The answer of a small model is there within 10 .. 60 us: spin.  A caller that is still waiting after 200 us is
+    // behind other work on the device: give the core away between looks, and sleep between them after 5 ms -- a wait
+    // that runs into its time-out (seconds) must not burn a core for it.
     for (;;) {
         for (int spin = 0; spin < 2048; ++spin) {
             if (*f == seq) { std::atomic_thread_fence(std::memory_order_acquire); return SR_OK; }
             __builtin_ia32_pause();
         }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) break;
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > timeout_s) break;
+        if (waited > 5e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else if (waited > 2e-4) std::this_thread::yield();
     }
     sr_set_error("sr_wait_flag: sequence %llu not seen within %.3f s (flag = %llu)", seq, timeout_s, *f);
     return SR_ESTATE;

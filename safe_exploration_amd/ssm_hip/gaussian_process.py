@@ -79,12 +79,24 @@ class _Handle(object):
         itself).  Returns the first k doubles of the packed result, or None where the library has no one-launch
         posterior for this model."""
         io = self._single_io
-        if not (io["direct"] and io["mailbox"]):
+        if not io["mailbox"]:
             return None
+        if not io["direct"]:
+            # switched off for the model as it was then (SR_EUNSUPPORTED: too large for the one-launch posterior); a
+            # model whose padded size has changed since is asked again
+            npad = ctypes.c_long()
+            check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
+            if npad.value == io.get("direct_off_np"):
+                return None
+            io["direct"] = True
         io["seq"] = seq = io["seq"] + 1
         rc = lib.sr_gp_call1(self.h, io["p_in"], second_order, io["p_out"], io["p_flag"], seq, stream.cuda_stream)
         if rc != 0:
-            io["direct"] = False               # SR_EUNSUPPORTED (model too large / general kernel) or unpinned block
+            if rc != -5:                       # anything but SR_EUNSUPPORTED is an error of this call
+                check(rc)
+            npad = ctypes.c_long()
+            check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
+            io["direct"], io["direct_off_np"] = False, npad.value
             return None
         rc = lib.sr_wait_flag(io["p_flag"], seq, 5.0)
         if rc != 0:
