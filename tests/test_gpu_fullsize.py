@@ -328,6 +328,45 @@ def test_first_small_batch_reach_call_on_a_big_model():
     np.testing.assert_allclose(qa, qb, rtol=1e-7, atol=1e-13)
 
 
+def test_streamed_small_batches_at_the_headline_model_size():
+    """5 .. 64 queries against the N = 5000 model take the streamed route with RUNS of k-chunks per workgroup
+    (sr_stream_mfma_kernel, only dispatched from N ~ 4000 on) and the one-workgroup-per-query reduction: every width
+    (16 / 32 / 64 columns, ragged counts) against the tile route of the same library and, for a sample, against the oracle
+    (explicit-inverse route and the tighter triangular-solve route); then the single query with second-order outputs
+    (the same kernels in linearize mode: columns [k*, dk*/dx], dot products with column 0)."""
+    N = 5000
+    syn = orc.make_synthetic(5, N, 2, 1, 64)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    om = cached_oracle_model(5, N, 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    at = max(mu_atol(om), 1e-12)
+    for T in (5, 16, 17, 33, 64):
+        mu, var, jac = gp.predict(x[:T], None, True)
+        gp.set_small_path(0)
+        mu0, var0, jac0 = gp.predict(x[:T], None, True)
+        gp.set_small_path(1)
+        np.testing.assert_allclose(mu, mu0, rtol=1e-11, atol=at)
+        np.testing.assert_allclose(jac, jac0, rtol=1e-11, atol=10 * at)
+        np.testing.assert_allclose(var, var0, rtol=0, atol=1e-12)          # two summation orders of the same factor
+        assert var.min() > 0
+    rmu, rvar, rjac = orc.gp_predict(x[:33], om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"])
+    mu, var, jac = gp.predict(x[:33], None, True)
+    np.testing.assert_allclose(mu, rmu, rtol=1e-9, atol=at)
+    np.testing.assert_allclose(jac, rjac, rtol=1e-9, atol=10 * at)
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-9)
+    _, cvar = orc.gp_predict_chol(x[:33], om["Z"], om["beta"], om["chol"], om["lengthscale"], om["signal_var"])
+    np.testing.assert_allclose(var, cvar, rtol=0, atol=2e-11)
+    # second order at one query
+    x1 = x[7]
+    out = gp.linearize_predict(x1[None, :2], x1[None, 2:], True)
+    rjv, rhm = orc.gp_linearize_extras(x1, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"])
+    np.testing.assert_allclose(out[0][:, 0], rmu[7], rtol=1e-9, atol=at)
+    np.testing.assert_allclose(out[1][:, 0], cvar[7], rtol=0, atol=2e-11)
+    np.testing.assert_allclose(out[2], rjac[7], rtol=1e-9, atol=10 * at)
+    np.testing.assert_allclose(out[3], rjv, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(out[4], rhm, rtol=1e-8, atol=100 * at)
+
+
 def test_config3_at_the_rollout_count_the_bench_times():
     """BASELINE configs[2] at the size `bench.py --workload c3` times: cart-pole dims (n_s = 4, n_u = 1), N = 5000, H = 15,
     65536 rollouts (983040 step evaluations).  Properties on ALL rows (finite, symmetric, positive definite shape
