@@ -37,5 +37,27 @@ print("%-60s %8s %16s %14s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct
 for name, calls, tot, avg, pct in sqlite3.connect(dbs[0]).execute("select * from top_kernels"):
     print("%-60s %8d %16.0f %14.1f %8.3f" % (name[:60], calls, tot * 1.0, avg * 1.0, pct))
 PY
+# kernel timeline of ONE N = 5000 model update (who waits for whom) and kernel trace of the chain benchmark
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$REPO/gpurun_out/prof_$TAG/tl5000" -o tl -- \
+    python "$REPO/scripts/timeline.py" run 5000 > "$EV/.tl.log" 2>&1 )
+python scripts/timeline.py show "$REPO/gpurun_out/prof_$TAG/tl5000" 400 > "$EV/${TAG}_timeline5000.txt" 2>>"$EV/.err"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_$TAG/chain" -o chain -- \
+    python "$REPO/scripts/chain_bench.py" > "$EV/.chaintrace.log" 2>&1 )
+python - "$REPO/gpurun_out/prof_$TAG/chain" > "$EV/${TAG}_chain_kernel_stats.txt" <<'PY'
+import glob, sqlite3, sys
+dbs = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)
+print("# rocprofv3 --kernel-trace --stats  (python scripts/chain_bench.py): persistent chain kernel against per-step launches")
+print("%-70s %8s %14s %12s" % ("kernel", "calls", "total_us", "avg_us"))
+for name, calls, tot, avg, pct in sqlite3.connect(dbs[0]).execute("select * from top_kernels"):
+    if "chain" in name or "small" in name or "ellipsoid" in name:
+        print("%-70s %8d %14.0f %12.1f" % (name[:70], calls, tot * 1.0, avg * 1.0))
+PY
+# per-kernel GPU time of the small-batch predict path at N = 5000
+for T in 1 16 32 64 128; do
+  ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_$TAG/lat/t$T" -o lat -- \
+      python "$REPO/scripts/latency_trace.py" run 5000 $T > "$EV/.lat_$T.log" 2>&1 )
+done
+{ echo "# per-kernel GPU time of predict at N = 5000 (rocprofv3 --kernel-trace --stats, 210 calls each; T = directory name)";
+  python scripts/latency_trace.py show "$REPO/gpurun_out/prof_$TAG/lat"; grep -h wall "$EV"/.lat_*.log; } > "$EV/${TAG}_latency_kernels.txt" 2>>"$EV/.err"
 ls -la "$EV"
 tail -n 5 "$EV/.err"
