@@ -77,25 +77,25 @@ __global__ __launch_bounds__(256) void sr_linearize_kernel(sr_lin_args a) {
         if (lane == 0) red[wave][q] = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot[NACC];
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) tot[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
-        int q = DT;
-#pragma unroll
-        for (int j = 0; j < DT; ++j) {
-            if (j < a.D) a.jac_var[d * a.D + j] = -2.0 * tot[j];
-#pragma unroll
-            for (int c = 0; c < DT; ++c)
-                if (c >= j) {
-                    if (j < a.D && c < a.D) {
-                        double hv = tot[q];
-                        if (c == j) hv -= tot[NACC - 1] * il2[j];
-                        a.hess_mu[((long)d * a.D + j) * a.D + c] = hv;
-                        a.hess_mu[((long)d * a.D + c) * a.D + j] = hv;
-                    }
-                    ++q;
+    // one thread per accumulator (thread 0 holding all NACC totals cost the D <= 12 instantiation 980 B of scratch per lane)
+    if (threadIdx.x < NACC - 1) {
+        const int t = threadIdx.x;
+        const double tot = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        if (t < DT) {
+            if (t < a.D) a.jac_var[d * a.D + t] = -2.0 * tot;
+        } else {
+            int e = t - DT, j = 0;
+            while (e >= DT - j) { e -= DT - j; ++j; }          // entry (j, c = j + e) of the DT-wide upper triangle
+            const int c = j + e;
+            if (j < a.D && c < a.D) {
+                double hv = tot;
+                if (c == j) {
+                    const double l = a.ls[d * a.D + j];
+                    hv -= (red[0][NACC - 1] + red[1][NACC - 1] + red[2][NACC - 1] + red[3][NACC - 1]) * (1.0 / (l * l));
                 }
+                a.hess_mu[((long)d * a.D + j) * a.D + c] = hv;
+                a.hess_mu[((long)d * a.D + c) * a.D + j] = hv;
+            }
         }
     }
 }

@@ -170,7 +170,10 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
     // registers throughout: there at most SR_CHAIN_HC steps (HC (DT + 1) doubles per lane) -- with half of the 16 steps
     // of Np = 512 hoisted the kernel needed 184 - 520 B of scratch per lane
     constexpr int HC0 = KSA <= 4 ? KSA : KSA / 2;
-    constexpr int HC = (NW == 16 || HC0 <= SR_CHAIN_HC) ? HC0 : ((KSA % SR_CHAIN_HC == 0) ? SR_CHAIN_HC : (KSA % 3 == 0 ? 3 : 2));
+    // (query width 8 in the one-launch kernels: 1024 threads = 128 registers per lane; four hoisted steps of 9 doubles each
+    //  beside xs / il made the LIN instantiations spill: 20 .. 116 B per lane)
+    constexpr int HC1 = (NW == 16 && DT >= 8 && HC0 > 2 && KSA % 2 == 0) ? 2 : HC0;
+    constexpr int HC = (NW == 16 || HC1 <= SR_CHAIN_HC) ? HC1 : ((KSA % SR_CHAIN_HC == 0) ? SR_CHAIN_HC : (KSA % 3 == 0 ? 3 : 2));
     static_assert(DT + 1 <= 16, "the mean/Jacobian right-hand side must fit the 16 MFMA columns");
     static_assert(NP % 128 == 0 && NP <= 512 && KSA % HC == 0 && KSA >= 1, "Np in {128, 256, 384, 512}");
     double (*ks)[SR_FQ] = L.ks;
@@ -890,15 +893,17 @@ __global__ __launch_bounds__(1024) void sr_gp_small_general_kernel(sr_kstar_args
     const double vv = kp[1], c0 = kp[2];
     const bool live = t0 + ln < a.T;
 
-    double x[DT], s2[DT], ax[DT], bx[DT];
+    // per lane: the query; the kernel parameters s_j^2, a_j, b_j are wavefront-uniform
+    double x[DT];
+    double s2[DT], av[DT], bv[DT];
 #pragma unroll
     for (int j = 0; j < DT; ++j) {
         x[j] = 0.0;
         if (live && j < a.D) x[j] = (j < a.na) ? a.xa[(t0 + ln) * a.lda + j] : a.xb[(t0 + ln) * a.ldb + (j - a.na)];
         const double sj = (j < a.D) ? kp[3 + j] : 0.0;
         s2[j] = sj * sj;
-        ax[j] = (j < a.D) ? kp[3 + a.D + j] * x[j] : 0.0;
-        bx[j] = (j < a.D) ? kp[3 + 2 * a.D + j] * x[j] : 0.0;
+        av[j] = (j < a.D) ? kp[3 + a.D + j] : 0.0;
+        bv[j] = (j < a.D) ? kp[3 + 2 * a.D + j] : 0.0;
     }
     sr_d4 acc[4];
 #pragma unroll
@@ -914,8 +919,8 @@ __global__ __launch_bounds__(1024) void sr_gp_small_general_kernel(sr_kstar_args
             const double z = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
             const double df = x[j] - z;
             r2 = fma(df * s2[j], df, r2);
-            la = fma(ax[j], z, la);
-            lb = fma(bx[j], z, lb);
+            la = fma(av[j] * x[j], z, la);
+            lb = fma(bv[j] * x[j], z, lb);
             if (ln == j + 1) bfrag = al * z;
         }
         double kap, g;
