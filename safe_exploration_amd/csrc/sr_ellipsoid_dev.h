@@ -16,22 +16,19 @@
 template <int NS, int NU>
 __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
                                                    const double (&kfb)[NU][NS]) {
-    double B[NS][NS];
+    // B[i][j] = delta_ij + sum_u K[u][i] K[u][j], formed where the factorisation consumes it (never stored)
+    auto Bij = [&](int i, int j) {
+        double s = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) s = fma(kfb[u][i], kfb[u][j], s);
-            B[i][j] = s;
-        }
-    if (NS == 1) return q[0][0] * B[0][0];
+        for (int u = 0; u < NU; ++u) s = fma(kfb[u][i], kfb[u][j], s);
+        return s;
+    };
+    if (NS == 1) return q[0][0] * Bij(0, 0);
     // lower Cholesky of B
     double L[NS][NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        double s = B[j][j];
+        double s = Bij(j, j);
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
         const double ljj = sqrt(s);
@@ -40,7 +37,7 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             if (i > j) {
-                double v = B[i][j];
+                double v = Bij(i, j);
 #pragma unroll
                 for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
                 L[i][j] = v * inv;
@@ -49,7 +46,9 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
             }
         }
     }
-    // M = L^T Q L
+    // M = L^T Q L, upper triangle only (M[i][j], j >= i: the entries below the diagonal are never formed -- half the
+    // registers and half the work of the rotations below; at n_s = 8 the full matrix beside Q, L, Q L and the caller's
+    // H Q H^T was what spilled)
     double QL[NS][NS], M[NS][NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -64,30 +63,27 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-                if (k >= i) s = fma(L[k][i], QL[k][j], s);
-            M[i][j] = s;
-        }
-    // symmetrise (Q is symmetric by contract; removes rounding asymmetry)
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
         for (int j = 0; j < NS; ++j)
-            if (j > i) { const double m = 0.5 * (M[i][j] + M[j][i]); M[i][j] = m; M[j][i] = m; }
+            if (j >= i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+                    if (k >= i) s = fma(L[k][i], QL[k][j], s);
+                M[i][j] = s;
+            }
     if (NS == 2) {
         const double tr = M[0][0] + M[1][1];
         const double df = M[0][0] - M[1][1];
         return 0.5 * (tr + sqrt(fma(df, df, 4.0 * M[0][1] * M[0][1])));
     }
-    // cyclic Jacobi (eigenvalues only).  Stops when the squared off-diagonal norm is below 1e-26 of the squared
-    // diagonal norm: the eigenvalue error is bounded by off^2 / (2 gap), i.e. far below one ulp unless two eigenvalues
-    // agree to 13 digits -- and then by their difference.  One rotation costs one sqrt, one division and one rsqrt:
-    //   t = sgn(d) 2 a / (|d| + sqrt(d^2 + 4 a^2)),  d = M_rr - M_pp, a = M_pr;   c = 1 / sqrt(1 + t^2),  s = t c
+    // cyclic Jacobi (eigenvalues only) on the upper triangle.  Stops when the squared off-diagonal norm is below 1e-26 of
+    // the squared diagonal norm: the eigenvalue error is bounded by off^2 / (2 gap), i.e. far below one ulp unless two
+    // eigenvalues agree to 13 digits -- and then by their difference.  One rotation costs one sqrt, one division and one
+    // rsqrt:   t = sgn(d) 2 a / (|d| + sqrt(d^2 + 4 a^2)),  d = M_rr - M_pp, a = M_pr;   c = 1 / sqrt(1 + t^2),  s = t c,
+    //          M_pp -= t a,  M_rr += t a,  M_pr = 0,  (M_kp, M_kr) <- (c M_kp - s M_kr, s M_kp + c M_kr)  for k != p, r
     // (the textbook form through theta = d / 2a takes two square roots and three divisions; on one lane per query the
-    // rotations are the whole cost of the step for n_s >= 3: 10 us per step inside the persistent chain kernel).
+    // rotations are the whole cost of the step for n_s >= 3).
+#define SR_SYM(i, j) M[(i) < (j) ? (i) : (j)][(i) < (j) ? (j) : (i)]
     for (int sweep = 0; sweep < 24; ++sweep) {
         double off = 0.0, dia = 0.0;
 #pragma unroll
@@ -111,22 +107,22 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
                         const double tt = ((dd >= 0.0) ? two_a : -two_a) / den;
                         const double c = rsqrt(fma(tt, tt, 1.0));
                         const double s = tt * c;
+                        M[p][p] = fma(-tt, apr, M[p][p]);
+                        M[r][r] = fma(tt, apr, M[r][r]);
+                        M[p][r] = 0.0;
 #pragma unroll
-                        for (int k = 0; k < NS; ++k) {   // columns p, r
-                            const double mkp = M[k][p], mkr = M[k][r];
-                            M[k][p] = c * mkp - s * mkr;
-                            M[k][r] = s * mkp + c * mkr;
-                        }
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) {   // rows p, r
-                            const double mpk = M[p][k], mrk = M[r][k];
-                            M[p][k] = c * mpk - s * mrk;
-                            M[r][k] = s * mpk + c * mrk;
+                        for (int k = 0; k < NS; ++k) {
+                            if (k != p && k != r) {
+                                const double mkp = SR_SYM(k, p), mkr = SR_SYM(k, r);
+                                SR_SYM(k, p) = c * mkp - s * mkr;
+                                SR_SYM(k, r) = s * mkp + c * mkr;
+                            }
                         }
                     }
                 }
             }
     }
+#undef SR_SYM
     double lam = M[0][0];
 #pragma unroll
     for (int i = 1; i < NS; ++i) lam = fmax(lam, M[i][i]);
@@ -181,16 +177,29 @@ __device__ __forceinline__ void sr_ellipsoid_one(const sr_ell_args& a, long t) {
         return;
     }
 
-    double q[NS][NS], kfb[NU][NS], H[NS][NS];
+    double q[NS][NS], H[NS][NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int j = 0; j < NS; ++j) q[i][j] = a.q[t * a.ldq + i * NS + j];
+
+    // remainder radius first: lambda_max(Q (I + K^T K)) needs Q, L, Q L and M at once -- computed before H Q H^T exists,
+    // the step stays in registers up to n_s = 7 (n_s = 8: see profiles/r03_kernel_resources.txt)   (:125-137, utils.py:129-142)
+    // (the feedback matrix is fetched twice -- here and for H below -- rather than held across the eigenvalue iteration)
+    double r2 = 0.0;
+    if (a.mode == 0) {
+        double kfb0[NU][NS];
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) kfb0[k][j] = a.k_fb[t * a.ldkfb + k * NS + j];
+        r2 = sr_lambda_max_qb<NS, NU>(q, kfb0);
+    }
+    double kfb[NU][NS];
 #pragma unroll
     for (int k = 0; k < NU; ++k)
 #pragma unroll
         for (int j = 0; j < NS; ++j) kfb[k][j] = a.k_fb[t * a.ldkfb + k * NS + j];
-
     // H = a + a_mu + (b_mu + b) k_fb                          (gp_reachability.py:110-114)
     // (mean-equivalent propagation drops the Jacobian terms: H = a + b k_fb)
     const double* jac = a.jac + t * NS * D;
@@ -208,28 +217,28 @@ __device__ __forceinline__ void sr_ellipsoid_one(const sr_ell_args& a, long t) {
             H[i][j] = s;
         }
     }
-    // Q0 = H Q H^T                                            (:117)
-    double HQ[NS][NS], Q0[NS][NS];
+    // Q0 = H Q H^T, one row of H Q at a time                   (:117)
+    double Q0[NS][NS];
+    double trQ0 = 0.0;
 #pragma unroll
-    for (int i = 0; i < NS; ++i)
+    for (int i = 0; i < NS; ++i) {
+        double hq[NS];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < NS; ++k) s = fma(H[i][k], q[k][j], s);
-            HQ[i][j] = s;
+            hq[j] = s;
         }
-    double trQ0 = 0.0;
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < NS; ++k) s = fma(HQ[i][k], H[j][k], s);
+            for (int k = 0; k < NS; ++k) s = fma(hq[k], H[j][k], s);
             Q0[i][j] = s;
             if (i == j) trQ0 += s;
         }
+    }
     if (a.mode != 0) {
         // Gaussian moment propagation: [a b I] Sigma_all [a b I]^T collapses to H Sigma H^T + diag(var)
         // (uncertainty_propagation_casadi.py:57-87 with the Jacobian cross terms, :260-283 without)
@@ -240,7 +249,6 @@ __device__ __forceinline__ void sr_ellipsoid_one(const sr_ell_args& a, long t) {
         return;
     }
     // remainder boxes                                          (:125-137, utils.py:129-142)
-    const double r2 = sr_lambda_max_qb<NS, NU>(q, kfb);
     const double r1 = sqrt(r2);
     double dL[NS], dM[NS];
     double trS = 0.0, trM = 0.0;
