@@ -351,28 +351,32 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 // uncertainty_propagation_casadi.py:88-190 through `mode`).
 //
 // Launched per step the chain costs two dependent launches per step (posterior 10.7 us + ellipsoid 4.7 us at N = 200:
-// 0.23 ms for H = 15), much of it launch latency.  Here workgroup (g, d, part) owns, for ALL steps, output d of the 16
-// rollouts of group g and P = Np / 128 workgroups share the contraction with U^-1 of one (g, d):
-//     once:    everything that does not change from step to step is fetched: the wavefront's fragments of U^-1 into
-//              REGISTERS (2 (Np / 16 + 1) doubles per lane; 8 wavefronts per workgroup = 256 VGPRs per lane), the
-//              training rows of phase A into registers where they fit,
-//              the group's control sequence and the constants of the ellipsoid step into LDS
-//     step i:  phase A at [p_i, k_ff_i] (all parts: k* is needed in full)
-//              phase B on the part's 4 strip pairs (strips s and Np/16-1-s; 2 wavefronts per pair, each half of the
-//              k range: 2 (Np / 16 + 1) MFMAs per wavefront whatever the pair), squared and summed per rollout
-//              (mu, d mu/dx)[d] from part 0 and every part's share of |U^-T k*|^2 -> exchange buffer, agent-scope
-//              stores; the group's ticket += 1
-//              wait until the ticket shows all n_out P workgroups of step i, read their results (agent-scope loads)
-//              ellipsoid step of the 16 rollouts, one lane each, state (p, Q) kept in LDS   (sr_ellipsoid_one)
-// Every workgroup of a group runs the (cheap) ellipsoid step itself, so that one hand-off per step is enough;
-// workgroup (d, part) = (0, 0) writes the results.  The exchange buffer is double-buffered by step parity: a
-// workgroup can only be one step ahead of the slowest one of its group.  No fences: payload and ticket are agent-scope
-// (write-through) accesses and the ticket is bumped after s_waitcnt vmcnt(0) + barrier (the protocol of
-// sr_stream.hip).  All groups x n_out x P workgroups must be resident at once (<= SR_CHAIN_GROUPS, one per CU; other
-// work on the device only delays them); a wait that does not end within 10 s poisons the outputs with NaN instead of
-// hanging the device.
-// Measured per step at N = 200 (in-kernel clock): first version (one workgroup per (g, d), U^-1 fragments from L2 every
-// step) posterior 8.1 us + hand-off 2.0 + ellipsoid 1.4 + output 0.5.
+// 0.23 ms for H = 15), much of it launch latency.  Here a group of 16 rollouts is served, for ALL steps, by
+//   n_out x P POSTERIOR workgroups (g, d, part): output d, P = Np / 128 of them sharing the contraction with U^-1 of one
+//        (g, d).  Fetched once: the wavefront's fragments of U^-1 into REGISTERS (2 (Np / 16 + 1) doubles per lane; 8
+//        wavefronts per workgroup = 256 VGPRs per lane), the training rows of phase A and 1 / l into LDS, the group's
+//        feed-forward controls into LDS.  Per step i:
+//            phase A at [p_i, k_ff_i] (all parts: k* is needed in full)
+//            part 0: (mu, d mu/dx)[d] -> exchange buffer      (BEFORE the contraction: they do not depend on it)
+//            phase B on the part's 4 strip pairs (strips s and Np/16-1-s; 2 wavefronts per pair, each half of the k range:
+//                2 (Np / 16 + 1) MFMAs per wavefront whatever the pair), squared and summed per rollout
+//            the part's share of |U^-T k*|^2 -> exchange buffer
+//            poll the means of ALL outputs of step i, move the centres: p_{i+1} = a p_i + b u_i + mu
+//   one TAIL workgroup: polls (mu, d mu/dx, shares of |U^-T k*|^2) of every step as they appear, runs the ellipsoid step of
+//        the 16 rollouts (sr_ellipsoid_one, one lane each, state (p, Q) in LDS), writes p_all / q_all.
+// The centres do not depend on the shape matrices, so the posterior workgroups never wait for an ellipsoid step (n_s = 4:
+// 8 us of Jacobi rotations): the Q chain trails the chain of centres.
+// Exchange: every element is 16 bytes (value, bits(value) ^ mix(tag)), tag = the group's epoch + step + 1, written by ONE
+// agent-scope store and read by one agent-scope load; a reader polls until value and check word agree for this step's
+// tag.  No ticket, no fence, no wait for the stores to be acknowledged; every (step, output) has its own slot, so
+// nothing is overwritten inside a launch; the epoch lives on the device (a captured launch can be replayed).
+// All groups x (n_out P + 1) workgroups of a launch must be resident at once (<= SR_CHAIN_GROUPS, one per CU; other work
+// on the device only delays them); a poll that does not end within SR_CHAIN_TIMEOUT_TICKS (100 ms) raises the status
+// word and poisons the group's outputs with NaN instead of hanging the device.
+// (n_out = 1 with Np = 128 needs no exchange: one workgroup does everything.)
+// History, per 15-step chain of 256 rollouts at N = 200: per-step launches 241 us; one workgroup per (g, d), U^-1 from L2
+// every step 188; fragments in registers, tickets, ellipsoid step in every workgroup 148; tagged elements 128; tail
+// workgroup + mean published before the contraction 102.
 // ------------------------------------------------------------------------------------------------
 #define SR_CHAIN_PARTS(NP) ((NP) / 128)
 #define SR_CHAIN_NW 8                /* wavefronts per workgroup: 256 registers per lane, room for the U^-1 fragments */
