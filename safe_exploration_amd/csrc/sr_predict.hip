@@ -17,33 +17,46 @@
 // address (broadcast).  K* stores: 64 consecutive queries per wavefront = 512 B contiguous.
 // ------------------------------------------------------------------------------------------------
 #define SR_ZT 256
-template <int DT>
+// QPT queries per thread (t, t + 256, ..): the workgroup's stores of a row are one contiguous run of QPT x 2 KiB, the
+// LDS reads of the training row are shared by QPT kernel evaluations, and QPT independent exp chains interleave.
+template <int DT, int QPT>
 __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
     __shared__ double zs[SR_ZT * DT];
     __shared__ double al[SR_ZT];
     const int d = blockIdx.y, sp = blockIdx.z;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = t < a.T;
-    const bool inpad = t < (a.Tw ? a.Tw : a.Tp);
-
-    double inv_l[DT], xs[DT], g[DT];
+    const long tb = (long)blockIdx.x * 256 * QPT + threadIdx.x;
+    const long tpad = a.Tw ? a.Tw : a.Tp;
+    bool live[QPT], inpad[QPT], any = false;
 #pragma unroll
-    for (int j = 0; j < DT; ++j) {
-        inv_l[j] = (j < a.D) ? 1.0 / a.ls[d * a.D + j] : 0.0;
-        double x = 0.0;
-        if (live && j < a.D)
-            x = (j < a.na) ? a.xa[t * a.lda + j] : a.xb[t * a.ldb + (j - a.na)];
-        xs[j] = x * inv_l[j];
-        g[j] = 0.0;
+    for (int q = 0; q < QPT; ++q) {
+        live[q] = tb + 256 * q < a.T;
+        inpad[q] = tb + 256 * q < tpad;
+        any |= inpad[q];
+    }
+
+    double inv_l[DT], xs[QPT][DT], g[QPT][DT], mu[QPT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) inv_l[j] = (j < a.D) ? 1.0 / a.ls[d * a.D + j] : 0.0;
+#pragma unroll
+    for (int q = 0; q < QPT; ++q) {
+        const long t = tb + 256 * q;
+        mu[q] = 0.0;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            double x = 0.0;
+            if (live[q] && j < a.D)
+                x = (j < a.na) ? a.xa[t * a.lda + j] : a.xb[t * a.ldb + (j - a.na)];
+            xs[q][j] = x * inv_l[j];
+            g[q][j] = 0.0;
+        }
     }
     const double sf2 = a.sf2[d];
-    double mu = 0.0;
 
     const int off = a.Np - a.N;
     const int rows_per = (a.Np + a.nsplit - 1) / a.nsplit;
     const int i_beg = sp * rows_per;
     const int i_end = min(a.Np, i_beg + rows_per);
-    double* ks_col = a.Ks + (long)d * a.Np * a.Tp + t;
+    double* ks_col = a.Ks + (long)d * a.Np * a.Tp + tb;
 
     for (int i0 = i_beg; i0 < i_end; i0 += SR_ZT) {
         const int nrow = min(SR_ZT, i_end - i0);
@@ -59,32 +72,45 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
         }
         __syncthreads();
         const int rpad = min(nrow, max(0, off - i0));     // leading padding rows of this tile
-        if (inpad) {
-            for (int r = 0; r < rpad; ++r) ks_col[(long)(i0 + r) * a.Tp] = 0.0;
+        if (any) {
+            for (int r = 0; r < rpad; ++r)
+#pragma unroll
+                for (int q = 0; q < QPT; ++q)
+                    if (inpad[q]) ks_col[(long)(i0 + r) * a.Tp + 256 * q] = 0.0;
             for (int r = rpad; r < nrow; ++r) {
-                double diff[DT];
-                double r2 = 0.0;
+                double z[DT];
 #pragma unroll
-                for (int j = 0; j < DT; ++j) {
-                    diff[j] = xs[j] - zs[r * DT + j];
-                    r2 = fma(diff[j], diff[j], r2);
+                for (int j = 0; j < DT; ++j) z[j] = zs[r * DT + j];
+                const double alr = al[r];
+#pragma unroll
+                for (int q = 0; q < QPT; ++q) {
+                    double diff[DT];
+                    double r2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) {
+                        diff[j] = xs[q][j] - z[j];
+                        r2 = fma(diff[j], diff[j], r2);
+                    }
+                    const double k = live[q] ? sf2 * exp(-0.5 * r2) : 0.0;
+                    if (inpad[q]) ks_col[(long)(i0 + r) * a.Tp + 256 * q] = k;
+                    const double w = k * alr;
+                    mu[q] += w;
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) g[q][j] = fma(-w, diff[j], g[q][j]);
                 }
-                const double k = live ? sf2 * exp(-0.5 * r2) : 0.0;
-                ks_col[(long)(i0 + r) * a.Tp] = k;
-                const double w = k * al[r];
-                mu += w;
-#pragma unroll
-                for (int j = 0; j < DT; ++j) g[j] = fma(-w, diff[j], g[j]);
             }
         }
     }
-    if (inpad) {
-        a.mu_part[((long)sp * a.n_out + d) * a.Tp + t] = mu;
 #pragma unroll
-        for (int j = 0; j < DT; ++j)
-            if (j < a.D)
-                a.jac_part[(((long)sp * a.n_out + d) * a.D + j) * a.Tp + t] = g[j] * inv_l[j];
-    }
+    for (int q = 0; q < QPT; ++q)
+        if (inpad[q]) {
+            const long t = tb + 256 * q;
+            a.mu_part[((long)sp * a.n_out + d) * a.Tp + t] = mu[q];
+#pragma unroll
+            for (int j = 0; j < DT; ++j)
+                if (j < a.D)
+                    a.jac_part[(((long)sp * a.n_out + d) * a.D + j) * a.Tp + t] = g[q][j] * inv_l[j];
+        }
 }
 
 // K1g: the same pass for the general kernel family of sr_common.h (Matern-5/2, linear x stationary +
@@ -198,7 +224,17 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s) {
         return SR_OK;
     }
 #define SR_KSTAR_CASE(DT) \
-    hipLaunchKernelGGL(sr_kstar_kernel<DT>, grid, dim3(256), 0, s, a)
+    hipLaunchKernelGGL((sr_kstar_kernel<DT, 1>), grid, dim3(256), 0, s, a)
+    // big batches: two queries per thread (65536 queries at N = 5000: 1.32 -> 1.19 ms; four: 1.32 -- the registers
+    // of four exp chains cost the occupancy what the sharing buys)
+    if (a.D <= 5 && (a.Tw ? a.Tw : a.Tp) >= 8192) {
+        const long tpad = a.Tw ? a.Tw : a.Tp;
+        dim3 g2((unsigned)((tpad + 511) / 512), a.n_out, a.nsplit);
+        if (a.D <= 3) hipLaunchKernelGGL((sr_kstar_kernel<3, 2>), g2, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((sr_kstar_kernel<5, 2>), g2, dim3(256), 0, s, a);
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
     if (a.D <= 3) SR_KSTAR_CASE(3);
     else if (a.D <= 5) SR_KSTAR_CASE(5);
     else if (a.D <= 8) SR_KSTAR_CASE(8);
