@@ -348,15 +348,16 @@ int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, doubl
 // then needs no host copy of the hyper-parameters before its first launch.  Thread = 4 rows x 1 column: the column's
 // scaled coordinates are loaded once per 4 entries, and the scaling is a multiplication by 1 / l (computed once per
 // thread; the division per entry and dimension was a third of the kernel's time).
+#define SR_GRAM_ROWS 32
 __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__ Z,
                                                       const double* __restrict__ ls, double sf2,
                                                       double noise, const double* __restrict__ sf2_dev,
                                                       const double* __restrict__ noise_dev,
                                                       double* __restrict__ K, int N, int Np, int D, long strideK) {
-    const int i0 = blockIdx.y * 4;
+    __shared__ double zs[SR_GRAM_ROWS][SR_MAX_D];
+    const int i0 = blockIdx.y * SR_GRAM_ROWS;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Np) return;
-    if ((j | 127) < i0) return;              // blocks left of the diagonal are never read (upper factorisation)
+    if (((blockIdx.x * 256 + 255) | 127) < i0) return;   // blocks left of the diagonal are never read (upper factorisation)
     const int b = blockIdx.z;                // batch member (output)
     ls += (long)b * D;
     K += (long)b * strideK;
@@ -366,10 +367,16 @@ __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__
     double il[SR_MAX_D], zj[SR_MAX_D];
     for (int c = 0; c < D; ++c) {
         il[c] = 1.0 / ls[c];
-        zj[c] = (j >= off) ? Z[(long)(j - off) * D + c] * il[c] : 0.0;
+        zj[c] = (j < Np && j >= off) ? Z[(long)(j - off) * D + c] * il[c] : 0.0;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    // the rows of this tile, scaled, in LDS (broadcast reads)
+    for (int e = threadIdx.x; e < SR_GRAM_ROWS * D; e += 256) {
+        const int r = e / D, c = e % D, i = i0 + r;
+        zs[r][c] = (i < Np && i >= off) ? Z[(long)(i - off) * D + c] * (1.0 / ls[c]) : 0.0;
+    }
+    __syncthreads();
+    if (j >= Np || (j | 127) < i0) return;
+    for (int u = 0; u < SR_GRAM_ROWS; ++u) {
         const int i = i0 + u;
         if (i >= Np) break;
         double v;
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__
         } else {
             double r2 = 0.0;
             for (int c = 0; c < D; ++c) {
-                const double t = fma(Z[(long)(i - off) * D + c], il[c], -zj[c]);
+                const double t = zs[u][c] - zj[c];
                 r2 = fma(t, t, r2);
             }
             v = sf2 * exp(-0.5 * r2);
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__
 
 int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, const double* sf2_dev,
                    const double* noise_dev, double* K, int N, int Np, int D, hipStream_t s, int nbatch, long strideK) {
-    dim3 grid((Np + 255) / 256, (Np + 3) / 4, nbatch);
+    dim3 grid((Np + 255) / 256, (Np + SR_GRAM_ROWS - 1) / SR_GRAM_ROWS, nbatch);
     hipLaunchKernelGGL(sr_gram_kernel, grid, dim3(256), 0, s, Z, ls, sf2, noise, sf2_dev, noise_dev, K, N, Np, D, strideK);
     SR_HIP(hipGetLastError());
     return SR_OK;
@@ -1252,9 +1259,12 @@ __global__ __launch_bounds__(256) void sr_trmv_kernel(const double* __restrict__
                                                       const double* __restrict__ x,
                                                       double* __restrict__ y, int n, int lower, long sM, long sx,
                                                       long sy) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // longest rows first (a row is one wavefront's chain of dependent load batches: scheduled last, the 5120-element
+    // rows of a lower triangle were the tail of the launch)
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (slot >= n) return;
+    const int row = lower ? n - 1 - slot : slot;
     M += (long)blockIdx.y * sM; x += (long)blockIdx.y * sx; y += (long)blockIdx.y * sy;
     const int c0 = lower ? 0 : row, c1 = lower ? row + 1 : n;
     const double* m = M + (long)row * ld;
