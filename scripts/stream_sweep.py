@@ -10,7 +10,7 @@ Ts = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "8,16,32,64,96,128"
 print("KC=%s MAX_T=%s" % (os.environ.get("SR_STREAM_KC"), os.environ.get("SR_STREAM_MAX_T")))
 print("%6s" % "N" + "".join("%8s" % ("T=%d" % t) for t in Ts))
 for N in Ns:
-    prob = workload.make_problem(9, N, 2, 1, 256, sf2=0.01)
+    prob = workload.make_problem(9, N, 2, 1, max(256, max(Ts)), sf2=0.01)
     gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob), device="cuda:0")
     gp.train(prob["Z"], prob["Y"], opt_hyp=False)
     row = []
