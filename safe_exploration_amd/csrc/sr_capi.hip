@@ -5,6 +5,7 @@
 #include "sr_mfma_tile.h"
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <algorithm>
@@ -112,6 +113,13 @@ static int dev_alloc(T** p, size_t count) {
     return SR_OK;
 }
 static void dev_free(void* p) { if (p) (void)hipFree(p); }
+// Zero a freshly allocated buffer and WAIT: a memset on the null stream is not ordered with the launches that follow on a
+// caller's non-blocking stream (first-use paths only; never inside a stream capture).
+static int dev_zero(void* p, size_t bytes) {
+    SR_HIP(hipMemset(p, 0, bytes));
+    SR_HIP(hipStreamSynchronize(nullptr));
+    return SR_OK;
+}
 
 extern "C" int sr_version(void) { return 100; }
 extern "C" const char* sr_last_error(void) { return g_err; }
@@ -243,7 +251,7 @@ static int ensure_wt(sr_gp* h) {
     if (!h->Wt) {
         SR_TRY(dev_alloc(&h->Wt, (size_t)h->n_out * h->Np * h->Np));
         // the strict lower triangle of U^-1 is never written by the factorisation: zero it once
-        SR_HIP(hipMemset(h->Wt, 0, sizeof(double) * h->n_out * h->Np * h->Np));
+        SR_TRY(dev_zero(h->Wt, sizeof(double) * h->n_out * h->Np * h->Np));
     }
     return SR_OK;
 }
@@ -918,7 +926,7 @@ static int stream_buffers(sr_gp* h, int ncols, hipStream_t s) {
     if (!h->stream_tickets) {
         const int n = sr_stream_tickets(h->Np, h->n_out);
         SR_TRY(dev_alloc(&h->stream_tickets, (size_t)n));
-        SR_HIP(hipMemset(h->stream_tickets, 0, sizeof(unsigned) * n));
+        SR_TRY(dev_zero(h->stream_tickets, sizeof(unsigned) * n));
     }
     return SR_OK;
 }
@@ -1066,7 +1074,7 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
             dev_free(h->sk_tickets);
             h->sk_tickets = nullptr; h->sk_tickets_cap = 0;
             SR_TRY(dev_alloc(&h->sk_tickets, (size_t)ntk));
-            SR_HIP(hipMemset(h->sk_tickets, 0, sizeof(unsigned) * ntk));
+            SR_TRY(dev_zero(h->sk_tickets, sizeof(unsigned) * ntk));
             h->sk_tickets_cap = ntk;
         }
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
@@ -1314,6 +1322,35 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
     return SR_OK;
 }
 
+// Persistent chain launches of one device never overlap, whichever handle or stream they come from: each needs (almost)
+// every CU resident at once, two of them side by side would wait for each other's workgroups until the time-out.  Every
+// launch waits for the event the previous one recorded (per device, process-wide) and records its own.  Not while the
+// caller's stream is being captured into a graph (a cross-stream wait on an uncaptured event is not capturable): a
+// captured chain is ordered by its graph.
+struct sr_chain_gate { std::mutex m; hipEvent_t ev[32] = {}; };
+static sr_chain_gate g_chain_gate;
+struct sr_chain_turn {                 // holds the gate from the wait to the record: host threads take turns too
+    int device; hipStream_t s; bool active = false;
+    sr_chain_turn(int device_, hipStream_t s_) : device(device_), s(s_) {}
+    int enter() {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        const hipError_t ce = hipStreamIsCapturing(s, &st);
+        const bool capturing = (ce == hipSuccess && st != hipStreamCaptureStatusNone);
+        if (capturing || device < 0 || device >= 32) return SR_OK;
+        g_chain_gate.m.lock();
+        active = true;
+        if (g_chain_gate.ev[device]) SR_HIP(hipStreamWaitEvent(s, g_chain_gate.ev[device], 0));
+        return SR_OK;
+    }
+    int leave() {
+        if (!active) return SR_OK;
+        if (!g_chain_gate.ev[device]) SR_HIP(hipEventCreateWithFlags(&g_chain_gate.ev[device], hipEventDisableTiming));
+        SR_HIP(hipEventRecord(g_chain_gate.ev[device], s));
+        return SR_OK;
+    }
+    ~sr_chain_turn() { if (active) g_chain_gate.m.unlock(); }
+};
+
 // The persistent kernel of sr_small.hip (K0c) for a chain of H >= 1 steps, where it applies; *taken says whether it ran.
 static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const double* q0, const double* k_fb0,
                      const double* k_ff, const double* k_fb, const double* a, const double* b, const double* l_mu,
@@ -1370,13 +1407,14 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
             SR_HIP(hipHostMalloc((void**)&h->chain_status_host, sizeof(int), hipHostMallocMapped));
             *h->chain_status_host = 0;
             SR_HIP(hipHostGetDevicePointer((void**)&h->chain_status_dev, h->chain_status_host, 0));
-            // (first use only: a blocking memset -- not inside a stream capture)
             SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_XELS));
             SR_TRY(dev_alloc(&h->chain_tickets, (size_t)2 * SR_CHAIN_GROUPS));
             SR_TRY(dev_alloc(&h->chain_done, (size_t)SR_CHAIN_GROUPS));
-            SR_HIP(hipMemset(h->chain_xch, 0, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS));     // tag 0 = never written
-            SR_HIP(hipMemset(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
-            SR_HIP(hipMemset(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS));
+            // ON THE CALLER'S STREAM: a memset on the null stream is not ordered with a launch on a non-blocking stream --
+            // it wiped tags the first launch had already written (41 MB take 20 us) and that launch timed out
+            SR_HIP(hipMemsetAsync(h->chain_xch, 0, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS, s));     // tag 0 = never written
+            SR_HIP(hipMemsetAsync(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS, s));
+            SR_HIP(hipMemsetAsync(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS, s));
         }
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         for (long t0 = 0; t0 < T; t0 += (long)gmax * SR_SMALL_T) {
@@ -1395,7 +1433,10 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
             ca.epoch = h->chain_tickets; ca.alive = h->chain_tickets + SR_CHAIN_GROUPS; ca.done = h->chain_done;
             ca.status = h->chain_status_dev;
             ca.test_drop = h->chain_test_drop;
+            sr_chain_turn turn(h->device, s);
+            SR_TRY(turn.enter());
             SR_TRY(sr_launch_chain(ca, s));
+            SR_TRY(turn.leave());
             (void)groups;
         }
         h->last_chain = 1;
@@ -1665,7 +1706,7 @@ extern "C" int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, do
     hipStream_t s = (hipStream_t)stream;
     if (!h->call_ticket) {
         SR_TRY(dev_alloc(&h->call_ticket, 1));
-        SR_HIP(hipMemset(h->call_ticket, 0, sizeof(unsigned)));
+        SR_TRY(dev_zero(h->call_ticket, sizeof(unsigned)));
     }
     double* out = nullptr;
     unsigned long long* flag = nullptr;
@@ -1762,9 +1803,9 @@ extern "C" int sr_test_chain_drop(sr_gp_t h, int drop) {
         // (in the field every workgroup runs, however late, and the last one to leave resynchronises the group)
         SR_DEVICE(h->device);
         SR_HIP(hipDeviceSynchronize());
-        SR_HIP(hipMemset(h->chain_xch, 0, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS));
-        SR_HIP(hipMemset(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
-        SR_HIP(hipMemset(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS));
+        SR_TRY(dev_zero(h->chain_xch, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS));
+        SR_TRY(dev_zero(h->chain_tickets, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
+        SR_TRY(dev_zero(h->chain_done, sizeof(unsigned) * SR_CHAIN_GROUPS));
     }
     return SR_OK;
 }

@@ -1523,6 +1523,42 @@ def test_persistent_chain_timeout_is_reported_not_silent():
         np.testing.assert_allclose(q3, q_ref, rtol=1e-7, atol=1e-14)
 
 
+def test_persistent_chains_of_two_models_on_two_streams_take_turns():
+    """Two handles, two streams, chains issued back to back without synchronising: each persistent launch needs (almost)
+    every CU resident, so launches of one device wait for each other (an event gate in the library) instead of waiting
+    for each other's workgroups until the time-out.  Every result must be right and nothing may time out."""
+    import torch
+    from safe_exploration_amd import gp_reachability as reach, _buffers as B
+    models, args, refs = [], [], []
+    for seed, (n_s, N) in enumerate(((2, 200), (4, 150))):
+        n_u, T, H = 1, 256, 12
+        syn = orc.make_synthetic(900 + seed, N, n_s, n_u, T)
+        gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+        rng = np.random.default_rng(seed)
+        l = np.linspace(0.005, 0.008, n_s)
+        a, b = 0.6 * np.eye(n_s), 0.1 * rng.standard_normal((n_s, n_u))
+        dev = gp.device
+        t_args = (B.as_dev(syn["p"], dev), gp, B.as_dev(0.1 * rng.standard_normal((T, H - 1, n_u, n_s)), dev),
+                  B.as_dev(0.3 * rng.standard_normal((T, H, n_u)), dev), l, l, None, 2.0, a, b)
+        models.append(gp)
+        args.append(t_args)
+        out = reach.multistep_reachability_batch(*t_args)
+        torch.cuda.synchronize()
+        assert gp.last_chain
+        refs.append((out[0].clone(), out[1].clone()))
+    streams = [torch.cuda.Stream(device=models[0].device) for _ in range(2)]
+    outs = [[], []]
+    for rep in range(20):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(reach.multistep_reachability_batch(*args[k]))
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert not reach.chain_timed_out(models[k]._handle, models[k].device)
+        for p_all, q_all in outs[k]:
+            assert torch.equal(p_all, refs[k][0]) and torch.equal(q_all, refs[k][1])
+
+
 def test_persistent_chain_beside_a_saturating_stream():
     """The chain kernel's workgroups wait for each other; while another stream keeps every CU busy (the 47 ms contraction
     of a 65536-query batch on an N = 5000 model) they may become resident late.  Whatever happens must be either the right
