@@ -1327,7 +1327,7 @@ extern "C" int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double
 // launch waits for the event the previous one recorded (per device, process-wide) and records its own.  Not while the
 // caller's stream is being captured into a graph (a cross-stream wait on an uncaptured event is not capturable): a
 // captured chain is ordered by its graph.
-struct sr_chain_gate { std::mutex m; hipEvent_t ev[32] = {}; };
+struct sr_chain_gate { std::mutex m; hipEvent_t ev[32] = {}; hipStream_t last[32] = {}; bool any[32] = {}; };
 static sr_chain_gate g_chain_gate;
 struct sr_chain_turn {                 // holds the gate from the wait to the record: host threads take turns too
     int device; hipStream_t s; bool active = false;
@@ -1339,13 +1339,16 @@ struct sr_chain_turn {                 // holds the gate from the wait to the re
         if (capturing || device < 0 || device >= 32) return SR_OK;
         g_chain_gate.m.lock();
         active = true;
-        if (g_chain_gate.ev[device]) SR_HIP(hipStreamWaitEvent(s, g_chain_gate.ev[device], 0));
+        // (the previous launch on the SAME stream is ordered by the stream itself)
+        if (g_chain_gate.ev[device] && !(g_chain_gate.any[device] && g_chain_gate.last[device] == s))
+            SR_HIP(hipStreamWaitEvent(s, g_chain_gate.ev[device], 0));
         return SR_OK;
     }
     int leave() {
         if (!active) return SR_OK;
         if (!g_chain_gate.ev[device]) SR_HIP(hipEventCreateWithFlags(&g_chain_gate.ev[device], hipEventDisableTiming));
         SR_HIP(hipEventRecord(g_chain_gate.ev[device], s));
+        g_chain_gate.last[device] = s; g_chain_gate.any[device] = true;
         return SR_OK;
     }
     ~sr_chain_turn() { if (active) g_chain_gate.m.unlock(); }
