@@ -40,6 +40,23 @@ def test_comm_library_exports_every_declared_symbol(lib_built):
         assert hasattr(comm, name), "libsafereach_comm.so does not export %s" % name
 
 
+def test_wait_flag_gives_up_and_gives_the_core_away(lib_built):
+    """sr_wait_flag is pure host code: a sequence number that never arrives ends in SR_ESTATE after the time-out (not
+    5 s of spinning whatever the caller asked for), and a waiting call leaves the core to others after the first 5 ms
+    (process CPU time well below wall time); a number that is already there returns at once."""
+    import ctypes
+    import time
+    from safe_exploration_amd import _lib
+    flag = ctypes.c_ulonglong(7)
+    assert _lib.lib.sr_wait_flag(ctypes.byref(flag), 7, 1.0) == 0
+    c0, w0 = time.process_time(), time.perf_counter()
+    rc = _lib.lib.sr_wait_flag(ctypes.byref(flag), 8, 0.3)
+    cpu, wall = time.process_time() - c0, time.perf_counter() - w0
+    assert rc == -4 and b"not seen" in _lib.lib.sr_last_error()
+    assert 0.3 <= wall < 1.0
+    assert cpu < 0.6 * wall, "busy-waited %.3f of %.3f s" % (cpu, wall)
+
+
 def test_no_gpu_fails_loudly(lib_built):
     import torch
     if torch.cuda.is_available():
