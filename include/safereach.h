@@ -266,6 +266,12 @@ int sr_gp_chain_status(sr_gp_t h, int* timed_out);
  * third of the device's memory, so that refits allocate nothing (40 GB at N = 50000); the row append keeps a strip and
  * the previous U^-1 buffer.  A host that will only evaluate the model from here on hands them back with this call. */
 int sr_gp_release_scratch(sr_gp_t h);
+/* Device buffers of >= 1 MB that a handle releases (a model that grew, a handle that was destroyed) stay with the library
+ * for the next request of their size class -- the first touch of a fresh allocation, not hipMalloc, is what a refit after
+ * a change of N used to pay for (48 against 6 ms at N = 5000); at most an eighth of the device's memory is held, a block is
+ * zeroed before it is handed out again, an allocation that fails returns them all before it is reported.  This call hands
+ * everything cached back to the driver (all devices). */
+int sr_release_cached_memory(void);
 
 /* ---- completion mailbox for a host that blocks on ONE small result --------------------------------
  * (the CasADi / IPOPT callback: CasadiSSMEvaluator.eval, state_space_models.py:271-303, calls the model, waits, and

@@ -12,4 +12,11 @@ from .state_space_models import StateSpaceModel  # noqa: F401
 from .ssm_hip.gaussian_process import SimpleGPModel  # noqa: F401
 from . import gp_reachability, utils, utils_ellipsoid  # noqa: F401
 
-__all__ = ["SimpleGPModel", "StateSpaceModel", "gp_reachability", "utils", "utils_ellipsoid"]
+
+
+def release_cached_memory():
+    """Hand the device buffers the library keeps for re-use (sr_release_cached_memory) back to the driver."""
+    _lib.check(_lib.lib.sr_release_cached_memory())
+
+
+__all__ = ["SimpleGPModel", "StateSpaceModel", "gp_reachability", "utils", "utils_ellipsoid", "release_cached_memory"]

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sr_gp_set_var_variant": (_I, [_H, _I]),
     "sr_gp_set_chain": (_I, [_H, _I]),
     "sr_gp_release_scratch": (_I, [_H]),
+    "sr_release_cached_memory": (_I, []),
     "sr_publish": (_I, [_I, _P, _I, _P, _P, ctypes.c_ulonglong, _P]),
     "sr_wait_flag": (_I, [_P, ctypes.c_ulonglong, ctypes.c_double]),
     "sr_gp_call1": (_I, [_H, _P, _I, _P, _P, ctypes.c_ulonglong, _P]),

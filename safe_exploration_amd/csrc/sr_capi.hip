@@ -105,14 +105,111 @@ struct sr_dev_guard {
 
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
-template <typename T>
-static int dev_alloc(T** p, size_t count) {
+// ---- device memory with a block cache ---------------------------------------------------------------------------
+// A model that grows (update_model with new points: every call a new padded size) or is replaced (a new handle per
+// refit) used to take its big buffers from hipMalloc every time -- and the first touch of a fresh allocation is what
+// costs: zeroing 1.7 GB of new memory took 24 ms, a refit after a change of N 48 ms against 5.7 ms in place.  Blocks of
+// >= 1 MB are therefore rounded up to a size class (steps of 1/8 of the power of two below the size: <= 12.5 % over) and
+// on release kept for the next request of their class (<= an eighth of device memory in all, oldest out first).  A
+// cached block is zeroed before it is handed out again (0.1 ms per 420 MB): what a caller finds in it is what it found
+// in a fresh allocation.  sr_release_cached_memory() hands everything back to the driver; so does a failed hipMalloc,
+// once, before it is reported.
+struct sr_block { void* p; size_t bytes; int device; unsigned long long stamp; };
+struct sr_block_cache {
+    std::mutex m;
+    std::vector<sr_block> idle;                    // cached blocks
+    std::vector<sr_block> live;                    // big blocks handed out (p -> class size)
+    size_t idle_bytes = 0, cap_bytes = 0;
+    unsigned long long clock = 0;
+};
+static sr_block_cache g_blocks;
+#define SR_CACHE_MIN ((size_t)1 << 20)
+
+static size_t sr_size_class(size_t bytes) {
+    size_t pw = (size_t)1 << 20;
+    while ((pw << 1) <= bytes) pw <<= 1;
+    const size_t step = pw / 8;
+    return (bytes + step - 1) / step * step;
+}
+static void sr_cache_drop_locked(size_t keep_bytes) {                  // oldest first until at most keep_bytes stay
+    while (g_blocks.idle_bytes > keep_bytes && !g_blocks.idle.empty()) {
+        size_t o = 0;
+        for (size_t i = 1; i < g_blocks.idle.size(); ++i)
+            if (g_blocks.idle[i].stamp < g_blocks.idle[o].stamp) o = i;
+        const sr_block b = g_blocks.idle[o];
+        g_blocks.idle.erase(g_blocks.idle.begin() + o);
+        g_blocks.idle_bytes -= b.bytes;
+        sr_dev_guard guard(b.device);
+        (void)hipFree(b.p);
+    }
+}
+static int dev_alloc_bytes(void** p, size_t bytes) {
     *p = nullptr;
-    if (count == 0) return SR_OK;
-    SR_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    if (bytes == 0) return SR_OK;
+    if (bytes < SR_CACHE_MIN) { SR_HIP(hipMalloc(p, bytes)); return SR_OK; }
+    int device = 0;
+    SR_HIP(hipGetDevice(&device));
+    const size_t cls = sr_size_class(bytes);
+    std::lock_guard<std::mutex> lk(g_blocks.m);
+    for (size_t i = 0; i < g_blocks.idle.size(); ++i)
+        if (g_blocks.idle[i].device == device && g_blocks.idle[i].bytes == cls) {
+            sr_block b = g_blocks.idle[i];
+            g_blocks.idle.erase(g_blocks.idle.begin() + i);
+            g_blocks.idle_bytes -= b.bytes;
+            SR_HIP(hipMemset(b.p, 0, b.bytes));
+            SR_HIP(hipStreamSynchronize(nullptr));
+            g_blocks.live.push_back(b);
+            *p = b.p;
+            return SR_OK;
+        }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {                           // out of memory: everything cached goes back first, then the exact size
+        (void)hipGetLastError();
+        sr_cache_drop_locked(0);
+        e = hipMalloc(p, cls);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+        if (e != hipSuccess) {
+            sr_set_error("hipMalloc of %zu bytes -> %s", bytes, hipGetErrorString(e));
+            (void)hipGetLastError();
+            *p = nullptr;
+            return SR_EHIP;
+        }
+    }
+    g_blocks.live.push_back({*p, cls, device, 0});
     return SR_OK;
 }
-static void dev_free(void* p) { if (p) (void)hipFree(p); }
+template <typename T>
+static int dev_alloc(T** p, size_t count) { return dev_alloc_bytes((void**)p, count * sizeof(T)); }
+static void dev_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_blocks.m);
+    for (size_t i = 0; i < g_blocks.live.size(); ++i)
+        if (g_blocks.live[i].p == p) {
+            sr_block b = g_blocks.live[i];
+            g_blocks.live.erase(g_blocks.live.begin() + i);
+            if (g_blocks.cap_bytes == 0) {
+                size_t mem_free = 0, mem_total = 0;
+                (void)hipMemGetInfo(&mem_free, &mem_total);
+                g_blocks.cap_bytes = mem_total / 8;
+            }
+            static const bool no_cache = getenv("SR_NO_BLOCK_CACHE") != nullptr;      // diagnostics: every release goes to the driver
+            if (b.bytes > g_blocks.cap_bytes / 2 || no_cache) { (void)hipFree(p); return; }
+            (void)hipDeviceSynchronize();              // what hipFree implied: nothing in flight still uses the block
+            b.stamp = ++g_blocks.clock;
+            g_blocks.idle.push_back(b);
+            g_blocks.idle_bytes += b.bytes;
+            sr_cache_drop_locked(g_blocks.cap_bytes);
+            return;
+        }
+    for (const sr_block& b : g_blocks.idle)
+        if (b.p == p) { fprintf(stderr, "libsafereach: block %p released twice\n", p); return; }
+    (void)hipFree(p);
+}
+extern "C" int sr_release_cached_memory(void) {
+    std::lock_guard<std::mutex> lk(g_blocks.m);
+    sr_cache_drop_locked(0);
+    return SR_OK;
+}
 // Zero a freshly allocated buffer and WAIT: a memset on the null stream is not ordered with the launches that follow on a
 // caller's non-blocking stream (first-use paths only; never inside a stream capture).
 static int dev_zero(void* p, size_t bytes) {
@@ -176,7 +273,6 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->yT_alt); dev_free(h->alpha_alt);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
-    for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream}) if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : {h->fact_join, h->ev_panel[0], h->ev_panel[1], h->ev_bulk[0], h->ev_bulk[1], h->ev_inv[0], h->ev_inv[1]})
         if (e) (void)hipEventDestroy(e);
     if (h->fact_fork) (void)hipEventDestroy(h->fact_fork);
@@ -371,9 +467,17 @@ static int make_masked_stream(hipStream_t* st, int ncu, int first_bit, int last_
     return SR_OK;
 }
 
+// The streams of the model update belong to the PROCESS (per device and (regime, reserved CUs)), not to a handle: creating
+// them -- a priority stream and two CU-masked ones -- takes 12 - 18 ms, which every handle of a model whose size changes
+// used to pay again (a refit after a change of N: 48 ms, of which 5 were the update).  Updates of different handles that
+// share them simply queue behind each other.
+struct sr_stream_set { int device, key; hipStream_t fact, bulk, inv; };
+static std::mutex g_stream_mutex;
+static std::vector<sr_stream_set> g_stream_sets;
 static void drop_fact_streams(sr_gp* h) {
+    // (the handle only forgets them; work it has in flight on them is waited for)
     for (hipStream_t* st : {&h->fact_stream, &h->bulk_stream, &h->inv_stream})
-        if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); *st = nullptr; }
+        if (*st) { (void)hipStreamSynchronize(*st); *st = nullptr; }
     h->fact_regime = 0;
 }
 
@@ -395,16 +499,26 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
     const int reserve = regime == 2 ? 8 : ((nblk > 36 && nblk <= 52) ? 2 * SR_FACT_RESERVED_CUS : SR_FACT_RESERVED_CUS);
     const int key = regime * 1000 + reserve;
     if (h->fact_regime != key) drop_fact_streams(h);
-    int prio_lo = 0, prio_hi = 0;
-    SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    if (!h->fact_stream) SR_HIP(hipStreamCreateWithPriority(&h->fact_stream, hipStreamNonBlocking, prio_hi));
-    if (!h->bulk_stream) {
-        if (can_mask) SR_TRY(make_masked_stream(&h->bulk_stream, ncu, reserve, ncu));
-        else SR_HIP(hipStreamCreateWithPriority(&h->bulk_stream, hipStreamNonBlocking, prio_lo));
-    }
-    if (regime == 1 && !h->inv_stream) {
-        if (can_mask) SR_TRY(make_masked_stream(&h->inv_stream, ncu, reserve, ncu));
-        else SR_HIP(hipStreamCreateWithPriority(&h->inv_stream, hipStreamNonBlocking, prio_lo));
+    if (!h->fact_stream) {
+        std::lock_guard<std::mutex> lk(g_stream_mutex);
+        sr_stream_set* set = nullptr;
+        for (sr_stream_set& c : g_stream_sets)
+            if (c.device == h->device && c.key == key) set = &c;
+        if (!set) {
+            sr_stream_set c{h->device, key, nullptr, nullptr, nullptr};
+            int prio_lo = 0, prio_hi = 0;
+            SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            SR_HIP(hipStreamCreateWithPriority(&c.fact, hipStreamNonBlocking, prio_hi));
+            if (can_mask) SR_TRY(make_masked_stream(&c.bulk, ncu, reserve, ncu));
+            else SR_HIP(hipStreamCreateWithPriority(&c.bulk, hipStreamNonBlocking, prio_lo));
+            if (regime == 1) {
+                if (can_mask) SR_TRY(make_masked_stream(&c.inv, ncu, reserve, ncu));
+                else SR_HIP(hipStreamCreateWithPriority(&c.inv, hipStreamNonBlocking, prio_lo));
+            }
+            g_stream_sets.push_back(c);
+            set = &g_stream_sets.back();
+        }
+        h->fact_stream = set->fact; h->bulk_stream = set->bulk; h->inv_stream = set->inv;
     }
     if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
     for (int e = 0; e < 2; ++e) {
@@ -421,8 +535,12 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
     SR_DEVICE(h->device);
     const auto t_begin = std::chrono::steady_clock::now();
+    static const bool trace_laps = getenv("SR_FACT_TRACE") != nullptr;
+    auto lap = [&](const char* what) { if (trace_laps) fprintf(stderr, "  %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     SR_TRY(ensure_wt(h));
+    lap("wt");
     SR_TRY(ensure_inv_jobs(h));
+    lap("inv_jobs");
     const int Np = h->Np, nb = Np / SR_NB;
     const int P = pick_fact_panel(h);
     const size_t NN = (size_t)Np * Np;
@@ -471,6 +589,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     // (nothing is read back or allocated before the first launch: the Gram kernels take the signal variance and the
     //  noise from device memory, the status words live with the handle -- round 2 paid a D2H copy, a stream
     //  synchronisation, a hipMalloc and a hipMemGetInfo here, 0.1 ms before the first kernel started)
+    lap("fact_ws");
     if (!h->fact_info) SR_F(dev_alloc(&h->fact_info, (size_t)64));
     int* info_dev = h->fact_info;
     SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s0));
@@ -478,6 +597,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_FH(hipEventRecord(h->fact_fork, s0));
     const int regime = nb <= 128 ? 1 : 2;
     SR_F(ensure_fact_streams(h, regime));
+    lap("streams");
     static const bool no_early_inv = getenv("SR_FACT_NO_EARLY_INV") != nullptr;
     hipStream_t sc = h->fact_stream, sb = h->bulk_stream, si = h->inv_stream;
     SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));

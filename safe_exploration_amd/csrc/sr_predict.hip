@@ -823,7 +823,8 @@ __global__ __launch_bounds__(1024) void sr_var_small_partial_mfma_kernel(const d
     if (i0 < Np) {
         // k-steps of 4 rows: rows k0 + 4u + lk.  Rows beyond the strip's last column hold zeros of U^-1 (skipped),
         // rows in front of k_lo carry K* == 0 (skipped at k-step granularity).
-        const int u_end = min(32, (i0 + 15 - k0) / 4 + 1);
+        // (a chunk may lie beyond the strip and, for an odd multiple of 128 rows, beyond the matrix: (-1) / 4 + 1 == 1)
+        const int u_end = (i0 + 15 < k0) ? 0 : min(min(32, (Np - k0) / 4), (i0 + 15 - k0) / 4 + 1);
         int u = max(0, (k_lo - k0) / 4);
         const double* w = Wt + (long)d * Np * Np + (long)(k0 + lk) * Np + i0 + ln;
         for (; u + 16 <= u_end; u += 16) {

@@ -327,7 +327,10 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma1_kernel(sr_stream_args a)
     if (i0 < a.Np) {
         // k-steps of 4 rows: rows k0 + 4u + lk.  Rows beyond the strip's last column hold zeros of U^-1 (skipped),
         // rows in front of k_lo carry K* == 0 (skipped at k-step granularity).
-        const int u_end = min(32, (i0 + 15 - k0) / 4 + 1);
+        // (k0 may lie beyond the strip -- and, in the last column block of a model whose padded size is an odd multiple
+        //  of 128, beyond the matrix: integer division truncates towards zero, (-1) / 4 + 1 used to give one k-step that read
+        //  four rows past U^-1 of the last output)
+        const int u_end = (i0 + 15 < k0) ? 0 : min(min(32, (a.Np - k0) / 4), (i0 + 15 - k0) / 4 + 1);
         int u = max(0, (a.k_lo - k0) / 4);
         const double* w = a.Wt + (long)d * a.Np * a.Np + (long)(k0 + lk) * a.Np + i0 + ln;
         constexpr int UB = (G <= 2) ? 16 : 8;            // A-fragments in flight per batch
@@ -467,11 +470,13 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = d4_t{0.0, 0.0, 0.0, 0.0};
     double pf[PF];
-    ks_fetch(0, pf);
     double A0[UB], A1[UB];
+    if (nsub > 0) {                                      // (a run can be empty: the chunk beyond Np of an odd padded size)
+        ks_fetch(0, pf);
 #pragma unroll
-    for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * q) * a.Np];
-    ks_put(0, pf);
+        for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * q) * a.Np];
+        ks_put(0, pf);
+    }
     __syncthreads();
     // BPS = 2: the even batch of a stage requests the next stage's K* rows, the odd one stores them and ends the stage
     for (int sub = 0; sub < nsub; ++sub) {

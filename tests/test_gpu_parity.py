@@ -653,6 +653,35 @@ def test_reference_test_scenarios_on_reference_data(name, n_s, n_u):
         np.testing.assert_allclose(qa, g["ms_q_" + tag], rtol=1e-6)
 
 
+def test_models_that_change_size_reuse_device_blocks_and_streams():
+    """A model whose N changes from call to call (the exploration loop: update_model after every episode) gets a new
+    handle each time; its big buffers come from the library's block cache (zeroed on re-use) and its update runs on the
+    process-wide streams.  Same posterior as a model fitted once at that size; release_cached_memory() in between."""
+    import safe_exploration_amd as sea
+    syn = orc.make_synthetic(12, 1500, 2, 1, 32)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    gp = hip_model(syn["Z"][:900], syn["Y"][:900], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    for k, n in enumerate((1300, 700, 1500, 1000, 1300, 900)):
+        gp.train(syn["Z"][:n], syn["Y"][:n], opt_hyp=False)
+        mu, var = gp.predict(x)
+        fresh = hip_model(syn["Z"][:n], syn["Y"][:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+        mu_f, var_f = fresh.predict(x)
+        np.testing.assert_array_equal(mu, mu_f)
+        np.testing.assert_array_equal(var, var_f)
+        del fresh
+        if k == 2:
+            sea.release_cached_memory()
+    # a chain of appends across several padded sizes on the same model, against one fit of everything
+    gp.train(syn["Z"][:1000], syn["Y"][:1000], opt_hyp=False)
+    for lo in range(1000, 1500, 100):
+        gp.update_model(syn["Z"][lo:lo + 100], syn["Y"][lo:lo + 100], opt_hyp=False, replace_old=False)
+    full = hip_model(syn["Z"][:1500], syn["Y"][:1500], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    mu, var = gp.predict(x)
+    mu_f, var_f = full.predict(x)
+    np.testing.assert_allclose(mu, mu_f, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(var, var_f, rtol=0, atol=1e-10)
+
+
 @pytest.mark.parametrize("N0,adds", [(100, [1]), (120, [8, 1]), (250, [6, 128, 3]), (384, [130]), (700, [40]),
                                      (300, [16, 16, 1, 5, 2]), (127, [1, 1, 1]), (1300, [2, 16, 1]), (1, [1, 3])])
 def test_row_append_update_equals_refit(N0, adds):
