@@ -444,7 +444,7 @@ class SimpleGPModel(StateSpaceModel):
         y = np.asarray(y, dtype=np.float64)
         if (not replace_old and not opt_hyp and self.gp_trained and self._handle is not None
                 and not self._handle.shared and self.m is None and self.x_train is not None and not self.z_fixed
-                and noise_diag == self._noise_diag and 0 < x.shape[0] <= self.append_limit):
+                and noise_diag == self._noise_diag and 0 < x.shape[0] <= self._append_limit_now()):
             self._append(x, y)                       # O(N^2 m) block row append instead of O(N^3)
             return
         if not replace_old and self.x_train is not None:
@@ -453,7 +453,16 @@ class SimpleGPModel(StateSpaceModel):
         self.train(x, y, self.m, opt_hyp=opt_hyp, noise_diag=noise_diag, Z=self.Z,
                    choose_data=choose_data)
 
-    append_limit = 1024      # more new points than this: refactorise (a few GEMM-rich passes beat many appends)
+    # More new points than this: refactorise.  None = by model size, N / 5 (at least 16): measured break-even of
+    # update_model(replace_old=False), appends in chunks of 128 against a refit of everything -- N = 300: ~50 points,
+    # 1000: ~200, 2000: ~350, 5000: ~1000, 10000: > 1024.  (Round 2's fixed 1024 appended 512 points to an N = 1000 model
+    # in 2.7 ms where the refit takes 1.2.)  An integer fixes it.
+    append_limit = None
+
+    def _append_limit_now(self):
+        if self.append_limit is not None:
+            return int(self.append_limit)
+        return max(16, int(self.x_train.shape[0]) // 5)
 
     def _append(self, x, y):
         """Condition on additional points through sr_gp_append (chunks of <= 128 rows)."""

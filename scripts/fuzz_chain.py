@@ -55,6 +55,7 @@ def main():
         Zx = syn["Z"][rng.integers(0, N, sum(adds))] + 0.05 * extra["Z"][:, :syn["Z"].shape[1]]
         Yx = extra["Y"]
         lo = 0
+        gp.append_limit = 10 ** 9           # exercise the append kernels whatever the size policy would choose
         for m in adds:
             gp.update_model(Zx[lo:lo + m], Yx[lo:lo + m], opt_hyp=False, replace_old=False)
             lo += m

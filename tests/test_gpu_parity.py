@@ -671,6 +671,13 @@ def test_models_that_change_size_reuse_device_blocks_and_streams():
         del fresh
         if k == 2:
             sea.release_cached_memory()
+    # the size policy: few new points are appended to the factor, many refactorise (N / 5, at least 16)
+    gp.train(syn["Z"][:1000], syn["Y"][:1000], opt_hyp=False)
+    h0 = gp._handle
+    gp.update_model(syn["Z"][1000:1100], syn["Y"][1000:1100], opt_hyp=False, replace_old=False)
+    assert gp._handle is h0 and gp._handle.N == 1100              # appended in place
+    gp.update_model(syn["Z"][1100:1400], syn["Y"][1100:1400], opt_hyp=False, replace_old=False)
+    assert gp._handle is not h0 and gp._handle.N == 1400          # 300 > 1100 / 5: a refit (new handle)
     # a chain of appends across several padded sizes on the same model, against one fit of everything
     gp.train(syn["Z"][:1000], syn["Y"][:1000], opt_hyp=False)
     for lo in range(1000, 1500, 100):
@@ -691,6 +698,7 @@ def test_row_append_update_equals_refit(N0, adds):
     syn = orc.make_synthetic(ntot, ntot, 2, 1, 64)
     Z, Y = syn["Z"], syn["Y"]
     gp = hip_model(Z[:N0], Y[:N0], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    gp.append_limit = 10 ** 9        # the mechanism under test, whatever the size policy (N / 5) would choose
     lo = N0
     for m in adds:
         gp.update_model(Z[lo:lo + m], Y[lo:lo + m], opt_hyp=False, replace_old=False)
