@@ -1858,7 +1858,8 @@ extern "C" int sr_gp_release_scratch(sr_gp_t h) {
     dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1;
     dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
     dev_free(h->yT_alt); dev_free(h->alpha_alt); h->yT_alt = h->alpha_alt = nullptr; h->vec_alt_np = 0;
-    return SR_OK;
+    // the caller wants the memory back: what these releases left in the block cache goes to the driver too
+    return sr_release_cached_memory();
 }
 
 extern "C" int sr_gp_set_chain(sr_gp_t h, int on) {
