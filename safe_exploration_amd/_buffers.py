@@ -76,3 +76,77 @@ def stream_ptr(device):
 
 def to_numpy(t):
     return t.detach().cpu().numpy()
+
+
+STAGING_MAX_DOUBLES = 1 << 22       # 32 MB of pinned memory at most per direction; bigger calls copy argument by argument
+
+
+class Staging(object):
+    """Packed host <-> device staging for an entry point called with NumPy arrays: ONE pinned block in (all inputs back
+    to back, one asynchronous H2D copy), ONE packed device block out and one pinned block back (one D2H copy, one stream
+    synchronisation).  Copying every argument on its own from pageable memory and every result back on its own cost a
+    256-rollout, 15-step chain 105 us of host time on top of the kernel's 105 us.  Grow-only; kept with the model handle."""
+
+    def __init__(self, device):
+        self.device = device
+        self.h_in = self.d_in = self.h_out = self.d_out = None
+        self._plans, self._gen, self._last = {}, 0, None
+
+    def _room(self, n_in, n_out):
+        if self.h_in is None or self.h_in.numel() < n_in:
+            self.h_in = torch.empty(max(n_in, 1024), dtype=torch.float64).pin_memory()
+            self.d_in = torch.empty(self.h_in.numel(), dtype=torch.float64, device=self.device)
+            self.h_in_np = self.h_in.numpy()
+            self._gen += 1
+        if self.h_out is None or self.h_out.numel() < n_out:
+            self.h_out = torch.empty(max(n_out, 1024), dtype=torch.float64).pin_memory()
+            self.d_out = torch.empty(self.h_out.numel(), dtype=torch.float64, device=self.device)
+            self.h_out_np = self.h_out.numpy()
+            self._gen += 1
+
+    def stage(self, arrays, out_shapes):
+        """arrays: NumPy float64 arrays (or None); out_shapes: shapes of the results.  Returns (device views of the
+        inputs -- None where the input was None --, device views of the outputs).  The views of a call signature
+        (shapes) are built once: slicing tensors costs microseconds each, and a caller repeats its shapes."""
+        key = (tuple(None if a is None else a.shape for a in arrays), tuple(tuple(sh) for sh in out_shapes))
+        plan = self._plans.get(key)
+        if plan is None or plan["gen"] != self._gen:
+            n_in = sum(int(a.size) for a in arrays if a is not None)
+            n_out = sum(int(np.prod(sh)) for sh in out_shapes)
+            self._room(n_in, n_out)
+            if len(self._plans) > 64:
+                self._plans.clear()
+            views, hviews, off = [], [], 0
+            for a in arrays:
+                if a is None:
+                    views.append(None)
+                    hviews.append(None)
+                    continue
+                n = int(a.size)
+                hviews.append(self.h_in_np[off:off + n].reshape(a.shape))
+                views.append(self.d_in[off:off + n].view(a.shape))
+                off += n
+            outs, houts, ooff = [], [], 0
+            for sh in out_shapes:
+                n = int(np.prod(sh))
+                outs.append(self.d_out[ooff:ooff + n].view(tuple(sh)))
+                houts.append(self.h_out_np[ooff:ooff + n].reshape(tuple(sh)))
+                ooff += n
+            plan = {"gen": self._gen, "views": views, "hviews": hviews, "outs": outs, "houts": houts,
+                    "d_in": self.d_in[:off] if off else None, "h_in": self.h_in[:off] if off else None,
+                    "d_out": self.d_out[:ooff], "h_out": self.h_out[:ooff]}
+            self._plans[key] = plan
+        for a, hv in zip(arrays, plan["hviews"]):
+            if a is not None:
+                np.copyto(hv, a)
+        if plan["d_in"] is not None:
+            plan["d_in"].copy_(plan["h_in"], non_blocking=True)
+        self._last = plan
+        return plan["views"], plan["outs"]
+
+    def fetch(self):
+        """The outputs of the last ``stage`` as NumPy arrays (copies); synchronises the current stream."""
+        plan = self._last
+        plan["h_out"].copy_(plan["d_out"], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return [h.copy() for h in plan["houts"]]

@@ -103,26 +103,59 @@ def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None,
     ssm._need_trained()
     dev = hd.device
     n_s, n_u = _reach_dims(hd, t_z_gp)
-    p = B.as_dev(p_center, dev)
-    T = p.shape[0]
-    if p.dim() != 2 or p.shape[1] != n_s:
-        raise ValueError("p_center must be (T, {})".format(n_s))
-    kff = B.as_dev(k_ff, dev, (T, n_u))
-    q = B.as_dev(q_shape, dev, (T, n_s, n_s)) if q_shape is not None else None
-    if q is not None and k_fb is None:
+    if q_shape is not None and k_fb is None:
         raise ValueError("k_fb is required when q_shape is given")
-    kfb = B.as_dev(k_fb, dev, (T, n_u, n_s)) if (k_fb is not None and q is not None) else None
+    staged = (not as_t) and not any(B.is_tensor(x) for x in (k_ff, q_shape, k_fb))
+    if staged:
+        np_p = np.ascontiguousarray(np.asarray(p_center, dtype=np.float64))
+        staged = np_p.ndim == 2 and np_p.shape[0] * (n_s * n_s + n_s + n_u * n_s + n_u) <= B.STAGING_MAX_DOUBLES
+    if staged:
+        # NumPy in / out: every argument through one pinned block, every result back through one (B.Staging)
+        f64 = lambda x: None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+        T = np_p.shape[0]
+        if np_p.shape[1] != n_s:
+            raise ValueError("p_center must be (T, {})".format(n_s))
+        np_q = f64(q_shape).reshape(T, n_s, n_s) if q_shape is not None else None
+        np_kfb = f64(k_fb).reshape(T, n_u, n_s) if (k_fb is not None and q_shape is not None) else None
+        st = getattr(hd, "_staging", None)
+        if st is None:
+            st = hd._staging = B.Staging(dev)
+        shapes = [(T, n_s), (T, n_s, n_s), (1,)] + ([(T, n_s)] if return_var else [])
+        (p, kff, q, kfb), outs_d = st.stage([np_p, f64(k_ff).reshape(T, n_u), np_q, np_kfb], shapes)
+        p_out, q_out, bad_slot = outs_d[:3]
+        var = outs_d[3] if return_var else None
+        n_bad = None
+        if check_bounds:
+            bad_slot.zero_()
+            n_bad = bad_slot.view(torch.int32)
+    else:
+        p = B.as_dev(p_center, dev)
+        T = p.shape[0]
+        if p.dim() != 2 or p.shape[1] != n_s:
+            raise ValueError("p_center must be (T, {})".format(n_s))
+        kff = B.as_dev(k_ff, dev, (T, n_u))
+        q = B.as_dev(q_shape, dev, (T, n_s, n_s)) if q_shape is not None else None
+        kfb = B.as_dev(k_fb, dev, (T, n_u, n_s)) if (k_fb is not None and q is not None) else None
+        p_out = B.empty((T, n_s), dev)
+        q_out = B.empty((T, n_s, n_s), dev)
+        var = B.empty((T, n_s), dev) if return_var else None
+        n_bad = B.zeros_i32(1, dev) if check_bounds else None
     a, b = _lin_model(a, b, n_s, n_u)
     ta, tb = B.const_dev(a, dev, (n_s, n_s)), B.const_dev(b, dev, (n_s, n_u))
     tlm, tls = B.const_dev(l_mu, dev, (n_s,)), B.const_dev(l_sigma, dev, (n_s,))
-    p_out = B.empty((T, n_s), dev)
-    q_out = B.empty((T, n_s, n_s), dev)
-    var = B.empty((T, n_s), dev) if return_var else None
-    n_bad = B.zeros_i32(1, dev) if check_bounds else None
     with _input_transform(ssm, t_z_gp):
         check(lib.sr_onestep_reach(hd.h, T, B.ptr(p), B.ptr(q), B.ptr(kff), B.ptr(kfb), B.ptr(ta),
                                    B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety), B.ptr(p_out),
                                    B.ptr(q_out), B.ptr(var), B.ptr(n_bad), B.stream_ptr(dev)))
+    if staged:
+        res = st.fetch()                              # (synchronises the stream)
+        if check_bounds:
+            n_viol = int(res[2].view(np.int32)[0])
+            if n_viol > 0:
+                raise AssertionError("all elements of u_b need to be greater than zero! "
+                                     "({} query state(s) affected)".format(n_viol))
+        _raise_if_chain_failed(hd, dev, True)
+        return (res[0], res[1], res[3]) if return_var else (res[0], res[1])
     _raise_if_bad(n_bad)
     outs = (p_out, q_out, var) if return_var else (p_out, q_out)
     if as_t:
@@ -215,30 +248,65 @@ def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_
     hd = gp._handle
     dev = hd.device
     n_s, n_u = _reach_dims(hd, t_z_gp)
-    p0 = B.as_dev(p_0, dev)
-    T = p0.shape[0]
-    kff = B.as_dev(k_ff, dev)
-    if kff.dim() != 3 or kff.shape[0] != T or kff.shape[2] != n_u:
-        raise ValueError("k_ff must be (T, H, {})".format(n_u))
-    H = kff.shape[1]
-    kfb = B.as_dev(k_fb, dev, (T, H - 1, n_u, n_s)) if H > 1 else None
-    q0 = B.as_dev(q_0, dev, (T, n_s, n_s)) if q_0 is not None else None
-    if q0 is not None and k_fb_init is None:
+    if q_0 is not None and k_fb_init is None:
         raise ValueError("k_fb_init is required when q_0 is given")
-    kfb0 = B.as_dev(k_fb_init, dev, (T, n_u, n_s)) if q0 is not None else None
+    staged = (not as_t) and not any(B.is_tensor(x) for x in (k_fb, k_ff, q_0, k_fb_init))
+    if staged:
+        staged = np.size(k_ff) * (n_s * n_s + n_s + 1) <= B.STAGING_MAX_DOUBLES * max(n_u, 1)
+    if staged:
+        # NumPy in / out: every argument through one pinned block, every result back through one (B.Staging)
+        f64 = lambda x: None if x is None else np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+        np_p0, np_kff = f64(p_0), f64(k_ff)
+        T = np_p0.shape[0]
+        if np_kff.ndim != 3 or np_kff.shape[0] != T or np_kff.shape[2] != n_u:
+            raise ValueError("k_ff must be (T, H, {})".format(n_u))
+        H = np_kff.shape[1]
+        np_kfb = f64(k_fb).reshape(T, H - 1, n_u, n_s) if H > 1 else None
+        np_q0 = f64(q_0).reshape(T, n_s, n_s) if q_0 is not None else None
+        np_kfb0 = f64(k_fb_init).reshape(T, n_u, n_s) if q_0 is not None else None
+        st = getattr(hd, "_staging", None)
+        if st is None:
+            st = hd._staging = B.Staging(dev)
+        (p0, kff, kfb, q0, kfb0), (p_all, q_all, bad_slot) = st.stage(
+            [np_p0.reshape(T, n_s), np_kff, np_kfb, np_q0, np_kfb0], [(T, H, n_s), (T, H, n_s, n_s), (1,)])
+    else:
+        p0 = B.as_dev(p_0, dev)
+        T = p0.shape[0]
+        kff = B.as_dev(k_ff, dev)
+        if kff.dim() != 3 or kff.shape[0] != T or kff.shape[2] != n_u:
+            raise ValueError("k_ff must be (T, H, {})".format(n_u))
+        H = kff.shape[1]
+        kfb = B.as_dev(k_fb, dev, (T, H - 1, n_u, n_s)) if H > 1 else None
+        q0 = B.as_dev(q_0, dev, (T, n_s, n_s)) if q_0 is not None else None
+        kfb0 = B.as_dev(k_fb_init, dev, (T, n_u, n_s)) if q0 is not None else None
+        p_all = B.empty((T, H, n_s), dev)
+        q_all = B.empty((T, H, n_s, n_s), dev)
     a, b = _lin_model(a, b, n_s, n_u)
     ta, tb = B.const_dev(a, dev, (n_s, n_s)), B.const_dev(b, dev, (n_s, n_u))
     tlm, tls = B.const_dev(L_mu, dev, (n_s,)), B.const_dev(L_sigm, dev, (n_s,))
-    p_all = B.empty((T, H, n_s), dev)
-    q_all = B.empty((T, H, n_s, n_s), dev)
-    n_bad = B.zeros_i32(1, dev) if check_bounds else None
+    if staged and check_bounds:
+        # the violation counter travels back inside the packed result block (its own D2H copy + synchronisation otherwise)
+        bad_slot.zero_()
+        n_bad = bad_slot.view(torch.int32)
+    else:
+        n_bad = B.zeros_i32(1, dev) if check_bounds else None
     with _input_transform(gp, t_z_gp):
         check(lib.sr_multistep_reach(hd.h, T, H, B.ptr(p0), B.ptr(q0), B.ptr(kfb0), B.ptr(kff), B.ptr(kfb),
                                      B.ptr(ta), B.ptr(tb), B.ptr(tlm), B.ptr(tls), float(c_safety),
                                      B.ptr(p_all), B.ptr(q_all), B.ptr(n_bad), B.stream_ptr(dev)))
-    _raise_if_bad(n_bad)
     if as_t:
+        _raise_if_bad(n_bad)
         return p_all, q_all
+    if staged:
+        p_np, q_np, bad_np = st.fetch()               # (synchronises the stream)
+        if check_bounds:
+            n_viol = int(bad_np.view(np.int32)[0])
+            if n_viol > 0:
+                raise AssertionError("all elements of u_b need to be greater than zero! "
+                                     "({} query state(s) affected)".format(n_viol))
+        _raise_if_chain_failed(hd, dev, True)
+        return p_np, q_np
+    _raise_if_bad(n_bad)
     _raise_if_chain_failed(hd, dev, n_bad is not None)
     return B.to_numpy(p_all), B.to_numpy(q_all)
 
