@@ -679,6 +679,26 @@ class SimpleGPModel(StateSpaceModel):
                                 B.stream_ptr(hd.device)))
         return (mu, var, jac) if compute_gradients else (mu, var)
 
+    def _predict_host(self, x_new, compute_gradients=False):
+        """predict for a NumPy batch: the queries through one pinned block, (mu, var[, jac]) back through one
+        (B.Staging) -- one H2D copy, one D2H copy, one synchronisation instead of one per array."""
+        self._need_trained()
+        hd = self._handle
+        x = np.ascontiguousarray(np.asarray(x_new, dtype=np.float64))
+        if x.ndim != 2 or x.shape[1] != hd.D:
+            raise ValueError("x_new must be (T, {})".format(hd.D))
+        T = x.shape[0]
+        if T == 0 or T * hd.n_out * (2 + hd.D) > B.STAGING_MAX_DOUBLES:
+            return tuple(B.to_numpy(o) for o in self.predict_device(x, compute_gradients))
+        st = getattr(hd, "_staging", None)
+        if st is None:
+            st = hd._staging = B.Staging(hd.device)
+        shapes = [(T, hd.n_out), (T, hd.n_out)] + ([(T, hd.n_out, hd.D)] if compute_gradients else [])
+        (dx,), outs = st.stage([x], shapes)
+        check(lib.sr_gp_predict(hd.h, B.ptr(dx), T, B.ptr(outs[0]), B.ptr(outs[1]),
+                                B.ptr(outs[2]) if compute_gradients else None, B.stream_ptr(hd.device)))
+        return tuple(st.fetch())
+
     def predict(self, *args, **kwargs):
         """Predictive mean and variance for a set of test inputs.
 
@@ -704,15 +724,17 @@ class SimpleGPModel(StateSpaceModel):
             else:
                 x_new = np.hstack((np.asarray(states, dtype=np.float64),
                                    np.asarray(actions, dtype=np.float64)))
-            out = self.predict_device(x_new, bool(jacobians))
-            return out if as_t else tuple(B.to_numpy(o) for o in out)
+            if not as_t:
+                return self._predict_host(x_new, bool(jacobians))
+            return self.predict_device(x_new, bool(jacobians))
         x_new = args[0] if args else kwargs.pop("x_new")
         quantiles = args[1] if len(args) > 1 else kwargs.pop("quantiles", None)
         compute_gradients = args[2] if len(args) > 2 else kwargs.pop("compute_gradients", False)
         if quantiles is not None:
             raise NotImplementedError()
-        out = self.predict_device(x_new, bool(compute_gradients))
-        return out if B.is_tensor(x_new) else tuple(B.to_numpy(o) for o in out)
+        if not B.is_tensor(x_new):
+            return self._predict_host(x_new, bool(compute_gradients))
+        return self.predict_device(x_new, bool(compute_gradients))
 
     def predictive_gradients(self, x_new, grad_sigma=False):
         """(T, n_s, D) gradients of the predictive mean (gaussian_process.py:570-596)."""
