@@ -143,9 +143,26 @@ static void sr_cache_drop_locked(size_t keep_bytes) {                  // oldest
         (void)hipFree(b.p);
     }
 }
+// SR_GUARD=1 (diagnostics): every allocation ends at the end of its own 2 MiB-granular hipMalloc, so that a read or write
+// past a buffer leaves the mapping (a GPU memory fault) instead of landing silently in a neighbour
+static std::vector<std::pair<void*, void*>> g_guard_map;      // user pointer -> base
 static int dev_alloc_bytes(void** p, size_t bytes) {
     *p = nullptr;
     if (bytes == 0) return SR_OK;
+    static const bool guard = getenv("SR_GUARD") != nullptr;
+    if (guard) {
+        const size_t gran = (size_t)2 << 20, al = 16;
+        const size_t need = (bytes + al - 1) / al * al;
+        const size_t tot = (need + gran - 1) / gran * gran;
+        void* base = nullptr;
+        SR_HIP(hipMalloc(&base, tot));
+        SR_HIP(hipMemset(base, 0, tot));
+        SR_HIP(hipStreamSynchronize(nullptr));
+        *p = (char*)base + (tot - need);
+        std::lock_guard<std::mutex> lk(g_blocks.m);
+        g_guard_map.push_back({*p, base});
+        return SR_OK;
+    }
     if (bytes < SR_CACHE_MIN) { SR_HIP(hipMalloc(p, bytes)); return SR_OK; }
     int device = 0;
     SR_HIP(hipGetDevice(&device));
@@ -183,6 +200,13 @@ static int dev_alloc(T** p, size_t count) { return dev_alloc_bytes((void**)p, co
 static void dev_free(void* p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_blocks.m);
+    for (size_t i = 0; i < g_guard_map.size(); ++i)
+        if (g_guard_map[i].first == p) {
+            void* base = g_guard_map[i].second;
+            g_guard_map.erase(g_guard_map.begin() + i);
+            (void)hipFree(base);
+            return;
+        }
     for (size_t i = 0; i < g_blocks.live.size(); ++i)
         if (g_blocks.live[i].p == p) {
             sr_block b = g_blocks.live[i];

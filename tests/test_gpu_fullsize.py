@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 from _helpers import hip_model, mu_atol, cached_oracle_model, hyp_from, oracle_model
+from conftest import ROOT
 from oracle import oracle_np as orc
 
 pytestmark = pytest.mark.gpu
@@ -511,3 +512,19 @@ def test_bench_model_update_line_is_self_consistent():
     assert line["config"]["max|mu(z)+s2n*alpha-y|"] < 1e-7
     assert set(line["kernel_ms_per_step"]) == {"sr_gram_kernel", "sr_potrf_diag_kernel", "sr_gemm_tn_kernel[cholesky]",
                                                "sr_gemm_tn_kernel[inverse]"}
+
+
+def test_no_access_past_a_buffer_under_guard_allocation():
+    """SR_GUARD=1 makes every device buffer of the library end at the end of its own 2 MiB-granular allocation: an access
+    past a buffer leaves the mapping and kills the process instead of landing silently in a neighbour.  (That is how the
+    four-rows-past-U^-1 read of the 16-wavefront streaming kernels showed itself -- odd padded sizes, last output.)  The
+    shape-heavy parity tests run in a child process under that mode and must pass."""
+    import subprocess
+    env = dict(os.environ, SR_GUARD="1")
+    sel = ("fused_small_model_linearize or ragged or small_batch_streaming or splitk or all_state_action or "
+           "row_append or streamed_linearize or fused_small_model_pass or persistent_chain_matches")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
