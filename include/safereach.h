@@ -268,8 +268,8 @@ int sr_gp_chain_status(sr_gp_t h, int* timed_out);
 int sr_gp_release_scratch(sr_gp_t h);
 /* Device buffers of >= 1 MB that a handle releases (a model that grew, a handle that was destroyed) stay with the library
  * for the next request of their size class -- the first touch of a fresh allocation, not hipMalloc, is what a refit after
- * a change of N used to pay for (48 against 6 ms at N = 5000); at most an eighth of the device's memory is held, a block is
- * zeroed before it is handed out again, an allocation that fails returns them all before it is reported.  This call hands
+ * a change of N used to pay for (48 against 6 ms at N = 5000); at most an eighth of the device's memory is held, an
+ * allocation that fails returns them all before it is reported.  This call hands
  * everything cached back to the driver (all devices). */
 int sr_release_cached_memory(void);
 

@@ -110,9 +110,10 @@ static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 // refit) used to take its big buffers from hipMalloc every time -- and the first touch of a fresh allocation is what
 // costs: zeroing 1.7 GB of new memory took 24 ms, a refit after a change of N 48 ms against 5.7 ms in place.  Blocks of
 // >= 1 MB are therefore rounded up to a size class (steps of 1/8 of the power of two below the size: <= 12.5 % over) and
-// on release kept for the next request of their class (<= an eighth of device memory in all, oldest out first).  A
-// cached block is zeroed before it is handed out again (0.1 ms per 420 MB): what a caller finds in it is what it found
-// in a fresh allocation.  sr_release_cached_memory() hands everything back to the driver; so does a failed hipMalloc,
+// on release kept for the next request of their class (<= an eighth of device memory in all, oldest out first).  The
+// contents of a block are unspecified, as hipMalloc's are: every buffer that must start from zeros is zeroed by its owner,
+// and the whole GPU suite passes with new buffers filled with NaN patterns (SR_GUARD=1 SR_POISON=1).
+// sr_release_cached_memory() hands everything back to the driver; so does a failed hipMalloc,
 // once, before it is reported.
 struct sr_block { void* p; size_t bytes; int device; unsigned long long stamp; };
 struct sr_block_cache {
@@ -144,7 +145,8 @@ static void sr_cache_drop_locked(size_t keep_bytes) {                  // oldest
     }
 }
 // SR_GUARD=1 (diagnostics): every allocation ends at the end of its own 2 MiB-granular hipMalloc, so that a read or write
-// past a buffer leaves the mapping (a GPU memory fault) instead of landing silently in a neighbour
+// past a buffer leaves the mapping (a GPU memory fault) instead of landing silently in a neighbour.  With SR_POISON=1 as
+// well the new buffer is filled with NaN bit patterns instead of zeros: code that relies on fresh memory being zero shows
 static std::vector<std::pair<void*, void*>> g_guard_map;      // user pointer -> base
 static int dev_alloc_bytes(void** p, size_t bytes) {
     *p = nullptr;
@@ -156,7 +158,8 @@ static int dev_alloc_bytes(void** p, size_t bytes) {
         const size_t tot = (need + gran - 1) / gran * gran;
         void* base = nullptr;
         SR_HIP(hipMalloc(&base, tot));
-        SR_HIP(hipMemset(base, 0, tot));
+        static const bool poison = getenv("SR_POISON") != nullptr;      // SR_POISON=1: new buffers hold NaN, not zeros
+        SR_HIP(hipMemset(base, poison ? 0xFF : 0, tot));
         SR_HIP(hipStreamSynchronize(nullptr));
         *p = (char*)base + (tot - need);
         std::lock_guard<std::mutex> lk(g_blocks.m);
@@ -173,8 +176,6 @@ static int dev_alloc_bytes(void** p, size_t bytes) {
             sr_block b = g_blocks.idle[i];
             g_blocks.idle.erase(g_blocks.idle.begin() + i);
             g_blocks.idle_bytes -= b.bytes;
-            SR_HIP(hipMemset(b.p, 0, b.bytes));
-            SR_HIP(hipStreamSynchronize(nullptr));
             g_blocks.live.push_back(b);
             *p = b.p;
             return SR_OK;

@@ -517,10 +517,11 @@ def test_bench_model_update_line_is_self_consistent():
 def test_no_access_past_a_buffer_under_guard_allocation():
     """SR_GUARD=1 makes every device buffer of the library end at the end of its own 2 MiB-granular allocation: an access
     past a buffer leaves the mapping and kills the process instead of landing silently in a neighbour.  (That is how the
-    four-rows-past-U^-1 read of the 16-wavefront streaming kernels showed itself -- odd padded sizes, last output.)  The
-    shape-heavy parity tests run in a child process under that mode and must pass."""
+    four-rows-past-U^-1 read of the 16-wavefront streaming kernels showed itself -- odd padded sizes, last output.)  With
+    SR_POISON=1 the new buffers also hold NaN patterns instead of zeros (the block cache hands out used memory as it is).
+    The shape-heavy parity tests run in a child process under that mode and must pass."""
     import subprocess
-    env = dict(os.environ, SR_GUARD="1")
+    env = dict(os.environ, SR_GUARD="1", SR_POISON="1")     # ... and new buffers hold NaN patterns, not zeros
     sel = ("fused_small_model_linearize or ragged or small_batch_streaming or splitk or all_state_action or "
            "row_append or streamed_linearize or fused_small_model_pass or persistent_chain_matches")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
