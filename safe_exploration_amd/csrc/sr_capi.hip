@@ -180,12 +180,13 @@ static int dev_alloc_bytes(void** p, size_t bytes) {
             *p = b.p;
             return SR_OK;
         }
+    size_t got = cls;                                // what the block really holds (its class, unless memory is short)
     hipError_t e = hipMalloc(p, cls);
     if (e != hipSuccess) {                           // out of memory: everything cached goes back first, then the exact size
         (void)hipGetLastError();
         sr_cache_drop_locked(0);
         e = hipMalloc(p, cls);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+        if (e != hipSuccess) { (void)hipGetLastError(); got = bytes; e = hipMalloc(p, bytes); }
         if (e != hipSuccess) {
             sr_set_error("hipMalloc of %zu bytes -> %s", bytes, hipGetErrorString(e));
             (void)hipGetLastError();
@@ -193,7 +194,7 @@ static int dev_alloc_bytes(void** p, size_t bytes) {
             return SR_EHIP;
         }
     }
-    g_blocks.live.push_back({*p, cls, device, 0});
+    g_blocks.live.push_back({*p, got, device, 0});
     return SR_OK;
 }
 template <typename T>
