@@ -437,6 +437,14 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
     const int j_hi = min(J * KC + KC, 2 * cb + 2);
     const int k0 = J * KC * SR_ST_ROWS, k1 = min(j_hi * SR_ST_ROWS, a.Np);
     const int nsub = (k1 - k0 + SUB - 1) / SUB;
+    if (k0 >= a.Np) {
+        // an EMPTY run (the chunk beyond Np of an odd padded size) reports zeros and is gone.  (Not a branch around the
+        // prologue below: with one, the G = 2 kernel went from 112 VGPRs to 128 + 76 B of scratch, T = 32 at N = 5000 75 ->
+        // 101 us; a run that starts at row 0 instead cost the same registers.)
+        double* out = a.Vp + (((long)d * gridDim.x + p) * (NC * gridDim.z) + blockIdx.z * NC) * SR_ST_COLS;
+        for (int e = threadIdx.x; e < NC * SR_ST_COLS; e += 1024) out[e] = 0.0;
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, ln = lane & 15;
@@ -471,12 +479,10 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
     for (int g = 0; g < G; ++g) acc[g] = d4_t{0.0, 0.0, 0.0, 0.0};
     double pf[PF];
     double A0[UB], A1[UB];
-    if (nsub > 0) {                                      // (a run can be empty: the chunk beyond Np of an odd padded size)
-        ks_fetch(0, pf);
+    ks_fetch(0, pf);
 #pragma unroll
-        for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * q) * a.Np];
-        ks_put(0, pf);
-    }
+    for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * q) * a.Np];
+    ks_put(0, pf);
     __syncthreads();
     // BPS = 2: the even batch of a stage requests the next stage's K* rows, the odd one stores them and ends the stage
     for (int sub = 0; sub < nsub; ++sub) {
