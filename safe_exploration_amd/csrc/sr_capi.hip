@@ -49,7 +49,7 @@ struct sr_gp {
     double* stream_vp = nullptr; long stream_vp_cap = 0;   // fused small-batch path: partial sums (grow-only)
     unsigned* stream_tickets = nullptr;
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
-    unsigned* sk_tickets = nullptr; long sk_tickets_cap = 0; int streamk = 1;   // stream-K: per-tile tickets; A/B switch
+    int balanced = 1;                                   // few query tiles: balanced shares (K2b) or chunks (K2k): A/B switch
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 64;      // query tiles per scheduling group of the variance kernel.  With the diagonal blocks cut short
                              // (variant 2) 64 beats 32: 70.7 against 70.0 TF at C2', fabric-side fetches 61.3 -> 42.9 M KiB per launch
@@ -292,7 +292,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     (void)hipDeviceSynchronize();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
-    dev_free(h->stream_vp); dev_free(h->stream_tickets); dev_free(h->sk_tickets);
+    dev_free(h->stream_vp); dev_free(h->stream_tickets);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
     dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->chain_done); dev_free(h->call_ticket);
     if (h->chain_status_host) (void)hipHostFree(h->chain_status_host);
@@ -1204,9 +1204,9 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, (int)Tc, s));
         nrb = (h->Np + 255) / 256;
-    } else if (h->small_path && h->streamk && sr_var_splitk_wanted(h->Np, Tp, h->n_out) && sr_var_streamk_wanted(h->Np, Tp, h->n_out)) {
-        // few query tiles: equal shares of the k-blocks of all tiles, reduced in the same launch (stream-K)
-        const long need = sr_var_streamk_ws(h->Np, Tp, h->n_out);
+    } else if (h->small_path && h->balanced && sr_var_splitk_wanted(h->Np, Tp, h->n_out) && sr_var_bal_wanted(h->Np, Tp, h->n_out)) {
+        // few query tiles: equal shares of the k-blocks of all tiles, the segments of a tile added by a second launch
+        const long need = sr_var_bal_ws(h->Np, Tp, h->n_out);
         if (need > h->splitk_cap) {
             (void)hipStreamSynchronize(s);
             dev_free(h->splitk_vt);
@@ -1214,17 +1214,11 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
             SR_TRY(dev_alloc(&h->splitk_vt, (size_t)need));
             h->splitk_cap = need;
         }
-        const long ntk = sr_var_streamk_tickets(h->Np, Tp, h->n_out);
-        if (ntk > h->sk_tickets_cap) {
-            (void)hipStreamSynchronize(s);
-            dev_free(h->sk_tickets);
-            h->sk_tickets = nullptr; h->sk_tickets_cap = 0;
-            SR_TRY(dev_alloc(&h->sk_tickets, (size_t)ntk));
-            SR_TRY(dev_zero(h->sk_tickets, sizeof(unsigned) * ntk));
-            h->sk_tickets_cap = ntk;
-        }
+        if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));
+        var_part = h->splitk_part;
+        nrb = 4 * (h->Np / SR_NB);
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var_streamk(h->Wt, h->Ks, h->splitk_vt, h->sk_tickets, h->var_part, h->N, h->Np, Tp, h->n_out, s));
+        SR_TRY(sr_launch_var_bal(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else if (h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) {
         // few query tiles: split the K range so that no workgroup serialises a whole row block
         const long need = sr_var_splitk_ws(h->Np, Tp, h->n_out);
@@ -1910,7 +1904,7 @@ extern "C" int sr_gp_chain_status(sr_gp_t h, int* timed_out) {
 extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_small_path: NULL handle");
     h->small_path = on & 3;  // 0: plain three-kernel pass only; 1: all latency paths; 2: all but the fused K0
-    h->streamk = (on & 4) ? 0 : 1;       // + 4: the two-launch split-K form instead of stream-K (A/B measurements)
+    h->balanced = (on & 4) ? 0 : 1;      // + 4: the chunks of K2k instead of the balanced shares of K2b (A/B measurements)
     return SR_OK;
 }
 
@@ -2144,7 +2138,6 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
         h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
         h->splitk_cap = 0;
-        dev_free(h->sk_tickets); h->sk_tickets = nullptr; h->sk_tickets_cap = 0;
         dev_free(h->stream_vp); dev_free(h->stream_tickets);
         h->stream_vp = nullptr; h->stream_vp_cap = 0; h->stream_tickets = nullptr;
         dev_free(h->fact_ws); h->fact_ws = nullptr; h->fact_cap = 0;
@@ -2280,7 +2273,6 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
         dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
         h->lin_v = h->lin_g = h->small_vp = h->splitk_vt = h->splitk_part = nullptr;
         h->splitk_cap = 0;
-        dev_free(h->sk_tickets); h->sk_tickets = nullptr; h->sk_tickets_cap = 0;
         dev_free(h->stream_vp); dev_free(h->stream_tickets);
         h->stream_vp = nullptr; h->stream_vp_cap = 0; h->stream_tickets = nullptr;
         dev_free(h->fact_ws); h->fact_ws = nullptr; h->fact_cap = 0;

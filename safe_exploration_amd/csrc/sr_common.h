@@ -241,12 +241,11 @@ int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int
                     hipStream_t s);
 
 // split-K form of the variance kernel for few query tiles (sr_predict.hip, K2k)
-// balanced one-launch form of the same regime (stream-K): workspace doubles, tickets (zeroed once, self-resetting)
-bool sr_var_streamk_wanted(int Np, long Tp, int n_out);
-long sr_var_streamk_ws(int Np, long Tp, int n_out);
-long sr_var_streamk_tickets(int Np, long Tp, int n_out);
-int sr_launch_var_streamk(const double* Wt, const double* Ks, double* Vt, unsigned* tickets, double* part, int N, int Np,
-                          long Tp, int n_out, hipStream_t s);
+// balanced form of the same regime (equal shares of the k-blocks + a reduce pass, K2b): workspace doubles; part layout of K2k
+bool sr_var_bal_wanted(int Np, long Tp, int n_out);
+long sr_var_bal_ws(int Np, long Tp, int n_out);
+int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
+                      hipStream_t s);
 long sr_var_splitk_ws(int Np, long Tp, int n_out);
 bool sr_var_splitk_wanted(int Np, long Tp, int n_out);
 int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,

@@ -549,17 +549,21 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2b: the same regime as K2k (few query tiles), BALANCED ("stream-K") and in ONE launch.  The work of the launch is the
-// list of k-blocks (128 k-rows of one 128 x 128 output tile), tiles ordered (output, query tile, row block DEScending:
-// heavy tiles first), blocks ascending inside a tile; workgroup g of G takes the contiguous share [g U / G, (g + 1) U / G)
-// of its U entries -- the same number of MFMAs for everybody, whatever the triangular k range of a tile (K2k cuts every
-// tile into chunks of 1 / 2 / 4 / 8 blocks: at N = 5000, T = 128 that is 440 workgroups of up to 4 blocks on 512 slots,
-// CUs with two of them take twice as long as CUs with one).  A share covers at most two partial tiles (its first and its
-// last) plus whole tiles in between.  A partial product goes to the workgroup's slot (accumulator layout, coalesced);
-// a ticket per tile elects the LAST arriver, which adds the tile's segments in ascending k order (its own from
-// registers: the sum does not depend on who is last), squares, reduces over the rows -- no second pass, no second launch.
-// Hand-off protocol of sr_stream.hip: agent-scope stores, s_waitcnt vmcnt(0), barrier, relaxed agent atomic; nobody waits
-// for anybody, so the workgroups need not be co-resident.
+// K2b: the same regime as K2k (few query tiles), BALANCED ("stream-K" shares).  The work of the launch is the list of
+// k-blocks (128 k-rows of one 128 x 128 output tile), tiles ordered (output, query tile, row block DEScending: heavy tiles
+// first), blocks ascending inside a tile; workgroup g of G takes the contiguous share [g U / G, (g + 1) U / G) of its U
+// entries -- the same number of MFMAs for everybody, whatever the triangular k range of a tile (K2k cuts every tile into
+// chunks of 1 / 2 / 4 / 8 blocks: at N = 5000, T = 128 that is 440 workgroups of up to 4 blocks on 512 slots, CUs with two
+// of them take twice as long as CUs with one).  A share covers at most two partial tiles (its first and its last) plus
+// whole tiles in between: a whole tile is squared and reduced on the spot, a partial product goes to the workgroup's slot
+// (accumulator layout, coalesced), and sr_var_bal_reduce_kernel -- four workgroups per tile, one per row of MFMA tiles of
+// the accumulator layout -- adds a tile's segments in ascending k order: deterministic, whoever ran first.
+// (First form of round 3: ONE launch, a ticket per tile electing the last arriving share to add the segments.  With 40 row
+//  blocks under one or two query tiles a heavy tile has a dozen segments of 128 KB and its last arriver adds them alone at
+//  the tail of the launch: N = 5000, T = 128 / 256: 192 / 297 us against 168 / 287 of K2k; with the second launch instead
+//  158 / 257, and it is faster everywhere else too -- N = 2000 T = 256 / 512: 96 / 136 -> 83 / 118 us, N = 3000 T = 512:
+//  207 -> 198, N = 4000 T = 128 / 512: 167 / 441 -> 120 / 323, N = 5000 T = 512 / 1024: 483 / 896 -> 451 / 844;
+//  profiles/r03_streamk.txt.)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ long sr_sk_bound(long g, long U, long G) { return (g * U) / G; }
 __device__ __forceinline__ long sr_sk_owner(long u, long U, long G) {        // the g with bound(g) <= u < bound(g + 1)
@@ -569,13 +573,10 @@ __device__ __forceinline__ long sr_sk_owner(long u, long U, long G) {        // 
     return g;
 }
 
-__global__ __launch_bounds__(256, 2) void sr_var_streamk_kernel(const double* __restrict__ Wt,
-                                                                const double* __restrict__ Ks,
-                                                                double* Vt, unsigned* tickets,
-                                                                double* __restrict__ part, int Np, long Tp,
-                                                                int nrb, int ntq, int k_beg, long U) {
+__global__ __launch_bounds__(256, 2) void sr_var_bal_kernel(const double* __restrict__ Wt, const double* __restrict__ Ks,
+                                                            double* Vt, double* __restrict__ part, int Np, long Tp,
+                                                            int nrb, int ntq, int k_beg, long U) {
     __shared__ double smem[srt::SMEM_DOUBLES];
-    __shared__ int s_flag;
     const long G = gridDim.x;
     const long S = (long)nrb * (nrb + 1) / 2;                 // blocks of one (output, query tile)
     // Which share this workgroup takes.  Workgroups b, b + 8, .. run on the same XCD and share its L2: they take the SAME
@@ -613,60 +614,16 @@ __global__ __launch_bounds__(256, 2) void sr_var_streamk_kernel(const double* __
         srt::Acc acc;
         acc.zero();
         srt::mainloop_tn_glds<16>(A, Np, B, Tp, k0, k1, smem, acc);
-        bool finish = (len == n);                              // the whole tile was ours
-        if (!finish) {
-            const long t0 = dx * S + c;                        // the tile's first entry
-            const long g_first = sr_sk_owner(t0, U, G), g_last = sr_sk_owner(t0 + n - 1, U, G);
-            const int nseg = (int)(g_last - g_first + 1), mine = (int)(g - g_first);
-            // slot of segment sg of a tile: its workgroup's slot 1 if the tile starts in that workgroup's share, else 0
-            double* slot = Vt + ((g * 2) + (mine == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN);
+        if (len != n) {
+            // slot of a segment: its workgroup's slot 1 if the tile starts in that workgroup's share, else 0
+            double* slot = Vt + ((g * 2) + (o == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) sr_st_agent(slot + ((mi * 4 + ni) * 4 + q) * 256 + tid, acc.v[mi][ni][q]);
-            unsigned* tk = tickets + (dx * nrb + rb);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = (old == (unsigned)nseg - 1u);
-                if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_flag = last;
-            }
-            __syncthreads();
-            if (s_flag) {
-                // segments in ascending k order; ours comes from the registers.  One row of MFMA tiles (16 values per lane)
-                // at a time, the loads of a segment issued together (with the segment loop innermost every one of the
-                // 64 x nseg loads waited for its own L2 round trip: 430 us at N = 5000, T = 128)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    double v[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = 0.0;
-                    for (int sg = 0; sg < nseg; ++sg) {
-                        if (sg == mine) {
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) v[e] += acc.v[mi][e >> 2][e & 3];
-                        } else {
-                            const double* src = Vt + (((g_first + sg) * 2) + (sg == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN) +
-                                                (long)(mi * 16) * 256 + tid;
-                            double w[16];
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) w[e] = sr_ld<true>(src + e * 256);
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) v[e] += w[e];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc.v[mi][e >> 2][e & 3] = v[e];
-                }
-                finish = true;
-            }
-            __syncthreads();                                   // s_flag and smem are reused
-        }
-        if (finish) {
+                    for (int q = 0; q < 4; ++q) slot[((mi * 4 + ni) * 4 + q) * 256 + tid] = acc.v[mi][ni][q];
+        } else {                                               // the whole tile was ours
             double sq[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
@@ -679,50 +636,83 @@ __global__ __launch_bounds__(256, 2) void sr_var_streamk_kernel(const double* __
                 v += __shfl_xor(v, 32);
                 sq[ni] = v;
             }
+            __syncthreads();                                   // (the main loop's LDS is reused)
             double* red = smem;
             if (lane < 16) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) red[wm * 128 + wn * 64 + ni * 16 + lane] = sq[ni];
             }
             __syncthreads();
-            if (tid < 128) part[((long)d * nrb + rb) * Tp + (long)x * srt::BN + tid] = red[tid] + red[128 + tid];
+            // four partial norms per tile (the layout of the reduce pass): the whole norm and three zeros
+            double* pt = part + ((long)d * 4 * nrb + rb * 4) * Tp + (long)x * srt::BN;
+            if (tid < 128) pt[tid] = red[tid] + red[128 + tid];
+            else for (int q = 1; q < 4; ++q) pt[q * Tp + tid - 128] = 0.0;
             __syncthreads();
         }
         u += len;
     }
 }
 
-// workgroups of the launch: two per CU of a 256-CU part (fewer when there is less work)
-// workgroups of the launch: two per CU once there are four blocks for each of them, one per CU below (fewer segments per
-// tile: the last arriver of a tile reads every other segment, 128 KB each, in batches that each wait for an L2 round trip)
-static long streamk_wgs(long U) {
-    const long g = U >= 2048 ? 512 : 256;
-    return g < U ? g : U;
+__global__ __launch_bounds__(256) void sr_var_bal_reduce_kernel(const double* __restrict__ Vt, double* __restrict__ part,
+                                                                long Tp, int nrb, int ntq, long U, long G) {
+    __shared__ double red[256];
+    const int mi = blockIdx.x;
+    const long dx = blockIdx.y / nrb;
+    const int rb = blockIdx.y % nrb, j = nrb - 1 - rb, n = rb + 1;
+    const long S = (long)nrb * (nrb + 1) / 2;
+    const long t0 = dx * S + (long)j * nrb - (long)j * (j - 1) / 2;        // the tile's first entry (heavy tiles first)
+    const long g_first = sr_sk_owner(t0, U, G), g_last = sr_sk_owner(t0 + n - 1, U, G);
+    if (g_first == g_last) return;                             // one segment: finished by its workgroup
+    const int nseg = (int)(g_last - g_first + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    double v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.0;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const double* src = Vt + (((g_first + sg) * 2) + (sg == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN) + (long)(mi * 16) * 256 + tid;
+        double w[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[e] = src[e * 256];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += w[e];
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        double q = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q = fma(v[ni * 4 + r], v[ni * 4 + r], q);
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        if (lane < 16) red[wm * 128 + wn * 64 + ni * 16 + lane] = q;
+    }
+    __syncthreads();
+    const int d = (int)(dx / ntq), x = (int)(dx % ntq);
+    if (tid < 128) part[((long)d * 4 * nrb + rb * 4 + mi) * Tp + (long)x * srt::BN + tid] = red[tid] + red[128 + tid];
 }
 
-// Measured against the two-launch split-K form (predict wall time in us, n_out = 2; profiles/r03_streamk.txt):
-//   N = 2000: T = 256 106 -> 98, 512 157 -> 131, 1024 239 -> 204;   N = 3000: T = 256 160 -> 134, 512 276 -> 210, 1024 480 -> 365;
-//   N = 5000: T = 512 533 -> 485, 1024 996 -> 907;  but T = 128 168 -> 192 and T = 256 287 -> 297 there: with 40 row blocks
-//   and one or two query tiles the heavy tiles are cut into a dozen segments and their reduction is the tail of the launch.
-bool sr_var_streamk_wanted(int Np, long Tp, int n_out) {
+// workgroups of the launch: one per CU, two once there are nine blocks for each of them (measured, G = 256 against 512,
+// n_out = 2: N = 4000 T = 128 (U = 1056) 120 / 137 us, N = 5000 T = 128 (1640) 158 / 161, T = 256 (3280) 257 / 263, N = 4500
+// T = 256 (2664) 222 / 216, N = 3000 T = 512 (2400) 204 / 198, N = 5000 T = 512 (6560) 476 / 451; 384 or 768 workgroups --
+// shares that do not line up with the residency of the chip -- lose 15 - 25 %)
+static long bal_wgs(long U) { return U >= 2304 ? 512 : (U >= 256 ? 256 : U); }
+long sr_var_bal_ws(int Np, long Tp, int n_out) {
     const long nrb = Np / srt::BM;
-    const long U = (long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2;
-    return U >= 512 && (nrb <= 28 || U >= 5000);
+    return bal_wgs((long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2) * 2 * (long)(srt::BM * srt::BN);
 }
-
-long sr_var_streamk_ws(int Np, long Tp, int n_out) {
+// (below 256 blocks the chunks of K2k are as good)
+bool sr_var_bal_wanted(int Np, long Tp, int n_out) {
     const long nrb = Np / srt::BM;
-    return streamk_wgs((long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2) * 2 * (long)(srt::BM * srt::BN);
+    return (long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2 >= 256;
 }
-long sr_var_streamk_tickets(int Np, long Tp, int n_out) { return (long)n_out * (Tp / srt::BN) * (Np / srt::BM); }
-
-int sr_launch_var_streamk(const double* Wt, const double* Ks, double* Vt, unsigned* tickets, double* part, int N, int Np,
-                          long Tp, int n_out, hipStream_t s) {
+int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
+                      hipStream_t s) {
     const int k_beg = ((Np - N) / srt::BK) * srt::BK;
     const int nrb = Np / srt::BM, ntq = (int)(Tp / srt::BN);
     const long U = (long)n_out * ntq * nrb * (nrb + 1) / 2;
-    hipLaunchKernelGGL(sr_var_streamk_kernel, dim3((unsigned)streamk_wgs(U)), dim3(256), 0, s, Wt, Ks, Vt, tickets, part, Np,
-                       Tp, nrb, ntq, k_beg, U);
+    const long G = bal_wgs(U);
+    hipLaunchKernelGGL(sr_var_bal_kernel, dim3((unsigned)G), dim3(256), 0, s, Wt, Ks, Vt, part, Np, Tp, nrb, ntq, k_beg, U);
+    SR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(sr_var_bal_reduce_kernel, dim3(4, n_out * ntq * nrb), dim3(256), 0, s, Vt, part, Tp, nrb, ntq, U, G);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

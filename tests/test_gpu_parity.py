@@ -502,12 +502,14 @@ def test_small_batch_streaming_path_matches_mfma_path(N, T):
     np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("N,T", [(1300, 17), (1300, 300), (2500, 129), (2000, 500), (3100, 1000), (1900, 257)])
+@pytest.mark.parametrize("N,T", [(1300, 17), (1300, 300), (2500, 129), (2000, 500), (3100, 1000), (1900, 257), (4100, 130),
+                                 (600, 700)])
 def test_splitk_path_matches_plain_path(N, T):
-    """few query tiles + more than 8 row blocks -> the K range of a tile is shared between workgroups: balanced shares
-    reduced inside one launch (stream-K; (2000, 500), (3100, 1000), (1900, 257) and (1300, 300) take it) or chunks reduced
-    by a second launch (split-K: the others, and everything with set_small_path(5)).  Both must agree with the plain
-    tiles, and stream-K with itself call after call (its tickets reset themselves)."""
+    """few query tiles -> the K range of a tile is shared between workgroups: balanced shares of the k-blocks of all tiles
+    (sr_var_bal_kernel: 256 blocks or more -- all cases but (1300, 17), which streams, and some shares cover whole tiles,
+    the end of one and the start of the next) or chunks of 1 / 2 / 4 / 8 blocks (split-K: set_small_path(5)), the segments
+    of a tile added by a second launch in ascending k order.  Both must agree with the plain tiles, and with themselves
+    call after call."""
     syn = orc.make_synthetic(N + T, N, 2, 1, T)
     gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
     x = np.hstack((syn["p"], syn["k_ff"]))
@@ -516,7 +518,7 @@ def test_splitk_path_matches_plain_path(N, T):
     for _ in range(3):
         mu_r, var_r = gp.predict(x)
         np.testing.assert_array_equal(var_r, var_s)          # deterministic: segments are added in ascending k order
-    gp.set_small_path(5)                                       # split-K instead of stream-K
+    gp.set_small_path(5)                                       # split-K chunks instead of balanced shares
     mu_k, var_k = gp.predict(x)
     gp.set_small_path(False)
     mu_m, var_m = gp.predict(x)
