@@ -668,13 +668,20 @@ __global__ __launch_bounds__(256) void sr_var_bal_reduce_kernel(const double* __
     double v[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = 0.0;
-    for (int sg = 0; sg < nseg; ++sg) {
-        const double* src = Vt + (((g_first + sg) * 2) + (sg == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN) + (long)(mi * 16) * 256 + tid;
-        double w[16];
+    // four segments' loads in flight (a heavy tile has 7 - 13 segments: one dependent round trip each cost 18 us at N = 5000)
+    for (int sg0 = 0; sg0 < nseg; sg0 += 4) {
+        double w[4][16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) w[e] = src[e * 256];
+        for (int b = 0; b < 4; ++b) {
+            const int sg = sg0 + b;
+            const double* src = Vt + (((g_first + sg) * 2) + (sg == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN) + (long)(mi * 16) * 256 + tid;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += w[e];
+            for (int e = 0; e < 16; ++e) w[b][e] = (sg < nseg) ? src[e * 256] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += w[b][e];
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
