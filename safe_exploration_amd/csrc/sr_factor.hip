@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void sr_gram_kernel(const double* __restrict__
     __shared__ double zs[SR_GRAM_ROWS][SR_MAX_D];
     const int i0 = blockIdx.y * SR_GRAM_ROWS;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (((blockIdx.x * 256 + 255) | 127) < i0) return;   // blocks left of the diagonal are never read (upper factorisation)
+    if ((int)((blockIdx.x * 256 + 255) | 127) < i0) return;   // blocks left of the diagonal are never read (upper factorisation)
     const int b = blockIdx.z;                // batch member (output)
     ls += (long)b * D;
     K += (long)b * strideK;
@@ -1196,14 +1196,14 @@ __global__ __launch_bounds__(256) void sr_append_alpha_kernel(const double* __re
             if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
         }
         __syncthreads();
-        if (threadIdx.x < 16 && q0 + threadIdx.x < m) {
+        if (threadIdx.x < 16 && q0 + (int)threadIdx.x < m) {
             const int q = q0 + threadIdx.x;
             const double mu = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
             r[q] = Ynew[(long)q * n_out + d] - mu;
         }
         __syncthreads();
     }
-    if (threadIdx.x < m) {
+    if ((int)threadIdx.x < m) {
         double v = 0.0;
         for (int b = 0; b <= (int)threadIdx.x; ++b) v = fma(invS[(pf + b) * SR_NB + pf + threadIdx.x], r[b], v);
         v2[threadIdx.x] = v;

@@ -151,7 +151,7 @@ __device__ __forceinline__ void sr_small_rows_fill(const sr_kstar_args& a, int d
 }
 template <int DT>
 __device__ __forceinline__ void sr_small_il_fill(const sr_kstar_args& a, int d, double* il) {
-    if (threadIdx.x < DT) il[threadIdx.x] = (threadIdx.x < a.D) ? 1.0 / a.ls[d * a.D + threadIdx.x] : 0.0;
+    if (threadIdx.x < DT) il[threadIdx.x] = ((int)threadIdx.x < a.D) ? 1.0 / a.ls[d * a.D + threadIdx.x] : 0.0;
 }
 
 // Phase A alone: k* into L.ks, R = k*^T M into L.Rs (valid for threads < 256 right away, for everybody after the next

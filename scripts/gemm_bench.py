@@ -4,7 +4,6 @@ both orders against each other and NumPy.  GPU box:  python scripts/gemm_bench.p
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

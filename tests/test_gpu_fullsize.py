@@ -191,7 +191,7 @@ def test_casadi_evaluator_callbacks_on_the_hip_model(kt, N, n_s, n_u, monkeypatc
     from safe_exploration_amd import SimpleGPModel
     monkeypatch.syspath_prepend(STANDIN)
     monkeypatch.delitem(sys.modules, "casadi", raising=False)
-    import casadi
+    import casadi  # noqa: F401  (the stand-in must be the module the evaluator finds)
     rng = np.random.default_rng(N + n_s)
     D = n_s + n_u
     Z = rng.uniform(-1, 1, (N, D))
