@@ -1159,7 +1159,11 @@ static int stream_linearize(sr_gp* h, const double* x, double* mu, double* var, 
 // GP posterior of Tc queries x = [xa | xb] into (mu, var, jac) in API layout (jac may be NULL).
 static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb,
                    int nb, double* mu, double* var, double* jac, hipStream_t s) {
-    if (h->small_path == 1 && !h->force_stream && sr_gp_small_wanted(h->Np, Tc, h->D, h->general != 0)) {
+    // (ONE query against Np = 384: the one-launch pass is a single workgroup per output that fetches 590 KB of U^-1 on its
+    //  own, 18.8 us; the streamed route spreads them over 6 workgroups per output: 12.4 us.  From 4 queries on the two
+    //  are level, and 16 queries share one fetch in the one-launch pass.)
+    const bool one_streamed = h->Np == 384 && Tc == 1 && !h->general && h->D <= 5;
+    if (h->small_path == 1 && !h->force_stream && !one_streamed && sr_gp_small_wanted(h->Np, Tc, h->D, h->general != 0)) {
         // small model, few queries: one launch, no workspace (sr_small.hip)
         sr_kstar_args ka{};
         ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
@@ -1171,7 +1175,8 @@ static int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const 
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         return sr_launch_gp_small(ka, h->Wt, mu, var, jac, s);
     }
-    if (h->small_path != 0 && !h->force_stream && h->Np > SR_STREAM_MIN_NP && Tc <= stream_max_t())
+    if (h->small_path != 0 && !h->force_stream && (h->Np > SR_STREAM_MIN_NP || (one_streamed && h->small_path == 1)) &&
+        Tc <= stream_max_t())
         return stream_predict(h, Tc, xa, lda, na, xb, ldb, nb, mu, var, jac, s);   // U^-1 streamed once, 1-3 launches
     const long Tp = round_up(Tc, srt::BN);
     const int nsplit = pick_nsplit(h, Tp);

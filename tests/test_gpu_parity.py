@@ -1203,6 +1203,45 @@ def test_fused_small_model_linearize(N, n_s, n_u):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,n_s,n_u", [(300, 2, 1), (384, 4, 1), (257, 3, 2)])
+def test_single_query_against_384_rows_takes_the_streamed_route(N, n_s, n_u):
+    """ONE query against a model padded to 384 rows (ARD-RBF, D <= 5): the streamed kernel (6 workgroups per output share
+    the fetch of U^-1) instead of the one-launch pass (one workgroup per output); two or more queries keep the one-launch
+    pass.  Both against the oracle and against each other."""
+    from safe_exploration_amd import _lib
+    syn = orc.make_synthetic(4000 + N, N, n_s, n_u, 8)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    at = max(mu_atol(om), 1e-12)
+    for T, small in ((1, 0), (2, 1)):
+        gp.prof_reset(); gp.prof_enable(True)
+        mu, var, jac = gp.predict(x[:T], None, True)
+        gp.prof_enable(False)
+        assert gp.prof_get(_lib.K_SMALL)[1] == small and gp.prof_get(_lib.K_VAR)[1] == 1 - small
+        rmu, rvar, rjac = orc.gp_predict(x[:T], om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], True)
+        np.testing.assert_allclose(mu, rmu, rtol=1e-9, atol=at)
+        np.testing.assert_allclose(jac, rjac, rtol=1e-9, atol=10 * at)
+        np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-9)
+        if T == 1:
+            mu1, var1, jac1 = mu, var, jac
+        else:
+            np.testing.assert_allclose(mu[:1], mu1, rtol=1e-12, atol=1e-3 * at)
+            np.testing.assert_allclose(jac[:1], jac1, rtol=1e-11, atol=1e-2 * at)
+            np.testing.assert_allclose(var[:1], var1, rtol=0, atol=1e-12)
+    # the one-step reachability of a single state goes the same way
+    from safe_exploration_amd import gp_reachability as reach
+    l = np.full(n_s, 0.05)
+    q = 0.01 * np.eye(n_s)
+    k_fb = 0.1 * np.ones((n_u, n_s))
+    p1, q1 = reach.onestep_reachability(syn["p"][0][:, None], gp, syn["k_ff"][0][:, None], l, l, q_shape=q, k_fb=k_fb,
+                                        c_safety=2.0, verbose=0)
+    rp, rq, _ = orc.onestep_reachability_batch(om, syn["p"][:1], q[None], syn["k_ff"][:1], k_fb[None], l, l, 2.0)
+    np.testing.assert_allclose(np.asarray(p1).ravel(), rp[0], rtol=1e-9, atol=at)
+    np.testing.assert_allclose(np.asarray(q1), rq[0], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kt,N,T", [("mat52", 90, 5), ("lin_mat52", 150, 40), ("lin_rbf", 256, 300), ("mat52", 400, 200), ("mat52", 300, 17),
                                     ("lin_mat52", 1, 3)])
 def test_fused_small_model_pass_general_kernels(kt, N, T):
