@@ -2017,9 +2017,11 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1, pf = SR_NB - m;
     const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
     // scratch layout
-    const size_t o_u12 = 0, o_xt = o_u12 + (size_t)n_out * SR_SMALL_T * Np0, o_y2 = o_xt + (size_t)SR_SMALL_T * Np0,
-                 o_g = o_y2 + (size_t)Np0 * SR_NB, o_sb = o_g + BB, o_inv = o_sb + BB, o_wdm = o_inv + BB,
-                 o_v = o_wdm + BB, o_info = o_v + (size_t)Np1, need = o_info + (size_t)n_out;
+    // (Xt, Y2, G, S, S^-1 once per output: every step below is ONE launch over all outputs)
+    const size_t s_xt = (size_t)SR_SMALL_T * Np0, s_y2 = (size_t)Np0 * SR_NB;
+    const size_t o_u12 = 0, o_xt = o_u12 + (size_t)n_out * SR_SMALL_T * Np0, o_y2 = o_xt + n_out * s_xt,
+                 o_g = o_y2 + n_out * s_y2, o_sb = o_g + n_out * BB, o_inv = o_sb + n_out * BB,
+                 o_info = o_inv + n_out * BB, need = o_info + (size_t)n_out;
     if (h->app_cap < need) {
         (void)hipDeviceSynchronize();
         dev_free(h->app_ws);
@@ -2055,14 +2057,6 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     }
     if (reuse_alt) Wt1 = h->Wt_alt;
     else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
-    if ((int)h->sf2_host.size() != n_out) {              // first append after set_data: one blocking read
-        h->sf2_host.assign(n_out, 0.0); h->noise_host.assign(n_out, 0.0);
-        SR_AH(hipMemcpyAsync(h->sf2_host.data(), h->sf2, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
-        SR_AH(hipMemcpyAsync(h->noise_host.data(), h->noise, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
-        SR_AH(hipStreamSynchronize(s));
-    }
-    const std::vector<double>& sf2 = h->sf2_host;
-    const std::vector<double>& noise = h->noise_host;
     SR_AH(hipMemsetAsync(info_dev, 0, sizeof(int) * n_out, s));
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
@@ -2084,26 +2078,24 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     if (!h->small_vp) SR_A(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(Np0, n_out)));
     SR_A(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, N0, Np0, Tp, n_out, m, s));
     SR_A(sr_launch_var_small_gather_all(h->small_vp, U12t, Np0, n_out, m, s));
-    for (int d = 0; d < n_out; ++d) {
-        const double* Wt0 = h->Wt + (size_t)d * NN0;
-        const double* u12 = U12t + (size_t)d * m * Np0;
-        SR_AH(hipMemsetAsync(G, 0, BB * sizeof(double), s));
-        SR_A(sr_launch_append_small(u12, Wt0, Np0, m, 0, G, nullptr, nullptr, nullptr, s));      // G = U12^T U12
-        if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp + (size_t)d * SR_KP(D), noise[d], nullptr, Sb, m, SR_NB, D, s));
-        else SR_A(sr_launch_gram(Znew, h->ls + (size_t)d * D, sf2[d], noise[d], nullptr, nullptr, Sb, m, SR_NB, D, s));
-        SR_A(sr_launch_sub_block(Sb, G, pf, s));                                                   // S = C - G
-        SR_A(sr_launch_potrf_corner16(Sb, SR_NB, invS, SR_NB, info_dev + d, s));                   // invS = U22^-1 (m <= 16: last pivot)
-        // Y2 = -U^-1 U12 U22^-1 and the move of the old factor to its new place in one pass over it; a buffer that
-        // did not hold an earlier state of this model is zeroed first (lower triangle, identity padding)
-        if (!(reuse_alt && h->wt_alt_off >= off1)) {
-            SR_AH(hipMemsetAsync(Wt1 + (size_t)d * NN1, 0, NN1 * sizeof(double), s));
-            SR_A(sr_launch_eye_front(Wt1 + (size_t)d * NN1, Np1, off1, s));
-        }
-        SR_A(sr_launch_append_move(Wt0, Np0, off0, N0, u12, invS, m, Xt, Y2, Wt1 + (size_t)d * NN1, Np1, off1, s));
-        // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1
-        SR_A(sr_launch_append_alpha(h->alpha + (size_t)d * Np0, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, d, Tp,
-                                    Ynew, m, alpha1 + (size_t)d * Np1, Np1, s));
+    // All outputs in every launch (round 3; before: a chain of 8 dependent launches PER OUTPUT -- 25 dispatches for one new
+    // point on a two-output model, 125 us on the host whatever the model size up to N ~ 1000):
+    // G = U12^T U12 (only its m x m corner is ever read: no zero fill), C = K(Z_new, Z_new) + noise, the corner kernel
+    // factors and inverts C - G
+    SR_A(sr_launch_append_small(U12t, h->Wt, Np0, m, 0, G, nullptr, nullptr, nullptr, s, n_out));
+    if (h->general) SR_A(sr_launch_gram_general(Znew, h->kp, 0.0, h->noise, Sb, m, SR_NB, D, s, n_out, (long)BB));
+    else SR_A(sr_launch_gram(Znew, h->ls, 0.0, 0.0, h->sf2, h->noise, Sb, m, SR_NB, D, s, n_out, (long)BB));
+    SR_A(sr_launch_potrf_corner16(Sb, SR_NB, invS, SR_NB, info_dev, s, G, pf, n_out, (long)BB, (long)BB));   // invS = U22^-1
+    // Y2 = -U^-1 U12 U22^-1 and the move of the old factor to its new place in one pass over it; a buffer that
+    // did not hold an earlier state of this model is zeroed first (lower triangle, identity padding)
+    if (!(reuse_alt && h->wt_alt_off >= off1)) {
+        SR_AH(hipMemsetAsync(Wt1, 0, (size_t)n_out * NN1 * sizeof(double), s));
+        SR_A(sr_launch_eye_front(Wt1, Np1, off1, s, n_out));
     }
+    SR_A(sr_launch_append_move(h->Wt, Np0, off0, N0, U12t, invS, m, Xt, Y2, Wt1, Np1, off1, s, n_out, (long)s_xt, (long)s_y2));
+    // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1
+    SR_A(sr_launch_append_alpha(h->alpha, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, 0, Tp, Ynew, m, alpha1, Np1, s, 0,
+                                n_out, (long)s_y2));
     std::vector<int> info_h(n_out, 0);
     SR_AH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
     SR_AH(hipStreamSynchronize(s));

@@ -135,9 +135,12 @@ int sr_launch_gram(const double* Z, const double* ls, double sf2, double noise, 
 // factor the diagonal block kb of the Np x Np matrix A (upper), write U_kk in place, U_kk^-1 to
 // wt_diag (into Wt's diagonal block) and U_kk^-T to w_diag (into W's diagonal block).
 int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const double* U12t, const double* invS, int m,
-                          double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s);
-int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s);
-int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s);
+                          double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s, int nbatch = 1,
+                          long sXt = 0, long sY2 = 0);
+int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s, int nbatch = 1);
+// G != NULL: factor A - G (rows / columns >= pf); nbatch blocks with strides sA (A) and sW (wt_diag), info_dev + b
+int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s,
+                             const double* G = nullptr, int pf = 0, int nbatch = 1, long sA = 0, long sW = 0);
 // bt: batch of blocks (sA: stride of A, sB: of wt_diag, sC: of w_diag; info_dev + b)
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
                          int kb, int* info_dev, hipStream_t s, int skip = 0, const sr_batch* bt = nullptr);
@@ -269,9 +272,9 @@ int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, i
 int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_out, int T, hipStream_t s);
 int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
                            const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
-                           double* alpha1, int Np1, hipStream_t s, int qoff = 0);
+                           double* alpha1, int Np1, hipStream_t s, int qoff = 0, int nbatch = 1, long sY2 = 0);
 int sr_launch_append_small(const double* U12t, const double* Wt0, int Np0, int m, int stage, double* G,
-                           const double* invS, double* Xt, double* Y2, hipStream_t s);
+                           const double* invS, double* Xt, double* Y2, hipStream_t s, int nbatch = 1);
 
 struct sr_final_args {
     const double* mu_part; const double* jac_part; const double* var_part; const double* sf2;

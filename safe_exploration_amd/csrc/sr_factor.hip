@@ -695,17 +695,24 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_v2_kernel(doub
 // The Schur complement of a row append of m <= 16 points lives in the LAST 16 x 16 pivot of an otherwise identity
 // 128 x 128 block: one wavefront factors and inverts that corner (3 us; the full kernel takes 62 us on the way of every
 // appended point).  Writes rows / columns 112 .. 127 of wt_diag (= U22^-1, upper) only.
+// G != NULL: the block factored is A - G on rows / columns >= pf (the Schur complement C - U12^T U12 of the append, G a
+// 128 x 128 block with leading dimension 128); blockIdx.x: batch member (strides sA of A, sW of wt_diag, 128 x 128 of G).
 __global__ __launch_bounds__(64) void sr_potrf_corner16_kernel(double* A, long lda, double* wt_diag, long ldw,
-                                                               int* info) {
+                                                               int* info, const double* __restrict__ G, int pf,
+                                                               long sA, long sW) {
     __shared__ double S[16 * SR_PD_LD];
     __shared__ double X[16 * SR_PD_XLD];
     __shared__ double invd[16];
     __shared__ int fail;
+    A += (long)blockIdx.x * sA; wt_diag += (long)blockIdx.x * sW; info += blockIdx.x;
+    if (G) G += (long)blockIdx.x * SR_NB * SR_NB;
     const int lane = threadIdx.x, c0 = SR_NB - 16;
     if (lane == 0) fail = 0;
     for (int idx = lane; idx < 256; idx += 64) {
         const int r = idx >> 4, c = idx & 15;
-        S[r * SR_PD_LD + c] = (c >= r) ? A[(long)(c0 + r) * lda + c0 + c] : 0.0;
+        double v = (c >= r) ? A[(long)(c0 + r) * lda + c0 + c] : 0.0;
+        if (G && c >= r && c0 + r >= pf) v -= G[(c0 + r) * SR_NB + c0 + c];
+        S[r * SR_PD_LD + c] = v;
     }
     __syncthreads();
     sr_factor16(S, 0, invd, &fail, lane);
@@ -722,8 +729,9 @@ __global__ __launch_bounds__(64) void sr_potrf_corner16_kernel(double* A, long l
     }
 }
 
-int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s) {
-    hipLaunchKernelGGL(sr_potrf_corner16_kernel, dim3(1), dim3(64), 0, s, A, lda, wt_diag, ldw, info_dev);
+int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int* info_dev, hipStream_t s,
+                             const double* G, int pf, int nbatch, long sA, long sW) {
+    hipLaunchKernelGGL(sr_potrf_corner16_kernel, dim3(nbatch), dim3(64), 0, s, A, lda, wt_diag, ldw, info_dev, G, pf, sA, sW);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -1045,6 +1053,7 @@ __global__ __launch_bounds__(256) void sr_append_gsmall_kernel(const double* __r
                                                                double* __restrict__ G) {
     __shared__ double red[4];
     const int a = blockIdx.x, b = blockIdx.y, pf = SR_NB - m;
+    U12t += (long)blockIdx.z * m * Np0; G += (long)blockIdx.z * SR_NB * SR_NB;      // batch member (output)
     double v = 0.0;
     for (int i = threadIdx.x; i < Np0; i += 256) v = fma(U12t[(long)a * Np0 + i], U12t[(long)b * Np0 + i], v);
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1056,8 +1065,9 @@ __global__ __launch_bounds__(256) void sr_append_gsmall_kernel(const double* __r
 // Xt[c][i] = sum_{a <= c} U12t[a][i] invS[pf+a][pf+c]   (X = U12 U22^-1, U22^-1 upper triangular)
 __global__ __launch_bounds__(256) void sr_append_xt_kernel(const double* __restrict__ U12t,
                                                            const double* __restrict__ invS, int Np0, int m,
-                                                           double* __restrict__ Xt) {
+                                                           double* __restrict__ Xt, long sXt) {
     const int i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, pf = SR_NB - m;
+    U12t += (long)blockIdx.z * m * Np0; invS += (long)blockIdx.z * SR_NB * SR_NB; Xt += (long)blockIdx.z * sXt;
     if (i >= Np0) return;
     double v = 0.0;
     for (int a = 0; a <= c; ++a) v = fma(U12t[(long)a * Np0 + i], invS[(pf + a) * SR_NB + pf + c], v);
@@ -1100,8 +1110,12 @@ __global__ __launch_bounds__(256) void sr_append_move_kernel(const double* __res
                                                              const double* __restrict__ Xt,
                                                              const double* __restrict__ invS, int m,
                                                              double* __restrict__ Y2, double* __restrict__ Wt1,
-                                                             int Np1, int off1) {
+                                                             int Np1, int off1, long sXt, long sY2) {
     const int lane = threadIdx.x & 63, pf = SR_NB - m;
+    {                                                       // batch member (output)
+        const long b = blockIdx.y;
+        Wt0 += b * Np0 * Np0; Xt += b * sXt; invS += b * SR_NB * SR_NB; Y2 += b * sY2; Wt1 += b * Np1 * Np1;
+    }
     const int nrow_blocks = (Np0 + 3) / 4;
     if ((int)blockIdx.x >= nrow_blocks) {
         // rows of the new points: Wt1[off1 + N0 + q][off1 + N0 + c] = U22^-1[q][c]
@@ -1139,27 +1153,31 @@ __global__ __launch_bounds__(256) void sr_append_move_kernel(const double* __res
 // ones on the first n diagonal entries (identity padding of a zeroed matrix)
 __global__ __launch_bounds__(256) void sr_eye_front_kernel(double* __restrict__ W, int ld, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    W += (long)blockIdx.y * ld * ld;                        // batch member: ld x ld matrices back to back
     if (i < n) W[(long)i * ld + i] = 1.0;
 }
 
-int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s) {
+int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s, int nbatch) {
     if (n <= 0) return SR_OK;
-    hipLaunchKernelGGL(sr_eye_front_kernel, dim3((n + 255) / 256), dim3(256), 0, s, W, ld, n);
+    hipLaunchKernelGGL(sr_eye_front_kernel, dim3((n + 255) / 256, nbatch), dim3(256), 0, s, W, ld, n);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
 
+// nbatch outputs in one launch each: U12t (m x Np0 each), invS (128 x 128), Wt0 / Wt1 (full squares) back to back, Xt and Y2
+// with the strides given
 int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const double* U12t, const double* invS, int m,
-                          double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s) {
-    hipLaunchKernelGGL(sr_append_xt_kernel, dim3((Np0 + 255) / 256, m), dim3(256), 0, s, U12t, invS, Np0, m, Xt);
+                          double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s, int nbatch, long sXt,
+                          long sY2) {
+    hipLaunchKernelGGL(sr_append_xt_kernel, dim3((Np0 + 255) / 256, m, nbatch), dim3(256), 0, s, U12t, invS, Np0, m, Xt, sXt);
     SR_HIP(hipGetLastError());
-    const dim3 grid((Np0 + 3) / 4 + 1);
+    const dim3 grid((Np0 + 3) / 4 + 1, nbatch);
     if (m <= 1)
-        hipLaunchKernelGGL(sr_append_move_kernel<1>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1);
+        hipLaunchKernelGGL(sr_append_move_kernel<1>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt, sY2);
     else if (m <= 4)
-        hipLaunchKernelGGL(sr_append_move_kernel<4>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1);
+        hipLaunchKernelGGL(sr_append_move_kernel<4>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt, sY2);
     else
-        hipLaunchKernelGGL(sr_append_move_kernel<16>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1);
+        hipLaunchKernelGGL(sr_append_move_kernel<16>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt, sY2);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
@@ -1173,10 +1191,14 @@ __global__ __launch_bounds__(256) void sr_append_alpha_kernel(const double* __re
                                                               const double* __restrict__ mu_part, int nsplit,
                                                               int n_out, int d, long Tp,
                                                               const double* __restrict__ Ynew, int m,
-                                                              double* __restrict__ alpha1, int Np1, int qoff) {
+                                                              double* __restrict__ alpha1, int Np1, int qoff, long sY2) {
     // qoff: position of the first new point among the queries of the K* pass (front-padded query block: 128 - m)
     __shared__ double r[SR_NB], v2[SR_NB], red[4][16];
     const int pf = SR_NB - m, off0 = Np0 - N0, off1 = Np1 - (N0 + m);
+    {                                                       // batch: output d + blockIdx.y, the pointers given belong to d
+        const long b = blockIdx.y;
+        d += (int)b; alpha0 += b * Np0; Y2 += b * sY2; invS += b * SR_NB * SR_NB; alpha1 += b * Np1;
+    }
     // mean of the old model at the new points: the N-split partials of the K* pass, summed by the whole workgroup
     // (one thread per point walking up to Np / 16 partials was 119 us of dependent-latency at N = 5000)
     for (int q0 = 0; q0 < m; q0 += 16) {
@@ -1227,19 +1249,19 @@ __global__ __launch_bounds__(256) void sr_append_alpha_kernel(const double* __re
 
 int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
                            const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
-                           double* alpha1, int Np1, hipStream_t s, int qoff) {
-    hipLaunchKernelGGL(sr_append_alpha_kernel, dim3((Np1 + 255) / 256), dim3(256), 0, s, alpha0, Np0, N0, Y2, invS,
-                       mu_part, nsplit, n_out, d, Tp, Ynew, m, alpha1, Np1, qoff);
+                           double* alpha1, int Np1, hipStream_t s, int qoff, int nbatch, long sY2) {
+    hipLaunchKernelGGL(sr_append_alpha_kernel, dim3((Np1 + 255) / 256, nbatch), dim3(256), 0, s, alpha0, Np0, N0, Y2, invS,
+                       mu_part, nsplit, n_out, d, Tp, Ynew, m, alpha1, Np1, qoff, sY2);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
 
 int sr_launch_append_small(const double* U12t, const double* Wt0, int Np0, int m, int stage, double* G,
-                           const double* invS, double* Xt, double* Y2, hipStream_t s) {
+                           const double* invS, double* Xt, double* Y2, hipStream_t s, int nbatch) {
     if (stage == 0) {
-        hipLaunchKernelGGL(sr_append_gsmall_kernel, dim3(m, m), dim3(256), 0, s, U12t, Np0, m, G);
+        hipLaunchKernelGGL(sr_append_gsmall_kernel, dim3(m, m, nbatch), dim3(256), 0, s, U12t, Np0, m, G);
     } else {
-        hipLaunchKernelGGL(sr_append_xt_kernel, dim3((Np0 + 255) / 256, m), dim3(256), 0, s, U12t, invS, Np0, m, Xt);
+        hipLaunchKernelGGL(sr_append_xt_kernel, dim3((Np0 + 255) / 256, m), dim3(256), 0, s, U12t, invS, Np0, m, Xt, 0L);
         SR_HIP(hipGetLastError());
         if (m <= 1)
             hipLaunchKernelGGL(sr_append_y2_kernel<1>, dim3((Np0 + 3) / 4), dim3(256), 0, s, Wt0, Np0, Xt, m, Y2);

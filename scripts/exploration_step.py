@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""The inner loop of the reference's exploration runner, per step (exploration_runner.py:176-189): one query through
+predict (NumPy in, NumPy out), one observed transition appended with update_model(replace_old=False), the information
+gain.  Wall time per call and per step, by model size.  GPU box:  python scripts/exploration_step.py [Ns] [steps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safe_exploration_amd import SimpleGPModel, workload  # noqa: E402
+
+
+def main():
+    Ns = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "50,200,1000,5000").split(",")]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    print("%6s %12s %14s %14s %12s   [us per call, mean of %d steps after 5 warm-up steps]"
+          % ("N", "predict(1)", "update(+1)", "info gain", "step", steps))
+    for N in Ns:
+        prob = workload.make_problem(6, N + steps + 5, 2, 1, 8)
+        gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob), device="cuda:0")
+        Z, Y = prob["Z"], prob["Y"]
+        gp.train(Z[:N], Y[:N], opt_hyp=False)
+        t = np.zeros(3)
+        for i in range(steps + 5):
+            if i == 5:
+                t[:] = 0.0
+            z_i, y_i = Z[N + i:N + i + 1], Y[N + i:N + i + 1]
+            t0 = time.perf_counter()
+            mu, s2 = gp.predict(z_i)
+            t1 = time.perf_counter()
+            gp.update_model(z_i, y_i, opt_hyp=False, replace_old=False)
+            t2 = time.perf_counter()
+            ig = gp.information_gain()
+            t3 = time.perf_counter()
+            t += (t1 - t0, t2 - t1, t3 - t2)
+        assert np.all(np.isfinite(mu)) and np.all(s2 > 0) and np.all(np.isfinite(ig))
+        t *= 1e6 / steps
+        print("%6d %12.1f %14.1f %14.1f %12.1f" % (N, t[0], t[1], t[2], t.sum()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
