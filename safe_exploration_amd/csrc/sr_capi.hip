@@ -1996,9 +1996,14 @@ __global__ void sr_append_queries_kernel(const double* __restrict__ Znew, double
     Xq[t * D + j] = Znew[(t < pf ? 0 : t - pf) * D + j];
 }
 
+// (info != NULL: also clears the per-output failure word of the append that follows; Zdst != NULL: also copies the m x D
+//  new inputs behind the old ones -- m D <= 16 x 12 values, the first workgroup does it)
 __global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int N0, const double* __restrict__ Ynew,
-                                   int m, double* __restrict__ yT1, int Np1, int n_out) {
+                                   int m, double* __restrict__ yT1, int Np1, int n_out, int* __restrict__ info,
+                                   const double* __restrict__ Znew, double* __restrict__ Zdst, int mD) {
     const int i = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+    if (info && i == 0) info[d] = 0;
+    if (Zdst && d == 0 && blockIdx.x == 0 && (int)threadIdx.x < mD) Zdst[threadIdx.x] = Znew[threadIdx.x];
     if (i >= Np1) return;
     const int off1 = Np1 - (N0 + m), off0 = Np0 - N0;
     double v = 0.0;
@@ -2057,12 +2062,11 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     }
     if (reuse_alt) Wt1 = h->Wt_alt;
     else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
-    SR_AH(hipMemsetAsync(info_dev, 0, sizeof(int) * n_out, s));
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
-    SR_AH(hipMemcpyAsync(Z1 + (size_t)N0 * D, Znew, sizeof(double) * m * D, hipMemcpyDeviceToDevice, s));
+    static_assert(SR_SMALL_T * SR_MAX_D <= 256, "the first workgroup of sr_append_y_kernel copies the new inputs");
     hipLaunchKernelGGL(sr_append_y_kernel, dim3((Np1 + 255) / 256, n_out), dim3(256), 0, s, h->yT, Np0, N0, Ynew, m,
-                       yT1, Np1, n_out);
+                       yT1, Np1, n_out, info_dev, Znew, Z1 + (size_t)N0 * D, m * D);
     SR_AH(hipGetLastError());
     // B = K(Z_old, Z_new) with the new points as queries, then U12 = U^-T B by streaming U^-1 once
     const long Tp = srt::BN;
@@ -2076,7 +2080,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     ka.N = N0; ka.Np = Np0; ka.D = D; ka.n_out = n_out; ka.nsplit = nsplit; ka.T = m; ka.Tp = Tp;
     SR_A(sr_launch_kstar(ka, s));
     if (!h->small_vp) SR_A(dev_alloc(&h->small_vp, (size_t)sr_var_small_ws(Np0, n_out)));
-    SR_A(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, N0, Np0, Tp, n_out, m, s));
+    SR_A(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, N0, Np0, Tp, n_out, m, s, 0, false));   // (no norms wanted)
     SR_A(sr_launch_var_small_gather_all(h->small_vp, U12t, Np0, n_out, m, s));
     // All outputs in every launch (round 3; before: a chain of 8 dependent launches PER OUTPUT -- 25 dispatches for one new
     // point on a two-output model, 125 us on the host whatever the model size up to N ~ 1000):
@@ -2198,7 +2202,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     SR_AH(hipMemcpyAsync(Z1 + (size_t)N0 * D, Znew, sizeof(double) * m * D, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(sr_append_y_kernel, dim3((Np1 + 255) / 256, n_out), dim3(256), 0, s, h->yT, Np0, N0, Ynew, m,
-                       yT1, Np1, n_out);
+                       yT1, Np1, n_out, (int*)nullptr, (const double*)nullptr, (double*)nullptr, 0);
     hipLaunchKernelGGL(sr_append_queries_kernel, dim3(SR_NB), dim3(64), 0, s, Znew, Xq, m, D);
     SR_AH(hipGetLastError());
     SR_AH(hipStreamSynchronize(s));

@@ -266,7 +266,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 long sr_var_small_ws(int Np, int n_out);
 int sr_var_small_groups_max(int Np, int n_out);   // query groups of 16 the streaming path may take (1 .. 8)
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
-                        long Tp, int n_out, int T, hipStream_t s, int dot0 = 0);
+                        long Tp, int n_out, int T, hipStream_t s, int dot0 = 0, bool reduce = true);
 
 int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, int t, int T, hipStream_t s);
 int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_out, int T, hipStream_t s);

@@ -1110,12 +1110,16 @@ __global__ __launch_bounds__(256) void sr_append_move_kernel(const double* __res
                                                              const double* __restrict__ Xt,
                                                              const double* __restrict__ invS, int m,
                                                              double* __restrict__ Y2, double* __restrict__ Wt1,
-                                                             int Np1, int off1, long sXt, long sY2) {
+                                                             int Np1, int off1, long sXt, long sY2,
+                                                             const double* __restrict__ U12one) {
+    // U12one != NULL (MC == 1, one new point): Xt[0][k] = U12t[0][k] U22^-1 is formed here, Xt is not read
     const int lane = threadIdx.x & 63, pf = SR_NB - m;
     {                                                       // batch member (output)
         const long b = blockIdx.y;
         Wt0 += b * Np0 * Np0; Xt += b * sXt; invS += b * SR_NB * SR_NB; Y2 += b * sY2; Wt1 += b * Np1 * Np1;
+        if (U12one) U12one += b * Np0;
     }
+    const double inv00 = (MC == 1 && U12one) ? invS[pf * SR_NB + pf] : 0.0;
     const int nrow_blocks = (Np0 + 3) / 4;
     if ((int)blockIdx.x >= nrow_blocks) {
         // rows of the new points: Wt1[off1 + N0 + q][off1 + N0 + c] = U22^-1[q][c]
@@ -1135,9 +1139,13 @@ __global__ __launch_bounds__(256) void sr_append_move_kernel(const double* __res
     for (int k = row + lane; k < Np0; k += 64) {
         const double w = Wt0[(long)row * Np0 + k];
         dst[k] = w;
+        if (MC == 1 && U12one) {
+            acc[0] = fma(w, U12one[k] * inv00, acc[0]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < MC; ++c)
-            if (c < m) acc[c] = fma(w, Xt[(long)c * Np0 + k], acc[c]);
+            for (int c = 0; c < MC; ++c)
+                if (c < m) acc[c] = fma(w, Xt[(long)c * Np0 + k], acc[c]);
+        }
     }
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
@@ -1169,15 +1177,21 @@ int sr_launch_eye_front(double* W, int ld, int n, hipStream_t s, int nbatch) {
 int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const double* U12t, const double* invS, int m,
                           double* Xt, double* Y2, double* Wt1, int Np1, int off1, hipStream_t s, int nbatch, long sXt,
                           long sY2) {
+    const dim3 grid((Np0 + 3) / 4 + 1, nbatch);
+    if (m <= 1) {                                           // one new point: X = U12 U22^-1 is a scaling, done in the move
+        hipLaunchKernelGGL(sr_append_move_kernel<1>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt,
+                           sY2, U12t);
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
     hipLaunchKernelGGL(sr_append_xt_kernel, dim3((Np0 + 255) / 256, m, nbatch), dim3(256), 0, s, U12t, invS, Np0, m, Xt, sXt);
     SR_HIP(hipGetLastError());
-    const dim3 grid((Np0 + 3) / 4 + 1, nbatch);
-    if (m <= 1)
-        hipLaunchKernelGGL(sr_append_move_kernel<1>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt, sY2);
-    else if (m <= 4)
-        hipLaunchKernelGGL(sr_append_move_kernel<4>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt, sY2);
+    if (m <= 4)
+        hipLaunchKernelGGL(sr_append_move_kernel<4>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt,
+                           sY2, (const double*)nullptr);
     else
-        hipLaunchKernelGGL(sr_append_move_kernel<16>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt, sY2);
+        hipLaunchKernelGGL(sr_append_move_kernel<16>, grid, dim3(256), 0, s, Wt0, Np0, off0, N0, Xt, invS, m, Y2, Wt1, Np1, off1, sXt,
+                           sY2, (const double*)nullptr);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

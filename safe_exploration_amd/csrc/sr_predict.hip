@@ -953,7 +953,7 @@ int sr_var_small_groups_max(int Np, int n_out) {
 }
 
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
-                        long Tp, int n_out, int T, hipStream_t s, int dot0) {
+                        long Tp, int n_out, int T, hipStream_t s, int dot0, bool reduce) {
     const int ncb = (Np + 255) / 256;              // Np is a multiple of 128: the last block may be half empty
     const int npairs = ncb * (ncb + 1);
     const int k_lo = Np - N;
@@ -970,6 +970,7 @@ int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* 
                            Np, Tp, npairs, k_lo);
 #undef SR_SMALL_LAUNCH
     SR_HIP(hipGetLastError());
+    if (!reduce) return SR_OK;                     // the caller gathers the partial products itself (sr_gp_append)
     const int tq = small_tq(T);
     hipLaunchKernelGGL(sr_var_small_reduce_kernel, dim3(ncb, n_out, tq * groups), dim3(256), 0, s, Vp, part, Tp,
                        npairs, ncb, tq, dot0);

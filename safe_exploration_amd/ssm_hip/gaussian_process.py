@@ -476,7 +476,15 @@ class SimpleGPModel(StateSpaceModel):
         step = 16 if x.shape[0] <= 16 else 128
         for lo in range(0, x.shape[0], step):
             xs, ys = x[lo:lo + step], y[lo:lo + step]
-            tx, ty = B.as_dev(xs, hd.device), B.as_dev(ys, hd.device)
+            if xs.shape[0] <= 16:
+                # one pinned block, one H2D copy for both arrays (two pageable copies cost 35 us of the 125 us of a
+                # one-point append); sr_gp_append returns after its own stream synchronisation, the block is free again
+                st = getattr(hd, "_staging", None)
+                if st is None:
+                    st = hd._staging = B.Staging(hd.device)
+                (tx, ty), _ = st.stage([np.ascontiguousarray(xs), np.ascontiguousarray(ys)], [])
+            else:
+                tx, ty = B.as_dev(xs, hd.device), B.as_dev(ys, hd.device)
             info = (ctypes.c_int * self.n_s_out)()
             # a failing chunk (SR_ENOTPD on a near-duplicate point, out of memory) leaves the handle as it was
             # before THAT chunk: the host state below is committed chunk by chunk, so both always agree
@@ -485,12 +493,26 @@ class SimpleGPModel(StateSpaceModel):
             npad = ctypes.c_long(0)
             check(lib.sr_gp_padded_n(hd.h, ctypes.byref(npad)))
             hd.Np = npad.value
-            self.x_train = np.vstack((self.x_train, xs))
-            self.y_train = np.vstack((self.y_train, ys))
+            self.x_train, self.y_train = self._grown(self.x_train, xs, self.y_train, ys)
             self.z = self.x_train
             self._z_fit, self._y_z = self.x_train, self.y_train
             self._beta = None
             self._inv_K = None
+
+    def _grown(self, x0, xs, y0, ys):
+        """[x0; xs], [y0; ys] as views of buffers with room to grow (a vstack per appended point copies the whole
+        training set: 15 us at N = 50, more with N)."""
+        n0, n1 = x0.shape[0], x0.shape[0] + xs.shape[0]
+        bufs = getattr(self, "_train_bufs", None)
+        if (bufs is None or bufs[0].shape[0] < n1 or bufs[0].shape[1:] != x0.shape[1:] or bufs[1].shape[1:] != y0.shape[1:]
+                or x0.base is not bufs[0] or y0.base is not bufs[1]
+                or x0.ctypes.data != bufs[0].ctypes.data or y0.ctypes.data != bufs[1].ctypes.data):
+            cap = max(64, 2 * n1)
+            bufs = (np.empty((cap,) + x0.shape[1:]), np.empty((cap,) + y0.shape[1:]))
+            bufs[0][:n0], bufs[1][:n0] = x0, y0
+            self._train_bufs = bufs
+        bufs[0][n0:n1], bufs[1][n0:n1] = xs, ys
+        return bufs[0][:n1], bufs[1][:n1]
 
     def _fit(self, Z, Y, noise_diag):
         dev = B.resolve_device(self._device_arg)
