@@ -27,6 +27,7 @@ timeout 300 python scripts/diag_bench.py > "$EV/${TAG}_diag_bench.txt" 2>>"$EV/.
 timeout 300 python scripts/call_latency.py > "$EV/${TAG}_call_latency.txt" 2>>"$EV/.err"
 timeout 300 python scripts/linearize_bench.py > "$EV/${TAG}_linearize_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/numpy_latency.py > "$EV/${TAG}_numpy_latency.txt" 2>>"$EV/.err"
+timeout 300 python scripts/exploration_step.py > "$EV/${TAG}_exploration_step.txt" 2>>"$EV/.err"
 timeout 300 python scripts/growing_model.py > "$EV/${TAG}_growing_model.txt" 2>>"$EV/.err"
 timeout 900 bash scripts/profile_gpu.sh "$TAG" > "$EV/.profile.log" 2>&1
 export TMPDIR=/tmp
