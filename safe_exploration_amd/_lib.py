@@ -70,6 +70,7 @@ SIGNATURES = {
     "sr_distance_to_center": (_I, [_I, _L, _I, _I, _P, _I, _P, _P, _P, _P]),
     "sr_gp_mll": (_I, [_H, _P, _P, _P]),
     "sr_gp_logdet": (_I, [_H, _P, _P]),
+    "sr_gp_logdet_cached": (_I, [_H, _P]),
     "sr_gp_sample": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sr_gp_set_chunk": (_I, [_H, _L]),
     "sr_gp_set_var_group": (_I, [_H, _I]),

@@ -50,6 +50,9 @@ struct sr_gp {
     unsigned* stream_tickets = nullptr;
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
     int balanced = 1;                                   // few query tiles: balanced shares (K2b) or chunks (K2k): A/B switch
+    // log det(K + noise) per output as of the last model update that read its status back anyway (the factorisation, the
+    // <= 16-row append): the blocking read of sr_gp_logdet costs the exploration loop 30 us per step
+    std::vector<double> logdet_host; int logdet_valid = 0;
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 64;      // query tiles per scheduling group of the variance kernel.  With the diagonal blocks cut short
                              // (variant 2) 64 beats 32: 70.7 against 70.0 TF at C2', fabric-side fetches 61.3 -> 42.9 M KiB per launch
@@ -330,7 +333,7 @@ extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const
     SR_HIP(hipGetLastError());
     h->general = 0;
     h->have_data = 1;
-    h->factorized = 0;
+    h->factorized = 0; h->logdet_valid = 0;
     h->sf2_host.clear(); h->noise_host.clear();
     return SR_OK;
 }
@@ -350,7 +353,7 @@ extern "C" int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* 
     h->general = 1;
     h->sf2_host.clear(); h->noise_host.clear();
     h->have_data = 1;
-    h->factorized = 0;
+    h->factorized = 0; h->logdet_valid = 0;
     return SR_OK;
 }
 
@@ -782,6 +785,12 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     const auto t_enq = std::chrono::steady_clock::now();
     std::vector<int> info_h(h->n_out, 0);
     SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s0));
+    // (log determinants behind the first half of the 64 status words: read back in the same synchronisation)
+    double* ld_dev = reinterpret_cast<double*>(info_dev + 32);
+    h->logdet_host.assign(h->n_out, 0.0);
+    h->logdet_valid = 0;
+    const bool ld_ok = h->n_out <= 16 && sr_launch_logdet(h->Wt, Np, h->n_out, ld_dev, s0) == SR_OK &&
+                       hipMemcpyAsync(h->logdet_host.data(), ld_dev, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0) == hipSuccess;
     SR_FH(hipStreamSynchronize(s0));
     if (trace) {
         const auto t_end = std::chrono::steady_clock::now();
@@ -799,11 +808,12 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         if (info_h[d] != 0 && !bad) bad = d + 1;
     }
     if (bad) {
-        h->factorized = 0;
+        h->factorized = 0; h->logdet_valid = 0;
         sr_set_error("Cholesky breakdown: output %d, pivot %d not positive", bad - 1, info_h[bad - 1]);
         return SR_ENOTPD;
     }
     h->factorized = 1;
+    h->logdet_valid = ld_ok ? 1 : 0;
     return SR_OK;
 }
 
@@ -841,7 +851,7 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
                             hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->Wt, Wt, sizeof(double) * h->n_out * h->Np * h->Np,
                           hipMemcpyDeviceToDevice, s));
-    h->factorized = 1;
+    h->factorized = 1; h->logdet_valid = 0;
     return SR_OK;
 }
 
@@ -895,7 +905,7 @@ extern "C" int sr_gp_import_begin(sr_gp_t h, const double* alpha, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
     SR_TRY(ensure_wt(h));             // zero below the diagonal from allocation on; nothing ever writes there
-    h->factorized = 0;
+    h->factorized = 0; h->logdet_valid = 0;
     h->import_open = 1;
     SR_HIP(hipMemsetAsync(h->alpha, 0, sizeof(double) * h->n_out * h->Np, s));
     SR_HIP(hipMemcpy2DAsync(h->alpha + (h->Np - h->N), sizeof(double) * h->Np, alpha, sizeof(double) * h->N,
@@ -923,7 +933,7 @@ extern "C" int sr_gp_import_end(sr_gp_t h) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_import_end: NULL handle");
     SR_CHECK(h->import_open, SR_ESTATE, "sr_gp_import_end: no import in progress");
     h->import_open = 0;
-    h->factorized = 1;
+    h->factorized = 1; h->logdet_valid = 0;
     return SR_OK;
 }
 
@@ -956,6 +966,18 @@ extern "C" int sr_gp_mll(sr_gp_t h, double* nll, double* grad, void* stream) {
     dev_free(W); dev_free(Kinv); dev_free(partial); dev_free(ld);
     if (rc != SR_OK) return rc;
     SR_HIP(e);
+    return SR_OK;
+}
+
+// host copy of the same numbers if the last model update left one (SR_ESTATE otherwise: call sr_gp_logdet)
+extern "C" int sr_gp_logdet_cached(sr_gp_t h, double* logdet_host) {
+    SR_CHECK(h && logdet_host, SR_EINVAL, "sr_gp_logdet_cached: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_logdet_cached: model not factorized");
+    if (!h->logdet_valid || (int)h->logdet_host.size() != h->n_out) {
+        sr_set_error("sr_gp_logdet_cached: no host copy");
+        return SR_ESTATE;
+    }
+    for (int d = 0; d < h->n_out; ++d) logdet_host[d] = h->logdet_host[d];
     return SR_OK;
 }
 
@@ -2026,7 +2048,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     const size_t s_xt = (size_t)SR_SMALL_T * Np0, s_y2 = (size_t)Np0 * SR_NB;
     const size_t o_u12 = 0, o_xt = o_u12 + (size_t)n_out * SR_SMALL_T * Np0, o_y2 = o_xt + n_out * s_xt,
                  o_g = o_y2 + n_out * s_y2, o_sb = o_g + n_out * BB, o_inv = o_sb + n_out * BB,
-                 o_info = o_inv + n_out * BB, need = o_info + (size_t)n_out;
+                 o_ld = o_inv + n_out * BB, o_info = o_ld + (size_t)n_out, need = o_info + (size_t)n_out;
     if (h->app_cap < need) {
         (void)hipDeviceSynchronize();
         dev_free(h->app_ws);
@@ -2100,9 +2122,15 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     // alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2],  v2 = U22^-T (y_new - mu_old(z_new)): no pass over U^-1
     SR_A(sr_launch_append_alpha(h->alpha, Np0, N0, Y2, invS, h->mu_part, nsplit, n_out, 0, Tp, Ynew, m, alpha1, Np1, s, 0,
                                 n_out, (long)s_y2));
-    std::vector<int> info_h(n_out, 0);
-    SR_AH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
+    // log det of the grown model beside the status words: ONE read-back for both (the reference's exploration loop asks
+    // for the information gain after every appended point)
+    SR_A(sr_launch_logdet(Wt1, Np1, n_out, ws + o_ld, s));
+    std::vector<double> back(n_out + (n_out + 1) / 2, 0.0);       // n_out doubles, then n_out ints
+    SR_AH(hipMemcpyAsync(back.data(), ws + o_ld, sizeof(double) * n_out + sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
     SR_AH(hipStreamSynchronize(s));
+    std::vector<int> info_h(n_out, 0);
+    memcpy(info_h.data(), back.data() + n_out, sizeof(int) * n_out);
+    h->logdet_valid = 0;
 #undef SR_A
 #undef SR_AH
     int bad = 0;
@@ -2122,6 +2150,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     if (!z_inplace) { dev_free(h->Z); h->Z = Z1; h->z_cap = Np1; }
     h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
     h->N = N1;
+    h->logdet_host.assign(back.begin(), back.begin() + n_out); h->logdet_valid = 1;
     if (Np1 == Np0) {
         if (!vec_alt) { dev_free(h->yT_alt); dev_free(h->alpha_alt); }
         h->yT_alt = old_yT; h->alpha_alt = old_alpha; h->vec_alt_np = Np0;
@@ -2260,6 +2289,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     h->Z = Z1; h->yT = yT1; h->alpha = alpha1; h->Wt = Wt1;
     h->z_cap = N1;
     h->N = N1;
+    h->logdet_valid = 0;
     if (Np1 == Np0) {
         // keep the previous buffer for the next append (bounded: not for huge factors)
         if (!reuse_alt) dev_free(h->Wt_alt);

@@ -935,10 +935,16 @@ class SimpleGPModel(StateSpaceModel):
         if x is not None and np.shape(x)[0] != hd.N:
             raise ValueError("information_gain is defined on the training inputs (got {} rows, model holds {})"
                              .format(np.shape(x)[0], hd.N))
-        out = B.empty((hd.n_out,), hd.device)
-        check(lib.sr_gp_logdet(hd.h, B.ptr(out), B.stream_ptr(hd.device)))
         nv = self._noise + float(self._noise_diag)
-        ld = B.to_numpy(out) - hd.N * np.log(nv)
+        host = (ctypes.c_double * hd.n_out)()
+        if lib.sr_gp_logdet_cached(hd.h, host) == 0:   # the last model update read it back with its status words
+            return [float(v) for v in np.array(host[:]) - hd.N * np.log(nv)]
+        st = getattr(hd, "_staging", None)          # (the result comes back through the pinned block of the NumPy routes)
+        if st is None:
+            st = hd._staging = B.Staging(hd.device)
+        _, (out,) = st.stage([], [(hd.n_out,)])
+        check(lib.sr_gp_logdet(hd.h, B.ptr(out), B.stream_ptr(hd.device)))
+        ld = st.fetch()[0] - hd.N * np.log(nv)
         return [float(v) for v in ld]
 
     # ------------------------------------------------------------------ measurement hooks

@@ -1012,6 +1012,50 @@ def test_sample_from_gp_and_information_gain():
 
 
 @pytest.mark.gpu
+def test_information_gain_from_the_host_copy_follows_the_model():
+    """sr_gp_factorize and the <= 16-row append read log det back with their status words (sr_gp_logdet_cached): the
+    information gain of the exploration loop then costs no launch.  The host copy must equal what the device route
+    computes on the same factor, after a fit, after short appends, and must step aside after a long append."""
+    import ctypes
+    from safe_exploration_amd import _buffers as B
+    from safe_exploration_amd._lib import lib, check
+    syn = orc.make_synthetic(77, 260, 2, 1, 4)
+    Z, Y = syn["Z"], syn["Y"]
+    gp = hip_model(Z[:150], Y[:150], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    gp.append_limit = 10 ** 9
+    hd = gp._handle
+
+    def both():
+        host = (ctypes.c_double * 2)()
+        rc = lib.sr_gp_logdet_cached(hd.h, host)
+        dev = B.empty((2,), hd.device)
+        check(lib.sr_gp_logdet(hd.h, B.ptr(dev), B.stream_ptr(hd.device)))
+        return rc, np.array(host[:]), B.to_numpy(dev)
+
+    rc, host, dev = both()
+    assert rc == 0
+    np.testing.assert_array_equal(host, dev)
+    n = 150
+    for m in (1, 3, 16, 1):                                # short appends keep the copy current
+        gp.update_model(Z[n:n + m], Y[n:n + m], opt_hyp=False, replace_old=False)
+        n += m
+        rc, host, dev = both()
+        assert rc == 0 and hd.N == n
+        np.testing.assert_array_equal(host, dev)
+        ig = gp.information_gain()
+        ref = orc.information_gain(Z[:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+        bound = n * 1e-8 / syn["noise_var"].min()
+        assert all(-1e-9 <= a - b <= bound + 1e-9 for a, b in zip(ig, ref))
+    gp.update_model(Z[n:n + 40], Y[n:n + 40], opt_hyp=False, replace_old=False)      # 40 rows: the other route
+    n += 40
+    rc, _, dev = both()
+    assert rc != 0 and hd.N == n
+    ig = gp.information_gain()                              # falls back to the device route
+    ref = orc.information_gain(Z[:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    assert all(-1e-9 <= a - b <= n * 1e-8 / syn["noise_var"].min() + 1e-9 for a, b in zip(ig, ref))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,n_s,n_u,T", [(1, 2, 1, 3), (2, 2, 1, 8), (100, 2, 1, 1), (128, 4, 1, 9), (129, 2, 1, 17),
                                          (200, 4, 1, 300), (256, 2, 1, 1024), (150, 3, 2, 64), (257, 2, 1, 33),
                                          (384, 4, 1, 16), (400, 2, 1, 250), (512, 3, 2, 200)])
