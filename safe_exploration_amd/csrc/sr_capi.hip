@@ -2048,7 +2048,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     const size_t s_xt = (size_t)SR_SMALL_T * Np0, s_y2 = (size_t)Np0 * SR_NB;
     const size_t o_u12 = 0, o_xt = o_u12 + (size_t)n_out * SR_SMALL_T * Np0, o_y2 = o_xt + n_out * s_xt,
                  o_g = o_y2 + n_out * s_y2, o_sb = o_g + n_out * BB, o_inv = o_sb + n_out * BB,
-                 o_ld = o_inv + n_out * BB, o_info = o_ld + (size_t)n_out, need = o_info + (size_t)n_out;
+                 o_ld = o_inv + n_out * BB, o_info = o_ld + (size_t)n_out * SR_APPEND1_WGS, need = o_info + (size_t)n_out;
     if (h->app_cap < need) {
         (void)hipDeviceSynchronize();
         dev_free(h->app_ws);
@@ -2086,6 +2086,12 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
+    // one point on a small ARD-RBF model: the whole append is ONE launch (sr_append1_small_kernel)
+    const bool fused1 = m == 1 && !h->general && Np0 <= 256 && Np1 <= 384 && h->small_path != 0;
+    if (fused1) {
+        SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, Znew, Ynew, Wt1, alpha1, yT1,
+                                     Z1 + (size_t)N0 * D, ws + o_ld, info_dev, N0, Np0, Np1, D, n_out, s));
+    } else {
     static_assert(SR_SMALL_T * SR_MAX_D <= 256, "the first workgroup of sr_append_y_kernel copies the new inputs");
     hipLaunchKernelGGL(sr_append_y_kernel, dim3((Np1 + 255) / 256, n_out), dim3(256), 0, s, h->yT, Np0, N0, Ynew, m,
                        yT1, Np1, n_out, info_dev, Znew, Z1 + (size_t)N0 * D, m * D);
@@ -2125,11 +2131,18 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     // log det of the grown model beside the status words: ONE read-back for both (the reference's exploration loop asks
     // for the information gain after every appended point)
     SR_A(sr_launch_logdet(Wt1, Np1, n_out, ws + o_ld, s));
-    std::vector<double> back(n_out + (n_out + 1) / 2, 0.0);       // n_out doubles, then n_out ints
-    SR_AH(hipMemcpyAsync(back.data(), ws + o_ld, sizeof(double) * n_out + sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
+    }
+    const int nld = n_out * SR_APPEND1_WGS;                       // (the one-launch route leaves partial sums)
+    std::vector<double> back(nld + (n_out + 1) / 2, 0.0);         // the log dets, then n_out ints
+    SR_AH(hipMemcpyAsync(back.data(), ws + o_ld, sizeof(double) * nld + sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
     SR_AH(hipStreamSynchronize(s));
     std::vector<int> info_h(n_out, 0);
-    memcpy(info_h.data(), back.data() + n_out, sizeof(int) * n_out);
+    memcpy(info_h.data(), back.data() + nld, sizeof(int) * n_out);
+    for (int d = 0; d < n_out; ++d) {
+        double t = back[fused1 ? d * SR_APPEND1_WGS : d];
+        for (int y = 1; fused1 && y < SR_APPEND1_WGS; ++y) t += back[d * SR_APPEND1_WGS + y];
+        back[d] = t;                                              // (d <= d * SR_APPEND1_WGS: nothing unread is overwritten)
+    }
     h->logdet_valid = 0;
 #undef SR_A
 #undef SR_AH

@@ -1196,6 +1196,174 @@ int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const do
     return SR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ONE new point on a SMALL ARD-RBF model (old padded size <= 256, new <= 384: the reference's own regime, a transition
+// appended after every step of its exploration loop, exploration_runner.py:186-188) -- the whole append in ONE launch,
+// one workgroup of 16 wavefronts per output:
+//   b = K(Z_old, z_new), mu_old = b . alpha0, u12 = U^-T b (thread = column, 4 k-slices), s = sf2 + noise - |u12|^2,
+//   u22^-1 = 1 / sqrt(s), X = u12 u22^-1;
+//   then the new factor row by row (wavefront = row), written IN FULL (zeros below the diagonal, identity padding: the
+//   target buffer needs no preparation): the old row moved to the new padding, its new last entry
+//   y2 = -sum_{k >= row} U^-1[row][k] X[k] from the same pass, alpha1 = alpha0 + y2 v2 (v2 = u22^-1 (y_new - mu_old)),
+//   the shifted targets, the new point's row (u22^-1), log det of the new factor (SR_APPEND1_WGS partial sums per
+//   output), the failure word.
+// The general route does this in 10 launches (65 us inside sr_gp_append at any size up to N ~ 1000); the arithmetic is
+// the same (same sums in another order: the tests compare both routes with the refit and the oracle).
+// ------------------------------------------------------------------------------------------------
+struct sr_append1_args {
+    const double* Wt0; const double* alpha0; const double* yT0; const double* Z;     // old state (Z: N0 x D)
+    const double* ls; const double* sf2; const double* noise;                         // n_out x D, n_out, n_out
+    const double* znew; const double* ynew;                                           // D, n_out
+    double* Wt1; double* alpha1; double* yT1; double* Zdst;                           // new state (Zdst: row N0 of Z, or NULL)
+    double* logdet; int* info;                                                        // n_out each
+    int N0, Np0, Np1, D, n_out;
+};
+
+__global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args a) {
+    __shared__ double b[256], u12[256], X[256], part[4][256], red[16];
+    __shared__ double s_mu, s_inv, s_v2;
+    const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N0 = a.N0, Np0 = a.Np0, Np1 = a.Np1, D = a.D;
+    auto sr_wave_sum = [](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    const int off0 = Np0 - N0, off1 = Np1 - (N0 + 1), shift = off1 - off0;
+    const double* Wt0 = a.Wt0 + (long)d * Np0 * Np0;
+    const double* alpha0 = a.alpha0 + (long)d * Np0;
+    double* Wt1 = a.Wt1 + (long)d * Np1 * Np1;
+    // gridDim.y workgroups per output share the rows of the new factor (each of them repeats the cheap first part: one
+    // workgroup alone writes a 256-row factor in 25 us, four take 8); workgroup y = 0 also reports failure and copies z_new
+    const int wy = blockIdx.y, nwy = gridDim.y;
+    if (d == 0 && wy == 0 && a.Zdst && tid < D) a.Zdst[tid] = a.znew[tid];
+    // ---- b = K(Z_old, z_new) in padded row indexing, mu_old = b . alpha0
+    double mu_t = 0.0;
+    if (tid < 256) {
+        double v = 0.0;
+        if (tid < Np0 && tid >= off0) {
+            double r2 = 0.0;
+            for (int c = 0; c < D; ++c) {
+                const double t = (a.Z[(long)(tid - off0) * D + c] - a.znew[c]) / a.ls[d * D + c];
+                r2 = fma(t, t, r2);
+            }
+            v = a.sf2[d] * exp(-0.5 * r2);
+            mu_t = v * alpha0[tid];
+        }
+        b[tid] = v;
+    }
+    {
+        const double w = sr_wave_sum(mu_t);
+        if (lane == 0) red[wave] = w;
+    }
+    __syncthreads();
+    if (tid == 0) s_mu = (red[0] + red[1]) + (red[2] + red[3]);
+    // ---- u12[i] = sum_{k <= i} U^-1[k][i] b[k]: thread (slice q of 64 rows, column i), 16 loads in flight
+    {
+        const int q = tid >> 8, i = tid & 255;
+        double acc = 0.0;
+        if (i < Np0) {
+            const int k_end = min(q * 64 + 63, i);
+            for (int k0 = q * 64; k0 <= k_end; k0 += 16) {
+                double w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = (k0 + u <= k_end) ? Wt0[(long)(k0 + u) * Np0 + i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = fma(w[u], b[min(k0 + u, 255)], acc);
+            }
+        }
+        part[q][i] = acc;
+    }
+    __syncthreads();
+    double g_t = 0.0;
+    if (tid < 256) {
+        const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        u12[tid] = v;
+        g_t = v * v;
+    }
+    {
+        const double w = sr_wave_sum(g_t);
+        __syncthreads();                                     // (red is read by thread 0 above)
+        if (lane == 0) red[wave] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double g = (red[0] + red[1]) + (red[2] + red[3]);
+        double sch = a.sf2[d] + a.noise[d] - g;              // Schur complement of the new point
+        if (!(sch > 0.0)) {                                  // also catches NaN
+            if (wy == 0) a.info[d] = N0 + 1;
+            sch = 1.0;
+        } else if (wy == 0) {
+            a.info[d] = 0;
+        }
+        double sd, inv;
+        sr_sqrt_rsqrt(sch, sd, inv);
+        s_inv = inv;
+        s_v2 = inv * (a.ynew[d] - s_mu);
+    }
+    __syncthreads();
+    const double inv = s_inv, v2 = s_v2;
+    if (tid < 256) X[tid] = u12[tid] * inv;
+    __syncthreads();
+    // ---- the new factor, alpha and targets, row by row
+    double ld = 0.0;                                         // sum of log(diagonal) over this wavefront's rows (lane 0)
+    const double* yT0 = a.yT0 + (long)d * Np0;
+    double* alpha1 = a.alpha1 + (long)d * Np1;
+    double* yT1 = a.yT1 + (long)d * Np1;
+    const int Rlast = Np1 - 1;                               // row of the new point
+    for (int R = wy * 16 + wave; R < Np1; R += 16 * nwy) {
+        double* dst = Wt1 + (long)R * Np1;
+        if (R < off1 || R == Rlast) {
+            const double dg = (R == Rlast) ? inv : 1.0;
+            for (int C = lane; C < Np1; C += 64) dst[C] = (C == R) ? dg : 0.0;
+            if (lane == 0) {
+                alpha1[R] = (R == Rlast) ? inv * v2 : 0.0;
+                yT1[R] = (R == Rlast) ? a.ynew[d] : 0.0;
+                if (R == Rlast) ld += log(inv);
+            }
+            continue;
+        }
+        const int r0 = R - shift;                            // old padded row
+        const double* src = Wt0 + (long)r0 * Np0;
+        double acc = 0.0, dgv = 1.0;
+        for (int C = lane; C < Rlast; C += 64) {
+            double v = 0.0;
+            if (C >= R) {
+                v = src[C - shift];
+                acc = fma(v, X[C - shift], acc);
+                if (C == R) dgv = v;
+            }
+            dst[C] = v;
+        }
+        acc = sr_wave_sum(acc);
+        dgv = __shfl(dgv, R & 63);                           // the lane that held the diagonal entry
+        if (lane == 0) {
+            dst[Rlast] = -acc;
+            alpha1[R] = fma(-acc, v2, alpha0[r0]);
+            yT1[R] = yT0[r0];
+            ld += log(dgv);
+        }
+    }
+    __syncthreads();
+    if (lane == 0) red[wave] = ld;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        a.logdet[d * nwy + wy] = -2.0 * t;                  // partial sums: the host adds the gridDim.y of an output
+    }
+}
+
+int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
+                            const double* sf2, const double* noise, const double* znew, const double* ynew, double* Wt1,
+                            double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
+                            int D, int n_out, hipStream_t s) {
+    SR_CHECK(Np0 <= 256 && Np1 <= 384 && N0 >= 1 && N0 <= Np0, SR_EINVAL, "append1_small: Np0 = %d, Np1 = %d", Np0, Np1);
+    sr_append1_args a{Wt0, alpha0, yT0, Z, ls, sf2, noise, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out};
+    hipLaunchKernelGGL(sr_append1_small_kernel, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
 // alpha of the grown model without another pass over U^-1:  with r = y_new - mu_old(z_new) (the old model's
 // mean at the new points, which the K* pass has just produced) and v2 = U22^-T r,
 //   alpha1 = [alpha0 + Y2 v2 ; U22^-1 v2].     One workgroup recomputes v2 (m <= 16), grid over the rows.

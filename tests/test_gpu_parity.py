@@ -734,6 +734,64 @@ def test_row_append_update_equals_refit(N0, adds):
         np.testing.assert_allclose(wa[d], wf[d], rtol=1e-6, atol=1e-9 * np.abs(wf[d]).max())
 
 
+@pytest.mark.parametrize("N0,n_s,n_u,steps", [(1, 2, 1, 5), (60, 4, 1, 6), (126, 2, 1, 4), (200, 3, 2, 3), (254, 2, 1, 5),
+                                               (256, 4, 1, 2)])
+def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
+    """ONE new point on an ARD-RBF model of <= 256 padded rows is one launch (sr_append1_small_kernel): against the
+    refit on all the data (factor entry by entry, zeros and identity padding included -- the kernel writes the whole
+    matrix), against the general route of the same library (set_small_path(0)), the oracle's variance, the log
+    determinant of both routes; crosses the padded sizes 128 -> 256 -> 384; a point that breaks the factorisation
+    down leaves the model as it was."""
+    import ctypes
+    from safe_exploration_amd._lib import lib
+    ntot = N0 + steps
+    syn = orc.make_synthetic(500 + N0, ntot, n_s, n_u, 32)
+    Z, Y = syn["Z"], syn["Y"]
+    gps = []
+    for mode in (1, 0):
+        gp = hip_model(Z[:N0], Y[:N0], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+        gp.append_limit = 10 ** 9
+        gp.set_small_path(mode)
+        for i in range(N0, ntot):
+            gp.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)
+            assert gp._handle.N == i + 1
+        gp.set_small_path(1)
+        gps.append(gp)
+    full = hip_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    wf = full.export_state()[1].cpu().numpy()
+    off = full._handle.Np - ntot
+    lds = []
+    for gp in gps:
+        wa = gp.export_state()[1].cpu().numpy()
+        for d in range(n_s):
+            assert np.all(np.tril(wa[d], -1) == 0.0)
+            assert np.all(wa[d][:off, :off] == np.eye(off)) and np.all(wa[d][:off, off:] == 0.0)
+            np.testing.assert_allclose(wa[d], wf[d], rtol=1e-6, atol=1e-9 * np.abs(wf[d]).max())
+        np.testing.assert_allclose(gp.beta, full.beta, rtol=1e-7, atol=1e-9 * np.abs(full.beta).max())
+        np.testing.assert_array_equal(gp.y_train, Y)
+        host = (ctypes.c_double * n_s)()
+        assert lib.sr_gp_logdet_cached(gp._handle.h, host) == 0
+        lds.append(np.array(host[:]))
+    np.testing.assert_allclose(lds[0], lds[1], rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(gps[0].information_gain(), full.information_gain(), rtol=1e-10, atol=1e-8)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    om = oracle_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    rmu, rvar, _ = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], True)
+    mu, var = gps[0].predict(x)
+    np.testing.assert_allclose(mu, rmu, rtol=1e-8, atol=max(mu_atol(om), 1e-12) * 10)
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=1e-9)
+    # breakdown: a NaN input gives a Schur complement that is not positive
+    gp = gps[0]
+    bad = Z[:1].copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.update_model(bad, Y[:1], opt_hyp=False, replace_old=False)
+    assert gp._handle.N == ntot and gp.x_train.shape[0] == ntot
+    mu2, var2 = gp.predict(x)
+    np.testing.assert_array_equal(mu2, mu)
+    np.testing.assert_array_equal(var2, var)
+
+
 def test_small_appends_after_refit_and_release():
     """The buffer a small append writes into may hold an older state of the model (ping-pong), a released or a fresh
     allocation: always a complete factor afterwards."""
@@ -1034,14 +1092,14 @@ def test_information_gain_from_the_host_copy_follows_the_model():
 
     rc, host, dev = both()
     assert rc == 0
-    np.testing.assert_array_equal(host, dev)
+    np.testing.assert_array_equal(host, dev)               # (the same kernel on the same factor)
     n = 150
     for m in (1, 3, 16, 1):                                # short appends keep the copy current
         gp.update_model(Z[n:n + m], Y[n:n + m], opt_hyp=False, replace_old=False)
         n += m
         rc, host, dev = both()
         assert rc == 0 and hd.N == n
-        np.testing.assert_array_equal(host, dev)
+        np.testing.assert_allclose(host, dev, rtol=1e-13, atol=0)     # (the one-point kernel adds the logs itself)
         ig = gp.information_gain()
         ref = orc.information_gain(Z[:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
         bound = n * 1e-8 / syn["noise_var"].min()
