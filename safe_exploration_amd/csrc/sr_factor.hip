@@ -1208,7 +1208,7 @@ int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const do
 //   the shifted targets, the new point's row (u22^-1), log det of the new factor (SR_APPEND1_WGS partial sums per
 //   output), the failure word.
 // The general route does this in 10 launches (65 us inside sr_gp_append at any size up to N ~ 1000); the arithmetic is
-// the same (same sums in another order: the tests compare both routes with the refit and the oracle).
+// the same (same sums in another order: the tests compare both routes with the refit and the CPU restatement).
 // ------------------------------------------------------------------------------------------------
 struct sr_append1_args {
     const double* Wt0; const double* alpha0; const double* yT0; const double* Z;     // old state (Z: N0 x D)
