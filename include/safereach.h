@@ -223,9 +223,9 @@ int sr_gp_mll(sr_gp_t h, double* nll /* n_out, device */, double* grad /* n_out 
  * (log det(I + K/sigma_n^2) = log det(K + sigma_n^2 I) - N log sigma_n^2).
  * logdet[d] = log det(K_d + noise_d I) of the factorised (or imported) model, from the diagonal of U^-1. */
 int sr_gp_logdet(sr_gp_t h, double* logdet /* n_out, device */, void* stream);
-/* The same numbers from the HOST copy that sr_gp_factorize and sr_gp_append (<= 16 rows) read back together with their
- * status words -- no launch, no synchronisation: the reference's exploration loop asks for the information gain after
- * every appended transition (exploration_runner.py:186-189).  SR_ESTATE when the last model update left no copy (an
+/* The same numbers from the HOST copy that sr_gp_append (<= 16 rows) reads back together with its status words -- no
+ * launch, no synchronisation: the reference's exploration loop asks for the information gain after every appended
+ * transition (exploration_runner.py:186-189).  SR_ESTATE when the last model update left no copy (a factorisation, an
  * imported model, an append of more than 16 rows): call sr_gp_logdet then. */
 int sr_gp_logdet_cached(sr_gp_t h, double* logdet_host /* n_out, host */);
 

@@ -50,8 +50,8 @@ struct sr_gp {
     unsigned* stream_tickets = nullptr;
     double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
     int balanced = 1;                                   // few query tiles: balanced shares (K2b) or chunks (K2k): A/B switch
-    // log det(K + noise) per output as of the last model update that read its status back anyway (the factorisation, the
-    // <= 16-row append): the blocking read of sr_gp_logdet costs the exploration loop 30 us per step
+    // log det(K + noise) per output as of the last <= 16-row append (read back with its status words): the blocking read of
+    // sr_gp_logdet costs the exploration loop 30 us per step
     std::vector<double> logdet_host; int logdet_valid = 0;
     double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
     int var_group = 64;      // query tiles per scheduling group of the variance kernel.  With the diagonal blocks cut short
@@ -785,12 +785,9 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     const auto t_enq = std::chrono::steady_clock::now();
     std::vector<int> info_h(h->n_out, 0);
     SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s0));
-    // (log determinants behind the first half of the 64 status words: read back in the same synchronisation)
-    double* ld_dev = reinterpret_cast<double*>(info_dev + 32);
-    h->logdet_host.assign(h->n_out, 0.0);
+    // (no log determinant here: a launch and a copy on the critical path of every refit -- 0.3 % at N = 5000 -- for a number
+    //  only the exploration loop asks for, and there the appends keep the host copy current)
     h->logdet_valid = 0;
-    const bool ld_ok = h->n_out <= 16 && sr_launch_logdet(h->Wt, Np, h->n_out, ld_dev, s0) == SR_OK &&
-                       hipMemcpyAsync(h->logdet_host.data(), ld_dev, sizeof(double) * h->n_out, hipMemcpyDeviceToHost, s0) == hipSuccess;
     SR_FH(hipStreamSynchronize(s0));
     if (trace) {
         const auto t_end = std::chrono::steady_clock::now();
@@ -813,7 +810,6 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         return SR_ENOTPD;
     }
     h->factorized = 1;
-    h->logdet_valid = ld_ok ? 1 : 0;
     return SR_OK;
 }
 

@@ -1071,9 +1071,9 @@ def test_sample_from_gp_and_information_gain():
 
 @pytest.mark.gpu
 def test_information_gain_from_the_host_copy_follows_the_model():
-    """sr_gp_factorize and the <= 16-row append read log det back with their status words (sr_gp_logdet_cached): the
-    information gain of the exploration loop then costs no launch.  The host copy must equal what the device route
-    computes on the same factor, after a fit, after short appends, and must step aside after a long append."""
+    """The <= 16-row append reads log det back with its status words (sr_gp_logdet_cached): the information gain of the
+    exploration loop then costs no launch.  The host copy must equal what the device route computes on the same
+    factor after short appends, and there is none after a fit or a long append."""
     import ctypes
     from safe_exploration_amd import _buffers as B
     from safe_exploration_amd._lib import lib, check
@@ -1091,8 +1091,10 @@ def test_information_gain_from_the_host_copy_follows_the_model():
         return rc, np.array(host[:]), B.to_numpy(dev)
 
     rc, host, dev = both()
-    assert rc == 0
-    np.testing.assert_array_equal(host, dev)               # (the same kernel on the same factor)
+    assert rc != 0                                          # a fit leaves no host copy (no extra launch on every refit) ...
+    ig0 = gp.information_gain()                            # ... the device route serves
+    ref0 = orc.information_gain(Z[:150], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    assert all(-1e-9 <= a - b <= 150 * 1e-8 / syn["noise_var"].min() + 1e-9 for a, b in zip(ig0, ref0))
     n = 150
     for m in (1, 3, 16, 1):                                # short appends keep the copy current
         gp.update_model(Z[n:n + m], Y[n:n + m], opt_hyp=False, replace_old=False)
