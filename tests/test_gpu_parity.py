@@ -792,6 +792,47 @@ def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
     np.testing.assert_array_equal(var2, var)
 
 
+@pytest.mark.parametrize("kt,N0,adds", [("lin_mat52", 90, [1, 4]), ("mat52", 250, [16, 1]), ("lin_rbf", 600, [3, 1, 40])])
+def test_row_append_with_the_journal_kernels(kt, N0, adds):
+    """update_model(replace_old=False) on models with the kernels of the reference's journal experiments (Matern-5/2,
+    linear x stationary + linear): the short appends (all outputs per launch, the Schur complement's Gram block from
+    sr_gram_general_kernel) and the 17..128-row route against a refit on all the data."""
+    from safe_exploration_amd import SimpleGPModel
+    rng = np.random.default_rng(77 + N0)
+    D, ntot = 3, N0 + sum(adds)
+    Z = rng.uniform(-1, 1, (ntot, D))
+    Y = rng.standard_normal((ntot, 2))
+    hyp = [orc.make_hyp(kt, rng, D) for _ in range(2)]
+    noise = np.array([0.02, 0.03])
+    hh = [dict(h, noise_variance=nv) for h, nv in zip(hyp, noise)]
+    gp = SimpleGPModel(2, 2, 1, kern_types=[kt] * 2, hyp=hh)
+    gp.train(Z[:N0], Y[:N0], opt_hyp=False)
+    gp.append_limit = 10 ** 9
+    lo = N0
+    for m in adds:
+        gp.update_model(Z[lo:lo + m], Y[lo:lo + m], opt_hyp=False, replace_old=False)
+        lo += m
+    assert gp._handle.N == ntot
+    full = SimpleGPModel(2, 2, 1, kern_types=[kt] * 2, hyp=hh)
+    full.train(Z, Y, opt_hyp=False)
+    np.testing.assert_allclose(gp.beta, full.beta, rtol=1e-6, atol=1e-8 * np.abs(full.beta).max())
+    x = rng.uniform(-0.8, 0.8, (40, D))
+    mu_a, var_a, jac_a = gp.predict(x, None, True)
+    mu_f, var_f, jac_f = full.predict(x, None, True)
+    scale = max(np.abs(full.beta).sum(0).max(), 1.0)
+    np.testing.assert_allclose(mu_a, mu_f, rtol=1e-8, atol=1e-10 * scale)
+    np.testing.assert_allclose(jac_a, jac_f, rtol=1e-8, atol=1e-9 * scale)
+    np.testing.assert_allclose(var_a, var_f, rtol=0, atol=1e-9 * scale)
+    wa, wf = gp.export_state()[1].cpu().numpy(), full.export_state()[1].cpu().numpy()
+    for d in range(2):
+        assert np.all(np.tril(wa[d], -1) == 0.0)
+        np.testing.assert_allclose(wa[d], wf[d], rtol=1e-6, atol=1e-9 * np.abs(wf[d]).max())
+    beta_ref, inv_K = orc.gp_fit_k(Z, Y, [kt] * 2, hyp, noise + 1e-5)
+    rmu, rvar = orc.gp_predict_k(x, Z, beta_ref, inv_K, [kt] * 2, hyp)
+    np.testing.assert_allclose(mu_a, rmu, rtol=1e-7, atol=1e-8 * scale)
+    np.testing.assert_allclose(var_a, rvar, rtol=0, atol=1e-7 * scale)
+
+
 def test_small_appends_after_refit_and_release():
     """The buffer a small append writes into may hold an older state of the model (ping-pong), a released or a fresh
     allocation: always a complete factor afterwards."""
