@@ -2082,10 +2082,11 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
-    // one point on a small ARD-RBF model: the whole append is ONE launch (sr_append1_small_kernel)
-    const bool fused1 = m == 1 && !h->general && Np0 <= 256 && Np1 <= 384 && h->small_path != 0;
+    // one point on a small model: the whole append is ONE launch (sr_append1_small_kernel)
+    const bool fused1 = m == 1 && Np0 <= 256 && Np1 <= 384 && h->small_path != 0;
     if (fused1) {
-        SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, Znew, Ynew, Wt1, alpha1, yT1,
+        SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
+                                     Znew, Ynew, Wt1, alpha1, yT1,
                                      Z1 + (size_t)N0 * D, ws + o_ld, info_dev, N0, Np0, Np1, D, n_out, s));
     } else {
     static_assert(SR_SMALL_T * SR_MAX_D <= 256, "the first workgroup of sr_append_y_kernel copies the new inputs");

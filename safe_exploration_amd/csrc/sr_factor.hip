@@ -1197,7 +1197,7 @@ int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const do
 }
 
 // ------------------------------------------------------------------------------------------------
-// ONE new point on a SMALL ARD-RBF model (old padded size <= 256, new <= 384: the reference's own regime, a transition
+// ONE new point on a SMALL model (ARD-RBF or the general kernel family; old padded size <= 256, new <= 384: the reference's own regime, a transition
 // appended after every step of its exploration loop, exploration_runner.py:186-188) -- the whole append in ONE launch,
 // one workgroup of 16 wavefronts per output:
 //   b = K(Z_old, z_new), mu_old = b . alpha0, u12 = U^-T b (thread = column, 4 k-slices), s = sf2 + noise - |u12|^2,
@@ -1213,6 +1213,7 @@ int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const do
 struct sr_append1_args {
     const double* Wt0; const double* alpha0; const double* yT0; const double* Z;     // old state (Z: N0 x D)
     const double* ls; const double* sf2; const double* noise;                         // n_out x D, n_out, n_out
+    const double* kp;                                                                 // general kernels: n_out x SR_KP(D), else NULL
     const double* znew; const double* ynew;                                           // D, n_out
     double* Wt1; double* alpha1; double* yT1; double* Zdst;                           // new state (Zdst: row N0 of Z, or NULL)
     double* logdet; int* info;                                                        // n_out each
@@ -1241,12 +1242,26 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
     if (tid < 256) {
         double v = 0.0;
         if (tid < Np0 && tid >= off0) {
-            double r2 = 0.0;
-            for (int c = 0; c < D; ++c) {
-                const double t = (a.Z[(long)(tid - off0) * D + c] - a.znew[c]) / a.ls[d * D + c];
-                r2 = fma(t, t, r2);
+            const double* z = a.Z + (long)(tid - off0) * D;
+            if (a.kp) {                                      // general family (sr_common.h), as sr_gram_general_kernel
+                const double* kp = a.kp + (long)d * SR_KP(D);
+                const double *sv = kp + 3, *av = kp + 3 + D, *bv = kp + 3 + 2 * D;
+                double r2 = 0.0, la = 0.0, lb = 0.0;
+                for (int c = 0; c < D; ++c) {
+                    const double t = (z[c] - a.znew[c]) * sv[c];
+                    r2 = fma(t, t, r2);
+                    la = fma(av[c] * z[c], a.znew[c], la);
+                    lb = fma(bv[c] * z[c], a.znew[c], lb);
+                }
+                v = (kp[2] + la) * kp[1] * sr_kappa((int)kp[0], r2) + lb;
+            } else {
+                double r2 = 0.0;
+                for (int c = 0; c < D; ++c) {
+                    const double t = (z[c] - a.znew[c]) / a.ls[d * D + c];
+                    r2 = fma(t, t, r2);
+                }
+                v = a.sf2[d] * exp(-0.5 * r2);
             }
-            v = a.sf2[d] * exp(-0.5 * r2);
             mu_t = v * alpha0[tid];
         }
         b[tid] = v;
@@ -1288,7 +1303,19 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
     __syncthreads();
     if (tid == 0) {
         const double g = (red[0] + red[1]) + (red[2] + red[3]);
-        double sch = a.sf2[d] + a.noise[d] - g;              // Schur complement of the new point
+        double prior;                                        // k(z_new, z_new)
+        if (a.kp) {
+            const double* kp = a.kp + (long)d * SR_KP(D);
+            double la = 0.0, lb = 0.0;
+            for (int c = 0; c < D; ++c) {
+                la = fma(kp[3 + D + c] * a.znew[c], a.znew[c], la);
+                lb = fma(kp[3 + 2 * D + c] * a.znew[c], a.znew[c], lb);
+            }
+            prior = (kp[2] + la) * kp[1] + lb;               // kappa(0) = 1
+        } else {
+            prior = a.sf2[d];
+        }
+        double sch = prior + a.noise[d] - g;                 // Schur complement of the new point
         if (!(sch > 0.0)) {                                  // also catches NaN
             if (wy == 0) a.info[d] = N0 + 1;
             sch = 1.0;
@@ -1354,11 +1381,11 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
 }
 
 int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
-                            const double* sf2, const double* noise, const double* znew, const double* ynew, double* Wt1,
+                            const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
                             int D, int n_out, hipStream_t s) {
     SR_CHECK(Np0 <= 256 && Np1 <= 384 && N0 >= 1 && N0 <= Np0, SR_EINVAL, "append1_small: Np0 = %d, Np1 = %d", Np0, Np1);
-    sr_append1_args a{Wt0, alpha0, yT0, Z, ls, sf2, noise, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out};
+    sr_append1_args a{Wt0, alpha0, yT0, Z, ls, sf2, noise, kp, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out};
     hipLaunchKernelGGL(sr_append1_small_kernel, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
     SR_HIP(hipGetLastError());
     return SR_OK;

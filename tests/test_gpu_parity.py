@@ -792,7 +792,8 @@ def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
     np.testing.assert_array_equal(var2, var)
 
 
-@pytest.mark.parametrize("kt,N0,adds", [("lin_mat52", 90, [1, 4]), ("mat52", 250, [16, 1]), ("lin_rbf", 600, [3, 1, 40])])
+@pytest.mark.parametrize("kt,N0,adds", [("lin_mat52", 90, [1, 4]), ("mat52", 250, [16, 1]), ("lin_rbf", 600, [3, 1, 40]),
+                                        ("lin_mat52", 125, [1] * 6), ("mat52", 30, [1, 1, 1])])
 def test_row_append_with_the_journal_kernels(kt, N0, adds):
     """update_model(replace_old=False) on models with the kernels of the reference's journal experiments (Matern-5/2,
     linear x stationary + linear): the short appends (all outputs per launch, the Schur complement's Gram block from
