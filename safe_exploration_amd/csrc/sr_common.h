@@ -273,9 +273,9 @@ int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_ou
 int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
                            const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
                            double* alpha1, int Np1, hipStream_t s, int qoff = 0, int nbatch = 1, long sY2 = 0);
-// one new point on a small model (Np0 <= 256, Np1 <= 384; kp != NULL: general kernels), all outputs, ONE launch (sr_factor.hip);
+// one new point on a small model (Np0 <= 512, Np1 <= 640; kp != NULL: general kernels), all outputs, ONE launch (sr_factor.hip);
 // logdet: n_out x SR_APPEND1_WGS partial sums
-#define SR_APPEND1_WGS 4
+#define SR_APPEND1_WGS 8
 int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                             const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,

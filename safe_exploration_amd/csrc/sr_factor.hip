@@ -1197,7 +1197,7 @@ int sr_launch_append_move(const double* Wt0, int Np0, int off0, int N0, const do
 }
 
 // ------------------------------------------------------------------------------------------------
-// ONE new point on a SMALL model (ARD-RBF or the general kernel family; old padded size <= 256, new <= 384: the reference's own regime, a transition
+// ONE new point on a SMALL model (ARD-RBF or the general kernel family; old padded size <= 512, new <= 640: the reference's own regime, a transition
 // appended after every step of its exploration loop, exploration_runner.py:186-188) -- the whole append in ONE launch,
 // one workgroup of 16 wavefronts per output:
 //   b = K(Z_old, z_new), mu_old = b . alpha0, u12 = U^-T b (thread = column, 4 k-slices), s = sf2 + noise - |u12|^2,
@@ -1220,8 +1220,9 @@ struct sr_append1_args {
     int N0, Np0, Np1, D, n_out;
 };
 
+template <int NPMAX>   // 256 or 512: the old padded size it serves
 __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args a) {
-    __shared__ double b[256], u12[256], X[256], part[4][256], red[16];
+    __shared__ double b[NPMAX], u12[NPMAX], X[NPMAX], part[4][NPMAX], red[16];
     __shared__ double s_mu, s_inv, s_v2;
     const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N0 = a.N0, Np0 = a.Np0, Np1 = a.Np1, D = a.D;
@@ -1239,10 +1240,11 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
     if (d == 0 && wy == 0 && a.Zdst && tid < D) a.Zdst[tid] = a.znew[tid];
     // ---- b = K(Z_old, z_new) in padded row indexing, mu_old = b . alpha0
     double mu_t = 0.0;
-    if (tid < 256) {
+#pragma unroll 1
+    for (int row = tid; row < NPMAX; row += 1024) {
         double v = 0.0;
-        if (tid < Np0 && tid >= off0) {
-            const double* z = a.Z + (long)(tid - off0) * D;
+        if (row < Np0 && row >= off0) {
+            const double* z = a.Z + (long)(row - off0) * D;
             if (a.kp) {                                      // general family (sr_common.h), as sr_gram_general_kernel
                 const double* kp = a.kp + (long)d * SR_KP(D);
                 const double *sv = kp + 3, *av = kp + 3 + D, *bv = kp + 3 + 2 * D;
@@ -1262,47 +1264,49 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
                 }
                 v = a.sf2[d] * exp(-0.5 * r2);
             }
-            mu_t = v * alpha0[tid];
+            mu_t += v * alpha0[row];
         }
-        b[tid] = v;
+        b[row] = v;
     }
-    {
-        const double w = sr_wave_sum(mu_t);
+    auto block_sum = [&](double v) {                         // fixed order: wavefront sums, then wavefront 0 .. 15
+        const double w = sr_wave_sum(v);
+        __syncthreads();                                     // (red may still be read from the previous sum)
         if (lane == 0) red[wave] = w;
-    }
-    __syncthreads();
-    if (tid == 0) s_mu = (red[0] + red[1]) + (red[2] + red[3]);
-    // ---- u12[i] = sum_{k <= i} U^-1[k][i] b[k]: thread (slice q of 64 rows, column i), 16 loads in flight
-    {
-        const int q = tid >> 8, i = tid & 255;
+        __syncthreads();
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        return t;
+    };
+    const double mu_old = block_sum(mu_t);
+    if (tid == 0) s_mu = mu_old;
+    // ---- u12[i] = sum_{k <= i} U^-1[k][i] b[k]: work item (slice q of NPMAX / 4 rows, column i), 16 loads in flight
+    constexpr int SLICE = NPMAX / 4;
+#pragma unroll 1
+    for (int wi = tid; wi < 4 * NPMAX; wi += 1024) {
+        const int q = wi / NPMAX, i = wi % NPMAX;
         double acc = 0.0;
         if (i < Np0) {
-            const int k_end = min(q * 64 + 63, i);
-            for (int k0 = q * 64; k0 <= k_end; k0 += 16) {
-                double w[16];
+            constexpr int UB = (NPMAX == 256) ? 16 : 8;      // loads in flight (the 512 form would spill with 16)
+            const int k_end = min(q * SLICE + SLICE - 1, i);
+            for (int k0 = q * SLICE; k0 <= k_end; k0 += UB) {
+                double w[UB];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) w[u] = (k0 + u <= k_end) ? Wt0[(long)(k0 + u) * Np0 + i] : 0.0;
+                for (int u = 0; u < UB; ++u) w[u] = (k0 + u <= k_end) ? Wt0[(long)(k0 + u) * Np0 + i] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc = fma(w[u], b[min(k0 + u, 255)], acc);
+                for (int u = 0; u < UB; ++u) acc = fma(w[u], b[min(k0 + u, NPMAX - 1)], acc);
             }
         }
         part[q][i] = acc;
     }
     __syncthreads();
     double g_t = 0.0;
-    if (tid < 256) {
-        const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        u12[tid] = v;
-        g_t = v * v;
+    for (int i = tid; i < NPMAX; i += 1024) {
+        const double v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+        u12[i] = v;
+        g_t = fma(v, v, g_t);
     }
-    {
-        const double w = sr_wave_sum(g_t);
-        __syncthreads();                                     // (red is read by thread 0 above)
-        if (lane == 0) red[wave] = w;
-    }
-    __syncthreads();
+    const double g = block_sum(g_t);
     if (tid == 0) {
-        const double g = (red[0] + red[1]) + (red[2] + red[3]);
         double prior;                                        // k(z_new, z_new)
         if (a.kp) {
             const double* kp = a.kp + (long)d * SR_KP(D);
@@ -1329,7 +1333,7 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
     }
     __syncthreads();
     const double inv = s_inv, v2 = s_v2;
-    if (tid < 256) X[tid] = u12[tid] * inv;
+    for (int i = tid; i < NPMAX; i += 1024) X[i] = u12[i] * inv;
     __syncthreads();
     // ---- the new factor, alpha and targets, row by row
     double ld = 0.0;                                         // sum of log(diagonal) over this wavefront's rows (lane 0)
@@ -1384,9 +1388,10 @@ int sr_launch_append1_small(const double* Wt0, const double* alpha0, const doubl
                             const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
                             int D, int n_out, hipStream_t s) {
-    SR_CHECK(Np0 <= 256 && Np1 <= 384 && N0 >= 1 && N0 <= Np0, SR_EINVAL, "append1_small: Np0 = %d, Np1 = %d", Np0, Np1);
+    SR_CHECK(Np0 <= 512 && Np1 <= 640 && N0 >= 1 && N0 <= Np0, SR_EINVAL, "append1_small: Np0 = %d, Np1 = %d", Np0, Np1);
     sr_append1_args a{Wt0, alpha0, yT0, Z, ls, sf2, noise, kp, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out};
-    hipLaunchKernelGGL(sr_append1_small_kernel, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
+    if (Np0 <= 256) hipLaunchKernelGGL(sr_append1_small_kernel<256>, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(sr_append1_small_kernel<512>, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

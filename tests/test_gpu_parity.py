@@ -735,13 +735,14 @@ def test_row_append_update_equals_refit(N0, adds):
 
 
 @pytest.mark.parametrize("N0,n_s,n_u,steps", [(1, 2, 1, 5), (60, 4, 1, 6), (126, 2, 1, 4), (200, 3, 2, 3), (254, 2, 1, 5),
-                                               (256, 4, 1, 2)])
+                                               (256, 4, 1, 2), (300, 2, 1, 3), (383, 4, 1, 3), (510, 2, 1, 4)])
 def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
-    """ONE new point on an ARD-RBF model of <= 256 padded rows is one launch (sr_append1_small_kernel): against the
+    """ONE new point on a model of <= 512 padded rows is one launch (sr_append1_small_kernel): against the
     refit on all the data (factor entry by entry, zeros and identity padding included -- the kernel writes the whole
     matrix), against the general route of the same library (set_small_path(0)), the oracle's variance, the log
-    determinant of both routes; crosses the padded sizes 128 -> 256 -> 384; a point that breaks the factorisation
-    down leaves the model as it was."""
+    determinant of both routes; crosses the padded sizes 128 -> 256 -> 384 -> 512 -> 640 (the last append of (510, ..)
+    starts from 640 rows and takes the general route); a point that breaks the factorisation down leaves the model as
+    it was."""
     import ctypes
     from safe_exploration_amd._lib import lib
     ntot = N0 + steps
