@@ -83,9 +83,11 @@ int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
  * replaces: update_model(x, y, opt_hyp=False, replace_old=False)  ssm_gpy/gaussian_process.py:347-419
  * (the reference refactorises; its own row-append sketch is ssm_pytorch/utilities.py:74-117).
  * info [host, n_out] like sr_gp_factorize.  On success N grows by m and Np may grow.
- * m <= 16 takes matrix-vector shaped passes (U12 through the streaming prediction kernels; 0.40 ms for one point, 0.73 ms for 16 at N = 5000), larger m
- * the same algebra on 64 x 64 MFMA tiles; either way alpha is updated from the old model's mean at the new points and no
- * buffer of the factor's size is allocated while the padded size stays the same. */
+ * m <= 16 takes matrix-vector shaped passes (U12 through the streaming prediction kernels, every step one launch over all
+ * outputs; 0.29 ms for one point, 0.57 ms for 16 at N = 5000), one point on a model of <= 512 padded rows is ONE launch
+ * (54 us per call at N = 50), larger m the same algebra on 64 x 64 MFMA tiles; either way alpha is updated from the old
+ * model's mean at the new points and no buffer of the factor's size is allocated while the padded size stays the same.
+ * m <= 16 also leaves log det of the grown model on the host (sr_gp_logdet_cached). */
 int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info);
 
 /* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and

@@ -471,7 +471,7 @@ class SimpleGPModel(StateSpaceModel):
             raise ValueError("x must be (n, n_s_in+n_u) and y (n, n_s_out)")
         hd = self._handle
         s = B.stream_ptr(hd.device)
-        # <= 16 rows per call take the matrix-vector shaped path of sr_gp_append (0.40-0.73 ms at N = 5000), more rows
+        # <= 16 rows per call take the matrix-vector shaped path of sr_gp_append (0.29-0.57 ms at N = 5000; one point on <= 512 padded rows: one launch), more rows
         # go 128 at a time through its MFMA path
         step = 16 if x.shape[0] <= 16 else 128
         for lo in range(0, x.shape[0], step):
