@@ -94,12 +94,15 @@ class Staging(object):
 
     def _room(self, n_in, n_out):
         if self.h_in is None or self.h_in.numel() < n_in:
-            self.h_in = torch.empty(max(n_in, 1024), dtype=torch.float64).pin_memory()
+            # (room to grow: a caller whose batches get a little longer every call must not pin a new block each time)
+            n_in = max(n_in, 1024, 0 if self.h_in is None else min(2 * self.h_in.numel(), STAGING_MAX_DOUBLES))
+            self.h_in = torch.empty(n_in, dtype=torch.float64).pin_memory()
             self.d_in = torch.empty(self.h_in.numel(), dtype=torch.float64, device=self.device)
             self.h_in_np = self.h_in.numpy()
             self._gen += 1
         if self.h_out is None or self.h_out.numel() < n_out:
-            self.h_out = torch.empty(max(n_out, 1024), dtype=torch.float64).pin_memory()
+            n_out = max(n_out, 1024, 0 if self.h_out is None else min(2 * self.h_out.numel(), STAGING_MAX_DOUBLES))
+            self.h_out = torch.empty(n_out, dtype=torch.float64).pin_memory()
             self.d_out = torch.empty(self.h_out.numel(), dtype=torch.float64, device=self.device)
             self.h_out_np = self.h_out.numpy()
             self._gen += 1
