@@ -1,0 +1,542 @@
+// sr_capi_update.hip -- model update entry points: sr_gp_factorize (Gram -> blocked fp64 Cholesky with MFMA trailing
+// updates -> explicit U^-1 -> alpha), its stream set, and the diagnostics that read the factor (marginal likelihood,
+// log determinant, explicit K^-1, GEMM / diagonal-block test hooks).
+#include "sr_handle.h"
+using namespace srh;
+
+// ---------------------------------------------------------------------------------------------
+// factorisation: K = U^T U (right-looking, 128-blocks in panels, look-ahead), U^-T / U^-1 by recursive halving
+// with all nodes of a level in one launch, alpha = U^-1 (U^-T y)
+// ---------------------------------------------------------------------------------------------
+// job lists of the recursive inversion  [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22],  L21 = U12^T,
+// one list per depth of the halving tree (children before parents):
+//   product 1:  Y   = U12^T W11   (A = U12 k-major -- the factor's off-diagonal blocks live in W's upper block
+//               triangle --, B = W11 lower-triangular: mode 2) -> parked in the unused strict lower triangle of U
+//   product 2:  W21 = -Wt22^T Y   (A = Wt22 = U22^-1 upper-triangular: mode 3), written to W and, transposed,
+//               to Wt12 (keeps U^-1 complete for the parent level)
+static int ensure_inv_jobs(sr_gp* h) {
+    if (h->inv_jobs && h->inv_jobs_np == h->Np) return SR_OK;
+    const int Np = h->Np, nb = Np / SR_NB;
+    struct Node { int lo, hi, depth; };
+    std::vector<Node> nodes, stack;
+    stack.push_back({0, nb, 0});
+    int max_depth = 0;
+    while (!stack.empty()) {
+        const Node r = stack.back();
+        stack.pop_back();
+        if (r.hi - r.lo <= 1) continue;
+        nodes.push_back(r);
+        max_depth = std::max(max_depth, r.depth);
+        const int mid = (r.lo + r.hi) / 2;
+        stack.push_back({r.lo, mid, r.depth + 1});
+        stack.push_back({mid, r.hi, r.depth + 1});
+    }
+    std::vector<sr_gemm_job> jobs;
+    h->inv_levels.clear();
+    const int root_mid = nb / 2;
+    for (int depth = max_depth; depth >= 0; --depth) {
+        sr_gp::inv_level lv{};
+        lv.depth = depth;
+        std::vector<sr_gemm_job> j1, j2;
+        for (int side = 0; side < 2; ++side)
+        for (const Node& r : nodes) {
+            if (r.depth != depth) continue;
+            const bool left = depth > 0 && r.hi <= root_mid;          // inside the root's left half
+            if (left != (side == 0)) continue;
+            const int mid = (r.lo + r.hi) / 2;
+            const int n1 = (mid - r.lo) * SR_NB, n2 = (r.hi - mid) * SR_NB;
+            const long o11 = (long)r.lo * SR_NB * Np + (long)r.lo * SR_NB;
+            const long o12 = (long)r.lo * SR_NB * Np + (long)mid * SR_NB;
+            const long o21 = (long)mid * SR_NB * Np + (long)r.lo * SR_NB;
+            const long o22 = (long)mid * SR_NB * Np + (long)mid * SR_NB;
+            j1.push_back({o12, o11, o21, 0, n2, n1, n1, 0});      // Y (in U's lower triangle) = U12^T W11
+            j2.push_back({o22, o21, o21, o12, n2, n1, n2, 0});    // W21 = -Wt22^T Y ; Wt12 = W21^T
+            lv.maxM = std::max(lv.maxM, n2);
+            lv.maxN = std::max(lv.maxN, n1);
+            lv.tiles += (long)(n2 / SR_NB) * (n1 / SR_NB);
+            if (left) { ++lv.n_left; lv.tiles_left += (long)(n2 / SR_NB) * (n1 / SR_NB); }
+        }
+        lv.count = (int)j1.size();
+        if (lv.count == 0) continue;
+        lv.off1 = (int)jobs.size();
+        jobs.insert(jobs.end(), j1.begin(), j1.end());
+        lv.off2 = (int)jobs.size();
+        jobs.insert(jobs.end(), j2.begin(), j2.end());
+        h->inv_levels.push_back(lv);
+    }
+    dev_free(h->inv_jobs);
+    h->inv_jobs = nullptr; h->inv_jobs_np = 0;
+    if (jobs.empty()) { h->inv_jobs_np = Np; return SR_OK; }
+    SR_TRY(dev_alloc(&h->inv_jobs, jobs.size()));
+    SR_HIP(hipMemcpy(h->inv_jobs, jobs.data(), jobs.size() * sizeof(sr_gemm_job), hipMemcpyHostToDevice));
+    h->inv_jobs_np = Np;
+    return SR_OK;
+}
+
+// blocks per Cholesky panel.  Inside a panel a factored block row updates only the panel's remaining rows;
+// everything below is updated once per panel with K = panel * 128, which divides the read-modify-write traffic
+// of the trailing matrix by `panel` and gives the bulk update K = panel * 128 (a K = 128 update spends most of its
+// time in the prologue and the read-modify-write epilogue of its tiles: measured 35 % of the K = 512 rate).
+// Measured at N = 1000 ... 10000: 4 beats 1 and 2 everywhere (N = 5000: 6.9 against 7.2-7.9 ms).
+static int pick_fact_panel(const sr_gp* h) {
+    if (h->fact_panel > 0) return h->fact_panel;
+    const int nb = h->Np / SR_NB;
+    // measured (scripts/factor_bench.py, n_out = 2): N = 3000 .. 6000 panels of 2 are 2 - 4 % ahead of 4 (3.33 / 3.49,
+    // 4.91 / 5.01, 6.82 / 7.01, 9.24 / 9.41 ms), N = 7000 and 10000 panels of 4 (12.99 / 13.04, 28.3 / 30.2 ms)
+    // N = 50000 (391 blocks): panels of 4 / 8 / 16 / 32 blocks 2.735 / 2.655 / 2.625 / 2.642 s; N = 30000: 8 and 16 alike
+    // round 3 (diagonal block 62 -> 30 us, batched outputs), n_out = 2, panels of 2 / 3 / 4 / 6 / 8 blocks: N = 3000 2.22 / 2.26 /
+    // 2.34 / 2.41 / 2.52 ms; N = 5000 5.26 / 5.15 / 5.15 / 5.29 / 5.64; N = 7000 11.0 / 10.5 / 10.2 / 10.3 / 10.5; N = 10000
+    // 28.3 / 26.7 / 25.8 / 25.5 / 25.0; N = 20000 (4 / 8 / 12 / 16) 186.8 / 184.3 / 187.4 / 188.6; N = 30000 592 / 578 / 575 /
+    // 574; N = 50000 (8 / 12 / 16 / 24) 2.599 / 2.580 / 2.570 / 2.555 s
+    // with the in-panel updates of long K on 128-tiles (sr_use_tile64): N = 30000 panels of 12 / 16 / 24 / 32: 565 / 562 / 561 / 562 ms;
+    // N = 50000 panels of 24 / 32 / 48: 2.521 / 2.514 / 2.508 s
+    return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 24 : 48))));
+}
+
+// Streams of the factorisation.  The chain of diagonal blocks is latency-bound and must never queue behind the
+// (throughput-bound) bulk update; the diagonal-block kernel moreover needs a CU to itself (150 KB of LDS), and a
+// workgroup is bound to a shader engine before it waits for a CU.  CU masks are dealt by the driver round-robin over
+// the 8 XCDs and, inside an XCD, over its 4 shader engines (scripts/cumask_probe.hip).
+//   regime 1 (chain-bound sizes, nb <= 128): critical stream = highest priority, every CU; bulk stream = CU mask
+//     without the first 32 bits: one CU per shader engine stays free, wherever the diagonal block lands
+//     (measured at N = 5000: 61 us alone, 140-210 us beside an unmasked bulk update, 75 us with the reserve);
+//     (a stream of their own for the diagonal blocks, so that a block is factored BESIDE the update of the rest of
+//     its block row, was measured here and lost: every hand-over between two hardware queues costs more than the
+//     25 us it hides -- N = 5000: 6.9 -> 15.2 ms.  The same holds for a third priority stream per output and for a
+//     row-wise inversion running beside the chain: 6.9 -> 12.5 resp. 8.0 -> 10.6 ms.  One critical stream per output.)
+//   regime 2 (GEMM-bound sizes): the bulk stream leaves only the first 8 bits out (one CU per XCD, 3 % of the
+//     chip), and the diagonal blocks run on a third stream that owns exactly those 8 CUs -- the bulk tiles last
+//     200 us there and would otherwise keep a diagonal block waiting for ~1.4 ms (N = 50000: the chain of 391 blocks
+//     then IS the critical path of the whole Cholesky).  The critical stream keeps every CU and its priority (a
+//     CU-masked stream cannot have one: with all three streams masked the look-ahead rows queued 1:1 with the bulk
+//     tiles and the update got 7 % slower); it is idle while a diagonal block runs, so the reserve is free then.
+// Few streams on purpose: streams of one priority share a small pool of hardware queues, and two chains on one
+// queue serialise (a third high-priority stream per output cost 45 % at N = 5000).
+static int make_masked_stream(hipStream_t* st, int ncu, int first_bit, int last_bit) {
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int c = first_bit; c < last_bit; ++c) mask[c / 32] |= 1u << (c % 32);
+    SR_HIP(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+    return SR_OK;
+}
+
+// The streams of the model update belong to the PROCESS (per device and (regime, reserved CUs)), not to a handle: creating
+// them -- a priority stream and two CU-masked ones -- takes 12 - 18 ms, which every handle of a model whose size changes
+// used to pay again (a refit after a change of N: 48 ms, of which 5 were the update).  Updates of different handles that
+// share them simply queue behind each other.
+struct sr_stream_set { int device, key; hipStream_t fact, bulk, inv; };
+static std::mutex g_stream_mutex;
+static std::vector<sr_stream_set> g_stream_sets;
+static void drop_fact_streams(sr_gp* h) {
+    // (the handle only forgets them; work it has in flight on them is waited for)
+    for (hipStream_t* st : {&h->fact_stream, &h->bulk_stream, &h->inv_stream})
+        if (*st) { (void)hipStreamSynchronize(*st); *st = nullptr; }
+    h->fact_regime = 0;
+}
+
+static int ensure_fact_streams(sr_gp* h, int regime) {
+    if (h->ncu == 0) {
+        int cus = 0;
+        SR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        h->ncu = cus;
+    }
+    const int ncu = h->ncu;
+    const bool can_mask = ncu >= 64;
+    // (giving each output's chain one half of the XCDs through CU masks on ALL of its streams was measured and lost:
+    //  N = 5000, two outputs 5.6 -> 8.7 ms -- kernels on a CU-masked queue start late, and the mask costs the priority)
+    // CUs the bulk streams leave to the critical chain: one per shader engine; two for 36 < Np / 128 <= 52, where the
+    // block-row solves and in-panel updates of the chain otherwise queue behind the trailing update's workgroups (50
+    // instead of 12 us each) and the trailing update has the slack (measured, reserve 32 / 64: N = 3500 2.79 / 2.80,
+    // N = 5000 5.14 / 4.99, N = 6500 8.79 / 8.74, N = 7500 12.17 / 12.45, N = 10000 25.1 / 26.7 ms)
+    const int nblk = h->Np / SR_NB;
+    const int reserve = regime == 2 ? 8 : ((nblk > 36 && nblk <= 52) ? 2 * SR_FACT_RESERVED_CUS : SR_FACT_RESERVED_CUS);
+    const int key = regime * 1000 + reserve;
+    if (h->fact_regime != key) drop_fact_streams(h);
+    if (!h->fact_stream) {
+        std::lock_guard<std::mutex> lk(g_stream_mutex);
+        sr_stream_set* set = nullptr;
+        for (sr_stream_set& c : g_stream_sets)
+            if (c.device == h->device && c.key == key) set = &c;
+        if (!set) {
+            sr_stream_set c{h->device, key, nullptr, nullptr, nullptr};
+            int prio_lo = 0, prio_hi = 0;
+            SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            SR_HIP(hipStreamCreateWithPriority(&c.fact, hipStreamNonBlocking, prio_hi));
+            if (can_mask) SR_TRY(make_masked_stream(&c.bulk, ncu, reserve, ncu));
+            else SR_HIP(hipStreamCreateWithPriority(&c.bulk, hipStreamNonBlocking, prio_lo));
+            if (regime == 1) {
+                if (can_mask) SR_TRY(make_masked_stream(&c.inv, ncu, reserve, ncu));
+                else SR_HIP(hipStreamCreateWithPriority(&c.inv, hipStreamNonBlocking, prio_lo));
+            }
+            g_stream_sets.push_back(c);
+            set = &g_stream_sets.back();
+        }
+        h->fact_stream = set->fact; h->bulk_stream = set->bulk; h->inv_stream = set->inv;
+    }
+    if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
+    for (int e = 0; e < 2; ++e) {
+        if (!h->ev_panel[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_panel[e], hipEventDisableTiming));
+        if (!h->ev_bulk[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_bulk[e], hipEventDisableTiming));
+        if (!h->ev_inv[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_inv[e], hipEventDisableTiming));
+    }
+    h->fact_regime = key;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_factorize: NULL handle");
+    SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
+    SR_DEVICE(h->device);
+    const auto t_begin = std::chrono::steady_clock::now();
+    static const bool trace_laps = getenv("SR_FACT_TRACE") != nullptr;
+    auto lap = [&](const char* what) { if (trace_laps) fprintf(stderr, "  %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
+    SR_TRY(ensure_wt(h));
+    lap("wt");
+    SR_TRY(ensure_inv_jobs(h));
+    lap("inv_jobs");
+    const int Np = h->Np, nb = Np / SR_NB;
+    const int P = pick_fact_panel(h);
+    const size_t NN = (size_t)Np * Np;
+    const size_t per = 2 * NN + (size_t)Np;              // scratch doubles per output in flight: U, W, v
+    // outputs in a batch: as many as fit a third of the device's memory in scratch (8 GB at least), at most SR_FACT_SLOTS.
+    // (Round 2 capped the scratch at 8 GB, so the outputs of a big model went one after the other; batched, the latency
+    // of one output's chain of panel steps is filled with the other's tiles: N = 50000, n_out = 2 -- 80 GB of scratch
+    // beside 40 GB of factors.)
+    // The scratch stays with the handle (refits allocate nothing): at N = 50000 a hipMalloc / hipFree of 40 GB per update
+    // made the first updates of a process take 4.0 - 4.8 s instead of 2.67 s (page-table work inside the timed call).
+    // sr_gp_release_scratch hands it back.
+    if (h->mem_total == 0) {
+        size_t mem_free = 0;
+        (void)hipMemGetInfo(&mem_free, &h->mem_total);
+    }
+    static const size_t par_cap_env = getenv("SR_FACT_PAR_GB") ? (size_t)atol(getenv("SR_FACT_PAR_GB")) << 30 : 0;
+    const size_t par_bytes = par_cap_env ? par_cap_env : std::max<size_t>(SR_FACT_PAR_BYTES, h->mem_total / 3);
+    int n_par = (int)std::min<size_t>((size_t)std::min(h->n_out, SR_FACT_SLOTS),
+                                      std::max<size_t>(1, par_bytes / (per * sizeof(double))));
+    const bool keep = per * n_par * sizeof(double) <= par_bytes;
+    double* scratch = nullptr;                           // owned here only when it is not kept in the handle
+    int rc = SR_OK;
+    hipStream_t s0 = (hipStream_t)stream;
+    auto cleanup = [&]() {
+        // never return with work in flight on the side streams
+        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream}) if (st) (void)hipStreamSynchronize(st);
+        dev_free(scratch);
+    };
+#define SR_F(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(); return rc; } } while (0)
+#define SR_FH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+        sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); cleanup(); return SR_EHIP; } } while (0)
+    double* ws;
+    if (keep) {
+        if (h->fact_cap < per * n_par) {
+            (void)hipDeviceSynchronize();
+            dev_free(h->fact_ws);
+            h->fact_ws = nullptr; h->fact_cap = 0;
+            SR_F(dev_alloc(&h->fact_ws, per * n_par));
+            h->fact_cap = per * n_par;
+        }
+        ws = h->fact_ws;
+    } else {
+        SR_F(dev_alloc(&scratch, per));
+        ws = scratch;
+    }
+    // (nothing is read back or allocated before the first launch: the Gram kernels take the signal variance and the
+    //  noise from device memory, the status words live with the handle -- round 2 paid a D2H copy, a stream
+    //  synchronisation, a hipMalloc and a hipMemGetInfo here, 0.1 ms before the first kernel started)
+    lap("fact_ws");
+    if (!h->fact_info) SR_F(dev_alloc(&h->fact_info, (size_t)64));
+    int* info_dev = h->fact_info;
+    SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s0));
+    if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
+    SR_FH(hipEventRecord(h->fact_fork, s0));
+    const int regime = nb <= 128 ? 1 : 2;
+    SR_F(ensure_fact_streams(h, regime));
+    lap("streams");
+    static const bool no_early_inv = getenv("SR_FACT_NO_EARLY_INV") != nullptr;
+    hipStream_t sc = h->fact_stream, sb = h->bulk_stream, si = h->inv_stream;
+    SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));
+
+    // Outputs are processed in rounds of n_par as a BATCH: one chain of launches, every kernel works on the n_par
+    // problems at once (grid dimension = output; operands `per` resp. NN doubles apart).  Round 2 ran one chain of
+    // launches per output on streams of their own; the chains got in each other's way -- a diagonal-block kernel needs
+    // a CU to itself (136 KB of LDS) and waited for the other chain's GEMM workgroups to drain, every GEMM of one chain
+    // slowed the other's: N = 5000, one output alone 4.0 ms, two outputs 5.6 ms.
+    // Buffers per output in flight:
+    //   U  = Gram matrix, updated in place; its diagonal blocks end up factored; its strict lower block triangle
+    //        is scratch of the inversion (Y).
+    //   W  = strict upper block triangle: the FINAL off-diagonal block rows of the factor (the block row solve
+    //        writes them here, out of place: with the 64 x 64 tile two workgroups share the 128 rows of a column
+    //        block, so an in-place solve would race); diagonal + lower: U^-T.  Every block of W is written before
+    //        it is read: no memset.
+    //   Wt = U^-1 (diagonal blocks from the diagonal-block kernel, upper blocks from the inversion; the strict
+    //        lower triangle is zero from allocation and never written).
+    for (int d0 = 0; d0 < h->n_out; d0 += n_par) {
+        const int nd = std::min(n_par, h->n_out - d0);
+        double* U = ws;                                   // batch member b: + b * per
+        double* W = U + NN;
+        double* Wt = h->Wt + (size_t)d0 * NN;             // batch member b: + b * NN
+        const long sP = (long)per, sN = (long)NN;
+        const sr_batch b_ppp{nd, sP, sP, sP, 0};          // all operands in the scratch
+        const sr_batch b_diag{nd, sP, sN, sP, 0};         // A = U, wt = Wt, w = W
+        const sr_batch b_solve{nd, sN, sP, sP, 0};        // A = Wt (U_kk^-1), B = U, C = W
+        const sr_batch b_inv1{nd, sP, sP, sP, 0};         // inversion, product 1: (W, W) -> U
+        const sr_batch b_inv2{nd, sN, sP, sP, sN};        // inversion, product 2: (Wt, U) -> W, Wt
+        int n_bulk = 0;                                   // bulk updates issued so far (event ping-pong)
+        // Early inversion (chain-bound sizes): once the chain has passed the middle block, the root's LEFT subtree of the
+        // inversion and the root's first product need nothing the Cholesky still writes (factor rows above the middle,
+        // their diagonal-block inverses; results go to W / Wt inside the left half and to U's unused lower-left block).
+        // They run on a low-priority stream of their own beside the second half of the chain, which leaves most of the
+        // chip idle -- 5/8 of the inversion's flops.  Afterwards: right subtree, root's second product.
+        const int root_mid = nb / 2;
+        const bool early_inv = regime == 1 && si != nullptr && nb >= 8 && !no_early_inv;
+        bool early_done = false;
+        {
+            sr_prof_scope ps(&h->prof, SR_K_GRAM, sc);
+            if (h->general)
+                SR_F(sr_launch_gram_general(h->Z, h->kp + (size_t)d0 * SR_KP(h->D), 0.0, h->noise + d0, U, h->N, Np, h->D, sc,
+                                            nd, sP));
+            else
+                SR_F(sr_launch_gram(h->Z, h->ls + (size_t)d0 * h->D, 0.0, 0.0, h->sf2 + d0, h->noise + d0, U, h->N, Np, h->D,
+                                    sc, nd, sP));
+        }
+        // --- Cholesky K = U^T U, right-looking in panels of P blocks with look-ahead: after a panel is factored
+        // (critical stream, per block: update of its row by the panel's rows above, diagonal block, block row solve),
+        // the trailing update is split -- the rows of the NEXT panel on the critical stream, so that its factorisation can start at
+        // once, everything behind them on the bulk stream, which may lag one panel behind.
+        int pi = 0;
+        for (int p0 = 0; p0 < nb; p0 += P, ++pi) {
+            const int p1 = std::min(nb, p0 + P);
+            for (int kb = p0; kb < p1; ++kb) {
+                const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
+                const int ncols = Np - (kb + 1) * SR_NB;
+                // left-looking INSIDE the panel: block row kb takes the updates of the panel's rows above it in
+                // one product with K = (kb - p0) * 128, right before it is needed -- each row block of the
+                // panel is read-modify-written once (eager rank-128 updates of all remaining panel rows
+                // touched it up to P - 1 times with K = 128, where prologue and epilogue dominate a tile).
+                // (Round 2 ran the diagonal block of the big sizes on a stream of its own beside the rest of its row's
+                // update; with the block down from 62 - 180 us to 35 the two event hand-offs per block cost more than the
+                // overlap bought: N = 50000 2.616 -> 2.594 s, N = 20000 193 -> 189 ms without it.)
+                const double* Upr = W + (size_t)p0 * SR_NB * Np + (size_t)kb * SR_NB;       // rows p0..kb-1, cols >= kb
+                const int Kin = (kb - p0) * SR_NB;
+                if (kb > p0) {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    SR_F(sr_launch_gemm_tn_upper(Upr, Np, Upr, Np, U + dg, Np, SR_NB, Np - kb * SR_NB, Kin, -1.0, 1.0, sc, 1, -1,
+                                                 &b_ppp));
+                }
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_POTRF, sc);
+                    SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d0, sc, 0, &b_diag));
+                }
+                if (ncols > 0) {
+                    const double* Arow = U + dg + SR_NB;          // updated Gram rows right of the block
+                    double* Urow = W + dg + SR_NB;                // factor rows U[kb][cols right of the block]
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    // U_k,: = U_kk^-T A_k,:   (A operand = U_kk^-1, k-major)
+                    SR_F(sr_launch_gemm_tn(Wt + dg, Np, Arow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, sc, 1, &b_solve));
+                }
+            }
+            if (early_inv && !early_done && p1 >= root_mid && p1 < nb) {
+                // every factor row above the middle is final (and its diagonal block inverted): left subtree + root product 1
+                early_done = true;
+                SR_FH(hipEventRecord(h->ev_inv[0], sc));
+                SR_FH(hipStreamWaitEvent(si, h->ev_inv[0], 0));
+                for (const sr_gp::inv_level& lv : h->inv_levels) {
+                    sr_prof_scope ps(&h->prof, SR_K_TRINV, si);
+                    if (lv.depth == 0) {
+                        SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, 1, lv.maxM, lv.maxN, lv.tiles, 1.0, 2,
+                                                    si, &b_inv1));
+                    } else if (lv.n_left > 0) {
+                        SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, lv.n_left, lv.maxM, lv.maxN,
+                                                    lv.tiles_left, 1.0, 2, si, &b_inv1));
+                        SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2, lv.n_left, lv.maxM, lv.maxN,
+                                                    lv.tiles_left, -1.0, 3, si, &b_inv2));
+                    }
+                }
+                SR_FH(hipEventRecord(h->ev_inv[1], si));
+            }
+            const int rest = Np - p1 * SR_NB;
+            if (rest <= 0) continue;
+            const int Kp = (p1 - p0) * SR_NB;
+            const double* Upan = W + (size_t)p0 * SR_NB * Np + (size_t)p1 * SR_NB;    // factor rows of the panel
+            double* Cnext = U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB;
+            const int la = std::min(P * SR_NB, rest);         // rows of the next panel
+            const int bulk = rest - la;
+            // regime 1 (chain-bound sizes): the bulk update starts only AFTER the look-ahead rows are done -- started
+            // together, its workgroups fill the CUs first and the look-ahead (on the critical path) takes 60 - 70 us
+            // instead of 20; regime 2: when the panel's rows are final
+            const bool bulk_after_la = (regime == 1);
+            if (bulk > 0 && !bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
+            // the previous bulk update wrote the look-ahead rows too: it has to be through
+            if (n_bulk > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
+            {
+                sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1, -1, &b_ppp));
+            }
+            if (bulk > 0) {
+                if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
+                SR_FH(hipStreamWaitEvent(sb, h->ev_panel[pi & 1], 0));
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sb);
+                    SR_F(sr_launch_gemm_tn_upper(Upan + la, Np, Upan + la, Np, Cnext + (size_t)la * Np + la, Np,
+                                                 bulk, bulk, Kp, -1.0, 1.0, sb, 0, -1, &b_ppp));
+                }
+                SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sb));
+                ++n_bulk;
+            }
+        }
+        if (n_bulk > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
+        // --- W = U^-T (lower) and Wt = U^-1 (upper) by recursive halving of the block range, level by level
+        // (ensure_inv_jobs).  The diagonal blocks of W / Wt were written by sr_potrf_diag_kernel.
+        if (early_done) SR_FH(hipStreamWaitEvent(sc, h->ev_inv[1], 0));
+        for (const sr_gp::inv_level& lv : h->inv_levels) {
+            sr_prof_scope ps(&h->prof, SR_K_TRINV, sc);
+            const int skip = early_done ? lv.n_left : 0;          // jobs of the left subtree already ran
+            const int cnt = lv.count - skip;
+            const long tiles = lv.tiles - (early_done ? lv.tiles_left : 0);
+            if (cnt > 0 && !(early_done && lv.depth == 0))
+                SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1 + skip, cnt, lv.maxM, lv.maxN, tiles, 1.0, 2,
+                                            sc, &b_inv1));
+            if (cnt > 0)
+                SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2 + skip, cnt, lv.maxM, lv.maxN, tiles, -1.0, 3,
+                                            sc, &b_inv2));
+        }
+        // alpha = Wt (W y)   (v behind W in the scratch)
+        SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d0 * Np, W + NN, Np, 1, sc, nd, sP, Np, sP));
+        SR_F(sr_launch_trmv(Wt, Np, W + NN, h->alpha + (size_t)d0 * Np, Np, 0, sc, nd, sN, sP, Np));
+    }
+    SR_FH(hipEventRecord(h->fact_join, sc));
+    SR_FH(hipStreamWaitEvent(s0, h->fact_join, 0));
+    static const bool trace = getenv("SR_FACT_TRACE") != nullptr;
+    const auto t_enq = std::chrono::steady_clock::now();
+    std::vector<int> info_h(h->n_out, 0);
+    SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s0));
+    // (no log determinant here: a launch and a copy on the critical path of every refit -- 0.3 % at N = 5000 -- for a number
+    //  only the exploration loop asks for, and there the appends keep the host copy current)
+    h->logdet_valid = 0;
+    SR_FH(hipStreamSynchronize(s0));
+    if (trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "sr_gp_factorize: Np=%d enqueue %.3f ms, total %.3f ms\n", Np,
+                std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_begin).count());
+    }
+    cleanup();
+#undef SR_F
+#undef SR_FH
+    int bad = 0;
+    for (int d = 0; d < h->n_out; ++d) {
+        if (info_h[d] > 0) info_h[d] = std::max(1, info_h[d] - (h->Np - h->N));   // padded -> training index
+        if (info) info[d] = info_h[d];
+        if (info_h[d] != 0 && !bad) bad = d + 1;
+    }
+    if (bad) {
+        h->factorized = 0; h->logdet_valid = 0;
+        sr_set_error("Cholesky breakdown: output %d, pivot %d not positive", bad - 1, info_h[bad - 1]);
+        return SR_ENOTPD;
+    }
+    h->factorized = 1;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_set_fact_panel(sr_gp_t h, int panel) {
+    SR_CHECK(h != nullptr && panel >= 0 && panel <= 64, SR_EINVAL, "sr_gp_set_fact_panel: bad argument");
+    h->fact_panel = panel;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_mll(sr_gp_t h, double* nll, double* grad, void* stream) {
+    SR_CHECK(h && nll && grad, SR_EINVAL, "sr_gp_mll: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_mll: model not factorized");
+    SR_CHECK(h->general, SR_ESTATE, "sr_gp_mll: set the data with sr_gp_set_data_general (packed parameters)");
+    hipStream_t s = (hipStream_t)stream;
+    SR_DEVICE(h->device);
+    const int Np = h->Np, D = h->D;
+    const size_t NN = (size_t)Np * Np;
+    const int ng = SR_KP(D);                        // [v, c0, s[D], a[D], b[D], noise]
+    double *W = nullptr, *Kinv = nullptr, *partial = nullptr, *ld = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&W, NN)) || (rc = dev_alloc(&Kinv, NN)) || (rc = dev_alloc(&partial, (size_t)sr_mll_ws(h->N))) ||
+        (rc = dev_alloc(&ld, (size_t)h->n_out))) {
+        dev_free(W); dev_free(Kinv); dev_free(partial); dev_free(ld);
+        return rc;
+    }
+    rc = sr_launch_logdet(h->Wt, Np, h->n_out, ld, s);
+    for (int d = 0; d < h->n_out && rc == SR_OK; ++d) {
+        // K_y^-1 = U^-1 U^-T = sum_k W[k][i] W[k][j]  (W = Wt^T, k-major)
+        rc = sr_launch_transpose(h->Wt + (size_t)d * NN, W, Np, s);
+        if (rc == SR_OK) rc = sr_launch_gemm_tn(W, Np, W, Np, Kinv, Np, Np, Np, Np, 1.0, 0.0, 0, s);
+        if (rc == SR_OK)
+            rc = sr_launch_mll(Kinv, Np, h->N, h->alpha + (size_t)d * Np, h->yT + (size_t)d * Np, h->Z,
+                               h->kp + (size_t)d * SR_KP(D), D, ld + d, partial, nll + d, grad + (size_t)d * ng, s);
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    dev_free(W); dev_free(Kinv); dev_free(partial); dev_free(ld);
+    if (rc != SR_OK) return rc;
+    SR_HIP(e);
+    return SR_OK;
+}
+
+// host copy of the same numbers if the last model update left one (SR_ESTATE otherwise: call sr_gp_logdet)
+extern "C" int sr_gp_logdet_cached(sr_gp_t h, double* logdet_host) {
+    SR_CHECK(h && logdet_host, SR_EINVAL, "sr_gp_logdet_cached: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_logdet_cached: model not factorized");
+    if (!h->logdet_valid || (int)h->logdet_host.size() != h->n_out) {
+        sr_set_error("sr_gp_logdet_cached: no host copy");
+        return SR_ESTATE;
+    }
+    for (int d = 0; d < h->n_out; ++d) logdet_host[d] = h->logdet_host[d];
+    return SR_OK;
+}
+
+extern "C" int sr_gp_logdet(sr_gp_t h, double* logdet, void* stream) {
+    SR_CHECK(h && logdet, SR_EINVAL, "sr_gp_logdet: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_logdet: model not factorized");
+    SR_DEVICE(h->device);
+    return sr_launch_logdet(h->Wt, h->Np, h->n_out, logdet, (hipStream_t)stream);
+}
+
+extern "C" int sr_gp_inv_k(sr_gp_t h, int d, double* inv_k, void* stream) {
+    SR_CHECK(h && inv_k, SR_EINVAL, "sr_gp_inv_k: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_inv_k: model not factorized");
+    SR_CHECK(d >= 0 && d < h->n_out, SR_EINVAL, "sr_gp_inv_k: d=%d out of range", d);
+    hipStream_t s = (hipStream_t)stream;
+    SR_DEVICE(h->device);
+    const int Np = h->Np;
+    const size_t NN = (size_t)Np * Np;
+    double *W = nullptr, *out = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&W, NN)) || (rc = dev_alloc(&out, NN))) { dev_free(W); dev_free(out); return rc; }
+    // K^-1 = U^-1 U^-T = sum_k W[k][i] W[k][j]  (W = Wt^T, k-major)
+    rc = sr_launch_transpose(h->Wt + (size_t)d * NN, W, Np, s);
+    if (rc == SR_OK) rc = sr_launch_gemm_tn(W, Np, W, Np, out, Np, Np, Np, Np, 1.0, 0.0, 0, s);
+    hipError_t e = hipSuccess;
+    if (rc == SR_OK)
+        e = hipMemcpy2DAsync(inv_k, sizeof(double) * h->N, out + (size_t)(Np - h->N) * Np + (Np - h->N),
+                             sizeof(double) * Np, sizeof(double) * h->N, h->N, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(W); dev_free(out);
+    if (rc != SR_OK) return rc;
+    SR_HIP(e);
+    return SR_OK;
+}
+
+extern "C" int sr_test_gemm_tn(int device, const double* A, long lda, const double* B, long ldb,
+                               double* C, long ldc, int M, int N, int K, double alpha, double beta,
+                               int mode, void* stream) {
+    SR_CHECK(A && B && C, SR_EINVAL, "sr_test_gemm_tn: NULL argument");
+    SR_DEVICE(device);
+    return sr_launch_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, mode, (hipStream_t)stream);
+}
+
+extern "C" int sr_test_gemm_tn_upper(int device, const double* A, long lda, const double* B, long ldb, double* C,
+                                     long ldc, int M, int N, int K, double alpha, double beta, int order, void* stream) {
+    SR_CHECK(A && B && C, SR_EINVAL, "sr_test_gemm_tn_upper: NULL argument");
+    SR_DEVICE(device);
+    return sr_launch_gemm_tn_upper(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, (hipStream_t)stream, 0, order);
+}
+
+extern "C" int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, long ldw, int* info,
+                                  int skip, void* stream) {
+    SR_CHECK(A && wt && w && info, SR_EINVAL, "sr_test_potrf_diag: NULL argument");
+    SR_DEVICE(device);
+    return sr_launch_potrf_diag(A, lda, wt, w, ldw, 0, info, (hipStream_t)stream, skip);
+}
+

@@ -1,0 +1,133 @@
+// sr_handle.h -- the model handle behind sr_gp_t and the host-side helpers the entry-point files share.
+// Private to the library (include/safereach.h is the public face).  The entry points live in
+//   sr_capi_handle.hip     handle life cycle, device-memory block cache, data, export / import / packed replication,
+//                          switches, per-kernel timing
+//   sr_capi_update.hip     model update: Gram -> blocked Cholesky -> U^-1 -> alpha (sr_gp_factorize) and its diagnostics
+//   sr_capi_append.hip     block row append (sr_gp_append)
+//   sr_capi_posterior.hip  workspace, dispatch of the posterior pass (sr_gp_predict, sr_gp_linearize, sr_gp_call1),
+//                          input transform, completion mailbox
+//   sr_capi_reach.hip      reachability / moment / sampling entry points and the persistent-chain dispatch
+#pragma once
+#include "sr_mfma_tile.h"
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <algorithm>
+
+struct sr_gp {
+    int device = 0, N = 0, Np = 0, D = 0, n_out = 0;
+    // persistent device state
+    double *Z = nullptr, *yT = nullptr, *ls = nullptr, *sf2 = nullptr, *noise = nullptr,
+           *alpha = nullptr, *Wt = nullptr;
+    double* kp = nullptr;     // general kernel family: n_out x SR_KP(D) packed parameters (else NULL)
+    // GP input transform of the reachability / moment entry points: x_gp = Tz x (Tz n_xin x n_s), NULL = identity
+    double* Tz = nullptr; int n_xin = 0;
+    double *tz_x = nullptr, *tz_jac = nullptr; long tz_cap = 0;   // transformed inputs / chain-ruled Jacobians (per chunk)
+    // persistent multi-step kernel (sr_small.hip K0c): exchange buffer, per group ticket + epoch + done counter (all of
+    // the hand-off state lives on the device), switch
+    sr_xel* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // the groups' epochs
+    unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0; int chain_cap = -1;
+    int* chain_status_host = nullptr; int* chain_status_dev = nullptr;   // pinned: set by a chain launch that timed out
+    int chain_occ_key = -1, chain_occ_blocks = 0;                         // occupancy of the kernel last asked about
+    int chain_test_drop = 0;                                              // sr_test_chain_drop
+    unsigned* call_ticket = nullptr;        // sr_gp_call1: workgroups done (reset by the last one)
+    int general = 0;
+    int have_data = 0, factorized = 0;
+    int import_open = 0;     // between sr_gp_import_begin and sr_gp_import_end
+    // per-chunk workspace (grow-only)
+    long chunk = 65536, ws_Tp = 0, ws_part = 0;     // ws_part: capacity of mu_part in units of n_out doubles
+    int ws_locked = 0;       // internal buffers (mu / var / jac) are referenced by an entry point: growing now is a bug
+    double *Ks = nullptr, *mu_part = nullptr, *jac_part = nullptr, *var_part = nullptr,
+           *mu = nullptr, *var = nullptr, *jac = nullptr, *kxx = nullptr;
+    double *lin_v = nullptr, *lin_g = nullptr, *small_vp = nullptr;   // small-batch scratch
+    size_t lin_cap = 0;                                                 // doubles behind lin_v
+    double* stream_vp = nullptr; long stream_vp_cap = 0;   // fused small-batch path: partial sums (grow-only)
+    unsigned* stream_tickets = nullptr;
+    double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
+    int balanced = 1;                                   // few query tiles: balanced shares (K2b) or chunks (K2k): A/B switch
+    // log det(K + noise) per output as of the last <= 16-row append (read back with its status words): the blocking read of
+    // sr_gp_logdet costs the exploration loop 30 us per step
+    std::vector<double> logdet_host; int logdet_valid = 0;
+    double* splitk_part = nullptr;                      // n_out x 4 nrb x Tp partial norms (<= 4 MB)     // 2 x (n_out x Np) scratch of sr_gp_linearize
+    int var_group = 64;      // query tiles per scheduling group of the variance kernel.  With the diagonal blocks cut short
+                             // (variant 2) 64 beats 32: 70.7 against 70.0 TF at C2', fabric-side fetches 61.3 -> 42.9 M KiB per launch
+                             // (scripts/pmc_groups.sh); 256 and more lose the sharing of the K* tiles (68.7 TF)
+    int small_path = 1;      // latency paths (streaming T <= 16, 64-tiles, split-K) instead of the plain MFMA tiles
+    int last_streamed = 0;   // the last gp_pass went through the streaming kernels (their partials hold U^-T k*)
+    int force_stream = 0;    // sr_gp_linearize wants those partials whatever the model size
+    int var_variant = 2;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles, 2: 1 + diagonal blocks
+                             // without their structural zeros (default; 69.8 -> 70.05 TF at C2')
+    // factorisation: the outputs are independent problems -- below SR_FACT_PAR_BYTES of scratch each gets its own
+    // HIP stream (the small-grid kernels of a modest model then overlap) and the scratch stays with the handle
+    double* fact_ws = nullptr; size_t fact_cap = 0;      // n_par x (U, W: Np^2 each, v: Np)
+    // row append of few points (m <= 16): scratch and a second U^-1 buffer the new factor is assembled into
+    // (kept while the padded size does not change: appends then allocate nothing big)
+    double* app_ws = nullptr; size_t app_cap = 0;
+    double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
+    int wt_alt_off = -1;     // front padding of the (complete, well-formed) factor Wt_alt last held; -1 unknown
+    // small appends allocate nothing while the padded size stays: Z has room for z_cap points, yT / alpha ping-pong
+    long z_cap = 0; double *yT_alt = nullptr, *alpha_alt = nullptr; int vec_alt_np = 0;
+    std::vector<double> sf2_host, noise_host;    // host copies of sf2 / noise (filled on first use after set_data)
+    // up to SR_FACT_SLOTS outputs are factorised at once as a BATCH (every launch covers all of them).  Streams:
+    // CRITICAL (diagonal blocks, panel rows, look-ahead rows, late inversion), BULK (the trailing update behind the
+    // look-ahead rows) and INVERSION (the early part of the triangular inversion); the caller's stream waits for them
+    hipStream_t fact_stream = nullptr, bulk_stream = nullptr, inv_stream = nullptr;
+    hipEvent_t fact_fork = nullptr, fact_join = nullptr;
+    hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_bulk[2] = {nullptr, nullptr};
+    hipEvent_t ev_inv[2] = {nullptr, nullptr};            // critical -> inversion stream, back
+    int fact_panel = 0;                                  // blocks per Cholesky panel; 0 = by size
+    int fact_regime = 0;                                 // how the streams below were made: 0 none, else 1000 x (1 chain-bound, 2 GEMM-bound) + reserved CUs
+    int ncu = 0;                                         // compute units of the device (cached)
+    // job lists of the level-batched triangular inversion (depend on Np only)
+    int* fact_info = nullptr;                            // status words of the factorisation (64 ints)
+    size_t mem_total = 0;                                // device memory (cached)
+    sr_gemm_job* inv_jobs = nullptr; int inv_jobs_np = 0;
+    struct inv_level { int off1, off2, count, maxM, maxN; long tiles; int depth, n_left; long tiles_left; };   // jobs of the root's left subtree first
+    std::vector<inv_level> inv_levels;
+    sr_prof prof;
+};
+#define SR_FACT_PAR_BYTES ((size_t)8 << 30)
+#define SR_FACT_RESERVED_CUS 32     // CU-mask bits the bulk streams of the factorisation leave out (1 CU per shader engine)
+
+// every entry point runs on the handle's device and leaves the caller's current device as it found it
+// (PyTorch reads its current device from the HIP runtime)
+struct sr_dev_guard {
+    int prev = -1; hipError_t err = hipSuccess;
+    explicit sr_dev_guard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~sr_dev_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define SR_DEVICE(dev) sr_dev_guard dev_guard_(dev); SR_HIP(dev_guard_.err)
+
+namespace srh {
+
+static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
+
+// device memory through the block cache (sr_capi_handle.hip)
+int dev_alloc_bytes(void** p, size_t bytes);
+template <typename T>
+static inline int dev_alloc(T** p, size_t count) { return dev_alloc_bytes((void**)p, count * sizeof(T)); }
+void dev_free(void* p);
+int dev_zero(void* p, size_t bytes);
+void free_ws(sr_gp* h);
+int ensure_wt(sr_gp* h);
+
+// posterior pass and its workspace (sr_capi_posterior.hip)
+int pick_nsplit(const sr_gp* h, long Tp);
+int ensure_ws(sr_gp* h, long Tp, int nsplit);
+int prepare_ws(sr_gp* h, long Tc);
+struct sr_ws_lock {
+    sr_gp* h;
+    explicit sr_ws_lock(sr_gp* h_) : h(h_) { h->ws_locked = 1; }
+    ~sr_ws_lock() { h->ws_locked = 0; }
+};
+int gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb,
+            int nb, double* mu, double* var, double* jac, hipStream_t s);
+int gp_pass_states(sr_gp* h, long Tc, const double* p, long ldp, int n_s, const double* kff, long ldkff, int n_u,
+                   double* mu, double* var, const double** jac_out, hipStream_t s);
+
+}  // namespace srh

@@ -132,3 +132,78 @@ def test_bench_two_ranks_c5_on_one_gpu(lib_built, tmp_path):
     np.testing.assert_allclose(d1["q_sum"], q1.sum(0), rtol=1e-10)
     d0 = np.load(os.path.join(str(tmp_path), "shard_rank0.npz"))
     assert int(d0["query_seed"]) == -1 and not np.array_equal(d0["p_head"], d1["p_head"])
+
+
+def test_bench_eight_ranks_c5_on_one_gpu(lib_built, tmp_path):
+    """Rehearsal of BASELINE config 5 as the driver's 8-GPU lease will launch it -- ``bench.py --gpus 8 --workload c5`` --
+    on the ONE device of this box: eight self-spawned ranks (gloo rendezvous, SR_SHARE_DEVICE: every replica of the
+    N = 5000 model and its 65536-query workspace on cuda:0, about 46 GB in all), one step of 65536 queries per rank.
+    Checks what only a world of 8 exercises: the piece schedule of the packed-triangle replication with seven
+    receivers, the port / spawn logic, the max-over-ranks timing and the LAST rank's shard against a single-process
+    evaluation of the same rows on a model factorised here."""
+    T, world = 65536, 8
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < 60e9:
+        pytest.skip("needs ~46 GB of free device memory for eight replicas")
+    line = _run_bench(["--gpus", str(world), "--workload", "c5", "--queries", str(T), "--steps", "1", "--warmup", "1",
+                       "--dump-shards", str(tmp_path)],
+                      {"SR_DIST_BACKEND": "gloo", "SR_SHARE_DEVICE": "1"}, timeout=2400)
+    assert line["n_gpus"] == world and line["steps"] == 1 and line["scaling"] == "weak"
+    par = line["config"]["parallelism"]
+    assert "gloo" in par and "world=8" in par and "all ranks on cuda:0" in par and "query-shard x8" in par
+    N, n_out = 5000, 2
+    packed = n_out * N * (N + 1) // 2 * 8
+    from safe_exploration_amd import parallel
+    assert line["config"]["broadcast_pieces"] == n_out * len(parallel.packed_pieces(N))
+    assert line["config"]["broadcast_bytes"] == packed + (N * 3 + N * n_out + n_out * N) * 8
+    assert line["config"]["broadcast_dense_factor_bytes"] == n_out * 5120 * 5120 * 8
+    assert line["config"]["broadcast_s"] > 0 and line["config"]["broadcast_GBps"] > 0
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert abs(line["value"] - world * T / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
+    # every rank wrote its shard; all seeds differ; the last rank's rows equal a single-process evaluation
+    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload
+    shards = [np.load(os.path.join(str(tmp_path), "shard_rank%d.npz" % r)) for r in range(world)]
+    assert [int(d["rank"]) for d in shards] == list(range(world)) and all(int(d["world"]) == world for d in shards)
+    assert len({int(d["query_seed"]) for d in shards}) == world
+    d7 = shards[world - 1]
+    prob = workload.make_problem(5, N, 2, 1, 16)
+    gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob))
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+    q = workload.make_queries(int(d7["query_seed"]), 2, 1, T)
+    l = np.array([0.05, 0.02])
+    head = d7["p_head"].shape[0]
+    p1, q1 = reach.onestep_reachability_batch(q["p"], gp, q["k_ff"], l, l, q["Q"], q["k_fb"], 2.0,
+                                              np.eye(2), np.zeros((2, 1)))
+    np.testing.assert_allclose(d7["p_head"], p1[:head], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(d7["q_head"], q1[:head], rtol=1e-12, atol=1e-16)
+    np.testing.assert_allclose(d7["p_sum"], p1.sum(0), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(d7["q_sum"], q1.sum(0), rtol=1e-10)
+
+
+def test_bench_eight_ranks_under_torchrun_default_workload(lib_built, tmp_path):
+    """The command line the driver's scaling run uses -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`` with the DEFAULT workload (c2p,
+    the headline) -- with the eight ranks sharing cuda:0 over gloo.  bench.py must take RANK / LOCAL_RANK / WORLD_SIZE
+    from the environment (no second spawn), and exactly one JSON line must come out."""
+    import json
+    import subprocess
+    import sys
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < 60e9:
+        pytest.skip("needs ~46 GB of free device memory for eight replicas")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SR_DIST_BACKEND="gloo", SR_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2",
+           "--warmup", "1", "--dump-shards", str(tmp_path)]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0, "torchrun bench failed:\n%s\n%s" % (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["metric"].startswith("one-step reachability evals/sec") and line["config"]["N"] == 5000
+    assert line["config"]["queries_per_gpu_per_step"] == 65536 and "world=8" in line["config"]["parallelism"]
+    assert abs(line["value"] - 8 * 65536 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert sorted(os.listdir(str(tmp_path))) == ["shard_rank%d.npz" % r for r in range(8)]

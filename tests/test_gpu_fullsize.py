@@ -159,6 +159,7 @@ def _nccl_worker(rank, world, port, ret):
             ret["dp"] = float(np.abs(full_p - rp).max())
             ret["dq"] = float(np.abs(full_q - rq).max() / np.abs(rq).max())
             ret["backend"] = dist.get_backend()
+            ret["world"] = dist.get_world_size()
         else:
             # the receiver holds a complete model: a later append works on consistent targets / noise
             gp.update_model(prob["Z"][:3] + 0.01, prob["Y"][:3], opt_hyp=False, replace_old=False, noise_diag=2e-5)
@@ -168,17 +169,20 @@ def _nccl_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_over_rccl():
-    """rank 0 factorises on cuda:0, rank 1 adopts the model over backend "nccl" (RCCL) on cuda:1; the sharded
-    one-step result equals the single-process one."""
+def test_ranks_over_rccl():
+    """One rank per visible GPU (at most 8) over backend "nccl" (RCCL): rank 0 factorises on cuda:0, the others adopt
+    the model through the packed-triangle broadcast on their own device; the sharded one-step result equals the
+    single-process one.  Skipped on a one-GPU box (RCCL refuses two ranks on one device; the same code path runs
+    there over gloo: tests/test_gpu_distributed.py)."""
     import torch
     import torch.multiprocessing as mp
-    if torch.cuda.device_count() < 2:
+    world = min(torch.cuda.device_count(), 8)
+    if world < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_nccl_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
-        assert ret["backend"] == "nccl"
+        mp.spawn(_nccl_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+        assert ret["backend"] == "nccl" and ret["world"] == world
         assert ret["dp"] < 1e-13 and ret["dq"] < 1e-12
 
 
