@@ -26,14 +26,27 @@ def is_tensor(x):
     return isinstance(x, torch.Tensor)
 
 
+def _retry_after_release(fn):
+    """Run ``fn``; if torch runs out of device memory, hand the blocks libsafereach keeps for re-use back to the driver
+    (sr_release_cached_memory: torch's allocator cannot reclaim them) and try once more."""
+    try:
+        return fn()
+    except torch.cuda.OutOfMemoryError:
+        from . import _lib
+        _lib.lib.sr_release_cached_memory()
+        torch.cuda.empty_cache()
+        return fn()
+
+
 def as_dev(x, device, shape=None):
     """float64, contiguous tensor on `device` (no copy when it already is one)."""
     if x is None:
         return None
     if isinstance(x, torch.Tensor):
-        t = x.to(device=device, dtype=torch.float64)
+        t = _retry_after_release(lambda: x.to(device=device, dtype=torch.float64))
     else:
-        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64))).to(device)
+        h = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
+        t = _retry_after_release(lambda: h.to(device))
     if shape is not None:
         t = t.reshape(shape)
     return t.contiguous()
@@ -59,7 +72,7 @@ def const_dev(x, device, shape):
 
 
 def empty(shape, device):
-    return torch.empty(shape, dtype=torch.float64, device=device)
+    return _retry_after_release(lambda: torch.empty(shape, dtype=torch.float64, device=device))
 
 
 def zeros_i32(n, device):

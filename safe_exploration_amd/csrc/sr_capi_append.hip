@@ -146,7 +146,9 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
 #undef SR_AH
     int bad = 0;
     for (int d = 0; d < n_out; ++d) {
-        if (info_h[d] > 0) info_h[d] = N0 + std::max(1, info_h[d] - pf);
+        // the corner kernel reports the pivot inside its front-padded 128-block; the one-launch append reports the
+        // training index (N0 + 1) itself
+        if (info_h[d] > 0 && !fused1) info_h[d] = N0 + std::max(1, info_h[d] - pf);
         if (info) info[d] = info_h[d];
         if (info_h[d] != 0 && !bad) bad = d + 1;
     }

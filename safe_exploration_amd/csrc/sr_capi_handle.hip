@@ -19,17 +19,20 @@ void sr_set_error(const char* fmt, ...) {
 // refit) used to take its big buffers from hipMalloc every time -- and the first touch of a fresh allocation is what
 // costs: zeroing 1.7 GB of new memory took 24 ms, a refit after a change of N 48 ms against 5.7 ms in place.  Blocks of
 // >= 1 MB are therefore rounded up to a size class (steps of 1/8 of the power of two below the size: <= 12.5 % over) and
-// on release kept for the next request of their class (<= an eighth of device memory in all, oldest out first).  The
-// contents of a block are unspecified, as hipMalloc's are: every buffer that must start from zeros is zeroed by its owner,
-// and the whole GPU suite passes with new buffers filled with NaN patterns (SR_GUARD=1 SR_POISON=1).
-// sr_release_cached_memory() hands everything back to the driver; so does a failed hipMalloc,
-// once, before it is reported.
+// on release kept for the next request of their class.  Bounds (PyTorch's caching allocator shares the device and cannot
+// reclaim what sits here): per DEVICE at most min(1/8 of its memory, 8 GB) -- SR_BLOCK_CACHE_MB overrides, 0 switches the
+// cache off --, oldest out first; a block larger than half the cap, or one that fell back to an exact (non-class) size
+// because memory was short, goes straight back to the driver.  The contents of a block are unspecified, as hipMalloc's
+// are: every buffer that must start from zeros is zeroed by its owner, and the whole GPU suite passes with new buffers
+// filled with NaN patterns (SR_GUARD=1 SR_POISON=1).  sr_release_cached_memory() hands everything back to the driver
+// (the Python layer calls it when a torch allocation fails, and retries); so does a failed hipMalloc in here, once,
+// before it is reported.
 struct sr_block { void* p; size_t bytes; int device; unsigned long long stamp; };
 struct sr_block_cache {
     std::mutex m;
     std::vector<sr_block> idle;                    // cached blocks
     std::vector<sr_block> live;                    // big blocks handed out (p -> class size)
-    size_t idle_bytes = 0, cap_bytes = 0;
+    size_t idle_bytes[32] = {0}, cap_bytes[32] = {0};     // per device
     unsigned long long clock = 0;
 };
 static sr_block_cache g_blocks;
@@ -41,14 +44,20 @@ static size_t sr_size_class(size_t bytes) {
     const size_t step = pw / 8;
     return (bytes + step - 1) / step * step;
 }
-static void sr_cache_drop_locked(size_t keep_bytes) {                  // oldest first until at most keep_bytes stay
-    while (g_blocks.idle_bytes > keep_bytes && !g_blocks.idle.empty()) {
-        size_t o = 0;
-        for (size_t i = 1; i < g_blocks.idle.size(); ++i)
-            if (g_blocks.idle[i].stamp < g_blocks.idle[o].stamp) o = i;
+// oldest first until at most keep_bytes stay on `device` (device < 0: on every device)
+static void sr_cache_drop_locked(int device, size_t keep_bytes) {
+    for (;;) {
+        size_t o = g_blocks.idle.size();
+        for (size_t i = 0; i < g_blocks.idle.size(); ++i) {
+            const sr_block& c = g_blocks.idle[i];
+            if (device >= 0 && c.device != device) continue;
+            if (g_blocks.idle_bytes[c.device & 31] <= keep_bytes) continue;
+            if (o == g_blocks.idle.size() || c.stamp < g_blocks.idle[o].stamp) o = i;
+        }
+        if (o == g_blocks.idle.size()) return;
         const sr_block b = g_blocks.idle[o];
         g_blocks.idle.erase(g_blocks.idle.begin() + o);
-        g_blocks.idle_bytes -= b.bytes;
+        g_blocks.idle_bytes[b.device & 31] -= b.bytes;
         sr_dev_guard guard(b.device);
         (void)hipFree(b.p);
     }
@@ -84,7 +93,7 @@ int srh::dev_alloc_bytes(void** p, size_t bytes) {
         if (g_blocks.idle[i].device == device && g_blocks.idle[i].bytes == cls) {
             sr_block b = g_blocks.idle[i];
             g_blocks.idle.erase(g_blocks.idle.begin() + i);
-            g_blocks.idle_bytes -= b.bytes;
+            g_blocks.idle_bytes[device & 31] -= b.bytes;
             g_blocks.live.push_back(b);
             *p = b.p;
             return SR_OK;
@@ -93,7 +102,7 @@ int srh::dev_alloc_bytes(void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, cls);
     if (e != hipSuccess) {                           // out of memory: everything cached goes back first, then the exact size
         (void)hipGetLastError();
-        sr_cache_drop_locked(0);
+        sr_cache_drop_locked(-1, 0);
         e = hipMalloc(p, cls);
         if (e != hipSuccess) { (void)hipGetLastError(); got = bytes; e = hipMalloc(p, bytes); }
         if (e != hipSuccess) {
@@ -120,18 +129,29 @@ void srh::dev_free(void* p) {
         if (g_blocks.live[i].p == p) {
             sr_block b = g_blocks.live[i];
             g_blocks.live.erase(g_blocks.live.begin() + i);
-            if (g_blocks.cap_bytes == 0) {
+            size_t& cap = g_blocks.cap_bytes[b.device & 31];
+            if (cap == 0) {
                 size_t mem_free = 0, mem_total = 0;
+                sr_dev_guard guard(b.device);
                 (void)hipMemGetInfo(&mem_free, &mem_total);
-                g_blocks.cap_bytes = mem_total / 8;
+                const char* env = getenv("SR_BLOCK_CACHE_MB");
+                cap = env ? ((size_t)atol(env) << 20) + 1 : std::min(mem_total / 8, (size_t)8 << 30);   // (+ 1: "asked" marker)
             }
             static const bool no_cache = getenv("SR_NO_BLOCK_CACHE") != nullptr;      // diagnostics: every release goes to the driver
-            if (b.bytes > g_blocks.cap_bytes / 2 || no_cache) { (void)hipFree(p); return; }
-            (void)hipDeviceSynchronize();              // what hipFree implied: nothing in flight still uses the block
+            // (a block that fell back to its exact size when memory was short would never match a request again)
+            if (b.bytes > cap / 2 || b.bytes != sr_size_class(b.bytes) || no_cache) {
+                sr_dev_guard guard(b.device);
+                (void)hipFree(p);
+                return;
+            }
+            {
+                sr_dev_guard guard(b.device);
+                (void)hipDeviceSynchronize();          // what hipFree implied: nothing in flight still uses the block
+            }
             b.stamp = ++g_blocks.clock;
             g_blocks.idle.push_back(b);
-            g_blocks.idle_bytes += b.bytes;
-            sr_cache_drop_locked(g_blocks.cap_bytes);
+            g_blocks.idle_bytes[b.device & 31] += b.bytes;
+            sr_cache_drop_locked(b.device, cap);
             return;
         }
     for (const sr_block& b : g_blocks.idle)
@@ -140,7 +160,7 @@ void srh::dev_free(void* p) {
 }
 extern "C" int sr_release_cached_memory(void) {
     std::lock_guard<std::mutex> lk(g_blocks.m);
-    sr_cache_drop_locked(0);
+    sr_cache_drop_locked(-1, 0);
     return SR_OK;
 }
 // Zero a freshly allocated buffer and WAIT: a memset on the null stream is not ordered with the launches that follow on a

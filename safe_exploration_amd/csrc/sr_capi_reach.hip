@@ -148,7 +148,7 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
         chain_launches <= chain_max_launches &&
         sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {
         // the kernel must be able to run at all: at least one workgroup per CU (registers, static + dynamic LDS)
-        const int occ_key = ((h->Np * 8 + n_s) * 8 + n_u) * 64 + std::min(H, 63);
+        const int occ_key = ((h->Np * 8 + n_s) * 8 + n_u) * 128 + std::min(H, 127);      // (H sizes the dynamic LDS; sr_chain_supported bounds it at 96)
         if (h->chain_occ_key != occ_key) {
             h->chain_occ_blocks = 0;
             SR_TRY(sr_chain_blocks_per_cu(h->Np, n_s, n_u, H, &h->chain_occ_blocks));
@@ -156,17 +156,37 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
         }
         if (h->chain_occ_blocks < 1) return SR_OK;                       // per-step launches
         if (!h->chain_xch) {
-            SR_HIP(hipHostMalloc((void**)&h->chain_status_host, sizeof(int), hipHostMallocMapped));
-            *h->chain_status_host = 0;
-            SR_HIP(hipHostGetDevicePointer((void**)&h->chain_status_dev, h->chain_status_host, 0));
-            SR_TRY(dev_alloc(&h->chain_xch, (size_t)SR_CHAIN_XELS));
-            SR_TRY(dev_alloc(&h->chain_tickets, (size_t)2 * SR_CHAIN_GROUPS));
-            SR_TRY(dev_alloc(&h->chain_done, (size_t)SR_CHAIN_GROUPS));
+            // all or nothing: the pointers are committed to the handle only once every allocation and memset is in place
+            // (a launch with one of them missing would run on NULL epoch / alive / done words)
+            int* st_host = h->chain_status_host; int* st_dev = h->chain_status_dev;
+            sr_xel* xch = nullptr; unsigned long long* tickets = nullptr; unsigned* done = nullptr;
+            int rc = SR_OK;
+            hipError_t he = hipSuccess;
+            if (!st_host) {
+                he = hipHostMalloc((void**)&st_host, sizeof(int), hipHostMallocMapped);
+                if (he == hipSuccess) { *st_host = 0; he = hipHostGetDevicePointer((void**)&st_dev, st_host, 0); }
+            }
+            if (he == hipSuccess) rc = dev_alloc(&xch, (size_t)SR_CHAIN_XELS);
+            if (he == hipSuccess && rc == SR_OK) rc = dev_alloc(&tickets, (size_t)2 * SR_CHAIN_GROUPS);
+            if (he == hipSuccess && rc == SR_OK) rc = dev_alloc(&done, (size_t)SR_CHAIN_GROUPS);
             // ON THE CALLER'S STREAM: a memset on the null stream is not ordered with a launch on a non-blocking stream --
             // it wiped tags the first launch had already written (41 MB take 20 us) and that launch timed out
-            SR_HIP(hipMemsetAsync(h->chain_xch, 0, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS, s));     // tag 0 = never written
-            SR_HIP(hipMemsetAsync(h->chain_tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS, s));
-            SR_HIP(hipMemsetAsync(h->chain_done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS, s));
+            if (he == hipSuccess && rc == SR_OK) he = hipMemsetAsync(xch, 0, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS, s);     // tag 0 = never written
+            if (he == hipSuccess && rc == SR_OK) he = hipMemsetAsync(tickets, 0, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS, s);
+            if (he == hipSuccess && rc == SR_OK) he = hipMemsetAsync(done, 0, sizeof(unsigned) * SR_CHAIN_GROUPS, s);
+            if (he != hipSuccess || rc != SR_OK) {
+                if (he != hipSuccess) {
+                    (void)hipStreamSynchronize(s);
+                    sr_set_error("persistent chain: setting up the exchange buffers -> %s", hipGetErrorString(he));
+                    (void)hipGetLastError();
+                    rc = SR_EHIP;
+                }
+                dev_free(xch); dev_free(tickets); dev_free(done);
+                if (st_host && !h->chain_status_host) (void)hipHostFree(st_host);
+                return rc;
+            }
+            h->chain_status_host = st_host; h->chain_status_dev = st_dev;
+            h->chain_xch = xch; h->chain_tickets = tickets; h->chain_done = done;
         }
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         for (long t0 = 0; t0 < T; t0 += (long)gmax * SR_SMALL_T) {

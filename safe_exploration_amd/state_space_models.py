@@ -21,6 +21,16 @@ def _dense(x):
     return a.reshape(-1, 1) if a.ndim < 2 else a
 
 
+def _casadi_version(cas):
+    """(major, minor) of the casadi module; (3, 5) when it does not say (the API generation of the reference:
+    ``jacobian_old``, one stacked Jacobian output per callback)."""
+    try:
+        parts = str(getattr(cas, "__version__", "3.5")).split(".")
+        return int(parts[0]), int("".join(ch for ch in parts[1] if ch.isdigit()) or 0)
+    except Exception:
+        return 3, 5
+
+
 def _evaluator_class(cas):
     """``CasadiSSMEvaluator`` on top of the given casadi module (cached per module)."""
     cached = _EVALUATOR_CACHE.get(id(cas))
@@ -90,13 +100,15 @@ def _evaluator_class(cas):
                 raise ValueError("Need to specify either has_jacobian or has_reverse")
             self.ssm = ssm
             self.linearize_mu = linearize_mu
-            # Row order of the d jac_mean/dz block of the stacked Jacobian.  "C" (default) is the reference's own
-            # convention, utils.reshape_derivatives_3d_to_2d (utils.py:357-380): row i*D + j <-> jac_mean[i, j].
-            # CasADi numbers the nonzeros of a dense output column by column, so an NLP whose objective depends
-            # on jac_mean through this Jacobian (rather than through get_reverse, whose seed arrives as a matrix
-            # and is unaffected) may want "F": row j*n + i <-> jac_mean[i, j].  The reference's only test of the
-            # block sums over it (test_state_space_models.py:103-139) and cannot tell the two apart.
-            self.jac_mu_order = "C"
+            # Row order of the d jac_mean/dz block of the stacked Jacobian.  CasADi numbers the entries of a dense
+            # matrix output column by column (its ``vec``), and the full Jacobian it asks a callback for has one row
+            # per such entry: row j*n + i <-> jac_mean[i, j] -- "F", the default here.  The reference states the same
+            # intent ("The reshaping rule has to follow the casadi rule", utils.py:357-380) but its helper flattens
+            # row-major (row i*D + j <-> jac_mean[i, j], "C"); its only test of the block sums over all entries
+            # (test_state_space_models.py:263-286) and cannot tell the two apart.  "C" reproduces the reference's
+            # rows exactly.  The reverse callback is unaffected (its seed arrives as an n x D matrix).
+            # tests/test_casadi_real.py settles it against IPOPT's derivative checker wherever casadi is installed.
+            self.jac_mu_order = "F"
             self.construct("CasadiModelEvaluator", opts)
 
         def get_n_in(self):
@@ -125,16 +137,43 @@ def _evaluator_class(cas):
             n, D = self.ssm.num_states, self.ssm.num_states + self.ssm.num_actions
             if self.linearize_mu:
                 _, _, jac_mu, jac_sigma, hess_mu = self.ssm.linearize_predict(state.T, action.T, True, False)
-                # (n, D, D) -> (n D, D): row i*D + j holds d jac_mu[i, j] / dz (utils.py:357-380); see jac_mu_order
+                # (n, D, D) -> (n D, D): "C": row i*D + j holds d jac_mu[i, j] / dz (utils.py:357-380), "F": row j*n + i
                 if self.jac_mu_order == "F":
                     hess_mu = np.transpose(np.reshape(hess_mu, (n, D, D)), (1, 0, 2))
                 return [np.vstack((jac_mu, jac_sigma, np.reshape(hess_mu, (n * D, D))))]
             _, _, jac_mu, jac_sigma = self.ssm.predict(state.T, action.T, True, False)
             return [np.vstack((np.reshape(jac_mu, (n, D)), np.reshape(jac_sigma, (n, D))))]
 
+        def _eval_jacobian_blocks(self, arg):
+            # CasADi >= 3.6: one block per (output, input) pair, output-major: d out_o / d in_i of shape
+            # numel(out_o) x numel(in_i), rows in CasADi's vec (column-major) order of out_o
+            (stacked,) = self._eval_jacobian_order(arg, "F")
+            n, m = self.ssm.num_states, self.ssm.num_actions
+            bounds = [0, n, 2 * n] + ([2 * n + n * (n + m)] if self.linearize_mu else [])
+            blocks = []
+            for o in range(len(bounds) - 1):
+                rows = stacked[bounds[o]:bounds[o + 1]]
+                blocks += [np.ascontiguousarray(rows[:, :n]), np.ascontiguousarray(rows[:, n:])]
+            return blocks
+
+        def _eval_jacobian_order(self, arg, order):
+            keep, self.jac_mu_order = self.jac_mu_order, order
+            try:
+                return self._eval_jacobian(arg)
+            finally:
+                self.jac_mu_order = keep
+
         def get_jacobian(self, name, inames, onames, opts):
-            n, D = self.ssm.num_states, self.ssm.num_states + self.ssm.num_actions
+            n, m = self.ssm.num_states, self.ssm.num_actions
+            D = n + m
             rows = 2 * n + (n * D if self.linearize_mu else 0)
+            if _casadi_version(cas) >= (3, 6):
+                # (the 3.6 API change: Function.jacobian() delivers the blocks jac_<out>_<in> instead of one matrix)
+                sizes = [n, n] + ([n * D] if self.linearize_mu else [])
+                sp_out = [cas.Sparsity.dense(r, c) for r in sizes for c in (n, m)]
+                self.jac_callback = _Derivative(name, self.ssm, dense_in(self.ssm, self.linearize_mu, True, False),
+                                                sp_out, self._eval_jacobian_blocks, opts)
+                return self.jac_callback
             self.jac_callback = _Derivative(name, self.ssm, dense_in(self.ssm, self.linearize_mu, True, False),
                                             [cas.Sparsity.dense(rows, D)], self._eval_jacobian, opts)
             return self.jac_callback

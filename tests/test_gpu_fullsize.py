@@ -217,6 +217,8 @@ def test_casadi_evaluator_callbacks_on_the_hip_model(kt, N, n_s, n_u, monkeypatc
     np.testing.assert_allclose(mu[:, 0], rmu[0], rtol=1e-9, atol=1e-11 * scale)
     np.testing.assert_allclose(var[:, 0], rvar[0], rtol=0, atol=1e-8 * max(1.0, float(rvar.max())))
     np.testing.assert_allclose(jac, rjm, rtol=1e-9, atol=1e-11 * scale)
+    assert ev.jac_mu_order == "F"                 # CasADi's vec rule is the default; "C" = the reference helper's rows
+    ev.jac_mu_order = "C"
     jfun = ev.get_jacobian("jac_CasadiModelEvaluator", [], [], {})
     (stacked,) = (np.array(o) for o in jfun(x, u, mu, var, jac))
     assert stacked.shape == (2 * n_s + n_s * D, D)

@@ -286,6 +286,13 @@ def _drive_evaluator(ev, ssm_cls, has_reverse):
     np.testing.assert_allclose(jac, ref[2])
     jfun = ev.get_jacobian("jac", [], [], {})
     assert jfun.get_n_in() == 5 and jfun.get_n_out() == 1 and jfun.get_sparsity_out(0) == (2 * 2 + 2 * 3, 3)
+    if hasattr(ev, "jac_mu_order"):
+        # this package's evaluator numbers the d jac_mean / dz rows by CasADi's vec rule (column-major) by default;
+        # "C" gives the rows of the reference's helper (utils.py:357-380), which the comparisons below use
+        assert ev.jac_mu_order == "F"
+        (stacked_f,) = jfun.eval([x, u, mu, var, jac])
+        np.testing.assert_allclose(np.array(stacked_f)[4:], np.transpose(ref[4], (1, 0, 2)).reshape(6, 3))
+        ev.jac_mu_order = "C"
     (stacked,) = jfun.eval([x, u, mu, var, jac])
     stacked = np.array(stacked)
     assert stacked.shape == (2 * 2 + 2 * 3, 3)                 # [jac_mu; jac_var; d jac_mu / dz]
@@ -356,6 +363,7 @@ def test_reference_casadi_evaluator_runs_on_this_surface(monkeypatch):
     ev = RefEvaluator(ssm, True, ssm.has_jacobian, ssm.has_reverse)
     bfun, stacked, (x, u, mu, var, jac) = _drive_evaluator(ev, Linear, True)
     mine = ssm.get_forward_model_casadi(True)
+    mine.jac_mu_order = "C"                      # the reference helper's row order
     (stacked_mine,) = mine.get_jacobian("jac", [], [], {}).eval([x, u, mu, var, jac])
     np.testing.assert_array_equal(stacked, np.array(stacked_mine))
     # reverse: the reference flattens the jac_mean seed with casadi's column-major reshape (:555-556) while its own
