@@ -243,6 +243,12 @@ bool sr_var64_wanted(int Np, long Tp, int n_out);
 int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                     hipStream_t s);
 
+// XCD-partitioned form of the same regime (sr_var_xcd.hip, K2x): k slabs per XCD, one workgroup per CU, four LDS stages
+#define SR_VAR_XCD_MIN_CELLS 512     /* (row block, k-block, query tile, output) cells from which K2x is taken */
+bool sr_var_xcd_wanted(int N, int Np, long Tp, int n_out);
+long sr_var_xcd_ws(int Np, long Tp, int n_out);
+int sr_launch_var_xcd(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
+                      hipStream_t s);
 // split-K form of the variance kernel for few query tiles (sr_predict.hip, K2k)
 // balanced form of the same regime (equal shares of the k-blocks + a reduce pass, K2b): workspace doubles; part layout of K2k
 bool sr_var_bal_wanted(int Np, long Tp, int n_out);

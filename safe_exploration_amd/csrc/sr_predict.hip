@@ -616,13 +616,16 @@ __global__ __launch_bounds__(256, 2) void sr_var_bal_kernel(const double* __rest
         srt::mainloop_tn_glds<16>(A, Np, B, Tp, k0, k1, smem, acc);
         if (len != n) {
             // slot of a segment: its workgroup's slot 1 if the tile starts in that workgroup's share, else 0
-            double* slot = Vt + ((g * 2) + (o == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN);
+            // (16-byte stores: the 128 KB of a partial product are store-issue bound -- half the instructions of the
+            //  8-byte form; element (mi, ni, half h) of lane tid at ((mi 4 + ni) 2 + h) 256 + tid double2's)
+            double2* slot = reinterpret_cast<double2*>(Vt + ((g * 2) + (o == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN));
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) slot[((mi * 4 + ni) * 4 + q) * 256 + tid] = acc.v[mi][ni][q];
+                    for (int hh = 0; hh < 2; ++hh)
+                        slot[((mi * 4 + ni) * 2 + hh) * 256 + tid] = double2{acc.v[mi][ni][2 * hh], acc.v[mi][ni][2 * hh + 1]};
         } else {                                               // the whole tile was ours
             double sq[4];
 #pragma unroll
@@ -665,29 +668,31 @@ __global__ __launch_bounds__(256) void sr_var_bal_reduce_kernel(const double* __
     if (g_first == g_last) return;                             // one segment: finished by its workgroup
     const int nseg = (int)(g_last - g_first + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    double v[16];
+    double2 v[8];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = 0.0;
+    for (int e = 0; e < 8; ++e) v[e] = double2{0.0, 0.0};
     // four segments' loads in flight (a heavy tile has 7 - 13 segments: one dependent round trip each cost 18 us at N = 5000)
     for (int sg0 = 0; sg0 < nseg; sg0 += 4) {
-        double w[4][16];
+        double2 w[4][8];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int sg = sg0 + b;
-            const double* src = Vt + (((g_first + sg) * 2) + (sg == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN) + (long)(mi * 16) * 256 + tid;
+            const double2* src = reinterpret_cast<const double2*>(Vt + (((g_first + sg) * 2) + (sg == 0 ? 1 : 0)) * (long)(srt::BM * srt::BN)) + (long)(mi * 8) * 256 + tid;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) w[b][e] = (sg < nseg) ? src[e * 256] : 0.0;
+            for (int e = 0; e < 8; ++e) w[b][e] = (sg < nseg) ? src[e * 256] : double2{0.0, 0.0};
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] += w[b][e];
+            for (int e = 0; e < 8; ++e) { v[e].x += w[b][e].x; v[e].y += w[b][e].y; }
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         double q = 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) q = fma(v[ni * 4 + r], v[ni * 4 + r], q);
+        q = fma(v[ni * 2].x, v[ni * 2].x, q);
+        q = fma(v[ni * 2].y, v[ni * 2].y, q);
+        q = fma(v[ni * 2 + 1].x, v[ni * 2 + 1].x, q);
+        q = fma(v[ni * 2 + 1].y, v[ni * 2 + 1].y, q);
         q += __shfl_xor(q, 16);
         q += __shfl_xor(q, 32);
         if (lane < 16) red[wm * 128 + wn * 64 + ni * 16 + lane] = q;
