@@ -300,6 +300,23 @@ int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, do
  * linearize_predict(jacobians=True) as CasadiSSMEvaluator drives them (state_space_models.py:271-303, 384-417). */
 int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, double* out_host,
                 unsigned long long* flag_host, unsigned long long seq, void* stream);
+/* Resident single-query server: the latency path of the MPC loop -- CasadiSSMEvaluator.eval / JacFun.eval
+ * (state_space_models.py:278-303, 384-417) call SimpleGPModel.__call__ / linearize_predict(jacobians=True)
+ * (ssm_gpy/gaussian_process.py:135-144) once per IPOPT iteration and block.  sr_gp_server_start launches one workgroup per
+ * output that STAYS on the device and polls a mailbox in pinned host memory; sr_gp_server_call posts the query x_host
+ * (D doubles, any host memory), waits for the answer and copies it to out_host (any host memory):
+ *   [mu n | var n | jac_mu n x D]                              second_order == 0
+ *   [... | jac_var n x D | hess_mu n x D x D]                  second_order != 0
+ * No launch, copy command or completion interrupt per query: one PCIe read to see the request, one posted write to
+ * answer it.  The kernel leaves after idle_timeout_s without a request (a hipDeviceSynchronize elsewhere in the process
+ * waits at most that long) and sr_gp_server_call launches it again; every entry point that writes the model takes it
+ * off the device first (it stays armed).  ARD-RBF models with a one-launch posterior (Np <= 384 with D <= 5, Np = 512 with D <= 3, no input
+ * transform); SR_EUNSUPPORTED otherwise and from sr_gp_server_call when no server is armed: use sr_gp_call1 /
+ * sr_gp_predict / sr_gp_linearize.  One host thread per handle, as everywhere. */
+int sr_gp_server_start(sr_gp_t h, double idle_timeout_s);
+int sr_gp_server_stop(sr_gp_t h);
+int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_order, double* out_host, double timeout_s);
+int sr_gp_server_state(sr_gp_t h, int* armed, int* resident, long* launches, long* calls);
 int sr_gp_last_chain(sr_gp_t h);
 /* diagnostic: C(M x N) = alpha * A^T B + beta * C with A (K x M), B (K x N) k-major; M, N multiples
  * of 128, K multiple of 16; mode 0 all tiles, 1 upper block triangle, 2 B block-lower-triangular.

@@ -81,6 +81,10 @@ SIGNATURES = {
     "sr_publish": (_I, [_I, _P, _I, _P, _P, ctypes.c_ulonglong, _P]),
     "sr_wait_flag": (_I, [_P, ctypes.c_ulonglong, ctypes.c_double]),
     "sr_gp_call1": (_I, [_H, _P, _I, _P, _P, ctypes.c_ulonglong, _P]),
+    "sr_gp_server_start": (_I, [_H, ctypes.c_double]),
+    "sr_gp_server_stop": (_I, [_H]),
+    "sr_gp_server_call": (_I, [_H, _P, _I, _P, ctypes.c_double]),
+    "sr_gp_server_state": (_I, [_H, _P, _P, _P, _P]),
     "sr_gp_last_chain": (_I, [_H]),
     "sr_gp_chain_status": (_I, [_H, _PI]),
     "sr_gp_set_small_path": (_I, [_H, _I]),

@@ -47,7 +47,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
                  o_g = o_y2 + n_out * s_y2, o_sb = o_g + n_out * BB, o_inv = o_sb + n_out * BB,
                  o_ld = o_inv + n_out * BB, o_info = o_ld + (size_t)n_out * SR_APPEND1_WGS, need = o_info + (size_t)n_out;
     if (h->app_cap < need) {
-        (void)hipDeviceSynchronize();
+        (void)device_sync();
         dev_free(h->app_ws);
         h->app_ws = nullptr; h->app_cap = 0;
         SR_TRY(dev_alloc(&h->app_ws, need));
@@ -195,6 +195,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     SR_CHECK(m >= 1 && m <= SR_NB, SR_EINVAL, "sr_gp_append: m=%d outside 1..%d (append in several calls)", m, SR_NB);
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
+    SR_TRY(server_quiesce(h));            // (it stays armed: the next single query launches it on the grown model)
     if (m <= SR_SMALL_T) return append_small(h, Znew, Ynew, m, s, info);
     // 17 .. 128 new points: the same algebra on the MFMA tile (64 x 64 workgroup tiles: the products are 128 columns wide).
     // Scratch lives with the handle, U^-1 ping-pongs between two buffers while the padded size stays, alpha is updated
@@ -211,7 +212,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
                  o_wtr = o_wdm + BB, o_part = o_wtr + NN0, o_info = o_part + (size_t)((Np0 + APP_KS - 1) / APP_KS) * PB,
                  need = o_info + (size_t)n_out;
     if (h->app_cap < need) {
-        (void)hipDeviceSynchronize();
+        (void)device_sync();
         dev_free(h->app_ws);
         h->app_ws = nullptr; h->app_cap = 0;
         SR_TRY(dev_alloc(&h->app_ws, need));

@@ -146,7 +146,7 @@ void srh::dev_free(void* p) {
             }
             {
                 sr_dev_guard guard(b.device);
-                (void)hipDeviceSynchronize();          // what hipFree implied: nothing in flight still uses the block
+                (void)device_sync();          // what hipFree implied: nothing in flight still uses the block
             }
             b.stamp = ++g_blocks.clock;
             g_blocks.idle.push_back(b);
@@ -216,7 +216,8 @@ void srh::free_ws(sr_gp* h) {
 extern "C" int sr_gp_destroy(sr_gp_t h) {
     if (!h) return SR_OK;
     sr_dev_guard guard(h->device);
-    (void)hipDeviceSynchronize();
+    server_release(h);
+    (void)device_sync();
     dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
@@ -248,6 +249,7 @@ extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const
     SR_CHECK(h && Z && Y && ls && sf2 && noise, SR_EINVAL, "sr_gp_set_data: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
+    SR_TRY(server_quiesce(h));            // the resident server reads the model: off the device before it changes
     SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->ls, ls, sizeof(double) * h->n_out * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->sf2, sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToDevice, s));
@@ -267,6 +269,7 @@ extern "C" int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* 
     SR_CHECK(h && Z && Y && kparams && noise, SR_EINVAL, "sr_gp_set_data_general: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
+    SR_TRY(server_quiesce(h));
     if (!h->kp) SR_TRY(dev_alloc(&h->kp, (size_t)h->n_out * SR_KP(h->D)));
     SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->kp, kparams, sizeof(double) * h->n_out * SR_KP(h->D), hipMemcpyDeviceToDevice, s));
@@ -326,6 +329,7 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
     SR_CHECK(alpha && Wt, SR_EINVAL, "sr_gp_import: alpha and Wt are both required");
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
+    SR_TRY(server_quiesce(h));
     SR_TRY(ensure_wt(h));
     SR_HIP(hipMemsetAsync(h->alpha, 0, sizeof(double) * h->n_out * h->Np, s));
     SR_HIP(hipMemcpy2DAsync(h->alpha + (h->Np - h->N), sizeof(double) * h->Np, alpha,
@@ -386,6 +390,7 @@ extern "C" int sr_gp_import_begin(sr_gp_t h, const double* alpha, void* stream) 
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_import_begin: call sr_gp_set_data first (Z and hyper-parameters)");
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
+    SR_TRY(server_quiesce(h));
     SR_TRY(ensure_wt(h));             // zero below the diagonal from allocation on; nothing ever writes there
     h->factorized = 0; h->logdet_valid = 0;
     h->import_open = 1;
@@ -434,7 +439,7 @@ extern "C" int sr_gp_set_var_group(sr_gp_t h, int group) {
 extern "C" int sr_gp_release_scratch(sr_gp_t h) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_release_scratch: NULL handle");
     SR_DEVICE(h->device);
-    SR_HIP(hipDeviceSynchronize());
+    SR_HIP(device_sync());
     dev_free(h->fact_ws); h->fact_ws = nullptr; h->fact_cap = 0;
     dev_free(h->Wt_alt); h->Wt_alt = nullptr; h->wt_alt_cap = 0; h->wt_alt_off = -1;
     dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;

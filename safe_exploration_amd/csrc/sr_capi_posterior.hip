@@ -32,7 +32,7 @@ int srh::ensure_ws(sr_gp* h, long Tp, int nsplit) {
              h->ws_Tp, h->ws_part, Tp, nsplit);
     const long nTp = std::max(Tp, h->ws_Tp);
     const long npart = std::max(need_part, h->ws_part);
-    (void)hipDeviceSynchronize();
+    (void)device_sync();
     free_ws(h);
     const int nrb = h->Np / SR_NB;
     int rc;
@@ -387,6 +387,7 @@ __global__ __launch_bounds__(256) void sr_tz_jac_kernel(const double* __restrict
 extern "C" int sr_gp_set_input_transform(sr_gp_t h, const double* Tz, int n_x_in, void* stream) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_input_transform: NULL handle");
     SR_DEVICE(h->device);
+    SR_TRY(server_quiesce(h));
     if (Tz == nullptr) { h->n_xin = 0; return SR_OK; }
     SR_CHECK(n_x_in >= 1 && n_x_in < h->D, SR_EINVAL, "sr_gp_set_input_transform: n_x_in=%d with D=%d", n_x_in, h->D);
     if (!h->Tz) SR_TRY(dev_alloc(&h->Tz, (size_t)SR_MAX_D * SR_MAX_NS));
@@ -398,7 +399,7 @@ extern "C" int sr_gp_set_input_transform(sr_gp_t h, const double* Tz, int n_x_in
 
 static int ensure_tz(sr_gp* h, long Tc, int n_s, int n_u) {
     if (h->n_xin == 0 || Tc <= h->tz_cap) return SR_OK;
-    (void)hipDeviceSynchronize();
+    (void)device_sync();
     dev_free(h->tz_x); dev_free(h->tz_jac);
     h->tz_x = h->tz_jac = nullptr; h->tz_cap = 0;
     SR_TRY(dev_alloc(&h->tz_x, (size_t)Tc * SR_MAX_D));

@@ -421,7 +421,7 @@ extern "C" int sr_test_chain_drop(sr_gp_t h, int drop) {
         // a launch that was short of a workgroup leaves its group's counters in a state no real launch can produce
         // (in the field every workgroup runs, however late, and the last one to leave resynchronises the group)
         SR_DEVICE(h->device);
-        SR_HIP(hipDeviceSynchronize());
+        SR_HIP(device_sync());
         SR_TRY(dev_zero(h->chain_xch, sizeof(sr_xel) * (size_t)SR_CHAIN_XELS));
         SR_TRY(dev_zero(h->chain_tickets, sizeof(unsigned long long) * 2 * SR_CHAIN_GROUPS));
         SR_TRY(dev_zero(h->chain_done, sizeof(unsigned) * SR_CHAIN_GROUPS));

@@ -1,0 +1,222 @@
+// sr_capi_server.hip -- the resident single-query server (kernel K0s, sr_small.hip): start / stop / blocking call, and the
+// hooks the other entry points use to take it off the device before they write the model or wait for the whole device.
+//
+// replaces the blocking evaluation inside CasadiSSMEvaluator.eval / JacFun.eval / BackFun.eval
+// (/root/reference/safe_exploration/state_space_models.py:278-303, 384-417, 534-562 -> SimpleGPModel.__call__ /
+// linearize_predict, ssm_gpy/gaussian_process.py:135-144) where the model has a one-launch posterior.
+#include "sr_handle.h"
+using namespace srh;
+
+namespace {
+
+std::mutex g_srv_mutex;
+std::vector<sr_gp*> g_srv_running;            // handles whose server kernel may be resident (any device)
+
+constexpr size_t MB_WORDS = 16;               // mailbox: 128 bytes (one line); reply: 2 x SR_SERVER_ALIVE words
+constexpr size_t REPLY_WORDS = 3 * SR_SERVER_ALIVE;
+
+size_t out_doubles(const sr_gp* h) { return (size_t)2 * h->n_out + (size_t)2 * h->n_out * h->D + (size_t)h->n_out * h->D * h->D; }
+
+bool servable(const sr_gp* h) {
+    return h->factorized && !h->general && h->n_xin == 0 && h->small_path == 1 && h->n_out <= SR_SERVER_ALIVE &&
+           sr_gp_server_supported(h->Np, h->D);
+}
+
+void registry_add(sr_gp* h) {
+    std::lock_guard<std::mutex> lk(g_srv_mutex);
+    if (std::find(g_srv_running.begin(), g_srv_running.end(), h) == g_srv_running.end()) g_srv_running.push_back(h);
+}
+void registry_remove(sr_gp* h) {
+    std::lock_guard<std::mutex> lk(g_srv_mutex);
+    g_srv_running.erase(std::remove(g_srv_running.begin(), g_srv_running.end(), h), g_srv_running.end());
+}
+
+// launch the kernel for the requests from first_seq on (the previous launch, if any, has left the device)
+int server_launch(sr_gp* h, unsigned long long first_seq) {
+    sr_server& sv = h->srv;
+    for (int d = 0; d < h->n_out; ++d) sv.reply[SR_SERVER_ALIVE + d] = 1ull;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    sr_kstar_args ka{};
+    ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.xa = nullptr; ka.lda = h->D; ka.na = h->D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
+    ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = 1; ka.T = 1; ka.Tp = 1;
+    sr_server_args sa{};
+    sa.mb = sv.mb_dev; sa.out = sv.out_dev; sa.reply = sv.reply_dev;
+    sa.first_seq = first_seq; sa.idle_ticks = sv.idle_ticks;
+    SR_TRY(sr_launch_gp_server(ka, h->Wt, sa, sv.stream));
+    sv.running = 1;
+    ++sv.launches;
+    registry_add(h);
+    return SR_OK;
+}
+
+bool any_left(const sr_gp* h) {
+    const volatile unsigned long long* alive = h->srv.reply + SR_SERVER_ALIVE;
+    for (int d = 0; d < h->n_out; ++d)
+        if (alive[d] == 0ull) return true;
+    return false;
+}
+
+}  // namespace
+
+// Take the server of this handle off the device (it stays armed: the next sr_gp_server_call launches it again).
+int srh::server_quiesce(sr_gp* h) {
+    sr_server& sv = h->srv;
+    if (!sv.running) return SR_OK;
+    // STOP under the next sequence number; a kernel that has already left on its idle time-out never reads it
+    sv.mb[6] = SR_SERVER_CMD_STOP;
+    std::atomic_thread_fence(std::memory_order_release);
+    *(volatile unsigned long long*)(sv.mb + 7) = sv.next_seq;
+    ++sv.next_seq;
+    sr_dev_guard guard(h->device);
+    const hipError_t e = hipStreamSynchronize(sv.stream);
+    sv.running = 0;
+    registry_remove(h);
+    SR_HIP(e);
+    return SR_OK;
+}
+
+// Before a device-wide wait (hipDeviceSynchronize inside the library): every resident server of this device leaves now
+// instead of after its idle time-out.
+void srh::servers_quiesce_device(int device) {
+    std::vector<sr_gp*> hs;
+    {
+        std::lock_guard<std::mutex> lk(g_srv_mutex);
+        for (sr_gp* h : g_srv_running)
+            if (h->device == device) hs.push_back(h);
+    }
+    for (sr_gp* h : hs) (void)server_quiesce(h);
+}
+
+void srh::server_release(sr_gp* h) {
+    (void)server_quiesce(h);
+    sr_server& sv = h->srv;
+    sv.armed = 0;
+    if (sv.stream) { (void)hipStreamDestroy(sv.stream); sv.stream = nullptr; }
+    if (sv.pinned) { (void)hipHostFree(sv.pinned); sv.pinned = nullptr; }
+    sv.mb = sv.reply = nullptr; sv.out = nullptr;
+}
+
+extern "C" int sr_gp_server_start(sr_gp_t h, double idle_timeout_s) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_server_start: NULL handle");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_server_start: model not factorized");
+    SR_CHECK(idle_timeout_s > 0.0 && idle_timeout_s <= 10.0, SR_EINVAL, "sr_gp_server_start: idle time-out %g s outside (0, 10]",
+             idle_timeout_s);
+    if (!servable(h)) {
+        sr_set_error("sr_gp_server_start: no resident server for this model (ARD-RBF, Np <= %d, D <= 5, no input transform; "
+                     "Np=%d D=%d general=%d)", SR_FUSED_NP, h->Np, h->D, h->general);
+        return SR_EUNSUPPORTED;
+    }
+    SR_DEVICE(h->device);
+    SR_TRY(server_quiesce(h));
+    sr_server& sv = h->srv;
+    const size_t bytes = (MB_WORDS + REPLY_WORDS) * sizeof(unsigned long long) + out_doubles(h) * sizeof(double);
+    if (sv.pinned && sv.pinned_bytes < bytes) { (void)hipHostFree(sv.pinned); sv.pinned = nullptr; }
+    if (!sv.pinned) {
+        void* p = nullptr;
+        // COHERENT (fine-grained): the device must read the mailbox from host memory every time it looks -- through a
+        // cacheable mapping a request became visible to the polling workgroups only after ~180 us
+        SR_HIP(hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+        void* pd = nullptr;
+        const hipError_t e = hipHostGetDevicePointer(&pd, p, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(p);
+            (void)hipGetLastError();
+            sr_set_error("sr_gp_server_start: pinned host memory is not device-visible here (%s)", hipGetErrorString(e));
+            return SR_EUNSUPPORTED;
+        }
+        memset(p, 0, bytes);
+        sv.pinned = p; sv.pinned_bytes = bytes;
+        sv.mb = (unsigned long long*)p; sv.reply = sv.mb + MB_WORDS; sv.out = (double*)(sv.reply + REPLY_WORDS);
+        sv.mb_dev = (unsigned long long*)pd; sv.reply_dev = sv.mb_dev + MB_WORDS; sv.out_dev = (double*)(sv.reply_dev + REPLY_WORDS);
+        sv.next_seq = 1;
+    }
+    if (!sv.stream) SR_HIP(hipStreamCreateWithFlags(&sv.stream, hipStreamNonBlocking));
+    sv.idle_ticks = (unsigned long long)(idle_timeout_s * 1e8);           // 100 MHz wall clock
+    sv.armed = 1;
+    return server_launch(h, sv.next_seq);
+}
+
+extern "C" int sr_gp_server_stop(sr_gp_t h) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_server_stop: NULL handle");
+    const int rc = server_quiesce(h);
+    h->srv.armed = 0;
+    return rc;
+}
+
+extern "C" int sr_gp_server_state(sr_gp_t h, int* armed, int* resident, long* launches, long* calls) {
+    SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_server_state: NULL handle");
+    if (armed) *armed = h->srv.armed;
+    if (resident) *resident = (h->srv.running && !any_left(h)) ? 1 : 0;
+    if (launches) *launches = h->srv.launches;
+    if (calls) *calls = h->srv.calls;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_order, double* out_host, double timeout_s) {
+    SR_CHECK(h != nullptr && x_host && out_host, SR_EINVAL, "sr_gp_server_call: NULL argument");
+    sr_server& sv = h->srv;
+    if (!sv.armed) { sr_set_error("sr_gp_server_call: no server armed (sr_gp_server_start)"); return SR_EUNSUPPORTED; }
+    if (!servable(h)) {                                   // the model has changed under the armed server
+        (void)server_quiesce(h);
+        sv.armed = 0;
+        sr_set_error("sr_gp_server_call: the model no longer has a resident server (Np=%d)", h->Np);
+        return SR_EUNSUPPORTED;
+    }
+    const unsigned long long seq = sv.next_seq;
+    if (!sv.running || any_left(h)) {
+        // never launched for this model state, or (partly) gone on its idle time-out: wait for the rest to leave, launch anew
+        SR_DEVICE(h->device);
+        if (sv.running) {
+            sv.mb[6] = SR_SERVER_CMD_STOP;                 // workgroups still polling leave at once (same sequence number
+            std::atomic_thread_fence(std::memory_order_release);      // as the request below: they answer nothing)
+            *(volatile unsigned long long*)(sv.mb + 7) = seq;
+            SR_HIP(hipStreamSynchronize(sv.stream));
+            *(volatile unsigned long long*)(sv.mb + 7) = 0ull;
+        }
+        SR_TRY(server_launch(h, seq));
+    }
+    const int D = h->D, n = h->n_out;
+    double* xs = reinterpret_cast<double*>(sv.mb);
+    for (int j = 0; j < D; ++j) xs[j] = x_host[j];
+    sv.mb[6] = second_order == 2 ? SR_SERVER_CMD_PING : (second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST);      // (2: diagnostics)
+    std::atomic_thread_fence(std::memory_order_release);  // payload before the sequence number (x86: store order)
+    *(volatile unsigned long long*)(sv.mb + 7) = seq;
+    const volatile unsigned long long* reply = sv.reply;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    for (;;) {
+        bool all = true;
+        for (int d = 0; d < n; ++d) all = all && (reply[d] == seq);
+        if (all) break;
+        __builtin_ia32_pause();
+        if ((++spins & 1023) == 0) {
+            if (any_left(h)) {
+                // a workgroup left on its idle time-out between our look at `alive` and the request: relaunch for this
+                // sequence number (the request is still in the mailbox; answers are idempotent)
+                bool done = true;
+                for (int d = 0; d < n; ++d) done = done && (reply[d] == seq);
+                if (done) break;
+                SR_DEVICE(h->device);
+                sv.mb[6] = SR_SERVER_CMD_STOP;
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+                SR_HIP(hipStreamSynchronize(sv.stream));
+                sv.mb[6] = second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST;
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+                SR_TRY(server_launch(h, seq));
+            }
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > timeout_s) {
+                sr_set_error("sr_gp_server_call: no answer to request %llu within %.3f s", seq, timeout_s);
+                return SR_ESTATE;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const size_t k = second_order == 2 ? 0 : (second_order ? out_doubles(h) : (size_t)2 * n + (size_t)n * D);
+    memcpy(out_host, sv.out, k * sizeof(double));
+    if (second_order == 2) out_host[0] = (double)sv.reply[2 * SR_SERVER_ALIVE] * 1e-2;      // us of the last evaluation on the device
+    ++sv.next_seq;
+    ++sv.calls;
+    return SR_OK;
+}

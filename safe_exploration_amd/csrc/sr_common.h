@@ -199,6 +199,25 @@ int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, dou
 int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac_mu,
                            double* jac_var, double* hess_mu, hipStream_t s);
 
+// K0s (sr_small.hip): resident single-query server of a small ARD-RBF model: one workgroup per output polls a mailbox in
+// pinned host memory.  All pointers are the DEVICE-visible addresses of pinned host memory.
+struct sr_server_args {
+    unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 5] x (D <= 6 doubles), [6] command, [7] sequence number (written last)
+    double* out;                     // reply block [mu n | var n | jac_mu n x D | jac_var n x D | hess n x D x D]
+    unsigned long long* reply;       // [d]: sequence number last answered by output d; [SR_SERVER_ALIVE + d]: 1 while it runs;
+                                     // [2 SR_SERVER_ALIVE + d]: device ticks (100 MHz) of the last evaluation
+    unsigned long long first_seq;    // the first sequence number this launch answers
+    unsigned long long idle_ticks;   // leave after this long without a request (100 MHz wall clock)
+};
+#define SR_SERVER_ALIVE 16
+#define SR_SERVER_CMD_FIRST 0ull     /* mu, var, d mu/dx */
+#define SR_SERVER_CMD_SECOND 1ull    /* + d var/dx, d2 mu/dx2 */
+#define SR_SERVER_CMD_STOP 2ull
+#define SR_SERVER_CMD_IDLE 3ull      /* (device-internal: the idle time-out) */
+#define SR_SERVER_CMD_PING 4ull      /* diagnostics: answer at once, evaluate nothing */
+bool sr_gp_server_supported(int Np, int D);
+int sr_launch_gp_server(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s);
+
 // Persistent multi-step kernel (sr_small.hip): the whole H-step chain of up to SR_CHAIN_GROUPS / (n_out Np / 128) * 16
 // rollouts in ONE launch (the posterior of sr_gp_small_kernel and the step of sr_ellipsoid_kernel inside a loop over the steps).
 struct sr_xel { double v; unsigned long long chk; };      // 16 bytes, written and read by single instructions; chk = bits(v) ^ mix(tag)

@@ -7,6 +7,7 @@
 //   sr_capi_posterior.hip  workspace, dispatch of the posterior pass (sr_gp_predict, sr_gp_linearize, sr_gp_call1),
 //                          input transform, completion mailbox
 //   sr_capi_reach.hip      reachability / moment / sampling entry points and the persistent-chain dispatch
+//   sr_capi_server.hip     resident single-query server: start / stop / blocking call
 #pragma once
 #include "sr_mfma_tile.h"
 #include <atomic>
@@ -16,8 +17,21 @@
 #include <vector>
 #include <algorithm>
 
+// resident single-query server (sr_capi_server.hip, kernel K0s of sr_small.hip)
+struct sr_server {
+    int armed = 0;                           // sr_gp_server_start was called: sr_gp_server_call (re)launches as needed
+    int running = 0;                         // a launch of this handle may be resident
+    void* pinned = nullptr; size_t pinned_bytes = 0;      // one pinned block: mailbox | reply words | reply block
+    unsigned long long *mb = nullptr, *reply = nullptr; double* out = nullptr;              // host addresses
+    unsigned long long *mb_dev = nullptr, *reply_dev = nullptr; double* out_dev = nullptr;  // the device's addresses of the same
+    hipStream_t stream = nullptr;            // non-blocking stream of its own: nothing else is ever ordered behind the kernel
+    unsigned long long next_seq = 1, idle_ticks = 500000;
+    long launches = 0, calls = 0;
+};
+
 struct sr_gp {
     int device = 0, N = 0, Np = 0, D = 0, n_out = 0;
+    sr_server srv;
     // persistent device state
     double *Z = nullptr, *yT = nullptr, *ls = nullptr, *sf2 = nullptr, *noise = nullptr,
            *alpha = nullptr, *Wt = nullptr;
@@ -115,6 +129,18 @@ void dev_free(void* p);
 int dev_zero(void* p, size_t bytes);
 void free_ws(sr_gp* h);
 int ensure_wt(sr_gp* h);
+
+// resident server (sr_capi_server.hip): off the device before the model is written / before a device-wide wait
+int server_quiesce(sr_gp* h);
+void servers_quiesce_device(int device);
+void server_release(sr_gp* h);
+// hipDeviceSynchronize for the library: resident servers of the current device leave first (they would keep the wait
+// until their idle time-out otherwise)
+static inline hipError_t device_sync() {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) servers_quiesce_device(dev);
+    return hipDeviceSynchronize();
+}
 
 // posterior pass and its workspace (sr_capi_posterior.hip)
 int pick_nsplit(const sr_gp* h, long Tp);

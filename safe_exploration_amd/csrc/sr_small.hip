@@ -160,7 +160,7 @@ template <int NP, int DT, bool LIN, bool KEEP = false, int NW = 16>
 __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
                                                  const double* xa, long lda, const double* xb, long ldb, long nq,
                                                  const sr_small_lds<NP, DT>& L,
-                                                 const sr_small_rows<NP, DT>* rows = nullptr) {
+                                                 const sr_small_rows<NP, DT>* rows = nullptr, int tid_in = -1) {
     constexpr int RPW = NP / NW;             // training rows per wavefront in phase A
     constexpr int KSA = RPW / 4;             // phase-A k-steps per wavefront
 #ifndef SR_CHAIN_HC
@@ -181,7 +181,7 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
     double (*pA)[256] = L.pA;
     double (*Rs)[16] = L.Rs;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, ln = lane & 15;             // fragment coordinates: k offset, m/n index
     const int off = NP - a.N;                             // front padding
@@ -264,29 +264,25 @@ template <int NP, int DT, bool LIN, bool KEEP = false>
 __device__ __forceinline__ void sr_small_posterior(const sr_kstar_args& a, const double* __restrict__ Wt, int d,
                                                    const double* xa, long lda, const double* xb, long ldb, long nq,
                                                    const sr_small_lds<NP, DT>& L,
-                                                   const sr_small_rows<NP, DT>* rows = nullptr) {
-    sr_small_phase_a<NP, DT, LIN, KEEP, 16>(a, d, xa, lda, xb, ldb, nq, L, rows);
+                                                   const sr_small_rows<NP, DT>* rows = nullptr, int tid_in = -1) {
+    // (tid_in: the thread index as the resident server hands it in -- through an empty asm every round, so that nothing
+    //  derived from it counts as loop-invariant there)
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
+    sr_small_phase_a<NP, DT, LIN, KEEP, 16>(a, d, xa, lda, xb, ldb, nq, L, rows, tid_in);
     // ---- phases B, C ---------------------------------------------------------------------------
-    sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, L.ks, L.pB, L.redC, threadIdx.x >> 6, threadIdx.x & 63);
+    sr_small_contract<NP, LIN>(Wt + (long)d * NP * NP, L.ks, L.pB, L.redC, tid >> 6, tid & 63);
 }
 
+// Outputs of one posterior evaluation (after sr_small_posterior), straight to the API layout; all threads call.
 template <int NP, int DT, bool LIN>
-__global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, const double* __restrict__ Wt,
-                                                           double* __restrict__ mu, double* __restrict__ var,
-                                                           double* __restrict__ jac, double* __restrict__ jac_var,
-                                                           double* __restrict__ hess) {
+__device__ __forceinline__ void sr_small_outputs(const sr_kstar_args& a, const sr_small_lds<NP, DT>& L, int d, long t0, double sf2,
+                                                 double* __restrict__ mu, double* __restrict__ var, double* __restrict__ jac,
+                                                 double* __restrict__ jac_var, double* __restrict__ hess, int tid_in = -1) {
     constexpr int NSTRIP = NP / 16;          // 16-column strips of U^-1
-    SR_SMALL_LDS_DECL(NP, DT);
     double (*xq)[DT] = L.xq;
     double (*Rs)[16] = L.Rs;
     double (*redC)[SR_FQ] = L.redC;
-    const int tid = threadIdx.x;
-    const int d = blockIdx.y;
-    const long t0 = (long)blockIdx.x * SR_FQ;
-    const double sf2 = a.sf2[d];
-    sr_small_posterior<NP, DT, LIN>(a, Wt, d, a.xa + t0 * a.lda, a.lda, a.xb + t0 * a.ldb, a.ldb, a.T - t0, L);
-
-    // ---- outputs ----------------------------------------------------------------------------------
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     if (LIN) {
         const double m = Rs[0][0];
         if (tid == 0) mu[d] = m;
@@ -330,6 +326,22 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
         var[(t0 + tid) * a.n_out + d] = v;
     }
 
+}
+
+template <int NP, int DT, bool LIN>
+__global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, const double* __restrict__ Wt,
+                                                           double* __restrict__ mu, double* __restrict__ var,
+                                                           double* __restrict__ jac, double* __restrict__ jac_var,
+                                                           double* __restrict__ hess) {
+    SR_SMALL_LDS_DECL(NP, DT);
+    const int tid = threadIdx.x;
+    const int d = blockIdx.y;
+    const long t0 = (long)blockIdx.x * SR_FQ;
+    const double sf2 = a.sf2[d];
+    sr_small_posterior<NP, DT, LIN>(a, Wt, d, a.xa + t0 * a.lda, a.lda, a.xb + t0 * a.ldb, a.ldb, a.T - t0, L);
+
+    sr_small_outputs<NP, DT, LIN>(a, L, d, t0, sf2, mu, var, jac, jac_var, hess);
+
     if (a.host_flag) {
         // blocking single query: the outputs above went to pinned host memory; once every workgroup's stores are
         // out (system-scope fence), the last one to arrive publishes the sequence number
@@ -343,6 +355,220 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0s: RESIDENT single-query server ("latency-optimised single-query kernel ... persistent kernel, pinned
+// host buffers").  The production loop evaluates the model once per IPOPT callback (CasadiSSMEvaluator.eval / JacFun.eval,
+// /root/reference/safe_exploration/state_space_models.py:278-303, 384-417): one query, the host blocks.  Launched per
+// call, K0 costs the dispatch latency of a 1024-thread workgroup on both sides of ~5 us of work (blocking call 22 - 30 us
+// at N = 100 .. 200).  Here one workgroup per output STAYS on its CU and polls a mailbox in pinned host memory:
+//   host:   x (D doubles) and the command word into the mailbox, then the sequence number (one cache line, written in
+//           this order by ordinary stores); spins on the n_out reply words
+//   device: lane 0 of each workgroup polls the sequence word with system-scope loads; on a hit the workgroup runs phases
+//           A - C of K0 (first order, or LIN for the second-order outputs), stores the results to the pinned reply block,
+//           fences (system scope) and stores the sequence number into ITS reply word
+// No launch, no copy command and no completion interrupt on the path: one PCIe read to see the request, one posted
+// write to answer it.  The workgroup leaves on the STOP command or when no request arrived for idle_ticks (its `alive`
+// word in the reply block then reads 0 and the host relaunches it with the next request): a device-wide synchronisation
+// elsewhere in the process waits at most that long.  The model is read through the L2 like K0 does (it cannot change
+// while the server runs: every entry point that writes it stops the server first).
+// ------------------------------------------------------------------------------------------------
+// Phase B with the wavefront's fragments of U^-1 held in REGISTERS across requests (NP = 128: 9 doubles per lane; the
+// strips of a wavefront and their k ranges as in sr_small_contract).  The run length of strip A is wavefront-uniform but
+// not a compile-time constant: one straight-line body per length (a branch per MFMA would serialise the LDS reads).
+template <int NP>
+struct sr_srv_frag {
+    static constexpr int NSTRIP = NP / 16, NPAIR = NSTRIP / 2, NSPLIT = 16 / NPAIR;
+    static constexpr int TOT = 4 * (NSTRIP + 1) / NSPLIT;            // k-steps (of 4 rows) of a wavefront, both strips
+    double w[TOT];
+    __device__ __forceinline__ void load(const double* __restrict__ Wd, int wave, int lane) {
+        const int lk = lane >> 4, ln = lane & 15;
+        const int pr = wave / NSPLIT, h = wave % NSPLIT;
+        const int nA = 4 * (pr + 1) / NSPLIT;
+#pragma unroll
+        for (int u = 0; u < TOT; ++u) {
+            const bool inA = u < nA;
+            const int sidx = inA ? pr : NSTRIP - 1 - pr;
+            const int chunk = 4 * (sidx + 1) / NSPLIT;
+            const int st = h * chunk + (inA ? u : u - nA);
+            w[u] = Wd[(long)(4 * st + lk) * NP + 16 * sidx + ln];
+        }
+    }
+};
+template <int NP, int NA>
+__device__ __forceinline__ void sr_srv_mfma(const sr_srv_frag<NP>& f, const double (*ks)[SR_FQ], int stA, int stB, int lk, int ln,
+                                            sr_d4 (&acc)[2]) {
+    constexpr int TOT = sr_srv_frag<NP>::TOT;
+    double bf[TOT];
+#pragma unroll
+    for (int u = 0; u < TOT; ++u) bf[u] = ks[4 * ((u < NA) ? stA + u : stB + (u - NA)) + lk][ln];
+    sr_d4 a = {0.0, 0.0, 0.0, 0.0}, b = a;
+#pragma unroll
+    for (int u = 0; u < TOT; ++u) {
+        if (u < NA) a = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf[u], a, 0, 0, 0);
+        else b = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf[u], b, 0, 0, 0);
+    }
+    acc[0] = a; acc[1] = b;
+}
+// same contract as sr_small_contract<NP, true> (DOT0: columns dotted with column 0)
+template <int NP>
+__device__ __forceinline__ void sr_srv_contract(const sr_srv_frag<NP>& f, const double (*ks)[SR_FQ], double* pB,
+                                                double (*redC)[SR_FQ], int wave, int lane) {
+    constexpr int NSTRIP = sr_srv_frag<NP>::NSTRIP, NSPLIT = sr_srv_frag<NP>::NSPLIT;
+    static_assert(NSPLIT >= 2 && NSTRIP <= 16, "register-held fragments: Np <= 256");
+    const int lk = lane >> 4, ln = lane & 15;
+    const int pr = wave / NSPLIT, h = wave % NSPLIT;
+    const int nA = 4 * (pr + 1) / NSPLIT, nB = 4 * (NSTRIP - pr) / NSPLIT;
+    sr_d4 accB[2];
+    const int stA = h * nA, stB = h * nB;
+    switch (nA) {
+#define SRV_CASE(NA_) case NA_: if constexpr (NA_ < sr_srv_frag<NP>::TOT) sr_srv_mfma<NP, NA_>(f, ks, stA, stB, lk, ln, accB); break;
+        SRV_CASE(1) SRV_CASE(2) SRV_CASE(3) SRV_CASE(4) SRV_CASE(6) SRV_CASE(8) SRV_CASE(10) SRV_CASE(12) SRV_CASE(14) SRV_CASE(16)
+#undef SRV_CASE
+        default: accB[0] = accB[1] = sr_d4{0.0, 0.0, 0.0, 0.0}; break;
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int sidx = which ? NSTRIP - 1 - pr : pr;
+        if (h > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pB[((h - 1) * NSTRIP + sidx) * 256 + r * 64 + lane] = accB[which][r];
+        }
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int sidx = which ? NSTRIP - 1 - pr : pr;
+            double q = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = accB[which][r];
+#pragma unroll
+                for (int hh = 0; hh < NSPLIT - 1; ++hh) v += pB[(hh * NSTRIP + sidx) * 256 + r * 64 + lane];
+                const double w = __shfl(v, lane & 48);               // dot with column 0 of the same row
+                q = fma(v, w, q);
+            }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            if (lane < 16) redC[sidx][lane] = q;
+        }
+    }
+    __syncthreads();
+}
+
+// (the model travels as the few words the evaluation needs -- sr_server_model -- and the argument block of phase A is
+//  rebuilt from them every round: with the whole sr_kstar_args live across the loop's back edge the scalar registers run
+//  out, spill into vector lanes and those into scratch: 12 .. 380 B per lane)
+struct sr_server_model { const double *Z, *alpha, *ls, *sf2, *Wt; int N, D, n_out; };
+template <int NP, int DT>
+__global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, sr_server_args sv) {
+    constexpr bool REGS = NP <= 128;          // U^-1 fragments in registers (Np = 256: 34 doubles per lane do not fit 128 VGPRs)
+    SR_SMALL_LDS_DECL(NP, DT);
+    __shared__ double rows_[NP][DT + 1];      // the training rows of phase A, pre-scaled, with alpha: fetched once
+    __shared__ double il_[DT];
+    __shared__ double xreq[8];
+    __shared__ unsigned long long req_cmd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d = blockIdx.y;
+    const int D = m.D, n = m.n_out;
+    double* out = sv.out;
+    unsigned long long expect = sv.first_seq;
+    sr_srv_frag<REGS ? NP : 128> frag;
+    {
+        sr_kstar_args a0{};
+        a0.Z = m.Z; a0.alpha = m.alpha; a0.ls = m.ls; a0.N = m.N; a0.Np = NP; a0.D = D; a0.n_out = n;
+        sr_small_rows_fill<NP, DT>(a0, d, rows_, 1024);
+        sr_small_il_fill<DT>(a0, d, il_);
+        if (REGS) frag.load(m.Wt + (long)d * NP * NP, wave, lane);
+    }
+    const double sf2 = m.sf2[d];
+    __syncthreads();
+    const sr_small_rows<NP, DT> rows{rows_, il_};
+    for (;;) {
+        if (wave == 0) {
+            // the mailbox is ONE 64-byte line [x0 .. x5 | command | sequence number]: lanes 0 .. 7 fetch it with one request,
+            // so a hit on the sequence number (written last by the host) comes with the query it belongs to
+            unsigned long long cmd = SR_SERVER_CMD_IDLE;
+            const unsigned long long t_last = wall_clock64();             // 100 MHz
+            for (;;) {
+                unsigned long long wv = 0;
+                if (lane < 8) wv = __hip_atomic_load(sv.mb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long s = __shfl(wv, 7);
+                if (s == expect) {
+                    cmd = __shfl(wv, 6);
+                    if (lane < 6) xreq[lane] = __longlong_as_double((long long)wv);
+                    break;
+                }
+                if (wall_clock64() - t_last > sv.idle_ticks) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) req_cmd = cmd;
+        }
+        __syncthreads();
+        const unsigned long long cmd = req_cmd;
+        if (cmd == SR_SERVER_CMD_STOP || cmd == SR_SERVER_CMD_IDLE) break; // stop command or idle time-out
+        const unsigned long long t_seen = wall_clock64();
+        if (cmd == SR_SERVER_CMD_PING) {                                   // diagnostics: answer without evaluating
+            if (tid == 0) __hip_atomic_store(sv.reply + d, expect, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            ++expect;
+            __syncthreads();
+            continue;
+        }
+        // Always the second-order evaluation: its outputs contain the first-order ones (mu, var, d mu/dx lead the reply block),
+        // it costs ~2 us more than the first-order pass, and ONE code path inside the loop keeps the kernel within its 128
+        // registers per lane (both paths inlined: 60 - 508 B of scratch per lane).
+        {
+            // (the pointers and the thread index pass through an empty asm every round: what the compiler can prove
+            //  loop-invariant -- the address arithmetic of the U^-1 fragments, 38 pointers per lane -- it hoists in front
+            //  of the polling loop and spills)
+            const double* pW = m.Wt;
+            int tq = tid;
+            asm volatile("" : "+s"(pW), "+v"(tq));
+            sr_kstar_args a{};
+            a.sf2 = m.sf2; a.ls = m.ls;
+            a.lda = D; a.na = D; a.N = m.N; a.Np = NP; a.D = D; a.n_out = n; a.nsplit = 1; a.T = 1; a.Tp = 1;
+            sr_small_phase_a<NP, DT, true, true, 16>(a, d, xreq, D, xreq, D, 1, L, &rows, tq);
+            if constexpr (REGS) sr_srv_contract<NP>(frag, L.ks, L.pB, L.redC, tq >> 6, tq & 63);
+            else sr_small_contract<NP, true>(pW + (long)d * NP * NP, L.ks, L.pB, L.redC, tq >> 6, tq & 63);
+            sr_small_outputs<NP, DT, true>(a, L, d, 0, sf2, out, out + n, out + 2 * n, out + 2 * n + n * D, out + 2 * n + 2 * n * D, tq);
+        }
+        __threadfence_system();
+        __syncthreads();                                                   // (also: everybody is through with req_cmd / xreq)
+        if (tid == 0) {
+            // (diagnostics: ticks of the 100 MHz clock this evaluation took on the device, request seen -> results fenced)
+            sv.reply[2 * SR_SERVER_ALIVE + d] = wall_clock64() - t_seen;
+            __hip_atomic_store(sv.reply + d, expect, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        ++expect;
+    }
+    if (tid == 0) __hip_atomic_store(sv.reply + SR_SERVER_ALIVE + d, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// D <= 5 (pendulum: 3, cart-pole: 4 or 5), and D <= 3 at 512 padded points: the other instantiations spill (16 - 60 B of
+// scratch per lane) and are not built
+bool sr_gp_server_supported(int Np, int D) { return Np % 128 == 0 && Np <= SR_FUSED_NP && D <= (Np == 512 ? 3 : 5); }
+
+template <int NP>
+static int launch_server_np(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s) {
+    dim3 grid(1, a.n_out);
+    const sr_server_model m{a.Z, a.alpha, a.ls, a.sf2, Wt, a.N, a.D, a.n_out};
+    SR_CHECK(sr_gp_server_supported(NP, a.D), SR_EUNSUPPORTED, "gp_server: Np=%d D=%d not built", NP, a.D);
+    if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_kernel<NP, 3>), grid, dim3(1024), 0, s, m, sv);
+    else if constexpr (NP < 512) hipLaunchKernelGGL((sr_gp_server_kernel<NP, 5>), grid, dim3(1024), 0, s, m, sv);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+int sr_launch_gp_server(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s) {
+    if (a.Np == 128) return launch_server_np<128>(a, Wt, sv, s);
+    if (a.Np == 256) return launch_server_np<256>(a, Wt, sv, s);
+    if (a.Np == 384) return launch_server_np<384>(a, Wt, sv, s);
+    if (a.Np == 512) return launch_server_np<512>(a, Wt, sv, s);
+    sr_set_error("gp_server: Np=%d not supported", a.Np);
+    return SR_EUNSUPPORTED;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ Also provided, each through its own C entry point: ``opt_hyp=True`` (L-BFGS-B ov
 Not provided: sparse GP regression (``do_sparse_gp``, GPy's ``SparseGPRegression``).
 """
 import ctypes
+import os
 import warnings
 
 import numpy as np
@@ -70,6 +71,8 @@ class _Handle(object):
             io["hm"] = o[2 * n + 2 * n * D:]
             io["h_in_np"], io["h_out_np"] = io["h_in"].numpy(), io["h_out"].numpy()
             io["p_in"], io["p_out"], io["p_flag"] = B.ptr(io["h_in"]), B.ptr(io["h_out"]), B.ptr(io["h_flag"])
+            io["srv_np"] = np.empty(total)                       # where sr_gp_server_call leaves its answer
+            io["p_srv"] = ctypes.c_void_p(io["srv_np"].ctypes.data)
             self._single_io = io
         return io
 
@@ -103,6 +106,21 @@ class _Handle(object):
             stream.synchronize()
             check(rc)
         return io["h_out_np"][:k].copy()
+
+    def server_call(self, second_order, k):
+        """One blocking single query through the RESIDENT server (sr_gp_server_call: the query in the pinned input block
+        goes into the mailbox the resident workgroups poll; no launch).  Returns the first k doubles of the packed result,
+        or None where no server is armed for this model (``SimpleGPModel.start_server``)."""
+        if not getattr(self, "_server_armed", False):
+            return None
+        io = self._single_io
+        rc = lib.sr_gp_server_call(self.h, io["p_in"], second_order, io["p_srv"], 5.0)
+        if rc != 0:
+            if rc != -5:                       # anything but SR_EUNSUPPORTED is an error of this call
+                check(rc)
+            self._server_armed = False         # the model outgrew the server (or it was stopped): the launched routes
+            return None
+        return io["srv_np"][:k].copy()
 
     def fetch(self, k, stream):
         """first k doubles of the packed device block -> NumPy (copy), blocking."""
@@ -534,6 +552,8 @@ class SimpleGPModel(StateSpaceModel):
         self._handle = handle
         self._beta = None
         self._inv_K = None
+        if old is not None and old is not handle and getattr(old, "_server_armed", False):
+            self.start_server(old._server_idle)      # a refit with a new size replaced the handle: the server follows
 
     def _set_data(self, handle, Z, Y, noise, dev, s):
         tz, ty, tn = (B.as_dev(a, dev) for a in (Z, Y, noise))
@@ -720,6 +740,12 @@ class SimpleGPModel(StateSpaceModel):
             #  not where the library has already declined the route for this padded size)
             n, D = hd.n_out, hd.D
             io = hd.single_io()
+            if getattr(hd, "_server_armed", False):
+                io["h_in_np"][:D] = x[0]
+                o = hd.server_call(0, 2 * n + n * D)
+                if o is not None:
+                    out = (o[None, :n], o[None, n:2 * n])
+                    return out + (o[2 * n:].reshape(1, n, D),) if compute_gradients else out
             if hd.Np != 384 and io["mailbox"] and (io["direct"] or io.get("direct_off_np") != hd.Np):
                 io["h_in_np"][:D] = x[0]
                 o = hd.call1(0, 2 * n + n * D, torch.cuda.current_stream(hd.device))
@@ -797,7 +823,9 @@ class SimpleGPModel(StateSpaceModel):
         stream = torch.cuda.current_stream(hd.device)
         io["h_in_np"][:states.shape[1]] = states[0]
         io["h_in_np"][states.shape[1]:] = actions[0]
-        o = hd.call1(0, 2 * n + n * D, stream)
+        o = hd.server_call(0, 2 * n + n * D)
+        if o is None:
+            o = hd.call1(0, 2 * n + n * D, stream)
         if o is not None:
             return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
@@ -853,7 +881,9 @@ class SimpleGPModel(StateSpaceModel):
         stream = torch.cuda.current_stream(hd.device)
         a, b, c = 2 * n, 2 * n + n * D, 2 * n + 2 * n * D
         io["h_in_np"][:] = x
-        o = hd.call1(1, io["d_out"].numel(), stream)
+        o = hd.server_call(1, io["d_out"].numel())
+        if o is None:
+            o = hd.call1(1, io["d_out"].numel(), stream)
         if o is not None:
             return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
@@ -979,6 +1009,52 @@ class SimpleGPModel(StateSpaceModel):
         self._fact_panel = int(panel)
         if self._handle is not None:
             check(lib.sr_gp_set_fact_panel(self._handle.h, int(panel)))
+
+    def get_forward_model_casadi(self, linearize_mu=True):
+        """state_space_models.py:140-166.  The evaluator calls the model once per IPOPT callback and blocks: the resident
+        single-query server is armed for it (``start_server``; SR_NO_SERVER=1 in the environment keeps the launched
+        routes)."""
+        if self.gp_trained and not os.environ.get("SR_NO_SERVER"):
+            try:
+                self.start_server()
+            except RuntimeError:
+                pass                                   # the launched routes serve the evaluator
+        return super(SimpleGPModel, self).get_forward_model_casadi(linearize_mu)
+
+    def start_server(self, idle_timeout_s=0.005):
+        """Put the RESIDENT single-query server of this model on the device (sr_gp_server_start): one workgroup per output
+        polls a mailbox in pinned host memory, so that ``__call__`` / ``linearize_predict`` / a one-row ``predict`` cost one
+        PCIe round trip plus the evaluation instead of a kernel launch each -- the regime of the MPC's IPOPT callbacks
+        (state_space_models.py:278-303, 384-417).  The kernel leaves by itself after ``idle_timeout_s`` without a query
+        (so a ``torch.cuda.synchronize()`` elsewhere waits at most that long) and comes back with the next one; model
+        updates take it off the device and leave it armed.  Returns False where the model has no such server (non-RBF
+        kernels, more than 512 padded points, an input transform): the launched routes serve it as before."""
+        self._need_trained()
+        hd = self._handle
+        hd.single_io()
+        rc = lib.sr_gp_server_start(hd.h, float(idle_timeout_s))
+        if rc == -5:
+            hd._server_armed = False
+            return False
+        check(rc)
+        hd._server_armed = True
+        hd._server_idle = float(idle_timeout_s)
+        return True
+
+    def stop_server(self):
+        """Take the resident server off the device and disarm it (sr_gp_server_stop)."""
+        hd = self._handle
+        if hd is not None and getattr(hd, "_server_armed", False):
+            hd._server_armed = False
+            check(lib.sr_gp_server_stop(hd.h))
+
+    def server_state(self):
+        """(armed, resident, launches, calls) of the resident server."""
+        self._need_trained()
+        a, r = ctypes.c_int(0), ctypes.c_int(0)
+        nl, nc = ctypes.c_long(0), ctypes.c_long(0)
+        check(lib.sr_gp_server_state(self._handle.h, ctypes.byref(a), ctypes.byref(r), ctypes.byref(nl), ctypes.byref(nc)))
+        return bool(a.value), bool(r.value), nl.value, nc.value
 
     def set_small_path(self, on):
         self._need_trained()

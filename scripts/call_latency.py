@@ -23,8 +23,35 @@ def t(fn, n=300):
     return (time.perf_counter() - t0) / n * 1e6
 
 
+SIZES = ((2, 25), (2, 100), (4, 150), (2, 200), (2, 350), (2, 500), (2, 1000), (2, 2000), (2, 5000))
+
+
+def cpu_time(prob, second_order, reps=200):
+    """The oracle's NumPy evaluation of the same single query (explicit inv_K route of the reference, BLAS threads as the
+    box gives them): what a CPU pays for the call the GPU columns time.  Model fit excluded."""
+    from oracle import oracle_np as orc
+    beta, inv_K, _ = orc.gp_fit(prob["Z"], prob["Y"], prob["lengthscale"], prob["signal_var"], prob["noise_var"] + 1e-5)
+    x = np.hstack((prob["p"][0], prob["k_ff"][0]))
+    if second_order:
+        fn = lambda: (orc.gp_predict(x[None], prob["Z"], beta, inv_K, prob["lengthscale"], prob["signal_var"], True),
+                      orc.gp_linearize_extras(x, prob["Z"], beta, inv_K, prob["lengthscale"], prob["signal_var"]))
+    else:
+        fn = lambda: orc.gp_predict(x[None], prob["Z"], beta, inv_K, prob["lengthscale"], prob["signal_var"], True)
+    for _ in range(5):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
 def main():
-    for n_s, N in ((2, 100), (2, 200), (4, 150), (2, 500), (2, 2000), (2, 5000)):
+    print("# blocking single-query entry points, wall time per call [us]; NumPy in / out.  GPU routes: copy + sync (H2D copy, "
+          "kernel, D2H copy, stream sync), mailbox (results published into pinned memory by a kernel), one command (query in the "
+          "kernel arguments, results written to pinned memory by the posterior kernel), RESIDENT SERVER (no launch: mailbox "
+          "polled by resident workgroups).  CPU: the oracle's NumPy evaluation of the same call on this box's host cores "
+          "(%d; model fit excluded)." % (os.cpu_count() or 1))
+    for n_s, N in SIZES:
         prob = workload.make_problem(9, N, n_s, 1, 4, sf2=0.01)
         gp = SimpleGPModel(n_s, n_s, 1, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device="cuda:0")
         gp.train(prob["Z"], prob["Y"], opt_hyp=False)
@@ -37,11 +64,23 @@ def main():
                          t(lambda: gp.linearize_predict(prob["p"][:1], prob["k_ff"][:1], True)))
             if mode == "direct" and not io["direct"]:
                 row[mode] = (float("nan"), float("nan"))
-        print("n_s=%d N=%5d  __call__: copy+sync %.1f us, mailbox %.1f, one command %.1f | linearize_predict(jacobians=True): "
-              "%.1f, %.1f, %.1f us | kernel alone (async) %.1f us" % (
-                  n_s, N, row["sync"][0], row["mailbox"][0], row["direct"][0], row["sync"][1], row["mailbox"][1],
-                  row["direct"][1], t(lambda: gp.predict_device(x, True))), flush=True)
+        kern = t(lambda: gp.predict_device(x, True))
+        row["server"] = (float("nan"), float("nan"))
+        if gp.start_server(idle_timeout_s=0.05):
+            row["server"] = (t(lambda: gp(prob["p"][:1], prob["k_ff"][:1])),
+                             t(lambda: gp.linearize_predict(prob["p"][:1], prob["k_ff"][:1], True)))
+            gp.stop_server()
+        print("n_s=%d N=%5d  __call__: copy+sync %.1f, mailbox %.1f, one command %.1f, resident server %.1f || "
+              "linearize_predict(jacobians=True): %.1f, %.1f, %.1f, server %.1f || kernel alone (async) %.1f" % (
+                  n_s, N, row["sync"][0], row["mailbox"][0], row["direct"][0], row["server"][0], row["sync"][1],
+                  row["mailbox"][1], row["direct"][1], row["server"][1], kern), flush=True)
         del gp
+    # the CPU columns last: the BLAS pool keeps its threads spinning after a call and would disturb the GPU timings
+    for n_s, N in SIZES:
+        prob = workload.make_problem(9, N, n_s, 1, 4, sf2=0.01)
+        reps = 200 if N <= 1000 else 20
+        print("n_s=%d N=%5d  CPU NumPy (oracle, %d host cores): __call__ %.1f us, linearize_predict(jacobians=True) %.1f us" % (
+            n_s, N, os.cpu_count() or 1, cpu_time(prob, False, reps), cpu_time(prob, True, reps)), flush=True)
 
 
 if __name__ == "__main__":

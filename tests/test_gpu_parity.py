@@ -1910,3 +1910,105 @@ def test_single_query_mailbox_and_fallback_agree():
     from safe_exploration_amd._lib import lib
     from safe_exploration_amd import _buffers as B
     assert lib.sr_wait_flag(B.ptr(io["h_flag"]), io["seq"] + 12345, 0.05) != 0
+
+
+@pytest.mark.parametrize("N,n_s,n_u", [(100, 2, 1), (150, 4, 1), (300, 2, 1), (450, 2, 1)])
+def test_resident_server_answers_single_queries(N, n_s, n_u):
+    """K0s (sr_gp_server_start / sr_gp_server_call): the resident workgroups answer __call__, linearize_predict(jacobians=True)
+    and a one-row predict from their mailbox.  Against the launched routes of the same model (to the last bits: the server
+    always runs the second-order evaluation, on rows it fetched and scaled once) and against the oracle's closed forms."""
+    import time
+    import torch
+    syn = orc.make_synthetic(40 + N, N, n_s, n_u, 12)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    D = n_s + n_u
+    plain = [gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1]) for t in range(12)]
+    plain_lin = [gp.linearize_predict(syn["p"][t:t + 1], syn["k_ff"][t:t + 1], True) for t in range(12)]
+    assert gp.server_state()[:2] == (False, False)
+    assert gp.start_server(idle_timeout_s=0.5) is True
+    armed, resident, launches, calls = gp.server_state()
+    assert armed and launches == 1 and calls == 0
+    for rnd in range(3):
+        for t in range(12):
+            o = gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1])
+            assert [a.shape for a in o] == [(n_s, 1), (n_s, 1), (n_s, D)]
+            for a, b in zip(o, plain[t]):
+                np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-3 * max(mu_atol(om), 1e-12))
+            lin = gp.linearize_predict(syn["p"][t:t + 1], syn["k_ff"][t:t + 1], True)
+            for a, b in zip(lin, plain_lin[t]):
+                # (last bits: the server holds the training rows pre-scaled and, at 128 padded rows, its U^-1 fragments in
+                #  registers with two accumulators per strip; at 512 the launched route is the streamed kernel)
+                np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    mu1, var1, jac1 = gp.predict(x[3:4], compute_gradients=True)          # one row: the server again
+    armed, resident, launches, calls = gp.server_state()
+    assert armed and resident and launches == 1 and calls == 3 * 24 + 1
+    rmu, rvar = orc.gp_predict(x[3:4], om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
+    np.testing.assert_allclose(mu1, rmu, rtol=1e-10, atol=mu_atol(om))
+    np.testing.assert_allclose(var1, rvar, rtol=0, atol=1e-9 * float(np.max(om["signal_var"])))
+    rjv, rhm = orc.gp_linearize_extras(x[5], om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"])
+    lin5 = gp.linearize_predict(syn["p"][5:6], syn["k_ff"][5:6], True)
+    np.testing.assert_allclose(lin5[3], rjv, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(rjv).max()))
+    np.testing.assert_allclose(lin5[4], rhm, rtol=1e-8, atol=1e3 * mu_atol(om))
+    # a batch goes the launched way beside the resident kernel
+    mu_b, var_b = gp.predict(x)
+    np.testing.assert_allclose(mu_b[3], mu1[0], rtol=1e-12, atol=1e-3 * max(mu_atol(om), 1e-12))
+    # a device-wide wait elsewhere in the process does not hang on the resident kernel beyond its idle time-out
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 2.0
+    gp.stop_server()
+    assert gp.server_state()[:2] == (False, False)
+    o = gp(syn["p"][:1], syn["k_ff"][:1])                                   # launched route again
+    for a, b in zip(o, plain[0]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_resident_server_idle_timeout_restart_and_model_updates():
+    """The server leaves by itself after its idle time-out and comes back with the next query; a model update takes it off
+    the device, and the next query is answered from the NEW model (row append inside the padded size, then a refit that
+    changes the handle); a model that outgrows the one-launch sizes falls back to the launched routes for good."""
+    import time
+    syn = orc.make_synthetic(77, 120, 2, 1, 6)
+    gp = hip_model(syn["Z"][:100], syn["Y"][:100], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    assert gp.start_server(idle_timeout_s=0.002)
+    a0 = gp(syn["p"][:1], syn["k_ff"][:1])
+    time.sleep(0.1)
+    armed, resident, launches, calls = gp.server_state()
+    assert armed and not resident and launches == 1 and calls == 1          # gone on its idle time-out
+    a1 = gp(syn["p"][:1], syn["k_ff"][:1])
+    for u, v in zip(a0, a1):
+        np.testing.assert_array_equal(u, v)
+    armed, resident, launches, calls = gp.server_state()
+    assert armed and launches >= 2 and calls == 2
+    # queries at the pace of the time-out: every one of them may find the kernel leaving
+    for i in range(40):
+        time.sleep(0.0021 if i % 2 else 0.0015)
+        o = gp(syn["p"][:1], syn["k_ff"][:1])
+        for u, v in zip(o, a0):
+            np.testing.assert_array_equal(u, v)
+    # row append: the model changes under the armed server
+    gp.update_model(syn["Z"][100:101], syn["Y"][100:101], opt_hyp=False, replace_old=False)
+    o = gp(syn["p"][:1], syn["k_ff"][:1])
+    assert gp.server_state()[0]
+    ref = hip_model(syn["Z"][:101], syn["Y"][:101], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    r = ref(syn["p"][:1], syn["k_ff"][:1])
+    for u, v in zip(o, r):
+        np.testing.assert_allclose(u, v, rtol=1e-9, atol=1e-11)
+    # refit with another size: a new handle, the server follows it
+    gp.train(syn["Z"][:120], syn["Y"][:120], opt_hyp=False)
+    o = gp(syn["p"][1:2], syn["k_ff"][1:2])
+    assert gp.server_state()[0] and gp.server_state()[3] >= 1
+    ref = hip_model(syn["Z"][:120], syn["Y"][:120], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    r = ref(syn["p"][1:2], syn["k_ff"][1:2])
+    for u, v in zip(o, r):
+        np.testing.assert_allclose(u, v, rtol=1e-12, atol=1e-13)
+    # a model beyond the one-launch sizes: no server, the launched routes answer
+    big = orc.make_synthetic(78, 700, 2, 1, 2)
+    gp.train(big["Z"], big["Y"], opt_hyp=False)
+    assert not gp.server_state()[0]
+    o = gp(big["p"][:1], big["k_ff"][:1])
+    mu, var = gp.predict(np.hstack((big["p"][:1], big["k_ff"][:1])))
+    np.testing.assert_array_equal(o[0][:, 0], mu[0])
+    assert gp.start_server() is False
