@@ -16,6 +16,7 @@ constexpr size_t MB_WORDS = 16;               // mailbox: 128 bytes (one line); 
 constexpr size_t REPLY_WORDS = 3 * SR_SERVER_ALIVE;
 
 size_t out_doubles(const sr_gp* h) { return (size_t)2 * h->n_out + (size_t)2 * h->n_out * h->D + (size_t)h->n_out * h->D * h->D; }
+size_t rec_doubles(const sr_gp* h) { return (size_t)h->n_out * SR_SERVER_REC; }
 
 bool servable(const sr_gp* h) {
     return h->factorized && !h->general && h->n_xin == 0 && h->small_path == 1 && h->n_out <= SR_SERVER_ALIVE &&
@@ -110,7 +111,7 @@ extern "C" int sr_gp_server_start(sr_gp_t h, double idle_timeout_s) {
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));
     sr_server& sv = h->srv;
-    const size_t bytes = (MB_WORDS + REPLY_WORDS) * sizeof(unsigned long long) + out_doubles(h) * sizeof(double);
+    const size_t bytes = (MB_WORDS + REPLY_WORDS) * sizeof(unsigned long long) + rec_doubles(h) * sizeof(double);
     if (sv.pinned && sv.pinned_bytes < bytes) { (void)hipHostFree(sv.pinned); sv.pinned = nullptr; }
     if (!sv.pinned) {
         void* p = nullptr;
@@ -213,9 +214,22 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    const size_t k = second_order == 2 ? 0 : (second_order ? out_doubles(h) : (size_t)2 * n + (size_t)n * D);
-    memcpy(out_host, sv.out, k * sizeof(double));
-    if (second_order == 2) out_host[0] = (double)sv.reply[2 * SR_SERVER_ALIVE] * 1e-2;      // us of the last evaluation on the device
+    if (second_order == 2) {
+        out_host[0] = (double)sv.reply[2 * SR_SERVER_ALIVE] * 1e-2;      // us of the last evaluation on the device
+    } else {
+        // per-output records -> the API layout [mu n | var n | jac_mu n x D | jac_var n x D | hess n x D x D]
+        const int DD = D * D;
+        for (int d = 0; d < n; ++d) {
+            const double* r = sv.out + (size_t)d * SR_SERVER_REC;
+            out_host[d] = r[0];
+            out_host[n + d] = r[1];
+            for (int j = 0; j < D; ++j) out_host[2 * n + d * D + j] = r[2 + j];
+            if (second_order) {
+                for (int j = 0; j < D; ++j) out_host[2 * n + n * D + d * D + j] = r[2 + D + j];
+                for (int q = 0; q < DD; ++q) out_host[2 * n + 2 * n * D + d * DD + q] = r[2 + 2 * D + q];
+            }
+        }
+    }
     ++sv.next_seq;
     ++sv.calls;
     return SR_OK;

@@ -203,13 +203,15 @@ int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu,
 // pinned host memory.  All pointers are the DEVICE-visible addresses of pinned host memory.
 struct sr_server_args {
     unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 5] x (D <= 6 doubles), [6] command, [7] sequence number (written last)
-    double* out;                     // reply block [mu n | var n | jac_mu n x D | jac_var n x D | hess n x D x D]
+    double* out;                     // reply block: per output d one record of SR_SERVER_REC doubles
+                                     // [mu, var, d mu/dx (D), d var/dx (D), d2 mu/dx2 (D x D)]
     unsigned long long* reply;       // [d]: sequence number last answered by output d; [SR_SERVER_ALIVE + d]: 1 while it runs;
                                      // [2 SR_SERVER_ALIVE + d]: device ticks (100 MHz) of the last evaluation
     unsigned long long first_seq;    // the first sequence number this launch answers
     unsigned long long idle_ticks;   // leave after this long without a request (100 MHz wall clock)
 };
 #define SR_SERVER_ALIVE 16
+#define SR_SERVER_REC 40          /* doubles per output record in the reply block (2 + 2 D + D^2 <= 37 for D <= 5) */
 #define SR_SERVER_CMD_FIRST 0ull     /* mu, var, d mu/dx */
 #define SR_SERVER_CMD_SECOND 1ull    /* + d var/dx, d2 mu/dx2 */
 #define SR_SERVER_CMD_STOP 2ull

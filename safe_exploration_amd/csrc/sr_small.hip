@@ -528,19 +528,48 @@ __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, s
             int tq = tid;
             asm volatile("" : "+s"(pW), "+v"(tq));
             sr_kstar_args a{};
-            a.sf2 = m.sf2; a.ls = m.ls;
+            a.sf2 = m.sf2;
             a.lda = D; a.na = D; a.N = m.N; a.Np = NP; a.D = D; a.n_out = n; a.nsplit = 1; a.T = 1; a.Tp = 1;
             sr_small_phase_a<NP, DT, true, true, 16>(a, d, xreq, D, xreq, D, 1, L, &rows, tq);
             if constexpr (REGS) sr_srv_contract<NP>(frag, L.ks, L.pB, L.redC, tq >> 6, tq & 63);
             else sr_small_contract<NP, true>(pW + (long)d * NP * NP, L.ks, L.pB, L.redC, tq >> 6, tq & 63);
-            sr_small_outputs<NP, DT, true>(a, L, d, 0, sf2, out, out + n, out + 2 * n, out + 2 * n + n * D, out + 2 * n + 2 * n * D, tq);
         }
-        __threadfence_system();
-        __syncthreads();                                                   // (also: everybody is through with req_cmd / xreq)
-        if (tid == 0) {
-            // (diagnostics: ticks of the 100 MHz clock this evaluation took on the device, request seen -> results fenced)
-            sv.reply[2 * SR_SERVER_ALIVE + d] = wall_clock64() - t_seen;
-            __hip_atomic_store(sv.reply + d, expect, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // The answer of this output is ONE record [mu, var, d mu/dx (D), d var/dx (D), d2 mu/dx2 (D x D)] of 2 + 2 D + D^2 <= 37
+        // doubles: lane e of the first wavefront forms element e and ONE store instruction carries the record to the pinned
+        // reply block (scattered over the API layout, five store instructions to host memory cost 4 us of the 8).
+        if (wave == 0) {
+            constexpr int NSTRIP = NP / 16;
+            const int e = lane, R = 2 + 2 * D + D * D;
+            const double mval = L.Rs[0][0];
+            double val = 0.0;
+            if (e == 0) val = mval;
+            else if (e < 2 + D) {
+                if (e >= 2) val = L.Rs[1 + (e - 2)][0];
+            } else if (e < 2 + 2 * D) {
+            } else if (e < R) {
+                const int q = e - (2 + 2 * D);
+                const int j = min(q / D, q % D), l = max(q / D, q % D);
+                val = (L.Rs[1 + j][1 + l] - L.xq[0][l] * L.Rs[1 + j][0]) * il_[l];
+                if (j == l) val -= mval * il_[j] * il_[j];
+            }
+            // var (element 1) and d var/dx_j (elements 2 + D + j): column c = 0 resp. 1 + j of the strip sums
+            const int c = (e == 1) ? 0 : ((e >= 2 + D && e < 2 + 2 * D) ? e - (2 + D) + 1 : -1);
+            if (c >= 0) {
+                double qn = 0.0;
+#pragma unroll
+                for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += L.redC[sidx][c];
+                if (c == 0) {
+                    val = sf2 - qn;
+                    if (!(val > SR_VAR_CLIP)) val = SR_VAR_CLIP;
+                } else val = -2.0 * qn;
+            }
+            if (e < R) out[(long)d * SR_SERVER_REC + e] = val;
+            __threadfence_system();
+            if (lane == 0) {
+                // (diagnostics: ticks of the 100 MHz clock this evaluation took on the device, request seen -> results fenced)
+                sv.reply[2 * SR_SERVER_ALIVE + d] = wall_clock64() - t_seen;
+                __hip_atomic_store(sv.reply + d, expect, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         ++expect;
     }

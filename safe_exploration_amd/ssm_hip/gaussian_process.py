@@ -24,6 +24,8 @@ from .. import _buffers as B
 from .._lib import lib, check
 from ..state_space_models import StateSpaceModel
 
+_server_call = lib.sr_gp_server_call
+
 GPY_JITTER = 1e-8   # GPy's exact inference adds this to diag(K) (from knowledge of GPy; unverifiable here)
 
 
@@ -37,6 +39,7 @@ class _Handle(object):
         check(lib.sr_gp_create(ctypes.byref(self.h), device.index, N, D, n_out))
         self.N, self.D, self.n_out = N, D, n_out
         self.shared = False              # set when a deep copy of the model holds this handle too
+        self._server_armed = False       # SimpleGPModel.start_server
         npad = ctypes.c_long(0)
         check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
         self.Np = npad.value
@@ -111,10 +114,10 @@ class _Handle(object):
         """One blocking single query through the RESIDENT server (sr_gp_server_call: the query in the pinned input block
         goes into the mailbox the resident workgroups poll; no launch).  Returns the first k doubles of the packed result,
         or None where no server is armed for this model (``SimpleGPModel.start_server``)."""
-        if not getattr(self, "_server_armed", False):
+        if not self._server_armed:
             return None
         io = self._single_io
-        rc = lib.sr_gp_server_call(self.h, io["p_in"], second_order, io["p_srv"], 5.0)
+        rc = _server_call(self.h, io["p_in"], second_order, io["p_srv"], 5.0)
         if rc != 0:
             if rc != -5:                       # anything but SR_EUNSUPPORTED is an error of this call
                 check(rc)
@@ -820,12 +823,13 @@ class SimpleGPModel(StateSpaceModel):
         if states.shape[1] + actions.shape[1] != D:
             raise ValueError("states and actions must have {} columns together".format(D))
         io = hd.single_io()
-        stream = torch.cuda.current_stream(hd.device)
         io["h_in_np"][:states.shape[1]] = states[0]
         io["h_in_np"][states.shape[1]:] = actions[0]
-        o = hd.server_call(0, 2 * n + n * D)
-        if o is None:
-            o = hd.call1(0, 2 * n + n * D, stream)
+        o = hd.server_call(0, 2 * n + n * D)          # the resident server, where one is armed: no launch, no stream
+        if o is not None:
+            return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
+        stream = torch.cuda.current_stream(hd.device)
+        o = hd.call1(0, 2 * n + n * D, stream)
         if o is not None:
             return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
@@ -878,12 +882,13 @@ class SimpleGPModel(StateSpaceModel):
         if x.size != D:
             raise ValueError("x must have {} entries".format(D))
         io = hd.single_io()
-        stream = torch.cuda.current_stream(hd.device)
         a, b, c = 2 * n, 2 * n + n * D, 2 * n + 2 * n * D
         io["h_in_np"][:] = x
-        o = hd.server_call(1, io["d_out"].numel())
-        if o is None:
-            o = hd.call1(1, io["d_out"].numel(), stream)
+        o = hd.server_call(1, c + n * D * D)
+        if o is not None:
+            return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
+        stream = torch.cuda.current_stream(hd.device)
+        o = hd.call1(1, io["d_out"].numel(), stream)
         if o is not None:
             return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
         io["d_in"].copy_(io["h_in"].view(1, D), non_blocking=True)
