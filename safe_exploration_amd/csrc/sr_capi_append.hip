@@ -84,7 +84,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
     // one point on a small model: the whole append is ONE launch (sr_append1_small_kernel)
-    const bool fused1 = m == 1 && Np0 <= 512 && Np1 <= 640 && h->small_path != 0;
+    const bool fused1 = m == 1 && Np0 <= SR_APPEND1_MAX_NP0 && Np1 <= SR_APPEND1_MAX_NP0 + SR_NB && h->small_path != 0;
     if (fused1) {
         SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
                                      Znew, Ynew, Wt1, alpha1, yT1,

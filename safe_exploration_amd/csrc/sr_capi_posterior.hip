@@ -101,8 +101,8 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
     const int ncb = (h->Np + 255) / 256;
     // 2 .. 4 queries on a moderate model: the one-launch VALU kernel has only ncb (ncb + 1) n_out workgroups of 256
     // threads there and loses to K1 + MFMA kernel + reduce (N = 700: 27 against 21 us; N = 3000: 34 against 40 us)
-    const bool mfma_small = Tc >= 2 && Tc <= 4 && h->Np <= 2048;
-    const bool fused = !h->general && h->D <= 5 && Tc <= 4 && !mfma_small;
+    const bool mfma_small = Tc >= 2 && Tc <= 4 && h->Np <= SR_MFMA_SMALL_MAX_NP;
+    const bool fused = !h->general && h->D <= SR_STREAM_FUSED_MAX_D && Tc <= 4 && !mfma_small;
     const int nsplit = fused ? 2 * ncb : pick_nsplit(h, Tp);
     SR_TRY(ensure_ws(h, Tp, std::max(nsplit, 2 * ncb)));
     SR_TRY(stream_buffers(h, mfma_small ? 16 : (int)Tc, s));
@@ -132,7 +132,7 @@ static int stream_linearize(sr_gp* h, const double* x, double* mu, double* var, 
                             double* hess_mu, hipStream_t s) {
     const long Tp = srt::BN;
     const int ncb = (h->Np + 255) / 256, ncols = 1 + h->D;
-    const bool fused = !h->general && h->D <= 3;
+    const bool fused = !h->general && h->D <= SR_LIN_FUSED_MAX_D;
     SR_TRY(ensure_ws(h, Tp, std::max(pick_nsplit(h, Tp), 2 * ncb)));
     SR_TRY(stream_buffers(h, ncols, s));
     const int nblk256 = (h->Np + 255) / 256;
@@ -172,7 +172,7 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
     // (ONE query against Np = 384: the one-launch pass is a single workgroup per output that fetches 590 KB of U^-1 on its
     //  own, 18.8 us; the streamed route spreads them over 6 workgroups per output: 12.4 us.  From 4 queries on the two
     //  are level, and 16 queries share one fetch in the one-launch pass.)
-    const bool one_streamed = h->Np == 384 && Tc == 1 && !h->general && h->D <= 5;
+    const bool one_streamed = h->Np == SR_ONE_STREAMED_NP && Tc == 1 && !h->general && h->D <= SR_STREAM_FUSED_MAX_D;
     if (h->small_path == 1 && !h->force_stream && !one_streamed && sr_gp_small_wanted(h->Np, Tc, h->D, h->general != 0)) {
         // small model, few queries: one launch, no workspace (sr_small.hip)
         sr_kstar_args ka{};

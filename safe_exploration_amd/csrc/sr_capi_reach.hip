@@ -143,7 +143,7 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
     // 960 rollouts: 454 against 413 us).
     // (one or two steps: a second launch costs what the per-step route's two launches per step cost -- N = 200, H = 1,
     //  960 rollouts: 29 against 24 us)
-    const long chain_max_launches = H <= 2 ? 1 : (T > SR_FUSED_T ? 6 : 2);
+    const long chain_max_launches = sr_chain_max_launches(T, H);
     if (h->chain && h->small_path == 1 && !h->force_stream && !h->general && h->n_xin == 0 &&
         chain_launches <= chain_max_launches &&
         sr_chain_supported(h->Np, h->D, n_s, n_u, H)) {

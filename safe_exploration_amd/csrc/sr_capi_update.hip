@@ -90,7 +90,7 @@ static int pick_fact_panel(const sr_gp* h) {
     // 574; N = 50000 (8 / 12 / 16 / 24) 2.599 / 2.580 / 2.570 / 2.555 s
     // with the in-panel updates of long K on 128-tiles (sr_use_tile64): N = 30000 panels of 12 / 16 / 24 / 32: 565 / 562 / 561 / 562 ms;
     // N = 50000 panels of 24 / 32 / 48: 2.521 / 2.514 / 2.508 s
-    return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 24 : 48))));
+    return sr_fact_panel(nb);                       // (the table of sr_common.h)
 }
 
 // Streams of the factorisation.  The chain of diagonal blocks is latency-bound and must never queue behind the
@@ -148,7 +148,7 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
     // instead of 12 us each) and the trailing update has the slack (measured, reserve 32 / 64: N = 3500 2.79 / 2.80,
     // N = 5000 5.14 / 4.99, N = 6500 8.79 / 8.74, N = 7500 12.17 / 12.45, N = 10000 25.1 / 26.7 ms)
     const int nblk = h->Np / SR_NB;
-    const int reserve = regime == 2 ? 8 : ((nblk > 36 && nblk <= 52) ? 2 * SR_FACT_RESERVED_CUS : SR_FACT_RESERVED_CUS);
+    const int reserve = sr_fact_reserved_cus(regime, nblk);
     const int key = regime * 1000 + reserve;
     if (h->fact_regime != key) drop_fact_streams(h);
     if (!h->fact_stream) {
@@ -248,7 +248,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_FH(hipMemsetAsync(info_dev, 0, sizeof(int) * h->n_out, s0));
     if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
     SR_FH(hipEventRecord(h->fact_fork, s0));
-    const int regime = nb <= 128 ? 1 : 2;
+    const int regime = nb <= SR_FACT_CHAIN_MAX_NB ? 1 : 2;
     SR_F(ensure_fact_streams(h, regime));
     lap("streams");
     static const bool no_early_inv = getenv("SR_FACT_NO_EARLY_INV") != nullptr;

@@ -193,7 +193,6 @@ struct sr_kstar_args {
 int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s);
 
 // K0 (sr_small.hip): whole posterior of a small ARD-RBF model in one launch, outputs in the API layout
-bool sr_gp_small_wanted(int Np, long T, int D, bool general);
 int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
                        hipStream_t s);
 int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac_mu,
@@ -217,7 +216,6 @@ struct sr_server_args {
 #define SR_SERVER_CMD_STOP 2ull
 #define SR_SERVER_CMD_IDLE 3ull      /* (device-internal: the idle time-out) */
 #define SR_SERVER_CMD_PING 4ull      /* diagnostics: answer at once, evaluate nothing */
-bool sr_gp_server_supported(int Np, int D);
 int sr_launch_gp_server(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s);
 
 // Persistent multi-step kernel (sr_small.hip): the whole H-step chain of up to SR_CHAIN_GROUPS / (n_out Np / 128) * 16
@@ -260,24 +258,20 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
                   int group, int variant, hipStream_t s, long Tw = 0);
 
 // 64 x 64 tile variant for small models (sr_predict.hip, K2m): part layout [d][Np/64][Tp]
-bool sr_var64_wanted(int Np, long Tp, int n_out);
 int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                     hipStream_t s);
 
 // XCD-partitioned form of the same regime (sr_var_xcd.hip, K2x): k slabs per XCD, one workgroup per CU, four LDS stages
-#define SR_VAR_XCD_MIN_CELLS 512     /* (row block, k-block, query tile, output) cells from which K2x is taken */
 bool sr_var_xcd_wanted(int N, int Np, long Tp, int n_out);
 long sr_var_xcd_ws(int Np, long Tp, int n_out);
 int sr_launch_var_xcd(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
                       hipStream_t s);
 // split-K form of the variance kernel for few query tiles (sr_predict.hip, K2k)
 // balanced form of the same regime (equal shares of the k-blocks + a reduce pass, K2b): workspace doubles; part layout of K2k
-bool sr_var_bal_wanted(int Np, long Tp, int n_out);
 long sr_var_bal_ws(int Np, long Tp, int n_out);
 int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
                       hipStream_t s);
 long sr_var_splitk_ws(int Np, long Tp, int n_out);
-bool sr_var_splitk_wanted(int Np, long Tp, int n_out);
 int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,
                          long Tp, int n_out, hipStream_t s);
 
@@ -290,8 +284,101 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #endif
 #define SR_STREAM_MAX_T 64     /* up to here a batch beyond the one-launch sizes streams U^-1 once (sr_stream.hip) */
 #define SR_FINAL_WAVE_T 4096   /* up to here sr_finalize runs one wavefront per (query, output) */
+
+// ================================================================================================================
+// DISPATCH TABLE -- every size threshold by which the host side picks a kernel, in one place, with the measurement that
+// set it (profiles/<round>_<file>; "r1d" .. "r04" = the round that measured it, MI355X).  Np = padded training points
+// (multiple of 128), T = queries of one call, Tp = T padded to 128, D = GP input dimension, nb = Np / 128.
+//
+//  posterior of ONE call (sr_capi_posterior.hip: gp_pass)
+//   K0  one launch (sr_small.hip)            Np <= SR_FUSED_NP (512), T <= SR_FUSED_T (1024), D <= 8; not Np = 512 with
+//                                            T <= 128 (streamed: 22-23 against 28 us, r02_latency_grid), not Np = 384 with T = 1
+//                                            (SR_ONE_STREAMED_NP: 12.4 against 18.8 us, r02_latency_grid)
+//   K2f streamed, fused (sr_stream.hip)      Np > SR_STREAM_MIN_NP (384), T <= SR_STREAM_MAX_T (64): N = 5000 T = 1 54 -> 37 us, T = 64
+//                                            143 -> 111 us (r02 / r03_latency_grid); one launch for T <= 4 with D <= 5 unless
+//                                            2 <= T <= 4 and Np <= SR_MFMA_SMALL_MAX_NP (2048): N = 700 27 against 21 us, N = 3000 34 / 40
+//   K2s streamed, groups of 16               T <= 16 x sr_var_small_groups_max (300 MB of re-read U^-1): N = 700 T = 128 41 -> 25 us,
+//                                            N = 2000 71 -> 40 us, from N = 3000 on the tiles win (r01d_latency_grid)
+//   K2b balanced shares (sr_predict.hip)     sr_var_splitk_wanted (nb > 2, <= 1024 plain workgroups) and >= 256 cells
+//                                            (sr_var_bal_wanted); 256 workgroups, 512 from 2304 cells on (r03_splitk_ab, r03_streamk)
+//   K2x XCD slabs (sr_var_xcd.hip)           OPTIONAL (sr_gp_set_small_path + 16): -21 % fabric bytes, time as K2b (r04_xcd_ablation)
+//   K2k split-K chunks                       the rest of sr_var_splitk_wanted; chunk size by splitk_kcb (<= 768 workgroups)
+//   K2m 64 x 64 tiles                        sr_var64_wanted: Np <= 1024 and < 256 plain workgroups (N = 200: 60 -> 31-37 us, r01d)
+//   K2  plain 128 x 128 tiles                everything else (the benchmark regime: 0.89-0.90 of the fp64 MFMA peak, r03_kernel_stats)
+//   K3  final stage                          one wavefront per (query, output) up to SR_FINAL_WAVE_T (4096) queries (44 -> 9.8 us at
+//                                            N = 5000, T = 1, r01d); K1 splits N down to 16 rows per workgroup there (26.6 -> 8.7 us)
+//  single blocking query (host entry points)
+//   K0s resident server (sr_capi_server.hip) sr_gp_server_supported: Np <= 384 with D <= 5, Np = 512 with D <= 3 (the others spill);
+//                                            U^-1 fragments in registers at Np = 128: __call__ 21.6 -> 9.6 us (r04_call_latency)
+//   one command (sr_gp_call1)                where K0 applies (Np <= 384; 512 with second order): 26.4 us at N = 200 (r03_call_latency)
+//  second order of one query (sr_gp_linearize)  K0 LIN up to Np = 384 (18 us at N = 200), streamed above: one launch for D <= 3
+//                                            (SR_LIN_FUSED_MAX_D): N = 5000 61 -> 51 us (r02_latency_grid)
+//  multi-step chains (sr_capi_reach.hip)     persistent kernel K0c up to SR_CHAIN_GROUPS workgroups (device CUs - 16 at most),
+//                                            1 launch for H <= 2, <= 2 launches for T <= 1024, <= 6 beyond (N = 200 H = 15: 1024
+//                                            rollouts 203 against 253 us, 4096 in six launches 608 / 722, r03_chain_bench); one-step
+//                                            through it for n_s <= 2 (24.5 -> 21.5 us; n_s >= 3: 25 -> 35 us)
+//  model update (sr_capi_update.hip)         panels of sr_fact_panel(nb) blocks (r03_factor_bench and the comment there); streams:
+//                                            regime 1 up to SR_FACT_CHAIN_MAX_NB (128) blocks -- bulk stream without 32 CUs (64 for
+//                                            36 < nb <= 52: N = 5000 5.14 -> 4.99 ms) --, regime 2 beyond (8 CUs for the diagonal
+//                                            blocks); early inversion from nb >= 8; GEMM tile: sr_use_tile64* (sr_factor.hip)
+//  row append (sr_capi_append.hip)           one launch for +1 point with Np <= 512 (SR_APPEND1_MAX_NP0, r03_exploration_step), <= 16
+//                                            points matrix-vector shaped, 17 .. 128 on the MFMA tile (r03_append_bench); the Python layer
+//                                            appends up to N / 5 points and refactorises beyond (break-even r03_growing_model)
+// ================================================================================================================
+#define SR_ONE_STREAMED_NP 384       /* ONE query at this padded size takes the streamed kernel, not K0 */
+#define SR_MFMA_SMALL_MAX_NP 2048    /* 2 .. 4 queries up to here: K1 + MFMA streaming kernel instead of the one-launch VALU kernel */
+#define SR_STREAM_FUSED_MAX_D 5      /* one-launch streamed predict (T <= 4) evaluates its own K* columns up to this D */
+#define SR_LIN_FUSED_MAX_D 3         /* one-launch streamed linearize up to this D */
+#define SR_FACT_CHAIN_MAX_NB 128     /* model update: up to here the chain of diagonal blocks bounds it (stream regime 1) */
+#define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch up to this padded size (the grown model: <= 640) */
+#define SR_VAR_XCD_MIN_CELLS 512     /* (row block, k-block, query tile, output) cells from which the optional K2x applies */
+
+static inline bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
+    (void)general;   // ARD-RBF and the general family both have a one-launch kernel
+    if (Np == 512 && T <= 128) return false;  // measured: streaming U^-1 (K2s, groups of 16 queries) 22-23 us against 28 us here
+    return Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
+}
+// D <= 5 (pendulum: 3, cart-pole: 4 or 5), and D <= 3 at 512 padded points: the other instantiations spill (16 - 60 B of
+// scratch per lane) and are not built
+static inline bool sr_gp_server_supported(int Np, int D) { return Np % 128 == 0 && Np <= SR_FUSED_NP && D <= (Np == 512 ? 3 : 5); }
+// 64 x 64 tiles: profitable when the model is small and the 128-tile grid would leave most of the chip idle
+static inline bool sr_var64_wanted(int Np, long Tp, int n_out) {
+    const long wgs128 = (long)(Np / SR_NB) * (Tp / SR_NB) * n_out;
+    return Np <= 1024 && wgs128 < 256;
+}
+// split-K / balanced shares: profitable when the plain kernel cannot fill the chip and there is a K range to split
+static inline bool sr_var_splitk_wanted(int Np, long Tp, int n_out) {
+    const int nrb = Np / SR_NB;
+    const long wgs = (long)nrb * (Tp / SR_NB) * n_out;
+    return nrb > 2 && wgs <= 1024;
+}
+// (below 256 cells the chunks of K2k are as good)
+static inline bool sr_var_bal_wanted(int Np, long Tp, int n_out) {
+    const long nrb = Np / SR_NB;
+    return (long)n_out * (Tp / SR_NB) * nrb * (nrb + 1) / 2 >= 256;
+}
+// workgroups of the balanced launch: one per CU, two once there are nine cells for each of them (measured, G = 256 against
+// 512, n_out = 2: N = 4000 T = 128 (U = 1056) 120 / 137 us, N = 5000 T = 128 (1640) 158 / 161, T = 256 (3280) 257 / 263, N = 4500
+// T = 256 (2664) 222 / 216, N = 3000 T = 512 (2400) 204 / 198, N = 5000 T = 512 (6560) 476 / 451; 384 or 768 workgroups --
+// shares that do not line up with the residency of the chip -- lose 15 - 25 %)
+static inline long sr_var_bal_wgs(long U) { return U >= 2304 ? 512 : (U >= 256 ? 256 : U); }
+// The MFMA streaming kernel also serves 17 .. 1024 queries as groups of 16 (every group re-reads U^-1 from
+// L2 / Infinity Cache) as long as that stays cheap: n_out Np^2/2 8 B x groups <= 300 MB.  Measured at N = 700,
+// T = 128: 41 -> 25 us against the split-K tiles; N = 2000: 71 -> 40 us; from N = 3000 on the tiles win.
+static inline int sr_var_small_groups_max(int Np, int n_out) {
+    const double bytes = (double)n_out * Np * (double)Np * 4.0;
+    int g = (int)(300e6 / bytes);
+    if (g > 64) g = 64;
+    return g < 1 ? 1 : g;
+}
+// blocks per Cholesky panel by the number of 128-blocks (measurements: sr_capi_update.hip, pick_fact_panel)
+static inline int sr_fact_panel(int nb) { return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 24 : 48)))); }
+// CUs the bulk streams of the model update leave to the critical chain (regime 1: one per shader engine, two for 36 < nb
+// <= 52; regime 2: one per XCD for the diagonal blocks)
+static inline int sr_fact_reserved_cus(int regime, int nb) { return regime == 2 ? 8 : ((nb > 36 && nb <= 52) ? 64 : 32); }
+// launches of the persistent chain kernel a batch of T rollouts over H steps may take before the per-step route is better
+static inline long sr_chain_max_launches(long T, int H) { return H <= 2 ? 1 : (T > SR_FUSED_T ? 6 : 2); }
 long sr_var_small_ws(int Np, int n_out);
-int sr_var_small_groups_max(int Np, int n_out);   // query groups of 16 the streaming path may take (1 .. 8)
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,
                         long Tp, int n_out, int T, hipStream_t s, int dot0 = 0, bool reduce = true);
 

@@ -103,7 +103,6 @@ struct sr_gp {
     sr_prof prof;
 };
 #define SR_FACT_PAR_BYTES ((size_t)8 << 30)
-#define SR_FACT_RESERVED_CUS 32     // CU-mask bits the bulk streams of the factorisation leave out (1 CU per shader engine)
 
 // every entry point runs on the handle's device and leaves the caller's current device as it found it
 // (PyTorch reads its current device from the HIP runtime)

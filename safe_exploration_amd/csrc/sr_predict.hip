@@ -427,12 +427,6 @@ __global__ __launch_bounds__(256) void sr_var64_kernel(const double* __restrict_
     if (tid < SR_T64) part[((long)d * nrb + rb) * Tp + (long)x * SR_T64 + tid] = red[0][tid] + red[1][tid];
 }
 
-// profitable when the model is small and the 128-tile grid would leave most of the chip idle
-bool sr_var64_wanted(int Np, long Tp, int n_out) {
-    const long wgs128 = (long)(Np / srt::BM) * (Tp / srt::BN) * n_out;
-    return Np <= 1024 && wgs128 < 256;
-}
-
 int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                     hipStream_t s) {
     const int k_beg = ((Np - N) / 16) * 16;
@@ -524,13 +518,6 @@ long sr_var_splitk_ws(int Np, long Tp, int n_out) {
     const int kcb = splitk_kcb(Np, Tp, n_out);
     const int maxch = (nrb + kcb - 1) / kcb;
     return (long)n_out * nrb * (Tp / srt::BN) * maxch * srt::BM * srt::BN;
-}
-
-// profitable when the plain kernel cannot fill the chip and there is a K range to split
-bool sr_var_splitk_wanted(int Np, long Tp, int n_out) {
-    const int nrb = Np / srt::BM;
-    const long wgs = (long)nrb * (Tp / srt::BN) * n_out;
-    return nrb > 2 && wgs <= 1024;
 }
 
 int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,
@@ -702,26 +689,16 @@ __global__ __launch_bounds__(256) void sr_var_bal_reduce_kernel(const double* __
     if (tid < 128) part[((long)d * 4 * nrb + rb * 4 + mi) * Tp + (long)x * srt::BN + tid] = red[tid] + red[128 + tid];
 }
 
-// workgroups of the launch: one per CU, two once there are nine blocks for each of them (measured, G = 256 against 512,
-// n_out = 2: N = 4000 T = 128 (U = 1056) 120 / 137 us, N = 5000 T = 128 (1640) 158 / 161, T = 256 (3280) 257 / 263, N = 4500
-// T = 256 (2664) 222 / 216, N = 3000 T = 512 (2400) 204 / 198, N = 5000 T = 512 (6560) 476 / 451; 384 or 768 workgroups --
-// shares that do not line up with the residency of the chip -- lose 15 - 25 %)
-static long bal_wgs(long U) { return U >= 2304 ? 512 : (U >= 256 ? 256 : U); }
 long sr_var_bal_ws(int Np, long Tp, int n_out) {
     const long nrb = Np / srt::BM;
-    return bal_wgs((long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2) * 2 * (long)(srt::BM * srt::BN);
-}
-// (below 256 blocks the chunks of K2k are as good)
-bool sr_var_bal_wanted(int Np, long Tp, int n_out) {
-    const long nrb = Np / srt::BM;
-    return (long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2 >= 256;
+    return sr_var_bal_wgs((long)n_out * (Tp / srt::BN) * nrb * (nrb + 1) / 2) * 2 * (long)(srt::BM * srt::BN);
 }
 int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
                       hipStream_t s) {
     const int k_beg = ((Np - N) / srt::BK) * srt::BK;
     const int nrb = Np / srt::BM, ntq = (int)(Tp / srt::BN);
     const long U = (long)n_out * ntq * nrb * (nrb + 1) / 2;
-    const long G = bal_wgs(U);
+    const long G = sr_var_bal_wgs(U);
     hipLaunchKernelGGL(sr_var_bal_kernel, dim3((unsigned)G), dim3(256), 0, s, Wt, Ks, Vt, part, Np, Tp, nrb, ntq, k_beg, U);
     SR_HIP(hipGetLastError());
     hipLaunchKernelGGL(sr_var_bal_reduce_kernel, dim3(4, n_out * ntq * nrb), dim3(256), 0, s, Vt, part, Tp, nrb, ntq, U, G);
@@ -945,16 +922,6 @@ int sr_launch_var_small_gather(const double* Vp, double* v, int Np, int n_out, i
 long sr_var_small_ws(int Np, int n_out) {
     const int ncb = (Np + 255) / 256;
     return (long)n_out * ncb * (ncb + 1) * SR_TS * 256 * sr_var_small_groups_max(Np, n_out);
-}
-
-// The MFMA streaming kernel also serves 17 .. 1024 queries as groups of 16 (every group re-reads U^-1 from
-// L2 / Infinity Cache) as long as that stays cheap: n_out Np^2/2 8 B x groups <= 300 MB.  Measured at N = 700,
-// T = 128: 41 -> 25 us against the split-K tiles; N = 2000: 71 -> 40 us; from N = 3000 on the tiles win.
-int sr_var_small_groups_max(int Np, int n_out) {
-    const double bytes = (double)n_out * Np * (double)Np * 4.0;
-    int g = (int)(300e6 / bytes);
-    if (g > 64) g = 64;
-    return g < 1 ? 1 : g;
 }
 
 int sr_launch_var_small(const double* Wt, const double* Ks, double* Vp, double* part, int N, int Np,

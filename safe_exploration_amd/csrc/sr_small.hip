@@ -576,10 +576,6 @@ __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, s
     if (tid == 0) __hip_atomic_store(sv.reply + SR_SERVER_ALIVE + d, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// D <= 5 (pendulum: 3, cart-pole: 4 or 5), and D <= 3 at 512 padded points: the other instantiations spill (16 - 60 B of
-// scratch per lane) and are not built
-bool sr_gp_server_supported(int Np, int D) { return Np % 128 == 0 && Np <= SR_FUSED_NP && D <= (Np == 512 ? 3 : 5); }
-
 template <int NP>
 static int launch_server_np(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s) {
     dim3 grid(1, a.n_out);
@@ -1251,11 +1247,6 @@ __global__ __launch_bounds__(1024) void sr_gp_small_general_kernel(sr_kstar_args
     }
 }
 
-bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
-    (void)general;   // ARD-RBF and the general family both have a one-launch kernel
-    if (Np == 512 && T <= 128) return false;  // measured: streaming U^-1 (K2s, groups of 16 queries) 22-23 us against 28 us here
-    return Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
-}
 
 template <int NP>
 static int launch_small_np(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,

@@ -9,18 +9,15 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from safe_exploration_amd import SimpleGPModel, workload, _buffers as B  # noqa: E402
 
 
+from _timing import timeit as _timeit  # noqa: E402  (median of batches)
+
+
 def t(fn, n=300):
-    for _ in range(20):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e6
+    return _timeit(fn, n=n, warmup=20)
 
 
 SIZES = ((2, 25), (2, 100), (4, 150), (2, 200), (2, 350), (2, 500), (2, 1000), (2, 2000), (2, 5000))
@@ -49,12 +46,7 @@ def cpu_time(prob, second_order, reps=200):
 
 
 def t_host(fn, n=300):
-    for _ in range(20):
-        fn()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    return (time.perf_counter() - t0) / n * 1e6
+    return _timeit(fn, n=n, warmup=20, sync=False)
 
 
 def main():

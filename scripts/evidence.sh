@@ -4,25 +4,26 @@
 # trace + PMC passes of the headline bench, kernel trace of the C4 model update).  Copy to profiles/ with
 #   python scripts/summarize_rocpd.py gpurun_out/prof_<tag> profiles/<tag> c2p   and   cp gpurun_out/ev_<tag>/* profiles/
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 REPO=$(pwd)
 EV=$REPO/gpurun_out/ev_$TAG
 mkdir -p "$EV"
 ulimit -c 0
 line() { tail -n 1; }
 timeout 600 python bench.py 2>"$EV/.err" | line > "$EV/${TAG}_bench_c2p.json"
-timeout 300 python bench.py --workload c2 --no-cpu-baseline 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c2.json"
-timeout 300 python bench.py --workload c3 --no-cpu-baseline --steps 3 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c3.json"
-timeout 300 python bench.py --workload c5 --no-cpu-baseline --steps 2 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c5.json"
+timeout 400 python bench.py --workload c2 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c2.json"
+timeout 400 python bench.py --workload c3 --steps 3 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c3.json"
+timeout 400 python bench.py --workload c5 --steps 2 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c5.json"
 timeout 600 python bench.py --workload c4 --steps 2 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c4.json"
 timeout 300 python bench.py --workload c4 --n-train 5000 --steps 20 --warmup 3 2>>"$EV/.err" | line > "$EV/${TAG}_bench_refit5000.json"
 timeout 600 python scripts/latency_grid.py > "$EV/${TAG}_latency_grid.txt" 2>>"$EV/.err"
-timeout 300 python scripts/splitk_ab.py 1024,2000,3000,4000,5000 128,256,512,1024 > "$EV/${TAG}_splitk_ab.txt" 2>>"$EV/.err"
+timeout 300 python scripts/splitk_ab.py 2000,3000,4000,5000 128,256,512,1024 > "$EV/${TAG}_splitk_ab.txt" 2>>"$EV/.err"
 timeout 300 python scripts/factor_bench.py > "$EV/${TAG}_factor_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/append_bench.py > "$EV/${TAG}_append_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/chain_bench.py > "$EV/${TAG}_chain_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/onestep_bench.py > "$EV/${TAG}_onestep_bench.txt" 2>>"$EV/.err"
 timeout 600 python scripts/fuzz_chain.py 60 4 > "$EV/${TAG}_fuzz_chain.txt" 2>>"$EV/.err"
+timeout 600 python scripts/fuzz_predict.py > "$EV/${TAG}_fuzz_predict.txt" 2>>"$EV/.err"
 timeout 300 python scripts/diag_bench.py > "$EV/${TAG}_diag_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/call_latency.py > "$EV/${TAG}_call_latency.txt" 2>>"$EV/.err"
 timeout 300 python scripts/linearize_bench.py > "$EV/${TAG}_linearize_bench.txt" 2>>"$EV/.err"
