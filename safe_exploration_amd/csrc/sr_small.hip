@@ -173,7 +173,10 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
     // (query width 8 in the one-launch kernels: 1024 threads = 128 registers per lane; four hoisted steps of 9 doubles each
     //  beside xs / il made the LIN instantiations spill: 20 .. 116 B per lane)
     constexpr int HC1 = (NW == 16 && DT >= 8 && HC0 > 2 && KSA % 2 == 0) ? 2 : HC0;
-    constexpr int HC = (NW == 16 || HC1 <= SR_CHAIN_HC) ? HC1 : ((KSA % SR_CHAIN_HC == 0) ? SR_CHAIN_HC : (KSA % 3 == 0 ? 3 : 2));
+    // (the resident server -- KEEP with 16 wavefronts -- reads its rows from LDS: one step at a time costs nothing there
+    //  and keeps the D = 5 instantiations inside 128 registers)
+    constexpr int HC = (KEEP && NW == 16) ? 1
+                     : ((NW == 16 || HC1 <= SR_CHAIN_HC) ? HC1 : ((KSA % SR_CHAIN_HC == 0) ? SR_CHAIN_HC : (KSA % 3 == 0 ? 3 : 2)));
     static_assert(DT + 1 <= 16, "the mean/Jacobian right-hand side must fit the 16 MFMA columns");
     static_assert(NP % 128 == 0 && NP <= 512 && KSA % HC == 0 && KSA >= 1, "Np in {128, 256, 384, 512}");
     double (*ks)[SR_FQ] = L.ks;
@@ -464,7 +467,7 @@ __device__ __forceinline__ void sr_srv_contract(const sr_srv_frag<NP>& f, const 
 struct sr_server_model { const double *Z, *alpha, *ls, *sf2, *Wt; int N, D, n_out; };
 template <int NP, int DT>
 __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, sr_server_args sv) {
-    constexpr bool REGS = NP <= 128;          // U^-1 fragments in registers (Np = 256: 34 doubles per lane do not fit 128 VGPRs)
+    constexpr bool REGS = NP <= 128 && DT <= 3;   // U^-1 fragments in registers (Np = 256: 34 doubles per lane do not fit 128 VGPRs; D = 5 at Np = 128: 20 B of scratch)
     SR_SMALL_LDS_DECL(NP, DT);
     __shared__ double rows_[NP][DT + 1];      // the training rows of phase A, pre-scaled, with alpha: fetched once
     __shared__ double il_[DT];
