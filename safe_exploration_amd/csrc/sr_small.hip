@@ -380,45 +380,50 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 // Phase B with the wavefront's fragments of U^-1 held in REGISTERS across requests (NP = 128: 9 doubles per lane; the
 // strips of a wavefront and their k ranges as in sr_small_contract).  The run length of strip A is wavefront-uniform but
 // not a compile-time constant: one straight-line body per length (a branch per MFMA would serialise the LDS reads).
-template <int NP>
+template <int NP, int HELD_ = -1>
 struct sr_srv_frag {
     static constexpr int NSTRIP = NP / 16, NPAIR = NSTRIP / 2, NSPLIT = 16 / NPAIR;
     static constexpr int TOT = 4 * (NSTRIP + 1) / NSPLIT;            // k-steps (of 4 rows) of a wavefront, both strips
-    double w[TOT];
-    __device__ __forceinline__ void load(const double* __restrict__ Wd, int wave, int lane) {
+    static constexpr int HELD = HELD_ < 0 ? TOT : (HELD_ < TOT ? HELD_ : TOT);      // how many of them this object holds
+    double w[HELD];
+    __device__ __forceinline__ static const double* addr(const double* __restrict__ Wd, int wave, int lane, int u) {
         const int lk = lane >> 4, ln = lane & 15;
         const int pr = wave / NSPLIT, h = wave % NSPLIT;
         const int nA = 4 * (pr + 1) / NSPLIT;
+        const bool inA = u < nA;
+        const int sidx = inA ? pr : NSTRIP - 1 - pr;
+        const int chunk = 4 * (sidx + 1) / NSPLIT;
+        const int st = h * chunk + (inA ? u : u - nA);
+        return Wd + (long)(4 * st + lk) * NP + 16 * sidx + ln;
+    }
+    __device__ __forceinline__ void load(const double* __restrict__ Wd, int wave, int lane) {
 #pragma unroll
-        for (int u = 0; u < TOT; ++u) {
-            const bool inA = u < nA;
-            const int sidx = inA ? pr : NSTRIP - 1 - pr;
-            const int chunk = 4 * (sidx + 1) / NSPLIT;
-            const int st = h * chunk + (inA ? u : u - nA);
-            w[u] = Wd[(long)(4 * st + lk) * NP + 16 * sidx + ln];
-        }
+        for (int u = 0; u < HELD; ++u) w[u] = *addr(Wd, wave, lane, u);
     }
 };
-template <int NP, int NA>
-__device__ __forceinline__ void sr_srv_mfma(const sr_srv_frag<NP>& f, const double (*ks)[SR_FQ], int stA, int stB, int lk, int ln,
-                                            sr_d4 (&acc)[2]) {
-    constexpr int TOT = sr_srv_frag<NP>::TOT;
-    double bf[TOT];
+template <int NP, int NA, class F>
+__device__ __forceinline__ void sr_srv_mfma(const F& f, const double* __restrict__ Wd, int wave, int lane,
+                                            const double (*ks)[SR_FQ], int stA, int stB, int lk, int ln, sr_d4 (&acc)[2]) {
+    constexpr int TOT = F::TOT, HELD = F::HELD;
+    double bf[TOT], rest[TOT - HELD > 0 ? TOT - HELD : 1];
+#pragma unroll
+    for (int u = HELD; u < TOT; ++u) rest[u - HELD] = *F::addr(Wd, wave, lane, u);      // (what the object does not hold)
 #pragma unroll
     for (int u = 0; u < TOT; ++u) bf[u] = ks[4 * ((u < NA) ? stA + u : stB + (u - NA)) + lk][ln];
     sr_d4 a = {0.0, 0.0, 0.0, 0.0}, b = a;
 #pragma unroll
     for (int u = 0; u < TOT; ++u) {
-        if (u < NA) a = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf[u], a, 0, 0, 0);
-        else b = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf[u], b, 0, 0, 0);
+        const double wv = u < HELD ? f.w[u < HELD ? u : 0] : rest[u >= HELD ? u - HELD : 0];
+        if (u < NA) a = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[u], a, 0, 0, 0);
+        else b = __builtin_amdgcn_mfma_f64_16x16x4f64(wv, bf[u], b, 0, 0, 0);
     }
     acc[0] = a; acc[1] = b;
 }
 // same contract as sr_small_contract<NP, true> (DOT0: columns dotted with column 0)
-template <int NP>
-__device__ __forceinline__ void sr_srv_contract(const sr_srv_frag<NP>& f, const double (*ks)[SR_FQ], double* pB,
+template <int NP, class F>
+__device__ __forceinline__ void sr_srv_contract(const F& f, const double* __restrict__ Wd, const double (*ks)[SR_FQ], double* pB,
                                                 double (*redC)[SR_FQ], int wave, int lane) {
-    constexpr int NSTRIP = sr_srv_frag<NP>::NSTRIP, NSPLIT = sr_srv_frag<NP>::NSPLIT;
+    constexpr int NSTRIP = F::NSTRIP, NSPLIT = F::NSPLIT;
     static_assert(NSPLIT >= 2 && NSTRIP <= 16, "register-held fragments: Np <= 256");
     const int lk = lane >> 4, ln = lane & 15;
     const int pr = wave / NSPLIT, h = wave % NSPLIT;
@@ -426,7 +431,7 @@ __device__ __forceinline__ void sr_srv_contract(const sr_srv_frag<NP>& f, const 
     sr_d4 accB[2];
     const int stA = h * nA, stB = h * nB;
     switch (nA) {
-#define SRV_CASE(NA_) case NA_: if constexpr (NA_ < sr_srv_frag<NP>::TOT) sr_srv_mfma<NP, NA_>(f, ks, stA, stB, lk, ln, accB); break;
+#define SRV_CASE(NA_) case NA_: if constexpr (NA_ < F::TOT) sr_srv_mfma<NP, NA_>(f, Wd, wave, lane, ks, stA, stB, lk, ln, accB); break;
         SRV_CASE(1) SRV_CASE(2) SRV_CASE(3) SRV_CASE(4) SRV_CASE(6) SRV_CASE(8) SRV_CASE(10) SRV_CASE(12) SRV_CASE(14) SRV_CASE(16)
 #undef SRV_CASE
         default: accB[0] = accB[1] = sr_d4{0.0, 0.0, 0.0, 0.0}; break;
@@ -467,7 +472,14 @@ __device__ __forceinline__ void sr_srv_contract(const sr_srv_frag<NP>& f, const 
 struct sr_server_model { const double *Z, *alpha, *ls, *sf2, *Wt; int N, D, n_out; };
 template <int NP, int DT>
 __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, sr_server_args sv) {
-    constexpr bool REGS = NP <= 128 && DT <= 3;   // U^-1 fragments in registers (Np = 256: 34 doubles per lane do not fit 128 VGPRs; D = 5 at Np = 128: 20 B of scratch)
+    // U^-1 fragments of the wavefront (9 doubles per lane at Np = 128) in registers ACROSS requests with D <= 3 (REGS); with
+    // D = 5 that costs 20 B of scratch: there six of the nine are fetched at the START of an evaluation, so that their L2
+    // round trip runs under phase A instead of after it (EARLY).  Np = 256 has 34 per lane: neither fits beside the
+    // working set of the straight-line contraction (fetching 8 .. 16 of them early: 20 - 84 B of scratch); it reads them
+    // after phase A like the launched kernel.
+    constexpr bool REGS = NP <= 128 && DT <= 3;
+    constexpr bool EARLY = !REGS && NP <= 128;
+    constexpr int HELD = REGS ? -1 : 6;
     SR_SMALL_LDS_DECL(NP, DT);
     __shared__ double rows_[NP][DT + 1];      // the training rows of phase A, pre-scaled, with alpha: fetched once
     __shared__ double il_[DT];
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, s
     const int D = m.D, n = m.n_out;
     double* out = sv.out;
     unsigned long long expect = sv.first_seq;
-    sr_srv_frag<REGS ? NP : 128> frag;
+    sr_srv_frag<(REGS || EARLY) ? NP : 128, HELD> frag;
     {
         sr_kstar_args a0{};
         a0.Z = m.Z; a0.alpha = m.alpha; a0.ls = m.ls; a0.N = m.N; a0.Np = NP; a0.D = D; a0.n_out = n;
@@ -533,8 +545,9 @@ __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, s
             sr_kstar_args a{};
             a.sf2 = m.sf2;
             a.lda = D; a.na = D; a.N = m.N; a.Np = NP; a.D = D; a.n_out = n; a.nsplit = 1; a.T = 1; a.Tp = 1;
+            if constexpr (EARLY) frag.load(pW + (long)d * NP * NP, __builtin_amdgcn_readfirstlane(tq >> 6), tq & 63);
             sr_small_phase_a<NP, DT, true, true, 16>(a, d, xreq, D, xreq, D, 1, L, &rows, tq);
-            if constexpr (REGS) sr_srv_contract<NP>(frag, L.ks, L.pB, L.redC, tq >> 6, tq & 63);
+            if constexpr (REGS || EARLY) sr_srv_contract<NP>(frag, pW + (long)d * NP * NP, L.ks, L.pB, L.redC, __builtin_amdgcn_readfirstlane(tq >> 6), tq & 63);
             else sr_small_contract<NP, true>(pW + (long)d * NP * NP, L.ks, L.pB, L.redC, tq >> 6, tq & 63);
         }
         // The answer of this output is ONE record [mu, var, d mu/dx (D), d var/dx (D), d2 mu/dx2 (D x D)] of 2 + 2 D + D^2 <= 37
