@@ -506,8 +506,14 @@ extern "C" int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, do
     }
     double* out = nullptr;
     unsigned long long* flag = nullptr;
-    SR_HIP(hipHostGetDevicePointer((void**)&out, out_host, 0));
-    SR_HIP(hipHostGetDevicePointer((void**)&flag, flag_host, 0));
+    // a host block that is not device-visible here is a reason to take the launched routes with their own copies (the
+    // caller's plain-copy fall-back), not an error of this call
+    if (hipHostGetDevicePointer((void**)&out, out_host, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&flag, flag_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        sr_set_error("sr_gp_call1: the result / flag block is not device-visible pinned memory");
+        return SR_EUNSUPPORTED;
+    }
     const int n = h->n_out, D = h->D;
     sr_kstar_args ka{};
     ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _buffers as B
-from .._lib import lib, check
+from .._lib import lib, check, last_error
 from ..state_space_models import StateSpaceModel
 
 _server_call = lib.sr_gp_server_call
@@ -51,6 +51,11 @@ class _Handle(object):
                 self.h = None
         except Exception:
             pass
+
+    def Np_now(self):
+        npad = ctypes.c_long()
+        check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
+        return npad.value
 
     def single_io(self):
         """Staging of the single-query (CasADi/IPOPT callback) entry points: one pinned host block in, one
@@ -87,22 +92,26 @@ class _Handle(object):
         io = self._single_io
         if not io["mailbox"]:
             return None
+        # The library declines (SR_EUNSUPPORTED) by padded size AND by what is asked (512 padded rows: second order only):
+        # refusals are remembered per (padded size, order); a model whose padded size has changed is asked again.
+        # io["direct"] = False with no refusal on record is a switch thrown by hand (measurements).
+        so = int(bool(second_order))
         if not io["direct"]:
-            # switched off for the model as it was then (SR_EUNSUPPORTED: too large for the one-launch posterior); a
-            # model whose padded size has changed since is asked again
-            npad = ctypes.c_long()
-            check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
-            if npad.value == io.get("direct_off_np"):
+            off = io.get("direct_off")
+            if not off or (self.Np_now(), so) in off:
                 return None
-            io["direct"] = True
         io["seq"] = seq = io["seq"] + 1
         rc = lib.sr_gp_call1(self.h, io["p_in"], second_order, io["p_out"], io["p_flag"], seq, stream.cuda_stream)
         if rc != 0:
             if rc != -5:                       # anything but SR_EUNSUPPORTED is an error of this call
                 check(rc)
-            npad = ctypes.c_long()
-            check(lib.sr_gp_padded_n(self.h, ctypes.byref(npad)))
-            io["direct"], io["direct_off_np"] = False, npad.value
+            if "not device-visible" in last_error():
+                io["mailbox"] = False          # the pinned blocks are not mapped here: plain copies from now on
+            else:
+                npad = self.Np_now()
+                io.setdefault("direct_off", set()).add((npad, so))
+                io["direct_off_np"] = npad
+            io["direct"] = False
             return None
         rc = lib.sr_wait_flag(io["p_flag"], seq, 5.0)
         if rc != 0:
