@@ -133,6 +133,32 @@ def cpu_baseline_chain(prob, roll, l_mu, l_sigma, a, b, H, budget_s=12.0):
                       % (done, H, prob["Z"].shape[0], spent, fit_s)}
 
 
+def cpu_baseline_update(n_s, n_u, N, budget_s=20.0):
+    """C4: the oracle's model update (the reference route: Cholesky, explicit inverse and alpha per output with SciPy /
+    LAPACK on the host cores) on a bounded number of training points; value in TFLOP/s on the same (2/3) N^3 n_out."""
+    from oracle import oracle_np as orc
+    from safe_exploration_amd import workload
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    Ns, done, spent = min(N, 1000), 0, 0.0
+    while True:
+        prob = workload.make_problem(4, Ns, n_s, n_u, 16)
+        t0 = time.time()
+        orc.gp_fit(prob["Z"], prob["Y"], prob["lengthscale"], prob["signal_var"], prob["noise_var"] + 1e-5)
+        dt = time.time() - t0
+        done, spent = Ns, dt
+        if dt > budget_s / 4 or Ns * 2 > N:
+            break
+        Ns *= 2
+    flops = n_s * (2.0 / 3.0) * float(done) ** 3
+    return {"value": flops / spent / 1e12, "unit": "TFLOP/s", "cores": int(thr), "kind": "port",
+            "sample": "model update of N=%d training points (n_out=%d) by the NumPy/SciPy oracle (Cholesky + explicit inverse per "
+                      "output), %.2f s timed" % (done, n_s, spent)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,6 +289,8 @@ def run_model_update(args, dev, world, rank):
             "kernel_launches_per_step": {k: v[1] / prof_steps for k, v in ms.items()},
             "gemm_TFLOPs_over_gemm_ms": flops / max(gemm_ms / prof_steps, 1e-9) / 1e9,
         }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_update(n_s, n_u, N)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

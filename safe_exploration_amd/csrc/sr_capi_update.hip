@@ -123,13 +123,21 @@ static int make_masked_stream(hipStream_t* st, int ncu, int first_bit, int last_
 // them -- a priority stream and two CU-masked ones -- takes 12 - 18 ms, which every handle of a model whose size changes
 // used to pay again (a refit after a change of N: 48 ms, of which 5 were the update).  Updates of different handles that
 // share them simply queue behind each other.
-struct sr_stream_set { int device, key; hipStream_t fact, bulk, inv; };
+// ONE set per device at a time (round 4).  Sets of different keys used to pile up -- a 1000-point model (reserve 32) and
+// then a 5000-point one (reserve 64) in the same process: two priority streams and four CU-masked ones -- and the streams
+// of one priority share a small pool of hardware queues: the critical chain of the second model then shared a queue with an
+// idle stream of the first and its kernels took twice as long in situ (diagonal block 38 -> 75 us, the whole update 4.9 ->
+// 7.6 - 8.9 ms; profiles/r04_factor_bench.txt against r03's).  A set of another key is destroyed when a new one is made,
+// unless an update is running on it at that moment (`busy`).
+struct sr_stream_set { int device, key, busy; hipStream_t fact, bulk, inv; };
 static std::mutex g_stream_mutex;
 static std::vector<sr_stream_set> g_stream_sets;
-static void drop_fact_streams(sr_gp* h) {
-    // (the handle only forgets them; work it has in flight on them is waited for)
-    for (hipStream_t* st : {&h->fact_stream, &h->bulk_stream, &h->inv_stream})
-        if (*st) { (void)hipStreamSynchronize(*st); *st = nullptr; }
+static void release_fact_streams(sr_gp* h) {           // end of an update: the handle forgets the streams, the set is free
+    if (!h->fact_stream) return;
+    std::lock_guard<std::mutex> lk(g_stream_mutex);
+    for (sr_stream_set& c : g_stream_sets)
+        if (c.device == h->device && c.fact == h->fact_stream && c.busy > 0) --c.busy;
+    h->fact_stream = h->bulk_stream = h->inv_stream = nullptr;
     h->fact_regime = 0;
 }
 
@@ -143,21 +151,29 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
     const bool can_mask = ncu >= 64;
     // (giving each output's chain one half of the XCDs through CU masks on ALL of its streams was measured and lost:
     //  N = 5000, two outputs 5.6 -> 8.7 ms -- kernels on a CU-masked queue start late, and the mask costs the priority)
-    // CUs the bulk streams leave to the critical chain: one per shader engine; two for 36 < Np / 128 <= 52, where the
-    // block-row solves and in-panel updates of the chain otherwise queue behind the trailing update's workgroups (50
-    // instead of 12 us each) and the trailing update has the slack (measured, reserve 32 / 64: N = 3500 2.79 / 2.80,
-    // N = 5000 5.14 / 4.99, N = 6500 8.79 / 8.74, N = 7500 12.17 / 12.45, N = 10000 25.1 / 26.7 ms)
+    // CUs the bulk streams leave to the critical chain: sr_fact_reserved_cus (the table of sr_common.h): one per shader
+    // engine; two for 36 < Np / 128 <= 52, where the block-row solves and in-panel updates of the chain otherwise queue
+    // behind the trailing update's workgroups (50 instead of 12 us each) and the trailing update has the slack (measured,
+    // reserve 32 / 64: N = 3500 2.79 / 2.80, N = 5000 5.14 / 4.99, N = 6500 8.79 / 8.74, N = 7500 12.17 / 12.45, N = 10000 25.1 / 26.7 ms)
     const int nblk = h->Np / SR_NB;
     const int reserve = sr_fact_reserved_cus(regime, nblk);
     const int key = regime * 1000 + reserve;
-    if (h->fact_regime != key) drop_fact_streams(h);
-    if (!h->fact_stream) {
+    {
         std::lock_guard<std::mutex> lk(g_stream_mutex);
         sr_stream_set* set = nullptr;
         for (sr_stream_set& c : g_stream_sets)
             if (c.device == h->device && c.key == key) set = &c;
         if (!set) {
-            sr_stream_set c{h->device, key, nullptr, nullptr, nullptr};
+            // idle sets of other keys on this device go first (their hardware queues are what the new set needs)
+            for (size_t i = 0; i < g_stream_sets.size();) {
+                sr_stream_set& c = g_stream_sets[i];
+                if (c.device == h->device && c.busy == 0) {
+                    for (hipStream_t st : {c.fact, c.bulk, c.inv})
+                        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+                    g_stream_sets.erase(g_stream_sets.begin() + i);
+                } else ++i;
+            }
+            sr_stream_set c{h->device, key, 0, nullptr, nullptr, nullptr};
             int prio_lo = 0, prio_hi = 0;
             SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
             SR_HIP(hipStreamCreateWithPriority(&c.fact, hipStreamNonBlocking, prio_hi));
@@ -170,6 +186,7 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
             g_stream_sets.push_back(c);
             set = &g_stream_sets.back();
         }
+        ++set->busy;
         h->fact_stream = set->fact; h->bulk_stream = set->bulk; h->inv_stream = set->inv;
     }
     if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
@@ -220,6 +237,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     auto cleanup = [&]() {
         // never return with work in flight on the side streams
         for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream}) if (st) (void)hipStreamSynchronize(st);
+        release_fact_streams(h);
         dev_free(scratch);
     };
 #define SR_F(expr) do { rc = (expr); if (rc != SR_OK) { cleanup(); return rc; } } while (0)

@@ -2012,3 +2012,40 @@ def test_resident_server_idle_timeout_restart_and_model_updates():
     mu, var = gp.predict(np.hstack((big["p"][:1], big["k_ff"][:1])))
     np.testing.assert_array_equal(o[0][:, 0], mu[0])
     assert gp.start_server() is False
+
+
+def test_resident_servers_of_two_models_and_a_deep_copy():
+    """Two models keep a resident server each (different sizes, different numbers of outputs); a deep copy of a model --
+    what CasadiSSMEvaluator holds (state_space_models.py:166) -- shares the handle and with it the server; destroying a
+    model whose server is resident takes the kernel off the device (no hang, no leak of the pinned block)."""
+    import copy
+    import gc
+    import torch
+    s1 = orc.make_synthetic(91, 90, 2, 1, 6)
+    s2 = orc.make_synthetic(92, 140, 4, 1, 6)
+    g1 = hip_model(s1["Z"], s1["Y"], s1["lengthscale"], s1["signal_var"], s1["noise_var"], 2, 1)
+    g2 = hip_model(s2["Z"], s2["Y"], s2["lengthscale"], s2["signal_var"], s2["noise_var"], 4, 1)
+    r1 = [g1(s1["p"][t:t + 1], s1["k_ff"][t:t + 1]) for t in range(6)]
+    r2 = [g2.linearize_predict(s2["p"][t:t + 1], s2["k_ff"][t:t + 1], True) for t in range(6)]
+    assert g1.start_server(0.2) and g2.start_server(0.2)
+    c1 = copy.deepcopy(g1)
+    assert c1._handle is g1._handle and c1.server_state()[0]
+    for rnd in range(3):
+        for t in range(6):
+            for m in (g1, c1):
+                o = m(s1["p"][t:t + 1], s1["k_ff"][t:t + 1])
+                for a, b in zip(o, r1[t]):
+                    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
+            o = g2.linearize_predict(s2["p"][t:t + 1], s2["k_ff"][t:t + 1], True)
+            for a, b in zip(o, r2[t]):
+                np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10)
+    assert g1.server_state()[1] and g2.server_state()[1]            # both resident
+    assert g1.server_state()[3] == 36 and g2.server_state()[3] == 18
+    del g2
+    gc.collect()
+    torch.cuda.synchronize()                                         # g1's server leaves on its idle time-out at the latest
+    o = g1(s1["p"][:1], s1["k_ff"][:1])
+    for a, b in zip(o, r1[0]):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
+    del c1
+    g1.stop_server()
