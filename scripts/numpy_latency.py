@@ -51,6 +51,19 @@ def main():
         print("%4d %6d %5d | %13.1f %14.1f | %8.1f %9.1f %9.1f | %8.1f %9.1f %9.1f" % (
             (n_s, N, T) + pr + tuple(one) + tuple(ms)), flush=True)
         del gp
+    # the headline batch handed over as NumPy arrays and taken back as NumPy arrays: the PCIe-inclusive rate (never the
+    # `value` of bench.py, whose inputs are resident in HBM when its timed region starts)
+    n_s, n_u, N, T = 2, 1, 5000, 65536
+    prob = workload.make_problem(5, N, n_s, n_u, T)
+    gp = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device="cuda:0")
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+    l = np.array([0.05, 0.02])
+    d = {k: B.as_dev(prob[k], gp.device) for k in ("p", "k_ff", "Q", "k_fb")}
+    t_dev = _timeit(lambda: reach.onestep_reachability_batch(d["p"], gp, d["k_ff"], l, l, d["Q"], d["k_fb"], 2.0), n=10, warmup=2)
+    t_np = _timeit(lambda: reach.onestep_reachability_batch(prob["p"], gp, prob["k_ff"], l, l, prob["Q"], prob["k_fb"], 2.0), n=10, warmup=2)
+    mb = T * 8 * (n_s + n_u + n_s * n_s + n_u * n_s + n_s + n_s * n_s) / 1e6
+    print("headline batch (N=5000, T=65536 one-step): device tensors in/out %.2f ms = %.4g evals/s; NumPy in/out %.2f ms = %.4g evals/s "
+          "(%.1f MB over PCIe per step)" % (t_dev / 1e3, T / (t_dev * 1e-6), t_np / 1e3, T / (t_np * 1e-6), mb), flush=True)
 
 
 if __name__ == "__main__":
