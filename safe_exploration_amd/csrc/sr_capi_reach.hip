@@ -188,6 +188,9 @@ static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const 
             h->chain_status_host = st_host; h->chain_status_dev = st_dev;
             h->chain_xch = xch; h->chain_tickets = tickets; h->chain_done = done;
         }
+        // every workgroup of a chain launch must be resident at once: resident single-query servers (up to n_out Np / 64 CUs
+        // each) leave the device first; they come back with their next query
+        servers_quiesce_device(h->device);
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
         for (long t0 = 0; t0 < T; t0 += (long)gmax * SR_SMALL_T) {
             const long Tc = std::min((long)gmax * SR_SMALL_T, T - t0);

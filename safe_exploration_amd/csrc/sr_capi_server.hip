@@ -16,10 +16,12 @@ constexpr size_t MB_WORDS = 16;               // mailbox: 128 bytes (one line); 
 constexpr size_t REPLY_WORDS = 3 * SR_SERVER_ALIVE;
 
 size_t out_doubles(const sr_gp* h) { return (size_t)2 * h->n_out + (size_t)2 * h->n_out * h->D + (size_t)h->n_out * h->D * h->D; }
-size_t rec_doubles(const sr_gp* h) { return (size_t)h->n_out * SR_SERVER_REC; }
+int parts_of(const sr_gp* h) { return sr_gp_server_parts(h->Np); }
+int slots_of(const sr_gp* h) { return h->n_out * parts_of(h); }                      // reply words: one per (output, part)
+size_t rec_doubles(const sr_gp* h) { return (size_t)SR_SERVER_ALIVE * SR_SERVER_REC; }     // (room for any model of the handle)
 
 bool servable(const sr_gp* h) {
-    return h->factorized && !h->general && h->n_xin == 0 && h->small_path == 1 && h->n_out <= SR_SERVER_ALIVE &&
+    return h->factorized && !h->general && h->n_xin == 0 && h->small_path == 1 && slots_of(h) <= SR_SERVER_ALIVE &&
            sr_gp_server_supported(h->Np, h->D);
 }
 
@@ -35,7 +37,7 @@ void registry_remove(sr_gp* h) {
 // launch the kernel for the requests from first_seq on (the previous launch, if any, has left the device)
 int server_launch(sr_gp* h, unsigned long long first_seq) {
     sr_server& sv = h->srv;
-    for (int d = 0; d < h->n_out; ++d) sv.reply[SR_SERVER_ALIVE + d] = 1ull;
+    for (int d = 0; d < slots_of(h); ++d) sv.reply[SR_SERVER_ALIVE + d] = 1ull;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     sr_kstar_args ka{};
     ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
@@ -53,7 +55,7 @@ int server_launch(sr_gp* h, unsigned long long first_seq) {
 
 bool any_left(const sr_gp* h) {
     const volatile unsigned long long* alive = h->srv.reply + SR_SERVER_ALIVE;
-    for (int d = 0; d < h->n_out; ++d)
+    for (int d = 0; d < slots_of(h); ++d)
         if (alive[d] == 0ull) return true;
     return false;
 }
@@ -177,7 +179,7 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
         }
         SR_TRY(server_launch(h, seq));
     }
-    const int D = h->D, n = h->n_out;
+    const int D = h->D, n = h->n_out, parts = parts_of(h), nslot = n * parts;
     double* xs = reinterpret_cast<double*>(sv.mb);
     for (int j = 0; j < D; ++j) xs[j] = x_host[j];
     sv.mb[6] = second_order == 2 ? SR_SERVER_CMD_PING : (second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST);      // (2: diagnostics)
@@ -188,7 +190,7 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
     long spins = 0;
     for (;;) {
         bool all = true;
-        for (int d = 0; d < n; ++d) all = all && (reply[d] == seq);
+        for (int d = 0; d < nslot; ++d) all = all && (reply[d] == seq);
         if (all) break;
         __builtin_ia32_pause();
         if ((++spins & 1023) == 0) {
@@ -196,7 +198,7 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
                 // a workgroup left on its idle time-out between our look at `alive` and the request: relaunch for this
                 // sequence number (the request is still in the mailbox; answers are idempotent)
                 bool done = true;
-                for (int d = 0; d < n; ++d) done = done && (reply[d] == seq);
+                for (int d = 0; d < nslot; ++d) done = done && (reply[d] == seq);
                 if (done) break;
                 SR_DEVICE(h->device);
                 sv.mb[6] = SR_SERVER_CMD_STOP;
@@ -217,17 +219,31 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
     if (second_order == 2) {
         out_host[0] = (double)sv.reply[2 * SR_SERVER_ALIVE] * 1e-2;      // us of the last evaluation on the device
     } else {
-        // per-output records -> the API layout [mu n | var n | jac_mu n x D | jac_var n x D | hess n x D x D]
+        // per-(output, part) records -> the API layout [mu n | var n | jac_mu n x D | jac_var n x D | hess n x D x D].  A model
+        // served in parts: part 0 carries mu and the mean's derivatives, every part its strips' share of |U^-T k*|^2 and of
+        // the dot products behind d var/dx -- added here in ascending part order
         const int DD = D * D;
         for (int d = 0; d < n; ++d) {
-            const double* r = sv.out + (size_t)d * SR_SERVER_REC;
+            const double* r = sv.out + (size_t)d * parts * SR_SERVER_REC;
             out_host[d] = r[0];
-            out_host[n + d] = r[1];
             for (int j = 0; j < D; ++j) out_host[2 * n + d * D + j] = r[2 + j];
-            if (second_order) {
-                for (int j = 0; j < D; ++j) out_host[2 * n + n * D + d * D + j] = r[2 + D + j];
-                for (int q = 0; q < DD; ++q) out_host[2 * n + 2 * n * D + d * DD + q] = r[2 + 2 * D + q];
+            if (parts == 1) {
+                out_host[n + d] = r[1];
+                if (second_order) for (int j = 0; j < D; ++j) out_host[2 * n + n * D + d * D + j] = r[2 + D + j];
+            } else {
+                double q0 = 0.0;
+                for (int pp = 0; pp < parts; ++pp) q0 += r[(size_t)pp * SR_SERVER_REC + 1];
+                double v = r[SR_SERVER_REC - 1] - q0;                   // sf2 - |U^-T k*|^2
+                if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+                out_host[n + d] = v;
+                if (second_order)
+                    for (int j = 0; j < D; ++j) {
+                        double qj = 0.0;
+                        for (int pp = 0; pp < parts; ++pp) qj += r[(size_t)pp * SR_SERVER_REC + 2 + D + j];
+                        out_host[2 * n + n * D + d * D + j] = -2.0 * qj;
+                    }
             }
+            if (second_order) for (int q = 0; q < DD; ++q) out_host[2 * n + 2 * n * D + d * DD + q] = r[2 + 2 * D + q];
         }
     }
     ++sv.next_seq;

@@ -202,14 +202,14 @@ int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu,
 // pinned host memory.  All pointers are the DEVICE-visible addresses of pinned host memory.
 struct sr_server_args {
     unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 5] x (D <= 6 doubles), [6] command, [7] sequence number (written last)
-    double* out;                     // reply block: per output d one record of SR_SERVER_REC doubles
-                                     // [mu, var, d mu/dx (D), d var/dx (D), d2 mu/dx2 (D x D)]
+    double* out;                     // reply block: per (output d, part) one record of SR_SERVER_REC doubles
+                                     // [mu, var or its share, d mu/dx (D), d var/dx or its shares (D), d2 mu/dx2 (D x D), .., sf2]
     unsigned long long* reply;       // [d]: sequence number last answered by output d; [SR_SERVER_ALIVE + d]: 1 while it runs;
                                      // [2 SR_SERVER_ALIVE + d]: device ticks (100 MHz) of the last evaluation
     unsigned long long first_seq;    // the first sequence number this launch answers
     unsigned long long idle_ticks;   // leave after this long without a request (100 MHz wall clock)
 };
-#define SR_SERVER_ALIVE 16
+#define SR_SERVER_ALIVE 64           /* reply words: one per (output, part) */
 #define SR_SERVER_REC 40          /* doubles per output record in the reply block (2 + 2 D + D^2 <= 37 for D <= 5) */
 #define SR_SERVER_CMD_FIRST 0ull     /* mu, var, d mu/dx */
 #define SR_SERVER_CMD_SECOND 1ull    /* + d var/dx, d2 mu/dx2 */
@@ -308,8 +308,9 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //   K3  final stage                          one wavefront per (query, output) up to SR_FINAL_WAVE_T (4096) queries (44 -> 9.8 us at
 //                                            N = 5000, T = 1, r01d); K1 splits N down to 16 rows per workgroup there (26.6 -> 8.7 us)
 //  single blocking query (host entry points)
-//   K0s resident server (sr_capi_server.hip) sr_gp_server_supported: Np <= 384 with D <= 5, Np = 512 with D <= 3 (the others spill);
-//                                            U^-1 fragments in registers at Np = 128: __call__ 21.6 -> 9.6 us (r04_call_latency)
+//   K0s resident server (sr_capi_server.hip) sr_gp_server_supported: Np <= 512, D <= 5; one 16-wavefront workgroup per output at Np = 128,
+//                                            Np / 64 parts of 8 wavefronts from 256 on (U^-1 fragments in registers): __call__ 21.6 -> 9.6 us
+//                                            at N <= 128, 27 -> 11.9 at N = 150 (cart-pole), 33 -> 12.8 at N = 350 (r04_call_latency)
 //   one command (sr_gp_call1)                where K0 applies (Np <= 384; 512 with second order): 26.4 us at N = 200 (r03_call_latency)
 //  second order of one query (sr_gp_linearize)  K0 LIN up to Np = 384 (18 us at N = 200), streamed above: one launch for D <= 3
 //                                            (SR_LIN_FUSED_MAX_D): N = 5000 61 -> 51 us (r02_latency_grid)
@@ -338,9 +339,11 @@ static inline bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
     if (Np == 512 && T <= 128) return false;  // measured: streaming U^-1 (K2s, groups of 16 queries) 22-23 us against 28 us here
     return Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
 }
-// D <= 5 (pendulum: 3, cart-pole: 4 or 5), and D <= 3 at 512 padded points: the other instantiations spill (16 - 60 B of
-// scratch per lane) and are not built
-static inline bool sr_gp_server_supported(int Np, int D) { return Np % 128 == 0 && Np <= SR_FUSED_NP && D <= (Np == 512 ? 3 : 5); }
+// workgroups per output of the resident server: from Np = 256 on an output is served in Np / 64 parts of eight wavefronts
+// (the U^-1 fragments of a part fit its registers), Np = 128 by one workgroup of sixteen
+constexpr int sr_gp_server_parts(int Np) { return Np >= 256 ? Np / 64 : 1; }
+// D <= 5 (pendulum: 3, cart-pole: 4 or 5): the D = 6 .. 8 instantiations of the sixteen-wavefront kernel spill and are not built
+static inline bool sr_gp_server_supported(int Np, int D) { return Np % 128 == 0 && Np <= SR_FUSED_NP && D <= 5; }
 // 64 x 64 tiles: profitable when the model is small and the 128-tile grid would leave most of the chip idle
 static inline bool sr_var64_wanted(int Np, long Tp, int n_out) {
     const long wgs128 = (long)(Np / SR_NB) * (Tp / SR_NB) * n_out;

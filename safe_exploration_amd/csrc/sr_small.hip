@@ -592,13 +592,201 @@ __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, s
     if (tid == 0) __hip_atomic_store(sv.reply + SR_SERVER_ALIVE + d, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- K0s in PARTS: Np = 256, 384, 512 ------------------------------------------------------------------------------------
+// One 16-wavefront workgroup cannot keep the U^-1 fragments of a 256-row model on chip (34 doubles per lane against a budget
+// of 128 registers).  Here an output is served by Np / 64 workgroups of EIGHT wavefronts (256 registers per lane), each
+// owning two strip pairs (strips s and Np/16 - 1 - s: whole COLUMNS of U^-1, so no partial products cross workgroups) with
+// the k range of a pair cut over four wavefronts: Np / 16 + 1 fragments per lane, in registers across requests.  Every part
+// polls the mailbox itself and evaluates phase A in full (it needs all of k*); part 0 answers with mu, d mu/dx, d2 mu/dx2,
+// every part with its strips' share of |U^-T k*|^2 and of the dot products with the dk*/dx columns; the HOST adds the
+// Np / 64 shares in a fixed order (sr_gp_server_call).  
+template <int NP>
+struct sr_part_frag {
+    static constexpr int NSTRIP = NP / 16, TOT = NSTRIP + 1;         // k-steps (of 4 rows) of a wavefront, both strips
+    double w[TOT];
+    // pair pr (strips pr and NSTRIP - 1 - pr), quarter h of their k ranges: pr + 1 resp. NSTRIP - pr steps
+    __device__ __forceinline__ void load(const double* __restrict__ Wd, int pr, int h, int lane) {
+        const int lk = lane >> 4, ln = lane & 15;
+        const int nA = pr + 1;
+#pragma unroll
+        for (int u = 0; u < TOT; ++u) {
+            const bool inA = u < nA;
+            const int sidx = inA ? pr : NSTRIP - 1 - pr;
+            const int st = h * (sidx + 1) + (inA ? u : u - nA);
+            w[u] = Wd[(long)(4 * st + lk) * NP + 16 * sidx + ln];
+        }
+    }
+};
+template <int NP, int NA>
+__device__ __forceinline__ void sr_part_mfma(const sr_part_frag<NP>& f, const double (*ks)[SR_FQ], int stA, int stB, int lk, int ln,
+                                             sr_d4 (&acc)[2]) {
+    constexpr int TOT = sr_part_frag<NP>::TOT;
+    sr_d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+    for (int u = 0; u < TOT; ++u) {
+        const double bf = ks[4 * ((u < NA) ? stA + u : stB + (u - NA)) + lk][ln];
+        if (u < NA) {
+            if (u & 1) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf, a1, 0, 0, 0);
+            else a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf, a0, 0, 0, 0);
+        } else {
+            if (u & 1) b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf, b1, 0, 0, 0);
+            else b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f.w[u], bf, b0, 0, 0, 0);
+        }
+    }
+    acc[0] = a0 + a1; acc[1] = b0 + b1;
+}
+
+template <int NP, int DT>
+__global__ __launch_bounds__(512) void sr_gp_server_parts_kernel(sr_server_model m, sr_server_args sv) {
+    constexpr int NSTRIP = NP / 16, NPAIR = NSTRIP / 2, PARTS = NP / 64;
+    static_assert(NPAIR == 2 * PARTS, "two strip pairs per part");
+    __shared__ double ks_[NP][SR_FQ];
+    __shared__ double xq_[SR_FQ][DT];
+    __shared__ double pA_[8][256];
+    __shared__ double Rs_[SR_FQ][16];
+    __shared__ double pB_[3 * 4 * 256];        // quarters h = 1 .. 3 of the part's four strips
+    __shared__ double redC_[NP / 16][SR_FQ];
+    sr_small_lds<NP, DT> L{ks_, xq_, pA_, Rs_, pB_, redC_};
+    __shared__ double rows_[NP][DT + 1];
+    __shared__ double il_[DT];
+    __shared__ double xreq[8];
+    __shared__ unsigned long long req_cmd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = blockIdx.x, d = blockIdx.y;
+    const int D = m.D, n = m.n_out;
+    const int pr = 2 * part + (wave >> 2), h = wave & 3;      // this wavefront's strip pair and quarter
+    const int lp = wave >> 2;                                  // local pair: local strips 2 lp (A) and 2 lp + 1 (B)
+    double* out = sv.out + ((long)d * PARTS + part) * SR_SERVER_REC;
+    unsigned long long expect = sv.first_seq;
+    sr_part_frag<NP> frag;
+    {
+        sr_kstar_args a0{};
+        a0.Z = m.Z; a0.alpha = m.alpha; a0.ls = m.ls; a0.N = m.N; a0.Np = NP; a0.D = D; a0.n_out = n;
+        sr_small_rows_fill<NP, DT>(a0, d, rows_, 512);
+        sr_small_il_fill<DT>(a0, d, il_);
+        frag.load(m.Wt + (long)d * NP * NP, pr, h, lane);
+    }
+    const double sf2 = m.sf2[d];
+    __syncthreads();
+    const sr_small_rows<NP, DT> rows{rows_, il_};
+    for (;;) {
+        if (wave == 0) {
+            unsigned long long cmd = SR_SERVER_CMD_IDLE;
+            const unsigned long long t_last = wall_clock64();
+            for (;;) {
+                unsigned long long wv = 0;
+                if (lane < 8) wv = __hip_atomic_load(sv.mb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long s = __shfl(wv, 7);
+                if (s == expect) {
+                    cmd = __shfl(wv, 6);
+                    if (lane < 6) xreq[lane] = __longlong_as_double((long long)wv);
+                    break;
+                }
+                if (wall_clock64() - t_last > sv.idle_ticks) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) req_cmd = cmd;
+        }
+        __syncthreads();
+        const unsigned long long cmd = req_cmd;
+        if (cmd == SR_SERVER_CMD_STOP || cmd == SR_SERVER_CMD_IDLE) break;
+        const unsigned long long t_seen = wall_clock64();
+        const int slot = d * PARTS + part;
+        if (cmd == SR_SERVER_CMD_PING) {
+            if (tid == 0) __hip_atomic_store(sv.reply + slot, expect, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            ++expect;
+            __syncthreads();
+            continue;
+        }
+        {
+            int tq = tid;
+            asm volatile("" : "+v"(tq));                       // (nothing derived from the thread index is loop-invariant)
+            sr_kstar_args a{};
+            a.sf2 = m.sf2;
+            a.lda = D; a.na = D; a.N = m.N; a.Np = NP; a.D = D; a.n_out = n; a.nsplit = 1; a.T = 1; a.Tp = 1;
+            sr_small_phase_a<NP, DT, true, true, 8>(a, d, xreq, D, xreq, D, 1, L, &rows, tq);
+            // phase B on the part's strips
+            const int lk = (tq & 63) >> 4, ln = tq & 15;
+            sr_d4 acc[2];
+            const int nA = pr + 1, nB = NSTRIP - pr;
+            switch (nA) {
+#define SRP_CASE(NA_) case NA_: if constexpr (NA_ <= NPAIR) sr_part_mfma<NP, NA_>(frag, ks_, h * nA, h * nB, lk, ln, acc); break;
+                SRP_CASE(1) SRP_CASE(2) SRP_CASE(3) SRP_CASE(4) SRP_CASE(5) SRP_CASE(6) SRP_CASE(7) SRP_CASE(8)
+                SRP_CASE(9) SRP_CASE(10) SRP_CASE(11) SRP_CASE(12) SRP_CASE(13) SRP_CASE(14) SRP_CASE(15) SRP_CASE(16)
+#undef SRP_CASE
+                default: acc[0] = acc[1] = sr_d4{0.0, 0.0, 0.0, 0.0}; break;
+            }
+            if (h > 0) {
+#pragma unroll
+                for (int which = 0; which < 2; ++which)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pB_[((h - 1) * 4 + 2 * lp + which) * 256 + r * 64 + (tq & 63)] = acc[which][r];
+            }
+            __syncthreads();
+            if (h == 0) {
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    double q = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double v = acc[which][r];
+#pragma unroll
+                        for (int hh = 0; hh < 3; ++hh) v += pB_[(hh * 4 + 2 * lp + which) * 256 + r * 64 + (tq & 63)];
+                        const double w = __shfl(v, (tq & 63) & 48);           // dot with column 0 of the same row
+                        q = fma(v, w, q);
+                    }
+                    q += __shfl_xor(q, 16);
+                    q += __shfl_xor(q, 32);
+                    if ((tq & 63) < 16) redC_[2 * lp + which][tq & 63] = q;       // (local strip index: 0 .. 3)
+                }
+            }
+            __syncthreads();
+        }
+        // the part's record: [mu, share of q_0, d mu/dx (D), shares of q_{1+j} (D), d2 mu/dx2 (D x D), .., sf2 at the end]; mu,
+        // the mean's derivatives and sf2 from part 0 only
+        if (wave == 0) {
+            const int e = lane, R = 2 + 2 * D + D * D;
+            const double mval = Rs_[0][0];
+            double val = 0.0;
+            if (part == 0) {
+                if (e == 0) val = mval;
+                else if (e >= 2 && e < 2 + D) val = Rs_[1 + (e - 2)][0];
+                else if (e >= 2 + 2 * D && e < R) {
+                    const int q = e - (2 + 2 * D);
+                    const int j = min(q / D, q % D), l = max(q / D, q % D);
+                    val = (Rs_[1 + j][1 + l] - xq_[0][l] * Rs_[1 + j][0]) * il_[l];
+                    if (j == l) val -= mval * il_[j] * il_[j];
+                } else if (e == SR_SERVER_REC - 1) val = sf2;
+            }
+            const int c = (e == 1) ? 0 : ((e >= 2 + D && e < 2 + 2 * D) ? e - (2 + D) + 1 : -1);
+            if (c >= 0) val = redC_[0][c] + redC_[1][c] + redC_[2][c] + redC_[3][c];
+            if (e < SR_SERVER_REC) out[e] = val;
+            __threadfence_system();
+            if (lane == 0) {
+                sv.reply[2 * SR_SERVER_ALIVE + slot] = wall_clock64() - t_seen;
+                __hip_atomic_store(sv.reply + slot, expect, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        ++expect;
+    }
+    if (tid == 0) __hip_atomic_store(sv.reply + SR_SERVER_ALIVE + d * PARTS + part, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int NP>
 static int launch_server_np(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s) {
-    dim3 grid(1, a.n_out);
     const sr_server_model m{a.Z, a.alpha, a.ls, a.sf2, Wt, a.N, a.D, a.n_out};
     SR_CHECK(sr_gp_server_supported(NP, a.D), SR_EUNSUPPORTED, "gp_server: Np=%d D=%d not built", NP, a.D);
-    if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_kernel<NP, 3>), grid, dim3(1024), 0, s, m, sv);
-    else if constexpr (NP < 512) hipLaunchKernelGGL((sr_gp_server_kernel<NP, 5>), grid, dim3(1024), 0, s, m, sv);
+    if constexpr (NP >= 256) {
+        static_assert(sr_gp_server_parts(NP) == NP / 64, "parts");
+        dim3 grid(NP / 64, a.n_out);
+        if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 3>), grid, dim3(512), 0, s, m, sv);
+        else hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 5>), grid, dim3(512), 0, s, m, sv);
+    } else {
+        dim3 grid(1, a.n_out);
+        if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_kernel<NP, 3>), grid, dim3(1024), 0, s, m, sv);
+        else hipLaunchKernelGGL((sr_gp_server_kernel<NP, 5>), grid, dim3(1024), 0, s, m, sv);
+    }
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

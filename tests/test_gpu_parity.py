@@ -2041,6 +2041,16 @@ def test_resident_servers_of_two_models_and_a_deep_copy():
                 np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-10)
     assert g1.server_state()[1] and g2.server_state()[1]            # both resident
     assert g1.server_state()[3] == 36 and g2.server_state()[3] == 18
+    # a persistent multi-step launch needs (almost) every CU: the resident servers leave for it and come back afterwards
+    from safe_exploration_amd import gp_reachability as reach, workload
+    roll = workload.random_rollout_controls(5, 64, 8, 2, 1)
+    l = np.array([0.05, 0.02])
+    pa, qa = reach.multistep_reachability_batch(roll["p0"], g1, roll["k_fb"], roll["k_ff"], l, l, None, 2.0, 0.8 * np.eye(2), np.zeros((2, 1)))
+    assert np.all(np.isfinite(qa)) and g1._handle and not g1.server_state()[1] and g1.server_state()[0]
+    o = g1(s1["p"][:1], s1["k_ff"][:1])
+    assert g1.server_state()[1]
+    for a, b in zip(o, r1[0]):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
     del g2
     gc.collect()
     torch.cuda.synchronize()                                         # g1's server leaves on its idle time-out at the latest
