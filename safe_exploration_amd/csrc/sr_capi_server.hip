@@ -38,6 +38,8 @@ void registry_remove(sr_gp* h) {
 int server_launch(sr_gp* h, unsigned long long first_seq) {
     sr_server& sv = h->srv;
     for (int d = 0; d < slots_of(h); ++d) sv.reply[SR_SERVER_ALIVE + d] = 1ull;
+    ++sv.epoch;
+    *(volatile unsigned long long*)(sv.mb + 5) = sv.epoch;
     std::atomic_thread_fence(std::memory_order_seq_cst);
     sr_kstar_args ka{};
     ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
@@ -45,7 +47,7 @@ int server_launch(sr_gp* h, unsigned long long first_seq) {
     ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = 1; ka.T = 1; ka.Tp = 1;
     sr_server_args sa{};
     sa.mb = sv.mb_dev; sa.out = sv.out_dev; sa.reply = sv.reply_dev;
-    sa.first_seq = first_seq; sa.idle_ticks = sv.idle_ticks;
+    sa.first_seq = first_seq; sa.idle_ticks = sv.idle_ticks; sa.epoch = sv.epoch;
     SR_TRY(sr_launch_gp_server(ka, h->Wt, sa, sv.stream));
     sv.running = 1;
     ++sv.launches;
@@ -66,11 +68,9 @@ bool any_left(const sr_gp* h) {
 int srh::server_quiesce(sr_gp* h) {
     sr_server& sv = h->srv;
     if (!sv.running) return SR_OK;
-    // STOP under the next sequence number; a kernel that has already left on its idle time-out never reads it
-    sv.mb[6] = SR_SERVER_CMD_STOP;
-    std::atomic_thread_fence(std::memory_order_release);
-    *(volatile unsigned long long*)(sv.mb + 7) = sv.next_seq;
-    ++sv.next_seq;
+    // a foreign epoch in the mailbox line: every workgroup leaves at its next look, whatever request it is waiting for
+    *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
     sr_dev_guard guard(h->device);
     const hipError_t e = hipStreamSynchronize(sv.stream);
     sv.running = 0;
@@ -171,11 +171,9 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
         // never launched for this model state, or (partly) gone on its idle time-out: wait for the rest to leave, launch anew
         SR_DEVICE(h->device);
         if (sv.running) {
-            sv.mb[6] = SR_SERVER_CMD_STOP;                 // workgroups still polling leave at once (same sequence number
-            std::atomic_thread_fence(std::memory_order_release);      // as the request below: they answer nothing)
-            *(volatile unsigned long long*)(sv.mb + 7) = seq;
+            *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;       // workgroups still polling leave at once
+            std::atomic_thread_fence(std::memory_order_seq_cst);
             SR_HIP(hipStreamSynchronize(sv.stream));
-            *(volatile unsigned long long*)(sv.mb + 7) = 0ull;
         }
         SR_TRY(server_launch(h, seq));
     }
@@ -201,11 +199,9 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
                 for (int d = 0; d < nslot; ++d) done = done && (reply[d] == seq);
                 if (done) break;
                 SR_DEVICE(h->device);
-                sv.mb[6] = SR_SERVER_CMD_STOP;
+                *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;
                 std::atomic_thread_fence(std::memory_order_seq_cst);
                 SR_HIP(hipStreamSynchronize(sv.stream));
-                sv.mb[6] = second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST;
-                std::atomic_thread_fence(std::memory_order_seq_cst);
                 SR_TRY(server_launch(h, seq));
             }
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -201,12 +201,14 @@ int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu,
 // K0s (sr_small.hip): resident single-query server of a small ARD-RBF model: one workgroup per output polls a mailbox in
 // pinned host memory.  All pointers are the DEVICE-visible addresses of pinned host memory.
 struct sr_server_args {
-    unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 5] x (D <= 6 doubles), [6] command, [7] sequence number (written last)
+    unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 4] x (D <= 5 doubles), [5] launch epoch (any other value: leave),
+                                     // [6] command, [7] sequence number (written last)
     double* out;                     // reply block: per (output d, part) one record of SR_SERVER_REC doubles
                                      // [mu, var or its share, d mu/dx (D), d var/dx or its shares (D), d2 mu/dx2 (D x D), .., sf2]
     unsigned long long* reply;       // [d]: sequence number last answered by output d; [SR_SERVER_ALIVE + d]: 1 while it runs;
                                      // [2 SR_SERVER_ALIVE + d]: device ticks (100 MHz) of the last evaluation
     unsigned long long first_seq;    // the first sequence number this launch answers
+    unsigned long long epoch;        // of this launch (mb[5] holds it while the launch is wanted)
     unsigned long long idle_ticks;   // leave after this long without a request (100 MHz wall clock)
 };
 #define SR_SERVER_ALIVE 64           /* reply words: one per (output, part) */

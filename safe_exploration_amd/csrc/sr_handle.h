@@ -25,7 +25,7 @@ struct sr_server {
     unsigned long long *mb = nullptr, *reply = nullptr; double* out = nullptr;              // host addresses
     unsigned long long *mb_dev = nullptr, *reply_dev = nullptr; double* out_dev = nullptr;  // the device's addresses of the same
     hipStream_t stream = nullptr;            // non-blocking stream of its own: nothing else is ever ordered behind the kernel
-    unsigned long long next_seq = 1, idle_ticks = 500000;
+    unsigned long long next_seq = 1, idle_ticks = 500000, epoch = 0;
     long launches = 0, calls = 0;
 };
 

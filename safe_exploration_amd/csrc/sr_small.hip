@@ -504,14 +504,16 @@ __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, s
     const sr_small_rows<NP, DT> rows{rows_, il_};
     for (;;) {
         if (wave == 0) {
-            // the mailbox is ONE 64-byte line [x0 .. x5 | command | sequence number]: lanes 0 .. 7 fetch it with one request,
-            // so a hit on the sequence number (written last by the host) comes with the query it belongs to
+            // the mailbox is ONE 64-byte line [x0 .. x4 | launch epoch | command | sequence number]: lanes 0 .. 7 fetch it with
+            // one request, so a hit on the sequence number (written last by the host) comes with the query it belongs to; an
+            // epoch other than this launch's means STOP, whatever request a workgroup is waiting for
             unsigned long long cmd = SR_SERVER_CMD_IDLE;
             const unsigned long long t_last = wall_clock64();             // 100 MHz
             for (;;) {
                 unsigned long long wv = 0;
                 if (lane < 8) wv = __hip_atomic_load(sv.mb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned long long s = __shfl(wv, 7);
+                if (__shfl(wv, 5) != sv.epoch) { cmd = SR_SERVER_CMD_STOP; break; }      // the host called this launch off
                 if (s == expect) {
                     cmd = __shfl(wv, 6);
                     if (lane < 6) xreq[lane] = __longlong_as_double((long long)wv);
@@ -678,6 +680,7 @@ __global__ __launch_bounds__(512) void sr_gp_server_parts_kernel(sr_server_model
                 unsigned long long wv = 0;
                 if (lane < 8) wv = __hip_atomic_load(sv.mb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned long long s = __shfl(wv, 7);
+                if (__shfl(wv, 5) != sv.epoch) { cmd = SR_SERVER_CMD_STOP; break; }      // the host called this launch off
                 if (s == expect) {
                     cmd = __shfl(wv, 6);
                     if (lane < 6) xreq[lane] = __longlong_as_double((long long)wv);
