@@ -64,8 +64,8 @@ bool any_left(const sr_gp* h) {
 
 }  // namespace
 
-// Take the server of this handle off the device (it stays armed: the next sr_gp_server_call launches it again).
-int srh::server_quiesce(sr_gp* h) {
+namespace {
+int quiesce_locked(sr_gp* h) {
     sr_server& sv = h->srv;
     if (!sv.running) return SR_OK;
     // a foreign epoch in the mailbox line: every workgroup leaves at its next look, whatever request it is waiting for
@@ -74,9 +74,17 @@ int srh::server_quiesce(sr_gp* h) {
     sr_dev_guard guard(h->device);
     const hipError_t e = hipStreamSynchronize(sv.stream);
     sv.running = 0;
+    sv.stale = 0;
     registry_remove(h);
     SR_HIP(e);
     return SR_OK;
+}
+}  // namespace
+
+// Take the server of this handle off the device (it stays armed: the next sr_gp_server_call launches it again).
+int srh::server_quiesce(sr_gp* h) {
+    std::lock_guard<std::mutex> lk(h->srv.mu);
+    return quiesce_locked(h);
 }
 
 // Before a device-wide wait (hipDeviceSynchronize inside the library): every resident server of this device leaves now
@@ -111,8 +119,9 @@ extern "C" int sr_gp_server_start(sr_gp_t h, double idle_timeout_s) {
         return SR_EUNSUPPORTED;
     }
     SR_DEVICE(h->device);
-    SR_TRY(server_quiesce(h));
     sr_server& sv = h->srv;
+    std::lock_guard<std::mutex> lk(sv.mu);
+    SR_TRY(quiesce_locked(h));
     const size_t bytes = (MB_WORDS + REPLY_WORDS) * sizeof(unsigned long long) + rec_doubles(h) * sizeof(double);
     if (sv.pinned && sv.pinned_bytes < bytes) { (void)hipHostFree(sv.pinned); sv.pinned = nullptr; }
     if (!sv.pinned) {
@@ -159,16 +168,18 @@ extern "C" int sr_gp_server_state(sr_gp_t h, int* armed, int* resident, long* la
 extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_order, double* out_host, double timeout_s) {
     SR_CHECK(h != nullptr && x_host && out_host, SR_EINVAL, "sr_gp_server_call: NULL argument");
     sr_server& sv = h->srv;
+    std::lock_guard<std::mutex> lk(sv.mu);
     if (!sv.armed) { sr_set_error("sr_gp_server_call: no server armed (sr_gp_server_start)"); return SR_EUNSUPPORTED; }
     if (!servable(h)) {                                   // the model has changed under the armed server
-        (void)server_quiesce(h);
+        (void)quiesce_locked(h);
         sv.armed = 0;
         sr_set_error("sr_gp_server_call: the model no longer has a resident server (Np=%d)", h->Np);
         return SR_EUNSUPPORTED;
     }
     const unsigned long long seq = sv.next_seq;
-    if (!sv.running || any_left(h)) {
-        // never launched for this model state, or (partly) gone on its idle time-out: wait for the rest to leave, launch anew
+    if (!sv.running || sv.stale || any_left(h)) {
+        // never launched for this model state, (partly) gone on its idle time-out, or called off after a request that was
+        // given up: wait for the rest to leave, launch anew
         SR_DEVICE(h->device);
         if (sv.running) {
             *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;       // workgroups still polling leave at once
@@ -176,6 +187,7 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
             SR_HIP(hipStreamSynchronize(sv.stream));
         }
         SR_TRY(server_launch(h, seq));
+        sv.stale = 0;
     }
     const int D = h->D, n = h->n_out, parts = parts_of(h), nslot = n * parts;
     double* xs = reinterpret_cast<double*>(sv.mb);
@@ -206,6 +218,12 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
             }
             const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (waited > timeout_s) {
+                // give the request up: its sequence number is never used again (workgroups that did answer it hold answers to
+                // THIS query in their reply words), and the launch is called off so that the next call starts a fresh one
+                *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+                sv.stale = 1;
+                ++sv.next_seq;
                 sr_set_error("sr_gp_server_call: no answer to request %llu within %.3f s", seq, timeout_s);
                 return SR_ESTATE;
             }

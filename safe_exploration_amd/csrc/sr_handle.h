@@ -27,6 +27,8 @@ struct sr_server {
     hipStream_t stream = nullptr;            // non-blocking stream of its own: nothing else is ever ordered behind the kernel
     unsigned long long next_seq = 1, idle_ticks = 500000, epoch = 0;
     long launches = 0, calls = 0;
+    int stale = 0;                           // a request was given up (time-out): the next call starts from a fresh launch
+    std::mutex mu;                           // one caller at a time: a call, and a quiesce from another thread's entry point
 };
 
 struct sr_gp {

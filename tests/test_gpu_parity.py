@@ -2014,6 +2014,59 @@ def test_resident_server_idle_timeout_restart_and_model_updates():
     assert gp.start_server() is False
 
 
+def test_resident_server_request_given_up_and_callers_on_two_threads():
+    """A request that is given up (time-out) never lends its answers to the next one: the library retires the sequence
+    number and calls the launch off; the next call starts a fresh launch and answers ITS query.  Two threads calling the
+    same model take turns (one mailbox)."""
+    import ctypes
+    import threading
+    import time
+    from safe_exploration_amd import _lib
+    syn = orc.make_synthetic(79, 100, 2, 1, 8)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    ref = [gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1]) for t in range(8)]        # launched route
+    assert gp.start_server(idle_timeout_s=0.002)
+    hd = gp._handle
+    io = hd.single_io()
+    given_up = 0
+    for rep in range(20):
+        time.sleep(0.01)                                    # the server has left: the next request needs a launch
+        x = np.concatenate((syn["p"][rep % 8], syn["k_ff"][rep % 8]))
+        io["h_in_np"][:x.size] = x
+        # a negative time-out gives up at the first look at the clock (about 1000 polls): sometimes before the fresh
+        # launch answers, sometimes after -- both must leave the protocol intact
+        rc = _lib.lib.sr_gp_server_call(hd.h, io["p_in"], 1, io["p_srv"], ctypes.c_double(-1.0))
+        assert rc in (0, _lib.SR_ESTATE), rc
+        given_up += rc != 0
+        t = (rep + 3) % 8
+        o = gp(syn["p"][t:t + 1], syn["k_ff"][t:t + 1])
+        for u, v in zip(o, ref[t]):
+            np.testing.assert_allclose(u, v, rtol=1e-12, atol=1e-14)
+    assert gp.server_state()[0]
+    print("requests given up: %d of 20" % given_up)
+
+    errors = []
+
+    def worker(k):                                          # the C-ABI with buffers of the thread's own
+        try:
+            x, out = np.empty(3), np.empty(2 * 2 + 2 * 2 * 3 + 2 * 9)
+            px, po = ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(out.ctypes.data)
+            for i in range(300):
+                t = (i + k) % 8
+                x[:2], x[2:] = syn["p"][t], syn["k_ff"][t]
+                rc = _lib.lib.sr_gp_server_call(hd.h, px, 0, po, ctypes.c_double(5.0))
+                assert rc == 0, rc
+                np.testing.assert_allclose(out[:2], np.ravel(ref[t][0]), rtol=1e-12, atol=1e-14)
+                np.testing.assert_allclose(out[2:4], np.ravel(ref[t][1]), rtol=1e-12, atol=1e-14)
+        except Exception as e:                              # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[0]
+
+
 def test_resident_servers_of_two_models_and_a_deep_copy():
     """Two models keep a resident server each (different sizes, different numbers of outputs); a deep copy of a model --
     what CasadiSSMEvaluator holds (state_space_models.py:166) -- shares the handle and with it the server; destroying a
