@@ -302,17 +302,22 @@ int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, double* out_h
                 unsigned long long* flag_host, unsigned long long seq, void* stream);
 /* Resident single-query server: the latency path of the MPC loop -- CasadiSSMEvaluator.eval / JacFun.eval
  * (state_space_models.py:278-303, 384-417) call SimpleGPModel.__call__ / linearize_predict(jacobians=True)
- * (ssm_gpy/gaussian_process.py:135-144) once per IPOPT iteration and block.  sr_gp_server_start launches one workgroup per
- * output that STAYS on the device and polls a mailbox in pinned host memory; sr_gp_server_call posts the query x_host
+ * (ssm_gpy/gaussian_process.py:135-144) once per IPOPT iteration and block.  sr_gp_server_start launches workgroups that
+ * STAY on the device and poll a mailbox in pinned host memory (one workgroup per output up to 128 padded rows, Np / 64
+ * per output from 256 on: every one keeps its strips of U^-1 in registers); sr_gp_server_call posts the query x_host
  * (D doubles, any host memory), waits for the answer and copies it to out_host (any host memory):
  *   [mu n | var n | jac_mu n x D]                              second_order == 0
  *   [... | jac_var n x D | hess_mu n x D x D]                  second_order != 0
  * No launch, copy command or completion interrupt per query: one PCIe read to see the request, one posted write to
  * answer it.  The kernel leaves after idle_timeout_s without a request (a hipDeviceSynchronize elsewhere in the process
- * waits at most that long) and sr_gp_server_call launches it again; every entry point that writes the model takes it
- * off the device first (it stays armed).  ARD-RBF models with a one-launch posterior (Np <= 384 with D <= 5, Np = 512 with D <= 3, no input
- * transform); SR_EUNSUPPORTED otherwise and from sr_gp_server_call when no server is armed: use sr_gp_call1 /
- * sr_gp_predict / sr_gp_linearize.  One host thread per handle, as everywhere. */
+ * waits at most that long) and sr_gp_server_call launches it again; every entry point that writes the model, and every
+ * persistent multi-step launch on the device, takes it off the device first (it stays armed).  ARD-RBF models of at most
+ * 512 padded rows with D <= 5 and no input transform; SR_EUNSUPPORTED otherwise and from sr_gp_server_call when no
+ * server is armed: use sr_gp_call1 / sr_gp_predict / sr_gp_linearize.
+ * Calls on one handle are serialised inside the library (one mailbox), so two host threads may evaluate the same model
+ * with buffers of their own; the model itself must not be written meanwhile, as everywhere.  A request that is not
+ * answered within timeout_s is given up with SR_ESTATE: its sequence number is retired and the launch called off, the
+ * next call starts a fresh one (a device kept busy by other work for longer than timeout_s is the expected cause). */
 int sr_gp_server_start(sr_gp_t h, double idle_timeout_s);
 int sr_gp_server_stop(sr_gp_t h);
 int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_order, double* out_host, double timeout_s);
