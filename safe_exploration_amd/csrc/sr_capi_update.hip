@@ -182,6 +182,10 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
             if (regime == 1) {
                 if (can_mask) SR_TRY(make_masked_stream(&c.inv, ncu, reserve, ncu));
                 else SR_HIP(hipStreamCreateWithPriority(&c.inv, hipStreamNonBlocking, prio_lo));
+            } else {
+                // regime 2: a second bulk stream WITHOUT a mask, for the trailing updates that are long enough to hide a
+                // chain that waits for its CUs (below)
+                SR_HIP(hipStreamCreateWithPriority(&c.inv, hipStreamNonBlocking, prio_lo));
             }
             g_stream_sets.push_back(c);
             set = &g_stream_sets.back();
@@ -320,9 +324,17 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         // (critical stream, per block: update of its row by the panel's rows above, diagonal block, block row solve),
         // the trailing update is split -- the rows of the NEXT panel on the critical stream, so that its factorisation can start at
         // once, everything behind them on the bulk stream, which may lag one panel behind.
-        int pi = 0;
-        for (int p0 = 0; p0 < nb; p0 += P, ++pi) {
-            const int p1 = std::min(nb, p0 + P);
+        // Panel boundaries: equal panels of P blocks.  (Round 4, N = 50000: panels that START narrow and double up to P -- 8,
+        // 16, 32, 48, .. -- so that the first panel's chain, which has no trailing update to run beside, is short: 65.9 /
+        // 65.7 / 65.8 TF with a first panel of 8 / 4 / 16 blocks against 66.0 with equal panels.  The first chain is not idle
+        // time: 53 of its 60 ms are the in-panel products, 13 % of the Cholesky's flops, and the narrow panels' trailing
+        // updates with their shorter K lose what the hidden chain gains.)
+        std::vector<int> pb;
+        for (int p = 0; p < nb; p += P) pb.push_back(p);
+        pb.push_back(nb);
+        for (int pi = 0; pi + 1 < (int)pb.size(); ++pi) {
+            const int p0 = pb[pi], p1 = pb[pi + 1];
+            const int next_w = pi + 2 < (int)pb.size() ? pb[pi + 2] - p1 : 0;      // blocks of the next panel
             for (int kb = p0; kb < p1; ++kb) {
                 const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
                 const int ncols = Np - (kb + 1) * SR_NB;
@@ -376,7 +388,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             const int Kp = (p1 - p0) * SR_NB;
             const double* Upan = W + (size_t)p0 * SR_NB * Np + (size_t)p1 * SR_NB;    // factor rows of the panel
             double* Cnext = U + (size_t)p1 * SR_NB * Np + (size_t)p1 * SR_NB;
-            const int la = std::min(P * SR_NB, rest);         // rows of the next panel
+            const int la = std::min(next_w * SR_NB, rest);    // rows of the next panel
             const int bulk = rest - la;
             // regime 1 (chain-bound sizes): the bulk update starts only AFTER the look-ahead rows are done -- started
             // together, its workgroups fill the CUs first and the look-ahead (on the critical path) takes 60 - 70 us
@@ -390,14 +402,28 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                 SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1, -1, &b_ppp));
             }
             if (bulk > 0) {
-                if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
-                SR_FH(hipStreamWaitEvent(sb, h->ev_panel[pi & 1], 0));
-                {
-                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sb);
-                    SR_F(sr_launch_gemm_tn_upper(Upan + la, Np, Upan + la, Np, Cnext + (size_t)la * Np + la, Np,
-                                                 bulk, bulk, Kp, -1.0, 1.0, sb, 0, -1, &b_ppp));
+                // regime 2: the CUs the masked bulk stream leaves to the chain (3 % of the chip) idle for most of a long
+                // trailing update.  Where the update is SR_FACT_FREE_RATIO times longer than a chain that has to wait for its
+                // CUs (a diagonal block then takes milliseconds instead of 0.26, a block step ~1.8 ms on average), it runs on the
+                // unmasked stream and takes the whole chip: the first three of the nine panels at N = 50000, 66.8 -> 67.2 TF
+                // (ratio 1: 67.2, 4: 66.8, 0.5 and below: 66.9 - 66.7 -- the chain's tail is exposed).
+                hipStream_t sbp = sb;
+                if (regime == 2 && si != nullptr) {
+                    const double t_bulk = (double)nd * (double)bulk * (double)bulk * (double)Kp / 65e12;      // s
+                    const double t_chain = (double)next_w * 1.8e-3;
+                    static const double free_ratio = getenv("SR_FACT_FREE_RATIO") ? atof(getenv("SR_FACT_FREE_RATIO")) : SR_FACT_FREE_RATIO;
+                    if (free_ratio > 0.0 && t_bulk > free_ratio * t_chain) sbp = si;
                 }
-                SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sb));
+                if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
+                SR_FH(hipStreamWaitEvent(sbp, h->ev_panel[pi & 1], 0));
+                // (two bulk streams: the previous trailing update may have run on the other one)
+                if (regime == 2 && n_bulk > 0) SR_FH(hipStreamWaitEvent(sbp, h->ev_bulk[(n_bulk - 1) & 1], 0));
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sbp);
+                    SR_F(sr_launch_gemm_tn_upper(Upan + la, Np, Upan + la, Np, Cnext + (size_t)la * Np + la, Np,
+                                                 bulk, bulk, Kp, -1.0, 1.0, sbp, 0, -1, &b_ppp));
+                }
+                SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sbp));
                 ++n_bulk;
             }
         }

@@ -323,7 +323,9 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //  model update (sr_capi_update.hip)         panels of sr_fact_panel(nb) blocks (r03_factor_bench and the comment there); streams:
 //                                            regime 1 up to SR_FACT_CHAIN_MAX_NB (128) blocks -- bulk stream without 32 CUs (64 for
 //                                            36 < nb <= 52: N = 5000 5.14 -> 4.99 ms) --, regime 2 beyond (8 CUs for the diagonal
-//                                            blocks); early inversion from nb >= 8; GEMM tile: sr_use_tile64* (sr_factor.hip)
+//                                            blocks; a trailing update SR_FACT_FREE_RATIO (2) times longer than the next chain takes
+//                                            the whole chip: N = 50000 66.8 -> 67.2 TF, r04_timeline50000); early inversion from
+//                                            nb >= 8; GEMM tile: sr_use_tile64* (sr_factor.hip)
 //  row append (sr_capi_append.hip)           one launch for +1 point with Np <= 512 (SR_APPEND1_MAX_NP0, r03_exploration_step), <= 16
 //                                            points matrix-vector shaped, 17 .. 128 on the MFMA tile (r03_append_bench); the Python layer
 //                                            appends up to N / 5 points and refactorises beyond (break-even r03_growing_model)
@@ -380,6 +382,9 @@ static inline int sr_var_small_groups_max(int Np, int n_out) {
 static inline int sr_fact_panel(int nb) { return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 24 : 48)))); }
 // CUs the bulk streams of the model update leave to the critical chain (regime 1: one per shader engine, two for 36 < nb
 // <= 52; regime 2: one per XCD for the diagonal blocks)
+// regime 2 of the model update (nb > SR_FACT_CHAIN_MAX_NB): a trailing update this many times longer than the next panel's
+// chain runs on the unmasked bulk stream (whole chip; the chain's diagonal blocks then wait for their CUs, hidden)
+#define SR_FACT_FREE_RATIO 2.0
 static inline int sr_fact_reserved_cus(int regime, int nb) { return regime == 2 ? 8 : ((nb > 36 && nb <= 52) ? 64 : 32); }
 // launches of the persistent chain kernel a batch of T rollouts over H steps may take before the per-step route is better
 static inline long sr_chain_max_launches(long T, int H) { return H <= 2 ? 1 : (T > SR_FUSED_T ? 6 : 2); }

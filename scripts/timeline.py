@@ -53,8 +53,42 @@ def show(d, max_rows=400):
                                                   r[ix[skey]] if skey else "-", g, r[ix["name"]].split("(")[0][-44:]))
 
 
+def showbig(d, min_ms=1.0):
+    """For an update of a LARGE model: every dispatch of at least min_ms on its own line, the short ones between them
+    collapsed per stream into (first start, last end, count, busy time)."""
+    for db in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
+        con = sqlite3.connect(db)
+        cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+        if not cols:
+            continue
+        skey = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else "name")
+        gkey = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else "start")
+        rows = list(con.execute("select name, start, end, %s, %s from kernels order by start" % (skey, gkey)))
+        starts = [i for i, r in enumerate(rows) if "sr_pack_y" in r[0]]
+        rows = rows[starts[-1]:] if starts else rows
+        t0 = rows[0][1]
+        print("== %s: last update spans %.2f ms, %d dispatches" % (db, (max(r[2] for r in rows) - t0) / 1e6, len(rows)))
+        pend = {}
+
+        def flush(sid):
+            g = pend.pop(sid, None)
+            if g:
+                print("%10.2f %9.2f  s=%-4s   [%d short dispatches, busy %.2f ms]" % ((g[0] - t0) / 1e6, (g[1] - g[0]) / 1e6, sid, g[2], g[3] / 1e6))
+        for name, st, en, sid, grid in rows:
+            if en - st >= min_ms * 1e6:
+                flush(sid)
+                print("%10.2f %9.2f  s=%-4s g=%-8s %s" % ((st - t0) / 1e6, (en - st) / 1e6, sid, grid, name.split("(")[0][-44:]))
+            else:
+                g = pend.get(sid)
+                pend[sid] = [st, en, 1, en - st] if g is None else [g[0], max(g[1], en), g[2] + 1, g[3] + en - st]
+        for sid in list(pend):
+            flush(sid)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "run":
+    if sys.argv[1] == "showbig":
+        showbig(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
+    elif sys.argv[1] == "run":
         run(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 2, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     else:
         show(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 400)
