@@ -8,6 +8,7 @@
 // 2. a 2-output GP on N = 300 synthetic points: factorise, predict at the training inputs and verify the exact
 //    posterior identity  mu(z_i) + s2n * alpha_i == y_i ; then one fused one-step reachability batch.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -99,8 +100,30 @@ int main() {
         dmin = std::fmin(dmin, hQ1[4 * t] * hQ1[4 * t + 3] - hQ1[4 * t + 1] * hQ1[4 * t + 2]);
     }
     std::printf("one-step reachability T=%d: n_bad = %d, max |Q-Q^T| = %.1e, min det Q1 = %.3e\n", T, bad, asym, dmin);
-    CK(sr_gp_destroy(h));
     if (bad != 0 || asym > 1e-15 || !(dmin > 0)) return 4;
+
+    // ---- 3. blocking single queries through the resident server (what an MPC's NLP solver does per iteration): no
+    // launch per query; plain host buffers in and out
+    if (sr_gp_server_start(h, 0.005) == 0) {
+        std::vector<double> out(2 * n_out + 2 * n_out * D + n_out * D * D);
+        double worst = 0;
+        for (int t = 0; t < 50; ++t) {
+            CK(sr_gp_server_call(h, &Z[t * D], 0, out.data(), 1.0));
+            for (int d = 0; d < n_out; ++d) {
+                worst = std::fmax(worst, std::fabs(out[d] - hmu[t * n_out + d]));
+                worst = std::fmax(worst, std::fabs(out[n_out + d] - hvar[t * n_out + d]));
+            }
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < 2000; ++t) CK(sr_gp_server_call(h, &Z[(t % N) * D], 1, out.data(), 1.0));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+        std::printf("resident server: 50 queries against sr_gp_predict max |diff| = %.1e; second-order call %.1f us\n", worst, us);
+        CK(sr_gp_server_stop(h));
+        if (worst > 1e-12) return 5;
+    } else {
+        std::printf("resident server: not available here (%s)\n", sr_last_error());
+    }
+    CK(sr_gp_destroy(h));
     std::printf("capi_demo OK\n");
     return 0;
 }

@@ -1912,7 +1912,8 @@ def test_single_query_mailbox_and_fallback_agree():
     assert lib.sr_wait_flag(B.ptr(io["h_flag"]), io["seq"] + 12345, 0.05) != 0
 
 
-@pytest.mark.parametrize("N,n_s,n_u", [(100, 2, 1), (150, 4, 1), (300, 2, 1), (450, 2, 1)])
+@pytest.mark.parametrize("N,n_s,n_u", [(100, 2, 1), (150, 4, 1), (300, 2, 1), (450, 2, 1), (5, 2, 1), (128, 2, 1), (512, 2, 1),
+                                      (200, 3, 2), (256, 2, 2)])
 def test_resident_server_answers_single_queries(N, n_s, n_u):
     """K0s (sr_gp_server_start / sr_gp_server_call): the resident workgroups answer __call__, linearize_predict(jacobians=True)
     and a one-row predict from their mailbox.  Against the launched routes of the same model (to the last bits: the server
