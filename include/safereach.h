@@ -89,6 +89,12 @@ int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
  * model's mean at the new points and no buffer of the factor's size is allocated while the padded size stays the same.
  * m <= 16 also leaves log det of the grown model on the host (sr_gp_logdet_cached). */
 int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info);
+/* ONE new point given in HOST memory (x_host: D doubles, y_host: n_out doubles; any host memory): what the reference's
+ * exploration loop does after every step (exploration_runner.py:186-188 -> update_model(x, y, replace_old=False)).  The
+ * point travels in the kernel arguments and the status words / log det come back through a pinned block the kernel
+ * writes: no copy command in either direction.  Only where the one-launch append applies (<= 512 padded rows, n_out <=
+ * 16); SR_EUNSUPPORTED otherwise, before anything is touched: copy the point to the device and call sr_gp_append. */
+int sr_gp_append1_host(sr_gp_t h, const double* x_host, const double* y_host, void* stream, int* info);
 
 /* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and
  * columns are at the FRONT (identity block): training point i has padded index i + (Np - N). */

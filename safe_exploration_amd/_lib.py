@@ -46,6 +46,7 @@ SIGNATURES = {
     "sr_gp_set_data_general": (_I, [_H, _P, _P, _P, _P, _P]),
     "sr_gp_factorize": (_I, [_H, _P, _PI]),
     "sr_gp_append": (_I, [_H, _P, _P, _I, _P, _PI]),
+    "sr_gp_append1_host": (_I, [_H, _P, _P, _P, _PI]),
     "sr_gp_padded_n": (_I, [_H, _PL]),
     "sr_gp_dims": (_I, [_H, _PI, _PI, _PI, _PL]),
     "sr_gp_export": (_I, [_H, _P, _P, _P]),

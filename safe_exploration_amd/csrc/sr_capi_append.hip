@@ -36,9 +36,36 @@ __global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int 
 // m <= 16 new points: U12 = U^-T B through the streaming kernels of the prediction path (the new points are
 // the queries), everything else as matrix-vector shaped passes -- see sr_factor.hip.  No big allocation while
 // the padded size stays the same (U^-1 ping-pongs between two buffers).
-static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m, hipStream_t s, int* info) {
+// x_host / y_host (sr_gp_append1_host): ONE new point given in host memory -- it travels in the kernel arguments and the
+// status words and log-det partials come back through a pinned block the kernel writes (no copy command either way);
+// only where the one-launch route applies, SR_EUNSUPPORTED before anything is touched otherwise.
+static bool append1_fused(const sr_gp* h, int m) {
+    const int Np1 = (int)round_up(h->N + m, SR_NB);
+    return m == 1 && h->Np <= SR_APPEND1_MAX_NP0 && Np1 <= SR_APPEND1_MAX_NP0 + SR_NB && h->small_path != 0;
+}
+
+static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m, hipStream_t s, int* info,
+                        const double* x_host = nullptr, const double* y_host = nullptr) {
     const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
     const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1, pf = SR_NB - m;
+    const bool host_new = x_host != nullptr;
+    if (host_new) {
+        if (!append1_fused(h, m) || n_out > SR_APPEND1_MAX_OUT) {
+            sr_set_error("sr_gp_append1_host: no one-launch append for this model (Np=%d, n_out=%d)", Np0, n_out);
+            return SR_EUNSUPPORTED;
+        }
+        if (!h->app_pin) {
+            void *p = nullptr, *pd = nullptr;
+            SR_HIP(hipHostMalloc(&p, sizeof(double) * (SR_APPEND1_MAX_OUT * SR_APPEND1_WGS + SR_APPEND1_MAX_OUT), hipHostMallocMapped));
+            if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) {
+                (void)hipHostFree(p);
+                (void)hipGetLastError();
+                sr_set_error("sr_gp_append1_host: pinned host memory is not device-visible here");
+                return SR_EUNSUPPORTED;
+            }
+            h->app_pin = p; h->app_pin_dev = (double*)pd;
+        }
+    }
     const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
     // scratch layout
     // (Xt, Y2, G, S, S^-1 once per output: every step below is ONE launch over all outputs)
@@ -84,11 +111,14 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
     // one point on a small model: the whole append is ONE launch (sr_append1_small_kernel)
-    const bool fused1 = m == 1 && Np0 <= SR_APPEND1_MAX_NP0 && Np1 <= SR_APPEND1_MAX_NP0 + SR_NB && h->small_path != 0;
+    const bool fused1 = append1_fused(h, m);
+    const int nld = n_out * SR_APPEND1_WGS;                       // (the one-launch route leaves partial sums)
     if (fused1) {
         SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
                                      Znew, Ynew, Wt1, alpha1, yT1,
-                                     Z1 + (size_t)N0 * D, ws + o_ld, info_dev, N0, Np0, Np1, D, n_out, s));
+                                     Z1 + (size_t)N0 * D, host_new ? h->app_pin_dev : ws + o_ld,
+                                     host_new ? reinterpret_cast<int*>(h->app_pin_dev + nld) : info_dev, N0, Np0, Np1, D, n_out, s,
+                                     x_host, y_host));
     } else {
     static_assert(SR_SMALL_T * SR_MAX_D <= 256, "the first workgroup of sr_append_y_kernel copies the new inputs");
     hipLaunchKernelGGL(sr_append_y_kernel, dim3((Np1 + 255) / 256, n_out), dim3(256), 0, s, h->yT, Np0, N0, Ynew, m,
@@ -130,10 +160,14 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     // for the information gain after every appended point)
     SR_A(sr_launch_logdet(Wt1, Np1, n_out, ws + o_ld, s));
     }
-    const int nld = n_out * SR_APPEND1_WGS;                       // (the one-launch route leaves partial sums)
     std::vector<double> back(nld + (n_out + 1) / 2, 0.0);         // the log dets, then n_out ints
-    SR_AH(hipMemcpyAsync(back.data(), ws + o_ld, sizeof(double) * nld + sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
-    SR_AH(hipStreamSynchronize(s));
+    if (host_new) {
+        SR_AH(hipStreamSynchronize(s));                           // (the kernel wrote both into the pinned block)
+        memcpy(back.data(), h->app_pin, sizeof(double) * nld + sizeof(int) * n_out);
+    } else {
+        SR_AH(hipMemcpyAsync(back.data(), ws + o_ld, sizeof(double) * nld + sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
+        SR_AH(hipStreamSynchronize(s));
+    }
     std::vector<int> info_h(n_out, 0);
     memcpy(info_h.data(), back.data() + nld, sizeof(int) * n_out);
     for (int d = 0; d < n_out; ++d) {
@@ -187,6 +221,18 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         dev_free(h->app_ws); h->app_ws = nullptr; h->app_cap = 0;
     }
     return SR_OK;
+}
+
+extern "C" int sr_gp_append1_host(sr_gp_t h, const double* x_host, const double* y_host, void* stream, int* info) {
+    SR_CHECK(h != nullptr && x_host && y_host, SR_EINVAL, "sr_gp_append1_host: NULL argument");
+    SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_append1_host: model not factorized");
+    SR_DEVICE(h->device);
+    if (!append1_fused(h, 1) || h->n_out > SR_APPEND1_MAX_OUT) {
+        sr_set_error("sr_gp_append1_host: no one-launch append for this model (Np=%d, n_out=%d)", h->Np, h->n_out);
+        return SR_EUNSUPPORTED;
+    }
+    SR_TRY(server_quiesce(h));
+    return append_small(h, nullptr, nullptr, 1, (hipStream_t)stream, info, x_host, y_host);
 }
 
 extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info) {

@@ -227,6 +227,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     dev_free(h->yT_alt); dev_free(h->alpha_alt);
     free_ws(h);
     dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->Wt_alt);
+    if (h->app_pin) (void)hipHostFree(h->app_pin);
     for (hipEvent_t e : {h->fact_join, h->ev_panel[0], h->ev_panel[1], h->ev_bulk[0], h->ev_bulk[1], h->ev_inv[0], h->ev_inv[1]})
         if (e) (void)hipEventDestroy(e);
     if (h->fact_fork) (void)hipEventDestroy(h->fact_fork);

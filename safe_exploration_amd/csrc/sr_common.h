@@ -400,10 +400,11 @@ int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* 
 // one new point on a small model (Np0 <= 512, Np1 <= 640; kp != NULL: general kernels), all outputs, ONE launch (sr_factor.hip);
 // logdet: n_out x SR_APPEND1_WGS partial sums
 #define SR_APPEND1_WGS 8
+#define SR_APPEND1_MAX_OUT 16   // outputs whose new targets fit the kernel arguments (sr_gp_append1_host)
 int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                             const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
-                            int D, int n_out, hipStream_t s);
+                            int D, int n_out, hipStream_t s, const double* x_host = nullptr, const double* y_host = nullptr);
 int sr_launch_append_small(const double* U12t, const double* Wt0, int Np0, int m, int stage, double* G,
                            const double* invS, double* Xt, double* Y2, hipStream_t s, int nbatch = 1);
 

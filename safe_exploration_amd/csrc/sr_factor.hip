@@ -1218,14 +1218,20 @@ struct sr_append1_args {
     double* Wt1; double* alpha1; double* yT1; double* Zdst;                           // new state (Zdst: row N0 of Z, or NULL)
     double* logdet; int* info;                                                        // n_out each
     int N0, Np0, Np1, D, n_out;
+    // the new point in the kernel arguments (a host caller: no H2D copy command); znew / ynew are NULL then
+    int inl; double xin[SR_MAX_D]; double yin[SR_APPEND1_MAX_OUT];
 };
 
 template <int NPMAX>   // 256 or 512: the old padded size it serves
 __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args a) {
     __shared__ double b[NPMAX], u12[NPMAX], X[NPMAX], part[4][NPMAX], red[16];
     __shared__ double s_mu, s_inv, s_v2;
+    __shared__ double zn[SR_MAX_D];                          // the new input (from memory or from the kernel arguments)
     const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N0 = a.N0, Np0 = a.Np0, Np1 = a.Np1, D = a.D;
+    if (tid < D) zn[tid] = a.inl ? a.xin[tid] : a.znew[tid];
+    const double y_new = a.inl ? a.yin[d] : a.ynew[d];
+    __syncthreads();
     auto sr_wave_sum = [](double v) {
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         return v;
@@ -1237,7 +1243,7 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
     // gridDim.y workgroups per output share the rows of the new factor (each of them repeats the cheap first part: one
     // workgroup alone writes a 256-row factor in 25 us, four take 8); workgroup y = 0 also reports failure and copies z_new
     const int wy = blockIdx.y, nwy = gridDim.y;
-    if (d == 0 && wy == 0 && a.Zdst && tid < D) a.Zdst[tid] = a.znew[tid];
+    if (d == 0 && wy == 0 && a.Zdst && tid < D) a.Zdst[tid] = zn[tid];
     // ---- b = K(Z_old, z_new) in padded row indexing, mu_old = b . alpha0
     double mu_t = 0.0;
 #pragma unroll 1
@@ -1250,16 +1256,16 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
                 const double *sv = kp + 3, *av = kp + 3 + D, *bv = kp + 3 + 2 * D;
                 double r2 = 0.0, la = 0.0, lb = 0.0;
                 for (int c = 0; c < D; ++c) {
-                    const double t = (z[c] - a.znew[c]) * sv[c];
+                    const double t = (z[c] - zn[c]) * sv[c];
                     r2 = fma(t, t, r2);
-                    la = fma(av[c] * z[c], a.znew[c], la);
-                    lb = fma(bv[c] * z[c], a.znew[c], lb);
+                    la = fma(av[c] * z[c], zn[c], la);
+                    lb = fma(bv[c] * z[c], zn[c], lb);
                 }
                 v = (kp[2] + la) * kp[1] * sr_kappa((int)kp[0], r2) + lb;
             } else {
                 double r2 = 0.0;
                 for (int c = 0; c < D; ++c) {
-                    const double t = (z[c] - a.znew[c]) / a.ls[d * D + c];
+                    const double t = (z[c] - zn[c]) / a.ls[d * D + c];
                     r2 = fma(t, t, r2);
                 }
                 v = a.sf2[d] * exp(-0.5 * r2);
@@ -1312,8 +1318,8 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
             const double* kp = a.kp + (long)d * SR_KP(D);
             double la = 0.0, lb = 0.0;
             for (int c = 0; c < D; ++c) {
-                la = fma(kp[3 + D + c] * a.znew[c], a.znew[c], la);
-                lb = fma(kp[3 + 2 * D + c] * a.znew[c], a.znew[c], lb);
+                la = fma(kp[3 + D + c] * zn[c], zn[c], la);
+                lb = fma(kp[3 + 2 * D + c] * zn[c], zn[c], lb);
             }
             prior = (kp[2] + la) * kp[1] + lb;               // kappa(0) = 1
         } else {
@@ -1329,7 +1335,7 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
         double sd, inv;
         sr_sqrt_rsqrt(sch, sd, inv);
         s_inv = inv;
-        s_v2 = inv * (a.ynew[d] - s_mu);
+        s_v2 = inv * (y_new - s_mu);
     }
     __syncthreads();
     const double inv = s_inv, v2 = s_v2;
@@ -1348,7 +1354,7 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
             for (int C = lane; C < Np1; C += 64) dst[C] = (C == R) ? dg : 0.0;
             if (lane == 0) {
                 alpha1[R] = (R == Rlast) ? inv * v2 : 0.0;
-                yT1[R] = (R == Rlast) ? a.ynew[d] : 0.0;
+                yT1[R] = (R == Rlast) ? y_new : 0.0;
                 if (R == Rlast) ld += log(inv);
             }
             continue;
@@ -1387,9 +1393,16 @@ __global__ __launch_bounds__(1024) void sr_append1_small_kernel(sr_append1_args 
 int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                             const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
-                            int D, int n_out, hipStream_t s) {
+                            int D, int n_out, hipStream_t s, const double* x_host, const double* y_host) {
     SR_CHECK(Np0 <= 512 && Np1 <= 640 && N0 >= 1 && N0 <= Np0, SR_EINVAL, "append1_small: Np0 = %d, Np1 = %d", Np0, Np1);
-    sr_append1_args a{Wt0, alpha0, yT0, Z, ls, sf2, noise, kp, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out};
+    sr_append1_args a{Wt0, alpha0, yT0, Z, ls, sf2, noise, kp, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out,
+                      0, {}, {}};
+    if (x_host) {                                            // the new point travels in the kernel arguments
+        SR_CHECK(y_host && D <= SR_MAX_D && n_out <= SR_APPEND1_MAX_OUT, SR_EINVAL, "append1_small: D = %d, n_out = %d", D, n_out);
+        a.inl = 1; a.znew = nullptr; a.ynew = nullptr;
+        for (int c = 0; c < D; ++c) a.xin[c] = x_host[c];
+        for (int d = 0; d < n_out; ++d) a.yin[d] = y_host[d];
+    }
     if (Np0 <= 256) hipLaunchKernelGGL(sr_append1_small_kernel<256>, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(sr_append1_small_kernel<512>, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
     SR_HIP(hipGetLastError());

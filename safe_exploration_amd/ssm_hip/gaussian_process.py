@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _buffers as B
-from .._lib import lib, check, last_error
+from .._lib import lib, check, last_error, SR_EUNSUPPORTED
 from ..state_space_models import StateSpaceModel
 
 _server_call = lib.sr_gp_server_call
@@ -506,7 +506,19 @@ class SimpleGPModel(StateSpaceModel):
         step = 16 if x.shape[0] <= 16 else 128
         for lo in range(0, x.shape[0], step):
             xs, ys = x[lo:lo + step], y[lo:lo + step]
-            if xs.shape[0] <= 16:
+            info = (ctypes.c_int * self.n_s_out)()
+            rc = None
+            if xs.shape[0] == 1 and getattr(hd, "_append1_off_np", None) != hd.Np:
+                # one point (the exploration loop, exploration_runner.py:186-188): it travels in the kernel arguments, status
+                # and log det come back through a pinned block -- no copy command either way (sr_gp_append1_host)
+                xr, yr = np.ascontiguousarray(xs[0]), np.ascontiguousarray(ys[0])
+                rc = lib.sr_gp_append1_host(hd.h, ctypes.c_void_p(xr.ctypes.data), ctypes.c_void_p(yr.ctypes.data), s, info)
+                if rc == SR_EUNSUPPORTED:
+                    hd._append1_off_np = hd.Np       # not for this padded size: the general route from now on
+                    rc = None
+            if rc is not None:
+                check(rc)
+            elif xs.shape[0] <= 16:
                 # one pinned block, one H2D copy for both arrays (two pageable copies cost 35 us of the 125 us of a
                 # one-point append); sr_gp_append returns after its own stream synchronisation, the block is free again
                 st = getattr(hd, "_staging", None)
@@ -515,10 +527,10 @@ class SimpleGPModel(StateSpaceModel):
                 (tx, ty), _ = st.stage([np.ascontiguousarray(xs), np.ascontiguousarray(ys)], [])
             else:
                 tx, ty = B.as_dev(xs, hd.device), B.as_dev(ys, hd.device)
-            info = (ctypes.c_int * self.n_s_out)()
             # a failing chunk (SR_ENOTPD on a near-duplicate point, out of memory) leaves the handle as it was
             # before THAT chunk: the host state below is committed chunk by chunk, so both always agree
-            check(lib.sr_gp_append(hd.h, B.ptr(tx), B.ptr(ty), xs.shape[0], s, info))
+            if rc is None:
+                check(lib.sr_gp_append(hd.h, B.ptr(tx), B.ptr(ty), xs.shape[0], s, info))
             hd.N += xs.shape[0]
             npad = ctypes.c_long(0)
             check(lib.sr_gp_padded_n(hd.h, ctypes.byref(npad)))

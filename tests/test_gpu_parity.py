@@ -827,6 +827,56 @@ def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
     np.testing.assert_array_equal(var2, var)
 
 
+@pytest.mark.parametrize("kt", ["rbf", "lin_mat52"])
+def test_one_point_append_from_host_memory_equals_the_device_pointer_route(kt):
+    """sr_gp_append1_host (the new point in the kernel arguments, status words and log det through a pinned block the kernel
+    writes) against sr_gp_append with device pointers: the same launch, the same bits; declined (SR_EUNSUPPORTED, nothing
+    touched) beyond 512 padded rows."""
+    import ctypes
+    import torch
+    from safe_exploration_amd import _lib, _buffers as B
+    syn = orc.make_synthetic(611, 140, 2, 1, 8)
+    Z, Y = syn["Z"], syn["Y"]
+
+    def model(n):
+        if kt == "rbf":
+            return hip_model(Z[:n], Y[:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+        from safe_exploration_amd import SimpleGPModel
+        rng = np.random.default_rng(5)
+        hyp = [dict(orc.make_hyp(kt, rng, 3), noise_variance=nv) for nv in (0.02, 0.03)]
+        gp = SimpleGPModel(2, 2, 1, kern_types=[kt] * 2, hyp=hyp, device="cuda:0")
+        gp.train(Z[:n], Y[:n], opt_hyp=False)
+        return gp
+
+    a, b = model(120), model(120)
+    a.append_limit = b.append_limit = 10 ** 9
+    for i in range(120, 135):                                    # crosses 128 -> 256 padded rows
+        a.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)          # host route
+        hd = b._handle
+        tx, ty = B.as_dev(Z[i:i + 1], hd.device), B.as_dev(Y[i:i + 1], hd.device)
+        info = (ctypes.c_int * 2)()
+        _lib.check(_lib.lib.sr_gp_append(hd.h, B.ptr(tx), B.ptr(ty), 1, B.stream_ptr(hd.device), info))
+        torch.cuda.synchronize()
+        npad = ctypes.c_long(0)                                  # (what SimpleGPModel._append keeps on the host side)
+        _lib.check(_lib.lib.sr_gp_padded_n(hd.h, ctypes.byref(npad)))
+        hd.N, hd.Np = hd.N + 1, npad.value
+    wa, wb = a.export_state(), b.export_state()
+    for u, v in zip(wa, wb):
+        np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
+    la, lb = (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
+    assert _lib.lib.sr_gp_logdet_cached(a._handle.h, la) == 0 and _lib.lib.sr_gp_logdet_cached(b._handle.h, lb) == 0
+    assert list(la) == list(lb)
+    big = hip_model(np.vstack([Z] * 5)[:600] + 0.01 * np.arange(600)[:, None], np.vstack([Y] * 5)[:600], syn["lengthscale"],
+                    syn["signal_var"], syn["noise_var"], 2, 1)
+    x1, y1 = np.ascontiguousarray(Z[0] + 0.5), np.ascontiguousarray(Y[0])
+    info = (ctypes.c_int * 2)()
+    rc = _lib.lib.sr_gp_append1_host(big._handle.h, ctypes.c_void_p(x1.ctypes.data), ctypes.c_void_p(y1.ctypes.data),
+                                     B.stream_ptr(big._handle.device), info)
+    assert rc == _lib.SR_EUNSUPPORTED
+    n = ctypes.c_long(0)
+    assert _lib.lib.sr_gp_padded_n(big._handle.h, ctypes.byref(n)) == 0 and n.value == 640
+
+
 @pytest.mark.parametrize("kt,N0,adds", [("lin_mat52", 90, [1, 4]), ("mat52", 250, [16, 1]), ("lin_rbf", 600, [3, 1, 40]),
                                         ("lin_mat52", 125, [1] * 6), ("mat52", 30, [1, 1, 1])])
 def test_row_append_with_the_journal_kernels(kt, N0, adds):
