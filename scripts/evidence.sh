@@ -46,6 +46,22 @@ PY
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$REPO/gpurun_out/prof_$TAG/tl5000" -o tl -- \
     python "$REPO/scripts/timeline.py" run 5000 > "$EV/.tl.log" 2>&1 )
 python scripts/timeline.py show "$REPO/gpurun_out/prof_$TAG/tl5000" 400 > "$EV/${TAG}_timeline5000.txt" 2>>"$EV/.err"
+# kernel timeline of ONE N = 50000 model update: default build (long trailing updates on the unmasked stream) and with every
+# trailing update on the masked stream; dispatches >= 4 ms, then the first chain-under-update region in full
+{ echo "# kernel timeline of ONE model update at N = 50000, n_out = 2 (scripts/timeline.py run 50000 under rocprofv3 --kernel-trace; columns: start [ms], duration [ms], stream, grid threads, kernel; the short dispatches between two long ones collapsed per stream)"
+  for ratio in default 0; do
+    rm -rf "$REPO/gpurun_out/prof_$TAG/tl50000"
+    if [ $ratio = default ]; then unset SR_FACT_FREE_RATIO; else export SR_FACT_FREE_RATIO=$ratio; fi
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -d "$REPO/gpurun_out/prof_$TAG/tl50000" -o tl -- \
+        python "$REPO/scripts/timeline.py" run 50000 > "$EV/.tl50k_$ratio.log" 2>&1 )
+    python scripts/timeline.py showbig "$REPO/gpurun_out/prof_$TAG/tl50000" 1.0 > "$EV/.tl50k_$ratio.txt" 2>>"$EV/.err"
+    echo "# ---- SR_FACT_FREE_RATIO=$ratio: dispatches >= 4 ms"
+    grep -v "short dispatches" "$EV/.tl50k_$ratio.txt" | awk 'NR==1 || $2>4'
+  done
+  unset SR_FACT_FREE_RATIO
+  echo "# ---- default build: from the end of the first panel's chain to the start of the second trailing update, everything"
+  awk '$1>55 && $1<480' "$EV/.tl50k_default.txt" | head -150
+  rm -rf "$REPO/gpurun_out/prof_$TAG/tl50000"; } > "$EV/${TAG}_timeline50000.txt"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof_$TAG/chain" -o chain -- \
     python "$REPO/scripts/chain_bench.py" > "$EV/.chaintrace.log" 2>&1 )
 python - "$REPO/gpurun_out/prof_$TAG/chain" > "$EV/${TAG}_chain_kernel_stats.txt" <<'PY'
