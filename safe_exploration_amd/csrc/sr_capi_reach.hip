@@ -1,6 +1,6 @@
 // sr_capi_reach.hip -- reachability entry points: one-step and multi-step ellipsoid propagation, Gaussian moment
 // propagation, the stateless per-query steps (ellipsoid, remainder, safety distance, distance to centre, sampling)
-// and the dispatch of the persistent chain kernel (sr_small.hip K0c) with its process-wide launch gate.
+// and the dispatch of the persistent chain kernel (sr_chain.hip K0c) with its process-wide launch gate.
 #include "sr_handle.h"
 using namespace srh;
 
@@ -103,14 +103,14 @@ struct sr_chain_turn {                 // holds the gate from the wait to the re
     ~sr_chain_turn() { if (active) g_chain_gate.m.unlock(); }
 };
 
-// The persistent kernel of sr_small.hip (K0c) for a chain of H >= 1 steps, where it applies; *taken says whether it ran.
+// The persistent kernel of sr_chain.hip (K0c) for a chain of H >= 1 steps, where it applies; *taken says whether it ran.
 static int try_chain(sr_gp* h, long T, int H, int mode, const double* p0, const double* q0, const double* k_fb0,
                      const double* k_ff, const double* k_fb, const double* a, const double* b, const double* l_mu,
                      const double* l_sigma, double c_safety, double* p_all, double* q_all, double* gp_var_all,
                      int* n_bad, int n_s, int n_u, hipStream_t s, bool* taken) {
     *taken = false;
     const long nss = (long)n_s * n_s, nus = (long)n_u * n_s;
-    // small model, few rollouts: the whole chain in one launch (sr_small.hip K0c).  One launch holds SR_CHAIN_GROUPS
+    // small model, few rollouts: the whole chain in one launch (sr_chain.hip K0c).  One launch holds SR_CHAIN_GROUPS
     // workgroups = gmax groups of 16 rollouts (n_s Np / 128 posterior workgroups + the tail workgroup each): 768 rollouts
     // of a pendulum model with N <= 256, 416 of a cart-pole model.  Measured at N = 200, H = 15: 256 rollouts 246
     // (per-step launches) -> 102 us.

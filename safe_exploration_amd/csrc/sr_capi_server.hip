@@ -1,4 +1,4 @@
-// sr_capi_server.hip -- the resident single-query server (kernel K0s, sr_small.hip): start / stop / blocking call, and the
+// sr_capi_server.hip -- the resident single-query server (kernel K0s, sr_server.hip): start / stop / blocking call, and the
 // hooks the other entry points use to take it off the device before they write the model or wait for the whole device.
 //
 // replaces the blocking evaluation inside CasadiSSMEvaluator.eval / JacFun.eval / BackFun.eval

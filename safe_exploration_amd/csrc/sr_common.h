@@ -198,7 +198,7 @@ int sr_launch_gp_small(const sr_kstar_args& a, const double* Wt, double* mu, dou
 int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac_mu,
                            double* jac_var, double* hess_mu, hipStream_t s);
 
-// K0s (sr_small.hip): resident single-query server of a small ARD-RBF model: one workgroup per output polls a mailbox in
+// K0s (sr_server.hip): resident single-query server of a small ARD-RBF model: one workgroup per output polls a mailbox in
 // pinned host memory.  All pointers are the DEVICE-visible addresses of pinned host memory.
 struct sr_server_args {
     unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 4] x (D <= 5 doubles), [5] launch epoch (any other value: leave),
@@ -220,7 +220,7 @@ struct sr_server_args {
 #define SR_SERVER_CMD_PING 4ull      /* diagnostics: answer at once, evaluate nothing */
 int sr_launch_gp_server(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s);
 
-// Persistent multi-step kernel (sr_small.hip): the whole H-step chain of up to SR_CHAIN_GROUPS / (n_out Np / 128) * 16
+// Persistent multi-step kernel (sr_chain.hip): the whole H-step chain of up to SR_CHAIN_GROUPS / (n_out Np / 128) * 16
 // rollouts in ONE launch (the posterior of sr_gp_small_kernel and the step of sr_ellipsoid_kernel inside a loop over the steps).
 struct sr_xel { double v; unsigned long long chk; };      // 16 bytes, written and read by single instructions; chk = bits(v) ^ mix(tag)
 struct sr_chain_args {

@@ -1,5 +1,5 @@
 // sr_ellipsoid_dev.h -- the per-query ellipsoid step as a device function (shared by sr_ellipsoid.hip and the
-// persistent multi-step kernel of sr_small.hip).
+// persistent multi-step kernel of sr_chain.hip).
 //
 // replaces the algebra of
 //   /root/reference/safe_exploration/gp_reachability.py:65-88   (point branch)
@@ -130,7 +130,7 @@ __device__ __forceinline__ double sr_lambda_max_qb(const double (&q)[NS][NS],
 }
 
 // One ellipsoid (or Gaussian-moment) step of query t; every pointer of `a` may be global or LDS (flat addressing):
-// the persistent chain kernel of sr_small.hip keeps the state of its 16 rollouts in LDS between steps.
+// the persistent chain kernel of sr_chain.hip keeps the state of its 16 rollouts in LDS between steps.
 // p / q are read completely before p_out / q_out are written, so the step may run in place.
 template <int NS, int NU>
 __device__ __forceinline__ void sr_ellipsoid_one(const sr_ell_args& a, long t) {

@@ -17,7 +17,7 @@
 #include <vector>
 #include <algorithm>
 
-// resident single-query server (sr_capi_server.hip, kernel K0s of sr_small.hip)
+// resident single-query server (sr_capi_server.hip, kernel K0s of sr_server.hip)
 struct sr_server {
     int armed = 0;                           // sr_gp_server_start was called: sr_gp_server_call (re)launches as needed
     int running = 0;                         // a launch of this handle may be resident
@@ -41,7 +41,7 @@ struct sr_gp {
     // GP input transform of the reachability / moment entry points: x_gp = Tz x (Tz n_xin x n_s), NULL = identity
     double* Tz = nullptr; int n_xin = 0;
     double *tz_x = nullptr, *tz_jac = nullptr; long tz_cap = 0;   // transformed inputs / chain-ruled Jacobians (per chunk)
-    // persistent multi-step kernel (sr_small.hip K0c): exchange buffer, per group ticket + epoch + done counter (all of
+    // persistent multi-step kernel (sr_chain.hip K0c): exchange buffer, per group ticket + epoch + done counter (all of
     // the hand-off state lives on the device), switch
     sr_xel* chain_xch = nullptr; unsigned long long* chain_tickets = nullptr;       // the groups' epochs
     unsigned* chain_done = nullptr; int chain = 1; int last_chain = 0; int chain_cap = -1;

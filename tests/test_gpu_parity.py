@@ -1695,7 +1695,7 @@ def test_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
     np.testing.assert_allclose(sig_f.reshape(H, n_s, n_s), g["sigma_taylor"][0], rtol=1e-7, atol=1e-13)
 
 
-# ------------------------------------------------------------------ persistent multi-step kernel (sr_small.hip K0c)
+# ------------------------------------------------------------------ persistent multi-step kernel (sr_chain.hip K0c)
 @pytest.mark.parametrize("n_s,n_u,N,T,H,with_q0", [
     (2, 1, 100, 1, 2, False),        # Np = 128, one rollout
     (2, 1, 200, 256, 15, False),     # the regime of the reference's experiments
