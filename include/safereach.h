@@ -342,7 +342,7 @@ int sr_test_gemm_tn_upper(int device, const double* A, long lda, const double* B
 /* diagnostic: the diagonal-block kernel of the factorisation alone: A (128 x 128 SPD, upper triangle read, leading
  * dimension lda) -> upper Cholesky factor in place, wt = its inverse, w = the inverse transposed (leading dimension
  * ldw); info: device int, 0 or the 1-based first non-positive pivot.  skip: 0 in production; 64 leaves A untouched
- * (back-to-back timing on one input), 128 runs the round-2 kernel (A/B timing). */
+ * (back-to-back timing on one input). */
 int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, long ldw, int* info, int skip,
                        void* stream);
 /* diagnostic: the following persistent multi-step launches of the handle are `drop` workgroups short, so that the last

@@ -34,7 +34,7 @@ __global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int 
 }
 
 // m <= 16 new points: U12 = U^-T B through the streaming kernels of the prediction path (the new points are
-// the queries), everything else as matrix-vector shaped passes -- see sr_factor.hip.  No big allocation while
+// the queries), everything else as matrix-vector shaped passes -- see sr_append.hip.  No big allocation while
 // the padded size stays the same (U^-1 ping-pongs between two buffers).
 // x_host / y_host (sr_gp_append1_host): ONE new point given in host memory -- it travels in the kernel arguments and the
 // status words and log-det partials come back through a pinned block the kernel writes (no copy command either way);

@@ -325,7 +325,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //                                            36 < nb <= 52: N = 5000 5.14 -> 4.99 ms) --, regime 2 beyond (8 CUs for the diagonal
 //                                            blocks; a trailing update SR_FACT_FREE_RATIO (2) times longer than the next chain takes
 //                                            the whole chip: N = 50000 66.8 -> 67.2 TF, r04_timeline50000); early inversion from
-//                                            nb >= 8; GEMM tile: sr_use_tile64* (sr_factor.hip)
+//                                            nb >= 8; GEMM tile: sr_use_tile64* (sr_gemm.hip)
 //  row append (sr_capi_append.hip)           one launch for +1 point with Np <= 512 (SR_APPEND1_MAX_NP0, r03_exploration_step), <= 16
 //                                            points matrix-vector shaped, 17 .. 128 on the MFMA tile (r03_append_bench); the Python layer
 //                                            appends up to N / 5 points and refactorises beyond (break-even r03_growing_model)
@@ -397,7 +397,7 @@ int sr_launch_var_small_gather_all(const double* Vp, double* v, int Np, int n_ou
 int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* Y2, const double* invS,
                            const double* mu_part, int nsplit, int n_out, int d, long Tp, const double* Ynew, int m,
                            double* alpha1, int Np1, hipStream_t s, int qoff = 0, int nbatch = 1, long sY2 = 0);
-// one new point on a small model (Np0 <= 512, Np1 <= 640; kp != NULL: general kernels), all outputs, ONE launch (sr_factor.hip);
+// one new point on a small model (Np0 <= 512, Np1 <= 640; kp != NULL: general kernels), all outputs, ONE launch (sr_append.hip);
 // logdet: n_out x SR_APPEND1_WGS partial sums
 #define SR_APPEND1_WGS 8
 #define SR_APPEND1_MAX_OUT 16   // outputs whose new targets fit the kernel arguments (sr_gp_append1_host)
