@@ -24,6 +24,7 @@ timeout 300 python scripts/chain_bench.py > "$EV/${TAG}_chain_bench.txt" 2>>"$EV
 timeout 300 python scripts/onestep_bench.py > "$EV/${TAG}_onestep_bench.txt" 2>>"$EV/.err"
 timeout 600 python scripts/fuzz_chain.py 60 4 > "$EV/${TAG}_fuzz_chain.txt" 2>>"$EV/.err"
 timeout 600 python scripts/fuzz_predict.py > "$EV/${TAG}_fuzz_predict.txt" 2>>"$EV/.err"
+timeout 600 python scripts/fuzz_server.py > "$EV/${TAG}_fuzz_server.txt" 2>>"$EV/.err"
 timeout 300 python scripts/diag_bench.py > "$EV/${TAG}_diag_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/call_latency.py > "$EV/${TAG}_call_latency.txt" 2>>"$EV/.err"
 timeout 300 python scripts/linearize_bench.py > "$EV/${TAG}_linearize_bench.txt" 2>>"$EV/.err"
