@@ -167,6 +167,7 @@ extern "C" int sr_gp_server_state(sr_gp_t h, int* armed, int* resident, long* la
 
 extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_order, double* out_host, double timeout_s) {
     SR_CHECK(h != nullptr && x_host && out_host, SR_EINVAL, "sr_gp_server_call: NULL argument");
+    SR_CHECK(timeout_s == timeout_s, SR_EINVAL, "sr_gp_server_call: time-out is NaN");
     sr_server& sv = h->srv;
     std::lock_guard<std::mutex> lk(sv.mu);
     if (!sv.armed) { sr_set_error("sr_gp_server_call: no server armed (sr_gp_server_start)"); return SR_EUNSUPPORTED; }
