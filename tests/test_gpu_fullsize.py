@@ -529,7 +529,8 @@ def test_no_access_past_a_buffer_under_guard_allocation():
     import subprocess
     env = dict(os.environ, SR_GUARD="1", SR_POISON="1")     # ... and new buffers hold NaN patterns, not zeros
     sel = ("fused_small_model_linearize or ragged or small_batch_streaming or splitk or all_state_action or "
-           "row_append or streamed_linearize or fused_small_model_pass or persistent_chain_matches")
+           "row_append or streamed_linearize or fused_small_model_pass or persistent_chain_matches or "
+           "resident_server_answers or one_point_append")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                         "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-1500:]
