@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time the diagonal-block kernel of the factorisation alone (200 back-to-back launches on one input) against the
-round-2 kernel, and check factor and inverse against NumPy.  GPU box:  python scripts/diag_bench.py"""
+"""Time the diagonal-block kernel of the factorisation alone (200 back-to-back launches on one input) and check factor
+and inverse against NumPy.  GPU box:  python scripts/diag_bench.py"""
 import os
 import sys
 
