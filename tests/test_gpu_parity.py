@@ -2063,6 +2063,16 @@ def test_resident_server_idle_timeout_restart_and_model_updates():
     mu, var = gp.predict(np.hstack((big["p"][:1], big["k_ff"][:1])))
     np.testing.assert_array_equal(o[0][:, 0], mu[0])
     assert gp.start_server() is False
+    # the journal experiments' kernels have no resident server either: declined, the launched routes answer
+    from safe_exploration_amd import SimpleGPModel
+    rng = np.random.default_rng(3)
+    hyp = [dict(orc.make_hyp("lin_mat52", rng, 3), noise_variance=nv) for nv in (0.02, 0.03)]
+    gm = SimpleGPModel(2, 2, 1, kern_types=["lin_mat52"] * 2, hyp=hyp)
+    gm.train(syn["Z"][:60], syn["Y"][:60], opt_hyp=False)
+    assert gm.start_server() is False and gm.server_state()[0] is False
+    o = gm(syn["p"][:1], syn["k_ff"][:1])
+    mu, var = gm.predict(np.hstack((syn["p"][:1], syn["k_ff"][:1])))
+    np.testing.assert_allclose(o[0][:, 0], mu[0], rtol=1e-12, atol=1e-14)
 
 
 def test_resident_server_request_given_up_and_callers_on_two_threads():
