@@ -984,7 +984,7 @@ def test_distance_to_center_batch_vs_reference_golden():
 def test_moment_propagation_vs_reference_golden(name, n_s, n_u):
     """Taylor / mean-equivalent Gaussian moment propagation; expected values are the reference's
     own multi_step_taylor_symbolic / mean_equivalent_multistep evaluated on numbers."""
-    from safe_exploration_amd import uncertainty_propagation as prop
+    from safe_exploration_amd import uncertainty_propagation_casadi as prop
     g = load_golden(name)
     gp = hip_model(g["Z"], g["Y"], g["lengthscale"], g["signal_var"], g["noise_var"], n_s, n_u)
     for tag, mode in (("taylor", prop.TAYLOR), ("meaneq", prop.MEAN_EQUIVALENT)):
@@ -1646,7 +1646,7 @@ def test_gp_input_transform_vs_reference_golden(name, n_s, n_xin, n_u):
     sees t_z_gp @ state -- the journal cart-pole configuration drops the cart position (n_s = 4, D = 4).  Fixtures: the
     reference's numeric onestep / multistep functions on the wrapped model and its moment-propagation builders with
     a_gp_inp_x, both evaluated in the build container (tests/golden/make_golden.py, tz_case)."""
-    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, uncertainty_propagation as prop
+    from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, uncertainty_propagation_casadi as prop
     g = load_golden(name)
     tz = g["tz"]
     gp = SimpleGPModel(n_s, n_xin, n_u, kern_types=["rbf"] * n_s,
