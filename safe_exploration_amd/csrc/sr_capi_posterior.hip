@@ -102,7 +102,18 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
     // 2 .. 4 queries on a moderate model: the one-launch VALU kernel has only ncb (ncb + 1) n_out workgroups of 256
     // threads there and loses to K1 + MFMA kernel + reduce (N = 700: 27 against 21 us; N = 3000: 34 against 40 us)
     const bool mfma_small = Tc >= 2 && Tc <= 4 && h->Np <= SR_MFMA_SMALL_MAX_NP;
-    const bool fused = !h->general && h->D <= SR_STREAM_FUSED_MAX_D && Tc <= 4 && !mfma_small;
+    // 5 .. 32 queries (and 2 .. 4 on the MFMA kernel) where the MFMA route runs one-chunk work items of 16 or 32 columns:
+    // the workgroups evaluate their rows of K* themselves too, no K* pass in front (T = 16, N = 1024 / 1500 / 2000 / 3000:
+    // 23 / 26 / 28 / 39 -> 21 / 23 / 25 / 34 us; T = 32, N = 1024 / 1500 / 2000: 25 / 28 / 35 -> 22 / 25 / 31 us).  Every
+    // column block re-evaluates a chunk's rows, so wide work items on models of many column blocks lose (32 columns at
+    // N = 3000: 49 -> 53 us, 64 columns: 76 -> 93 us): those, and the run kernel of the big models, read K* from its pass.
+    bool fused_mfma = false;
+    if (!h->general && h->D <= SR_STREAM_FUSED_MAX_D && (Tc > 4 || mfma_small) && h->small_path != 0) {
+        int g = 0, kc = 0;
+        sr_stream_plan(h->Np, h->n_out, std::max(sr_stream_width((int)Tc), mfma_small ? 16 : 0), &g, &kc);
+        fused_mfma = kc == 1 && (g == 1 || (g == 2 && ncb <= SR_STREAM_FUSED32_MAX_NCB));
+    }
+    const bool fused = (!h->general && h->D <= SR_STREAM_FUSED_MAX_D && Tc <= 4 && !mfma_small) || fused_mfma;
     const int nsplit = fused ? 2 * ncb : pick_nsplit(h, Tp);
     SR_TRY(ensure_ws(h, Tp, std::max(nsplit, 2 * ncb)));
     SR_TRY(stream_buffers(h, mfma_small ? 16 : (int)Tc, s));

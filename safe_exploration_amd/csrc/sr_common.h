@@ -299,6 +299,8 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //   K2f streamed, fused (sr_stream.hip)      Np > SR_STREAM_MIN_NP (384), T <= SR_STREAM_MAX_T (64): N = 5000 T = 1 54 -> 37 us, T = 64
 //                                            143 -> 111 us (r02 / r03_latency_grid); one launch for T <= 4 with D <= 5 unless
 //                                            2 <= T <= 4 and Np <= SR_MFMA_SMALL_MAX_NP (2048): N = 700 27 against 21 us, N = 3000 34 / 40
+//                                            no K* pass either for 16 columns per workgroup on one-chunk work items, nor for 32 up to
+//                                            SR_STREAM_FUSED32_MAX_NCB (8) column blocks: T = 16 N = 2000 / 3000 28 / 39 -> 25 / 34 us (r04_latency_grid)
 //   K2s streamed, groups of 16               T <= 16 x sr_var_small_groups_max (300 MB of re-read U^-1): N = 700 T = 128 41 -> 25 us,
 //                                            N = 2000 71 -> 40 us, from N = 3000 on the tiles win (r01d_latency_grid)
 //   K2b balanced shares (sr_predict.hip)     sr_var_splitk_wanted (nb > 2, <= 1024 plain workgroups) and >= 256 cells
@@ -336,6 +338,7 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #define SR_LIN_FUSED_MAX_D 3         /* one-launch streamed linearize up to this D */
 #define SR_FACT_CHAIN_MAX_NB 128     /* model update: up to here the chain of diagonal blocks bounds it (stream regime 1) */
 #define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch up to this padded size (the grown model: <= 640) */
+#define SR_STREAM_FUSED32_MAX_NCB 8   // 32 columns per workgroup are evaluated inside the MFMA kernel up to this many 256-column blocks (Np <= 2048)
 #define SR_VAR_XCD_MIN_CELLS 512     /* (row block, k-block, query tile, output) cells from which the optional K2x applies */
 
 static inline bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
@@ -475,6 +478,7 @@ struct sr_stream_args {
 long sr_stream_vp_doubles(int Np, int n_out, int ncols);
 int sr_stream_tickets(int Np, int n_out);
 int sr_stream_width(int ncols);
+void sr_stream_plan(int Np, int n_out, int nc, int* g, int* kc);
 int sr_launch_stream(sr_stream_args a, int src, hipStream_t s);
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s);
 int sr_lin_nacc(int D);

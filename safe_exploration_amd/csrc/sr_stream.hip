@@ -301,11 +301,22 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
 // k-rows of a 32-lane ds_read_b64 group then sit on opposite bank halves), one ds_read_b64 per MFMA, G MFMAs per loaded
 // A-fragment.  Vp[(d, pair)][column][256].
 // ------------------------------------------------------------------------------------------------
-template <int G>
+// SRC 1 (ARD-RBF, D <= DT <= 5): the workgroup EVALUATES its 128 rows of K* itself instead of reading them from a K*
+// pass of their own (a launch of 8 - 10 us in front of a kernel of 10 - 40): thread (row r = tid % 128, query group
+// tid / 128) holds its training row and evaluates NC / 8 queries against it; the workgroup with the smallest column block
+// of the chunk (cb == j / 2) also owns the chunk's share of the sums over the training points (mean, mean-Jacobian):
+// slot j of the 2 ncb N-split partials the final stage adds.
+template <int G, int SRC = 0, int DT = 1>
 __global__ __launch_bounds__(1024) void sr_stream_mfma1_kernel(sr_stream_args a) {
     constexpr int NC = 16 * G;
     constexpr int LDK = (G == 1) ? 16 : NC + 16;
     __shared__ double ks[SR_ST_ROWS * LDK];
+    // (G > 1: the owner's partial sums live in the 16 padding columns of the K* rows -- a buffer of their own would cost the
+    //  G = 4 kernel its second workgroup per CU)
+    __shared__ double own_[(SRC == 1 && G == 1) ? 2 * NC * (1 + DT) : 1];
+    auto own = [&](int half, int t, int c) -> double& {
+        return (G == 1) ? own_[(half * NC + t) * (1 + DT) + c] : ks[t * LDK + NC + half * (1 + DT) + c];
+    };
     const int d = blockIdx.y, p = blockIdx.x;
     int cb, j;
     sr_pair_decode(p, cb, j);
@@ -314,10 +325,62 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma1_kernel(sr_stream_args a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lk = lane >> 4, ln = lane & 15;
     const int c0 = blockIdx.z * NC;                      // first column of this workgroup (grid.z: column blocks)
-    const double* ksrc = a.Ks + (long)d * a.Np * a.Tp + (long)k0 * a.Tp + c0;
-    for (int e = threadIdx.x; e < SR_ST_ROWS * NC; e += 1024) {
-        const int r = e / NC, t = e % NC;
-        ks[r * LDK + t] = (k0 + r < a.Np && c0 + t < a.ncols_pad) ? ksrc[(long)r * a.Tp + t] : 0.0;
+    if (SRC == 0) {
+        const double* ksrc = a.Ks + (long)d * a.Np * a.Tp + (long)k0 * a.Tp + c0;
+        for (int e = threadIdx.x; e < SR_ST_ROWS * NC; e += 1024) {
+            const int r = e / NC, t = e % NC;
+            ks[r * LDK + t] = (k0 + r < a.Np && c0 + t < a.ncols_pad) ? ksrc[(long)r * a.Tp + t] : 0.0;
+        }
+    } else {
+        constexpr int TPG = NC / 8;                      // queries per thread
+        const int r = threadIdx.x & 127, tg = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7);
+        const int ip = k0 + r, it = ip - (a.Np - a.N);
+        const bool valid = ip < a.Np && it >= 0;
+        const bool owner = (cb == (j >> 1));             // workgroup-uniform
+        const double wgt = valid ? a.alpha[(long)d * a.Np + ip] : 0.0;
+        const double sf2 = a.sf2[d];
+        double z[DT], il2[DT];
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            const double l = (c < a.D) ? a.ls[d * a.D + c] : 1.0;
+            il2[c] = (c < a.D) ? 1.0 / (l * l) : 0.0;
+            z[c] = (valid && c < a.D) ? a.Z[(long)it * a.D + c] : 0.0;
+        }
+#pragma unroll
+        for (int tt = 0; tt < TPG; ++tt) {
+            const int t = tg * TPG + tt;
+            const long tq = c0 + t;
+            const bool live = tq < a.ncols;              // wavefront-uniform (a wavefront = 64 rows of one query group)
+            double u[DT], r2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                double x = 0.0;
+                if (live && c < a.D) x = (c < a.na) ? a.xa[tq * a.lda + c] : a.xb[tq * a.ldb + (c - a.na)];
+                u[c] = (z[c] - x) * il2[c];
+                r2 = fma(u[c], z[c] - x, r2);
+            }
+            const double k = (valid && live) ? sf2 * exp(-0.5 * r2) : 0.0;
+            ks[r * LDK + t] = k;
+            if (owner) {
+                const double w = wgt * k;
+                const double m = sr_wave_sum(w);
+                if (lane == 0) own(wave & 1, t, 0) = m;
+#pragma unroll
+                for (int c = 0; c < DT; ++c) {
+                    const double gc = sr_wave_sum(w * u[c]);
+                    if (lane == 0) own(wave & 1, t, 1 + c) = gc;
+                }
+            }
+        }
+        if (owner) {
+            __syncthreads();
+            const int t = (int)threadIdx.x / (1 + DT), c = (int)threadIdx.x % (1 + DT);
+            if (t < NC && c0 + t < a.ncols) {
+                const double sum = own(0, t, c) + own(1, t, c);
+                if (c == 0) a.mu_part_w[((long)j * a.n_out + d) * a.Tp + c0 + t] = sum;
+                else if (c - 1 < a.D) a.jac_part_w[(((long)j * a.n_out + d) * a.D + (c - 1)) * a.Tp + c0 + t] = sum;
+            }
+        }
     }
     __syncthreads();
     const int i0 = cb * SR_ST_COLS + 16 * wave;          // first column of this strip
@@ -533,6 +596,23 @@ __global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a,
     const long cs = (long)nc * SR_ST_COLS;               // item stride
     const double* base = a.Vp + (long)d * nitems * cs + col;
     const bool dot = a.dot0 && t != 0;
+    // predict mode: the first wavefront requests the query's partial sums of mean and mean-Jacobian (written by the K*
+    // pass: they do not depend on this reduction) BEFORE its share of the reduction, and holds them in registers -- the
+    // final stage below then costs two butterflies instead of two more dependent round trips (16.9 -> 12 us at N = 5000).
+    // Same loads, same order of additions as sr_final_query_wave (the results are the same to the last bit).
+    const bool pre = a.mode == 0 && tid < 64 && a.fa.nsplit <= 512 && a.fa.D <= 3;
+    double xm[8], xg[3][8];
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sp = tid + 64 * u;
+            const bool in = sp < a.fa.nsplit;
+            xm[u] = in ? a.fa.mu_part[((long)sp * a.fa.n_out + d) * a.fa.Tp + t] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                xg[c][u] = (in && a.fa.jac && c < a.fa.D) ? a.fa.jac_part[(((long)sp * a.fa.n_out + d) * a.fa.D + c) * a.fa.Tp + t] : 0.0;
+        }
+    }
     // first work item of this thread's first column block
     int p0 = 0;
     for (int c = 0; c < sub; ++c) p0 += sr_st_items_of(c, KC);
@@ -582,12 +662,33 @@ __global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a,
     const double wsum = sr_wave_sum(acc);
     if ((tid & 63) == 0) red[tid >> 6] = wsum;
     __syncthreads();
+    double q = 0.0;
     if (tid == 0) {
-        double q = 0.0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) q += red[w];
         // (agent scope: in linearize mode another workgroup reads it; the final stage below reads it back the same way)
         sr_st_agent(a.part + (long)d * a.Tp + t, q);
+    }
+    if (pre) {
+        double m = 0.0, g[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m += xm[u];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[c] += xg[c][u];
+        m = sr_wave_sum(m);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = sr_wave_sum(g[c]);
+        if (tid == 0) {
+            double v = (a.fa.kxx ? a.fa.kxx[(long)d * a.fa.Tp + t] : a.fa.sf2[d]) - q;
+            if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+            a.fa.mu[(long)t * a.fa.n_out + d] = m;
+            a.fa.var[(long)t * a.fa.n_out + d] = v;
+            if (a.fa.jac)
+                for (int c = 0; c < a.fa.D; ++c) a.fa.jac[((long)t * a.fa.n_out + d) * a.fa.D + c] = g[c];
+        }
+        return;
     }
     if (a.mode == 0) {
         if (tid < 64) {
@@ -625,6 +726,24 @@ int sr_stream_width(int ncols) {
     return 128;
 }
 
+// The plan of the MFMA route for nc (16 .. 128) columns: g = groups of 16 columns per workgroup, kc = k-chunks per work item.
+void sr_stream_plan(int Np, int n_out, int nc, int* g_out, int* kc_out) {
+    const int ncb = (Np + SR_ST_COLS - 1) / SR_ST_COLS;
+    const long npairs = (long)ncb * (ncb + 1);
+    // columns per workgroup: as many as possible (U^-1 is then read once for all of them) while the grid still
+    // covers the chip; a small model keeps its column groups side by side in grid.z (they re-read U^-1 from L2)
+    int g = nc / 16;
+    while (g > 1 && npairs * n_out * (nc / (16 * g)) < 256) g >>= 1;
+    const int gz = nc / (16 * g);
+    // k-chunks per workgroup: as long a run as still leaves about one workgroup per CU (N = 5000, T = 16 / 64 / 128
+    // columns, whole call: runs of 1 / 2 / 3 / 4 chunks 79 / 70 / 81 / 66, 169 / 138 / 166 / 125, 288 / 245 / 300 / 218 us)
+    auto items = [&](int kc) { long n = 0; for (int cb = 0; cb < ncb; ++cb) n += sr_st_items_of(cb, kc); return n; };
+    int kc = 1;
+    for (int c : {2, 3, 4, 6, 8})
+        if (items(c) * n_out * gz >= 200) kc = c;
+    *g_out = g; *kc_out = kc;
+}
+
 // src: 0 columns from a.Ks, 1 ARD-RBF predict columns evaluated in the kernel, 2 ARD-RBF linearize columns
 int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     a.ncb = (a.Np + SR_ST_COLS - 1) / SR_ST_COLS;
@@ -644,26 +763,27 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
         SR_HIP(hipGetLastError());
         return SR_OK;
     }
-    SR_CHECK(src == 0, SR_EINVAL, "stream: more than 4 columns come from the workspace");
+    SR_CHECK(src == 0 || (src == 1 && a.D <= 5), SR_EINVAL, "stream: src %d with %d columns, D = %d", src, a.ncols, a.D);
     a.ncols_pad = a.ncols;
-    // columns per workgroup: as many as possible (U^-1 is then read once for all of them) while the grid still
-    // covers the chip; a small model keeps its column groups side by side in grid.z (they re-read U^-1 from L2)
-    int g = nc / 16;
-    while (g > 1 && (long)a.npairs * a.n_out * (nc / (16 * g)) < 256) g >>= 1;
+    int g, kc;
+    sr_stream_plan(a.Np, a.n_out, nc, &g, &kc);
     grid.z = nc / (16 * g);
-    // k-chunks per workgroup: as long a run as still leaves about one workgroup per CU (N = 5000, T = 16 / 64 / 128
-    // columns, whole call: runs of 1 / 2 / 3 / 4 chunks 79 / 70 / 81 / 66, 169 / 138 / 166 / 125, 288 / 245 / 300 / 218 us)
-    auto items = [&](int kc) { long n = 0; for (int cb = 0; cb < a.ncb; ++cb) n += sr_st_items_of(cb, kc); return n; };
-    int kc = 1;
-    for (int c : {2, 3, 4, 6, 8})
-        if (items(c) * a.n_out * grid.z >= 200) kc = c;
+    auto items = [&](int kc_) { long n = 0; for (int cb = 0; cb < a.ncb; ++cb) n += sr_st_items_of(cb, kc_); return n; };
+    SR_CHECK(src == 0 || kc == 1, SR_EINVAL, "stream: columns evaluated in the kernel only for one-chunk work items (runs of %d)", kc);
     if (kc == 1) {
+        // (columns evaluated in the kernel: 16 or 32 per workgroup only -- every column block re-evaluates the chunk's rows,
+        //  and from 64 columns on that costs a workgroup more than the K* pass it saves: N = 3000, T = 64 76 -> 93 us)
+        SR_CHECK(src == 0 || g <= 2, SR_EINVAL, "stream: %d columns per workgroup are not evaluated in the kernel", 16 * g);
+#define SR_M1(G_) do { if (src == 0) hipLaunchKernelGGL((sr_stream_mfma1_kernel<G_, 0, 1>), grid, dim3(1024), 0, s, a); \
+                       else if (a.D <= 3) hipLaunchKernelGGL((sr_stream_mfma1_kernel<G_, 1, 3>), grid, dim3(1024), 0, s, a); \
+                       else hipLaunchKernelGGL((sr_stream_mfma1_kernel<G_, 1, 5>), grid, dim3(1024), 0, s, a); } while (0)
         switch (g) {
-            case 1: hipLaunchKernelGGL(sr_stream_mfma1_kernel<1>, grid, dim3(1024), 0, s, a); break;
-            case 2: hipLaunchKernelGGL(sr_stream_mfma1_kernel<2>, grid, dim3(1024), 0, s, a); break;
-            case 4: hipLaunchKernelGGL(sr_stream_mfma1_kernel<4>, grid, dim3(1024), 0, s, a); break;
-            default: hipLaunchKernelGGL(sr_stream_mfma1_kernel<8>, grid, dim3(1024), 0, s, a); break;
+            case 1: SR_M1(1); break;
+            case 2: SR_M1(2); break;
+            case 4: hipLaunchKernelGGL((sr_stream_mfma1_kernel<4, 0, 1>), grid, dim3(1024), 0, s, a); break;
+            default: hipLaunchKernelGGL((sr_stream_mfma1_kernel<8, 0, 1>), grid, dim3(1024), 0, s, a); break;
         }
+#undef SR_M1
         SR_HIP(hipGetLastError());
         hipLaunchKernelGGL(sr_stream_reduce1_kernel, dim3(a.ncb, a.n_out, a.ncols), dim3(256), 0, s, a, nc);
         SR_HIP(hipGetLastError());
