@@ -300,9 +300,12 @@ int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, do
  * kernel arguments, the results go straight to the pinned host block
  *   out_host = [mu n | var n | jac_mu n x D]                      (second_order == 0)
  *              [... | jac_var n x D | hess_mu n x D x D]          (second_order != 0)
- * and the last workgroup stores seq to *flag_host (pinned; wait with sr_wait_flag).  Available where the one-launch
- * posterior applies (ARD-RBF, Np <= 384; Np = 512 for second order); SR_EUNSUPPORTED otherwise: use sr_gp_predict /
- * sr_gp_linearize.  replaces SimpleGPModel.__call__ (ssm_gpy/gaussian_process.py:135-144) and
+ * and the last workgroup stores seq to *flag_host (pinned; wait with sr_wait_flag).  Where the one-launch posterior applies
+ * (ARD-RBF, Np <= 384; Np = 512 for second order) that is one launch; on larger models (from 512 padded rows; any kernel
+ * family) the streamed route takes it over: x_host must then be PINNED, device-visible memory too -- the kernels read the
+ * query from it -- and the workgroup that runs the final stage writes results and sequence number (N = 1000: 32 -> 26 us per
+ * blocking call, N = 5000: 56 -> 49).  SR_EUNSUPPORTED with an input transform, with the size dispatch switched off, or
+ * where a block is not device-visible: use sr_gp_predict / sr_gp_linearize.  replaces SimpleGPModel.__call__ (ssm_gpy/gaussian_process.py:135-144) and
  * linearize_predict(jacobians=True) as CasadiSSMEvaluator drives them (state_space_models.py:271-303, 384-417). */
 int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, double* out_host,
                 unsigned long long* flag_host, unsigned long long seq, void* stream);

@@ -93,6 +93,7 @@ static void stream_common(const sr_gp* h, sr_stream_args& a, int ncols, long Tp)
     a.Tp = Tp;
     a.Z = h->Z; a.alpha = h->alpha; a.ls = h->ls; a.sf2 = h->sf2;
     a.mu_part_w = h->mu_part; a.jac_part_w = h->jac_part;
+    a.host_flag = h->call_flag; a.host_seq = h->call_seq;
 }
 
 static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb, int nb,
@@ -504,13 +505,35 @@ extern "C" int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, do
                            unsigned long long* flag_host, unsigned long long seq, void* stream) {
     SR_CHECK(h != nullptr && x_host && out_host && flag_host, SR_EINVAL, "sr_gp_call1: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_call1: model not factorized");
-    if (!(h->small_path == 1 && !h->general && h->n_xin == 0 &&
-          sr_gp_small_wanted(h->Np, second_order ? SR_SMALL_T : 1, h->D, false))) {
-        sr_set_error("sr_gp_call1: no one-launch posterior for this model (Np=%d, general=%d)", h->Np, h->general);
+    const bool one_launch = h->small_path == 1 && !h->general && h->n_xin == 0 &&
+                            sr_gp_small_wanted(h->Np, second_order ? SR_SMALL_T : 1, h->D, false);
+    // beyond the one-launch sizes: the streamed route (one to three launches) with the query READ from the pinned input block
+    // and outputs and sequence number WRITTEN to the pinned result block by the workgroup that runs the final stage
+    const bool streamed = !one_launch && h->small_path == 1 && h->n_xin == 0 && !h->force_stream && h->Np >= SR_FUSED_NP;
+    if (!one_launch && !streamed) {
+        sr_set_error("sr_gp_call1: no one-command route for this model (Np=%d, general=%d)", h->Np, h->general);
         return SR_EUNSUPPORTED;
     }
     SR_DEVICE(h->device);
     hipStream_t s = (hipStream_t)stream;
+    if (streamed) {
+        double *out_d = nullptr, *x_d = nullptr;
+        unsigned long long* flag_d = nullptr;
+        if (hipHostGetDevicePointer((void**)&out_d, out_host, 0) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&flag_d, flag_host, 0) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&x_d, const_cast<double*>(x_host), 0) != hipSuccess) {
+            (void)hipGetLastError();
+            sr_set_error("sr_gp_call1: the query / result / flag block is not device-visible pinned memory");
+            return SR_EUNSUPPORTED;
+        }
+        const int n = h->n_out, D = h->D;
+        h->call_flag = flag_d; h->call_seq = seq;
+        int rc;
+        if (second_order) rc = stream_linearize(h, x_d, out_d, out_d + n, out_d + 2 * n, out_d + 2 * n + n * D, out_d + 2 * n + 2 * n * D, s);
+        else rc = stream_predict(h, 1, x_d, D, D, nullptr, 0, 0, out_d, out_d + n, out_d + 2 * n, s);
+        h->call_flag = nullptr; h->call_seq = 0;
+        return rc;
+    }
     if (!h->call_ticket) {
         SR_TRY(dev_alloc(&h->call_ticket, 1));
         SR_TRY(dev_zero(h->call_ticket, sizeof(unsigned)));

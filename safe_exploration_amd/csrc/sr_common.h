@@ -474,6 +474,9 @@ struct sr_stream_args {
     double* mu_part_w; double* jac_part_w; double* lin_part_w;
     sr_final_args fa;
     sr_lin_args la; const double* lin_part; int nblk, lin_dt; double* lmu; double* lvar; double* ljac_mu;
+    // one-command single query (sr_gp_call1 on a streamed model): the workgroup that runs the final stage publishes this
+    // sequence number into pinned host memory after its outputs (which then live in pinned host memory too)
+    unsigned long long* host_flag; unsigned long long host_seq;
 };
 long sr_stream_vp_doubles(int Np, int n_out, int ncols);
 int sr_stream_tickets(int Np, int n_out);

@@ -81,6 +81,7 @@ struct sr_gp {
     // row append of few points (m <= 16): scratch and a second U^-1 buffer the new factor is assembled into
     // (kept while the padded size does not change: appends then allocate nothing big)
     double* app_ws = nullptr; size_t app_cap = 0;
+    unsigned long long* call_flag = nullptr; unsigned long long call_seq = 0;   // set by sr_gp_call1 around a streamed pass
     void* app_pin = nullptr; double* app_pin_dev = nullptr;   // pinned, mapped: results of sr_gp_append1_host (log det partials, status words)
     double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
     int wt_alt_off = -1;     // front padding of the (complete, well-formed) factor Wt_alt last held; -1 unknown

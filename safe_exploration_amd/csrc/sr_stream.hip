@@ -80,6 +80,11 @@ __device__ __forceinline__ void sr_stream_final(const sr_stream_args& a, double*
                 sr_lin_final_wave<true>(a.la, a.lin_part, a.nblk, a.lin_dt, a.part, a.ncb, a.lmu, a.lvar, a.ljac_mu, d,
                                         threadIdx.x & 63, sh + wave * 120);
     }
+    if (a.host_flag) {                                   // (workgroup-uniform; every thread of the workgroup is here)
+        __threadfence_system();                          // this thread's outputs, in pinned host memory, before the flag
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

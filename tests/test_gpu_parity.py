@@ -1951,14 +1951,34 @@ def test_single_query_mailbox_and_fallback_agree():
     for a, b in zip(lin, lin2):
         np.testing.assert_array_equal(a, b)
     io["mailbox"] = True
-    # a model beyond the one-launch sizes declines the direct route and stays correct
+    # a model beyond the one-launch sizes: one command too -- the streamed kernels read the query from the pinned input block
+    # and the workgroup that runs the final stage writes results and sequence number into the pinned result block
     syn2 = orc.make_synthetic(18, 900, 2, 1, 4)
     gp2 = hip_model(syn2["Z"], syn2["Y"], syn2["lengthscale"], syn2["signal_var"], syn2["noise_var"], 2, 1)
+    io2 = gp2._handle.single_io()
     o2 = gp2(syn2["p"][:1], syn2["k_ff"][:1])
-    assert not gp2._handle.single_io()["direct"]
+    l2 = gp2.linearize_predict(syn2["p"][1:2], syn2["k_ff"][1:2], True)
+    assert io2["direct"] and io2["seq"] == 2
+    io2["direct"] = False                                  # the copy + publish route of the same kernels
+    o2b = gp2(syn2["p"][:1], syn2["k_ff"][:1])
+    l2b = gp2.linearize_predict(syn2["p"][1:2], syn2["k_ff"][1:2], True)
+    for a, b in zip(o2 + l2, o2b + l2b):
+        np.testing.assert_array_equal(a, b)
+    io2["direct"] = True
     mu2, var2 = gp2.predict(np.hstack((syn2["p"][:1], syn2["k_ff"][:1])))
     np.testing.assert_array_equal(o2[0][:, 0], mu2[0])
     np.testing.assert_array_equal(o2[1][:, 0], var2[0])
+    om2 = oracle_model(syn2["Z"], syn2["Y"], syn2["lengthscale"], syn2["signal_var"], syn2["noise_var"])
+    x2 = np.hstack((syn2["p"][1:2], syn2["k_ff"][1:2]))
+    rjv, rhm = orc.gp_linearize_extras(x2[0], om2["Z"], om2["beta"], om2["inv_K"], om2["lengthscale"], om2["signal_var"])
+    np.testing.assert_allclose(l2[3], rjv, rtol=1e-7, atol=1e-9 * max(1.0, np.abs(rjv).max()))
+    np.testing.assert_allclose(l2[4], rhm, rtol=1e-8, atol=1e3 * mu_atol(om2))
+    # with the library's size dispatch switched off it declines, the refusal is remembered, the answer stays the same
+    gp2.set_small_path(0)
+    o2c = gp2(syn2["p"][:1], syn2["k_ff"][:1])
+    assert not io2["direct"]
+    np.testing.assert_allclose(o2c[0], o2[0], rtol=1e-10, atol=1e-12)
+    gp2.set_small_path(1)
     # a flag that never comes is an error, not a hang
     from safe_exploration_amd._lib import lib
     from safe_exploration_amd import _buffers as B
