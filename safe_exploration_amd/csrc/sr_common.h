@@ -316,6 +316,8 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //                                            Np / 64 parts of 8 wavefronts from 256 on (U^-1 fragments in registers): __call__ 21.6 -> 9.6 us
 //                                            at N <= 128, 27 -> 11.9 at N = 150 (cart-pole), 33 -> 12.8 at N = 350 (r04_call_latency)
 //   one command (sr_gp_call1)                where K0 applies (Np <= 384; 512 with second order): 26.4 us at N = 200 (r03_call_latency)
+//                                            and on the streamed route from 512 padded rows on (query read from the pinned block,
+//                                            results + flag by the final stage's workgroup): N = 1000 32 -> 26 us (r04_call_latency)
 //  second order of one query (sr_gp_linearize)  K0 LIN up to Np = 384 (18 us at N = 200), streamed above: one launch for D <= 3
 //                                            (SR_LIN_FUSED_MAX_D): N = 5000 61 -> 51 us (r02_latency_grid)
 //  multi-step chains (sr_capi_reach.hip)     persistent kernel K0c up to SR_CHAIN_GROUPS workgroups (device CUs - 16 at most),
