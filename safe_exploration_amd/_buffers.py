@@ -92,6 +92,9 @@ def to_numpy(t):
 
 
 STAGING_MAX_DOUBLES = 1 << 22       # 32 MB of pinned memory at most per direction; bigger calls copy argument by argument
+import os as _os
+# inputs + outputs of a call up to this many doubles are not copied at all (Staging.stage); 0 switches it off
+ZERO_COPY_DOUBLES = int(_os.environ.get("SR_ZERO_COPY_DOUBLES", "512"))
 
 
 class Staging(object):
@@ -120,11 +123,13 @@ class Staging(object):
             self.h_out_np = self.h_out.numpy()
             self._gen += 1
 
-    def stage(self, arrays, out_shapes):
+    def stage(self, arrays, out_shapes, zero_copy=False):
         """arrays: NumPy float64 arrays (or None); out_shapes: shapes of the results.  Returns (device views of the
         inputs -- None where the input was None --, device views of the outputs).  The views of a call signature
-        (shapes) are built once: slicing tensors costs microseconds each, and a caller repeats its shapes."""
-        key = (tuple(None if a is None else a.shape for a in arrays), tuple(tuple(sh) for sh in out_shapes))
+        (shapes) are built once: slicing tensors costs microseconds each, and a caller repeats its shapes.
+        zero_copy: the caller's entry point hands these pointers to KERNELS only (no copy command reads or writes them), so
+        a handful of numbers may stay in the pinned blocks."""
+        key = (tuple(None if a is None else a.shape for a in arrays), tuple(tuple(sh) for sh in out_shapes), bool(zero_copy))
         plan = self._plans.get(key)
         if plan is None or plan["gen"] != self._gen:
             n_in = sum(int(a.size) for a in arrays if a is not None)
@@ -132,6 +137,12 @@ class Staging(object):
             self._room(n_in, n_out)
             if len(self._plans) > 64:
                 self._plans.clear()
+            # a handful of numbers (one query, one rollout): the kernels read the pinned block itself and write their
+            # results into the pinned result block -- pinned host memory is device-visible at its own address --, so the
+            # call costs no copy command in either direction (ZERO_COPY_DOUBLES; one-step reachability of one query, NumPy
+            # in and out: 50 -> 40 us)
+            direct = zero_copy and ZERO_COPY_DOUBLES > 0 and n_in + n_out <= ZERO_COPY_DOUBLES
+            src_in, src_out = (self.h_in, self.h_out) if direct else (self.d_in, self.d_out)
             views, hviews, off = [], [], 0
             for a in arrays:
                 if a is None:
@@ -140,22 +151,22 @@ class Staging(object):
                     continue
                 n = int(a.size)
                 hviews.append(self.h_in_np[off:off + n].reshape(a.shape))
-                views.append(self.d_in[off:off + n].view(a.shape))
+                views.append(src_in[off:off + n].view(a.shape))
                 off += n
             outs, houts, ooff = [], [], 0
             for sh in out_shapes:
                 n = int(np.prod(sh))
-                outs.append(self.d_out[ooff:ooff + n].view(tuple(sh)))
+                outs.append(src_out[ooff:ooff + n].view(tuple(sh)))
                 houts.append(self.h_out_np[ooff:ooff + n].reshape(tuple(sh)))
                 ooff += n
-            plan = {"gen": self._gen, "views": views, "hviews": hviews, "outs": outs, "houts": houts,
+            plan = {"gen": self._gen, "views": views, "hviews": hviews, "outs": outs, "houts": houts, "direct": direct,
                     "d_in": self.d_in[:off] if off else None, "h_in": self.h_in[:off] if off else None,
                     "d_out": self.d_out[:ooff], "h_out": self.h_out[:ooff]}
             self._plans[key] = plan
         for a, hv in zip(arrays, plan["hviews"]):
             if a is not None:
                 np.copyto(hv, a)
-        if plan["d_in"] is not None:
+        if plan["d_in"] is not None and not plan["direct"]:
             plan["d_in"].copy_(plan["h_in"], non_blocking=True)
         self._last = plan
         return plan["views"], plan["outs"]
@@ -163,6 +174,7 @@ class Staging(object):
     def fetch(self):
         """The outputs of the last ``stage`` as NumPy arrays (copies); synchronises the current stream."""
         plan = self._last
-        plan["h_out"].copy_(plan["d_out"], non_blocking=True)
+        if not plan["direct"]:
+            plan["h_out"].copy_(plan["d_out"], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         return [h.copy() for h in plan["houts"]]

@@ -121,7 +121,7 @@ def onestep_reachability_batch(p_center, ssm, k_ff, l_mu, l_sigma, q_shape=None,
         if st is None:
             st = hd._staging = B.Staging(dev)
         shapes = [(T, n_s), (T, n_s, n_s), (1,)] + ([(T, n_s)] if return_var else [])
-        (p, kff, q, kfb), outs_d = st.stage([np_p, f64(k_ff).reshape(T, n_u), np_q, np_kfb], shapes)
+        (p, kff, q, kfb), outs_d = st.stage([np_p, f64(k_ff).reshape(T, n_u), np_q, np_kfb], shapes, zero_copy=True)
         p_out, q_out, bad_slot = outs_d[:3]
         var = outs_d[3] if return_var else None
         n_bad = None

@@ -792,7 +792,7 @@ class SimpleGPModel(StateSpaceModel):
         if st is None:
             st = hd._staging = B.Staging(hd.device)
         shapes = [(T, hd.n_out), (T, hd.n_out)] + ([(T, hd.n_out, hd.D)] if compute_gradients else [])
-        (dx,), outs = st.stage([x], shapes)
+        (dx,), outs = st.stage([x], shapes, zero_copy=True)
         check(lib.sr_gp_predict(hd.h, B.ptr(dx), T, B.ptr(outs[0]), B.ptr(outs[1]),
                                 B.ptr(outs[2]) if compute_gradients else None, B.stream_ptr(hd.device)))
         return tuple(st.fetch())
