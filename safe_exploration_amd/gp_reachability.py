@@ -268,7 +268,7 @@ def multistep_reachability_batch(p_0, gp, k_fb, k_ff, L_mu, L_sigm, q_0=None, c_
         if st is None:
             st = hd._staging = B.Staging(dev)
         (p0, kff, kfb, q0, kfb0), (p_all, q_all, bad_slot) = st.stage(
-            [np_p0.reshape(T, n_s), np_kff, np_kfb, np_q0, np_kfb0], [(T, H, n_s), (T, H, n_s, n_s), (1,)])
+            [np_p0.reshape(T, n_s), np_kff, np_kfb, np_q0, np_kfb0], [(T, H, n_s), (T, H, n_s, n_s), (1,)], zero_copy=True)
     else:
         p0 = B.as_dev(p_0, dev)
         T = p0.shape[0]
