@@ -267,6 +267,26 @@ def test_bad_box_raises_like_reference():
         reach.onestep_reachability(g["p"], const, g["k_ff"], 0 * g["l"], g["l"], g["Q"], g["k_fb"], 2.0, 0)
 
 
+def test_bad_box_is_counted_on_every_staging_route():
+    """A zero-width box must raise for NumPy callers whether the batch is copied to the device or -- a handful of numbers --
+    read and written in the pinned staging blocks by the kernels themselves (the violation counter then lives in pinned host
+    memory and is incremented from the device), and for device tensors."""
+    import torch
+    from safe_exploration_amd import gp_reachability as reach
+    syn = orc.make_synthetic(5, 120, 2, 1, 300)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    l, l0 = np.array([0.05, 0.02]), np.zeros(2)
+    for T in (1, 3, 300):                                    # 1, 3: zero-copy; 300: one pinned block copied
+        args = (syn["p"][:T], gp, syn["k_ff"][:T])
+        reach.onestep_reachability_batch(*args, l, l, syn["Q"][:T], syn["k_fb"][:T], 2.0, check_bounds=True)
+        with pytest.raises(AssertionError):
+            reach.onestep_reachability_batch(*args, l0, l, syn["Q"][:T], syn["k_fb"][:T], 2.0, check_bounds=True)
+    dev = lambda a: torch.as_tensor(a, device="cuda:0")
+    with pytest.raises(AssertionError):
+        reach.onestep_reachability_batch(dev(syn["p"][:2]), gp, dev(syn["k_ff"][:2]), l0, l, dev(syn["Q"][:2]), dev(syn["k_fb"][:2]),
+                                         2.0, check_bounds=True)
+
+
 # ------------------------------------------------------------------ fused GP + ellipsoid
 @pytest.mark.parametrize("name,n_s,n_u", [("reach_pend.npz", 2, 1), ("reach_cart.npz", 4, 1),
                                           ("reach_n3u2.npz", 3, 2)])
