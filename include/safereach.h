@@ -296,6 +296,10 @@ int sr_release_cached_memory(void);
 int sr_publish(int device, const double* src_dev, int n, double* dst_host, unsigned long long* flag_host,
                unsigned long long seq, void* stream);
 int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s);
+/* 1 where kernels of `device` may be handed the HOST address of this pinned block as it is (device-visible at the same
+ * address), 0 otherwise: asked once by a host layer that lets the kernels read / write its pinned staging blocks directly
+ * (tiny batches: no copy command in either direction; safe_exploration_amd/_buffers.py). */
+int sr_host_block_is_device_visible(int device, const void* host_block);
 /* One blocking single query as ONE command: the D coordinates x_host (host memory, read at call time) travel in the
  * kernel arguments, the results go straight to the pinned host block
  *   out_host = [mu n | var n | jac_mu n x D]                      (second_order == 0)

@@ -107,6 +107,7 @@ class Staging(object):
         self.device = device
         self.h_in = self.d_in = self.h_out = self.d_out = None
         self._plans, self._gen, self._last = {}, 0, None
+        self._vis, self._vis_gen = False, -1
 
     def _room(self, n_in, n_out):
         if self.h_in is None or self.h_in.numel() < n_in:
@@ -122,6 +123,16 @@ class Staging(object):
             self.d_out = torch.empty(self.h_out.numel(), dtype=torch.float64, device=self.device)
             self.h_out_np = self.h_out.numpy()
             self._gen += 1
+
+    def _visible(self):
+        """The pinned blocks are device-visible at their own addresses (asked once per pair of blocks)."""
+        if self._vis_gen != self._gen:
+            from . import _lib
+            dev = self.device.index or 0
+            self._vis = all(_lib.lib.sr_host_block_is_device_visible(dev, ctypes.c_void_p(t.data_ptr())) == 1
+                            for t in (self.h_in, self.h_out))
+            self._vis_gen = self._gen
+        return self._vis
 
     def stage(self, arrays, out_shapes, zero_copy=False):
         """arrays: NumPy float64 arrays (or None); out_shapes: shapes of the results.  Returns (device views of the
@@ -141,7 +152,7 @@ class Staging(object):
             # results into the pinned result block -- pinned host memory is device-visible at its own address --, so the
             # call costs no copy command in either direction (ZERO_COPY_DOUBLES; one-step reachability of one query, NumPy
             # in and out: 50 -> 40 us)
-            direct = zero_copy and ZERO_COPY_DOUBLES > 0 and n_in + n_out <= ZERO_COPY_DOUBLES
+            direct = zero_copy and ZERO_COPY_DOUBLES > 0 and n_in + n_out <= ZERO_COPY_DOUBLES and self._visible()
             src_in, src_out = (self.h_in, self.h_out) if direct else (self.d_in, self.d_out)
             views, hviews, off = [], [], 0
             for a in arrays:

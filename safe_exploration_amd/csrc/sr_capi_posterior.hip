@@ -473,6 +473,19 @@ extern "C" int sr_publish(int device, const double* src_dev, int n, double* dst_
     return SR_OK;
 }
 
+// 1 where kernels of `device` may be handed the HOST address of this pinned block as it is (the device sees the block at the
+// same address), 0 otherwise -- what a host layer asks once before it lets kernels read / write its pinned staging blocks.
+extern "C" int sr_host_block_is_device_visible(int device, const void* host_block) {
+    if (!host_block) return 0;
+    sr_dev_guard guard(device);
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host_block), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dp == host_block ? 1 : 0;
+}
+
 extern "C" int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s) {
     SR_CHECK(flag_host != nullptr, SR_EINVAL, "sr_wait_flag: NULL flag");
     const volatile unsigned long long* f = flag_host;
