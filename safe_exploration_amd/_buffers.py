@@ -83,8 +83,31 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+class RawStream(object):
+    """The current stream of a device as its raw handle (``cuda_stream``) with ``synchronize()``: what the entry points
+    need of ``torch.cuda.current_stream(device)``, whose Stream object costs 2 - 3 us to build per call."""
+    __slots__ = ("cuda_stream",)
+
+    def __init__(self, device):
+        if _raw_stream is not None and device.index is not None:
+            self.cuda_stream = _raw_stream(device.index)
+        else:
+            self.cuda_stream = torch.cuda.current_stream(device).cuda_stream
+
+    def synchronize(self):
+        from . import _lib
+        _lib.check(_lib.lib.sr_stream_synchronize(ctypes.c_void_p(self.cuda_stream)))
+
+
+def current_stream(device):
+    return RawStream(device)
+
+
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(RawStream(device).cuda_stream)
 
 
 def to_numpy(t):
@@ -187,5 +210,5 @@ class Staging(object):
         plan = self._last
         if not plan["direct"]:
             plan["h_out"].copy_(plan["d_out"], non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        RawStream(self.device).synchronize()
         return [h.copy() for h in plan["houts"]]

@@ -473,6 +473,13 @@ extern "C" int sr_publish(int device, const double* src_dev, int n, double* dst_
     return SR_OK;
 }
 
+// hipStreamSynchronize for a host layer that holds the raw stream (PyTorch builds a Stream object per current_stream() call:
+// 2 - 3 us of the 40 a blocking NumPy-level call takes)
+extern "C" int sr_stream_synchronize(void* stream) {
+    SR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return SR_OK;
+}
+
 // 1 where kernels of `device` may be handed the HOST address of this pinned block as it is (the device sees the block at the
 // same address), 0 otherwise -- what a host layer asks once before it lets kernels read / write its pinned staging blocks.
 extern "C" int sr_host_block_is_device_visible(int device, const void* host_block) {

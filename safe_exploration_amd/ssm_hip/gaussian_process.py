@@ -784,7 +784,7 @@ class SimpleGPModel(StateSpaceModel):
                     return out + (o[2 * n:].reshape(1, n, D),) if compute_gradients else out
             if hd.Np != 384 and io["mailbox"] and (io["direct"] or io.get("direct_off_np") != hd.Np):
                 io["h_in_np"][:D] = x[0]
-                o = hd.call1(0, 2 * n + n * D, torch.cuda.current_stream(hd.device))
+                o = hd.call1(0, 2 * n + n * D, B.current_stream(hd.device))
                 if o is not None:
                     out = (o[None, :n], o[None, n:2 * n])
                     return out + (o[2 * n:].reshape(1, n, D),) if compute_gradients else out
@@ -861,7 +861,7 @@ class SimpleGPModel(StateSpaceModel):
         o = hd.server_call(0, 2 * n + n * D)          # the resident server, where one is armed: no launch, no stream
         if o is not None:
             return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
-        stream = torch.cuda.current_stream(hd.device)
+        stream = B.current_stream(hd.device)
         o = hd.call1(0, 2 * n + n * D, stream)
         if o is not None:
             return o[:n, None], o[n:2 * n, None], o[2 * n:].reshape(n, D)
@@ -920,7 +920,7 @@ class SimpleGPModel(StateSpaceModel):
         o = hd.server_call(1, c + n * D * D)
         if o is not None:
             return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
-        stream = torch.cuda.current_stream(hd.device)
+        stream = B.current_stream(hd.device)
         o = hd.call1(1, io["d_out"].numel(), stream)
         if o is not None:
             return o[:n], o[n:a], o[a:b].reshape(n, D), o[b:c].reshape(n, D), o[c:].reshape(n, D, D)
