@@ -300,8 +300,9 @@ int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, do
  * address), 0 otherwise: asked once by a host layer that lets the kernels read / write its pinned staging blocks directly
  * (tiny batches: no copy command in either direction; safe_exploration_amd/_buffers.py). */
 int sr_host_block_is_device_visible(int device, const void* host_block);
-/* hipStreamSynchronize(stream), for a host layer that holds the raw stream handle. */
-int sr_stream_synchronize(void* stream);
+/* hipStreamSynchronize(stream) with `device` current, for a host layer that holds the raw stream handle (the handle 0 --
+ * the null stream, PyTorch's default -- names the stream of whichever device is current: hence the device). */
+int sr_stream_synchronize(int device, void* stream);
 /* One blocking single query as ONE command: the D coordinates x_host (host memory, read at call time) travel in the
  * kernel arguments, the results go straight to the pinned host block
  *   out_host = [mu n | var n | jac_mu n x D]                      (second_order == 0)

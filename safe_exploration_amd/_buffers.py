@@ -89,17 +89,22 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 class RawStream(object):
     """The current stream of a device as its raw handle (``cuda_stream``) with ``synchronize()``: what the entry points
     need of ``torch.cuda.current_stream(device)``, whose Stream object costs 2 - 3 us to build per call."""
-    __slots__ = ("cuda_stream",)
+    __slots__ = ("cuda_stream", "index")
 
     def __init__(self, device):
         if _raw_stream is not None and device.index is not None:
+            self.index = device.index
             self.cuda_stream = _raw_stream(device.index)
         else:
-            self.cuda_stream = torch.cuda.current_stream(device).cuda_stream
+            st = torch.cuda.current_stream(device)
+            self.index = st.device.index
+            self.cuda_stream = st.cuda_stream
 
     def synchronize(self):
+        # (with the stream's device current: handle 0 -- PyTorch's default stream -- is the null stream of whichever
+        #  device is current, and a model may live on another one than the caller's)
         from . import _lib
-        _lib.check(_lib.lib.sr_stream_synchronize(ctypes.c_void_p(self.cuda_stream)))
+        _lib.check(_lib.lib.sr_stream_synchronize(self.index, ctypes.c_void_p(self.cuda_stream)))
 
 
 def current_stream(device):

@@ -82,7 +82,7 @@ SIGNATURES = {
     "sr_publish": (_I, [_I, _P, _I, _P, _P, ctypes.c_ulonglong, _P]),
     "sr_wait_flag": (_I, [_P, ctypes.c_ulonglong, ctypes.c_double]),
     "sr_host_block_is_device_visible": (_I, [_I, _P]),
-    "sr_stream_synchronize": (_I, [_P]),
+    "sr_stream_synchronize": (_I, [_I, _P]),
     "sr_gp_call1": (_I, [_H, _P, _I, _P, _P, ctypes.c_ulonglong, _P]),
     "sr_gp_server_start": (_I, [_H, ctypes.c_double]),
     "sr_gp_server_stop": (_I, [_H]),

@@ -325,10 +325,11 @@ extern "C" int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* v
     SR_CHECK(x && mu && var && jac_mu && jac_var && hess_mu, SR_EINVAL, "sr_gp_linearize: NULL argument");
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
-    if (h->small_path == 1 && !h->general && sr_gp_small_wanted(h->Np, SR_SMALL_T, h->D, false)) {
-        // small ARD-RBF model: everything in one launch (sr_small.hip, LIN mode)
+    if (h->small_path == 1 && sr_gp_small_lin_wanted(h->Np, h->D, h->general != 0)) {
+        // small model: everything in one launch (sr_small.hip, LIN mode; the general family in its own kernel)
         sr_kstar_args ka{};
         ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+        ka.kp = h->general ? h->kp : nullptr;
         ka.xa = x; ka.lda = h->D; ka.na = h->D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
         ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = 1; ka.T = 1; ka.Tp = 1;
         sr_prof_scope ps(&h->prof, SR_K_SMALL, s);
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void sr_tz_jac_kernel(const double* __restrict
 extern "C" int sr_gp_set_input_transform(sr_gp_t h, const double* Tz, int n_x_in, void* stream) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_input_transform: NULL handle");
     SR_DEVICE(h->device);
-    SR_TRY(server_quiesce(h));
+    // (the resident server answers in the GP's input space and never reads Tz: it stays on the device)
     if (Tz == nullptr) { h->n_xin = 0; return SR_OK; }
     SR_CHECK(n_x_in >= 1 && n_x_in < h->D, SR_EINVAL, "sr_gp_set_input_transform: n_x_in=%d with D=%d", n_x_in, h->D);
     if (!h->Tz) SR_TRY(dev_alloc(&h->Tz, (size_t)SR_MAX_D * SR_MAX_NS));
@@ -475,7 +476,9 @@ extern "C" int sr_publish(int device, const double* src_dev, int n, double* dst_
 
 // hipStreamSynchronize for a host layer that holds the raw stream (PyTorch builds a Stream object per current_stream() call:
 // 2 - 3 us of the 40 a blocking NumPy-level call takes)
-extern "C" int sr_stream_synchronize(void* stream) {
+// (on `device`: the null stream -- PyTorch's default stream has the raw handle 0 -- is the CURRENT device's)
+extern "C" int sr_stream_synchronize(int device, void* stream) {
+    SR_DEVICE(device);
     SR_HIP(hipStreamSynchronize((hipStream_t)stream));
     return SR_OK;
 }
@@ -503,7 +506,7 @@ extern "C" int sr_wait_flag(const unsigned long long* flag_host, unsigned long l
     for (;;) {
         for (int spin = 0; spin < 2048; ++spin) {
             if (*f == seq) { std::atomic_thread_fence(std::memory_order_acquire); return SR_OK; }
-            __builtin_ia32_pause();
+            cpu_relax();
         }
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (waited > timeout_s) break;
@@ -525,11 +528,13 @@ extern "C" int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, do
                            unsigned long long* flag_host, unsigned long long seq, void* stream) {
     SR_CHECK(h != nullptr && x_host && out_host && flag_host, SR_EINVAL, "sr_gp_call1: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_call1: model not factorized");
-    const bool one_launch = h->small_path == 1 && !h->general && h->n_xin == 0 &&
-                            sr_gp_small_wanted(h->Np, second_order ? SR_SMALL_T : 1, h->D, false);
+    // (x is in the GP's input space, as for sr_gp_predict: an input transform of the reachability entry points does not matter)
+    const bool one_launch = h->small_path == 1 &&
+                            (second_order ? sr_gp_small_lin_wanted(h->Np, h->D, h->general != 0)
+                                          : sr_gp_small_wanted(h->Np, 1, h->D, h->general != 0));
     // beyond the one-launch sizes: the streamed route (one to three launches) with the query READ from the pinned input block
     // and outputs and sequence number WRITTEN to the pinned result block by the workgroup that runs the final stage
-    const bool streamed = !one_launch && h->small_path == 1 && h->n_xin == 0 && !h->force_stream && h->Np >= SR_FUSED_NP;
+    const bool streamed = !one_launch && h->small_path == 1 && !h->force_stream && h->Np >= SR_FUSED_NP;
     if (!one_launch && !streamed) {
         sr_set_error("sr_gp_call1: no one-command route for this model (Np=%d, general=%d)", h->Np, h->general);
         return SR_EUNSUPPORTED;
@@ -571,6 +576,7 @@ extern "C" int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, do
     const int n = h->n_out, D = h->D;
     sr_kstar_args ka{};
     ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.kp = h->general ? h->kp : nullptr;
     ka.xa = nullptr; ka.lda = D; ka.na = D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
     ka.N = h->N; ka.Np = h->Np; ka.D = D; ka.n_out = n; ka.nsplit = 1; ka.T = 1; ka.Tp = 1;
     ka.xv_on = 1;

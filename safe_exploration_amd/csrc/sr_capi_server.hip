@@ -16,13 +16,40 @@ constexpr size_t MB_WORDS = 16;               // mailbox: 128 bytes (one line); 
 constexpr size_t REPLY_WORDS = 3 * SR_SERVER_ALIVE;
 
 size_t out_doubles(const sr_gp* h) { return (size_t)2 * h->n_out + (size_t)2 * h->n_out * h->D + (size_t)h->n_out * h->D * h->D; }
-int parts_of(const sr_gp* h) { return sr_gp_server_parts(h->Np); }
+int parts_of(const sr_gp* h) { return sr_gp_server_parts(h->Np, h->general != 0); }
 int slots_of(const sr_gp* h) { return h->n_out * parts_of(h); }                      // reply words: one per (output, part)
 size_t rec_doubles(const sr_gp* h) { return (size_t)SR_SERVER_ALIVE * SR_SERVER_REC; }     // (room for any model of the handle)
 
+// Every kernel identifier (ARD-RBF; mat52 / lin_rbf / lin_mat52 through the general family) up to 512 padded rows, D <= 5.
+// Queries are in the GP's INPUT space, as for sr_gp_predict: an input transform set for the reachability entry points
+// (sr_gp_set_input_transform) neither concerns nor disturbs the server.
 bool servable(const sr_gp* h) {
-    return h->factorized && !h->general && h->n_xin == 0 && h->small_path == 1 && slots_of(h) <= SR_SERVER_ALIVE &&
-           sr_gp_server_supported(h->Np, h->D);
+    return h->factorized && h->small_path == 1 && slots_of(h) <= SR_SERVER_ALIVE && sr_gp_server_supported(h->Np, h->D);
+}
+
+// ---- the mailbox line (layout: sr_server_args in sr_common.h) -------------------------------------------------------------
+// HOST MEMORY MODEL.  The host side publishes with ordinary stores in program order -- payload words, check word, sequence
+// number last -- separated by release fences.  On x86-64 (TSO: stores are not reordered with older stores) the fences
+// cost nothing and the device, which validates every fetch of the line against the check word anyway, sees the request
+// with its first look after the sequence number lands.  On a weaker host memory model the fences are what orders the
+// stores; correctness does not depend on the order either way (a half-written line fails the check and is fetched again).
+inline void mb_store(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long mb_load(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+inline unsigned long long mb_check(const unsigned long long* mb) {
+    unsigned long long c = SR_SERVER_CHK;
+    for (int i = 0; i < 7; ++i) c ^= mb_load(mb + i);
+    return c;
+}
+// epoch word of the line for this launch, command kept; the check word follows it
+inline void mb_set_epoch(sr_server& sv, unsigned long long epoch) {
+    mb_store(sv.mb + 5, (epoch << 8) | (mb_load(sv.mb + 5) & 0xffull));
+    mb_store(sv.mb + 7, mb_check(sv.mb));
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+// call the launch off: every workgroup leaves at its next look, whatever request it is waiting for
+inline void mb_call_off(sr_server& sv) {
+    mb_store(sv.mb + 5, ~0ull);
+    std::atomic_thread_fence(std::memory_order_seq_cst);
 }
 
 void registry_add(sr_gp* h) {
@@ -39,10 +66,10 @@ int server_launch(sr_gp* h, unsigned long long first_seq) {
     sr_server& sv = h->srv;
     for (int d = 0; d < slots_of(h); ++d) sv.reply[SR_SERVER_ALIVE + d] = 1ull;
     ++sv.epoch;
-    *(volatile unsigned long long*)(sv.mb + 5) = sv.epoch;
-    std::atomic_thread_fence(std::memory_order_seq_cst);
+    mb_set_epoch(sv, sv.epoch);
     sr_kstar_args ka{};
     ka.Z = h->Z; ka.alpha = h->alpha; ka.ls = h->ls; ka.sf2 = h->sf2;
+    ka.kp = h->general ? h->kp : nullptr;
     ka.xa = nullptr; ka.lda = h->D; ka.na = h->D; ka.xb = nullptr; ka.ldb = 0; ka.nb = 0;
     ka.N = h->N; ka.Np = h->Np; ka.D = h->D; ka.n_out = h->n_out; ka.nsplit = 1; ka.T = 1; ka.Tp = 1;
     sr_server_args sa{};
@@ -68,9 +95,7 @@ namespace {
 int quiesce_locked(sr_gp* h) {
     sr_server& sv = h->srv;
     if (!sv.running) return SR_OK;
-    // a foreign epoch in the mailbox line: every workgroup leaves at its next look, whatever request it is waiting for
-    *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;
-    std::atomic_thread_fence(std::memory_order_seq_cst);
+    mb_call_off(sv);
     sr_dev_guard guard(h->device);
     const hipError_t e = hipStreamSynchronize(sv.stream);
     sv.running = 0;
@@ -114,8 +139,8 @@ extern "C" int sr_gp_server_start(sr_gp_t h, double idle_timeout_s) {
     SR_CHECK(idle_timeout_s > 0.0 && idle_timeout_s <= 10.0, SR_EINVAL, "sr_gp_server_start: idle time-out %g s outside (0, 10]",
              idle_timeout_s);
     if (!servable(h)) {
-        sr_set_error("sr_gp_server_start: no resident server for this model (ARD-RBF, Np <= %d, D <= 5, no input transform; "
-                     "Np=%d D=%d general=%d)", SR_FUSED_NP, h->Np, h->D, h->general);
+        sr_set_error("sr_gp_server_start: no resident server for this model (Np <= %d, D <= 5; Np=%d D=%d)", SR_FUSED_NP,
+                     h->Np, h->D);
         return SR_EUNSUPPORTED;
     }
     SR_DEVICE(h->device);
@@ -158,6 +183,7 @@ extern "C" int sr_gp_server_stop(sr_gp_t h) {
 
 extern "C" int sr_gp_server_state(sr_gp_t h, int* armed, int* resident, long* launches, long* calls) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_server_state: NULL handle");
+    std::lock_guard<std::mutex> lk(h->srv.mu);            // (a call or a quiesce on another thread writes these)
     if (armed) *armed = h->srv.armed;
     if (resident) *resident = (h->srv.running && !any_left(h)) ? 1 : 0;
     if (launches) *launches = h->srv.launches;
@@ -183,19 +209,29 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
         // given up: wait for the rest to leave, launch anew
         SR_DEVICE(h->device);
         if (sv.running) {
-            *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;       // workgroups still polling leave at once
-            std::atomic_thread_fence(std::memory_order_seq_cst);
+            mb_call_off(sv);                                  // workgroups still polling leave at once
             SR_HIP(hipStreamSynchronize(sv.stream));
         }
         SR_TRY(server_launch(h, seq));
         sv.stale = 0;
     }
     const int D = h->D, n = h->n_out, parts = parts_of(h), nslot = n * parts;
-    double* xs = reinterpret_cast<double*>(sv.mb);
-    for (int j = 0; j < D; ++j) xs[j] = x_host[j];
-    sv.mb[6] = second_order == 2 ? SR_SERVER_CMD_PING : (second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST);      // (2: diagnostics)
-    std::atomic_thread_fence(std::memory_order_release);  // payload before the sequence number (x86: store order)
-    *(volatile unsigned long long*)(sv.mb + 7) = seq;
+    {
+        // the request: query and command, the check word over the line as it will stand, the sequence number last
+        unsigned long long w[8];
+        for (int j = 0; j < 5; ++j) {
+            const double xv = j < D ? x_host[j] : 0.0;
+            memcpy(&w[j], &xv, sizeof(double));
+        }
+        w[5] = (sv.epoch << 8) | (second_order == 2 ? SR_SERVER_CMD_PING : (second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST));   // (2: diagnostics)
+        w[6] = seq;
+        w[7] = SR_SERVER_CHK;
+        for (int i = 0; i < 7; ++i) w[7] ^= w[i];
+        for (int i = 0; i < 6; ++i) mb_store(sv.mb + i, w[i]);
+        mb_store(sv.mb + 7, w[7]);
+        std::atomic_thread_fence(std::memory_order_release);
+        mb_store(sv.mb + 6, w[6]);
+    }
     const volatile unsigned long long* reply = sv.reply;
     const auto t0 = std::chrono::steady_clock::now();
     long spins = 0;
@@ -203,7 +239,7 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
         bool all = true;
         for (int d = 0; d < nslot; ++d) all = all && (reply[d] == seq);
         if (all) break;
-        __builtin_ia32_pause();
+        srh::cpu_relax();
         if ((++spins & 1023) == 0) {
             if (any_left(h)) {
                 // a workgroup left on its idle time-out between our look at `alive` and the request: relaunch for this
@@ -212,8 +248,7 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
                 for (int d = 0; d < nslot; ++d) done = done && (reply[d] == seq);
                 if (done) break;
                 SR_DEVICE(h->device);
-                *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;
-                std::atomic_thread_fence(std::memory_order_seq_cst);
+                mb_call_off(sv);
                 SR_HIP(hipStreamSynchronize(sv.stream));
                 SR_TRY(server_launch(h, seq));
             }
@@ -221,8 +256,7 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
             if (waited > timeout_s) {
                 // give the request up: its sequence number is never used again (workgroups that did answer it hold answers to
                 // THIS query in their reply words), and the launch is called off so that the next call starts a fresh one
-                *(volatile unsigned long long*)(sv.mb + 5) = ~0ull;
-                std::atomic_thread_fence(std::memory_order_seq_cst);
+                mb_call_off(sv);
                 sv.stale = 1;
                 ++sv.next_seq;
                 sr_set_error("sr_gp_server_call: no answer to request %llu within %.3f s", seq, timeout_s);

@@ -201,8 +201,8 @@ int sr_launch_gp_small_lin(const sr_kstar_args& a, const double* Wt, double* mu,
 // K0s (sr_server.hip): resident single-query server of a small ARD-RBF model: one workgroup per output polls a mailbox in
 // pinned host memory.  All pointers are the DEVICE-visible addresses of pinned host memory.
 struct sr_server_args {
-    unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 4] x (D <= 5 doubles), [5] launch epoch (any other value: leave),
-                                     // [6] command, [7] sequence number (written last)
+    unsigned long long* mb;          // mailbox, ONE 64-byte line: [0 .. 4] x (D <= 5 doubles), [5] (launch epoch << 8) | command (any
+                                     // other epoch: leave), [6] sequence number, [7] check word = [0] ^ .. ^ [6] ^ SR_SERVER_CHK
     double* out;                     // reply block: per (output d, part) one record of SR_SERVER_REC doubles
                                      // [mu, var or its share, d mu/dx (D), d var/dx or its shares (D), d2 mu/dx2 (D x D), .., sf2]
     unsigned long long* reply;       // [d]: sequence number last answered by output d; [SR_SERVER_ALIVE + d]: 1 while it runs;
@@ -213,6 +213,7 @@ struct sr_server_args {
 };
 #define SR_SERVER_ALIVE 64           /* reply words: one per (output, part) */
 #define SR_SERVER_REC 40          /* doubles per output record in the reply block (2 + 2 D + D^2 <= 37 for D <= 5) */
+#define SR_SERVER_CHK 0x5afe5eedc0ffee11ull   /* the eight words of a consistent mailbox line xor to this */
 #define SR_SERVER_CMD_FIRST 0ull     /* mu, var, d mu/dx */
 #define SR_SERVER_CMD_SECOND 1ull    /* + d var/dx, d2 mu/dx2 */
 #define SR_SERVER_CMD_STOP 2ull
@@ -348,9 +349,15 @@ static inline bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
     if (Np == 512 && T <= 128) return false;  // measured: streaming U^-1 (K2s, groups of 16 queries) 22-23 us against 28 us here
     return Np % 128 == 0 && Np <= SR_FUSED_NP && T <= SR_FUSED_T && D <= 8;   // (D > 8: the hoisted training rows do not fit 128 VGPRs)
 }
+// ONE query with second-order outputs in one launch (K0 LIN): the ARD-RBF form up to D = 8, the general family (its own phase A:
+// two MFMA products, rows 9 + j of the first) up to D = 5
+static inline bool sr_gp_small_lin_wanted(int Np, int D, bool general) {
+    return sr_gp_small_wanted(Np, SR_SMALL_T, D, general) && (!general || D <= 5);
+}
 // workgroups per output of the resident server: from Np = 256 on an output is served in Np / 64 parts of eight wavefronts
 // (the U^-1 fragments of a part fit its registers), Np = 128 by one workgroup of sixteen
-constexpr int sr_gp_server_parts(int Np) { return Np >= 256 ? Np / 64 : 1; }
+// (a general-family model -- mat52 / lin_* -- is served in parts at every size: two at Np = 128)
+constexpr int sr_gp_server_parts(int Np, bool general) { return (Np >= 256 || general) ? Np / 64 : 1; }
 // D <= 5 (pendulum: 3, cart-pole: 4 or 5): the D = 6 .. 8 instantiations of the sixteen-wavefront kernel spill and are not built
 static inline bool sr_gp_server_supported(int Np, int D) { return Np % 128 == 0 && Np <= SR_FUSED_NP && D <= 5; }
 // 64 x 64 tiles: profitable when the model is small and the 128-tile grid would leave most of the chip idle

@@ -124,6 +124,15 @@ namespace srh {
 
 static inline long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
+// one turn of a host spin loop (the pause hint where the host has one)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 // device memory through the block cache (sr_capi_handle.hip)
 int dev_alloc_bytes(void** p, size_t bytes);
 template <typename T>

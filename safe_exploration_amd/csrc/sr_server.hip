@@ -107,10 +107,46 @@ __device__ __forceinline__ void sr_srv_contract(const F& f, const double* __rest
     __syncthreads();
 }
 
+// The mailbox is ONE 64-byte line in pinned host memory:
+//   [x0 .. x4 | (launch epoch << 8) | command | sequence number | check word = x0 ^ .. ^ seq ^ SR_SERVER_CHK]
+// Lanes 0 .. 7 of the first wavefront fetch it with one request.  A request is taken when the sequence number is the
+// expected one AND the eight words xor to SR_SERVER_CHK: a fetch that reached host memory as several transactions and
+// caught the line half written (new sequence number, old query) fails the check and is simply repeated -- nothing is
+// assumed about the atomicity of the 64-byte read.  An epoch other than this launch's (one 8-byte word: never torn) means
+// STOP, whatever request a workgroup is waiting for.  Returns the command (SR_SERVER_CMD_IDLE after idle_ticks without a
+// request); on a hit x0 .. x4 are in xreq.
+__device__ __forceinline__ unsigned long long sr_srv_poll(const sr_server_args& sv, unsigned long long expect, int lane,
+                                                          double* xreq) {
+    unsigned long long cmd = SR_SERVER_CMD_IDLE;
+    const unsigned long long t_last = wall_clock64();             // 100 MHz
+    for (;;) {
+        unsigned long long wv = 0;
+        if (lane < 8) wv = __hip_atomic_load(sv.mb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (words read into scalar registers lane by lane: the check costs the polling wavefront no vector registers)
+        const unsigned wlo = (unsigned)wv, whi = (unsigned)(wv >> 32);
+#define SR_MB_WORD(l) (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)whi, l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wlo, l))
+        const unsigned long long w5 = SR_MB_WORD(5);
+        if ((w5 >> 8) != sv.epoch) { cmd = SR_SERVER_CMD_STOP; break; }      // the host called this launch off
+        if (SR_MB_WORD(6) == expect) {
+            const unsigned long long c = SR_MB_WORD(0) ^ SR_MB_WORD(1) ^ SR_MB_WORD(2) ^ SR_MB_WORD(3) ^ SR_MB_WORD(4) ^ w5 ^
+                                         expect ^ SR_MB_WORD(7);
+#undef SR_MB_WORD
+            if (c == SR_SERVER_CHK) {
+                cmd = w5 & 0xffull;
+                if (lane < 5) xreq[lane] = __longlong_as_double((long long)wv);
+                break;
+            }
+        }
+        if (wall_clock64() - t_last > sv.idle_ticks) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return cmd;
+}
+
 // (the model travels as the few words the evaluation needs -- sr_server_model -- and the argument block of phase A is
 //  rebuilt from them every round: with the whole sr_kstar_args live across the loop's back edge the scalar registers run
 //  out, spill into vector lanes and those into scratch: 12 .. 380 B per lane)
-struct sr_server_model { const double *Z, *alpha, *ls, *sf2, *Wt; int N, D, n_out; };
+struct sr_server_model { const double *Z, *alpha, *ls, *sf2, *Wt, *kp; int N, D, n_out; };
 template <int NP, int DT>
 __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, sr_server_args sv) {
     // U^-1 fragments of the wavefront (9 doubles per lane at Np = 128) in registers ACROSS requests with D <= 3 (REGS); with
@@ -145,24 +181,7 @@ __global__ __launch_bounds__(1024) void sr_gp_server_kernel(sr_server_model m, s
     const sr_small_rows<NP, DT> rows{rows_, il_};
     for (;;) {
         if (wave == 0) {
-            // the mailbox is ONE 64-byte line [x0 .. x4 | launch epoch | command | sequence number]: lanes 0 .. 7 fetch it with
-            // one request, so a hit on the sequence number (written last by the host) comes with the query it belongs to; an
-            // epoch other than this launch's means STOP, whatever request a workgroup is waiting for
-            unsigned long long cmd = SR_SERVER_CMD_IDLE;
-            const unsigned long long t_last = wall_clock64();             // 100 MHz
-            for (;;) {
-                unsigned long long wv = 0;
-                if (lane < 8) wv = __hip_atomic_load(sv.mb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned long long s = __shfl(wv, 7);
-                if (__shfl(wv, 5) != sv.epoch) { cmd = SR_SERVER_CMD_STOP; break; }      // the host called this launch off
-                if (s == expect) {
-                    cmd = __shfl(wv, 6);
-                    if (lane < 6) xreq[lane] = __longlong_as_double((long long)wv);
-                    break;
-                }
-                if (wall_clock64() - t_last > sv.idle_ticks) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
+            const unsigned long long cmd = sr_srv_poll(sv, expect, lane, xreq);
             if (lane == 0) req_cmd = cmd;
         }
         __syncthreads();
@@ -279,19 +298,26 @@ __device__ __forceinline__ void sr_part_mfma(const sr_part_frag<NP>& f, const do
     acc[0] = a0 + a1; acc[1] = b0 + b1;
 }
 
-template <int NP, int DT>
+// GEN: the general kernel family (mat52 / lin_rbf / lin_mat52: sr_small_dev.h, second part) -- the training rows stay
+// unscaled, the output's packed parameters sit in LDS, phase A forms two products, the record carries k(x,x) instead of
+// sf2 and part 0 folds the prior variance's gradient into its shares.  Also at Np = 128 (two parts).
+template <int NP, int DT, bool GEN>
 __global__ __launch_bounds__(512) void sr_gp_server_parts_kernel(sr_server_model m, sr_server_args sv) {
     constexpr int NSTRIP = NP / 16, NPAIR = NSTRIP / 2, PARTS = NP / 64;
     static_assert(NPAIR == 2 * PARTS, "two strip pairs per part");
     __shared__ double ks_[NP][SR_FQ];
-    __shared__ double xq_[SR_FQ][DT];
+    __shared__ double xq_[GEN ? 1 : SR_FQ][DT];
     __shared__ double pA_[8][256];
+    __shared__ double pA2_[GEN ? 8 : 1][256];
     __shared__ double Rs_[SR_FQ][16];
+    __shared__ double Rs2_[GEN ? SR_FQ : 1][16];
     __shared__ double pB_[3 * 4 * 256];        // quarters h = 1 .. 3 of the part's four strips
     __shared__ double redC_[NP / 16][SR_FQ];
     sr_small_lds<NP, DT> L{ks_, xq_, pA_, Rs_, pB_, redC_};
+    const sr_gen_lds<NP, DT> LG{L, pA2_, Rs2_};
     __shared__ double rows_[NP][DT + 1];
     __shared__ double il_[DT];
+    __shared__ double gp_[3 + 3 * DT];         // GEN: packed parameters of this output
     __shared__ double xreq[8];
     __shared__ unsigned long long req_cmd;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -306,30 +332,21 @@ __global__ __launch_bounds__(512) void sr_gp_server_parts_kernel(sr_server_model
     {
         sr_kstar_args a0{};
         a0.Z = m.Z; a0.alpha = m.alpha; a0.ls = m.ls; a0.N = m.N; a0.Np = NP; a0.D = D; a0.n_out = n;
-        sr_small_rows_fill<NP, DT>(a0, d, rows_, 512);
-        sr_small_il_fill<DT>(a0, d, il_);
+        if constexpr (GEN) {
+            sr_small_rows_fill_raw<NP, DT>(a0, d, rows_, 512);
+            if (tid < SR_KP(D)) gp_[tid] = m.kp[(long)d * SR_KP(D) + tid];
+        } else {
+            sr_small_rows_fill<NP, DT>(a0, d, rows_, 512);
+            sr_small_il_fill<DT>(a0, d, il_);
+        }
         frag.load(m.Wt + (long)d * NP * NP, pr, h, lane);
     }
-    const double sf2 = m.sf2[d];
+    const double sf2 = GEN ? 0.0 : m.sf2[d];
     __syncthreads();
     const sr_small_rows<NP, DT> rows{rows_, il_};
     for (;;) {
         if (wave == 0) {
-            unsigned long long cmd = SR_SERVER_CMD_IDLE;
-            const unsigned long long t_last = wall_clock64();
-            for (;;) {
-                unsigned long long wv = 0;
-                if (lane < 8) wv = __hip_atomic_load(sv.mb + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned long long s = __shfl(wv, 7);
-                if (__shfl(wv, 5) != sv.epoch) { cmd = SR_SERVER_CMD_STOP; break; }      // the host called this launch off
-                if (s == expect) {
-                    cmd = __shfl(wv, 6);
-                    if (lane < 6) xreq[lane] = __longlong_as_double((long long)wv);
-                    break;
-                }
-                if (wall_clock64() - t_last > sv.idle_ticks) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
+            const unsigned long long cmd = sr_srv_poll(sv, expect, lane, xreq);
             if (lane == 0) req_cmd = cmd;
         }
         __syncthreads();
@@ -349,7 +366,8 @@ __global__ __launch_bounds__(512) void sr_gp_server_parts_kernel(sr_server_model
             sr_kstar_args a{};
             a.sf2 = m.sf2;
             a.lda = D; a.na = D; a.N = m.N; a.Np = NP; a.D = D; a.n_out = n; a.nsplit = 1; a.T = 1; a.Tp = 1;
-            sr_small_phase_a<NP, DT, true, true, 8>(a, d, xreq, D, xreq, D, 1, L, &rows, tq);
+            if constexpr (GEN) sr_small_phase_a_gen<NP, DT, true, 8>(a, d, xreq, gp_, LG, &rows, tq);
+            else sr_small_phase_a<NP, DT, true, true, 8>(a, d, xreq, D, xreq, D, 1, L, &rows, tq);
             // phase B on the part's strips
             const int lk = (tq & 63) >> 4, ln = tq & 15;
             sr_d4 acc[2];
@@ -393,18 +411,31 @@ __global__ __launch_bounds__(512) void sr_gp_server_parts_kernel(sr_server_model
             const int e = lane, R = 2 + 2 * D + D * D;
             const double mval = Rs_[0][0];
             double val = 0.0;
-            if (part == 0) {
-                if (e == 0) val = mval;
-                else if (e >= 2 && e < 2 + D) val = Rs_[1 + (e - 2)][0];
-                else if (e >= 2 + 2 * D && e < R) {
-                    const int q = e - (2 + 2 * D);
-                    const int j = min(q / D, q % D), l = max(q / D, q % D);
-                    val = (Rs_[1 + j][1 + l] - xq_[0][l] * Rs_[1 + j][0]) * il_[l];
-                    if (j == l) val -= mval * il_[j] * il_[j];
-                } else if (e == SR_SERVER_REC - 1) val = sf2;
-            }
             const int c = (e == 1) ? 0 : ((e >= 2 + D && e < 2 + 2 * D) ? e - (2 + D) + 1 : -1);
-            if (c >= 0) val = redC_[0][c] + redC_[1][c] + redC_[2][c] + redC_[3][c];
+            if constexpr (GEN) {
+                // (the host forms var = rec[REC - 1] - sum of the shares of q_0 and d var/dx_j = -2 sum of the shares of q_j:
+                //  part 0 hands k(x,x) over in place of sf2 and takes half the prior variance's gradient off its share)
+                if (part == 0) {
+                    if (e == SR_SERVER_REC - 1) val = sr_gen_record_elem<NP, DT>(1, D, LG, gp_);
+                    else if (e < R && e != 1) val = sr_gen_record_elem<NP, DT>(e, D, LG, gp_);
+                }
+                if (c >= 0) {
+                    const double share = redC_[0][c] + redC_[1][c] + redC_[2][c] + redC_[3][c];
+                    val = (c == 0) ? share : fma(-0.5, val, share);
+                }
+            } else {
+                if (part == 0) {
+                    if (e == 0) val = mval;
+                    else if (e >= 2 && e < 2 + D) val = Rs_[1 + (e - 2)][0];
+                    else if (e >= 2 + 2 * D && e < R) {
+                        const int q = e - (2 + 2 * D);
+                        const int j = min(q / D, q % D), l = max(q / D, q % D);
+                        val = (Rs_[1 + j][1 + l] - xq_[0][l] * Rs_[1 + j][0]) * il_[l];
+                        if (j == l) val -= mval * il_[j] * il_[j];
+                    } else if (e == SR_SERVER_REC - 1) val = sf2;
+                }
+                if (c >= 0) val = redC_[0][c] + redC_[1][c] + redC_[2][c] + redC_[3][c];
+            }
             if (e < SR_SERVER_REC) out[e] = val;
             __threadfence_system();
             if (lane == 0) {
@@ -419,13 +450,18 @@ __global__ __launch_bounds__(512) void sr_gp_server_parts_kernel(sr_server_model
 
 template <int NP>
 static int launch_server_np(const sr_kstar_args& a, const double* Wt, const sr_server_args& sv, hipStream_t s) {
-    const sr_server_model m{a.Z, a.alpha, a.ls, a.sf2, Wt, a.N, a.D, a.n_out};
+    const sr_server_model m{a.Z, a.alpha, a.ls, a.sf2, Wt, a.kp, a.N, a.D, a.n_out};
     SR_CHECK(sr_gp_server_supported(NP, a.D), SR_EUNSUPPORTED, "gp_server: Np=%d D=%d not built", NP, a.D);
-    if constexpr (NP >= 256) {
-        static_assert(sr_gp_server_parts(NP) == NP / 64, "parts");
+    if (a.kp) {                                            // general kernel family: in parts at every size
+        static_assert(sr_gp_server_parts(NP, true) == NP / 64, "parts");
         dim3 grid(NP / 64, a.n_out);
-        if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 3>), grid, dim3(512), 0, s, m, sv);
-        else hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 5>), grid, dim3(512), 0, s, m, sv);
+        if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 3, true>), grid, dim3(512), 0, s, m, sv);
+        else hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 5, true>), grid, dim3(512), 0, s, m, sv);
+    } else if constexpr (NP >= 256) {
+        static_assert(sr_gp_server_parts(NP, false) == NP / 64, "parts");
+        dim3 grid(NP / 64, a.n_out);
+        if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 3, false>), grid, dim3(512), 0, s, m, sv);
+        else hipLaunchKernelGGL((sr_gp_server_parts_kernel<NP, 5, false>), grid, dim3(512), 0, s, m, sv);
     } else {
         dim3 grid(1, a.n_out);
         if (a.D <= 3) hipLaunchKernelGGL((sr_gp_server_kernel<NP, 3>), grid, dim3(1024), 0, s, m, sv);

@@ -22,6 +22,21 @@
 #include "sr_common.h"
 #include "sr_small_dev.h"
 
+// blocking single query (sr_gp_call1): the outputs went to pinned host memory; once every workgroup's stores are out
+// (system-scope fence), the last one to arrive publishes the sequence number the host spins on
+__device__ __forceinline__ void sr_small_publish(const sr_kstar_args& a, int tid) {
+    if (!a.host_flag) return;
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x * gridDim.y - 1u) {
+            __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int NP, int DT, bool LIN>
 __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, const double* __restrict__ Wt,
                                                            double* __restrict__ mu, double* __restrict__ var,
@@ -36,19 +51,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_kernel(sr_kstar_args a, cons
 
     sr_small_outputs<NP, DT, LIN>(a, L, d, t0, sf2, mu, var, jac, jac_var, hess);
 
-    if (a.host_flag) {
-        // blocking single query: the outputs above went to pinned host memory; once every workgroup's stores are
-        // out (system-scope fence), the last one to arrive publishes the sequence number
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == gridDim.x * gridDim.y - 1u) {
-                __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
+    sr_small_publish(a, tid);
 }
 
 // General kernel family (Matern-5/2, linear x stationary + linear: sr_common.h; the kernels of the reference's
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(1024) void sr_gp_small_general_kernel(sr_kstar_args
 #pragma unroll
     for (int j = 0; j < DT; ++j) {
         x[j] = 0.0;
-        if (live && j < a.D) x[j] = (j < a.na) ? a.xa[(t0 + ln) * a.lda + j] : a.xb[(t0 + ln) * a.ldb + (j - a.na)];
+        if (live && j < a.D) x[j] = a.xv_on ? a.xv[j] : ((j < a.na) ? a.xa[(t0 + ln) * a.lda + j] : a.xb[(t0 + ln) * a.ldb + (j - a.na)]);
         const double sj = (j < a.D) ? kp[3 + j] : 0.0;
         s2[j] = sj * sj;
         av[j] = (j < a.D) ? kp[3 + a.D + j] : 0.0;
@@ -181,12 +184,66 @@ __global__ __launch_bounds__(1024) void sr_gp_small_general_kernel(sr_kstar_args
         if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
         var[(t0 + tid) * a.n_out + d] = v;
     }
+    sr_small_publish(a, tid);
+}
+
+// The same family, ONE query with second-order outputs (sr_gp_linearize / sr_gp_call1 of a small mat52 / lin_* model: the
+// call CasadiSSMEvaluator makes per IPOPT iteration with the journal experiments' kernels, state_space_models.py:384-417):
+// phase A of sr_small_dev.h (general form), the contraction of the columns [k*, dk*/dx] with U^-1, outputs in the API layout.
+template <int NP, int DT>
+__global__ __launch_bounds__(1024) void sr_gp_small_gen_lin_kernel(sr_kstar_args a, const double* __restrict__ Wt,
+                                                                   double* __restrict__ mu, double* __restrict__ var,
+                                                                   double* __restrict__ jac, double* __restrict__ jac_var,
+                                                                   double* __restrict__ hess) {
+    constexpr int NSTRIP = NP / 16;
+    __shared__ double ks_[NP][SR_FQ];
+    __shared__ double xq_[1][DT];
+    __shared__ double pA_[16][256];
+    __shared__ double pA2_[16][256];
+    __shared__ double Rs_[SR_FQ][16];
+    __shared__ double Rs2_[SR_FQ][16];
+    __shared__ double pB_[((16 / (NP / 32)) > 1 ? (16 / (NP / 32)) - 1 : 1) * ((16 / (NP / 32)) > 1 ? NP / 16 : 1) * 256];
+    __shared__ double redC_[NP / 16][SR_FQ];
+    const sr_gen_lds<NP, DT> L{{ks_, xq_, pA_, Rs_, pB_, redC_}, pA2_, Rs2_};
+    const int tid = threadIdx.x;
+    const int d = blockIdx.y, D = a.D;
+    const double* kp = a.kp + (long)d * SR_KP(D);
+    sr_small_phase_a_gen<NP, DT, false, 16>(a, d, a.xa, kp, L);
+    sr_small_contract<NP, true>(Wt + (long)d * NP * NP, ks_, pB_, redC_, tid >> 6, tid & 63);
+    const int R = 2 + 2 * D + D * D;
+    if (tid < R) {
+        double val = sr_gen_record_elem<NP, DT>(tid, D, L, kp);
+        const int c = (tid == 1) ? 0 : ((tid >= 2 + D && tid < 2 + 2 * D) ? tid - (2 + D) + 1 : -1);
+        if (c >= 0) {
+            double qn = 0.0;
+#pragma unroll
+            for (int sidx = 0; sidx < NSTRIP; ++sidx) qn += redC_[sidx][c];
+            if (c == 0) {
+                val -= qn;
+                if (!(val > SR_VAR_CLIP)) val = SR_VAR_CLIP;
+            } else val = fma(-2.0, qn, val);
+        }
+        if (tid == 0) mu[d] = val;
+        else if (tid == 1) var[d] = val;
+        else if (tid < 2 + D) jac[d * D + tid - 2] = val;
+        else if (tid < 2 + 2 * D) jac_var[d * D + tid - (2 + D)] = val;
+        else hess[(long)d * D * D + tid - (2 + 2 * D)] = val;
+    }
+    sr_small_publish(a, tid);
 }
 
 
 template <int NP>
 static int launch_small_np(const sr_kstar_args& a, const double* Wt, double* mu, double* var, double* jac,
                            double* jac_var, double* hess, hipStream_t s) {
+    if (hess && a.kp) {                                    // the same for the general kernel family (D <= 5)
+        dim3 grid(1, a.n_out);
+        SR_CHECK(a.D <= 5, SR_EUNSUPPORTED, "gp_small: second order of a general kernel in one launch needs D <= 5 (D=%d)", a.D);
+        if (a.D <= 3) hipLaunchKernelGGL((sr_gp_small_gen_lin_kernel<NP, 3>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac, jac_var, hess);
+        else hipLaunchKernelGGL((sr_gp_small_gen_lin_kernel<NP, 5>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac, jac_var, hess);
+        SR_HIP(hipGetLastError());
+        return SR_OK;
+    }
     if (hess) {                                            // single query with second-order outputs
         dim3 grid(1, a.n_out);
 #define SR_SMALL_LIN(DT) hipLaunchKernelGGL((sr_gp_small_kernel<NP, DT, true>), grid, dim3(1024), 0, s, a, Wt, mu, var, jac, jac_var, hess)

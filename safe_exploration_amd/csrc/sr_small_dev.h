@@ -313,3 +313,189 @@ __device__ __forceinline__ void sr_small_outputs(const sr_kstar_args& a, const s
     }
 
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// GENERAL kernel family (sr_common.h: k = (c0 + sum a x z) v kappa(r) + sum b x z, kappa in {RBF, Matern-5/2} -- the
+// reference's mat52 / lin_rbf / lin_mat52, ssm_gpy/gp_models_utils_casadi.py:43-157, which its journal experiments run:
+// experiments/journal_experiment_configs/defaultconfig_episode.py:39), ONE query with second-order outputs, on the same
+// MFMA tile as the ARD-RBF form above.  With u_j = s_j^2 (x_j - z_j), c = c0 + sum a x z, g = kappa'/r, h = g'/r
+// (sr_linearize.hip):
+//   dk/dx_j        = a_j z_j v kappa + c v g u_j + b_j z_j
+//   d2k/dx_j dx_l  = v g (a_j z_j u_l + a_l z_l u_j) + c v (h u_j u_l + g s_j^2 delta_jl)
+// Two products against the SAME right-hand side M[i][:] = alpha_i [1, z_i - x] (16 columns, 1 + D used):
+//   P1 rows m:  0: k    1+j: dk/dx_j    8: c v g    9+j: c v h u_j          P2 rows m:  1+l: v g u_l
+//   mu = P1[0][0],  d mu/dx_j = P1[1+j][0],
+//   d2 mu/dx_j dx_l = a_j (P2[1+l][1+j] + x_j P2[1+l][0]) + a_l (P2[1+j][1+l] + x_l P2[1+j][0]) - s_l^2 P1[9+j][1+l]
+//                     + delta_jl s_j^2 P1[8][0]
+// and rows 0 .. D of P1's left operand are the columns [k*, dk*/dx] phase B contracts with U^-1:
+//   var = k(x,x) - V_0.V_0,  d var/dx_j = 2 (a_j v + b_j) x_j - 2 V_j.V_0,   k(x,x) = (c0 + sum a x^2) v + sum b x^2.
+// D <= 5 (rows 9 + j <= 15 would allow 7; the D = 8 instantiations of the sixteen-wavefront kernels spill).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NP, int DT>
+struct sr_gen_lds {
+    sr_small_lds<NP, DT> s;     // ks, xq (row 0: the query, UNSCALED), pA, Rs (P1), pB, redC
+    double (*pA2)[256];         // per-wavefront partial P2
+    double (*Rs2)[16];          // P2
+};
+// packed parameters of one output (SR_KP(D) doubles: kappa id, v, c0, s[D], a[D], b[D]) -> what the evaluation uses
+template <int DT>
+struct sr_gen_par {
+    int kind; double v, c0, s2[DT], a[DT], b[DT];
+    __device__ __forceinline__ void load(const double* kp, int D) {
+        kind = (int)kp[0]; v = kp[1]; c0 = kp[2];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const double sj = (j < D) ? kp[3 + j] : 0.0;
+            s2[j] = sj * sj;
+            a[j] = (j < D) ? kp[3 + D + j] : 0.0;
+            b[j] = (j < D) ? kp[3 + 2 * D + j] : 0.0;
+        }
+    }
+};
+// rows for KEEP: z_ij UNSCALED, alpha_i (0 on padding rows)
+template <int NP, int DT>
+__device__ __forceinline__ void sr_small_rows_fill_raw(const sr_kstar_args& a, int d, double (*dst)[DT + 1], int nthreads) {
+    const int off = NP - a.N;
+    for (int e = threadIdx.x; e < NP * (DT + 1); e += nthreads) {
+        const int i = e / (DT + 1), j = e % (DT + 1);
+        const bool valid = i >= off;
+        double v = 0.0;
+        if (valid && j == DT) v = a.alpha[(long)d * NP + i];
+        else if (valid && j < a.D) v = a.Z[(long)(i - off) * a.D + j];
+        dst[i][j] = v;
+    }
+}
+
+// Phase A of the general family for ONE query x (D doubles at xsrc: global, LDS or the kernel arguments a.xv): the columns
+// [k*, dk*/dx] into L.s.ks, P1 into L.s.Rs and P2 into L.Rs2 (both valid after the NEXT barrier), the query into L.s.xq[0].
+// kp: the output's packed parameters (global or LDS).  All NW wavefronts call.
+template <int NP, int DT, bool KEEP, int NW>
+__device__ __forceinline__ void sr_small_phase_a_gen(const sr_kstar_args& a, int d, const double* xsrc, const double* kp,
+                                                     const sr_gen_lds<NP, DT>& L,
+                                                     const sr_small_rows<NP, DT>* rows = nullptr, int tid_in = -1) {
+    constexpr int RPW = NP / NW, KSA = RPW / 4;
+    static_assert(DT <= 5, "rows 9 + j of P1 and the registers of the sixteen-wavefront kernels: D <= 5");
+    double (*ks)[SR_FQ] = L.s.ks;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
+    const int off = NP - a.N;
+    sr_gen_par<DT> P;
+    P.load(kp, a.D);
+    double x[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) x[j] = (j < a.D) ? (a.xv_on ? a.xv[j] : xsrc[j]) : 0.0;
+    sr_d4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1;
+#pragma unroll
+    for (int st = 0; st < KSA; ++st) {
+        const int i = wave * RPW + 4 * st + lk;
+        const bool valid = i >= off;
+        double al, z[DT];
+        if (KEEP) {
+            al = rows->r[i][DT];
+#pragma unroll
+            for (int j = 0; j < DT; ++j) z[j] = rows->r[i][j];
+        } else {
+            al = valid ? a.alpha[(long)d * NP + i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) z[j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
+        }
+        double r2 = 0.0, la = 0.0, lb = 0.0, u[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const double df = x[j] - z[j];
+            u[j] = P.s2[j] * df;
+            r2 = fma(u[j], df, r2);
+            la = fma(P.a[j] * x[j], z[j], la);
+            lb = fma(P.b[j] * x[j], z[j], lb);
+        }
+        double kap, g, hh;
+        if (P.kind == 0) {
+            kap = exp(-0.5 * r2);
+            g = -kap;
+            hh = kap;
+        } else {
+            const double rr = sqrt(r2);
+            const double e = exp(-2.23606797749978969641 * rr);
+            kap = (1.0 + 2.23606797749978969641 * rr + (5.0 / 3.0) * r2) * e;
+            g = -(5.0 / 3.0) * (1.0 + 2.23606797749978969641 * rr) * e;
+            hh = (25.0 / 3.0) * e;
+        }
+        const double pre = (P.c0 + la) * P.v;
+        const double vk = P.v * kap, pg = pre * g, ph = pre * hh, vg = P.v * g;
+        // this lane's row m = ln of the two left operands, and its column n = ln of the right-hand side
+        double A1 = (ln == 0) ? fma(pre, kap, lb) : ((ln == 8) ? pg : 0.0), A2 = 0.0, bsel = (ln == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            if (ln == 1 + j) {
+                A1 = fma(vk, P.a[j] * z[j], fma(pg, u[j], P.b[j] * z[j]));
+                A2 = vg * u[j];
+                bsel = z[j] - x[j];
+            }
+            if (ln == 9 + j) A1 = ph * u[j];
+        }
+        if (!valid || ln > 9 + a.D - 1 || (ln > a.D && ln < 8)) { A1 = 0.0; }
+        if (!valid || ln > a.D) A2 = 0.0;
+        if (ln > a.D) bsel = 0.0;
+        ks[i][ln] = (ln <= a.D) ? A1 : 0.0;
+        const double bfrag = al * bsel;
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, bfrag, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, bfrag, acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        L.s.pA[wave][r * 64 + lane] = acc1[r];
+        L.pA2[wave][r * 64 + lane] = acc2[r];
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int j = 0; j < DT; ++j) L.s.xq[0][j] = x[j];
+    }
+    __syncthreads();
+    if (tid < 512) {
+        const int t2 = tid & 255;
+        double v = 0.0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += L.s.pA[w][t2];
+        } else {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += L.pA2[w][t2];
+        }
+        const int l2 = t2 & 63, r = t2 >> 6;
+        (tid < 256 ? L.s.Rs : L.Rs2)[(l2 >> 4) + 4 * r][l2 & 15] = v;
+    }
+}
+
+// Element e of the record [mu, var (here: the prior variance k(x,x); the caller subtracts V_0.V_0), d mu/dx (D),
+// d k(x,x)/dx (D; the caller subtracts 2 V_j.V_0), d2 mu/dx2 (D x D)] of the general family after sr_small_phase_a_gen
+// (+ a barrier).  kp as there.
+template <int NP, int DT>
+__device__ __forceinline__ double sr_gen_record_elem(int e, int D, const sr_gen_lds<NP, DT>& L, const double* kp) {
+    const double (*R1)[16] = L.s.Rs;
+    const double (*R2)[16] = L.Rs2;
+    const double* x = L.s.xq[0];
+    const double v = kp[1], c0 = kp[2];
+    if (e == 0) return R1[0][0];
+    if (e == 1) {
+        double kxx = c0 * v;
+        for (int j = 0; j < D; ++j) kxx = fma((kp[3 + D + j] * v + kp[3 + 2 * D + j]) * x[j], x[j], kxx);
+        return kxx;
+    }
+    if (e < 2 + D) return R1[1 + (e - 2)][0];
+    if (e < 2 + 2 * D) {
+        const int j = e - (2 + D);
+        return 2.0 * (kp[3 + D + j] * v + kp[3 + 2 * D + j]) * x[j];
+    }
+    if (e < 2 + 2 * D + D * D) {
+        const int q = e - (2 + 2 * D);
+        const int j = min(q / D, q % D), l = max(q / D, q % D);       // (j <= l: the matrix comes out exactly symmetric)
+        const double aj = kp[3 + D + j], al = kp[3 + D + l], sl = kp[3 + l];
+        const double s1jl = fma(x[j], R2[1 + l][0], R2[1 + l][1 + j]);
+        const double s1lj = fma(x[l], R2[1 + j][0], R2[1 + j][1 + l]);
+        double hv = aj * s1jl + al * s1lj - sl * sl * R1[9 + j][1 + l];
+        if (j == l) hv = fma(kp[3 + j] * kp[3 + j], R1[8][0], hv);
+        return hv;
+    }
+    return 0.0;
+}

@@ -1065,8 +1065,10 @@ class SimpleGPModel(StateSpaceModel):
         PCIe round trip plus the evaluation instead of a kernel launch each -- the regime of the MPC's IPOPT callbacks
         (state_space_models.py:278-303, 384-417).  The kernel leaves by itself after ``idle_timeout_s`` without a query
         (so a ``torch.cuda.synchronize()`` elsewhere waits at most that long) and comes back with the next one; model
-        updates take it off the device and leave it armed.  Returns False where the model has no such server (non-RBF
-        kernels, more than 512 padded points, an input transform): the launched routes serve it as before."""
+        updates take it off the device and leave it armed.  Every kernel identifier is served ("rbf", and since round 5
+        "mat52" / "lin_rbf" / "lin_mat52", the kernels of the reference's journal experiments); queries are in the GP's
+        input space.  Returns False where the model has no such server (more than 512 padded points, more than 5
+        inputs): the launched routes serve it as before."""
         self._need_trained()
         hd = self._handle
         hd.single_io()

@@ -21,6 +21,90 @@ def t(fn, n=300):
 
 
 SIZES = ((2, 25), (2, 100), (4, 150), (2, 200), (2, 350), (2, 500), (2, 1000), (2, 2000), (2, 5000))
+# --kern mat52 | lin_rbf | lin_mat52: the journal experiments' kernels (defaultconfig_episode.py:39: lin_mat52, m = 150,
+# 4 outputs, GP inputs = 3 transformed states + 1 action -> (n_s_out, n_s_in, n_u) = (4, 3, 1), D = 4; untransformed: D = 5)
+JOURNAL_SIZES = ((4, 3, 1, 25), (4, 4, 1, 25), (4, 3, 1, 150), (4, 4, 1, 150), (2, 2, 1, 100), (2, 2, 1, 350), (2, 2, 1, 500),
+                 (4, 3, 1, 1000))
+
+
+def kern_hyp(kt, rng, D, n_out):
+    """hyper-parameters with the reference's key names (ssm_gpy/gaussian_process.py:491-544)"""
+    out = []
+    for _ in range(n_out):
+        if kt in ("rbf", "mat52"):
+            out.append({"lengthscale": rng.uniform(0.5, 1.5, D), "variance": float(rng.uniform(0.5, 1.5)), "noise_variance": 0.02})
+        else:
+            st = "rbf" if kt == "lin_rbf" else "mat52"
+            out.append({"prod.%s.lengthscale" % st: np.array([rng.uniform(0.5, 1.5)]), "prod.%s.variance" % st: float(rng.uniform(0.5, 1.5)),
+                        "prod.linear.variances": np.array([rng.uniform(0.5, 1.5)]), "linear.variances": rng.uniform(0.2, 1.0, D),
+                        "noise_variance": 0.02})
+    return out
+
+
+def cpu_time_k(Z, Y, kt, hyp, x, second_order, reps=200):
+    """as cpu_time, for the general kernels (the oracle's closed forms of the same call)"""
+    from oracle import oracle_np as orc
+    n = Y.shape[1]
+    hy = [{k: v for k, v in h.items() if k != "noise_variance"} for h in hyp]
+    beta, inv_K = orc.gp_fit_k(Z, Y, [kt] * n, hy, np.full(n, 0.02 + 1e-5))
+    if second_order:
+        fn = lambda: (orc.gp_predict_k(x[None], Z, beta, inv_K, [kt] * n, hy), orc.gp_mean_jacobian_k(x[None], Z, beta, [kt] * n, hy),
+                      orc.gp_linearize_extras_k(x, Z, beta, inv_K, [kt] * n, hy))
+    else:
+        fn = lambda: (orc.gp_predict_k(x[None], Z, beta, inv_K, [kt] * n, hy), orc.gp_mean_jacobian_k(x[None], Z, beta, [kt] * n, hy))
+    for _ in range(3):
+        fn()
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+    return best
+
+
+def main_kern(kt):
+    print("# blocking single-query entry points with kern_types = ['%s'] * n_out (the journal experiments' kernel family), wall time "
+          "per call [us]; NumPy in / out.  Routes as in the ARD-RBF table: copy + sync, mailbox, one command (sr_gp_call1), RESIDENT "
+          "SERVER; CPU: the oracle's NumPy closed forms of the same call (1 BLAS thread / all %d cores; model fit excluded)."
+          % (kt, os.cpu_count() or 1))
+    from threadpoolctl import threadpool_limits
+    cpu_rows = []
+    for n_out, n_in, n_u, N in JOURNAL_SIZES:
+        rng = np.random.default_rng(100 + N + n_in)
+        D = n_in + n_u
+        Z = rng.uniform(-1, 1, (N, D))
+        Y = rng.standard_normal((N, n_out))
+        hyp = kern_hyp(kt, rng, D, n_out)
+        gp = SimpleGPModel(n_out, n_in, n_u, kern_types=[kt] * n_out, hyp=hyp, device="cuda:0")
+        gp.train(Z, Y, opt_hyp=False)
+        io = gp._handle.single_io()
+        xq = rng.uniform(-0.6, 0.6, (1, D))
+        st, ac = xq[:, :n_in], xq[:, n_in:]
+        row = {}
+        for mode, (mb, di) in (("sync", (False, False)), ("mailbox", (True, False)), ("direct", (True, True))):
+            io["mailbox"], io["direct"] = mb, di
+            io.pop("direct_off", None)
+            row[mode] = (t(lambda: gp(st, ac)), t(lambda: gp.linearize_predict(st, ac, True)))
+            if mode == "direct" and not io["direct"]:
+                row[mode] = (float("nan"), float("nan"))
+        row["server"] = (float("nan"), float("nan"))
+        if gp.start_server(idle_timeout_s=0.05):
+            row["server"] = (t_host(lambda: gp(st, ac)), t_host(lambda: gp.linearize_predict(st, ac, True)))
+            gp.stop_server()
+        print("%s n_out=%d D=%d N=%5d  __call__: copy+sync %.1f, mailbox %.1f, one command %.1f, resident server %.1f || "
+              "linearize_predict(jacobians=True): %.1f, %.1f, %.1f, server %.1f" % (
+                  kt, n_out, D, N, row["sync"][0], row["mailbox"][0], row["direct"][0], row["server"][0], row["sync"][1],
+                  row["mailbox"][1], row["direct"][1], row["server"][1]), flush=True)
+        cpu_rows.append((n_out, D, N, Z, Y, hyp, xq[0]))
+        del gp
+    for n_out, D, N, Z, Y, hyp, x in cpu_rows:
+        reps = 100 if N <= 500 else 20
+        with threadpool_limits(limits=1):
+            one = (cpu_time_k(Z, Y, kt, hyp, x, False, reps), cpu_time_k(Z, Y, kt, hyp, x, True, reps))
+        allc = (cpu_time_k(Z, Y, kt, hyp, x, False, reps), cpu_time_k(Z, Y, kt, hyp, x, True, reps))
+        print("%s n_out=%d D=%d N=%5d  CPU NumPy (oracle): __call__ %.1f us with 1 BLAS thread, %.1f with all cores; "
+              "linearize_predict(jacobians=True) %.1f / %.1f us" % (kt, n_out, D, N, one[0], allc[0], one[1], allc[1]), flush=True)
 
 
 def cpu_time(prob, second_order, reps=200):
@@ -95,4 +179,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--kern" in sys.argv:
+        main_kern(sys.argv[sys.argv.index("--kern") + 1])
+    else:
+        main()

@@ -13,13 +13,26 @@ from safe_exploration_amd import SimpleGPModel, workload  # noqa: E402
 
 
 def main():
-    Ns = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "50,200,1000,5000").split(",")]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    args = list(sys.argv[1:])
+    kt = "rbf"
+    if "--kern" in args:                                    # rbf (default) | mat52 | lin_rbf | lin_mat52
+        i = args.index("--kern")
+        kt = args[i + 1]
+        del args[i:i + 2]
+    Ns = [int(v) for v in (args[0] if len(args) > 0 else "50,200,1000,5000").split(",")]
+    steps = int(args[1]) if len(args) > 1 else 60
+    print("# kern_types = ['%s'] * 2" % kt)
     print("%6s %12s %14s %14s %12s   [us per call, mean of %d steps after 5 warm-up steps]"
           % ("N", "predict(1)", "update(+1)", "info gain", "step", steps))
     for N in Ns:
         prob = workload.make_problem(6, N + steps + 5, 2, 1, 8)
-        gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob), device="cuda:0")
+        if kt == "rbf":
+            hyp = workload.hyp_list(prob)
+        else:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            from call_latency import kern_hyp
+            hyp = kern_hyp(kt, np.random.default_rng(N), 3, 2)
+        gp = SimpleGPModel(2, 2, 1, kern_types=[kt] * 2, hyp=hyp, device="cuda:0")
         Z, Y = prob["Z"], prob["Y"]
         gp.train(Z[:N], Y[:N], opt_hyp=False)
         t = np.zeros(3)

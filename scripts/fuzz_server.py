@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the blocking single-query surface through the RESIDENT server (sr_gp_server_*): random model
 sizes across the padded sizes 128 ... 512 (one workgroup per output up to 128 rows, Np / 64 parts beyond), 1 ... 4 outputs,
-D = 2 ... 5, with appends, refits and idle time-outs in between -- against the CPU oracle's closed forms and against the
+D = 2 ... 5, the four kernel identifiers (ARD-RBF, mat52, lin_rbf, lin_mat52), with appends, refits and idle time-outs in between -- against the CPU oracle's closed forms and against the
 launched routes of the same model.  Run on the GPU box:
     python scripts/fuzz_server.py [cases] [seed]
 Exits non-zero on the first case outside the tolerances of the parity tests."""
@@ -37,6 +37,43 @@ def check(gp, om, syn, t, worst, n_s):
     return max(e.values())
 
 
+class KernCase(object):
+    """a model with one of the journal kernels (mat52 / lin_rbf / lin_mat52) and the oracle's closed forms for it"""
+
+    def __init__(self, kt, rng, Z, Y, n_s, n_u):
+        from safe_exploration_amd import SimpleGPModel
+        self.kt, self.n_s, self.n_u = kt, n_s, n_u
+        self.hyp = [orc.make_hyp(kt, rng, n_s + n_u) for _ in range(n_s)]
+        self.noise = np.full(n_s, 0.02)
+        self.gp = SimpleGPModel(n_s, n_s, n_u, kern_types=[kt] * n_s,
+                                hyp=[dict(h, noise_variance=nv) for h, nv in zip(self.hyp, self.noise)])
+        self.gp.train(Z, Y, opt_hyp=False)
+        self.fit(Z, Y)
+
+    def fit(self, Z, Y):
+        self.Z = Z
+        self.beta, self.inv_K = orc.gp_fit_k(Z, Y, [self.kt] * self.n_s, self.hyp, self.noise + 1e-5)
+
+    def check(self, syn, t, worst):
+        kts = [self.kt] * self.n_s
+        p, k = syn["p"][t:t + 1], syn["k_ff"][t:t + 1]
+        x = np.hstack((p, k))
+        mu, sig, jac = self.gp(p, k)
+        lin = self.gp.linearize_predict(p, k, True)
+        rmu, rvar = orc.gp_predict_k(x, self.Z, self.beta, self.inv_K, kts, self.hyp)
+        rjac = orc.gp_mean_jacobian_k(x, self.Z, self.beta, kts, self.hyp)
+        rjv, rhm = orc.gp_linearize_extras_k(x[0], self.Z, self.beta, self.inv_K, kts, self.hyp)
+        scale = max(np.abs(self.beta).sum(0).max(), 1.0)
+        e = {"mu": np.abs(mu[:, 0] - rmu[0]).max() / (1e-11 * scale + 1e-9 * np.abs(rmu).max()),
+             "var": np.abs(lin[1][:, 0] - rvar[0]).max() / (1e-8 * max(1.0, float(rvar.max()))),
+             "jac": np.abs(jac - rjac[0]).max() / (1e-10 * scale + 1e-9 * np.abs(rjac).max()),
+             "jvar": np.abs(lin[3] - rjv).max() / (1e-6 * np.abs(rjv).max() + 1e-8 * max(1.0, np.abs(rjv).max())),
+             "hess": np.abs(lin[4] - rhm).max() / (1e-8 * np.abs(rhm).max() + 1e-10 * scale)}
+        for kk, v in e.items():
+            worst[kk] = max(worst[kk], float(v))
+        return max(e.values())
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -47,25 +84,35 @@ def main():
         extra = int(rng.integers(0, 4))
         syn = orc.make_synthetic(int(rng.integers(1 << 30)), N + extra, n_s, n_u, 8, sf2=float(rng.choice([1.0, 0.01])))
         Z, Y = syn["Z"], syn["Y"]
-        gp = hip_model(Z[:N], Y[:N], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+        kt = str(rng.choice(["rbf", "rbf", "mat52", "lin_rbf", "lin_mat52", "lin_mat52"]))
+        if kt == "rbf":
+            gp = hip_model(Z[:N], Y[:N], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+            om = oracle_model(Z[:N], Y[:N], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+            chk = lambda t: check(gp, om, syn, t, worst, n_s)
+        else:
+            kc = KernCase(kt, rng, Z[:N], Y[:N], n_s, n_u)
+            gp = kc.gp
+            chk = lambda t: kc.check(syn, t, worst)
         gp.append_limit = 10 ** 9
         armed = gp.start_server(idle_timeout_s=float(rng.choice([0.0005, 0.002, 0.05])))
-        om = oracle_model(Z[:N], Y[:N], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
         err = 0.0
         for t in range(4):
-            err = max(err, check(gp, om, syn, t, worst, n_s))
+            err = max(err, chk(t))
             if rng.integers(3) == 0:
                 time.sleep(0.003)                            # the server may leave on its idle time-out in between
         for i in range(N, N + extra):                        # the model grows under the armed server (may cross a padded size)
             gp.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)
         if extra:
-            om = oracle_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+            if kt == "rbf":
+                om = oracle_model(Z, Y, syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+            else:
+                kc.fit(Z, Y)
             for t in range(4, 8):
-                err = max(err, check(gp, om, syn, t, worst, n_s))
+                err = max(err, chk(t))
         a, r, nl, nc = gp.server_state()
-        status = "ok" if err <= 1.0 and (not armed or nc > 0 or not a) else "FAIL"
-        print("%3d N=%3d+%d n_s=%d n_u=%d armed=%d launches=%d calls=%d  worst err/tol %.2e  %s" %
-              (c, N, extra, n_s, n_u, int(a), nl, nc, err, status), flush=True)
+        status = "ok" if err <= 1.0 and armed and (nc > 0 or not a) else "FAIL"
+        print("%3d %-9s N=%3d+%d n_s=%d n_u=%d armed=%d launches=%d calls=%d  worst err/tol %.2e  %s" %
+              (c, kt, N, extra, n_s, n_u, int(a), nl, nc, err, status), flush=True)
         if status != "ok":
             sys.exit(1)
         del gp

@@ -2059,6 +2059,118 @@ def test_resident_server_answers_single_queries(N, n_s, n_u):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("kt,N,n_s,n_u", [("mat52", 100, 2, 1), ("lin_rbf", 128, 2, 1), ("lin_mat52", 150, 4, 1), ("lin_mat52", 25, 4, 1),
+                                          ("lin_mat52", 150, 3, 1), ("mat52", 300, 2, 1), ("lin_rbf", 450, 2, 2), ("lin_mat52", 512, 2, 1),
+                                          ("mat52", 5, 1, 1)])
+def test_single_query_routes_with_the_journal_kernels(kt, N, n_s, n_u):
+    """mat52 / lin_rbf / lin_mat52 -- the kernels of the reference's journal experiments
+    (experiments/journal_experiment_configs/defaultconfig_episode.py:39, m = 150 inducing points, GP inputs = 3 transformed
+    states + 1 action: the (150, 3, 1) row, D = 4; (150, 4, 1): D = 5) -- on the three fast single-query routes: the resident
+    server, the one-command call (sr_gp_call1) and the one-launch second order (K0 LIN, general form).  Against the oracle's
+    closed forms (gp_predict_k, gp_mean_jacobian_k, gp_linearize_extras_k), against the streamed multi-launch route of the
+    same library (set_small_path(0)), and route against route."""
+    from safe_exploration_amd import SimpleGPModel
+    rng = np.random.default_rng(500 + N + n_s)
+    D = n_s + n_u
+    Z = rng.uniform(-1, 1, (N, D))
+    Y = rng.standard_normal((N, n_s))
+    hyp = [orc.make_hyp(kt, rng, D) for _ in range(n_s)]
+    noise = np.full(n_s, 0.02)
+    kts = [kt] * n_s
+    beta, inv_K = orc.gp_fit_k(Z, Y, kts, hyp, noise + 1e-5)
+    gp = SimpleGPModel(n_s, n_s, n_u, kern_types=kts, hyp=[dict(h, noise_variance=nv) for h, nv in zip(hyp, noise)])
+    gp.train(Z, Y, opt_hyp=False)
+    X = rng.uniform(-0.7, 0.7, (6, D))
+    X[5] = Z[N // 2]                                            # a query ON a training point (Matern: r = 0)
+    scale = max(np.abs(beta).sum(0).max(), 1.0)
+
+    def against_oracle(x, out, second):
+        rmu, rvar = orc.gp_predict_k(x[None], Z, beta, inv_K, kts, hyp)
+        np.testing.assert_allclose(out[0][:, 0], rmu[0], rtol=1e-9, atol=1e-11 * scale)
+        np.testing.assert_allclose(out[1][:, 0], rvar[0], rtol=0, atol=1e-8 * max(1.0, float(rvar.max())))
+        np.testing.assert_allclose(out[2], orc.gp_mean_jacobian_k(x[None], Z, beta, kts, hyp)[0], rtol=1e-9, atol=1e-10 * scale)
+        if second:
+            rjv, rhm = orc.gp_linearize_extras_k(x, Z, beta, inv_K, kts, hyp)
+            np.testing.assert_allclose(out[3], rjv, rtol=1e-6, atol=1e-8 * max(1.0, np.abs(rjv).max()))
+            np.testing.assert_allclose(out[4], rhm, rtol=1e-8, atol=1e-10 * scale)
+            np.testing.assert_array_equal(out[4], np.swapaxes(out[4], 1, 2))
+
+    # 1. launched routes: one command (the default of a blocking call without a server) and the streamed reference route
+    io = gp._handle.single_io()
+    one_cmd = []
+    for x in X:
+        o1 = gp(x[None, :n_s], x[None, n_s:])
+        o2 = gp.linearize_predict(x[None, :n_s], x[None, n_s:], True)
+        against_oracle(x, o1, False)
+        against_oracle(x, o2, True)
+        one_cmd.append((o1, o2))
+    assert io["mailbox"], "the pinned blocks of this box are expected to be device-visible"
+    if gp._handle.Np < 512:
+        assert io["direct"], "sr_gp_call1 declined a %s model of %d padded rows" % (kt, gp._handle.Np)
+    gp.set_small_path(0)
+    ref = [(gp(x[None, :n_s], x[None, n_s:]), gp.linearize_predict(x[None, :n_s], x[None, n_s:], True)) for x in X]
+    gp.set_small_path(1)
+    io["direct"] = True
+    io.pop("direct_off", None)
+    for (o1, o2), (r1, r2) in zip(one_cmd, ref):
+        for a_, b_ in zip(o1 + o2, r1 + r2):
+            np.testing.assert_allclose(a_, b_, rtol=1e-7, atol=1e-9 * scale)
+    # 2. the same through sr_gp_linearize on device tensors (K0 LIN, general form, launched on the caller's stream)
+    from safe_exploration_amd import _buffers as B
+    mu_d, var_d, jm_d, jv_d, hm_d = gp.linearize_device(X[1])
+    for a_, b_ in zip((B.to_numpy(jm_d), B.to_numpy(jv_d), B.to_numpy(hm_d)), one_cmd[1][1][2:]):
+        np.testing.assert_allclose(a_, b_, rtol=1e-12, atol=1e-13 * scale)
+    # 3. the resident server
+    assert gp.start_server(idle_timeout_s=0.5) is True
+    for rnd in range(2):
+        for x, (o1, o2) in zip(X, one_cmd):
+            s1 = gp(x[None, :n_s], x[None, n_s:])
+            s2 = gp.linearize_predict(x[None, :n_s], x[None, n_s:], True)
+            against_oracle(x, s1, False)
+            against_oracle(x, s2, True)
+            for a_, b_ in zip(s1 + s2, o1 + o2):
+                np.testing.assert_allclose(a_, b_, rtol=1e-8, atol=1e-10 * scale)
+    armed, resident, launches, calls = gp.server_state()
+    assert armed and resident and launches == 1 and calls == 2 * 2 * len(X)
+    # an input transform of the reachability entry points neither takes the server off the device nor changes its answers
+    if n_u >= 1 and n_s >= 2:
+        from safe_exploration_amd._lib import lib, check
+        tz = B.as_dev(np.eye(n_s)[:n_s - 1], gp.device) if D - (n_s - 1) >= 1 and n_s - 1 >= 1 else None
+        if tz is not None and n_s - 1 < D:
+            check(lib.sr_gp_set_input_transform(gp._handle.h, B.ptr(tz), n_s - 1, B.stream_ptr(gp.device)))
+            s1 = gp(X[0][None, :n_s], X[0][None, n_s:])
+            check(lib.sr_gp_set_input_transform(gp._handle.h, None, 0, B.stream_ptr(gp.device)))
+            for a_, b_ in zip(s1, one_cmd[0][0]):
+                np.testing.assert_allclose(a_, b_, rtol=1e-8, atol=1e-10 * scale)
+            assert gp.server_state()[1] and gp.server_state()[2] == 1
+    gp.stop_server()
+
+
+def test_model_on_a_device_that_is_not_current():
+    """the NumPy routes synchronise the model's stream through its raw handle; handle 0 -- PyTorch's
+    default stream -- is the null stream of the CURRENT device, so the wait must run with the model's device current.
+    Needs two GPUs (skipped on the one-GPU box; the one-GPU part checks the handle carries its device)."""
+    import torch
+    from safe_exploration_amd import SimpleGPModel, _buffers as B
+    rs = B.current_stream(torch.device("cuda:0"))
+    assert rs.index == 0
+    rs.synchronize()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    syn = orc.make_synthetic(5, 1500, 2, 1, 300)
+    hyp = hyp_from(syn["lengthscale"], syn["signal_var"], syn["noise_var"])
+    g1 = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=hyp, device="cuda:1")
+    g1.train(syn["Z"], syn["Y"], opt_hyp=False)
+    g0 = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    assert torch.cuda.current_device() == 0
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    for _ in range(5):
+        m1, v1 = g1.predict(x)
+        m0, v0 = g0.predict(x)
+        np.testing.assert_allclose(m1, m0, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(v1, v0, rtol=0, atol=1e-12)
+
+
 def test_resident_server_idle_timeout_restart_and_model_updates():
     """The server leaves by itself after its idle time-out and comes back with the next query; a model update takes it off
     the device, and the next query is answered from the NEW model (row append inside the padded size, then a refit that
@@ -2106,16 +2218,19 @@ def test_resident_server_idle_timeout_restart_and_model_updates():
     mu, var = gp.predict(np.hstack((big["p"][:1], big["k_ff"][:1])))
     np.testing.assert_array_equal(o[0][:, 0], mu[0])
     assert gp.start_server() is False
-    # the journal experiments' kernels have no resident server either: declined, the launched routes answer
+    # the journal experiments' kernels have a resident server too (round 5; the refusal this test used to assert is gone)
     from safe_exploration_amd import SimpleGPModel
     rng = np.random.default_rng(3)
     hyp = [dict(orc.make_hyp("lin_mat52", rng, 3), noise_variance=nv) for nv in (0.02, 0.03)]
     gm = SimpleGPModel(2, 2, 1, kern_types=["lin_mat52"] * 2, hyp=hyp)
     gm.train(syn["Z"][:60], syn["Y"][:60], opt_hyp=False)
-    assert gm.start_server() is False and gm.server_state()[0] is False
+    mu, var = gm.predict(np.hstack((syn["p"][:2], syn["k_ff"][:2])))          # launched, two rows
+    assert gm.start_server() is True and gm.server_state()[0] is True
     o = gm(syn["p"][:1], syn["k_ff"][:1])
-    mu, var = gm.predict(np.hstack((syn["p"][:1], syn["k_ff"][:1])))
-    np.testing.assert_allclose(o[0][:, 0], mu[0], rtol=1e-12, atol=1e-14)
+    assert gm.server_state()[3] == 1
+    np.testing.assert_allclose(o[0][:, 0], mu[0], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(o[1][:, 0], var[0], rtol=0, atol=1e-11)
+    gm.stop_server()
 
 
 def test_resident_server_request_given_up_and_callers_on_two_threads():
