@@ -192,6 +192,48 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
             xs[j] *= il[j];
         }
         sr_d4 accA = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (LIN) {
+            // ONE query: the 16 lanes of a fragment row share the training row, so the row's k* is evaluated once -- lane r
+            // of the wavefront owns row r of its RPW rows (round 1) -- and handed to the fragment layout by a shuffle (round 2:
+            // each lane then needs one coordinate of its row, jc = ln - 1).  In the fragment layout every lane repeated the
+            // exp: KSA serial evaluations per wavefront, times the wavefronts of a SIMD.  Same arithmetic, same bits.
+            static_assert(RPW <= 64, "one lane per training row of the wavefront");
+            double k1, al1;
+            {
+                const int i1 = wave * RPW + (lane < RPW ? lane : RPW - 1);
+                const bool valid = i1 >= off;
+                double r2 = 0.0;
+                al1 = KEEP ? rows->r[i1][DT] : (valid ? a.alpha[(long)d * NP + i1] : 0.0);
+#pragma unroll
+                for (int j = 0; j < DT; ++j) {
+                    const double zs = KEEP ? rows->r[i1][j] : (((valid && j < a.D) ? a.Z[(long)(i1 - off) * a.D + j] : 0.0) * il[j]);
+                    const double df = xs[j] - zs;
+                    r2 = fma(df, df, r2);
+                }
+                k1 = valid ? sf2 * exp(-0.5 * r2) : 0.0;
+            }
+            const int jc = (ln >= 1 && ln <= DT) ? ln - 1 : -1;
+            double xc = 0.0, ilc = 0.0;
+#pragma unroll
+            for (int j = 0; j < DT; ++j)
+                if (jc == j) { xc = xs[j]; ilc = il[j]; }
+#pragma unroll
+            for (int st = 0; st < KSA; ++st) {
+                const int i = wave * RPW + 4 * st + lk;
+                double zc = 0.0;
+                if (jc >= 0) {
+                    if (KEEP) zc = rows->r[i][jc];
+                    else if (i >= off && jc < a.D) zc = a.Z[(long)(i - off) * a.D + jc] * ilc;
+                }
+                const double ki = __shfl(k1, 4 * st + lk), ali = __shfl(al1, 4 * st + lk);
+                const double df = xc - zc;
+                const double bfrag = (ln == 0) ? ali : ((jc >= 0) ? ali * zc : 0.0);
+                const double scale = (ln == 0) ? 1.0 : ((jc >= 0) ? -df * ilc : 0.0);      // (z_j - x_j) / l_j^2
+                const double k = ki * scale;                   // column c: k* (c = 0), dk*/dx_{c-1}, 0 beyond D
+                ks[i][ln] = k;
+                accA = __builtin_amdgcn_mfma_f64_16x16x4f64(k, bfrag, accA, 0, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int c0 = 0; c0 < KSA; c0 += HC) {
             double zv[HC][DT], al[HC];
@@ -385,27 +427,29 @@ __device__ __forceinline__ void sr_small_phase_a_gen(const sr_kstar_args& a, int
     double x[DT];
 #pragma unroll
     for (int j = 0; j < DT; ++j) x[j] = (j < a.D) ? (a.xv_on ? a.xv[j] : xsrc[j]) : 0.0;
-    sr_d4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1;
-#pragma unroll
-    for (int st = 0; st < KSA; ++st) {
-        const int i = wave * RPW + 4 * st + lk;
-        const bool valid = i >= off;
-        double al, z[DT];
+    static_assert(RPW <= 64, "one lane per training row of the wavefront");
+    // Round 1 -- lane r of the wavefront owns training row r of its RPW rows and evaluates the row's radial terms ONCE (in
+    // the fragment layout of round 2 the 16 lanes of a row would each repeat the exp and the square root: with eight
+    // wavefronts on four SIMDs that was 16 serial evaluations per SIMD, 4.8 of the 10.6 us of a 256-row model).
+    double k0, vk, pg, ph, vg, al1;
+    {
+        const int i1 = wave * RPW + (lane < RPW ? lane : RPW - 1);
+        const bool valid = i1 >= off;
+        double z[DT];
         if (KEEP) {
-            al = rows->r[i][DT];
+            al1 = rows->r[i1][DT];
 #pragma unroll
-            for (int j = 0; j < DT; ++j) z[j] = rows->r[i][j];
+            for (int j = 0; j < DT; ++j) z[j] = rows->r[i1][j];
         } else {
-            al = valid ? a.alpha[(long)d * NP + i] : 0.0;
+            al1 = valid ? a.alpha[(long)d * NP + i1] : 0.0;
 #pragma unroll
-            for (int j = 0; j < DT; ++j) z[j] = (valid && j < a.D) ? a.Z[(long)(i - off) * a.D + j] : 0.0;
+            for (int j = 0; j < DT; ++j) z[j] = (valid && j < a.D) ? a.Z[(long)(i1 - off) * a.D + j] : 0.0;
         }
-        double r2 = 0.0, la = 0.0, lb = 0.0, u[DT];
+        double r2 = 0.0, la = 0.0, lb = 0.0;
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
             const double df = x[j] - z[j];
-            u[j] = P.s2[j] * df;
-            r2 = fma(u[j], df, r2);
+            r2 = fma(P.s2[j] * df, df, r2);
             la = fma(P.a[j] * x[j], z[j], la);
             lb = fma(P.b[j] * x[j], z[j], lb);
         }
@@ -422,23 +466,40 @@ __device__ __forceinline__ void sr_small_phase_a_gen(const sr_kstar_args& a, int
             hh = (25.0 / 3.0) * e;
         }
         const double pre = (P.c0 + la) * P.v;
-        const double vk = P.v * kap, pg = pre * g, ph = pre * hh, vg = P.v * g;
-        // this lane's row m = ln of the two left operands, and its column n = ln of the right-hand side
-        double A1 = (ln == 0) ? fma(pre, kap, lb) : ((ln == 8) ? pg : 0.0), A2 = 0.0, bsel = (ln == 0) ? 1.0 : 0.0;
+        k0 = valid ? fma(pre, kap, lb) : 0.0;
+        vk = valid ? P.v * kap : 0.0;
+        pg = valid ? pre * g : 0.0;
+        ph = valid ? pre * hh : 0.0;
+        vg = valid ? P.v * g : 0.0;
+    }
+    // Round 2 -- fragment layout: this lane's row m = ln of the two left operands and its column n = ln of the right-hand
+    // side need ONE coordinate of the training row: jc = ln - 1 (rows 1 + j, column 1 + j) or ln - 9 (rows 9 + j)
+    const int jc = (ln >= 1 && ln <= a.D) ? ln - 1 : ((ln >= 9 && ln < 9 + a.D) ? ln - 9 : -1);
+    double xc = 0.0, s2c = 0.0, ac = 0.0, bc = 0.0;
 #pragma unroll
-        for (int j = 0; j < DT; ++j) {
-            if (ln == 1 + j) {
-                A1 = fma(vk, P.a[j] * z[j], fma(pg, u[j], P.b[j] * z[j]));
-                A2 = vg * u[j];
-                bsel = z[j] - x[j];
-            }
-            if (ln == 9 + j) A1 = ph * u[j];
+    for (int j = 0; j < DT; ++j)
+        if (jc == j) { xc = x[j]; s2c = P.s2[j]; ac = P.a[j]; bc = P.b[j]; }
+    const bool low = ln >= 1 && ln <= a.D;                // rows / column 1 + j
+    sr_d4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1;
+#pragma unroll
+    for (int st = 0; st < KSA; ++st) {
+        const int i = wave * RPW + 4 * st + lk;
+        const int src = 4 * st + lk;                      // the lane that holds row i's terms
+        double zc = 0.0;
+        if (jc >= 0) {
+            if (KEEP) zc = rows->r[i][jc];
+            else if (i >= off) zc = a.Z[(long)(i - off) * a.D + jc];
         }
-        if (!valid || ln > 9 + a.D - 1 || (ln > a.D && ln < 8)) { A1 = 0.0; }
-        if (!valid || ln > a.D) A2 = 0.0;
-        if (ln > a.D) bsel = 0.0;
+        const double k0s = __shfl(k0, src), vks = __shfl(vk, src), pgs = __shfl(pg, src), phs = __shfl(ph, src),
+                     vgs = __shfl(vg, src), als = __shfl(al1, src);
+        const double dfc = xc - zc, uc = s2c * dfc;
+        double A1, A2 = 0.0, bsel = 0.0;
+        if (ln == 0) { A1 = k0s; bsel = 1.0; }
+        else if (ln == 8) A1 = pgs;
+        else if (low) { A1 = fma(vks, ac * zc, fma(pgs, uc, bc * zc)); A2 = vgs * uc; bsel = -dfc; }
+        else A1 = phs * uc;                                // rows 9 + j; 0 elsewhere (jc < 0: uc = 0)
         ks[i][ln] = (ln <= a.D) ? A1 : 0.0;
-        const double bfrag = al * bsel;
+        const double bfrag = als * bsel;
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, bfrag, acc1, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, bfrag, acc2, 0, 0, 0);
     }
