@@ -297,8 +297,9 @@ int sr_publish(int device, const double* src_dev, int n, double* dst_host, unsig
                unsigned long long seq, void* stream);
 int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s);
 /* 1 where kernels of `device` may be handed the HOST address of this pinned block as it is (device-visible at the same
- * address), 0 otherwise: asked once by a host layer that lets the kernels read / write its pinned staging blocks directly
- * (tiny batches: no copy command in either direction; safe_exploration_amd/_buffers.py). */
+ * address, and the device's atomic adds -- the n_bad counters -- arrive in it: probed with one tiny launch that leaves
+ * the block as it found it), 0 otherwise: asked once by a host layer that lets the kernels read / write its pinned staging
+ * blocks directly (tiny batches: no copy command in either direction; safe_exploration_amd/_buffers.py). */
 int sr_host_block_is_device_visible(int device, const void* host_block);
 /* hipStreamSynchronize(stream) with `device` current, for a host layer that holds the raw stream handle (the handle 0 --
  * the null stream, PyTorch's default -- names the stream of whichever device is current: hence the device). */
@@ -327,9 +328,19 @@ int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, double* out_h
  * No launch, copy command or completion interrupt per query: one PCIe read to see the request, one posted write to
  * answer it.  The kernel leaves after idle_timeout_s without a request (a hipDeviceSynchronize elsewhere in the process
  * waits at most that long) and sr_gp_server_call launches it again; every entry point that writes the model, and every
- * persistent multi-step launch on the device, takes it off the device first (it stays armed).  ARD-RBF models of at most
- * 512 padded rows with D <= 5 and no input transform; SR_EUNSUPPORTED otherwise and from sr_gp_server_call when no
+ * persistent multi-step launch on the device, takes it off the device first (it stays armed).  Models of at most 512
+ * padded rows with D <= 5, every kernel identifier (ARD-RBF: one workgroup per output at 128 rows; mat52 / lin_rbf /
+ * lin_mat52 -- the general family of sr_gp_set_data_general -- in Np / 64 parts at every size); x_host is in the GP's
+ * input space, as for sr_gp_predict (an input transform set with sr_gp_set_input_transform concerns the reachability
+ * entry points only and leaves the server resident).  SR_EUNSUPPORTED otherwise and from sr_gp_server_call when no
  * server is armed: use sr_gp_call1 / sr_gp_predict / sr_gp_linearize.
+ * Host memory model: the request is ONE 64-byte mailbox line [x0 .. x4 | (epoch << 8) | command | sequence number | check
+ * word]; the host writes payload, check word and sequence number (last) with ordinary stores separated by release
+ * fences and spins on the reply words with volatile loads + an acquire fence.  The device takes a request only when the
+ * eight words of its fetch xor to the check constant, so neither the atomicity of the 64-byte PCIe read nor the host's
+ * store order is relied upon for CORRECTNESS: a half-written line is fetched again.  On x86-64 (TSO) the fences cost
+ * nothing and a request is seen with the first fetch after its sequence number; a weaker host memory model only adds
+ * re-fetches.  The spin loops use the pause hint on x86 and std::this_thread::yield elsewhere.
  * Calls on one handle are serialised inside the library (one mailbox), so two host threads may evaluate the same model
  * with buffers of their own; the model itself must not be written meanwhile, as everywhere.  A request that is not
  * answered within timeout_s is given up with SR_ESTATE: its sequence number is retired and the launch called off, the

@@ -485,6 +485,11 @@ extern "C" int sr_stream_synchronize(int device, void* stream) {
 
 // 1 where kernels of `device` may be handed the HOST address of this pinned block as it is (the device sees the block at the
 // same address), 0 otherwise -- what a host layer asks once before it lets kernels read / write its pinned staging blocks.
+// (and where the device's ATOMIC adds reach the block: the kernels count violated bounds with atomicAdd on a word of the
+//  result block, and over a link without PCIe AtomicOps such an add can be dropped silently -- probed once per block with 64
+//  adds on its first word, which is restored)
+__global__ void sr_probe_atomic_kernel(int* w) { atomicAdd(w, 1); }
+
 extern "C" int sr_host_block_is_device_visible(int device, const void* host_block) {
     if (!host_block) return 0;
     sr_dev_guard guard(device);
@@ -493,7 +498,23 @@ extern "C" int sr_host_block_is_device_visible(int device, const void* host_bloc
         (void)hipGetLastError();
         return 0;
     }
-    return dp == host_block ? 1 : 0;
+    if (dp != host_block) return 0;
+    volatile int* w = reinterpret_cast<volatile int*>(const_cast<void*>(host_block));
+    const int saved = *w;
+    *w = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    hipStream_t ps = nullptr;
+    bool ok = hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(sr_probe_atomic_kernel, dim3(1), dim3(64), 0, ps, reinterpret_cast<int*>(dp));
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ps) == hipSuccess;
+        (void)hipStreamDestroy(ps);
+    }
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    ok = ok && *w == 64;
+    *w = saved;
+    if (!ok) (void)hipGetLastError();
+    return ok ? 1 : 0;
 }
 
 extern "C" int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s) {

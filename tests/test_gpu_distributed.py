@@ -207,3 +207,19 @@ def test_bench_eight_ranks_under_torchrun_default_workload(lib_built, tmp_path):
     assert line["config"]["queries_per_gpu_per_step"] == 65536 and "world=8" in line["config"]["parallelism"]
     assert abs(line["value"] - 8 * 65536 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     assert sorted(os.listdir(str(tmp_path))) == ["shard_rank%d.npz" % r for r in range(8)]
+
+
+def test_bench_dry_run_of_the_rccl_process_group_with_one_rank(lib_built):
+    """the first RCCL call must not happen on the multi-GPU lease.  ``bench.py --dry-nccl`` on one GPU
+    creates the nccl (= RCCL) process group with a single rank, sends the model through parallel.replicate_model to itself
+    (object broadcast, tensor broadcasts, the packed upper triangle in 64 MB pieces through the two staging buffers, async
+    works) and times a 64 MB broadcast: librccl is loaded, a communicator is built and bytes move through it."""
+    line = _run_bench(["--dry-nccl", "--workload", "c2", "--queries", "8192", "--steps", "1", "--warmup", "1",
+                       "--no-cpu-baseline"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    d = line["config"]["dry_nccl"]
+    assert d["backend"] == "nccl" and d["world"] == 1
+    N, n_out = 2000, 2
+    assert d["replication_bytes"] == (n_out * N * (N + 1) // 2 + N * 3 + N * n_out + n_out * N) * 8
+    assert d["pieces"] >= 2 and d["broadcast_64MB_ms"] > 0
+    assert "nccl" in line["config"]["parallelism"]
+    assert np.isfinite(line["value"]) and line["value"] > 0

@@ -422,6 +422,67 @@ def test_config3_at_the_rollout_count_the_bench_times():
     np.testing.assert_allclose(q_all[ti].cpu().numpy(), rq, rtol=1e-6, atol=1e-13)
 
 
+def test_config3_with_the_parameters_the_survey_wrote():
+    """BASELINE configs[2] with SURVEY 8(d)'s parameters for row C3 AS WRITTEN: sigma_f^2 = 1, prior a = I (the shipped `c3`
+    workload uses sigma_f^2 = 0.01, a = 0.5 I).  With them the chain is not computable in fp64, by the
+    reference either: far from the data the remainder box grows as l_mu r^2 with r^2 = lambda_max(Q (I + K^T K)), so
+    Q_{k+1} ~ n_s l_mu^2 |Q_k|^2 = 0.01 |Q_k|^2 -- doubly exponential once |Q| > 100 (trace 0.13, 1.3, 7, 50, 480, 1e4, 1e6,
+    6e9, 1e17, 3e31, 2e60, 1e118, 3e233, inf).  Pinned here at the full size (65536 rollouts x 15 steps, N = 5000):
+      * every rollout is finite through step 10 and holds its first inf / NaN at step 11, 12, 13 or 14;
+      * three rollouts agree with the oracle chain on every step the oracle can compute, and the oracle -- like the
+        reference, whose scipy.linalg.eig refuses non-finite input (utils.py:108-144) -- raises ValueError at the step after
+        the first inf, the step this build reports;
+      * with check_bounds=True the batched entry point raises (the reference's assert u_b > 0, utils_ellipsoid.py:227)."""
+    import torch
+    from safe_exploration_amd import gp_reachability as reach, workload
+    N, T, H, n_s, n_u = 5000, 65536, 15, 4, 1
+    syn = orc.make_synthetic(3, N, n_s, n_u, 8, sf2=1.0)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
+    roll = workload.random_rollout_controls(34, T, H, n_s, n_u)
+    dev = gp.device
+    tp0, tkff, tkfb = (torch.from_numpy(roll[k]).to(dev) for k in ("p0", "k_ff", "k_fb"))
+    l = np.full(n_s, 0.05)
+    a, b = np.eye(n_s), np.zeros((n_s, n_u))
+    p_all, q_all = reach.multistep_reachability_batch(tp0, gp, tkfb, tkff, l, l, None, 2.0, a, b)
+    fin = torch.isfinite(q_all).reshape(T, H, -1).all(-1) & torch.isfinite(p_all).all(-1)
+    assert bool(fin[:, :11].all()), "a rollout left fp64 before step 11"
+    first = torch.where(fin.all(1), torch.full((T,), H, device=dev), (~fin).int().argmax(1))
+    counts = {int(k): int((first == k).sum()) for k in torch.unique(first)}
+    print("first non-finite step -> rollouts:", counts)
+    assert int(first.min()) >= 11 and int(first.max()) <= 14, counts
+    assert not bool(fin[:, H - 1].any()), "a rollout survived the horizon"
+    # once gone, gone: no step after the first non-finite one is finite again
+    assert bool((fin.int().diff(dim=1) <= 0).all())
+    # growth as derived: the trace at step 9 is beyond 1e12 for every rollout (7.6e16 ... 1e65 on this data) and at least
+    # squares from there on while it is finite
+    tr = q_all.diagonal(dim1=-2, dim2=-1).sum(-1)
+    assert float(tr[:, 9].min()) > 1e12
+    ok10 = fin[:, 10]
+    assert bool((tr[ok10, 10] > 1e-3 * tr[ok10, 9] ** 2).all())
+    om = cached_oracle_model(3, N, n_s, n_u, sf2=1.0)
+    pick = [0, 31337, T - 1]
+    for r in pick:
+        p, q = roll["p0"][r:r + 1], None
+        raised = None
+        with np.errstate(all="ignore"):
+            for i in range(H):
+                try:
+                    p, q, _ = orc.onestep_reachability_batch(om, p, q, roll["k_ff"][r:r + 1, i],
+                                                             None if i == 0 else roll["k_fb"][r:r + 1, i - 1], l, l, 2.0, a, b)
+                except ValueError:
+                    raised = i
+                    break
+                if np.all(np.isfinite(q)):
+                    # (the relative error doubles per step as the magnitudes square: 1e-13 2^13 and the conditioning)
+                    np.testing.assert_allclose(p_all[r, i].cpu().numpy(), p[0], rtol=1e-7, atol=1e-9)
+                    np.testing.assert_allclose(q_all[r, i].cpu().numpy(), q[0].real, rtol=1e-5, atol=0)
+                else:
+                    assert int(first[r]) == i, (int(first[r]), i)
+        assert raised is not None and raised == int(first[r]) + 1, (raised, int(first[r]))
+    with pytest.raises(AssertionError):
+        reach.multistep_reachability_batch(tp0[:256], gp, tkfb[:256], tkff[:256], l, l, None, 2.0, a, b, check_bounds=True)
+
+
 @pytest.mark.parametrize("adds", [[1], [16], [50], [128], [1, 16, 50, 128, 3]])
 def test_row_append_at_the_headline_model_size(adds):
     """update_model(replace_old=False) at N = 5000 (where DESIGN quotes 0.40 / 0.73 / 1.2 / 2.25 ms): + 1, + 16, + 50, + 128
