@@ -231,24 +231,6 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, (int)Tc, s));
         nrb = (h->Np + 255) / 256;
-    } else if (h->small_path && h->few_route == 3 && sr_var_splitk_wanted(h->Np, Tp, h->n_out) &&
-               sr_var_xcd_wanted(h->N, h->Np, Tp, h->n_out)) {
-        // OPTIONAL route (sr_gp_set_small_path(h, 1 + 16)), not the default: k slabs per XCD (K* from the L2: 21 % less
-        // fabric traffic than the balanced shares below at N = 5000, T = 128) -- at the same or slightly more time, because
-        // this regime is bound by its compute side (sr_var_xcd.hip, profiles/r04_xcd_ablation.txt)
-        const long need = sr_var_xcd_ws(h->Np, Tp, h->n_out);
-        if (need > h->splitk_cap) {
-            (void)hipStreamSynchronize(s);
-            dev_free(h->splitk_vt);
-            h->splitk_vt = nullptr; h->splitk_cap = 0;
-            SR_TRY(dev_alloc(&h->splitk_vt, (size_t)need));
-            h->splitk_cap = need;
-        }
-        if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));
-        var_part = h->splitk_part;
-        nrb = 4 * (h->Np / SR_NB);
-        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var_xcd(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else if (h->small_path && h->few_route != 1 && sr_var_splitk_wanted(h->Np, Tp, h->n_out) && sr_var_bal_wanted(h->Np, Tp, h->n_out)) {
         // few query tiles: equal shares of the k-blocks of all tiles, the segments of a tile added by a second launch
         const long need = sr_var_bal_ws(h->Np, Tp, h->n_out);

@@ -264,11 +264,6 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
 int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                     hipStream_t s);
 
-// XCD-partitioned form of the same regime (sr_var_xcd.hip, K2x): k slabs per XCD, one workgroup per CU, four LDS stages
-bool sr_var_xcd_wanted(int N, int Np, long Tp, int n_out);
-long sr_var_xcd_ws(int Np, long Tp, int n_out);
-int sr_launch_var_xcd(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
-                      hipStream_t s);
 // split-K form of the variance kernel for few query tiles (sr_predict.hip, K2k)
 // balanced form of the same regime (equal shares of the k-blocks + a reduce pass, K2b): workspace doubles; part layout of K2k
 long sr_var_bal_ws(int Np, long Tp, int n_out);
@@ -306,7 +301,8 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //                                            N = 2000 71 -> 40 us, from N = 3000 on the tiles win (r01d_latency_grid)
 //   K2b balanced shares (sr_predict.hip)     sr_var_splitk_wanted (nb > 2, <= 1024 plain workgroups) and >= 256 cells
 //                                            (sr_var_bal_wanted); 256 workgroups, 512 from 2304 cells on (r03_splitk_ab, r03_streamk)
-//   K2x XCD slabs (sr_var_xcd.hip)           OPTIONAL (sr_gp_set_small_path + 16): -21 % fabric bytes, time as K2b (r04_xcd_ablation)
+//   (K2x, k slabs per XCD: built in round 4, -21 % fabric bytes at the same time -- the regime is compute-side bound,
+//    profiles/r04_xcd_ablation.txt -- and removed in round 5)
 //   K2k split-K chunks                       the rest of sr_var_splitk_wanted; chunk size by splitk_kcb (<= 768 workgroups)
 //   K2m 64 x 64 tiles                        sr_var64_wanted: Np <= 1024 and < 256 plain workgroups (N = 200: 60 -> 31-37 us, r01d)
 //   K2  plain 128 x 128 tiles                everything else (the benchmark regime: 0.89-0.90 of the fp64 MFMA peak, r03_kernel_stats)
@@ -342,7 +338,6 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 #define SR_FACT_CHAIN_MAX_NB 128     /* model update: up to here the chain of diagonal blocks bounds it (stream regime 1) */
 #define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch up to this padded size (the grown model: <= 640) */
 #define SR_STREAM_FUSED32_MAX_NCB 8   // 32 columns per workgroup are evaluated inside the MFMA kernel up to this many 256-column blocks (Np <= 2048)
-#define SR_VAR_XCD_MIN_CELLS 512     /* (row block, k-block, query tile, output) cells from which the optional K2x applies */
 
 static inline bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
     (void)general;   // ARD-RBF and the general family both have a one-launch kernel

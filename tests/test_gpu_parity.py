@@ -558,36 +558,6 @@ def test_splitk_path_matches_plain_path(N, T):
     np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("N,T,n_s,n_u", [(2500, 128, 2, 1), (1700, 100, 3, 1), (1300, 256, 4, 1), (3000, 512, 1, 2),
-                                         (2049, 1024, 2, 1), (5000, 128, 2, 1), (1153, 200, 4, 2), (2600, 120, 3, 2)])
-def test_xcd_slab_path_matches_plain_path(N, T, n_s, n_u):
-    """K2x (sr_var_xcd.hip, the optional route set_small_path(1 + 16)): one, two, four or eight query tiles on a model of
-    thousands of points -- the k range cut into
-    eight slabs of equal area over (output, k), shares of a slab's segments per group of workgroups, partial products in
-    geometry-derived slots, added in ascending k order.  Cases: slabs inside one output (n_out = 1: eight per output), slabs
-    that end one output and start the next (n_out = 3), one slab per output pair, front padding of 0 .. 127 rows, a k range
-    of the first block that starts mid-block.  Against the plain tiles (to the last bits of the summation order), against
-    the balanced shares, call after call, and against the oracle."""
-    syn = orc.make_synthetic(N + T + n_s, N, n_s, n_u, T)
-    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, n_u)
-    x = np.hstack((syn["p"], syn["k_ff"]))
-    gp.set_small_path(17)                                      # the optional route: XCD slabs
-    mu_s, var_s = gp.predict(x)
-    for _ in range(3):
-        mu_r, var_r = gp.predict(x)
-        np.testing.assert_array_equal(var_r, var_s)
-    gp.set_small_path(True)                                    # default: balanced shares
-    mu_b, var_b = gp.predict(x)
-    gp.set_small_path(False)
-    mu_m, var_m = gp.predict(x)
-    np.testing.assert_array_equal(mu_s, mu_m)
-    np.testing.assert_allclose(var_s, var_m, rtol=0, atol=1e-12)
-    np.testing.assert_allclose(var_b, var_m, rtol=0, atol=1e-12)
-    om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
-    _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
-    np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
-
-
 def _kern_hyp(g, kt, n_out=2):
     hyp = []
     for d in range(n_out):
