@@ -247,6 +247,156 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
 #undef SRT_DMA
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the same contract with the k-tile boundary crossed UNDER the MFMA stream (scripts/mfma_pipe_tile.hip,
+// profiles/r05_mfma_pipe_tile.txt: 69.7 TF for the skeleton of mainloop_tn_glds, 77.8 TF for this one on the same box).
+// What the old loop lost: after its barrier at the top of a k-tile a wavefront issued its DMA burst, then its first
+// fragment reads, waited for them, and only then its first MFMA; and hipcc's s_waitcnt pass, which stops counting LDS
+// reads in order once a global_load_lds builtin is in the loop, waited lgkmcnt(0) before EVERY block of 16 MFMAs, i.e. for
+// reads it had just issued.  While a wavefront sits in such a gap the other wavefront of its SIMD runs alone, and a lone
+// wavefront reaches 74 % of the fp64 matrix pipe whatever it does (57 TF with one workgroup per CU, with or without
+// double-buffered fragments).  Here:
+//   * fragments are double-buffered in registers: the reads of k-step kk + 1 are issued before the MFMAs of kk;
+//   * the barrier of a tile sits in front of its LAST block of 16 MFMAs: by then the wavefront has issued (and waited
+//     for) all its reads of this stage, so behind the barrier it issues the first reads of the NEXT tile and the DMA of the
+//     tile after that into the stage just freed -- under 16 MFMAs that are already its own;
+//   * the eight DMA instructions are spread over those MFMAs (one per two), SGPR base + one loop-invariant VGPR offset,
+//     through inline asm so that the compiler's waitcnt pass keeps counting (lgkmcnt(4) / (6) instead of (0));
+//   * two k-tiles per trip, so the stage is a compile-time constant: LDS offsets are immediates, no VALU between MFMAs.
+// One barrier per k-tile and two LDS stages, as before.  Same order of accumulation: identical results bit for bit.
+// ------------------------------------------------------------------------------------------------------------------
+struct Frag { double a[4], b[4]; };
+
+// one LDS-DMA instruction: 1 KiB tile row from gbase (SGPR pair) + voff (bytes, per lane) to LDS byte address lds0 + IMM
+// (M0 is a reserved register: the compiler loads it in front of each of its own uses and keeps nothing in it)
+#define SRT_DMA1(lds0_, IMM_, voff_, gbase_)                                                        \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                    \
+                 :: "s"((lds0_) + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory")
+
+template <bool DIAG = false>
+__device__ __forceinline__ void mainloop_tn_pipe(const double* __restrict__ A, long lda,
+                                                 const double* __restrict__ B, long ldb,
+                                                 int k_beg, int k_end, double* smem, Acc& acc) {
+    constexpr int STG = BK * LDT;              // doubles per operand per stage; layout [A st0 | A st1 | B st0 | B st1]
+    if (k_beg >= k_end) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const double* As = smem;
+    const double* Bs = smem + 2 * STG;
+    const int fa = (lane >> 4) * LDT + (DIAG ? wm * 16 : wm * 64) + (lane & 15);
+    constexpr int FAS = DIAG ? 32 : 16;        // distance of consecutive row tiles of one wavefront (interleaved with DIAG)
+    const int fb = (lane >> 4) * LDT + wn * 64 + (lane & 15);
+    // DMA: wavefront w moves rows w, w + 4, w + 8, w + 12 of both operand tiles
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned lds0 = (unsigned)(size_t)(smem + wave * LDT);
+    const double* ga = A + (long)(k_beg + wave) * lda;       // row `wave` of the current DMA tile (uniform)
+    const double* gb = B + (long)(k_beg + wave) * ldb;
+    const long sa4 = 4 * lda, sb4 = 4 * ldb;
+
+#define SRT_RD(F, st, kk)                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                              \
+        (F).a[i_] = As[(st) * STG + (kk) * 4 * LDT + i_ * FAS + fa];                                \
+        (F).b[i_] = Bs[(st) * STG + (kk) * 4 * LDT + i_ * 16 + fb];                                 \
+    }
+    // MI0: first live row tile (DIAG: row tiles below it hold structural zeros in this k-tile)
+#define SRT_MF(F, MI0)                                                                              \
+    _Pragma("unroll") for (int i_ = (MI0); i_ < 4; ++i_)                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                            \
+            acc.v[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64((F).a[i_], (F).b[j_], acc.v[i_][j_], 0, 0, 0);
+#define SRT_SB __builtin_amdgcn_sched_barrier(0)
+    // the whole DMA of the tile at (ga, gb) into stage st, as a burst (prologue only)
+#define SRT_DMA_TILE(st)                                                                            \
+    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                              \
+        SRT_DMA1(lds0, ((st) * STG + 4 * r_ * LDT) * 8, voff, ga + r_ * sa4);                       \
+        SRT_DMA1(lds0, ((2 + (st)) * STG + 4 * r_ * LDT) * 8, voff, gb + r_ * sb4);                 \
+    }
+    // last MFMA block of a tile (fragments F, rows >= MI0); with `dma` (wavefront-uniform) the DMA of the tile at (ga, gb)
+    // into stage st is spread over it -- the branches go around the asm statements only, the MFMAs are unconditional
+#define SRT_MF_DMA(F, MI0, st, dma)                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                              \
+        if (i_ >= (MI0)) {                                                                          \
+            acc.v[i_][0] = __builtin_amdgcn_mfma_f64_16x16x4f64((F).a[i_], (F).b[0], acc.v[i_][0], 0, 0, 0); \
+            acc.v[i_][1] = __builtin_amdgcn_mfma_f64_16x16x4f64((F).a[i_], (F).b[1], acc.v[i_][1], 0, 0, 0); \
+        }                                                                                           \
+        SRT_SB;                                                                                     \
+        if (dma) SRT_DMA1(lds0, ((st) * STG + 4 * i_ * LDT) * 8, voff, ga + i_ * sa4);              \
+        SRT_SB;                                                                                     \
+        if (i_ >= (MI0)) {                                                                          \
+            acc.v[i_][2] = __builtin_amdgcn_mfma_f64_16x16x4f64((F).a[i_], (F).b[2], acc.v[i_][2], 0, 0, 0); \
+            acc.v[i_][3] = __builtin_amdgcn_mfma_f64_16x16x4f64((F).a[i_], (F).b[3], acc.v[i_][3], 0, 0, 0); \
+        }                                                                                           \
+        SRT_SB;                                                                                     \
+        if (dma) SRT_DMA1(lds0, ((2 + (st)) * STG + 4 * i_ * LDT) * 8, voff, gb + i_ * sb4);        \
+        SRT_SB;                                                                                     \
+    }
+    // A tile on stage st with the fragments of its k-step 0 already in F0; leaves the next tile's k-step 0 in F0 (read in any
+    // case: without a next tile it is a harmless read of the other stage).  next: another tile follows (barrier); dma: and
+    // one after that, whose DMA goes into this stage.  Both wavefront-uniform.
+#define SRT_TILE(st, MI0, next, dma)                                                                \
+    do {                                                                                            \
+        SRT_RD(F1, st, 1); SRT_SB; SRT_MF(F0, MI0); SRT_SB;                                         \
+        SRT_RD(F0, st, 2); SRT_SB; SRT_MF(F1, MI0); SRT_SB;                                         \
+        SRT_RD(F1, st, 3); SRT_SB; SRT_MF(F0, MI0); SRT_SB;                                         \
+        if (next) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
+        SRT_RD(F0, (st) ^ 1, 0); SRT_SB;                                                            \
+        if (dma) { ga += 16 * lda; gb += 16 * ldb; }                                                \
+        SRT_MF_DMA(F1, MI0, st, dma);                                                               \
+    } while (0)
+
+    Frag F0, F1;
+    const int nt = (k_end - k_beg) / BK;
+    const bool diag = DIAG && nt >= 8;         // the masked walk needs the whole diagonal block inside the range
+    // Tiles go in PAIRS (stage 0, stage 1); an odd count starts with one tile on stage 1.  A pair at tile t: its first tile
+    // always has a successor; `more` = the pair has a successor pair = everything else it needs to know.
+    const int s0 = nt & 1;
+    // prologue: the DMAs of tiles 0 and 1 (both stages are free), wait for tile 0 only
+    if (s0) { SRT_DMA_TILE(1); } else { SRT_DMA_TILE(0); }
+    if (nt > 1) {
+        ga += 16 * lda; gb += 16 * ldb;
+        if (s0) { SRT_DMA_TILE(0); } else { SRT_DMA_TILE(1); }
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // (ga, gb) point at the LAST tile whose DMA was issued; SRT_TILE advances them before it issues the next
+    int t = 0;
+    if (s0) {
+        SRT_RD(F0, 1, 0);
+        const bool nx = nt > 1, dm = nt > 2;
+        SRT_TILE(1, 0, nx, dm);
+        t = 1;
+    } else {
+        SRT_RD(F0, 0, 0);
+    }
+    const int t_gen = diag ? nt - 8 : nt;      // pairs before the diagonal block (nt - 8 - s0 is even)
+    for (; t < t_gen; t += 2) {
+        const bool more = t + 2 < nt;
+        SRT_TILE(0, 0, true, more);
+        SRT_TILE(1, 0, more, more);
+    }
+    if (diag) {
+        // k-tile kt of the diagonal block: row tile it = 2 mi + wm carries numbers iff it >= kt; both wavefront rows use the
+        // live set mi >= kt / 2 (exact for wm = 1, one block of zeros too many per odd kt for wm = 0)
+        SRT_TILE(0, 0, true, true);
+        SRT_TILE(1, 0, true, true);
+        SRT_TILE(0, 1, true, true);
+        SRT_TILE(1, 1, true, true);
+        SRT_TILE(0, 2, true, true);
+        SRT_TILE(1, 2, true, true);
+        SRT_TILE(0, 3, true, false);
+        SRT_TILE(1, 3, false, false);
+    }
+    __syncthreads();                           // callers reuse smem after the main loop
+#undef SRT_RD
+#undef SRT_MF
+#undef SRT_SB
+#undef SRT_DMA_TILE
+#undef SRT_MF_DMA
+#undef SRT_TILE
+}
+
 // Round 3, measured and NOT kept (scripts/mfma_lds_tile.hip, profiles/r03_mfma_lds_tile.txt): where the 9 % between this
 // loop (70.5 TF inside sr_var_kernel) and the matrix pipe (77.5 TF) go.  An LDS-fed loop of the same fragment reads and
 // MFMAs runs at 77.0 - 77.7 TF for EVERY wavefront tile from 32 x 32 to 96 x 64 at two wavefronts per SIMD: the LDS -> VGPR

@@ -281,7 +281,10 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
     acc.zero();
     // VARIANT 2: as 1, with the structural zeros of the diagonal block left out (row tiles interleaved over the two
     // wavefront rows; the epilogue below sums over all rows of the block, so the row assignment does not show).
-    if (VARIANT == 2) srt::mainloop_tn_glds<16, true>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+    // VARIANT 3 / 4: the pipelined loop of round 5 (barrier under the MFMA stream), without / with the diagonal-block walk
+    if (VARIANT == 4) srt::mainloop_tn_pipe<true>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+    else if (VARIANT == 3) srt::mainloop_tn_pipe<false>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+    else if (VARIANT == 2) srt::mainloop_tn_glds<16, true>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
     else if (VARIANT == 1) srt::mainloop_tn_glds<16>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
     else srt::mainloop_tn(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
 
@@ -323,7 +326,13 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
     const int ngrp = (ntq + group - 1) / group;
     const long blocks = (long)n_out * ngrp * nrb * group;
     SR_CHECK(blocks < 2147483647L, SR_EINVAL, "var: grid too large (%ld blocks)", blocks);
-    if (variant == 2)
+    if (variant == 4)
+        hipLaunchKernelGGL(sr_var_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
+                           nrb, ntq, group, k_beg);
+    else if (variant == 3)
+        hipLaunchKernelGGL(sr_var_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
+                           nrb, ntq, group, k_beg);
+    else if (variant == 2)
         hipLaunchKernelGGL(sr_var_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
                            nrb, ntq, group, k_beg);
     else if (variant == 1)
