@@ -14,7 +14,8 @@ struct sr_tile128 {
         // LDS-DMA staging (+5 % over register staging).  (Four stages of 8 k-rows in the same LDS -- three k-tiles in
         // flight, hand-placed vmcnt -- measured the same: 42.9 TF at K = 256, 51.4 at K = 1024, C4 63.2 against 64.2.
         // What these products lose, they lose to the tail of the grid, not to the pipeline of a tile.)
-        srt::mainloop_tn_glds<16>(A, lda, B, ldb, k0, k1, smem, acc);
+        // Round 5: the pipelined loop (barrier under the MFMA stream; sr_mfma_tile.h).
+        srt::mainloop_tn_pipe<false>(A, lda, B, ldb, k0, k1, smem, acc);
     }
     static __device__ __forceinline__ int row(int wm, int mi, int lane, int r) { return srt::acc_row(wm, mi, lane, r); }
     static __device__ __forceinline__ int col(int wn, int ni, int lane) { return srt::acc_col(wn, ni, lane); }

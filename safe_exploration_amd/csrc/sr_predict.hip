@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void sr_var_splitk_kernel(const double* __r
     const double* B = Ks + (long)d * Np * Tp + (long)x * srt::BN;
     srt::Acc acc;
     acc.zero();
-    srt::mainloop_tn_glds<16>(A, Np, B, Tp, k0, k1, smem, acc);
+    srt::mainloop_tn_pipe<false>(A, Np, B, Tp, k0, k1, smem, acc);
     double* out = Vt + ((((long)d * nrb + rb) * ntq + x) * maxch + ch) * (srt::BM * srt::BN);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void sr_var_bal_kernel(const double* __rest
         const double* B = Ks + (long)d * Np * Tp + (long)x * srt::BN;
         srt::Acc acc;
         acc.zero();
-        srt::mainloop_tn_glds<16>(A, Np, B, Tp, k0, k1, smem, acc);
+        srt::mainloop_tn_pipe<false>(A, Np, B, Tp, k0, k1, smem, acc);
         if (len != n) {
             // slot of a segment: its workgroup's slot 1 if the tile starts in that workgroup's share, else 0
             // (16-byte stores: the 128 KB of a partial product are store-issue bound -- half the instructions of the
