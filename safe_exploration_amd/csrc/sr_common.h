@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstring>
 #include <vector>
@@ -371,11 +372,18 @@ static inline bool sr_var_bal_wanted(int Np, long Tp, int n_out) {
     const long nrb = Np / SR_NB;
     return (long)n_out * (Tp / SR_NB) * nrb * (nrb + 1) / 2 >= 256;
 }
-// workgroups of the balanced launch: one per CU, two once there are nine cells for each of them (measured, G = 256 against
-// 512, n_out = 2: N = 4000 T = 128 (U = 1056) 120 / 137 us, N = 5000 T = 128 (1640) 158 / 161, T = 256 (3280) 257 / 263, N = 4500
-// T = 256 (2664) 222 / 216, N = 3000 T = 512 (2400) 204 / 198, N = 5000 T = 512 (6560) 476 / 451; 384 or 768 workgroups --
-// shares that do not line up with the residency of the chip -- lose 15 - 25 %)
-static inline long sr_var_bal_wgs(long U) { return U >= 2304 ? 512 : (U >= 256 ? 256 : U); }
+// workgroups of the balanced launch: one per CU, two from 8192 cells on.  Round 5, with the pipelined main loop (G = 256
+// against 512, n_out = 2, profiles/r05_bal_ab.txt): N = 5000 T = 128 (U = 1640) 142 / 148 us, T = 256 (3280) 235 / 250, T = 512
+// (6560) 426 / 425, T = 1024 (13120) 801 / 795; N = 4000 T = 512 (4224) 291 / 306, T = 1024 (8448) 525 / 535; N = 3000 T = 1024
+// 321 / 329 -- the threshold of round 3 (2304 cells, old loop) sent T = 256 at N = 5000 to 512 workgroups; 384, 768 or
+// 1024 workgroups -- shares that do not line up with the residency of the chip -- lose 15 - 30 %.  Half of a 512-way launch's
+// time goes to twice the partial products (128 KB each, written and read again by the reduce pass).
+static inline long sr_var_bal_wgs(long U) {
+    static const long forced = getenv("SR_BAL_WGS") ? atol(getenv("SR_BAL_WGS")) : 0;     // (measurements)
+    static const long thr = getenv("SR_BAL_THR") ? atol(getenv("SR_BAL_THR")) : 8192;
+    if (forced > 0) return U < forced ? U : forced;
+    return U >= thr ? 512 : (U >= 256 ? 256 : U);
+}
 // The MFMA streaming kernel also serves 17 .. 1024 queries as groups of 16 (every group re-reads U^-1 from
 // L2 / Infinity Cache) as long as that stays cheap: n_out Np^2/2 8 B x groups <= 300 MB.  Measured at N = 700,
 // T = 128: 41 -> 25 us against the split-K tiles; N = 2000: 71 -> 40 us; from N = 3000 on the tiles win.
