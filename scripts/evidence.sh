@@ -4,7 +4,7 @@
 # trace + PMC passes of the headline bench, kernel trace of the C4 model update).  Copy to profiles/ with
 #   python scripts/summarize_rocpd.py gpurun_out/prof_<tag> profiles/<tag> c2p   and   cp gpurun_out/ev_<tag>/* profiles/
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$(pwd)
 EV=$REPO/gpurun_out/ev_$TAG
 mkdir -p "$EV"
@@ -27,9 +27,23 @@ timeout 600 python scripts/fuzz_predict.py > "$EV/${TAG}_fuzz_predict.txt" 2>>"$
 timeout 600 python scripts/fuzz_server.py > "$EV/${TAG}_fuzz_server.txt" 2>>"$EV/.err"
 timeout 300 python scripts/diag_bench.py > "$EV/${TAG}_diag_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/call_latency.py > "$EV/${TAG}_call_latency.txt" 2>>"$EV/.err"
+# the journal experiments' kernels (defaultconfig_episode.py:39) on the same blocking single-query routes
+for K in lin_mat52 mat52 lin_rbf; do
+  timeout 300 python scripts/call_latency.py --kern $K >> "$EV/${TAG}_call_latency.txt" 2>>"$EV/.err"
+done
+timeout 200 python scripts/server_ticks.py > "$EV/${TAG}_server_ticks.txt" 2>>"$EV/.err"
 timeout 300 python scripts/linearize_bench.py > "$EV/${TAG}_linearize_bench.txt" 2>>"$EV/.err"
+timeout 300 python scripts/linearize_bench.py --kern lin_mat52 >> "$EV/${TAG}_linearize_bench.txt" 2>>"$EV/.err"
+timeout 300 python scripts/exploration_step.py --kern lin_mat52 > "$EV/.expl_lin_mat52.txt" 2>>"$EV/.err"
+timeout 400 python bench.py --workload c3s --steps 3 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c3s.json"
+timeout 300 python bench.py --dry-nccl --steps 3 --warmup 1 --no-cpu-baseline 2>>"$EV/.err" | line > "$EV/${TAG}_bench_dry_nccl.json"
+# the skeleton of the 128 x 128 main loop in isolation (built by the caller: hipcc -O3 scripts/mfma_pipe_tile.hip -o scripts/_bin/pipe)
+if [ -x scripts/_bin/pipe ]; then
+  { echo "# hipcc --offload-arch=gfx950 -O3 scripts/mfma_pipe_tile.hip -o pipe && ./pipe   (1 x MI355X; modes in the header of the source)"; ./scripts/_bin/pipe; } > "$EV/${TAG}_mfma_pipe_tile.txt" 2>>"$EV/.err"
+fi
 timeout 300 python scripts/numpy_latency.py > "$EV/${TAG}_numpy_latency.txt" 2>>"$EV/.err"
 timeout 300 python scripts/exploration_step.py > "$EV/${TAG}_exploration_step.txt" 2>>"$EV/.err"
+cat "$EV/.expl_lin_mat52.txt" >> "$EV/${TAG}_exploration_step.txt" 2>/dev/null
 timeout 300 python scripts/growing_model.py > "$EV/${TAG}_growing_model.txt" 2>>"$EV/.err"
 timeout 900 bash scripts/profile_gpu.sh "$TAG" > "$EV/.profile.log" 2>&1
 export TMPDIR=/tmp
