@@ -297,8 +297,8 @@ int sr_publish(int device, const double* src_dev, int n, double* dst_host, unsig
                unsigned long long seq, void* stream);
 int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s);
 /* 1 where kernels of `device` may be handed the HOST address of this pinned block as it is (device-visible at the same
- * address, and the device's atomic adds -- the n_bad counters -- arrive in it: probed with one tiny launch that leaves
- * the block as it found it), 0 otherwise: asked once by a host layer that lets the kernels read / write its pinned staging
+ * address, and the device's atomic adds -- the n_bad counters -- reach pinned host memory: probed once per device and
+ * process with one tiny launch on a word of the library's own), 0 otherwise: asked once by a host layer that lets the kernels read / write its pinned staging
  * blocks directly (tiny batches: no copy command in either direction; safe_exploration_amd/_buffers.py). */
 int sr_host_block_is_device_visible(int device, const void* host_block);
 /* hipStreamSynchronize(stream) with `device` current, for a host layer that holds the raw stream handle (the handle 0 --

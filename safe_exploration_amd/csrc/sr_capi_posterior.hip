@@ -467,10 +467,35 @@ extern "C" int sr_stream_synchronize(int device, void* stream) {
 
 // 1 where kernels of `device` may be handed the HOST address of this pinned block as it is (the device sees the block at the
 // same address), 0 otherwise -- what a host layer asks once before it lets kernels read / write its pinned staging blocks.
-// (and where the device's ATOMIC adds reach the block: the kernels count violated bounds with atomicAdd on a word of the
-//  result block, and over a link without PCIe AtomicOps such an add can be dropped silently -- probed once per block with 64
-//  adds on its first word, which is restored)
+// (and where the device's ATOMIC adds reach pinned host memory: the kernels count violated bounds with atomicAdd on a word of
+//  the result block, and over a link without PCIe AtomicOps such an add can be dropped silently.  A property of the device
+//  and its link, not of the block: probed ONCE per device and process -- 64 adds on a pinned word of the library's own, on
+//  the null stream; a stream of its own per probe cost a caller milliseconds every time it pinned a new block.)
 __global__ void sr_probe_atomic_kernel(int* w) { atomicAdd(w, 1); }
+
+static int host_atomics_reach(int device) {
+    static std::mutex mu;
+    static int cached[64];                     // 0 unknown, 1 yes, -1 no
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64) return 0;
+    if (cached[device] != 0) return cached[device] > 0;
+    int* w = nullptr;
+    int* wd = nullptr;
+    bool ok = hipHostMalloc((void**)&w, 64, hipHostMallocMapped) == hipSuccess;
+    if (ok) {
+        *w = 0;
+        ok = hipHostGetDevicePointer((void**)&wd, w, 0) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(sr_probe_atomic_kernel, dim3(1), dim3(64), 0, (hipStream_t)nullptr, wd);
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize((hipStream_t)nullptr) == hipSuccess;
+        }
+        ok = ok && *(volatile int*)w == 64;
+        (void)hipHostFree(w);
+    }
+    if (!ok) (void)hipGetLastError();
+    cached[device] = ok ? 1 : -1;
+    return ok ? 1 : 0;
+}
 
 extern "C" int sr_host_block_is_device_visible(int device, const void* host_block) {
     if (!host_block) return 0;
@@ -481,22 +506,7 @@ extern "C" int sr_host_block_is_device_visible(int device, const void* host_bloc
         return 0;
     }
     if (dp != host_block) return 0;
-    volatile int* w = reinterpret_cast<volatile int*>(const_cast<void*>(host_block));
-    const int saved = *w;
-    *w = 0;
-    std::atomic_thread_fence(std::memory_order_seq_cst);
-    hipStream_t ps = nullptr;
-    bool ok = hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(sr_probe_atomic_kernel, dim3(1), dim3(64), 0, ps, reinterpret_cast<int*>(dp));
-        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ps) == hipSuccess;
-        (void)hipStreamDestroy(ps);
-    }
-    std::atomic_thread_fence(std::memory_order_seq_cst);
-    ok = ok && *w == 64;
-    *w = saved;
-    if (!ok) (void)hipGetLastError();
-    return ok ? 1 : 0;
+    return host_atomics_reach(device);
 }
 
 extern "C" int sr_wait_flag(const unsigned long long* flag_host, unsigned long long seq, double timeout_s) {

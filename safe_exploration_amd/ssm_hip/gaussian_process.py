@@ -577,7 +577,12 @@ class SimpleGPModel(StateSpaceModel):
         self._beta = None
         self._inv_K = None
         if old is not None and old is not handle and getattr(old, "_server_armed", False):
-            self.start_server(old._server_idle)      # a refit with a new size replaced the handle: the server follows
+            # a refit with a new size replaced the handle: the server follows -- the model is already in place, so a
+            # failure to re-arm leaves the launched routes, not an exception out of the update
+            try:
+                self.start_server(old._server_idle)
+            except RuntimeError as e:
+                warnings.warn("resident server not re-armed after the model update: {}".format(e))
 
     def _set_data(self, handle, Z, Y, noise, dev, s):
         rbf = all(kt == "rbf" for kt in self.kern_types)         # ARD-RBF fast path (north_star kernel)

@@ -197,8 +197,9 @@ def _evaluator_class(cas):
             state, action = _dense(arg[0]), _dense(arg[1])
             if self.linearize_mu:
                 self.ssm.linearize_predict(state.T, action.T, True, False)
-                # jac_mean seed flattened row-major: entry i*D + j multiplies d jac_mean[i, j] / dz, the layout
-                # of the third block of the stacked Jacobian above
+                # jac_mean seed flattened row-major: entry i*D + j multiplies d jac_mean[i, j] / dz -- what
+                # get_linearize_reverse expects (the seed arrives as an n x D matrix, so this has nothing to do with the
+                # row order of the third block of the stacked Jacobian, jac_mu_order above)
                 seed = np.concatenate((seeds[0].reshape(-1), seeds[1].reshape(-1), seeds[2].reshape(-1)))
                 adj_state, adj_action = self.ssm.get_linearize_reverse(seed)
             else:

@@ -9,7 +9,7 @@ REPO=$(pwd)
 EV=$REPO/gpurun_out/ev_$TAG
 mkdir -p "$EV"
 ulimit -c 0
-line() { tail -n 1; }
+line() { grep "^{" | tail -n 1; }
 timeout 600 python bench.py 2>"$EV/.err" | line > "$EV/${TAG}_bench_c2p.json"
 timeout 400 python bench.py --workload c2 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c2.json"
 timeout 400 python bench.py --workload c3 --steps 3 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c3.json"
