@@ -252,9 +252,10 @@ int sr_gp_sample(int device, long T, int size, int n_out, int n_u, const double*
 int sr_gp_set_chunk(sr_gp_t h, long chunk);
 /* query tiles per scheduling group of the variance kernel (L2/XCD locality knob); default 64. */
 int sr_gp_set_var_group(sr_gp_t h, int group);
-/* main loop of the variance kernel: 0 = register-staged tiles (global->VGPR->LDS), 1 = LDS-DMA tiles
- * (global_load_lds_dwordx4; same results as 0 bit for bit), 2 = 1 with the structural zeros of the diagonal blocks
- * of U^-1 left out (default; same numbers summed in another order: equal to 1e-13).  A measurement knob. */
+/* main loop of the variance kernel: 1 = the loop of rounds 1 - 4 (LDS-DMA tiles, workgroup barrier on top of every
+ * k-tile), 3 = the pipelined loop of round 5 (barrier under the MFMA stream; same results as 1 bit for bit), 4 = 3 with
+ * the structural zeros of the diagonal blocks of U^-1 left out (default; same numbers summed in another order: equal
+ * to 1e-13).  A measurement knob; other values are SR_EINVAL. */
 int sr_gp_set_var_variant(sr_gp_t h, int variant);
 /* blocks of 128 rows per Cholesky panel of sr_gp_factorize (the trailing matrix is read-modify-written once per
  * panel); 0 = chosen by size (default).  Results agree to rounding; a measurement knob. */

@@ -459,7 +459,7 @@ extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
 }
 
 extern "C" int sr_gp_set_var_variant(sr_gp_t h, int variant) {
-    SR_CHECK(h != nullptr && (variant >= 0 && variant <= 4), SR_EINVAL, "sr_gp_set_var_variant: bad argument");
+    SR_CHECK(h != nullptr && (variant == 1 || variant == 3 || variant == 4), SR_EINVAL, "sr_gp_set_var_variant: 1, 3 or 4");
     h->var_variant = variant;
     return SR_OK;
 }

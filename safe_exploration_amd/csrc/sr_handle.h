@@ -73,9 +73,9 @@ struct sr_gp {
     int small_path = 1;      // latency paths (streaming T <= 16, 64-tiles, split-K) instead of the plain MFMA tiles
     int last_streamed = 0;   // the last gp_pass went through the streaming kernels (their partials hold U^-T k*)
     int force_stream = 0;    // sr_gp_linearize wants those partials whatever the model size
-    int var_variant = 4;     // 0: register-staged tiles, 1: LDS-DMA (global_load_lds) tiles, 2: 1 + diagonal blocks without
-                             // their structural zeros (69.8 -> 70.05 TF at C2'), 3: the pipelined loop of round 5 (barrier
-                             // under the MFMA stream: 73.1 TF), 4: 3 + the diagonal-block walk (default: 74.5 TF)
+    int var_variant = 4;     // 1: the loop of rounds 1 - 4 (LDS-DMA, barrier on top of a k-tile: 70 TF; the A/B reference), 3: the
+                             // pipelined loop of round 5 (barrier under the MFMA stream: 73.1 TF), 4: 3 + diagonal blocks without
+                             // their structural zeros (default: 74.5 TF)
     // factorisation: the outputs are independent problems -- below SR_FACT_PAR_BYTES of scratch each gets its own
     // HIP stream (the small-grid kernels of a modest model then overlap) and the scratch stays with the handle
     double* fact_ws = nullptr; size_t fact_cap = 0;      // n_par x (U, W: Np^2 each, v: Np)

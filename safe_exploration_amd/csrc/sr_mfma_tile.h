@@ -40,113 +40,23 @@ __device__ __forceinline__ int acc_col(int wn, int ni, int lane) {
     return wn * 64 + ni * 16 + (lane & 15);
 }
 
-// A points at A[0][m0], B at B[0][n0] (row strides lda/ldb in doubles); k range [k_beg, k_end),
-// both multiples of BK.  smem: SMEM_DOUBLES doubles.  All 256 threads must call.
-__device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long lda,
-                                            const double* __restrict__ B, long ldb,
-                                            int k_beg, int k_end, double* smem, Acc& acc) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+// Contract of the main loops below: A points at A[0][m0], B at B[0][n0] (row strides lda / ldb in doubles); k range
+// [k_beg, k_end), both multiples of BK.  smem: SMEM_DOUBLES doubles.  All 256 threads must call.
+// (The register-staged loop of round 1 -- global_load -> VGPR -> ds_write, 205 VGPRs, 66.5 TF -- is gone since round 5.)
 
-    double* As = smem;                 // [2][BK][LDT]
-    double* Bs = smem + 2 * STAGE;     // [2][BK][LDT]
-
-    // staging map: 16 rows x 64 double2 per operand; thread handles 4 double2 per operand
-    // e = tid + j*256 -> row = e >> 6 (one wavefront == one 1 KiB row), c2 = e & 63
-    double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const int c2 = tid & 63;
-    const int r0 = tid >> 6;           // rows r0, r0+4, r0+8, r0+12
-    const double* ga = A + (long)r0 * lda + 2 * c2;
-    const double* gb = B + (long)r0 * ldb + 2 * c2;
-    const int so = r0 * LDT + 2 * c2;  // LDS offset of row r0 inside a stage
-
-#define SRT_GLOAD(k0)                                                                   \
-    do {                                                                                \
-        const double* pa_ = ga + (long)(k0) * lda;                                      \
-        const double* pb_ = gb + (long)(k0) * ldb;                                      \
-        ra0 = *reinterpret_cast<const double2*>(pa_);                                   \
-        ra1 = *reinterpret_cast<const double2*>(pa_ + 4 * lda);                         \
-        ra2 = *reinterpret_cast<const double2*>(pa_ + 8 * lda);                         \
-        ra3 = *reinterpret_cast<const double2*>(pa_ + 12 * lda);                        \
-        rb0 = *reinterpret_cast<const double2*>(pb_);                                   \
-        rb1 = *reinterpret_cast<const double2*>(pb_ + 4 * ldb);                         \
-        rb2 = *reinterpret_cast<const double2*>(pb_ + 8 * ldb);                         \
-        rb3 = *reinterpret_cast<const double2*>(pb_ + 12 * ldb);                        \
-    } while (0)
-#define SRT_SSTORE(buf)                                                                 \
-    do {                                                                                \
-        double* sa_ = As + (buf) * STAGE + so;                                          \
-        double* sb_ = Bs + (buf) * STAGE + so;                                          \
-        *reinterpret_cast<double2*>(sa_) = ra0;                                         \
-        *reinterpret_cast<double2*>(sa_ + 4 * LDT) = ra1;                               \
-        *reinterpret_cast<double2*>(sa_ + 8 * LDT) = ra2;                               \
-        *reinterpret_cast<double2*>(sa_ + 12 * LDT) = ra3;                              \
-        *reinterpret_cast<double2*>(sb_) = rb0;                                         \
-        *reinterpret_cast<double2*>(sb_ + 4 * LDT) = rb1;                               \
-        *reinterpret_cast<double2*>(sb_ + 8 * LDT) = rb2;                               \
-        *reinterpret_cast<double2*>(sb_ + 12 * LDT) = rb3;                              \
-    } while (0)
-
-    if (k_beg >= k_end) return;
-    SRT_GLOAD(k_beg);
-    SRT_SSTORE(0);
-    __syncthreads();
-
-    const int fa = (lane >> 4) * LDT + wm * 64 + (lane & 15);   // fragment offsets inside a stage
-    const int fb = (lane >> 4) * LDT + wn * 64 + (lane & 15);
-
-    int buf = 0;
-    for (int k0 = k_beg; k0 < k_end; k0 += BK) {
-        const bool more = (k0 + BK) < k_end;
-        if (more) SRT_GLOAD(k0 + BK);
-        const double* as = As + buf * STAGE + fa;
-        const double* bs = Bs + buf * STAGE + fb;
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = as[kk * 4 * LDT + i * 16];
-                bf[i] = bs[kk * 4 * LDT + i * 16];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0);
-        }
-        if (more) SRT_SSTORE(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-#undef SRT_GLOAD
-#undef SRT_SSTORE
-}
-
-// Same contract as mainloop_tn, but global->LDS goes through the LDS-DMA path
+// Rounds 1 - 4: global->LDS through the LDS-DMA path
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass).  Each wavefront-instruction moves one
 // 1 KiB tile row (lane-linear destination == our row layout; the padding sits between rows).
 // Two LDS stages; the barrier at the top of a k-step carries the vmcnt(0) that retires the DMA of the
 // tile about to be read, and frees the other stage for the next DMA.
 #define SRT_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
 #define SRT_AS3(p) ((__attribute__((address_space(3))) void*)(p))
-// DIAG: the LAST 128 k of the range multiply a diagonal block of an upper-triangular A (A[k][m] == 0 for k > m inside
-// the block).  In 16 x 16 sub-blocks only the pairs (k-tile kt <= row tile it) carry numbers -- 36 of 64 -- and the plain
-// loop spends a full MFMA on each of the other 28 (2.6 % of all MFMAs of the triangular contraction at N = 5000).  With
-// DIAG the two wavefront rows own INTERLEAVED row tiles (wm = 0: it = 0, 2, 4, 6; wm = 1: it = 1, 3, 5, 7) instead of
-// the upper and the lower half, so that both lose work at the same pace (16 resp. 20 of 32 pairs each), and the eight
-// diagonal k-tiles run fully unrolled with the row tiles kt > it left out at compile time.  A workgroup advances at the
-// pace of its slower wavefront row: 20 / 32 of the diagonal block's time.  (Skipping with the half / half assignment --
-// 10 resp. 26 of 32 -- buys nothing: measured in round 1.)  Callers must use acc_row_ilv for the row of an accumulator.
-// Measured at C2' (N = 5000, 65536 queries): 69.8 -> 70.05 TFLOP/s, a quarter of the 1.8 % the MFMA count promises:
-// a k-tile with 16 .. 48 MFMAs instead of 64 no longer covers the latency of the next tile's LDS-DMA.
 __device__ __forceinline__ int acc_row_ilv(int wm, int mi, int lane, int r) {
     return (2 * mi + wm) * 16 + (lane >> 4) + 4 * r;
 }
 
-template <int BKT, bool DIAG = false>
+// (kept as the A/B reference of the pipelined loop below: variant 1 of sr_var_kernel, same bits)
+template <int BKT>
 __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb,
                                                  int k_beg, int k_end, double* smem, Acc& acc) {
@@ -177,15 +87,11 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
 
     SRT_DMA(k_beg, 0);
     // A-fragment of row tile mi: columns (rows of the product) wm*64 + mi*16 .. , or (2 mi + wm)*16 .. when interleaved
-    const int fa = (lane >> 4) * LDT + (DIAG ? wm * 16 : wm * 64) + (lane & 15);
-    constexpr int FAS = DIAG ? 32 : 16;        // distance of consecutive row tiles of one wavefront
+    const int fa = (lane >> 4) * LDT + wm * 64 + (lane & 15);
+    constexpr int FAS = 16;                    // distance of consecutive row tiles of one wavefront
     const int fb = (lane >> 4) * LDT + wn * 64 + (lane & 15);
     int buf = 0;
-    // the masked walk needs the whole diagonal block inside the range (not so only for row block 0 of a padded model:
-    // the plain loop multiplies its few zeros)
-    const bool diag = DIAG && k_end - 128 >= k_beg;
-    const int k_gen_end = diag ? k_end - 128 : k_end;                 // [k_beg, k_gen_end): all row tiles
-    for (int k0 = k_beg; k0 < k_gen_end; k0 += BKT) {
+    for (int k0 = k_beg; k0 < k_end; k0 += BKT) {
         __syncthreads();                       // vmcnt(0) + s_barrier: tile k0 landed, other stage is free
         if (k0 + BKT < k_end) SRT_DMA(k0 + BKT, buf ^ 1);
         const double* as = As + buf * STG + fa;
@@ -205,43 +111,6 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
                     acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0);
         }
         buf ^= 1;
-    }
-    if (diag) {
-        static_assert(!DIAG || BKT == 16, "the diagonal block is walked in k-tiles of 16");
-        int kd = k_end - 128;                  // first k of the diagonal block
-        // k-tile kt of the block: row tile it = 2 mi + wm carries numbers iff it >= kt.  Both wavefront rows use the
-        // SAME live set mi >= kt / 2 (exact for wm = 1, one 16 x 16 block of zeros too many per odd kt for wm = 0):
-        // the workgroup moves at the pace of wm = 1 anyway, and one straight-line body keeps the register allocator
-        // out of trouble (a wavefront-uniform branch over two exact copies spilled 500 VGPRs).
-#define SRT_DIAG_BODY                                                                                \
-        _Pragma("unroll") for (int kt = 0; kt < 8; ++kt) {                                           \
-            __syncthreads();                                                                         \
-            if (kt < 7) {                                                                            \
-                kd += 16;                                                                            \
-                asm volatile("" : "+s"(kd));   /* one running k: no table of 8 x 8 precomputed addresses (spills) */ \
-                SRT_DMA(kd, buf ^ 1);                                                                \
-            }                                                                                        \
-            const double* as = As + buf * STG + fa;                                                  \
-            const double* bs = Bs + buf * STG + fb;                                                  \
-            const int MI0 = kt >> 1;       /* first live row tile */                                    \
-            if (MI0 < 4) {                                                                           \
-                _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                   \
-                    double af[4], bf[4];                                                             \
-                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
-                        if (i >= MI0) af[i] = as[kk * 4 * LDT + i * FAS];                            \
-                        bf[i] = bs[kk * 4 * LDT + i * 16];                                           \
-                    }                                                                                \
-                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                    \
-                        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                \
-                            if (i >= MI0)                                                            \
-                                acc.v[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc.v[i][j], 0, 0, 0); \
-                    __builtin_amdgcn_sched_barrier(0);   /* later k-steps' reads stay behind (else spills) */ \
-                }                                                                                    \
-            }                                                                                        \
-            buf ^= 1;                                                                                \
-        }
-        SRT_DIAG_BODY
-#undef SRT_DIAG_BODY
     }
     __syncthreads();                           // callers reuse smem after the main loop
 #undef SRT_DMA
@@ -265,6 +134,15 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
 //   * two k-tiles per trip, so the stage is a compile-time constant: LDS offsets are immediates, no VALU between MFMAs.
 // One barrier per k-tile and two LDS stages, as before.  Same order of accumulation: identical results bit for bit.
 // ------------------------------------------------------------------------------------------------------------------
+// DIAG: the LAST 128 k of the range multiply a diagonal block of an upper-triangular A (A[k][m] == 0 for k > m inside
+// the block).  In 16 x 16 sub-blocks only the pairs (k-tile kt <= row tile it) carry numbers -- 36 of 64 -- and the plain
+// loop spends a full MFMA on each of the other 28 (2.6 % of all MFMAs of the triangular contraction at N = 5000).  With
+// DIAG the two wavefront rows own INTERLEAVED row tiles (wm = 0: it = 0, 2, 4, 6; wm = 1: it = 1, 3, 5, 7) instead of
+// the upper and the lower half, so that both lose work at the same pace (16 resp. 20 of 32 pairs each), and the eight
+// diagonal k-tiles run fully unrolled with the row tiles kt > it left out at compile time.  A workgroup advances at the
+// pace of its slower wavefront row: 20 / 32 of the diagonal block's time.  (Skipping with the half / half assignment --
+// 10 resp. 26 of 32 -- buys nothing: measured in round 1.)  Callers must use acc_row_ilv for the row of an accumulator.
+// Measured at C2' (N = 5000, 65536 queries): 73.1 -> 74.5 TFLOP/s with the pipelined loop (round 4's loop: 69.8 -> 70.05).
 struct Frag { double a[4], b[4]; };
 
 // one LDS-DMA instruction: 1 KiB tile row from gbase (SGPR pair) + voff (bytes, per lane) to LDS byte address lds0 + IMM

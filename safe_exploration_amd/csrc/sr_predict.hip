@@ -279,14 +279,12 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
 
     srt::Acc acc;
     acc.zero();
-    // VARIANT 2: as 1, with the structural zeros of the diagonal block left out (row tiles interleaved over the two
-    // wavefront rows; the epilogue below sums over all rows of the block, so the row assignment does not show).
+    // VARIANT 4 leaves out the structural zeros of the diagonal block (row tiles interleaved over the two wavefront rows;
+    // the epilogue below sums over all rows of the block, so the row assignment does not show).
     // VARIANT 3 / 4: the pipelined loop of round 5 (barrier under the MFMA stream), without / with the diagonal-block walk
     if (VARIANT == 4) srt::mainloop_tn_pipe<true>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
     else if (VARIANT == 3) srt::mainloop_tn_pipe<false>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
-    else if (VARIANT == 2) srt::mainloop_tn_glds<16, true>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
-    else if (VARIANT == 1) srt::mainloop_tn_glds<16>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
-    else srt::mainloop_tn(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+    else srt::mainloop_tn_glds<16>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);      // (1: the loop of rounds 1 - 4)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -332,14 +330,8 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
     else if (variant == 3)
         hipLaunchKernelGGL(sr_var_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
                            nrb, ntq, group, k_beg);
-    else if (variant == 2)
-        hipLaunchKernelGGL(sr_var_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
-                           nrb, ntq, group, k_beg);
-    else if (variant == 1)
-        hipLaunchKernelGGL(sr_var_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
-                           nrb, ntq, group, k_beg);
     else
-        hipLaunchKernelGGL(sr_var_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
+        hipLaunchKernelGGL(sr_var_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
                            nrb, ntq, group, k_beg);
     SR_HIP(hipGetLastError());
     return SR_OK;

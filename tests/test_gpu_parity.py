@@ -397,27 +397,22 @@ def test_full_size_properties():
 
 
 def test_var_kernel_variants_agree_bitwise():
-    """register-staged and LDS-DMA tile staging are the same arithmetic in the same order."""
+    """The pipelined main loop of round 5 (variant 3) is the arithmetic of the loop of rounds 1 - 4 (variant 1) in the same
+    order: equal bit for bit.  Variant 4 (default) leaves out the structural zeros of the diagonal blocks and deals the rows
+    of a block to the wavefronts differently: same numbers, another order of summation."""
     syn = orc.make_synthetic(91, 700, 2, 1, 3000)
     gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
     x = np.hstack((syn["p"], syn["k_ff"]))
-    gp.set_var_variant(0)
+    gp.set_var_variant(1)
     mu0, var0 = gp.predict(x)
-    for variant in (1, 3):                                 # (3: the pipelined loop of round 5, all row tiles)
-        gp.set_var_variant(variant)
-        mu1, var1 = gp.predict(x)
-        np.testing.assert_array_equal(var0, var1)
-        np.testing.assert_array_equal(mu0, mu1)
-    # variants 2 and 4 leave out the structural zeros of the diagonal blocks and deal the rows of a block to the
-    # wavefronts differently: same numbers, another order of summation (the same one in both: equal bit for bit)
-    res = {}
-    for variant in (2, 4):
-        gp.set_var_variant(variant)
-        mu2, var2 = gp.predict(x)
-        np.testing.assert_array_equal(mu0, mu2)
-        np.testing.assert_allclose(var2, var0, rtol=0, atol=1e-13)
-        res[variant] = var2
-    np.testing.assert_array_equal(res[2], res[4])
+    gp.set_var_variant(3)
+    mu1, var1 = gp.predict(x)
+    np.testing.assert_array_equal(var0, var1)
+    np.testing.assert_array_equal(mu0, mu1)
+    gp.set_var_variant(4)
+    mu2, var2 = gp.predict(x)
+    np.testing.assert_array_equal(mu0, mu2)
+    np.testing.assert_allclose(var2, var0, rtol=0, atol=1e-13)
     # every count of k-tiles modulo the pair structure of the pipelined loop, with and without a diagonal-block walk
     # (front padding 0 .. 127 rows moves the first k-tile; row block 0 of a padded model has fewer than eight k-tiles)
     for N in (1, 17, 33, 100, 128, 129, 145, 161, 250, 257, 300, 383, 400):
@@ -427,14 +422,12 @@ def test_var_kernel_variants_agree_bitwise():
         x2 = np.hstack((s2["p"], s2["k_ff"]))
         g2.set_var_variant(1)
         _, v1 = g2.predict(x2)
-        g2.set_var_variant(2)
-        _, v2 = g2.predict(x2)
         g2.set_var_variant(3)
         _, v3 = g2.predict(x2)
         g2.set_var_variant(4)
         _, v4 = g2.predict(x2)
         np.testing.assert_array_equal(v1, v3, err_msg="N=%d" % N)
-        np.testing.assert_array_equal(v2, v4, err_msg="N=%d" % N)
+        np.testing.assert_allclose(v4, v3, rtol=0, atol=1e-13, err_msg="N=%d" % N)
     om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
     _, rvar = orc.gp_predict(x, om["Z"], om["beta"], om["inv_K"], om["lengthscale"], om["signal_var"], False)
     np.testing.assert_allclose(var2, rvar, rtol=0, atol=1e-9)
