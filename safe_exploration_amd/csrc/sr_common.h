@@ -489,6 +489,7 @@ struct sr_stream_args {
     // one-command single query (sr_gp_call1 on a streamed model): the workgroup that runs the final stage publishes this
     // sequence number into pinned host memory after its outputs (which then live in pinned host memory too)
     unsigned long long* host_flag; unsigned long long host_seq;
+    int probe = 0;                   // measurements only (SR_ST1_PROBE): 1 = sr_stream1_kernel stops after its streaming part
 };
 long sr_stream_vp_doubles(int Np, int n_out, int ncols);
 int sr_stream_tickets(int Np, int n_out);

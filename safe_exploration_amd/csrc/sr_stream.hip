@@ -265,9 +265,11 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
 #pragma unroll
     for (int t = 0; t < TQ; ++t) sr_st_agent(out + t * SR_ST_COLS + tid, acc[t]);
 
+    if (a.probe == 1) return;
     // ---- last workgroup of this column block: add the chunks, square (or multiply with column 0), reduce
     const int nch = 2 * cb + 2;
     if (!sr_ticket_last(a.tickets + d * a.ncb + cb, (unsigned)nch, &s_flag)) return;
+    if (a.probe == 2) return;
     {
         const double* src = a.Vp + ((long)d * a.npairs + cb * (cb + 1)) * TQ * SR_ST_COLS + tid;
         double v[TQ];
@@ -755,6 +757,8 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     a.npairs = a.ncb * (a.ncb + 1);
     const int nc = max(sr_stream_width(a.ncols), a.width_min);
     SR_CHECK(a.ncols >= 1 && a.ncols <= 128, SR_EINVAL, "stream: %d columns", a.ncols);
+    static const int probe_env = getenv("SR_ST1_PROBE") ? atoi(getenv("SR_ST1_PROBE")) : 0;
+    a.probe = probe_env;
     dim3 grid(a.npairs, a.n_out);
     if (nc <= 4) {
         SR_CHECK(src == 0 || (a.D <= 5 && (src == 1 || a.D + 1 <= 4)), SR_EINVAL, "stream: src %d with D = %d", src, a.D);
