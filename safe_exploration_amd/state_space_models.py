@@ -91,7 +91,7 @@ def _evaluator_class(cas):
         [jac_mean; jac_variance[; d jac_mean/dz]] (:305-419); ``get_reverse`` one producing the adjoints of
         (state, action) for the output seeds (:435-566).  One model evaluation per call of either."""
 
-        def __init__(self, ssm, linearize_mu=True, has_jacobian=True, has_reverse=False, opts={}):
+        def __init__(self, ssm, linearize_mu=True, has_jacobian=True, has_reverse=False, opts={}, jac_mu_order="F"):
             cas.Callback.__init__(self)
             self.v_has_jacobian = has_jacobian
             self.v_has_reverse = has_reverse
@@ -108,7 +108,10 @@ def _evaluator_class(cas):
             # (test_state_space_models.py:263-286) and cannot tell the two apart.  "C" reproduces the reference's
             # rows exactly.  The reverse callback is unaffected (its seed arrives as an n x D matrix).
             # tests/test_casadi_real.py settles it against IPOPT's derivative checker wherever casadi is installed.
-            self.jac_mu_order = "F"
+            # (constructor argument jac_mu_order="C" for runs that must match the reference's rows byte for byte)
+            if jac_mu_order not in ("F", "C"):
+                raise ValueError("jac_mu_order must be 'F' (CasADi's vec rule) or 'C' (the reference helper's rows)")
+            self.jac_mu_order = jac_mu_order
             self.construct("CasadiModelEvaluator", opts)
 
         def get_n_in(self):
