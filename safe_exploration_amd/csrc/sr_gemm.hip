@@ -2,6 +2,9 @@
 // sr_mfma_tile.h): plain, split-K, upper-block-triangle (trailing update of the Cholesky) and job-table (one launch per
 // level of the recursive triangular inversion).  Launch plan: sr_capi_update.hip / sr_capi_append.hip.
 #include "sr_mfma_tile.h"
+#ifndef SR_T64_PIPE
+#define SR_T64_PIPE 1     /* 64 x 64 tile: the pipelined loop of round 5 (0: the loop of round 3, for A/B builds) */
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // TN GEMMs on the fp64 matrix cores, on either workgroup tile of sr_mfma_tile.h
@@ -25,7 +28,9 @@ struct sr_tile64 {
     static constexpr int T = 64, NI = 2, SMEM = srt64::SMEM_DOUBLES, WPS = 2;
     static __device__ __forceinline__ void mainloop(const double* A, long lda, const double* B, long ldb, int k0,
                                                     int k1, double* smem, Acc& acc) {
-        srt64::mainloop_tn(A, lda, B, ldb, k0, k1, smem, acc);
+        static_assert(true, "");
+        if (SR_T64_PIPE) srt64::mainloop_tn_pipe(A, lda, B, ldb, k0, k1, smem, acc);
+        else srt64::mainloop_tn(A, lda, B, ldb, k0, k1, smem, acc);
     }
     static __device__ __forceinline__ int row(int wm, int mi, int lane, int r) { return srt64::acc_row(wm, mi, lane, r); }
     static __device__ __forceinline__ int col(int wn, int ni, int lane) { return srt64::acc_col(wn, ni, lane); }

@@ -397,4 +397,113 @@ __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long l
 #undef SRT64_DMA
 }
 
+// Round 5: the 64 x 64 loop in the pipelined form of srt::mainloop_tn_pipe (see there): fragments of k-step kk + 1 read
+// under the four MFMAs of kk, the barrier of a 16-row k-tile in front of its LAST four MFMAs, behind it the first reads of
+// the next tile and the DMA of the tile four ahead (FOUR stages: three tiles in flight, as before), the four DMA
+// instructions spread over those MFMAs, inline asm so that the compiler's waitcnt pass keeps counting, four k-tiles per trip
+// so that the stage is a compile-time constant.  Same order of accumulation as mainloop_tn: identical bits.
+struct Frag { double a[2], b[2]; };
+
+__device__ __forceinline__ void mainloop_tn_pipe(const double* __restrict__ A, long lda, const double* __restrict__ B,
+                                                 long ldb, int k_beg, int k_end, double* smem, Acc& acc) {
+    if (k_beg >= k_end) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const double* As = smem;
+    const double* Bs = smem + NS * STAGE;
+    const int nsteps = (k_end - k_beg) / BK;
+    // DMA: wavefront w moves pairs w and w + 4 of each operand; lanes 0 - 31 one row of a pair, lanes 32 - 63 the row two below
+    const int half = lane >> 5, l32 = lane & 31;
+    const unsigned voa = (unsigned)((2L * half * lda + 2 * l32) * 8);
+    const unsigned vob = (unsigned)((2L * half * ldb + 2 * l32) * 8);
+    const int r0 = 4 * (wave >> 1) + (wave & 1);                      // first row of pair `wave` (uniform)
+    const double* ga = A + (long)(k_beg + r0) * lda;                  // tile whose DMA is issued next
+    const double* gb = B + (long)(k_beg + r0) * ldb;
+    const unsigned lds0 = (unsigned)(size_t)(smem + wave * LDP);
+    // fragment reads: row_off(4 kk + lk) = 2 kk LDP + [(lk & 1) LDP + ((lk >> 1) & 1) 64]
+    const int lk = lane >> 4, ln = lane & 15;
+    const int fo = (lk & 1) * LDP + ((lk >> 1) & 1) * 64 + ln;
+    const int fa = fo + wm * 32, fb = fo + wn * 32;
+
+#define S64_DMA1(IMM_, voff_, gbase_)                                                               \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                    \
+                 :: "s"(lds0 + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory")
+    // instruction q (0 .. 3) of the DMA of the tile at (ga, gb) into stage st: A pair w, B pair w, A pair w + 4, B pair w + 4
+#define S64_DMAQ(st, q)                                                                             \
+    do {                                                                                            \
+        if ((q) == 0) S64_DMA1(((st) * STAGE) * 8, voa, ga);                                        \
+        else if ((q) == 1) S64_DMA1(((NS + (st)) * STAGE) * 8, vob, gb);                            \
+        else if ((q) == 2) S64_DMA1(((st) * STAGE + 4 * LDP) * 8, voa, ga + 8 * lda);               \
+        else S64_DMA1(((NS + (st)) * STAGE + 4 * LDP) * 8, vob, gb + 8 * ldb);                      \
+    } while (0)
+#define S64_RD(F, st, kk)                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                              \
+        (F).a[i_] = As[(st) * STAGE + 2 * (kk) * LDP + i_ * 16 + fa];                               \
+        (F).b[i_] = Bs[(st) * STAGE + 2 * (kk) * LDP + i_ * 16 + fb];                               \
+    }
+#define S64_MF(F)                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
+            acc.v[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64((F).a[i_], (F).b[j_], acc.v[i_][j_], 0, 0, 0);
+#define S64_SB __builtin_amdgcn_sched_barrier(0)
+    // k-tile t on stage st, fragments of its k-step 0 in F0.  Behind its barrier: tile t + 1 has landed (the tiles t + 2,
+    // t + 3 -- as far as they exist -- may still be in flight), stage st is free for tile t + 4.
+#define S64_STEP(st, t)                                                                             \
+    do {                                                                                            \
+        S64_RD(F1, st, 1); S64_SB; S64_MF(F0); S64_SB;                                              \
+        S64_RD(F0, st, 2); S64_SB; S64_MF(F1); S64_SB;                                              \
+        S64_RD(F1, st, 3); S64_SB; S64_MF(F0); S64_SB;                                              \
+        const int left_ = nsteps - 1 - (t);            /* tiles behind this one */                   \
+        if (left_ >= 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+        else if (left_ == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else if (left_ == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        S64_RD(F0, ((st) + 1) & 3, 0); S64_SB;                                                      \
+        const bool dma_ = left_ >= 4;                                                               \
+        if (dma_) { ga += 16 * lda; gb += 16 * ldb; }                                               \
+        acc.v[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(F1.a[0], F1.b[0], acc.v[0][0], 0, 0, 0); \
+        S64_SB; if (dma_) S64_DMAQ(st, 0); S64_SB;                                                  \
+        acc.v[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(F1.a[0], F1.b[1], acc.v[0][1], 0, 0, 0); \
+        S64_SB; if (dma_) S64_DMAQ(st, 1); S64_SB;                                                  \
+        acc.v[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(F1.a[1], F1.b[0], acc.v[1][0], 0, 0, 0); \
+        S64_SB; if (dma_) S64_DMAQ(st, 2); S64_SB;                                                  \
+        acc.v[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(F1.a[1], F1.b[1], acc.v[1][1], 0, 0, 0); \
+        S64_SB; if (dma_) S64_DMAQ(st, 3); S64_SB;                                                  \
+    } while (0)
+
+    // everything of this wavefront that is older than the DMAs below (a caller's loads) must not count against them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: the first four tiles (all stages are free), wait for the first
+    const int npro = nsteps < NS ? nsteps : NS;
+    _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {
+        if (s_ < npro) {
+            if (s_ > 0) { ga += 16 * lda; gb += 16 * ldb; }
+            S64_DMAQ(s_, 0); S64_DMAQ(s_, 1); S64_DMAQ(s_, 2); S64_DMAQ(s_, 3);
+        }
+    }
+    if (npro == 4) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    else if (npro == 3) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    Frag F0, F1;
+    S64_RD(F0, 0, 0);
+    for (int t = 0; t < nsteps; t += 4) {
+        S64_STEP(0, t);
+        if (t + 1 >= nsteps) break;
+        S64_STEP(1, t + 1);
+        if (t + 2 >= nsteps) break;
+        S64_STEP(2, t + 2);
+        if (t + 3 >= nsteps) break;
+        S64_STEP(3, t + 3);
+    }
+    __syncthreads();                           // callers reuse smem after the main loop
+#undef S64_DMA1
+#undef S64_DMAQ
+#undef S64_RD
+#undef S64_MF
+#undef S64_SB
+#undef S64_STEP
+}
+
 }  // namespace srt64
