@@ -194,7 +194,7 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
         sr_d4 accA = {0.0, 0.0, 0.0, 0.0};
         if constexpr (LIN) {
             // ONE query: the 16 lanes of a fragment row share the training row, so the row's k* is evaluated once -- lane r
-            // of the wavefront owns row r of its RPW rows (round 1) -- and handed to the fragment layout by a shuffle (round 2:
+            // of the wavefront owns row r of its RPW rows (round 1) -- and handed to the fragment layout through LDS (round 2:
             // each lane then needs one coordinate of its row, jc = ln - 1).  In the fragment layout every lane repeated the
             // exp: KSA serial evaluations per wavefront, times the wavefronts of a SIMD.  Same arithmetic, same bits.
             static_assert(RPW <= 64, "one lane per training row of the wavefront");
@@ -211,6 +211,9 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
                     r2 = fma(df, df, r2);
                 }
                 k1 = valid ? sf2 * exp(-0.5 * r2) : 0.0;
+                // to the 16 lanes of the row's fragment row through LDS: columns 14, 15 of its own K* row (1 + D <= 9 columns
+                // carry numbers); a ds_bpermute_b32 per dword and step cost ~64 cycles each
+                if (lane < RPW) { ks[i1][14] = k1; ks[i1][15] = al1; }
             }
             const int jc = (ln >= 1 && ln <= DT) ? ln - 1 : -1;
             double xc = 0.0, ilc = 0.0;
@@ -225,12 +228,12 @@ __device__ __forceinline__ void sr_small_phase_a(const sr_kstar_args& a, int d,
                     if (KEEP) zc = rows->r[i][jc];
                     else if (i >= off && jc < a.D) zc = a.Z[(long)(i - off) * a.D + jc] * ilc;
                 }
-                const double ki = __shfl(k1, 4 * st + lk), ali = __shfl(al1, 4 * st + lk);
+                const double ki = ks[i][14], ali = ks[i][15];
                 const double df = xc - zc;
                 const double bfrag = (ln == 0) ? ali : ((jc >= 0) ? ali * zc : 0.0);
                 const double scale = (ln == 0) ? 1.0 : ((jc >= 0) ? -df * ilc : 0.0);      // (z_j - x_j) / l_j^2
                 const double k = ki * scale;                   // column c: k* (c = 0), dk*/dx_{c-1}, 0 beyond D
-                ks[i][ln] = k;
+                if (ln < 14) ks[i][ln] = k;
                 accA = __builtin_amdgcn_mfma_f64_16x16x4f64(k, bfrag, accA, 0, 0, 0);
             }
         } else
@@ -472,34 +475,53 @@ __device__ __forceinline__ void sr_small_phase_a_gen(const sr_kstar_args& a, int
         ph = valid ? pre * hh : 0.0;
         vg = valid ? P.v * g : 0.0;
     }
+    // The row's terms go to the 16 lanes of its fragment row through LDS: columns 10 .. 15 of the row's own K* row (columns
+    // beyond 1 + D <= 6 of ks carry nothing: phase B multiplies them along and nobody reads the result).  A shuffle per term
+    // and step was the first form: ds_bpermute_b32 costs ~64 cycles on this part, twelve of them per step 900 cycles --
+    // 3.0 of the 7.5 us a 256-row model took on the device (timestamps inside the kernel); a broadcast ds_read_b64 costs 2.
+    if (lane < RPW) {
+        double* rs = &ks[wave * RPW + lane][10];
+        rs[0] = k0; rs[1] = vk; rs[2] = pg; rs[3] = ph; rs[4] = vg; rs[5] = al1;
+    }
     // Round 2 -- fragment layout: this lane's row m = ln of the two left operands and its column n = ln of the right-hand
-    // side need ONE coordinate of the training row: jc = ln - 1 (rows 1 + j, column 1 + j) or ln - 9 (rows 9 + j)
+    // side need ONE coordinate of the training row: jc = ln - 1 (rows 1 + j, column 1 + j) or ln - 9 (rows 9 + j).
+    // What a lane forms from the row's terms is written with per-lane 0 / 1 factors instead of branches on its role, and the
+    // terms of step st + 1 are requested before the arithmetic of step st:
+    //   A1 = c0 k0 + c8 pg + zc (vk a_c + b_c) + (lo pg + hi ph) u_c ,   A2 = lo vg u_c ,   B = alpha (c0 + lo (zc - x_c))
     const int jc = (ln >= 1 && ln <= a.D) ? ln - 1 : ((ln >= 9 && ln < 9 + a.D) ? ln - 9 : -1);
+    const bool low = ln >= 1 && ln <= a.D, high = ln >= 9 && ln < 9 + a.D;
     double xc = 0.0, s2c = 0.0, ac = 0.0, bc = 0.0;
 #pragma unroll
     for (int j = 0; j < DT; ++j)
-        if (jc == j) { xc = x[j]; s2c = P.s2[j]; ac = P.a[j]; bc = P.b[j]; }
-    const bool low = ln >= 1 && ln <= a.D;                // rows / column 1 + j
+        if (jc == j) { xc = x[j]; s2c = P.s2[j]; if (low) { ac = P.a[j]; bc = P.b[j]; } }
+    const double c0 = (ln == 0) ? 1.0 : 0.0, c8 = (ln == 8) ? 1.0 : 0.0, lo = low ? 1.0 : 0.0, hi = high ? 1.0 : 0.0;
+    const double ksm = (ln <= a.D) ? 1.0 : 0.0;
+    const double cx = s2c * xc;
+    struct RowTerms { double k0, vk, pg, ph, vg, al, zc; };
+    auto fetch = [&](int st) -> RowTerms {
+        const int i = wave * RPW + 4 * st + lk;
+        RowTerms t;
+        t.zc = 0.0;
+        if (jc >= 0) {
+            if (KEEP) t.zc = rows->r[i][jc];
+            else if (i >= off) t.zc = a.Z[(long)(i - off) * a.D + jc];
+        }
+        const double* rs = &ks[i][10];
+        t.k0 = rs[0]; t.vk = rs[1]; t.pg = rs[2]; t.ph = rs[3]; t.vg = rs[4]; t.al = rs[5];
+        return t;
+    };
     sr_d4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = acc1;
+    RowTerms nx = fetch(0);
 #pragma unroll
     for (int st = 0; st < KSA; ++st) {
         const int i = wave * RPW + 4 * st + lk;
-        const int src = 4 * st + lk;                      // the lane that holds row i's terms
-        double zc = 0.0;
-        if (jc >= 0) {
-            if (KEEP) zc = rows->r[i][jc];
-            else if (i >= off) zc = a.Z[(long)(i - off) * a.D + jc];
-        }
-        const double k0s = __shfl(k0, src), vks = __shfl(vk, src), pgs = __shfl(pg, src), phs = __shfl(ph, src),
-                     vgs = __shfl(vg, src), als = __shfl(al1, src);
-        const double dfc = xc - zc, uc = s2c * dfc;
-        double A1, A2 = 0.0, bsel = 0.0;
-        if (ln == 0) { A1 = k0s; bsel = 1.0; }
-        else if (ln == 8) A1 = pgs;
-        else if (low) { A1 = fma(vks, ac * zc, fma(pgs, uc, bc * zc)); A2 = vgs * uc; bsel = -dfc; }
-        else A1 = phs * uc;                                // rows 9 + j; 0 elsewhere (jc < 0: uc = 0)
-        ks[i][ln] = (ln <= a.D) ? A1 : 0.0;
-        const double bfrag = als * bsel;
+        const RowTerms t = nx;
+        if (st + 1 < KSA) nx = fetch(st + 1);
+        const double uc = fma(-s2c, t.zc, cx);                               // s_c^2 (x_c - z_c)
+        const double A1 = fma(c0, t.k0, fma(c8, t.pg, fma(t.zc, fma(t.vk, ac, bc), fma(lo, t.pg, hi * t.ph) * uc)));
+        const double A2 = lo * t.vg * uc;
+        const double bfrag = t.al * fma(lo, t.zc - xc, c0);
+        if (ln < 10) ks[i][ln] = ksm * A1;                                  // (columns 10 .. 15: the row's terms stay)
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, bfrag, acc1, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A2, bfrag, acc2, 0, 0, 0);
     }
