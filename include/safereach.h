@@ -262,8 +262,8 @@ int sr_gp_set_var_variant(sr_gp_t h, int variant);
 int sr_gp_set_fact_panel(sr_gp_t h, int panel);
 /* latency paths instead of the plain MFMA tiles: one-launch pass for small models (Np <= 512, T <= 1024),
  * HBM-bound streaming of U^-1 for batches of <= 64 queries, 64 x 64 tiles, balanced shares of the k-blocks under few
- * query tiles.  on = 1 (default) all of them, 2 all but the one-launch pass, 0 none, + 4: split-K chunks instead of the
- * balanced shares; an A/B measurement knob.  Results agree to rounding. */
+ * query tiles.  on = 1 (default) all of them, 2 all but the one-launch pass, 0 none; an A/B measurement knob.  Results
+ * agree to rounding. */
 int sr_gp_set_small_path(sr_gp_t h, int on);
 /* multi-step chains (sr_multistep_reach / sr_multistep_moments) of small ARD-RBF models (Np <= 512, <= 4096 rollouts,
  * the reference's systems n_s <= 4) run all H steps inside ONE persistent launch; on = 0 forces the per-step launches.

@@ -452,9 +452,6 @@ extern "C" int sr_gp_release_scratch(sr_gp_t h) {
 extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
     SR_CHECK(h != nullptr, SR_EINVAL, "sr_gp_set_small_path: NULL handle");
     h->small_path = on & 3;  // 0: plain three-kernel pass only; 1: all latency paths; 2: all but the fused K0
-    // A/B measurements of the few-query-tile contraction: + 4 the chunks of K2k, + 8 the balanced shares of K2b (what the
-    // choice by size takes anyway where it applies)
-    h->few_route = (on & 4) ? 1 : ((on & 8) ? 2 : 0);
     return SR_OK;
 }
 

@@ -231,7 +231,7 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_small(h->Wt, h->Ks, h->small_vp, h->var_part, h->N, h->Np, Tp, h->n_out, (int)Tc, s));
         nrb = (h->Np + 255) / 256;
-    } else if (h->small_path && h->few_route != 1 && sr_var_splitk_wanted(h->Np, Tp, h->n_out) && sr_var_bal_wanted(h->Np, Tp, h->n_out)) {
+    } else if (h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) {
         // few query tiles: equal shares of the k-blocks of all tiles, the segments of a tile added by a second launch
         const long need = sr_var_bal_ws(h->Np, Tp, h->n_out);
         if (need > h->splitk_cap) {
@@ -246,21 +246,6 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
         nrb = 4 * (h->Np / SR_NB);
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
         SR_TRY(sr_launch_var_bal(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
-    } else if (h->small_path && sr_var_splitk_wanted(h->Np, Tp, h->n_out)) {
-        // few query tiles: split the K range so that no workgroup serialises a whole row block
-        const long need = sr_var_splitk_ws(h->Np, Tp, h->n_out);
-        if (need > h->splitk_cap) {
-            (void)hipStreamSynchronize(s);
-            dev_free(h->splitk_vt);
-            h->splitk_vt = nullptr; h->splitk_cap = 0;
-            SR_TRY(dev_alloc(&h->splitk_vt, (size_t)need));
-            h->splitk_cap = need;
-        }
-        if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));  // wgs <= 1024
-        var_part = h->splitk_part;
-        nrb = 4 * (h->Np / SR_NB);
-        sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(sr_launch_var_splitk(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else if (h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out)) {
         // small model, few tiles: 64 x 64 workgroup tiles shorten the critical path of the tiny grid
         if (!h->splitk_part) SR_TRY(dev_alloc(&h->splitk_part, (size_t)4 * 1024 * srt::BN));

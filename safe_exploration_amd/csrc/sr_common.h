@@ -265,14 +265,11 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
 int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int Np, long Tp, int n_out,
                     hipStream_t s);
 
-// split-K form of the variance kernel for few query tiles (sr_predict.hip, K2k)
-// balanced form of the same regime (equal shares of the k-blocks + a reduce pass, K2b): workspace doubles; part layout of K2k
+// few query tiles: balanced shares of the k-blocks + a reduce pass (sr_predict.hip, K2b); workspace doubles; part layout
+// [d][4 nrb][Tp]
 long sr_var_bal_ws(int Np, long Tp, int n_out);
 int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np, long Tp, int n_out,
                       hipStream_t s);
-long sr_var_splitk_ws(int Np, long Tp, int n_out);
-int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,
-                         long Tp, int n_out, hipStream_t s);
 
 // small-batch (T <= 16) variance path: U^-1 streamed once at HBM rate (sr_predict.hip, K2s)
 #define SR_SMALL_T 16
@@ -300,11 +297,9 @@ int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double*
 //                                            SR_STREAM_FUSED32_MAX_NCB (8) column blocks: T = 16 N = 2000 / 3000 28 / 39 -> 25 / 34 us (r04_latency_grid)
 //   K2s streamed, groups of 16               T <= 16 x sr_var_small_groups_max (300 MB of re-read U^-1): N = 700 T = 128 41 -> 25 us,
 //                                            N = 2000 71 -> 40 us, from N = 3000 on the tiles win (r01d_latency_grid)
-//   K2b balanced shares (sr_predict.hip)     sr_var_splitk_wanted (nb > 2, <= 1024 plain workgroups) and >= 256 cells
-//                                            (sr_var_bal_wanted); 256 workgroups, 512 from 2304 cells on (r03_splitk_ab, r03_streamk)
-//   (K2x, k slabs per XCD: built in round 4, -21 % fabric bytes at the same time -- the regime is compute-side bound,
-//    profiles/r04_xcd_ablation.txt -- and removed in round 5)
-//   K2k split-K chunks                       the rest of sr_var_splitk_wanted; chunk size by splitk_kcb (<= 768 workgroups)
+//   K2b balanced shares (sr_predict.hip)     sr_var_splitk_wanted (nb > 2, <= 1024 plain workgroups): one workgroup per cell below
+//                                            256 cells, 256 workgroups up to 8192 cells, 512 beyond (r05_bal_ab); the chunked
+//                                            split-K route K2k of rounds 1 - 4 and the XCD slabs K2x of round 4 are gone
 //   K2m 64 x 64 tiles                        sr_var64_wanted: Np <= 1024 and < 256 plain workgroups (N = 200: 60 -> 31-37 us, r01d)
 //   K2  plain 128 x 128 tiles                everything else (the benchmark regime: 0.89-0.90 of the fp64 MFMA peak, r03_kernel_stats)
 //   K3  final stage                          one wavefront per (query, output) up to SR_FINAL_WAVE_T (4096) queries (44 -> 9.8 us at
@@ -366,11 +361,6 @@ static inline bool sr_var_splitk_wanted(int Np, long Tp, int n_out) {
     const int nrb = Np / SR_NB;
     const long wgs = (long)nrb * (Tp / SR_NB) * n_out;
     return nrb > 2 && wgs <= 1024;
-}
-// (below 256 cells the chunks of K2k are as good)
-static inline bool sr_var_bal_wanted(int Np, long Tp, int n_out) {
-    const long nrb = Np / SR_NB;
-    return (long)n_out * (Tp / SR_NB) * nrb * (nrb + 1) / 2 >= 256;
 }
 // workgroups of the balanced launch: one per CU, two from 8192 cells on.  Round 5, with the pipelined main loop (G = 256
 // against 512, n_out = 2, profiles/r05_bal_ab.txt): N = 5000 T = 128 (U = 1640) 142 / 148 us, T = 256 (3280) 235 / 250, T = 512

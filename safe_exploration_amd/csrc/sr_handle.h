@@ -61,8 +61,7 @@ struct sr_gp {
     size_t lin_cap = 0;                                                 // doubles behind lin_v
     double* stream_vp = nullptr; long stream_vp_cap = 0;   // fused small-batch path: partial sums (grow-only)
     unsigned* stream_tickets = nullptr;
-    double* splitk_vt = nullptr; long splitk_cap = 0;   // split-K partial tiles (grow-only)
-    int few_route = 0;                                  // few query tiles: 0 by size (K2b shares, K2k chunks), 1 K2k, 2 K2b: A/B switch
+    double* splitk_vt = nullptr; long splitk_cap = 0;   // partial products of the balanced few-query-tile route (grow-only)
     // log det(K + noise) per output as of the last <= 16-row append (read back with its status words): the blocking read of
     // sr_gp_logdet costs the exploration loop 30 us per step
     std::vector<double> logdet_host; int logdet_valid = 0;

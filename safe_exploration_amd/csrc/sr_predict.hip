@@ -438,106 +438,10 @@ int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2k: split-K form of K2 for FEW query tiles (16 < T <~ 1500 at N = 5000: batches of candidate
-// rollouts).  With so few tiles the plain kernel is serialised on its longest row block (40 k-blocks);
-// here every (row block, query tile) is cut into chunks of 8 k-blocks that run as independent
-// workgroups and store their 128 x 128 partial product; a second pass adds the chunks, squares and
-// reduces over the rows.  Same MFMA tile, same arithmetic per chunk.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void sr_var_splitk_kernel(const double* __restrict__ Wt,
-                                                               const double* __restrict__ Ks,
-                                                               double* __restrict__ Vt, int Np, long Tp,
-                                                               int nrb, int ntq, int maxch, int k_beg,
-                                                               int kcb) {
-    __shared__ double smem[srt::SMEM_DOUBLES];
-    const int x = blockIdx.x, rb = blockIdx.y;
-    const int d = blockIdx.z / maxch, ch = blockIdx.z % maxch;
-    const int k0 = max(k_beg, ch * kcb * srt::BM);
-    const int k1 = min((rb + 1) * srt::BM, (ch + 1) * kcb * srt::BM);
-    if (k0 >= k1) return;
-    const double* A = Wt + (long)d * Np * Np + (long)rb * srt::BM;
-    const double* B = Ks + (long)d * Np * Tp + (long)x * srt::BN;
-    srt::Acc acc;
-    acc.zero();
-    srt::mainloop_tn_pipe<false>(A, Np, B, Tp, k0, k1, smem, acc);
-    double* out = Vt + ((((long)d * nrb + rb) * ntq + x) * maxch + ch) * (srt::BM * srt::BN);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                out[srt::acc_row(wm, mi, lane, r) * srt::BN + srt::acc_col(wn, ni, lane)] = acc.v[mi][ni][r];
-}
-
-__global__ __launch_bounds__(256) void sr_var_splitk_reduce_kernel(const double* __restrict__ Vt,
-                                                                   double* __restrict__ part, long Tp,
-                                                                   int nrb, int ntq, int maxch, int k_beg,
-                                                                   int kcb) {
-    // one workgroup = 32 rows of one partial tile: 4 workgroups per (row block, query tile)
-    __shared__ double red[128];
-    const int x = blockIdx.x >> 2, q = blockIdx.x & 3, rb = blockIdx.y, d = blockIdx.z;
-    const int n = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const int ch0 = k_beg / (kcb * srt::BM);                    // chunks below k_beg were never written
-    const int nch = (rb + 1 + kcb - 1) / kcb;
-    const double* base = Vt + (((long)d * nrb + rb) * ntq + x) * maxch * (srt::BM * srt::BN) +
-                         (q * 32 + half * 16) * srt::BN + n;
-    double v[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = 0.0;
-    for (int c = ch0; c < nch; ++c) {
-        const double* src = base + (long)c * (srt::BM * srt::BN);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] += src[m * srt::BN];
-    }
-    double s = 0.0;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) s = fma(v[m], v[m], s);
-    if (half == 1) red[n] = s;
-    __syncthreads();
-    if (half == 0) part[((long)d * (4 * nrb) + rb * 4 + q) * Tp + (long)x * srt::BN + n] = s + red[n];
-}
-
-// k-blocks per chunk: the finest of 1, 2, 4, 8 that keeps the chunk workgroups within ~1.5 residency rounds
-// (768 of them; measured on N = 700 .. 5000, T = 32 .. 1024: a chunk of one k-block is 8 k-tiles = 7 us of
-// serial work, and the partial tiles it writes cost bandwidth, so finer is better only while everything is
-// co-resident).  N = 1024, T <= 256: 71 -> 46 us; N = 2000, T <= 128: 92 -> 63 us; N = 5000 keeps 4 / 8.
-static int splitk_kcb(int Np, long Tp, int n_out) {
-    const long nrb = Np / srt::BM;
-    for (int kcb = 1; kcb < 8; kcb *= 2) {
-        long wg = 0;
-        for (long rb = 0; rb < nrb; ++rb) wg += (rb + kcb) / kcb;
-        if (wg * (Tp / srt::BN) * n_out <= 768) return kcb;
-    }
-    return 8;
-}
-
-long sr_var_splitk_ws(int Np, long Tp, int n_out) {
-    const int nrb = Np / srt::BM;
-    const int kcb = splitk_kcb(Np, Tp, n_out);
-    const int maxch = (nrb + kcb - 1) / kcb;
-    return (long)n_out * nrb * (Tp / srt::BN) * maxch * srt::BM * srt::BN;
-}
-
-int sr_launch_var_splitk(const double* Wt, const double* Ks, double* Vt, double* part, int N, int Np,
-                         long Tp, int n_out, hipStream_t s) {
-    const int k_beg = ((Np - N) / srt::BK) * srt::BK;
-    const int nrb = Np / srt::BM, ntq = (int)(Tp / srt::BN);
-    const int kcb = splitk_kcb(Np, Tp, n_out);
-    const int maxch = (nrb + kcb - 1) / kcb;
-    hipLaunchKernelGGL(sr_var_splitk_kernel, dim3(ntq, nrb, n_out * maxch), dim3(256), 0, s, Wt, Ks, Vt, Np,
-                       Tp, nrb, ntq, maxch, k_beg, kcb);
-    SR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(sr_var_splitk_reduce_kernel, dim3(ntq * 4, nrb, n_out), dim3(256), 0, s, Vt, part, Tp,
-                       nrb, ntq, maxch, k_beg, kcb);
-    SR_HIP(hipGetLastError());
-    return SR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2b: the same regime as K2k (few query tiles), BALANCED ("stream-K" shares).  The work of the launch is the list of
+// K2b: few query tiles (<= 1024 plain workgroups on a model of more than two row blocks), BALANCED ("stream-K" shares).
+// (K2k -- every tile cut into chunks of 1 / 2 / 4 / 8 k-blocks, rounds 1 - 4 -- lost to this kernel everywhere once the main
+//  loop was the pipelined one, also below 256 cells where it used to be the default: 46 against 60 us at N = 512, T = 1100;
+//  removed in round 5, profiles/r05_bal_ab.txt.)  The work of the launch is the list of
 // k-blocks (128 k-rows of one 128 x 128 output tile), tiles ordered (output, query tile, row block DEScending: heavy tiles
 // first), blocks ascending inside a tile; workgroup g of G takes the contiguous share [g U / G, (g + 1) U / G) of its U
 // entries -- the same number of MFMAs for everybody, whatever the triangular k range of a tile (K2k cuts every tile into

@@ -17,7 +17,7 @@ timeout 400 python bench.py --workload c5 --steps 2 --warmup 1 2>>"$EV/.err" | l
 timeout 600 python bench.py --workload c4 --steps 2 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c4.json"
 timeout 300 python bench.py --workload c4 --n-train 5000 --steps 20 --warmup 3 2>>"$EV/.err" | line > "$EV/${TAG}_bench_refit5000.json"
 timeout 600 python scripts/latency_grid.py > "$EV/${TAG}_latency_grid.txt" 2>>"$EV/.err"
-timeout 300 python scripts/splitk_ab.py 2000,3000,4000,5000 128,256,512,1024 > "$EV/${TAG}_splitk_ab.txt" 2>>"$EV/.err"
+timeout 300 python scripts/bal_ab.py 2000,3000,4000,5000 128,256,512,1024 > "$EV/${TAG}_bal_grid.txt" 2>>"$EV/.err"
 timeout 300 python scripts/factor_bench.py > "$EV/${TAG}_factor_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/append_bench.py > "$EV/${TAG}_append_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/chain_bench.py > "$EV/${TAG}_chain_bench.txt" 2>>"$EV/.err"

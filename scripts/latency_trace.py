@@ -22,7 +22,7 @@ def run(N, T, H=1):
     prob = workload.make_problem(9, N, 2, 1, max(T, 8), sf2=0.01)
     gp = SimpleGPModel(2, 2, 1, kern_types=["rbf"] * 2, hyp=workload.hyp_list(prob), device="cuda:0")
     gp.train(prob["Z"], prob["Y"], opt_hyp=False)
-    if os.environ.get("SR_SMALL_PATH"):          # A/B of the routes: 1 default, 9 balanced shares, 5 split-K chunks, 0 plain tiles
+    if os.environ.get("SR_SMALL_PATH"):          # A/B of the routes: 1 default, 2 without the one-launch pass, 0 plain tiles
         gp.set_small_path(int(os.environ["SR_SMALL_PATH"]))
     x = B.as_dev(np.hstack((prob["p"][:T], prob["k_ff"][:T])), gp.device)
     for _ in range(10):
