@@ -384,7 +384,9 @@ static inline int sr_var_small_groups_max(int Np, int n_out) {
     return g < 1 ? 1 : g;
 }
 // blocks per Cholesky panel by the number of 128-blocks (measurements: sr_capi_update.hip, pick_fact_panel)
-static inline int sr_fact_panel(int nb) { return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : (nb <= 300 ? 24 : 48)))); }
+// (round 5, with the pipelined GEMM loops: at N = 50000 panels of 12 .. 24 blocks 69.0 - 69.2 TF, 32: 68.5, 48 -- round 4's choice --
+//  67.8, 64: 66.5 on one box, profiles/r05_c4_panels.txt; N = 10000 / 20000 / 30000 keep 8 / 8 / 24)
+static inline int sr_fact_panel(int nb) { return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : 24))); }
 // CUs the bulk streams of the model update leave to the critical chain (regime 1: one per shader engine, two for 36 < nb
 // <= 52; regime 2: one per XCD for the diagonal blocks)
 // regime 2 of the model update (nb > SR_FACT_CHAIN_MAX_NB): a trailing update this many times longer than the next panel's
