@@ -2,6 +2,7 @@
 // sr_mfma_tile.h): plain, split-K, upper-block-triangle (trailing update of the Cholesky) and job-table (one launch per
 // level of the recursive triangular inversion).  Launch plan: sr_capi_update.hip / sr_capi_append.hip.
 #include "sr_mfma_tile.h"
+#include <cstdlib>
 #ifndef SR_T64_PIPE
 #define SR_T64_PIPE 1     /* 64 x 64 tile: the pipelined loop of round 5 (0: the loop of round 3, for A/B builds) */
 #endif
@@ -95,22 +96,26 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_kernel(
 // One fp64 MFMA holds its SIMD for 64 cycles: a 128 x 128 tile with K = 128 is 14 us of one CU, whatever else
 // happens.  Products of few tiles are therefore latency-bound (the block row and the look-ahead row of the
 // Cholesky sit on its critical path) or balance-bound (triangular k ranges); they take the 64 x 64 tile.
+static long sr_env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
 static inline bool sr_use_tile64(long tiles128, int K = 0) {
+    static const long thr = sr_env_long("SR_T64_THR", 1024);           // (measurements)
     // ... unless K is long: then a grid that occupies the chip at least once is throughput-bound and the 64-tile's 8 flop
     // per operand byte is the limit (the in-panel updates of the N = 50000 factorisation -- 128 rows x 50000 columns, K up
     // to 2944: 21 TF on 64-tiles)
     if (K >= 768 && tiles128 >= 256) return false;
-    return tiles128 < 1024;
+    return tiles128 < thr;
 }
 // ... but a 64 x 64 tile moves 8 bytes of operands per 8 flop (K-independent): a grid of them that fills the chip is
 // bound by L2 / fabric bandwidth (N = 5000, K = 256 bulk update of two outputs: 1.7 GB in 254 us = 6.8 TB/s, 21 TF per
 // output).  THROUGHPUT-bound products (bulk trailing update, the big levels of the inversion) therefore take the
 // 128-tile (16 flop per byte) as soon as there are enough of them to occupy the chip once.
 static inline bool sr_use_tile64_bulk(long tiles128) {
-    return tiles128 < 192;
+    static const long thr = sr_env_long("SR_T64_BULK_THR", 192);
+    return tiles128 < thr;
 }
 static inline bool sr_use_tile64_jobs(long tiles128) {
-    return tiles128 < 1024;
+    static const long thr = sr_env_long("SR_T64_JOBS_THR", 1024);
+    return tiles128 < thr;
 }
 
 int sr_launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
