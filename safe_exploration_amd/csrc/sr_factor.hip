@@ -126,7 +126,8 @@ int sr_launch_gram_general(const double* Z, const double* kp, double noise, cons
 // (Round 2's form -- panel rows by forward substitution, sub-block inverses on a spare wavefront, U_kk^-1 assembled by
 // [A B; 0 C]^-1 steps at block sizes 16, 32, 64: 62 us -- and the first one, 88 us, are in the history of the repository.)
 // ------------------------------------------------------------------------------------------------
-#define SR_PD_LD 129
+#define SR_PD_LD 144     // 128 + 16: the four row groups (lane >> 4) of an MFMA operand read land 16 doubles apart modulo 32,
+                         // i.e. on disjoint LDS banks (129 = 128 + 1 made every such read a two-way conflict)
 #define SR_PD_THREADS 1024
 #define SR_PD_XLD 17
 
@@ -227,60 +228,111 @@ int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Diagonal block, round 3: factor AND inverse in ONE sweep over the 8 panels of 16 columns.
+// Diagonal block: factor AND inverse in ONE sweep over the 8 panels of 16 columns.
 // The elimination that turns A_kk into U_kk (U^-T A = U) is applied to an augmented identity at the same time, so that
-// V = U_kk^-T is complete the moment the factor is -- the separate inversion phase of the kernel above (sub-block
-// inverses + three combination levels, 5 more barriers) is gone, and so are the VALU forward substitutions:
-//   * sr_factor16_aug: the 16 x 16 pivot block in registers as before; lanes 16..31, which only mirrored lanes 0..15,
-//     now carry the columns of the identity through the same row operations: T_p = U_pp^-T at no extra instruction;
-//   * phase 1 of panel p: the panel row  U[p][c] = T_p A[p][c] (c > p)  and  V[p][c'] = T_p V[p][c'] (c' < p): seven
-//     16 x 16 tiles, 4 MFMAs each, one wavefront per tile, in place in LDS and straight to global memory;
-//   * phase 2: trailing updates  A[r][c] -= U[p][r]^T U[p][c]  (p < r <= c)  and  V[r][c'] -= U[p][r]^T V[p][c']
-//     (c' <= p < r) as independent tile jobs; wavefront 0 updates the next pivot tile from the panel tile it still
-//     holds in registers (the MFMA result layout IS the operand layout of the next product: row (lane>>4) + 4 reg,
-//     column lane & 15) and factors it at once.
+// V = U_kk^-T is complete the moment the factor is:
+//   * sr_factor16_aug: the 16 x 16 pivot tile in the registers of ONE wavefront (wavefront 0), 16 of its lanes carrying
+//     the columns of the identity through the same row operations: T_p = U_pp^-T at no extra instruction;
+//   * the panel row  U[p][c] = T_p A[p][c] (c > p)  and  V[p][c'] = T_p V[p][c'] (c' < p): seven 16 x 16 tiles, 4 MFMAs
+//     each, one wavefront per tile, in place in LDS and straight to global memory;
+//   * trailing updates  A[r][c] -= U[p][r]^T U[p][c]  (p < r <= c)  and  V[r][c'] -= U[p][r]^T V[p][c']  (c' <= p < r)
+//     as independent tile jobs of 12 worker wavefronts;
+//   * wavefront 0 -- the critical path: 128 dependent pivots -- computes the ONE tile it needs (U[p][p+1]) itself,
+//     updates the next pivot tile with it (the MFMA result layout IS the operand layout of the next product: row
+//     (lane >> 4) + 4 reg, column lane & 15) and factors it at once; it never waits for the rest of the panel row.
 //   V lives in the strict lower block triangle of S (A needs the upper one only): no second LDS matrix.
 // fp64 MFMA and fp64 VALU share the DP pipe of a SIMD: the wavefronts that sit on wavefront 0's SIMD (4, 8, 12) take no
-// MFMA job in phase 2 -- they copy the pivot stage to global memory and write the structural zeros of the outputs --,
-// else the pivot chain (the critical path: 16 dependent rsqrt / FMA sequences per panel) stalls behind their MFMAs
-// (first version of this kernel, every wavefront computing the panel tiles it needs itself: 43 us).
-// Two barriers per panel.
+// MFMA job -- they copy the pivot stage to global memory and write the structural zeros of the outputs.
+// Synchronisation: ONE LDS-only workgroup barrier per panel (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would
+// also wait for the global stores in flight, which nobody reads back) and a tile count in LDS that tells the workers when
+// the panel row is complete.
+// History (profiles/r05_diag_kernel.txt has the cycle counts): 88 us (round 1) -> 62 (sub-block inverses on a spare
+// wavefront) -> 43 (one sweep) -> 30 (round 3: pivots by v_readlane, two barriers per panel) -> 23 (this form: pivot
+// chain written for the smallest fp64 instruction count, one barrier, loads of the upper triangle only and in flight
+// together, wavefront 0 starting on the first tile while the other 15 load).  What is left: wavefront 0's 4.8k cycles per
+// panel (3.1k of them the 16 pivots) and, in the first four panels, the 35 .. 26 trailing tiles, whose 16 LDS operations
+// per tile keep the LDS busier than the pivots keep wavefront 0 (tiles resident in worker registers would halve that).
 // ------------------------------------------------------------------------------------------------
 #define SR_PD_TLD 33      // pivot stage: 16 rows of [U_pp (16 columns) | T_p = U_pp^-T (16 columns)], padded
 
 // (A square-root-free variant that takes R_j[r] from lane r with the DPP row broadcast of the fp64 ALU -- one
 //  v_fmac_f64_dpp ... row_newbcast:r per updated entry, reciprocal instead of rsqrt on the chain, the 16 square roots
-//  at the end -- was built and measured: 38 us per block against 30 with the v_readlane form below, software-pipelined
-//  or not.  DPP on the fp64 ALU is slow on this part.)
-// upper Cholesky of the 16 x 16 tile at (j0, j0) of S by one wavefront in registers.  X (LDS, 16 x SR_PD_TLD) receives
+//  at the end -- was built and measured in round 3: 38 us per block against 30 with v_readlane.  DPP on the fp64 ALU is
+//  slow on this part.)
+// upper Cholesky of a 16 x 16 tile (src, ld) by one wavefront in registers.  X (LDS, 16 x SR_PD_TLD) receives
 // [U | T], T = U^-T (lower triangular, exact zeros above; the part of U below its diagonal is scratch).
-// *fail: 1-based index of the first non-positive pivot.  Nothing but the 16 LDS writes follows the pivot chain: the
-// copies to global memory are another wavefront's job.
-__device__ __forceinline__ void sr_factor16_aug(const double* S, int j0, double* X, int* fail, int lane) {
+// src, ld: the tile (LDS), its leading dimension.  *fail: 1-based index of the first non-positive pivot (j0 + ...).
+// The copies to global memory are another wavefront's job.
+__device__ __forceinline__ void sr_factor16_aug(const double* src, long ld, int j0, double* X, int* fail, int lane) {
+    // A single wavefront is bound by instruction ISSUE here, not by latency: an fp64 operation holds the issue port of its
+    // wavefront for 8 cycles, anything else for 4, and filling the latency slots of the pivot chain with independent work
+    // buys nothing (scripts/pivot_chain.hip: chain alone 186 cycles per pivot, with the row updates 262 = 186 + their
+    // issue time).  So the 16 pivots are written for the smallest fp64 instruction count:
+    //   * lanes 32 .. 63, which only mirrored lanes 0 .. 31 (16 columns of the tile, 16 of the augmented identity), now own
+    //     the ODD rows and lanes 0 .. 31 the EVEN ones: a rank-1 update is one FMA per PAIR of rows (71 instead of 120 per
+    //     tile), its multipliers U[j][r] read back from the pivot stage in LDS -- the finished row has to go there anyway
+    //     -- with one ds_read per pair of rows, the address differing by half (two v_readlane, a hazard nop per row before);
+    //   * the finished row crosses to the other half by v_permlane32_swap (two instructions);
+    //   * pivot j = a[j][j] - U[j-1][j]^2 is taken from lane j, which has both terms, before the pending update of row j;
+    //   * 1 / sqrt(d) by two coupled Goldschmidt steps from the v_rsq_f64 seed (halving / doubling by integer adds on the
+    //     exponent), U[j][j] = d / sqrt(d) falls out of the row scaling: no select, no second residual step.
+    // Scheduling barriers keep the order (left to itself the compiler builds a left-looking form whose row j + 1 waits for
+    // a chain of j dependent FMAs, and any branch in here makes it sink the updates to their uses: 5450 -- 6100 cycles per
+    // tile against 2.7k).  A non-positive pivot takes no branch: it leaves NaN in every row after it.
     const int c = lane & 15;
-    const bool aug = (lane & 16) != 0;              // lanes 16..31 (and their mirrors 48..63): columns of the identity
-    double a[16];
+    const bool aug = (lane & 16) != 0;              // lanes 16..31, 48..63: columns of the identity
+    const int hf = lane >> 5;                       // rows 2 k + hf
+    double b[8], u[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = aug ? ((r == c) ? 1.0 : 0.0) : S[(j0 + r) * SR_PD_LD + j0 + c];
+    for (int k = 0; k < 8; ++k) b[k] = aug ? ((2 * k + hf == c) ? 1.0 : 0.0) : src[(2 * k + hf) * ld + c];
+    const double* Xh = X + hf;
+    double sp = 0.0;                                // row j - 1 of [U | U^-T], in both halves
+#define SR_PV_SB __builtin_amdgcn_sched_barrier(0)
+#define SR_PV_U(k_) if (j > 0 && (k_) >= (j >> 1)) u[k_] = Xh[(j > 0 ? j - 1 : 0) * SR_PD_TLD + 2 * (k_)];
+#define SR_PV_F(i_) if (j > 0 && (j >> 1) + (i_) < 8) b[((j >> 1) + (i_)) & 7] = fma(-u[((j >> 1) + (i_)) & 7], sp, b[((j >> 1) + (i_)) & 7]);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        double d = sr_readlane_f64(a[j], j);       // pivot: wavefront-uniform
-        if (!(d > 0.0)) {                          // also catches NaN
-            if (lane == 0 && *fail == 0) *fail = j0 + j + 1;
-            d = 1.0;
-        }
-        double sd, inv;
-        sr_sqrt_rsqrt(d, sd, inv);
-        a[j] = (!aug && c == j) ? sd : a[j] * inv; // row j of [U | U^-T]
-#pragma unroll
-        for (int r = j + 1; r < 16; ++r) {
-            const double ujr = sr_readlane_f64(a[j], r);     // U[j][r]: wavefront-uniform
-            a[r] = fma(-ujr, a[j], a[r]);
-        }
+        const int kj = j >> 1, ho = j & 1;
+        SR_PV_U(0) SR_PV_U(1) SR_PV_U(2) SR_PV_U(3) SR_PV_U(4) SR_PV_U(5) SR_PV_U(6) SR_PV_U(7)
+        SR_PV_SB;
+        const double t = (j > 0) ? fma(-sp, sp, b[kj]) : b[kj];
+        const double d = sr_readlane_f64(t, j + 32 * ho);      // pivot: wavefront-uniform
+        SR_PV_SB;
+        const double y = __builtin_amdgcn_rsq(d);
+        SR_PV_SB;
+        double g = d * y;
+        double h = __hiloint2double(__double2hiint(y) - 0x00100000, __double2loint(y));
+        SR_PV_SB;
+        const double r = fma(-h, g, 0.5);
+        SR_PV_SB;
+        g = fma(g, r, g);
+        h = fma(h, r, h);
+        SR_PV_SB;
+        const double r2 = fma(-h, g, 0.5);
+        const double hh = __hiloint2double(__double2hiint(h) + 0x00100000, __double2loint(h));
+        SR_PV_F(0) SR_PV_F(1) SR_PV_F(2)
+        SR_PV_SB;
+        const double inv = fma(hh, r2, hh);
+        SR_PV_F(3) SR_PV_F(4) SR_PV_F(5)
+        SR_PV_SB;
+        SR_PV_F(6) SR_PV_F(7)
+        const double so = b[kj] * inv;               // row j, in the half that owns it
+        SR_PV_SB;
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(so), (unsigned)__double2loint(so), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(so), (unsigned)__double2hiint(so), false, false);
+        sp = __hiloint2double((int)hi[ho], (int)lo[ho]);
+        X[j * SR_PD_TLD + (lane & 31)] = sp;         // both halves: same value, same address
+        SR_PV_SB;
     }
-    if (lane < 32) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) X[r * SR_PD_TLD + lane] = a[r];
+#undef SR_PV_F
+#undef SR_PV_U
+#undef SR_PV_SB
+    // a bad pivot leaves NaN in every row after it: the last diagonal entry tells (wavefront-uniform branch)
+    const double last = sr_readlane_f64(sp, 15);
+    if (!(last > 0.0 && last < __builtin_inf())) {
+        const double sd = X[c * SR_PD_TLD + c];
+        const unsigned long long okm = __ballot(sd > 0.0 && sd < __builtin_inf());
+        if (lane == 0 && *fail == 0) *fail = j0 + __builtin_ctzll(~okm | (1ull << 16)) + 1;
     }
 }
 
@@ -297,6 +349,23 @@ __device__ __forceinline__ d4_t sr_pd_panel_tile(const double* S, const double* 
     return acc;
 }
 
+// LDS-only workgroup barrier: __syncthreads() also waits for the global stores in flight (vmcnt(0)), and this kernel
+// streams its results to global memory all the way through without ever reading them back
+__device__ __forceinline__ void sr_pd_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// count of panel tiles in LDS (monotonic over the kernel): a wavefront adds one when its tile of panel row p is written,
+// the wavefronts that need the whole row wait for 7 (p + 1).  LDS executes the operations of a wavefront in order, so
+// whoever sees the count sees the tile; the compiler is held by the asm statements.
+__device__ __forceinline__ void sr_pd_signal(int* cnt, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void sr_pd_wait(int* cnt, int target) {
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
 __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
                                                                          double* wt_diag, double* w_diag,
                                                                          long ldw, int kb, int* info, int skip,
@@ -304,7 +373,7 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
     // skip (sr_test_potrf_diag; 0 in production): 64 = leave A untouched (back-to-back timing on one input)
     __shared__ double S[SR_NB * SR_PD_LD];
     __shared__ double Xb[2][16 * SR_PD_TLD];
-    __shared__ int fail;
+    __shared__ int fail, done;
     A += (long)blockIdx.x * bt.sA; wt_diag += (long)blockIdx.x * bt.sB; w_diag += (long)blockIdx.x * bt.sC;
     info += blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -314,127 +383,197 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
     const bool storeA = !(skip & 64);
     double* Ag = A + k0 * lda + k0;
     __builtin_amdgcn_s_setprio(3);
-    if (tid == 0) fail = 0;
-    for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        S[r * SR_PD_LD + c] = (c >= r) ? Ag[(long)r * lda + c] : 0.0;       // strict lower triangle: V = 0 off its diagonal
-    }
-    __syncthreads();
-    if (wave == 0) sr_factor16_aug(S, 0, Xb[0], &fail, lane);
-    __syncthreads();
-    // wavefront -> role in phase 2: 0 pivots; 4, 8, 12 (same SIMD as 0) stores only; the other 12 the MFMA jobs
+    if (tid == 0) { fail = 0; done = 0; }
+    // wavefront -> role: 0 the pivots; 1 .. 6 a tile of the panel row each, then trailing-update jobs; 4, 8, 12 (the SIMD
+    // of wavefront 0: fp64 MFMA and fp64 VALU share its DP pipe, MFMA jobs there stall the pivot chain) stores only
+    // (4: one panel tile too); the other 12 are the MFMA workers of the trailing update.
     const bool simd0 = (wave & 3) == 0;
     const int worker = wave - 1 - (wave >> 2);             // 0 .. 11 for the MFMA wavefronts
     constexpr int NWORK = 12;
-    for (int p = 0; p < SR_NB / 16; ++p) {
+    if (wave != 0) {
+        // the 36 upper tiles come from global memory -- every load in flight before the first LDS write, and issued a
+        // little AFTER the eight loads of wavefront 0, which would otherwise queue behind these 150 --, the 28 strictly
+        // lower ones (V = 0 off its diagonal) are zero-filled while the loads fly
+        constexpr int NT = SR_NB / 16, NUP = NT * (NT + 1) / 2 * 256, NLO = NT * (NT - 1) / 2 * 256;
+        constexpr int NTH = SR_PD_THREADS - 64, NLD = (NUP + NTH - 1) / NTH, NZ = (NLO + NTH - 1) / NTH;
+        const auto tri = [](int t) { return (t >= 1) + (t >= 3) + (t >= 6) + (t >= 10) + (t >= 15) + (t >= 21) + (t >= 28); };
+        __builtin_amdgcn_s_sleep(4);
+        double v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = tid - 64 + i * NTH, tile = m >> 8, e = m & 255;
+            const int tc = tri(tile), tr = tile - tc * (tc + 1) / 2;         // column-major upper triangle
+            const int r = 16 * tr + (e >> 4), c = 16 * tc + (e & 15);
+            v[i] = (m < NUP && c >= r) ? Ag[(long)r * lda + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+            const int m = tid - 64 + i * NTH, tile = m >> 8, e = m & 255;
+            const int tr = tri(tile) + 1, tc = tile - tr * (tr - 1) / 2;     // row-major strict lower triangle
+            if (m < NLO) S[(16 * tr + (e >> 4)) * SR_PD_LD + 16 * tc + (e & 15)] = 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = tid - 64 + i * NTH, tile = m >> 8, e = m & 255;
+            const int tc = tri(tile), tr = tile - tc * (tc + 1) / 2;
+            if (m < NUP) S[(16 * tr + (e >> 4)) * SR_PD_LD + 16 * tc + (e & 15)] = v[i];
+        }
+    }
+    // Panel p = -1 is the prologue: wavefront 0 factors the first pivot tile straight from global memory while the other
+    // 15 bring the block into LDS (one copy of the pivot code in the kernel: it starts cold in the instruction cache of
+    // whatever CU the launch lands on).
+    // ONE workgroup barrier per panel.  Wavefront 0 never waits for the panel row: it computes the one tile it needs
+    // (U[p][p+1]) itself, updates the next pivot tile with it and factors that -- 16 dependent pivots, the critical path
+    // -- while the others compute the rest of the row, count their tiles in, and run the trailing update of panel p once
+    // the count says the row is complete.
+    for (int p = -1; p < SR_NB / 16; ++p) {
         const int j0 = 16 * p;
         const double* X = Xb[p & 1];
         const int nbt = SR_NB / 16 - 1 - p;
-        // ---- phase 1: the seven tiles of panel row p, in place: wavefront w takes tile w (0: the next pivot's column)
-        d4_t mine = {0.0, 0.0, 0.0, 0.0};
-        if (wave < SR_NB / 16 - 1) {
-            const int ct = (wave < nbt) ? p + 1 + wave : wave - nbt;         // tile column: A part c > p, then V part c' < p
-            const int c0 = 16 * ct;
-            mine = sr_pd_panel_tile(S, X, j0, c0, lk, ln);
-            if (wave != 0 || nbt == 0) {
+        {
+            const int target = (SR_NB / 16 - 1) * (p + 1);
+            if (wave == 0 && nbt > 0 && p < 0) {
+                // first pivot tile: global memory -> LDS, then the one copy of the pivot code below (a second copy reading
+                // global memory would start cold in the instruction cache once more)
+                int z = 0;
+                asm volatile("" : "+v"(z));              // keeps these addresses out of the registers of the whole loop
 #pragma unroll
-                for (int q = 0; q < 4; ++q) S[(j0 + lk + 4 * q) * SR_PD_LD + c0 + ln] = mine[q];
-            }
-            if (ct > p) {
-                if (storeA && wave != 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Ag[(long)(j0 + lk + 4 * q) * lda + c0 + ln] = mine[q];
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w_diag[(long)(j0 + lk + 4 * q) * ldw + c0 + ln] = mine[q];
-                    wt_diag[(long)(c0 + ln) * ldw + j0 + lk + 4 * q] = mine[q];
-                }
-            }
-        }
-        if (wave == 0 && nbt > 0) {
-            // the panel tile of the next pivot's column is needed by the others too (row p + 1 of the trailing update)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) S[(j0 + lk + 4 * q) * SR_PD_LD + j0 + 16 + ln] = mine[q];
-        }
-        __syncthreads();
-        // ---- phase 2
-        if (wave == 0) {
-            if (nbt > 0) {
-                d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mine[kk], mine[kk], acc, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) S[(j0 + 16 + lk + 4 * q) * SR_PD_LD + j0 + 16 + ln] -= acc[q];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // the tile update above, then its reads below
-                sr_factor16_aug(S, j0 + 16, Xb[(p + 1) & 1], &fail, lane);
-            }
-        } else if (!simd0) {
-            const int nA = nbt * (nbt + 1) / 2;        // trailing tiles of A; tile 0 is wavefront 0's
-            const int nV = nbt * (p + 1);              // trailing tiles of V
-            for (int e = 1 + worker; e < nA + nV; e += NWORK) {
-                int r0, c0;
-                bool useT = false;
-                if (e < nA) {
-                    int ti = 0, rem = e;
-                    while (rem >= nbt - ti) { rem -= nbt - ti; ++ti; }
-                    r0 = 16 * (p + 1 + ti);
-                    c0 = r0 + 16 * rem;
-                } else {
-                    const int v = e - nA, ti = v / (p + 1), cq = v % (p + 1);
-                    r0 = 16 * (p + 1 + ti);
-                    c0 = 16 * cq;
-                    useT = (cq == p);                   // V[p][p] after the panel step is T itself (kept in the pivot stage)
-                }
-                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                for (int q = 0; q < 4; ++q) S[(lk + 4 * q) * SR_PD_LD + ln] = Ag[(long)(lk + 4 * q + z) * lda + ln];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                sr_factor16_aug(&S[0], SR_PD_LD, 0, Xb[0], &fail, lane);
+            } else if (wave == 0 && nbt > 0) {
+                // U[p][p+1] = T_p A[p][p+1]; next pivot tile -= U[p][p+1]^T U[p][p+1]; factor it.  All operands in one
+                // LDS round trip; the MFMA result layout IS the operand layout of the next product.
+                const int c0 = j0 + 16;
+                double af[4], bf[4];
+                d4_t cc, mine = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const double af = S[(j0 + 4 * kk + lk) * SR_PD_LD + r0 + ln];
-                    const double bf = useT ? X[(4 * kk + lk) * SR_PD_TLD + 16 + ln] : S[(j0 + 4 * kk + lk) * SR_PD_LD + c0 + ln];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+                    af[kk] = X[ln * SR_PD_TLD + 16 + 4 * kk + lk];
+                    bf[kk] = S[(j0 + 4 * kk + lk) * SR_PD_LD + c0 + ln];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) S[(r0 + lk + 4 * q) * SR_PD_LD + c0 + ln] -= acc[q];
-            }
-        } else {
-            const int sw = (wave >> 2) - 1;            // 0, 1, 2
-            if (sw == 0) {
-                // the pivot stage of this panel: U_pp (zeros below its diagonal), T_p (lower) and T_p^T (upper)
+                for (int q = 0; q < 4; ++q) cc[q] = S[(c0 + lk + 4 * q) * SR_PD_LD + c0 + ln];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = lk + 4 * q;
-                    const double u = X[r * SR_PD_TLD + ln], t = X[r * SR_PD_TLD + 16 + ln];
-                    if (storeA) Ag[(long)(j0 + r) * lda + j0 + ln] = (r <= ln) ? u : 0.0;
-                    w_diag[(long)(j0 + r) * ldw + j0 + ln] = t;
-                    wt_diag[(long)(j0 + ln) * ldw + j0 + r] = t;
-                }
-                if (nbt > 0 && storeA) {                // wavefront 0 left the store of U[p][p+1] to us
+                for (int kk = 0; kk < 4; ++kk) mine = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], mine, 0, 0, 0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        Ag[(long)(j0 + lk + 4 * q) * lda + j0 + 16 + ln] = S[(j0 + lk + 4 * q) * SR_PD_LD + j0 + 16 + ln];
-                }
-            }
-            // structural zeros: 28 pairs (strictly-lower tile (zr, zc) of A and U^-1, its mirror of U^-T), 4 per panel,
-            // wavefronts 8 and 12 two each (wavefront 4 has the pivot stage)
-            if (sw > 0 && p < 7) {
-                for (int i = 0; i < 2; ++i) {
-                    int z = 4 * p + 2 * (sw - 1) + i, zr = 1;
-                    while (z >= zr) { z -= zr; ++zr; }
-                    const int zc = z;
+                for (int q = 0; q < 4; ++q) S[(j0 + lk + 4 * q) * SR_PD_LD + c0 + ln] = mine[q];   // row p + 1 of the trailing update
+                sr_pd_signal(&done, lane);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-mine[kk], mine[kk], cc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[(c0 + lk + 4 * q) * SR_PD_LD + c0 + ln] = cc[q];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // the tile update above, then its reads below
+                sr_factor16_aug(&S[c0 * SR_PD_LD + c0], SR_PD_LD, c0, Xb[(p + 1) & 1], &fail, lane);
+            } else if (p >= 0 && wave < SR_NB / 16 - 1) {
+                // the other tiles of panel row p, in place: wavefront w takes tile w
+                const int ct = (wave < nbt) ? p + 1 + wave : wave - nbt;     // tile column: A part c > p, then V part c' < p
+                const int c0 = 16 * ct;
+                const d4_t mine = sr_pd_panel_tile(S, X, j0, c0, lk, ln);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[(j0 + lk + 4 * q) * SR_PD_LD + c0 + ln] = mine[q];
+                sr_pd_signal(&done, lane);
+                if (ct > p) {
+                    if (storeA) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Ag[(long)(j0 + lk + 4 * q) * lda + c0 + ln] = mine[q];
+                    }
+                } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const long rr = 16 * zr + lk + 4 * q, cc = 16 * zc + ln;
-                        if (storeA) Ag[rr * lda + cc] = 0.0;
-                        wt_diag[rr * ldw + cc] = 0.0;
-                        w_diag[(long)(16 * zc + lk + 4 * q) * ldw + 16 * zr + ln] = 0.0;
+                        w_diag[(long)(j0 + lk + 4 * q) * ldw + c0 + ln] = mine[q];
+                        wt_diag[(long)(c0 + ln) * ldw + j0 + lk + 4 * q] = mine[q];
+                    }
+                }
+            }
+            if (p >= 0 && wave != 0) {
+                sr_pd_wait(&done, target);
+                if (!simd0) {
+                    // ---- trailing updates  A[r][c] -= U[p][r]^T U[p][c]  (p < r <= c)  and  V[r][c'] -= U[p][r]^T V[p][c']
+                    const int nA = nbt * (nbt + 1) / 2;        // trailing tiles of A; tile 0 is wavefront 0's
+                    const int nV = nbt * (p + 1);              // trailing tiles of V
+                    // Each job: operands AND the tile to be updated in ONE LDS round trip (left to the compiler: read, wait,
+                    // MFMA, four times over, then the read-modify-write: 1800 cycles per job instead of 1100).  Job -> tile
+                    // without loops or divisions (a quarter of the instructions of a job were its index arithmetic).
+                    // (Prefetching the next job's operands under the MFMAs of this one was measured slower.)
+                    const int ne = nA + nV;
+                    const int rcp = (65536 + p) / (p + 1);                 // v / (p + 1) = (v * rcp) >> 16 for v < 64
+                    for (int e = 1 + worker; e < ne; e += NWORK) {
+                        int r0, c0;
+                        bool useT = false;
+                        if (e < nA) {
+                            // row ti of the triangle has nbt - ti tiles; f counts from the far end, where row 7-.. has 1, 2, 3 ...
+                            const int f = nA - 1 - e;                      // 0 .. nA - 1, last tile first
+                            const int g = (f >= 1) + (f >= 3) + (f >= 6) + (f >= 10) + (f >= 15) + (f >= 21);   // rows from the end
+                            const int ti = nbt - 1 - g, rem = (nbt - ti) - 1 - (f - g * (g + 1) / 2);
+                            r0 = 16 * (p + 1 + ti);
+                            c0 = r0 + 16 * rem;
+                        } else {
+                            const int v = e - nA, ti = (v * rcp) >> 16, cq = v - ti * (p + 1);
+                            r0 = 16 * (p + 1 + ti);
+                            c0 = 16 * cq;
+                            useT = (cq == p);           // V[p][p] after the panel step is T itself (kept in the pivot stage)
+                        }
+                        const double* bsrc = useT ? &X[lk * SR_PD_TLD + 16 + ln] : &S[(j0 + lk) * SR_PD_LD + c0 + ln];
+                        const int bld = useT ? 4 * SR_PD_TLD : 4 * SR_PD_LD;
+                        double af[4], bf[4];
+                        d4_t cc;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            af[kk] = S[(j0 + 4 * kk + lk) * SR_PD_LD + r0 + ln];
+                            bf[kk] = bsrc[kk * bld];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) cc[q] = S[(r0 + lk + 4 * q) * SR_PD_LD + c0 + ln];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) cc = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[kk], bf[kk], cc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) S[(r0 + lk + 4 * q) * SR_PD_LD + c0 + ln] = cc[q];
+                    }
+                } else {
+                    const int sw = (wave >> 2) - 1;            // 0, 1, 2
+                    if (sw == 0) {
+                        // the pivot stage of this panel: U_pp (zeros below its diagonal), T_p (lower) and T_p^T (upper)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = lk + 4 * q;
+                            const double u = X[r * SR_PD_TLD + ln], t = X[r * SR_PD_TLD + 16 + ln];
+                            if (storeA) Ag[(long)(j0 + r) * lda + j0 + ln] = (r <= ln) ? u : 0.0;
+                            w_diag[(long)(j0 + r) * ldw + j0 + ln] = t;
+                            wt_diag[(long)(j0 + ln) * ldw + j0 + r] = t;
+                        }
+                        if (nbt > 0 && storeA) {                // wavefront 0 left the store of U[p][p+1] to us
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                Ag[(long)(j0 + lk + 4 * q) * lda + j0 + 16 + ln] = S[(j0 + lk + 4 * q) * SR_PD_LD + j0 + 16 + ln];
+                        }
+                    }
+                    // structural zeros: 28 pairs (strictly-lower tile (zr, zc) of A and U^-1, its mirror of U^-T), 4 per
+                    // panel, wavefronts 8 and 12 two each (wavefront 4 has the pivot stage)
+                    if (sw > 0 && p < 7) {
+                        for (int i = 0; i < 2; ++i) {
+                            int z = 4 * p + 2 * (sw - 1) + i, zr = 1;
+                            while (z >= zr) { z -= zr; ++zr; }
+                            const int zc = z;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const long rr = 16 * zr + lk + 4 * q, cc = 16 * zc + ln;
+                                if (storeA) Ag[rr * lda + cc] = 0.0;
+                                wt_diag[rr * ldw + cc] = 0.0;
+                                w_diag[(long)(16 * zc + lk + 4 * q) * ldw + 16 * zr + ln] = 0.0;
+                            }
+                        }
                     }
                 }
             }
         }
-        __syncthreads();
+        sr_pd_barrier();
     }
     if (fail) {
+        __syncthreads();                                // every store above has landed before the block is replaced
         if (tid == 0 && *info == 0) *info = (int)k0 + fail;
         // keep downstream kernels finite: identity block
         for (int idx = tid; idx < SR_NB * SR_NB; idx += SR_PD_THREADS) {

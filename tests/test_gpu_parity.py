@@ -91,6 +91,20 @@ def test_potrf_diag_block_matches_numpy(seed, cond):
     check(lib.sr_test_potrf_diag(0, B.ptr(tA), 128, B.ptr(wt2), B.ptr(w2), 128, B.ptr(info), 0, B.stream_ptr(dev)))
     assert int(info.item()) == 70
     assert np.array_equal(B.to_numpy(wt2), np.eye(128)) and np.array_equal(B.to_numpy(w2), np.eye(128))
+    # the first bad pivot wherever it sits in a 16-pivot tile (first / last pivot of a tile, first / last tile), also when
+    # it is a NaN, and when a second bad pivot follows (the branch-free pivot chain finds it from the NaNs it leaves behind)
+    for pos, val, extra in ((0, -1.0, None), (15, 0.0, None), (16, -2.0, None), (31, np.nan, None), (112, -1.0, 120),
+                            (127, -1e-300, None), (5, -1.0, 6)):
+        bad = A.copy()
+        bad[pos, pos] = val
+        if extra is not None:
+            bad[extra, extra] = -1.0
+        tA = B.as_dev(bad, dev)
+        info.zero_()
+        check(lib.sr_test_potrf_diag(0, B.ptr(tA), 128, B.ptr(wt2), B.ptr(w2), 128, B.ptr(info), 0, B.stream_ptr(dev)))
+        assert int(info.item()) == pos + 1, (pos, val, int(info.item()))
+        assert np.array_equal(B.to_numpy(wt2), np.eye(128)) and np.array_equal(B.to_numpy(w2), np.eye(128))
+        assert np.array_equal(B.to_numpy(tA), np.eye(128))
 
 
 # ------------------------------------------------------------------ GP fit + predict
