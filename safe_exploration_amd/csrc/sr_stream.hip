@@ -522,11 +522,17 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
     const double* ksrc = a.Ks + (long)d * a.Np * a.Tp + (long)k0 * a.Tp + c0;
 
     // K* rows of stage `sub` that this thread moves (element e = tid + 1024 m: row e / NC, column e % NC)
+    // (Every global load of the main loop is UNCONDITIONAL -- a clamped address and a select instead of a predicate, the
+    //  current stage fetched once more instead of `if (more)`: behind a load that may or may not have been issued the
+    //  compiler's s_waitcnt has to assume it was not, and the wavefronts drained their whole queue, the next batch
+    //  included, at the end of every stage: T = 64 at N = 5000 86 us with the MFMA pipe 50 % busy.)
     auto ks_fetch = [&](int sub, double (&pf)[PF]) {
 #pragma unroll
         for (int m = 0; m < PF; ++m) {
             const int e = tid + 1024 * m, r = sub * SUB + e / NC, t = e % NC;
-            pf[m] = (c0 + t < a.ncols_pad) ? ksrc[(long)r * a.Tp + t] : 0.0;
+            const bool in = c0 + t < a.ncols_pad;
+            const double v = ksrc[(long)r * a.Tp + (in ? t : 0)];
+            pf[m] = in ? v : 0.0;
         }
     };
     auto ks_put = [&](int buf, const double (&pf)[PF]) {
@@ -554,29 +560,46 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
     for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * q) * a.Np];
     ks_put(0, pf);
     __syncthreads();
-    // BPS = 2: the even batch of a stage requests the next stage's K* rows, the odd one stores them and ends the stage
+    // One stage = 2 UB k-steps of 4 rows: A-fragment of the step (A0: first half, A1: second half, each requested half a
+    // stage ahead, ONE load per step), G B-fragments out of the LDS stage, G MFMAs.  The B-fragments run PD steps ahead of
+    // their MFMAs in a ring of registers: read, wait, multiply in turn -- as the compiler arranges it -- ties every pair of
+    // MFMAs to an LDS round trip; a wavefront then fills 40 % of the pipe, the oldest one of a SIMD is served first and
+    // the last one runs alone at the end of every stage (measured at T = 64, N = 5000: wavefront 0 through its 64 MFMAs
+    // after 11.3k cycles, at the barrier for 8.8k more; 20.9k per stage against 16.4k of MFMA time).  Scheduling barriers
+    // pin the order.  The stage barrier is LDS-only: __syncthreads() would drain the A-fragments in flight.
+    constexpr int PD = (G == 4) ? 1 : (G == 2 ? 2 : 4), NR = PD + 1;
     for (int sub = 0; sub < nsub; ++sub) {
         const double* kb = ks[sub & 1] + lk * LDK + ln;
         const bool more = sub + 1 < nsub;
-        if (more) ks_fetch(sub + 1, pf);
+        const int sn = more ? sub + 1 : sub;                  // the last stage fetches itself again (unused)
+        double Bq[NR][G];
 #pragma unroll
-        for (int q = 0; q < UB; ++q) A1[q] = w[(long)(4 * ((2 * sub + 1) * UB + q)) * a.Np];
+        for (int i = 0; i < PD; ++i)
 #pragma unroll
-        for (int q = 0; q < UB; ++q)
+            for (int g = 0; g < G; ++g) Bq[i][g] = kb[4 * i * LDK + 16 * g];
+#pragma unroll
+        for (int qq = 0; qq < 2 * UB; ++qq) {
+            // the further a wavefront is into its stage, the lower its priority: the SIMD serves its OLDEST wavefront first,
+            // and the youngest used to be left with half its stage to run alone (at 82 % of the pipe) behind the others
+            if (qq == 0) __builtin_amdgcn_s_setprio(3);
+            if (qq == UB / 2) __builtin_amdgcn_s_setprio(2);
+            if (qq == UB) __builtin_amdgcn_s_setprio(1);
+            if (qq == UB + UB / 2) __builtin_amdgcn_s_setprio(0);
+            if (qq == 0) ks_fetch(sn, pf);
+            if (qq < UB) A1[qq] = w[(long)(4 * ((2 * sub + 1) * UB + qq)) * a.Np];
+            else A0[qq - UB] = w[(long)(4 * ((2 * sn) * UB + qq - UB)) * a.Np];
+            if (qq + PD < 2 * UB) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) Bq[(qq + PD) % NR][g] = kb[4 * (qq + PD) * LDK + 16 * g];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[q], kb[4 * q * LDK + 16 * g], acc[g], 0, 0, 0);
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * ((2 * sub + 2) * UB + q)) * a.Np];
+                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(qq < UB ? A0[qq] : A1[qq - UB], Bq[qq % NR][g], acc[g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int q = 0; q < UB; ++q)
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[q], kb[4 * (UB + q) * LDK + 16 * g], acc[g], 0, 0, 0);
         if (more) ks_put((sub + 1) & 1, pf);                  // (that buffer was last read in stage sub - 1)
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // acc[g][r] = V[column i0 + lk + 4r][query 16 g + ln]; strips beyond the matrix (last column block) report zeros
     const bool live = cb * SR_ST_COLS + 16 * wave < a.Np;
