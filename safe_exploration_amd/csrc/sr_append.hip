@@ -3,6 +3,7 @@
 // (the reference refactorises; its row-append sketch: ssm_pytorch/utilities.py:74-117).
 #include "sr_mfma_tile.h"
 #include "sr_pivot_dev.h"
+#include "sr_final_dev.h"
 
 // ---- helpers of the block row-append update (sr_gp_append) --------------------------------------
 // S[r][c] -= G[r][c] on the real block r, c >= pf of a front-padded 128 x 128 tile
@@ -412,6 +413,277 @@ int sr_launch_append1_small(const double* Wt0, const double* alpha0, const doubl
     }
     if (Np0 <= 256) hipLaunchKernelGGL(sr_append1_small_kernel<256>, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(sr_append1_small_kernel<512>, dim3(n_out, SR_APPEND1_WGS), dim3(1024), 0, s, a);
+    SR_HIP(hipGetLastError());
+    return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE new point on a model of up to SR_APPEND1G_MAX_NP0 padded rows, in ONE launch of a GRID of workgroups (the general
+// route below takes 10 dependent launches: 93 us of mostly launch latency at N = 1000, where the arithmetic needs 15).
+// gridDim = (n_out, W); the W workgroups of an output meet twice at a device-wide barrier (a counter in device memory that
+// only grows: the arrivals of all launches so far + W, + 2 W as targets).  Every workgroup of the grid must be resident at
+// once: one fits a CU (73 KB of LDS, 1024 threads, ~100 registers), the host keeps n_out W below 7/8 of the CUs.
+//   every workgroup:  b = K(Z_old, z_new) and mu_old = b . alpha0 (N kernel evaluations: cheaper than handing them over)
+//   phase 1  workgroup w: vp[w][c] = sum over ITS rows k = off0 + w, + W, .. <= c of U^-1[k][c] b[k]   (rows read as rows)
+//   -- barrier --
+//   phase 2  256 columns at a time: u12[c] = sum_w vp[w][c] in the order of w, gpart[cb] = sum_c u12[c]^2
+//   -- barrier --
+//   every workgroup:  s = k(z, z) + noise - sum_cb gpart[cb], u22^-1 = 1 / sqrt(s), X = u12 u22^-1 (LDS), v2
+//   phase 3  the rows of the new factor, wavefront per row as in sr_append_move_kernel: the old row moved to the new
+//            padding (upper part only: the target holds zeros below the diagonal and its identity padding, see the host),
+//            its new last entry y2 = -sum_{k >= row} U^-1[row][k] X[k], alpha1 = alpha0 + y2 v2, the shifted targets,
+//            the new point's row, sum of log(diagonal) per workgroup.
+// What one workgroup hands to another goes out with agent-scope stores and comes in with agent-scope loads (the L2s of
+// the XCDs are not coherent with each other); the barrier itself is a relaxed agent-scope counter.
+// ------------------------------------------------------------------------------------------------
+struct sr_append1g_args {
+    sr_append1_args a;
+    double* vp; double* u12; double* gpart;      // n_out x W x Np0, n_out x Np0, n_out x ncb
+    unsigned* cnt; unsigned base;                // n_out counters (zero at allocation), arrivals of all launches so far
+    int ncb, npairs;
+};
+
+__device__ __forceinline__ void sr_appg_barrier(unsigned* cnt, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args g) {
+    const sr_append1_args& a = g.a;
+    __shared__ double b[SR_APPEND1G_MAX_NP0];                // b, then X
+    __shared__ double part[4][256];
+    __shared__ double red[16];
+    __shared__ double s_mu, s_inv, s_v2;
+    __shared__ double zn[SR_MAX_D];
+    const int d = blockIdx.x, w = blockIdx.y, W = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N0 = a.N0, Np0 = a.Np0, Np1 = a.Np1, D = a.D;
+    if (tid < D) zn[tid] = a.inl ? a.xin[tid] : a.znew[tid];
+    const double y_new = a.inl ? a.yin[d] : a.ynew[d];
+    __syncthreads();
+    const int off0 = Np0 - N0, off1 = Np1 - (N0 + 1), shift = off1 - off0;
+    const double* Wt0 = a.Wt0 + (long)d * Np0 * Np0;
+    const double* alpha0 = a.alpha0 + (long)d * Np0;
+    double* Wt1 = a.Wt1 + (long)d * Np1 * Np1;
+    if (d == 0 && w == 0 && a.Zdst && tid < D) a.Zdst[tid] = zn[tid];
+    // ---- b = K(Z_old, z_new) in padded row indexing, mu_old = b . alpha0 (as sr_append1_small_kernel)
+    double mu_t = 0.0;
+#pragma unroll 2
+    for (int row = tid; row < Np0; row += 1024) {
+        double v = 0.0;
+        if (row >= off0) {
+            const double* z = a.Z + (long)(row - off0) * D;
+            if (a.kp) {
+                const double* kp = a.kp + (long)d * SR_KP(D);
+                const double *sv = kp + 3, *av = kp + 3 + D, *bv = kp + 3 + 2 * D;
+                double r2 = 0.0, la = 0.0, lb = 0.0;
+                for (int c = 0; c < D; ++c) {
+                    const double t = (z[c] - zn[c]) * sv[c];
+                    r2 = fma(t, t, r2);
+                    la = fma(av[c] * z[c], zn[c], la);
+                    lb = fma(bv[c] * z[c], zn[c], lb);
+                }
+                v = (kp[2] + la) * kp[1] * sr_kappa((int)kp[0], r2) + lb;
+            } else {
+                double r2 = 0.0;
+                for (int c = 0; c < D; ++c) {
+                    const double t = (z[c] - zn[c]) / a.ls[d * D + c];
+                    r2 = fma(t, t, r2);
+                }
+                v = a.sf2[d] * exp(-0.5 * r2);
+            }
+            mu_t += v * alpha0[row];
+        }
+        b[row] = v;
+    }
+    auto wave_sum = [](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    auto block_sum = [&](double v) {                         // fixed order: wavefront sums, then wavefront 0 .. 15
+        const double ws = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = ws;
+        __syncthreads();
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        return t;
+    };
+    const double mu_old = block_sum(mu_t);
+    if (tid == 0) s_mu = mu_old;
+    // ---- phase 1: workgroup w takes the old rows k = off0 + w, + W, .. (interleaved: the rows of a triangle differ in
+    // length) and adds b[k] times row k into ITS partial of u12 = U^-T b -- thread = column (+ 1024 i), the rows of a column
+    // eight at a time in flight, every load part of an 8 KB run of its row
+    {
+        const int ncol_t = (Np0 + 1023) / 1024;
+        for (int i = 0; i < ncol_t; ++i) {
+            // (odd column groups mirrored: a wavefront with the short columns of one group has the long ones of the next --
+            //  the wavefronts of a workgroup wait for each other at the barrier)
+            const int c = 1024 * i + ((i & 1) ? 1023 - tid : tid);
+            if (c >= Np0) continue;                          // (Np0 is a multiple of 128: whole wavefronts skip)
+            const int cw = min(__builtin_amdgcn_readfirstlane(c) | 63, Np0 - 1);   // last column of this wavefront: rows beyond it hold
+            const double* col = Wt0 + c;                                // zeros for all 64 (rows between c and cw: zeros read)
+            double acc = 0.0;
+            // sixteen rows in flight, every load unconditional (a row beyond the last one wanted is read once more with a zero
+            // multiplier: behind a load that may not have been issued the compiler waits for each one)
+            for (int k = off0 + w; k <= cw; k += 16 * W) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = col[(long)min(k + u * W, cw) * Np0];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = fma(v[u], (k + u * W <= cw) ? b[k + u * W] : 0.0, acc);
+            }
+            sr_st_agent(g.vp + ((long)d * W + w) * Np0 + c, acc);
+        }
+    }
+    unsigned* cnt = g.cnt + d;
+    sr_appg_barrier(cnt, g.base + (unsigned)W);
+    // ---- phase 2: u12 = sum over the workgroups' partials in the order of w, and the squares, 256 columns at a time
+    for (int cb = w; cb < g.ncb; cb += W) {
+        const int cl = tid & 255, q = tid >> 8, c = cb * 256 + cl;
+        double v = 0.0;
+        if (c < Np0) {
+            const double* src = g.vp + (long)d * W * Np0 + c;
+            for (int w0 = q; w0 < W; w0 += 32) {             // eight partials in flight (same order of additions)
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = (w0 + 4 * u < W) ? sr_ld<true>(src + (long)(w0 + 4 * u) * Np0) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += x[u];
+            }
+        }
+        part[q][cl] = v;
+        __syncthreads();
+        v = 0.0;
+        if (tid < 256) {
+            v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            if (cb * 256 + tid < Np0) sr_st_agent(g.u12 + (long)d * Np0 + cb * 256 + tid, v);
+            else v = 0.0;
+        }
+        const double gs = block_sum(v * v);
+        if (tid == 0) sr_st_agent(g.gpart + (long)d * g.ncb + cb, gs);
+    }
+    sr_appg_barrier(cnt, g.base + 2u * (unsigned)W);
+    // ---- the new point's pivot (every workgroup; workgroup 0 reports)
+    if (tid == 0) {
+        double gsum = 0.0;
+        for (int cb = 0; cb < g.ncb; ++cb) gsum += sr_ld<true>(g.gpart + (long)d * g.ncb + cb);
+        double prior;                                        // k(z_new, z_new)
+        if (a.kp) {
+            const double* kp = a.kp + (long)d * SR_KP(D);
+            double la = 0.0, lb = 0.0;
+            for (int c = 0; c < D; ++c) {
+                la = fma(kp[3 + D + c] * zn[c], zn[c], la);
+                lb = fma(kp[3 + 2 * D + c] * zn[c], zn[c], lb);
+            }
+            prior = (kp[2] + la) * kp[1] + lb;               // kappa(0) = 1
+        } else {
+            prior = a.sf2[d];
+        }
+        double sch = prior + a.noise[d] - gsum;              // Schur complement of the new point
+        if (!(sch > 0.0)) {                                  // also catches NaN
+            if (w == 0) a.info[d] = N0 + 1;
+            sch = 1.0;
+        } else if (w == 0) {
+            a.info[d] = 0;
+        }
+        double sd, inv;
+        sr_sqrt_rsqrt(sch, sd, inv);
+        s_inv = inv;
+        s_v2 = inv * (y_new - s_mu);
+    }
+    __syncthreads();
+    const double inv = s_inv, v2 = s_v2;
+    for (int i = tid; i < Np0; i += 1024) b[i] = sr_ld<true>(g.u12 + (long)d * Np0 + i) * inv;     // X
+    __syncthreads();
+    // ---- phase 3: the new factor, alpha and targets, row by row (upper part: the rest of the target is in place)
+    double ld = 0.0;
+    const double* yT0 = a.yT0 + (long)d * Np0;
+    double* alpha1 = a.alpha1 + (long)d * Np1;
+    double* yT1 = a.yT1 + (long)d * Np1;
+    const int Rlast = Np1 - 1;                               // row of the new point
+    for (int R = w * 16 + wave; R < Np1; R += 16 * W) {
+        double* dst = Wt1 + (long)R * Np1;
+        if (R < off1 || R == Rlast) {
+            if (lane == 0) {
+                if (R == Rlast) { dst[Rlast] = inv; ld += log(inv); }
+                alpha1[R] = (R == Rlast) ? inv * v2 : 0.0;
+                yT1[R] = (R == Rlast) ? y_new : 0.0;
+            }
+            continue;
+        }
+        const int r0 = R - shift;                            // old padded row
+        const double* src = Wt0 + (long)r0 * Np0 - shift;    // src[C] = old entry of new column C
+        double acc = 0.0;
+        int C0 = R;
+        for (; C0 + 512 <= Rlast; C0 += 512) {               // eight loads in flight per lane, no predicates
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[C0 + 64 * u + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int C = C0 + 64 * u + lane;
+                dst[C] = v[u];
+                acc = fma(v[u], b[C - shift], acc);
+            }
+        }
+        for (; C0 < Rlast; C0 += 64) {
+            const int C = C0 + lane;
+            if (C < Rlast) {
+                const double v = src[C];
+                dst[C] = v;
+                acc = fma(v, b[C - shift], acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            dst[Rlast] = -acc;
+            alpha1[R] = fma(-acc, v2, alpha0[r0]);
+            yT1[R] = yT0[r0];
+            ld += log(src[R]);
+        }
+    }
+    __syncthreads();
+    if (lane == 0) red[wave] = ld;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        a.logdet[d * W + w] = -2.0 * t;                      // partial sums: the host adds the W of an output
+    }
+}
+
+long sr_append1_grid_ws(int Np0, int n_out) {                 // doubles of scratch: vp (W partials of u12), u12, gpart
+    const int ncb = (Np0 + 255) / 256;
+    return (long)n_out * ((long)SR_APPEND1G_MAX_W * Np0 + Np0 + ncb);
+}
+
+int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
+                           const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
+                           double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
+                           int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, hipStream_t s,
+                           const double* x_host, const double* y_host) {
+    SR_CHECK(Np0 <= SR_APPEND1G_MAX_NP0 && Np0 % 128 == 0 && N0 >= 1 && N0 <= Np0 && W >= 1, SR_EINVAL, "append1_grid: Np0 = %d, W = %d", Np0, W);
+    sr_append1g_args g;
+    g.a = sr_append1_args{Wt0, alpha0, yT0, Z, ls, sf2, noise, kp, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out,
+                          0, {}, {}};
+    if (x_host) {                                            // the new point travels in the kernel arguments
+        SR_CHECK(y_host && D <= SR_MAX_D && n_out <= SR_APPEND1_MAX_OUT, SR_EINVAL, "append1_grid: D = %d, n_out = %d", D, n_out);
+        g.a.inl = 1; g.a.znew = nullptr; g.a.ynew = nullptr;
+        for (int c = 0; c < D; ++c) g.a.xin[c] = x_host[c];
+        for (int d = 0; d < n_out; ++d) g.a.yin[d] = y_host[d];
+    }
+    SR_CHECK(W <= SR_APPEND1G_MAX_W, SR_EINVAL, "append1_grid: W = %d", W);
+    g.ncb = (Np0 + 255) / 256;
+    g.npairs = 0;
+    g.vp = ws; g.u12 = ws + (long)n_out * SR_APPEND1G_MAX_W * Np0; g.gpart = g.u12 + (long)n_out * Np0;
+    g.cnt = cnt; g.base = base;
+    hipLaunchKernelGGL(sr_append1_grid_kernel, dim3(n_out, W), dim3(1024), 0, s, g);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

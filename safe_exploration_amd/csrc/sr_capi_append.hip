@@ -39,9 +39,28 @@ __global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int 
 // x_host / y_host (sr_gp_append1_host): ONE new point given in host memory -- it travels in the kernel arguments and the
 // status words and log-det partials come back through a pinned block the kernel writes (no copy command either way);
 // only where the one-launch route applies, SR_EUNSUPPORTED before anything is touched otherwise.
-static bool append1_fused(const sr_gp* h, int m) {
+// 0: the general route (a chain of launches); 1: one launch, one workgroup per output and share of the rows (small models);
+// 2: one launch of a grid of workgroups with two device-wide barriers (sr_append1_grid_kernel)
+static int append1_route(const sr_gp* h, int m) {
+    if (m != 1 || h->small_path == 0) return 0;
     const int Np1 = (int)round_up(h->N + m, SR_NB);
-    return m == 1 && h->Np <= SR_APPEND1_MAX_NP0 && Np1 <= SR_APPEND1_MAX_NP0 + SR_NB && h->small_path != 0;
+    if (h->Np <= SR_APPEND1_MAX_NP0 && Np1 <= SR_APPEND1_MAX_NP0 + SR_NB) return 1;
+    static const bool no_grid = getenv("SR_APPEND_NO_GRID") != nullptr;       // (A/B measurements)
+    if (h->Np <= SR_APPEND1G_MAX_NP0 && h->n_out <= SR_APPEND1_MAX_OUT && !no_grid) return 2;
+    return 0;
+}
+static bool append1_fused(const sr_gp* h, int m) { return append1_route(h, m) != 0; }
+// workgroups per output of the grid route: all of them must be resident at once (they wait for each other) and one fits a
+// CU, so the grid leaves an eighth of the CUs to whatever else is resident on the device (the single-query servers of other
+// models: a few workgroups); and no more workgroups than there is work for
+static int append1_grid_w(sr_gp* h) {
+    if (h->ncu == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 64;
+        h->ncu = cus;
+    }
+    const int useful = (h->Np + SR_NB + 15) / 16;             // (16 rows of the new factor per workgroup and pass)
+    return std::max(1, std::min(std::min(SR_APPEND1G_MAX_W, useful), (h->ncu - h->ncu / 8) / h->n_out));
 }
 
 static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m, hipStream_t s, int* info,
@@ -56,7 +75,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         }
         if (!h->app_pin) {
             void *p = nullptr, *pd = nullptr;
-            SR_HIP(hipHostMalloc(&p, sizeof(double) * (SR_APPEND1_MAX_OUT * SR_APPEND1_WGS + SR_APPEND1_MAX_OUT), hipHostMallocMapped));
+            SR_HIP(hipHostMalloc(&p, sizeof(double) * (SR_APPEND1_MAX_OUT * SR_APPEND1G_MAX_W + SR_APPEND1_MAX_OUT), hipHostMallocMapped));
             if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) {
                 (void)hipHostFree(p);
                 (void)hipGetLastError();
@@ -67,12 +86,17 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         }
     }
     const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
+    const int route = append1_route(h, m);
+    const bool fused1 = route != 0;
+    const int nwy = route == 2 ? append1_grid_w(h) : SR_APPEND1_WGS;
+    const int nld = n_out * nwy;                                  // log-det partial sums the kernels leave (the status words follow them)
     // scratch layout
     // (Xt, Y2, G, S, S^-1 once per output: every step below is ONE launch over all outputs)
     const size_t s_xt = (size_t)SR_SMALL_T * Np0, s_y2 = (size_t)Np0 * SR_NB;
     const size_t o_u12 = 0, o_xt = o_u12 + (size_t)n_out * SR_SMALL_T * Np0, o_y2 = o_xt + n_out * s_xt,
                  o_g = o_y2 + n_out * s_y2, o_sb = o_g + n_out * BB, o_inv = o_sb + n_out * BB,
-                 o_ld = o_inv + n_out * BB, o_info = o_ld + (size_t)n_out * SR_APPEND1_WGS, need = o_info + (size_t)n_out;
+                 o_ld = o_inv + n_out * BB, o_info = o_ld + (size_t)nld, o_grid = o_info + (size_t)n_out,
+                 need = o_grid + (route == 2 ? (size_t)sr_append1_grid_ws(Np0, n_out) : 0);
     if (h->app_cap < need) {
         (void)device_sync();
         dev_free(h->app_ws);
@@ -111,9 +135,23 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
     // one point on a small model: the whole append is ONE launch (sr_append1_small_kernel)
-    const bool fused1 = append1_fused(h, m);
-    const int nld = n_out * SR_APPEND1_WGS;                       // (the one-launch route leaves partial sums)
-    if (fused1) {
+    if (route == 2) {
+        // the target holds zeros below the diagonal and its identity padding, or gets them now (as on the general route)
+        if (!(reuse_alt && h->wt_alt_off >= off1)) {
+            SR_AH(hipMemsetAsync(Wt1, 0, (size_t)n_out * NN1 * sizeof(double), s));
+            SR_A(sr_launch_eye_front(Wt1, Np1, off1, s, n_out));
+        }
+        if (!h->appg_cnt) {
+            SR_A(dev_alloc(&h->appg_cnt, (size_t)SR_APPEND1_MAX_OUT));        // (unsigned counters in a block of doubles)
+            SR_AH(hipMemsetAsync(h->appg_cnt, 0, sizeof(double) * SR_APPEND1_MAX_OUT, s));
+            h->appg_base = 0;
+        }
+        SR_A(sr_launch_append1_grid(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
+                                    Znew, Ynew, Wt1, alpha1, yT1, Z1 + (size_t)N0 * D, host_new ? h->app_pin_dev : ws + o_ld,
+                                    host_new ? reinterpret_cast<int*>(h->app_pin_dev + nld) : info_dev, N0, Np0, Np1, D, n_out, nwy,
+                                    ws + o_grid, reinterpret_cast<unsigned*>(h->appg_cnt), h->appg_base, s, x_host, y_host));
+        h->appg_base += 2u * (unsigned)nwy;                       // (every workgroup arrives twice, whatever the launch finds)
+    } else if (fused1) {
         SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
                                      Znew, Ynew, Wt1, alpha1, yT1,
                                      Z1 + (size_t)N0 * D, host_new ? h->app_pin_dev : ws + o_ld,
@@ -171,9 +209,9 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     std::vector<int> info_h(n_out, 0);
     memcpy(info_h.data(), back.data() + nld, sizeof(int) * n_out);
     for (int d = 0; d < n_out; ++d) {
-        double t = back[fused1 ? d * SR_APPEND1_WGS : d];
-        for (int y = 1; fused1 && y < SR_APPEND1_WGS; ++y) t += back[d * SR_APPEND1_WGS + y];
-        back[d] = t;                                              // (d <= d * SR_APPEND1_WGS: nothing unread is overwritten)
+        double t = back[fused1 ? d * nwy : d];
+        for (int y = 1; fused1 && y < nwy; ++y) t += back[d * nwy + y];
+        back[d] = t;                                              // (d <= d * nwy: nothing unread is overwritten)
     }
     h->logdet_valid = 0;
 #undef SR_A

@@ -332,7 +332,9 @@ int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* pa
 #define SR_STREAM_FUSED_MAX_D 5      /* one-launch streamed predict (T <= 4) evaluates its own K* columns up to this D */
 #define SR_LIN_FUSED_MAX_D 3         /* one-launch streamed linearize up to this D */
 #define SR_FACT_CHAIN_MAX_NB 128     /* model update: up to here the chain of diagonal blocks bounds it (stream regime 1) */
-#define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch up to this padded size (the grown model: <= 640) */
+#define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch of one workgroup per output up to this padded size (the grown model: <= 640) */
+#define SR_APPEND1G_MAX_NP0 8192     /* +1 point in ONE launch of a grid of workgroups up to this padded size (K* row in LDS) */
+#define SR_APPEND1G_MAX_W 128        /* workgroups per output of that grid */
 #define SR_STREAM_FUSED32_MAX_NCB 8   // 32 columns per workgroup are evaluated inside the MFMA kernel up to this many 256-column blocks (Np <= 2048)
 
 static inline bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
@@ -408,6 +410,12 @@ int sr_launch_append_alpha(const double* alpha0, int Np0, int N0, const double* 
 // logdet: n_out x SR_APPEND1_WGS partial sums
 #define SR_APPEND1_WGS 8
 #define SR_APPEND1_MAX_OUT 16   // outputs whose new targets fit the kernel arguments (sr_gp_append1_host)
+long sr_append1_grid_ws(int Np0, int n_out);
+int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
+                           const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
+                           double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
+                           int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, hipStream_t s,
+                           const double* x_host = nullptr, const double* y_host = nullptr);
 int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                             const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,

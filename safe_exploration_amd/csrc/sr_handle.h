@@ -82,6 +82,7 @@ struct sr_gp {
     // (kept while the padded size does not change: appends then allocate nothing big)
     double* app_ws = nullptr; size_t app_cap = 0;
     unsigned long long* call_flag = nullptr; unsigned long long call_seq = 0;   // set by sr_gp_call1 around a streamed pass
+    double* appg_cnt = nullptr; unsigned appg_base = 0;      // barrier counters of the grid append (zero at allocation), their value after the last launch
     void* app_pin = nullptr; double* app_pin_dev = nullptr;   // pinned, mapped: results of sr_gp_append1_host (log det partials, status words)
     double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
     int wt_alt_off = -1;     // front padding of the (complete, well-formed) factor Wt_alt last held; -1 unknown

@@ -782,14 +782,15 @@ def test_row_append_update_equals_refit(N0, adds):
 
 
 @pytest.mark.parametrize("N0,n_s,n_u,steps", [(1, 2, 1, 5), (60, 4, 1, 6), (126, 2, 1, 4), (200, 3, 2, 3), (254, 2, 1, 5),
-                                               (256, 4, 1, 2), (300, 2, 1, 3), (383, 4, 1, 3), (510, 2, 1, 4)])
+                                               (256, 4, 1, 2), (300, 2, 1, 3), (383, 4, 1, 3), (510, 2, 1, 4),
+                                               (600, 2, 1, 3), (1022, 2, 1, 4), (1151, 4, 1, 2), (2047, 3, 2, 2)])
 def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
-    """ONE new point on a model of <= 512 padded rows is one launch (sr_append1_small_kernel): against the
-    refit on all the data (factor entry by entry, zeros and identity padding included -- the kernel writes the whole
-    matrix), against the general route of the same library (set_small_path(0)), the oracle's variance, the log
-    determinant of both routes; crosses the padded sizes 128 -> 256 -> 384 -> 512 -> 640 (the last append of (510, ..)
-    starts from 640 rows and takes the general route); a point that breaks the factorisation down leaves the model as
-    it was."""
+    """ONE new point is one launch -- one workgroup per output and share of the rows up to 512 padded rows
+    (sr_append1_small_kernel), a grid of workgroups with two device-wide barriers up to 8192 (sr_append1_grid_kernel):
+    against the refit on all the data (factor entry by entry, zeros and identity padding included), against the general
+    route of the same library (set_small_path(0)), the oracle's variance, the log determinant of both routes; crosses the
+    padded sizes 128 -> .. -> 640 (from 640 rows on the grid kernel), 1024 -> 1152 (an odd number of 128-row chunks)
+    -> 1280, 2048 -> 2176; a point that breaks the factorisation down leaves the model as it was."""
     import ctypes
     from safe_exploration_amd._lib import lib
     ntot = N0 + steps
@@ -843,8 +844,8 @@ def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
 @pytest.mark.parametrize("kt", ["rbf", "lin_mat52"])
 def test_one_point_append_from_host_memory_equals_the_device_pointer_route(kt):
     """sr_gp_append1_host (the new point in the kernel arguments, status words and log det through a pinned block the kernel
-    writes) against sr_gp_append with device pointers: the same launch, the same bits; declined (SR_EUNSUPPORTED, nothing
-    touched) beyond 512 padded rows."""
+    writes) against sr_gp_append with device pointers: the same launch, the same bits -- on both one-launch routes; declined
+    (SR_EUNSUPPORTED, nothing touched) where they are switched off."""
     import ctypes
     import torch
     from safe_exploration_amd import _lib, _buffers as B
@@ -879,15 +880,29 @@ def test_one_point_append_from_host_memory_equals_the_device_pointer_route(kt):
     la, lb = (ctypes.c_double * 2)(), (ctypes.c_double * 2)()
     assert _lib.lib.sr_gp_logdet_cached(a._handle.h, la) == 0 and _lib.lib.sr_gp_logdet_cached(b._handle.h, lb) == 0
     assert list(la) == list(lb)
-    big = hip_model(np.vstack([Z] * 5)[:600] + 0.01 * np.arange(600)[:, None], np.vstack([Y] * 5)[:600], syn["lengthscale"],
-                    syn["signal_var"], syn["noise_var"], 2, 1)
+    # beyond 512 padded rows: the grid kernel, the same two entry points, the same bits; declined where the one-launch
+    # routes are switched off (nothing touched)
+    bigs = [hip_model(np.vstack([Z] * 5)[:600] + 0.01 * np.arange(600)[:, None], np.vstack([Y] * 5)[:600], syn["lengthscale"],
+                      syn["signal_var"], syn["noise_var"], 2, 1) for _ in range(2)]
     x1, y1 = np.ascontiguousarray(Z[0] + 0.5), np.ascontiguousarray(Y[0])
     info = (ctypes.c_int * 2)()
-    rc = _lib.lib.sr_gp_append1_host(big._handle.h, ctypes.c_void_p(x1.ctypes.data), ctypes.c_void_p(y1.ctypes.data),
-                                     B.stream_ptr(big._handle.device), info)
+    bigs[0].set_small_path(0)
+    rc = _lib.lib.sr_gp_append1_host(bigs[0]._handle.h, ctypes.c_void_p(x1.ctypes.data), ctypes.c_void_p(y1.ctypes.data),
+                                     B.stream_ptr(bigs[0]._handle.device), info)
     assert rc == _lib.SR_EUNSUPPORTED
     n = ctypes.c_long(0)
-    assert _lib.lib.sr_gp_padded_n(big._handle.h, ctypes.byref(n)) == 0 and n.value == 640
+    assert _lib.lib.sr_gp_padded_n(bigs[0]._handle.h, ctypes.byref(n)) == 0 and n.value == 640
+    bigs[0].set_small_path(1)
+    _lib.check(_lib.lib.sr_gp_append1_host(bigs[0]._handle.h, ctypes.c_void_p(x1.ctypes.data), ctypes.c_void_p(y1.ctypes.data),
+                                           B.stream_ptr(bigs[0]._handle.device), info))
+    hd = bigs[1]._handle
+    tx, ty = B.as_dev(x1[None, :], hd.device), B.as_dev(y1[None, :], hd.device)
+    _lib.check(_lib.lib.sr_gp_append(hd.h, B.ptr(tx), B.ptr(ty), 1, B.stream_ptr(hd.device), info))
+    torch.cuda.synchronize()
+    for g_ in bigs:
+        g_._handle.N = 601
+    for u, v in zip(bigs[0].export_state(), bigs[1].export_state()):
+        np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
 
 
 @pytest.mark.parametrize("kt,N0,adds", [("lin_mat52", 90, [1, 4]), ("mat52", 250, [16, 1]), ("lin_rbf", 600, [3, 1, 40]),
