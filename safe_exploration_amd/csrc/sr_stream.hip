@@ -567,7 +567,7 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
     // the last one runs alone at the end of every stage (measured at T = 64, N = 5000: wavefront 0 through its 64 MFMAs
     // after 11.3k cycles, at the barrier for 8.8k more; 20.9k per stage against 16.4k of MFMA time).  Scheduling barriers
     // pin the order.  The stage barrier is LDS-only: __syncthreads() would drain the A-fragments in flight.
-    constexpr int PD = (G == 4) ? 1 : (G == 2 ? 2 : 4), NR = PD + 1;
+    constexpr int PD = (G == 8) ? 0 : (G == 4 ? 1 : (G == 2 ? 2 : 4)), NR = PD + 1;   // (G = 8: 64 accumulator registers, no room for a ring)
     for (int sub = 0; sub < nsub; ++sub) {
         const double* kb = ks[sub & 1] + lk * LDK + ln;
         const bool more = sub + 1 < nsub;

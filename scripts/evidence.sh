@@ -37,10 +37,14 @@ timeout 300 python scripts/linearize_bench.py --kern lin_mat52 >> "$EV/${TAG}_li
 timeout 300 python scripts/exploration_step.py --kern lin_mat52 > "$EV/.expl_lin_mat52.txt" 2>>"$EV/.err"
 timeout 400 python bench.py --workload c3s --steps 3 --warmup 1 2>>"$EV/.err" | line > "$EV/${TAG}_bench_c3s.json"
 timeout 300 python bench.py --dry-nccl --steps 3 --warmup 1 --no-cpu-baseline 2>>"$EV/.err" | line > "$EV/${TAG}_bench_dry_nccl.json"
-# the skeleton of the 128 x 128 main loop in isolation (built by the caller: hipcc -O3 scripts/mfma_pipe_tile.hip -o scripts/_bin/pipe)
+# the skeleton of the 128 x 128 main loop in isolation (built by scripts/build_bins.sh)
 if [ -x scripts/_bin/pipe ]; then
   { echo "# hipcc --offload-arch=gfx950 -O3 scripts/mfma_pipe_tile.hip -o pipe && ./pipe   (1 x MI355X; modes in the header of the source)"; ./scripts/_bin/pipe; } > "$EV/${TAG}_mfma_pipe_tile.txt" 2>>"$EV/.err"
 fi
+# the 16-pivot chain of the diagonal-block kernel and the fp64 MFMA issue rate in isolation (built by scripts/build_bins.sh)
+if [ -x scripts/_bin/pivot ]; then ./scripts/_bin/pivot > "$EV/${TAG}_pivot_chain.txt" 2>>"$EV/.err"; fi
+if [ -x scripts/_bin/mfma_issue ]; then ./scripts/_bin/mfma_issue > "$EV/${TAG}_mfma_issue.txt" 2>>"$EV/.err"; fi
+timeout 300 python scripts/refit_ab.py 500,1000,2000,5000,10000 > "$EV/${TAG}_refit_sizes.txt" 2>>"$EV/.err"
 timeout 300 python scripts/numpy_latency.py > "$EV/${TAG}_numpy_latency.txt" 2>>"$EV/.err"
 timeout 300 python scripts/exploration_step.py > "$EV/${TAG}_exploration_step.txt" 2>>"$EV/.err"
 cat "$EV/.expl_lin_mat52.txt" >> "$EV/${TAG}_exploration_step.txt" 2>/dev/null
