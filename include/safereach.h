@@ -92,8 +92,10 @@ int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void*
 /* ONE new point given in HOST memory (x_host: D doubles, y_host: n_out doubles; any host memory): what the reference's
  * exploration loop does after every step (exploration_runner.py:186-188 -> update_model(x, y, replace_old=False)).  The
  * point travels in the kernel arguments and the status words / log det come back through a pinned block the kernel
- * writes: no copy command in either direction.  Only where the one-launch append applies (<= 512 padded rows, n_out <=
- * 16); SR_EUNSUPPORTED otherwise, before anything is touched: copy the point to the device and call sr_gp_append. */
+ * writes: no copy command in either direction.  Only where a one-launch append applies (<= 8192 padded rows, n_out <= 16,
+ * sr_gp_set_small_path not 0: one workgroup per output up to 512 padded rows, a grid of workgroups with two device-wide
+ * barriers beyond -- every workgroup of that grid has to be resident at once, the library keeps it below 7/8 of the CUs);
+ * SR_EUNSUPPORTED otherwise, before anything is touched: copy the point to the device and call sr_gp_append. */
 int sr_gp_append1_host(sr_gp_t h, const double* x_host, const double* y_host, void* stream, int* info);
 
 /* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and
