@@ -435,12 +435,20 @@ int sr_launch_append1_small(const double* Wt0, const double* alpha0, const doubl
 //            the new point's row, sum of log(diagonal) per workgroup.
 // What one workgroup hands to another goes out with agent-scope stores and comes in with agent-scope loads (the L2s of
 // the XCDs are not coherent with each other); the barrier itself is a relaxed agent-scope counter.
+// IN PLACE (`inplace`, the padded size stays): the new factor is the OLD MEMORY seen from Wt0 + Np0 + 1 with the same leading
+// dimension -- element (r, c) of that view is element (r + 1, c + 1) of the old one, which is exactly where the move would
+// put it -- so phase 3 only READS the rows (for y2) and writes the new column, the new point's diagonal entry, alpha and
+// the new target; nothing is written unless the pivots of ALL outputs are positive (the barriers are grid-wide for that).
+// The last column of the view wraps into column 0 of the rows two below (lower triangle: zero, never read again), its last
+// row into the front-padding row the next output has just dropped (zeros right of its diagonal) or into the slack behind
+// the last output.  alpha and yT slide by one element.
 // ------------------------------------------------------------------------------------------------
 struct sr_append1g_args {
     sr_append1_args a;
     double* vp; double* u12; double* gpart;      // n_out x W x Np0, n_out x Np0, n_out x ncb
-    unsigned* cnt; unsigned base;                // n_out counters (zero at allocation), arrivals of all launches so far
+    unsigned* cnt; unsigned base;                // ONE counter for the grid (zero at allocation), arrivals of all launches so far
     int ncb, npairs;
+    int inplace;                                 // Wt1 = Wt0 + Np0 + 1, alpha1 = alpha0 + 1, yT1 = yT0 + 1: see the kernel
 };
 
 __device__ __forceinline__ void sr_appg_barrier(unsigned* cnt, unsigned target) {
@@ -459,6 +467,7 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
     __shared__ double part[4][256];
     __shared__ double red[16];
     __shared__ double s_mu, s_inv, s_v2;
+    __shared__ int s_ok;
     __shared__ double zn[SR_MAX_D];
     const int d = blockIdx.x, w = blockIdx.y, W = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -541,8 +550,9 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
             sr_st_agent(g.vp + ((long)d * W + w) * Np0 + c, acc);
         }
     }
-    unsigned* cnt = g.cnt + d;
-    sr_appg_barrier(cnt, g.base + (unsigned)W);
+    unsigned* cnt = g.cnt;                               // ONE counter for the whole grid: every output waits for every other
+    const unsigned nwg = (unsigned)W * gridDim.x;        // (in place, no output may write unless the pivots of ALL are positive)
+    sr_appg_barrier(cnt, g.base + nwg);
     // ---- phase 2: u12 = sum over the workgroups' partials in the order of w, and the squares, 256 columns at a time
     for (int cb = w; cb < g.ncb; cb += W) {
         const int cl = tid & 255, q = tid >> 8, c = cb * 256 + cl;
@@ -568,37 +578,42 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
         const double gs = block_sum(v * v);
         if (tid == 0) sr_st_agent(g.gpart + (long)d * g.ncb + cb, gs);
     }
-    sr_appg_barrier(cnt, g.base + 2u * (unsigned)W);
-    // ---- the new point's pivot (every workgroup; workgroup 0 reports)
+    sr_appg_barrier(cnt, g.base + 2u * nwg);
+    // ---- the new point's pivot (every workgroup; workgroup 0 of an output reports); in place, the pivots of ALL outputs
     if (tid == 0) {
-        double gsum = 0.0;
-        for (int cb = 0; cb < g.ncb; ++cb) gsum += sr_ld<true>(g.gpart + (long)d * g.ncb + cb);
-        double prior;                                        // k(z_new, z_new)
-        if (a.kp) {
-            const double* kp = a.kp + (long)d * SR_KP(D);
-            double la = 0.0, lb = 0.0;
-            for (int c = 0; c < D; ++c) {
-                la = fma(kp[3 + D + c] * zn[c], zn[c], la);
-                lb = fma(kp[3 + 2 * D + c] * zn[c], zn[c], lb);
+        int ok_all = 1;
+        for (int dd = 0; dd < (int)gridDim.x; ++dd) {
+            if (!g.inplace && dd != d) continue;
+            double gsum = 0.0;
+            for (int cb = 0; cb < g.ncb; ++cb) gsum += sr_ld<true>(g.gpart + (long)dd * g.ncb + cb);
+            double prior;                                    // k(z_new, z_new)
+            if (a.kp) {
+                const double* kp = a.kp + (long)dd * SR_KP(D);
+                double la = 0.0, lb = 0.0;
+                for (int c = 0; c < D; ++c) {
+                    la = fma(kp[3 + D + c] * zn[c], zn[c], la);
+                    lb = fma(kp[3 + 2 * D + c] * zn[c], zn[c], lb);
+                }
+                prior = (kp[2] + la) * kp[1] + lb;           // kappa(0) = 1
+            } else {
+                prior = a.sf2[dd];
             }
-            prior = (kp[2] + la) * kp[1] + lb;               // kappa(0) = 1
-        } else {
-            prior = a.sf2[d];
+            double sch = prior + a.noise[dd] - gsum;         // Schur complement of the new point
+            const bool pos = sch > 0.0;                      // false for NaN too
+            if (!pos) { ok_all = 0; sch = 1.0; }
+            if (dd == d) {
+                if (w == 0) a.info[d] = pos ? 0 : N0 + 1;
+                double sd, inv;
+                sr_sqrt_rsqrt(sch, sd, inv);
+                s_inv = inv;
+                s_v2 = inv * (y_new - s_mu);
+            }
         }
-        double sch = prior + a.noise[d] - gsum;              // Schur complement of the new point
-        if (!(sch > 0.0)) {                                  // also catches NaN
-            if (w == 0) a.info[d] = N0 + 1;
-            sch = 1.0;
-        } else if (w == 0) {
-            a.info[d] = 0;
-        }
-        double sd, inv;
-        sr_sqrt_rsqrt(sch, sd, inv);
-        s_inv = inv;
-        s_v2 = inv * (y_new - s_mu);
+        s_ok = ok_all;
     }
     __syncthreads();
     const double inv = s_inv, v2 = s_v2;
+    const bool wr = !g.inplace || s_ok != 0;               // in place: a failed pivot (of any output) leaves the model as it is
     for (int i = tid; i < Np0; i += 1024) b[i] = sr_ld<true>(g.u12 + (long)d * Np0 + i) * inv;     // X
     __syncthreads();
     // ---- phase 3: the new factor, alpha and targets, row by row (upper part: the rest of the target is in place)
@@ -611,9 +626,11 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
         double* dst = Wt1 + (long)R * Np1;
         if (R < off1 || R == Rlast) {
             if (lane == 0) {
-                if (R == Rlast) { dst[Rlast] = inv; ld += log(inv); }
-                alpha1[R] = (R == Rlast) ? inv * v2 : 0.0;
-                yT1[R] = (R == Rlast) ? y_new : 0.0;
+                if (R == Rlast) { if (wr) dst[Rlast] = inv; ld += log(inv); }
+                if (wr && (!g.inplace || R == Rlast)) {      // (in place the padding entries of alpha and yT are the old ones)
+                    alpha1[R] = (R == Rlast) ? inv * v2 : 0.0;
+                    yT1[R] = (R == Rlast) ? y_new : 0.0;
+                }
             }
             continue;
         }
@@ -621,31 +638,48 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
         const double* src = Wt0 + (long)r0 * Np0 - shift;    // src[C] = old entry of new column C
         double acc = 0.0;
         int C0 = R;
-        for (; C0 + 512 <= Rlast; C0 += 512) {               // eight loads in flight per lane, no predicates
-            double v[8];
+        if (g.inplace) {                                     // dst[C] IS src[C]: read only
+            for (; C0 + 512 <= Rlast; C0 += 512) {
+                double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[C0 + 64 * u + lane];
+                for (int u = 0; u < 8; ++u) v[u] = src[C0 + 64 * u + lane];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int C = C0 + 64 * u + lane;
-                dst[C] = v[u];
-                acc = fma(v[u], b[C - shift], acc);
+                for (int u = 0; u < 8; ++u) acc = fma(v[u], b[C0 + 64 * u + lane - shift], acc);
             }
-        }
-        for (; C0 < Rlast; C0 += 64) {
-            const int C = C0 + lane;
-            if (C < Rlast) {
-                const double v = src[C];
-                dst[C] = v;
-                acc = fma(v, b[C - shift], acc);
+            for (; C0 < Rlast; C0 += 64) {
+                const int C = C0 + lane;
+                if (C < Rlast) acc = fma(src[C], b[C - shift], acc);
+            }
+        } else {
+            for (; C0 + 512 <= Rlast; C0 += 512) {           // eight loads in flight per lane, no predicates
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[C0 + 64 * u + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int C = C0 + 64 * u + lane;
+                    dst[C] = v[u];
+                    acc = fma(v[u], b[C - shift], acc);
+                }
+            }
+            for (; C0 < Rlast; C0 += 64) {
+                const int C = C0 + lane;
+                if (C < Rlast) {
+                    const double v = src[C];
+                    dst[C] = v;
+                    acc = fma(v, b[C - shift], acc);
+                }
             }
         }
         acc = wave_sum(acc);
         if (lane == 0) {
-            dst[Rlast] = -acc;
-            alpha1[R] = fma(-acc, v2, alpha0[r0]);
-            yT1[R] = yT0[r0];
-            ld += log(src[R]);
+            const double dg = src[R];                        // the old diagonal entry
+            if (wr) {
+                dst[Rlast] = -acc;
+                alpha1[R] = fma(-acc, v2, alpha0[r0]);
+                if (!g.inplace) yT1[R] = yT0[r0];
+            }
+            ld += log(dg);
         }
     }
     __syncthreads();
@@ -667,7 +701,7 @@ int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double
                            const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                            double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
                            int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, hipStream_t s,
-                           const double* x_host, const double* y_host) {
+                           const double* x_host, const double* y_host, int inplace) {
     SR_CHECK(Np0 <= SR_APPEND1G_MAX_NP0 && Np0 % 128 == 0 && N0 >= 1 && N0 <= Np0 && W >= 1, SR_EINVAL, "append1_grid: Np0 = %d, W = %d", Np0, W);
     sr_append1g_args g;
     g.a = sr_append1_args{Wt0, alpha0, yT0, Z, ls, sf2, noise, kp, znew, ynew, Wt1, alpha1, yT1, Zdst, logdet, info, N0, Np0, Np1, D, n_out,
@@ -683,6 +717,9 @@ int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double
     g.npairs = 0;
     g.vp = ws; g.u12 = ws + (long)n_out * SR_APPEND1G_MAX_W * Np0; g.gpart = g.u12 + (long)n_out * Np0;
     g.cnt = cnt; g.base = base;
+    g.inplace = inplace;
+    SR_CHECK(!inplace || (Np1 == Np0 && Wt1 == Wt0 + Np0 + 1 && alpha1 == alpha0 + 1 && yT1 == yT0 + 1), SR_EINVAL,
+             "append1_grid: in place needs the slid views of the same buffers");
     hipLaunchKernelGGL(sr_append1_grid_kernel, dim3(n_out, W), dim3(1024), 0, s, g);
     SR_HIP(hipGetLastError());
     return SR_OK;

@@ -63,8 +63,88 @@ static int append1_grid_w(sr_gp* h) {
     return std::max(1, std::min(std::min(SR_APPEND1G_MAX_W, useful), (h->ncu - h->ncu / 8) / h->n_out));
 }
 
+// ONE new point IN PLACE (the padded size stays: a front-padding row is left): the grid kernel computes the new column
+// and writes it, the new diagonal entry, alpha and the new target into the memory the model already lives in, and the
+// model's buffers become views one step further into their allocations (sr_gp::slide; sr_append1_grid_kernel says why
+// that is the appended model).  Nothing is moved, nothing is allocated; a pivot that fails leaves every byte as it was.
+static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipStream_t s, int* info, const double* x_host,
+                         const double* y_host) {
+    const int N0 = h->N, Np0 = h->Np, D = h->D, n_out = h->n_out;
+    const bool host_new = x_host != nullptr;
+    const int W = append1_grid_w(h), nld = n_out * W;
+    if (host_new && !h->app_pin) {
+        void *p = nullptr, *pd = nullptr;
+        SR_HIP(hipHostMalloc(&p, sizeof(double) * (SR_APPEND1_MAX_OUT * SR_APPEND1G_MAX_W + SR_APPEND1_MAX_OUT), hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&pd, p, 0) != hipSuccess) {
+            (void)hipHostFree(p);
+            (void)hipGetLastError();
+            sr_set_error("sr_gp_append1_host: pinned host memory is not device-visible here");
+            return SR_EUNSUPPORTED;
+        }
+        h->app_pin = p; h->app_pin_dev = (double*)pd;
+    }
+    const size_t o_ld = 0, o_info = o_ld + (size_t)nld, o_grid = o_info + (size_t)n_out,
+                 need = o_grid + (size_t)sr_append1_grid_ws(Np0, n_out);
+    if (h->app_cap < need) {
+        (void)device_sync();
+        dev_free(h->app_ws);
+        h->app_ws = nullptr; h->app_cap = 0;
+        SR_TRY(dev_alloc(&h->app_ws, need));
+        h->app_cap = need;
+    }
+    double* ws = h->app_ws;
+    if (!h->appg_cnt) {
+        SR_TRY(dev_alloc(&h->appg_cnt, (size_t)SR_APPEND1_MAX_OUT));          // (unsigned counters in a block of doubles)
+        SR_HIP(hipMemsetAsync(h->appg_cnt, 0, sizeof(double) * SR_APPEND1_MAX_OUT, s));
+        h->appg_base = 0;
+    }
+    SR_TRY(sr_launch_append1_grid(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr, Znew, Ynew,
+                                  h->Wt + Np0 + 1, h->alpha + 1, h->yT + 1, h->Z + (size_t)N0 * D,
+                                  host_new ? h->app_pin_dev : ws + o_ld,
+                                  host_new ? reinterpret_cast<int*>(h->app_pin_dev + nld) : reinterpret_cast<int*>(ws + o_info), N0,
+                                  Np0, Np0, D, n_out, W, ws + o_grid, reinterpret_cast<unsigned*>(h->appg_cnt), h->appg_base, s, x_host,
+                                  y_host, 1));
+    h->appg_base += 2u * (unsigned)W * (unsigned)n_out;
+    std::vector<double> back(nld + (n_out + 1) / 2, 0.0);         // the log-det partial sums, then n_out ints
+    if (host_new) {
+        SR_HIP(hipStreamSynchronize(s));
+        memcpy(back.data(), h->app_pin, sizeof(double) * nld + sizeof(int) * n_out);
+    } else {
+        SR_HIP(hipMemcpyAsync(back.data(), ws + o_ld, sizeof(double) * nld + sizeof(int) * n_out, hipMemcpyDeviceToHost, s));
+        SR_HIP(hipStreamSynchronize(s));
+    }
+    std::vector<int> info_h(n_out, 0);
+    memcpy(info_h.data(), back.data() + nld, sizeof(int) * n_out);
+    int bad = 0;
+    for (int d = 0; d < n_out; ++d) {
+        if (info) info[d] = info_h[d];
+        if (info_h[d] != 0 && !bad) bad = d + 1;
+    }
+    if (bad) {               // (the kernel wrote nothing: every workgroup has seen the pivots of all outputs)
+        sr_set_error("sr_gp_append: Schur complement not positive definite (output %d, point %d)", bad - 1, info_h[bad - 1]);
+        return SR_ENOTPD;
+    }
+    std::vector<double> ld(n_out, 0.0);
+    for (int d = 0; d < n_out; ++d)
+        for (int y = 0; y < W; ++y) ld[d] += back[(size_t)d * W + y];
+    h->Wt += Np0 + 1; h->alpha += 1; h->yT += 1;
+    ++h->slide;
+    h->N = N0 + 1;
+    h->logdet_host = ld; h->logdet_valid = 1;
+    return SR_OK;
+}
+
 static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m, hipStream_t s, int* info,
                         const double* x_host = nullptr, const double* y_host = nullptr) {
+    {
+        // one point, the padded size stays, the buffers carry their slack: in place
+        static const bool no_slide = getenv("SR_APPEND_NO_SLIDE") != nullptr;      // (A/B measurements)
+        const int np1 = (int)round_up(h->N + m, SR_NB);
+        if (append1_route(h, m) == 2 && np1 == h->Np && h->slack_ok && h->slide < SR_SLIDE_STEPS - 1 && h->N + 1 <= h->z_cap &&
+            h->n_out <= SR_APPEND1_MAX_OUT && !no_slide)
+            return append1_slide(h, Znew, Ynew, s, info, x_host, y_host);
+        SR_TRY(unslide(h));                  // everything below works on plain buffers
+    }
     const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
     const int N1 = N0 + m, Np1 = (int)round_up(N1, SR_NB), off1 = Np1 - N1, pf = SR_NB - m;
     const bool host_new = x_host != nullptr;
@@ -127,11 +207,16 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     else SR_A(dev_alloc(&Z1, (size_t)Np1 * D));
     if (vec_alt) { yT1 = h->yT_alt; alpha1 = h->alpha_alt; }
     else {
-        SR_A(dev_alloc(&yT1, (size_t)n_out * Np1));
-        SR_A(dev_alloc(&alpha1, (size_t)n_out * Np1));
+        SR_A(dev_alloc(&yT1, vec_doubles(n_out, Np1)));
+        SR_A(dev_alloc(&alpha1, vec_doubles(n_out, Np1)));
+        SR_AH(hipMemsetAsync(yT1 + (size_t)n_out * Np1, 0, sizeof(double) * SR_SLIDE_STEPS, s));         // (the slack: sr_gp::slide)
+        SR_AH(hipMemsetAsync(alpha1 + (size_t)n_out * Np1, 0, sizeof(double) * SR_SLIDE_STEPS, s));
     }
     if (reuse_alt) Wt1 = h->Wt_alt;
-    else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
+    else {
+        SR_A(dev_alloc(&Wt1, wt_doubles(n_out, Np1)));
+        SR_AH(hipMemsetAsync(Wt1 + (size_t)n_out * NN1, 0, sizeof(double) * (wt_doubles(n_out, Np1) - (size_t)n_out * NN1), s));
+    }
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
     // one point on a small model: the whole append is ONE launch (sr_append1_small_kernel)
@@ -150,7 +235,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
                                     Znew, Ynew, Wt1, alpha1, yT1, Z1 + (size_t)N0 * D, host_new ? h->app_pin_dev : ws + o_ld,
                                     host_new ? reinterpret_cast<int*>(h->app_pin_dev + nld) : info_dev, N0, Np0, Np1, D, n_out, nwy,
                                     ws + o_grid, reinterpret_cast<unsigned*>(h->appg_cnt), h->appg_base, s, x_host, y_host));
-        h->appg_base += 2u * (unsigned)nwy;                       // (every workgroup arrives twice, whatever the launch finds)
+        h->appg_base += 2u * (unsigned)nwy * (unsigned)n_out;                       // (every workgroup arrives twice, whatever the launch finds)
     } else if (fused1) {
         SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
                                      Znew, Ynew, Wt1, alpha1, yT1,
@@ -281,6 +366,7 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));            // (it stays armed: the next single query launches it on the grown model)
     if (m <= SR_SMALL_T) return append_small(h, Znew, Ynew, m, s, info);
+    SR_TRY(unslide(h));
     // 17 .. 128 new points: the same algebra on the MFMA tile (64 x 64 workgroup tiles: the products are 128 columns wide).
     // Scratch lives with the handle, U^-1 ping-pongs between two buffers while the padded size stays, alpha is updated
     // from the old model's mean at the new points like in the few-points route -- no allocation of the factor's size, no
@@ -319,10 +405,15 @@ extern "C" int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, i
 #define SR_AH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
         sr_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); drop_new(); return SR_EHIP; } } while (0)
     SR_A(dev_alloc(&Z1, (size_t)N1 * D));
-    SR_A(dev_alloc(&yT1, (size_t)n_out * Np1));
-    SR_A(dev_alloc(&alpha1, (size_t)n_out * Np1));
+    SR_A(dev_alloc(&yT1, vec_doubles(n_out, Np1)));
+    SR_A(dev_alloc(&alpha1, vec_doubles(n_out, Np1)));
+    SR_AH(hipMemsetAsync(yT1 + (size_t)n_out * Np1, 0, sizeof(double) * SR_SLIDE_STEPS, s));             // (the slack: sr_gp::slide)
+    SR_AH(hipMemsetAsync(alpha1 + (size_t)n_out * Np1, 0, sizeof(double) * SR_SLIDE_STEPS, s));
     if (reuse_alt) Wt1 = h->Wt_alt;
-    else SR_A(dev_alloc(&Wt1, (size_t)n_out * NN1));
+    else {
+        SR_A(dev_alloc(&Wt1, wt_doubles(n_out, Np1)));
+        SR_AH(hipMemsetAsync(Wt1 + (size_t)n_out * NN1, 0, sizeof(double) * (wt_doubles(n_out, Np1) - (size_t)n_out * NN1), s));
+    }
     SR_AH(hipMemsetAsync(info_dev, 0, sizeof(int) * n_out, s));
     SR_AH(hipMemcpyAsync(sf2.data(), h->sf2, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));
     SR_AH(hipMemcpyAsync(noise.data(), h->noise, sizeof(double) * n_out, hipMemcpyDeviceToHost, s));

@@ -196,9 +196,11 @@ extern "C" int sr_gp_create(sr_gp_t* out, int device, int N, int D, int n_out) {
     h->Np = (int)round_up(N, SR_NB);
     int rc = SR_OK;
     h->z_cap = h->Np;
-    if ((rc = dev_alloc(&h->Z, (size_t)h->Np * D)) || (rc = dev_alloc(&h->yT, (size_t)n_out * h->Np)) ||
+    if ((rc = dev_alloc(&h->Z, (size_t)h->Np * D)) || (rc = dev_alloc(&h->yT, vec_doubles(n_out, h->Np))) ||
         (rc = dev_alloc(&h->ls, (size_t)n_out * D)) || (rc = dev_alloc(&h->sf2, n_out)) ||
-        (rc = dev_alloc(&h->noise, n_out)) || (rc = dev_alloc(&h->alpha, (size_t)n_out * h->Np))) {
+        (rc = dev_alloc(&h->noise, n_out)) || (rc = dev_alloc(&h->alpha, vec_doubles(n_out, h->Np))) ||
+        (rc = dev_zero(h->yT, sizeof(double) * vec_doubles(n_out, h->Np))) ||
+        (rc = dev_zero(h->alpha, sizeof(double) * vec_doubles(n_out, h->Np)))) {
         sr_gp_destroy(h);
         return rc;
     }
@@ -218,8 +220,8 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     sr_dev_guard guard(h->device);
     server_release(h);
     (void)device_sync();
-    dev_free(h->Z); dev_free(h->yT); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
-    dev_free(h->alpha); dev_free(h->Wt); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
+    dev_free(h->Z); dev_free(yT_alloc_of(h)); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
+    dev_free(alpha_alloc_of(h)); dev_free(wt_alloc_of(h)); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
     dev_free(h->stream_vp); dev_free(h->stream_tickets);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
     dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->chain_done); dev_free(h->call_ticket);
@@ -251,6 +253,7 @@ extern "C" int sr_gp_set_data(sr_gp_t h, const double* Z, const double* Y, const
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));            // the resident server reads the model: off the device before it changes
+    SR_TRY(unslide(h));
     SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->ls, ls, sizeof(double) * h->n_out * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->sf2, sf2, sizeof(double) * h->n_out, hipMemcpyDeviceToDevice, s));
@@ -271,6 +274,7 @@ extern "C" int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* 
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));
+    SR_TRY(unslide(h));
     if (!h->kp) SR_TRY(dev_alloc(&h->kp, (size_t)h->n_out * SR_KP(h->D)));
     SR_HIP(hipMemcpyAsync(h->Z, Z, sizeof(double) * h->N * h->D, hipMemcpyDeviceToDevice, s));
     SR_HIP(hipMemcpyAsync(h->kp, kparams, sizeof(double) * h->n_out * SR_KP(h->D), hipMemcpyDeviceToDevice, s));
@@ -302,10 +306,43 @@ extern "C" int sr_gp_padded_n(sr_gp_t h, long* Np) {
 
 int srh::ensure_wt(sr_gp* h) {
     if (!h->Wt) {
-        SR_TRY(dev_alloc(&h->Wt, (size_t)h->n_out * h->Np * h->Np));
-        // the strict lower triangle of U^-1 is never written by the factorisation: zero it once
-        SR_TRY(dev_zero(h->Wt, sizeof(double) * h->n_out * h->Np * h->Np));
+        SR_TRY(dev_alloc(&h->Wt, wt_doubles(h->n_out, h->Np)));
+        // the strict lower triangle of U^-1 is never written by the factorisation: zero it once (and the slack behind it)
+        SR_TRY(dev_zero(h->Wt, sizeof(double) * wt_doubles(h->n_out, h->Np)));
+        h->slack_ok = 1;                 // (alpha and yT carry theirs from sr_gp_create / the append routes on)
     }
+    return SR_OK;
+}
+
+// The model back in plain buffers: the views are contiguous ranges of their allocations, so each moves with ONE copy into
+// a fresh allocation (a copy onto its own allocation would overlap).  Rare: a refit, new data, an import, an append of
+// several points or a big batch (whose tile kernels read U^-1 in 16-byte pieces) after in-place one-point appends.
+int srh::unslide(sr_gp* h) {
+    if (h->slide == 0) return SR_OK;
+    sr_dev_guard guard(h->device);
+    const size_t nw = (size_t)h->n_out * h->Np * h->Np, nv = (size_t)h->n_out * h->Np;
+    double *w = nullptr, *a = nullptr, *y = nullptr;
+    int rc = SR_OK;
+    if ((rc = dev_alloc(&w, wt_doubles(h->n_out, h->Np))) || (rc = dev_alloc(&a, vec_doubles(h->n_out, h->Np))) ||
+        (rc = dev_alloc(&y, vec_doubles(h->n_out, h->Np)))) {
+        dev_free(w); dev_free(a); dev_free(y);
+        return rc;
+    }
+    hipError_t e = hipMemcpy(w, h->Wt, sizeof(double) * nw, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemset(w + nw, 0, sizeof(double) * (wt_doubles(h->n_out, h->Np) - nw));
+    if (e == hipSuccess) e = hipMemcpy(a, h->alpha, sizeof(double) * nv, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemset(a + nv, 0, sizeof(double) * SR_SLIDE_STEPS);
+    if (e == hipSuccess) e = hipMemcpy(y, h->yT, sizeof(double) * nv, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemset(y + nv, 0, sizeof(double) * SR_SLIDE_STEPS);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (not the device: resident servers of other models stay)
+    if (e != hipSuccess) {
+        dev_free(w); dev_free(a); dev_free(y);
+        sr_set_error("unslide: %s", hipGetErrorString(e));
+        return SR_EHIP;
+    }
+    dev_free(wt_alloc_of(h)); dev_free(alpha_alloc_of(h)); dev_free(yT_alloc_of(h));
+    h->Wt = w; h->alpha = a; h->yT = y;
+    h->slide = 0;
     return SR_OK;
 }
 
@@ -331,6 +368,7 @@ extern "C" int sr_gp_import(sr_gp_t h, const double* alpha, const double* Wt, vo
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));
+    SR_TRY(unslide(h));
     SR_TRY(ensure_wt(h));
     SR_HIP(hipMemsetAsync(h->alpha, 0, sizeof(double) * h->n_out * h->Np, s));
     SR_HIP(hipMemcpy2DAsync(h->alpha + (h->Np - h->N), sizeof(double) * h->Np, alpha,
@@ -392,6 +430,7 @@ extern "C" int sr_gp_import_begin(sr_gp_t h, const double* alpha, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));
+    SR_TRY(unslide(h));
     SR_TRY(ensure_wt(h));             // zero below the diagonal from allocation on; nothing ever writes there
     h->factorized = 0; h->logdet_valid = 0;
     h->import_open = 1;

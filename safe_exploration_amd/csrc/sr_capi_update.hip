@@ -208,6 +208,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_CHECK(h->have_data, SR_ESTATE, "sr_gp_factorize: call sr_gp_set_data first");
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));
+    SR_TRY(unslide(h));
     const auto t_begin = std::chrono::steady_clock::now();
     static const bool trace_laps = getenv("SR_FACT_TRACE") != nullptr;
     auto lap = [&](const char* what) { if (trace_laps) fprintf(stderr, "  %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };

@@ -335,6 +335,7 @@ int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* pa
 #define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch of one workgroup per output up to this padded size (the grown model: <= 640) */
 #define SR_APPEND1G_MAX_NP0 8192     /* +1 point in ONE launch of a grid of workgroups up to this padded size (K* row in LDS) */
 #define SR_APPEND1G_MAX_W 128        /* workgroups per output of that grid */
+#define SR_SLIDE_STEPS SR_NB         /* in-place one-point appends a set of model buffers can take: zeroed slack behind U^-1 (SR_SLIDE_STEPS (Np + 1) doubles), alpha and yT (SR_SLIDE_STEPS each) */
 #define SR_STREAM_FUSED32_MAX_NCB 8   // 32 columns per workgroup are evaluated inside the MFMA kernel up to this many 256-column blocks (Np <= 2048)
 
 static inline bool sr_gp_small_wanted(int Np, long T, int D, bool general) {
@@ -415,7 +416,7 @@ int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double
                            const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                            double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
                            int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, hipStream_t s,
-                           const double* x_host = nullptr, const double* y_host = nullptr);
+                           const double* x_host = nullptr, const double* y_host = nullptr, int inplace = 0);
 int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                             const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,

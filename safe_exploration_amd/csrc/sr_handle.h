@@ -82,6 +82,10 @@ struct sr_gp {
     // (kept while the padded size does not change: appends then allocate nothing big)
     double* app_ws = nullptr; size_t app_cap = 0;
     unsigned long long* call_flag = nullptr; unsigned long long call_seq = 0;   // set by sr_gp_call1 around a streamed pass
+    // In-place one-point appends (sr_capi_append.hip): Wt, alpha and yT may be VIEWS `slide` steps into their allocations
+    // (Wt: slide * (Np + 1) doubles, alpha / yT: slide doubles); every entry point that rewrites the model, and every kernel
+    // that wants U^-1 aligned to 16 bytes, calls unslide() first.  slack_ok: the three allocations carry the zeroed slack.
+    int slide = 0; int slack_ok = 0;
     double* appg_cnt = nullptr; unsigned appg_base = 0;      // barrier counters of the grid append (zero at allocation), their value after the last launch
     void* app_pin = nullptr; double* app_pin_dev = nullptr;   // pinned, mapped: results of sr_gp_append1_host (log det partials, status words)
     double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
@@ -142,6 +146,13 @@ void dev_free(void* p);
 int dev_zero(void* p, size_t bytes);
 void free_ws(sr_gp* h);
 int ensure_wt(sr_gp* h);
+// doubles of the three model buffers with their slack (see sr_gp::slide)
+static inline size_t wt_doubles(int n_out, int Np) { return (size_t)n_out * Np * Np + (size_t)SR_SLIDE_STEPS * (Np + 1); }
+static inline size_t vec_doubles(int n_out, int Np) { return (size_t)n_out * Np + SR_SLIDE_STEPS; }
+static inline double* wt_alloc_of(const sr_gp* h) { return h->Wt ? h->Wt - (size_t)h->slide * (h->Np + 1) : nullptr; }
+static inline double* alpha_alloc_of(const sr_gp* h) { return h->alpha ? h->alpha - h->slide : nullptr; }
+static inline double* yT_alloc_of(const sr_gp* h) { return h->yT ? h->yT - h->slide : nullptr; }
+int unslide(sr_gp* h);               // back to plain buffers (fresh allocations, two contiguous copies); no-op when slide == 0
 
 // resident server (sr_capi_server.hip): off the device before the model is written / before a device-wide wait
 int server_quiesce(sr_gp* h);

@@ -841,6 +841,54 @@ def test_one_point_appends_to_small_models_in_one_launch(N0, n_s, n_u, steps):
     np.testing.assert_array_equal(var2, var)
 
 
+def test_in_place_appends_and_what_follows_them():
+    """Beyond 512 padded rows a one-point append that keeps the padded size is IN PLACE: the model's buffers become views one
+    step further into their allocations (sr_gp::slide).  Everything that may follow such appends: a big batch (tile kernels
+    read U^-1 in 16-byte pieces: plain buffers first), an append of several points, more single points, a refit on the same
+    handle, an export -- each against a model fitted on the same data from scratch; an odd and an even number of steps."""
+    syn = orc.make_synthetic(77, 740, 2, 1, 8)
+    Z, Y = syn["Z"], syn["Y"]
+    ref = lambda n: hip_model(Z[:n], Y[:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    rng = np.random.default_rng(4)
+    xq = np.hstack((rng.uniform(-1, 1, (3000, 2)), rng.uniform(-1, 1, (3000, 1))))
+    gp = ref(700)
+    gp.append_limit = 10 ** 9
+    n = 700
+    for steps in (5, 2):
+        for i in range(n, n + steps):
+            gp.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)
+        n += steps
+        full = ref(n)
+        for u, v in zip(gp.export_state(), full.export_state()):                      # alpha, U^-1 (views exported as matrices)
+            np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-6, atol=1e-9 * float(v.abs().max()))
+        m1, v1 = gp.predict(xq[:4])                                                   # single-query / small-batch routes on the views
+        m2, v2 = full.predict(xq[:4])
+        np.testing.assert_allclose(m1, m2, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
+        m1, v1 = gp.predict(xq)                                                       # tile kernels
+        m2, v2 = full.predict(xq)
+        np.testing.assert_allclose(m1, m2, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
+    # in-place steps, then several points at once, then a single one again
+    for i in range(n, n + 3):
+        gp.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)
+    gp.update_model(Z[n + 3:n + 9], Y[n + 3:n + 9], opt_hyp=False, replace_old=False)
+    gp.update_model(Z[n + 9:n + 10], Y[n + 9:n + 10], opt_hyp=False, replace_old=False)
+    n += 10
+    full = ref(n)
+    m1, v1 = gp.predict(xq[:300])
+    m2, v2 = full.predict(xq[:300])
+    np.testing.assert_allclose(m1, m2, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(gp.information_gain(), full.information_gain(), rtol=1e-10, atol=1e-8)
+    # a refit of the same handle after in-place steps (the factorisation writes into plain, clean buffers)
+    gp.update_model(Z[n:n + 1], Y[n:n + 1], opt_hyp=False, replace_old=False)
+    gp.train(Z[:n + 1], Y[:n + 1], opt_hyp=False)
+    full = ref(n + 1)
+    for u, v in zip(gp.export_state(), full.export_state()):
+        np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
+
+
 @pytest.mark.parametrize("kt", ["rbf", "lin_mat52"])
 def test_one_point_append_from_host_memory_equals_the_device_pointer_route(kt):
     """sr_gp_append1_host (the new point in the kernel arguments, status words and log det through a pinned block the kernel
