@@ -95,7 +95,10 @@ int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void*
  * writes: no copy command in either direction.  Only where a one-launch append applies (<= 8192 padded rows, n_out <= 16,
  * sr_gp_set_small_path not 0: one workgroup per output up to 512 padded rows, a grid of workgroups with two device-wide
  * barriers beyond -- every workgroup of that grid has to be resident at once, the library keeps it below 7/8 of the CUs);
- * SR_EUNSUPPORTED otherwise, before anything is touched: copy the point to the device and call sr_gp_append. */
+ * SR_EUNSUPPORTED otherwise, before anything is touched: copy the point to the device and call sr_gp_append.
+ * Beyond 512 padded rows, and while the padded size stays, the point is appended IN PLACE (the model's buffers become views
+ * one step further into their allocations; sr_gp_export and every query work on the views; calls that rewrite the model and
+ * big batches first copy it back into plain buffers).  sr_gp_append with m = 1 does the same. */
 int sr_gp_append1_host(sr_gp_t h, const double* x_host, const double* y_host, void* stream, int* info);
 
 /* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and
