@@ -526,7 +526,8 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
     const double mu_old = block_sum(mu_t);
     if (tid == 0) s_mu = mu_old;
     // ---- phase 1: workgroup w takes the old rows k = off0 + w, + W, .. (interleaved: the rows of a triangle differ in
-    // length) and adds b[k] times row k into ITS partial of u12 = U^-T b -- thread = column (+ 1024 i), the rows of a column
+    // length; runs of 2 .. 8 neighbouring rows per workgroup instead measured the same) and adds b[k] times row k into ITS
+    // partial of u12 = U^-T b -- thread = column (+ 1024 i), the rows of a column
     // eight at a time in flight, every load part of an 8 KB run of its row
     {
         const int ncol_t = (Np0 + 1023) / 1024;
