@@ -376,6 +376,11 @@ int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, l
  * group of rollouts waits for partners that never come: the deterministic way into the time-out path (the tests check
  * that it is reported -- sr_gp_chain_status -- and not silent).  0 restores normal launches. */
 int sr_test_chain_drop(sr_gp_t h, int drop);
+/* diagnostic: the next n launches of the one-launch append of a grid of workgroups (sr_gp_append / sr_gp_append1_host with
+ * one point beyond 512 padded rows) wait at their first device-wide barrier for a workgroup that does not exist and give
+ * it up after ~10 ms: the deterministic way into the path a grid takes that cannot become resident as a whole (nothing of
+ * the model written, the append done by separate launches instead; sr_gp_append1_host answers SR_EUNSUPPORTED). */
+int sr_test_grid_append_abort(int n);
 /* per-kernel hipEvent timing inside the library (adds an event pair per launch while enabled). */
 int sr_prof_enable(sr_gp_t h, int on);
 int sr_prof_reset (sr_gp_t h);

@@ -96,6 +96,7 @@ SIGNATURES = {
     "sr_test_gemm_tn_upper": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_potrf_diag": (_I, [_I, _P, _L, _P, _P, _L, _P, _I, _P]),
     "sr_test_chain_drop": (_I, [_H, _I]),
+    "sr_test_grid_append_abort": (_I, [_I]),
     "sr_prof_enable": (_I, [_H, _I]),
     "sr_prof_reset": (_I, [_H]),
     "sr_prof_get": (_I, [_H, _I, _PD, _PL]),

@@ -446,19 +446,47 @@ int sr_launch_append1_small(const double* Wt0, const double* alpha0, const doubl
 struct sr_append1g_args {
     sr_append1_args a;
     double* vp; double* u12; double* gpart;      // n_out x W x Np0, n_out x Np0, n_out x ncb
-    unsigned* cnt; unsigned base;                // ONE counter for the grid (zero at allocation), arrivals of all launches so far
+    unsigned extra;                              // tests: arrivals that never come (the barrier is given up)
+    unsigned* cnt; unsigned base; unsigned q0;   // cnt[0]: arrivals, cnt[1]: barrier state (both zero at allocation); arrivals and
+                                                 // barriers of all launches so far
     int ncb, npairs;
     int inplace;                                 // Wt1 = Wt0 + Np0 + 1, alpha1 = alpha0 + 1, yT1 = yT0 + 1: see the kernel
 };
 
-__device__ __forceinline__ void sr_appg_barrier(unsigned* cnt, unsigned target) {
+// Device-wide barrier of the grid.  cnt[0] counts arrivals (it only grows: `target` = arrivals of all barriers so far +
+// this grid), cnt[1] is the STATE of the barriers: 2 q after barrier number q has opened, 2 q - 1 after it was given up.  The
+// last arriver opens (compare-and-swap 2 (q - 1) -> 2 q); a workgroup that has polled SR_APPG_SPINS times (~10 ms: some of the
+// grid never became resident -- another process holding the CUs with a grid of its own, say) gives up with the same
+// compare-and-swap towards 2 q - 1: whichever lands first decides for the whole grid.  Returns false when the barrier was
+// given up: the caller reports SR_APPG_ABORTED for every output and leaves the kernel, before anything of the model is
+// written; the host resets both words and takes the route of separate launches.
+#define SR_APPG_SPINS 8192
+__device__ __forceinline__ bool sr_appg_barrier(unsigned* cnt, unsigned target, unsigned q, int* s_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(16);
+        unsigned* state = cnt + 1;
+        const unsigned before = 2u * (q - 1u), open = 2u * q, given_up = 2u * q - 1u;
+        if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target - 1u) {
+            unsigned e = before;
+            __hip_atomic_compare_exchange_strong(state, &e, open, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned st = before;
+        for (int it = 0;; ++it) {
+            st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st != before) break;
+            if (it >= SR_APPG_SPINS) {
+                unsigned e = before;
+                __hip_atomic_compare_exchange_strong(state, &e, given_up, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        *s_flag = (st == open);
     }
     __syncthreads();
+    return *s_flag != 0;
 }
 
 __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args g) {
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
     __shared__ double part[4][256];
     __shared__ double red[16];
     __shared__ double s_mu, s_inv, s_v2;
-    __shared__ int s_ok;
+    __shared__ int s_ok, s_bar;
     __shared__ double zn[SR_MAX_D];
     const int d = blockIdx.x, w = blockIdx.y, W = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -552,8 +580,11 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
         }
     }
     unsigned* cnt = g.cnt;                               // ONE counter for the whole grid: every output waits for every other
-    const unsigned nwg = (unsigned)W * gridDim.x;        // (in place, no output may write unless the pivots of ALL are positive)
-    sr_appg_barrier(cnt, g.base + nwg);
+    const unsigned nwg = (unsigned)W * gridDim.x + g.extra;   // (in place, no output may write unless the pivots of ALL are positive)
+    if (!sr_appg_barrier(cnt, g.base + nwg, g.q0 + 1u, &s_bar)) {
+        if (tid < (int)gridDim.x) a.info[tid] = SR_APPG_ABORTED;
+        return;
+    }
     // ---- phase 2: u12 = sum over the workgroups' partials in the order of w, and the squares, 256 columns at a time
     for (int cb = w; cb < g.ncb; cb += W) {
         const int cl = tid & 255, q = tid >> 8, c = cb * 256 + cl;
@@ -579,7 +610,10 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
         const double gs = block_sum(v * v);
         if (tid == 0) sr_st_agent(g.gpart + (long)d * g.ncb + cb, gs);
     }
-    sr_appg_barrier(cnt, g.base + 2u * nwg);
+    if (!sr_appg_barrier(cnt, g.base + 2u * nwg, g.q0 + 2u, &s_bar)) {
+        if (tid < (int)gridDim.x) a.info[tid] = SR_APPG_ABORTED;
+        return;
+    }
     // ---- the new point's pivot (every workgroup; workgroup 0 of an output reports); in place, the pivots of ALL outputs
     if (tid == 0) {
         int ok_all = 1;
@@ -693,6 +727,10 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
     }
 }
 
+static int g_test_grid_abort = 0;
+// tests: the next n launches of the grid kernel wait for a workgroup that does not exist and give up
+extern "C" int sr_test_grid_append_abort(int n) { g_test_grid_abort = n; return SR_OK; }
+
 long sr_append1_grid_ws(int Np0, int n_out) {                 // doubles of scratch: vp (W partials of u12), u12, gpart
     const int ncb = (Np0 + 255) / 256;
     return (long)n_out * ((long)SR_APPEND1G_MAX_W * Np0 + Np0 + ncb);
@@ -701,7 +739,7 @@ long sr_append1_grid_ws(int Np0, int n_out) {                 // doubles of scra
 int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                            const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                            double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
-                           int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, hipStream_t s,
+                           int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, unsigned q0, hipStream_t s,
                            const double* x_host, const double* y_host, int inplace) {
     SR_CHECK(Np0 <= SR_APPEND1G_MAX_NP0 && Np0 % 128 == 0 && N0 >= 1 && N0 <= Np0 && W >= 1, SR_EINVAL, "append1_grid: Np0 = %d, W = %d", Np0, W);
     sr_append1g_args g;
@@ -717,7 +755,9 @@ int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double
     g.ncb = (Np0 + 255) / 256;
     g.npairs = 0;
     g.vp = ws; g.u12 = ws + (long)n_out * SR_APPEND1G_MAX_W * Np0; g.gpart = g.u12 + (long)n_out * Np0;
-    g.cnt = cnt; g.base = base;
+    g.cnt = cnt; g.base = base; g.q0 = q0;
+    g.extra = 0;
+    if (g_test_grid_abort > 0) { --g_test_grid_abort; g.extra = 1; }
     g.inplace = inplace;
     SR_CHECK(!inplace || (Np1 == Np0 && Wt1 == Wt0 + Np0 + 1 && alpha1 == alpha0 + 1 && yT1 == yT0 + 1), SR_EINVAL,
              "append1_grid: in place needs the slid views of the same buffers");

@@ -1,5 +1,6 @@
 // sr_capi_append.hip -- sr_gp_append: condition the model on up to 128 additional training points without refactorising.
 #include "sr_handle.h"
+#include <mutex>
 using namespace srh;
 
 // ---------------------------------------------------------------------------------------------
@@ -39,6 +40,11 @@ __global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int 
 // x_host / y_host (sr_gp_append1_host): ONE new point given in host memory -- it travels in the kernel arguments and the
 // status words and log-det partials come back through a pinned block the kernel writes (no copy command either way);
 // only where the one-launch route applies, SR_EUNSUPPORTED before anything is touched otherwise.
+// The grid kernel's workgroups wait for each other on the device, so two of its launches must never be in flight together
+// (each could hold a part of the CUs and wait for the rest): one at a time per process, from the launch to the stream
+// synchronisation behind it.  (Launches of OTHER processes on the same device are outside this lock.)
+static std::mutex g_grid_append_mutex;
+
 // 0: the general route (a chain of launches); 1: one launch, one workgroup per output and share of the rows (small models);
 // 2: one launch of a grid of workgroups with two device-wide barriers (sr_append1_grid_kernel)
 static int append1_route(const sr_gp* h, int m) {
@@ -63,12 +69,22 @@ static int append1_grid_w(sr_gp* h) {
     return std::max(1, std::min(std::min(SR_APPEND1G_MAX_W, useful), (h->ncu - h->ncu / 8) / h->n_out));
 }
 
+// The grid did not assemble (status SR_APPG_ABORTED in every output's word): nothing of the model was written; the barrier
+// words start from zero again and the caller takes the route of separate launches.
+static int grid_append_reset(sr_gp* h, hipStream_t s) {
+    SR_HIP(hipMemsetAsync(h->appg_cnt, 0, sizeof(double) * SR_APPEND1_MAX_OUT, s));
+    SR_HIP(hipStreamSynchronize(s));
+    h->appg_base = 0; h->appg_q = 0;
+    return SR_OK;
+}
+
 // ONE new point IN PLACE (the padded size stays: a front-padding row is left): the grid kernel computes the new column
 // and writes it, the new diagonal entry, alpha and the new target into the memory the model already lives in, and the
 // model's buffers become views one step further into their allocations (sr_gp::slide; sr_append1_grid_kernel says why
 // that is the appended model).  Nothing is moved, nothing is allocated; a pivot that fails leaves every byte as it was.
 static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipStream_t s, int* info, const double* x_host,
-                         const double* y_host) {
+                         const double* y_host, bool* aborted) {
+    *aborted = false;
     const int N0 = h->N, Np0 = h->Np, D = h->D, n_out = h->n_out;
     const bool host_new = x_host != nullptr;
     const int W = append1_grid_w(h), nld = n_out * W;
@@ -96,15 +112,16 @@ static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipSt
     if (!h->appg_cnt) {
         SR_TRY(dev_alloc(&h->appg_cnt, (size_t)SR_APPEND1_MAX_OUT));          // (unsigned counters in a block of doubles)
         SR_HIP(hipMemsetAsync(h->appg_cnt, 0, sizeof(double) * SR_APPEND1_MAX_OUT, s));
-        h->appg_base = 0;
+        h->appg_base = 0; h->appg_q = 0;
     }
+    std::unique_lock<std::mutex> grid_lock(g_grid_append_mutex);
     SR_TRY(sr_launch_append1_grid(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr, Znew, Ynew,
                                   h->Wt + Np0 + 1, h->alpha + 1, h->yT + 1, h->Z + (size_t)N0 * D,
                                   host_new ? h->app_pin_dev : ws + o_ld,
                                   host_new ? reinterpret_cast<int*>(h->app_pin_dev + nld) : reinterpret_cast<int*>(ws + o_info), N0,
-                                  Np0, Np0, D, n_out, W, ws + o_grid, reinterpret_cast<unsigned*>(h->appg_cnt), h->appg_base, s, x_host,
-                                  y_host, 1));
-    h->appg_base += 2u * (unsigned)W * (unsigned)n_out;
+                                  Np0, Np0, D, n_out, W, ws + o_grid, reinterpret_cast<unsigned*>(h->appg_cnt), h->appg_base, h->appg_q, s,
+                                  x_host, y_host, 1));
+    h->appg_base += 2u * (unsigned)W * (unsigned)n_out; h->appg_q += 2u;
     std::vector<double> back(nld + (n_out + 1) / 2, 0.0);         // the log-det partial sums, then n_out ints
     if (host_new) {
         SR_HIP(hipStreamSynchronize(s));
@@ -115,6 +132,12 @@ static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipSt
     }
     std::vector<int> info_h(n_out, 0);
     memcpy(info_h.data(), back.data() + nld, sizeof(int) * n_out);
+    if (info_h[0] == SR_APPG_ABORTED) {                           // the grid did not assemble: nothing written
+        SR_TRY(grid_append_reset(h, s));
+        *aborted = true;
+        return SR_EUNSUPPORTED;
+    }
+    grid_lock.unlock();
     int bad = 0;
     for (int d = 0; d < n_out; ++d) {
         if (info) info[d] = info_h[d];
@@ -135,14 +158,19 @@ static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipSt
 }
 
 static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m, hipStream_t s, int* info,
-                        const double* x_host = nullptr, const double* y_host = nullptr) {
+                        const double* x_host = nullptr, const double* y_host = nullptr, bool no_grid = false) {
     {
         // one point, the padded size stays, the buffers carry their slack: in place
         static const bool no_slide = getenv("SR_APPEND_NO_SLIDE") != nullptr;      // (A/B measurements)
         const int np1 = (int)round_up(h->N + m, SR_NB);
-        if (append1_route(h, m) == 2 && np1 == h->Np && h->slack_ok && h->slide < SR_SLIDE_STEPS - 1 && h->N + 1 <= h->z_cap &&
-            h->n_out <= SR_APPEND1_MAX_OUT && !no_slide)
-            return append1_slide(h, Znew, Ynew, s, info, x_host, y_host);
+        if (!no_grid && append1_route(h, m) == 2 && np1 == h->Np && h->slack_ok && h->slide < SR_SLIDE_STEPS - 1 &&
+            h->N + 1 <= h->z_cap && h->n_out <= SR_APPEND1_MAX_OUT && !no_slide) {
+            bool aborted = false;
+            const int rc = append1_slide(h, Znew, Ynew, s, info, x_host, y_host, &aborted);
+            if (!aborted) return rc;
+            if (x_host) return rc;               // (the routes of separate launches want the point in device memory: SR_EUNSUPPORTED)
+            no_grid = true;                      // the grid did not assemble: separate launches
+        }
         SR_TRY(unslide(h));                  // everything below works on plain buffers
     }
     const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
@@ -166,7 +194,8 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         }
     }
     const size_t NN0 = (size_t)Np0 * Np0, NN1 = (size_t)Np1 * Np1, BB = (size_t)SR_NB * SR_NB;
-    const int route = append1_route(h, m);
+    int route = append1_route(h, m);
+    if (no_grid && route == 2) route = 0;
     const bool fused1 = route != 0;
     const int nwy = route == 2 ? append1_grid_w(h) : SR_APPEND1_WGS;
     const int nld = n_out * nwy;                                  // log-det partial sums the kernels leave (the status words follow them)
@@ -220,7 +249,9 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
     // one point on a small model: the whole append is ONE launch (sr_append1_small_kernel)
+    std::unique_lock<std::mutex> grid_lock(g_grid_append_mutex, std::defer_lock);
     if (route == 2) {
+        grid_lock.lock();
         // the target holds zeros below the diagonal and its identity padding, or gets them now (as on the general route)
         if (!(reuse_alt && h->wt_alt_off >= off1)) {
             SR_AH(hipMemsetAsync(Wt1, 0, (size_t)n_out * NN1 * sizeof(double), s));
@@ -229,13 +260,13 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         if (!h->appg_cnt) {
             SR_A(dev_alloc(&h->appg_cnt, (size_t)SR_APPEND1_MAX_OUT));        // (unsigned counters in a block of doubles)
             SR_AH(hipMemsetAsync(h->appg_cnt, 0, sizeof(double) * SR_APPEND1_MAX_OUT, s));
-            h->appg_base = 0;
+            h->appg_base = 0; h->appg_q = 0;
         }
         SR_A(sr_launch_append1_grid(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
                                     Znew, Ynew, Wt1, alpha1, yT1, Z1 + (size_t)N0 * D, host_new ? h->app_pin_dev : ws + o_ld,
                                     host_new ? reinterpret_cast<int*>(h->app_pin_dev + nld) : info_dev, N0, Np0, Np1, D, n_out, nwy,
-                                    ws + o_grid, reinterpret_cast<unsigned*>(h->appg_cnt), h->appg_base, s, x_host, y_host));
-        h->appg_base += 2u * (unsigned)nwy * (unsigned)n_out;                       // (every workgroup arrives twice, whatever the launch finds)
+                                    ws + o_grid, reinterpret_cast<unsigned*>(h->appg_cnt), h->appg_base, h->appg_q, s, x_host, y_host));
+        h->appg_base += 2u * (unsigned)nwy * (unsigned)n_out; h->appg_q += 2u;                       // (every workgroup arrives twice, whatever the launch finds)
     } else if (fused1) {
         SR_A(sr_launch_append1_small(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr,
                                      Znew, Ynew, Wt1, alpha1, yT1,
@@ -293,6 +324,16 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     }
     std::vector<int> info_h(n_out, 0);
     memcpy(info_h.data(), back.data() + nld, sizeof(int) * n_out);
+    if (route == 2 && info_h[0] == SR_APPG_ABORTED) {            // the grid did not assemble: nothing of the model was written
+        const int rr = grid_append_reset(h, s);
+        grid_lock.unlock();
+        if (reuse_alt) h->wt_alt_off = -1;
+        drop_new();
+        if (rr != SR_OK) return rr;
+        if (host_new) { sr_set_error("sr_gp_append1_host: the grid of the one-launch append did not assemble"); return SR_EUNSUPPORTED; }
+        return append_small(h, Znew, Ynew, m, s, info, nullptr, nullptr, true);
+    }
+    if (grid_lock.owns_lock()) grid_lock.unlock();
     for (int d = 0; d < n_out; ++d) {
         double t = back[fused1 ? d * nwy : d];
         for (int y = 1; fused1 && y < nwy; ++y) t += back[d * nwy + y];

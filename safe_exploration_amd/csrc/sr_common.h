@@ -415,8 +415,9 @@ long sr_append1_grid_ws(int Np0, int n_out);
 int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                            const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                            double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,
-                           int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, hipStream_t s,
+                           int D, int n_out, int W, double* ws, unsigned* cnt, unsigned base, unsigned q0, hipStream_t s,
                            const double* x_host = nullptr, const double* y_host = nullptr, int inplace = 0);
+#define SR_APPG_ABORTED (-2)         /* status word of every output when the grid of sr_append1_grid_kernel did not assemble */
 int sr_launch_append1_small(const double* Wt0, const double* alpha0, const double* yT0, const double* Z, const double* ls,
                             const double* sf2, const double* noise, const double* kp, const double* znew, const double* ynew, double* Wt1,
                             double* alpha1, double* yT1, double* Zdst, double* logdet, int* info, int N0, int Np0, int Np1,

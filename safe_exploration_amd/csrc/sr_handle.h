@@ -86,7 +86,7 @@ struct sr_gp {
     // (Wt: slide * (Np + 1) doubles, alpha / yT: slide doubles); every entry point that rewrites the model, and every kernel
     // that wants U^-1 aligned to 16 bytes, calls unslide() first.  slack_ok: the three allocations carry the zeroed slack.
     int slide = 0; int slack_ok = 0;
-    double* appg_cnt = nullptr; unsigned appg_base = 0;      // barrier counters of the grid append (zero at allocation), their value after the last launch
+    double* appg_cnt = nullptr; unsigned appg_base = 0, appg_q = 0;   // (arrivals and barriers of all launches so far)      // barrier counters of the grid append (zero at allocation), their value after the last launch
     void* app_pin = nullptr; double* app_pin_dev = nullptr;   // pinned, mapped: results of sr_gp_append1_host (log det partials, status words)
     double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
     int wt_alt_off = -1;     // front padding of the (complete, well-formed) factor Wt_alt last held; -1 unknown

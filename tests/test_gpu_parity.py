@@ -889,6 +889,34 @@ def test_in_place_appends_and_what_follows_them():
         np.testing.assert_array_equal(u.cpu().numpy(), v.cpu().numpy())
 
 
+def test_grid_append_that_cannot_assemble_falls_back():
+    """The one-launch append beyond 512 padded rows is a grid of workgroups that wait for each other; where the grid cannot
+    become resident as a whole, its barrier is given up after ~10 ms, nothing of the model is written, and the append is done
+    by separate launches (sr_gp_append1_host says SR_EUNSUPPORTED and the Python layer takes sr_gp_append).  Forced here
+    with sr_test_grid_append_abort; in place (padded size stays) and into new buffers (padded size grows); the appends
+    after it work as before."""
+    from safe_exploration_amd._lib import lib
+    syn = orc.make_synthetic(78, 780, 2, 1, 8)
+    Z, Y = syn["Z"], syn["Y"]
+    ref = lambda n: hip_model(Z[:n], Y[:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    for n0 in (700, 768):                                       # 768: the padded size grows with the next point
+        gp = ref(n0)
+        gp.append_limit = 10 ** 9
+        assert lib.sr_test_grid_append_abort(2) == 0            # host route gives up, then the device-pointer route too
+        gp.update_model(Z[n0:n0 + 1], Y[n0:n0 + 1], opt_hyp=False, replace_old=False)
+        assert lib.sr_test_grid_append_abort(0) == 0
+        for i in range(n0 + 1, n0 + 4):
+            gp.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)
+        full = ref(n0 + 4)
+        for u, v in zip(gp.export_state(), full.export_state()):
+            np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-6, atol=1e-9 * float(v.abs().max()))
+        m1, v1 = gp.predict(x)
+        m2, v2 = full.predict(x)
+        np.testing.assert_allclose(m1, m2, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
+
+
 @pytest.mark.parametrize("kt", ["rbf", "lin_mat52"])
 def test_one_point_append_from_host_memory_equals_the_device_pointer_route(kt):
     """sr_gp_append1_host (the new point in the kernel arguments, status words and log det through a pinned block the kernel
