@@ -21,6 +21,7 @@ timeout 300 python scripts/bal_ab.py 2000,3000,4000,5000 128,256,512,1024 > "$EV
 timeout 300 python scripts/factor_bench.py > "$EV/${TAG}_factor_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/append_bench.py > "$EV/${TAG}_append_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/append_soak.py > "$EV/${TAG}_append_soak.txt" 2>>"$EV/.err"
+timeout 600 python scripts/fuzz_append.py 30 150 > "$EV/${TAG}_fuzz_append.txt" 2>>"$EV/.err"
 timeout 300 python scripts/chain_bench.py > "$EV/${TAG}_chain_bench.txt" 2>>"$EV/.err"
 timeout 300 python scripts/onestep_bench.py > "$EV/${TAG}_onestep_bench.txt" 2>>"$EV/.err"
 timeout 600 python scripts/fuzz_chain.py 60 4 > "$EV/${TAG}_fuzz_chain.txt" 2>>"$EV/.err"
