@@ -251,7 +251,8 @@ int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int
 // chain written for the smallest fp64 instruction count, one barrier, loads of the upper triangle only and in flight
 // together, wavefront 0 starting on the first tile while the other 15 load).  What is left: wavefront 0's 4.8k cycles per
 // panel (3.1k of them the 16 pivots) and, in the first four panels, the 35 .. 26 trailing tiles, whose 16 LDS operations
-// per tile keep the LDS busier than the pivots keep wavefront 0 (tiles resident in worker registers would halve that).
+// per tile keep the LDS busier than the pivots keep wavefront 0 (tiles resident in worker registers halve that traffic but
+// measured slower: 24.5 us, profiles/r05_diag_kernel.txt).
 // ------------------------------------------------------------------------------------------------
 #define SR_PD_TLD 33      // pivot stage: 16 rows of [U_pp (16 columns) | T_p = U_pp^-T (16 columns)], padded
 
