@@ -320,6 +320,7 @@ int srh::ensure_wt(sr_gp* h) {
 int srh::unslide(sr_gp* h) {
     if (h->slide == 0) return SR_OK;
     sr_dev_guard guard(h->device);
+    SR_TRY(server_quiesce(h));           // a resident server of this model reads the views that are about to be freed
     const size_t nw = (size_t)h->n_out * h->Np * h->Np, nv = (size_t)h->n_out * h->Np;
     double *w = nullptr, *a = nullptr, *y = nullptr;
     int rc = SR_OK;
