@@ -245,7 +245,7 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
         var_part = h->splitk_part;
         nrb = 4 * (h->Np / SR_NB);
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(unslide(h));          // (16-byte reads of U^-1: plain buffers; no-op unless one-point appends slid them)
+        if (h->slide & 1) SR_TRY(unslide(h));     // (16-byte reads of U^-1: after an odd number of in-place appends the view is 8 bytes off)
         SR_TRY(sr_launch_var_bal(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else if (h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out)) {
         // small model, few tiles: 64 x 64 workgroup tiles shorten the critical path of the tiny grid
@@ -253,11 +253,11 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
         var_part = h->splitk_part;             // n_out * (Np/64) * Tp <= 2 * 256 * 128 * 16 doubles
         nrb = h->Np / 64;
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(unslide(h));          // (16-byte reads of U^-1: plain buffers; no-op unless one-point appends slid them)
+        if (h->slide & 1) SR_TRY(unslide(h));     // (16-byte reads of U^-1: after an odd number of in-place appends the view is 8 bytes off)
         SR_TRY(sr_launch_var64(h->Wt, h->Ks, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else {
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        SR_TRY(unslide(h));          // (16-byte reads of U^-1: plain buffers; no-op unless one-point appends slid them)
+        if (h->slide & 1) SR_TRY(unslide(h));     // (16-byte reads of U^-1: after an odd number of in-place appends the view is 8 bytes off)
         SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, h->var_variant, s));
     }
     sr_final_args fa;
