@@ -335,7 +335,9 @@ int srh::unslide(sr_gp* h) {
     if (e == hipSuccess) e = hipMemset(a + nv, 0, sizeof(double) * SR_SLIDE_STEPS);
     if (e == hipSuccess) e = hipMemcpy(y, h->yT, sizeof(double) * nv, hipMemcpyDeviceToDevice);
     if (e == hipSuccess) e = hipMemset(y + nv, 0, sizeof(double) * SR_SLIDE_STEPS);
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (not the device: resident servers of other models stay)
+    // the old buffers go back to the block cache below: nothing on ANY stream may still be reading them (a prediction the
+    // caller launched asynchronously, say) -- the device-wide wait of the library (resident servers leave first)
+    if (e == hipSuccess) e = device_sync();
     if (e != hipSuccess) {
         dev_free(w); dev_free(a); dev_free(y);
         sr_set_error("unslide: %s", hipGetErrorString(e));
