@@ -378,7 +378,7 @@ int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, l
 int sr_test_chain_drop(sr_gp_t h, int drop);
 /* diagnostic: the next n launches of the one-launch append of a grid of workgroups (sr_gp_append / sr_gp_append1_host with
  * one point beyond 512 padded rows) wait at their first device-wide barrier for a workgroup that does not exist and give
- * it up after ~10 ms: the deterministic way into the path a grid takes that cannot become resident as a whole (nothing of
+ * it up after ~5 ms: the deterministic way into the path a grid takes that cannot become resident as a whole (nothing of
  * the model written, the append done by separate launches instead; sr_gp_append1_host answers SR_EUNSUPPORTED). */
 int sr_test_grid_append_abort(int n);
 /* per-kernel hipEvent timing inside the library (adds an event pair per launch while enabled). */

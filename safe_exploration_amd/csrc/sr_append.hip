@@ -455,7 +455,7 @@ struct sr_append1g_args {
 
 // Device-wide barrier of the grid.  cnt[0] counts arrivals (it only grows: `target` = arrivals of all barriers so far +
 // this grid), cnt[1] is the STATE of the barriers: 2 q after barrier number q has opened, 2 q - 1 after it was given up.  The
-// last arriver opens (compare-and-swap 2 (q - 1) -> 2 q); a workgroup that has polled SR_APPG_SPINS times (~10 ms: some of the
+// last arriver opens (compare-and-swap 2 (q - 1) -> 2 q); a workgroup that has polled SR_APPG_SPINS times (~5 ms: some of the
 // grid never became resident -- another process holding the CUs with a grid of its own, say) gives up with the same
 // compare-and-swap towards 2 q - 1: whichever lands first decides for the whole grid.  Returns false when the barrier was
 // given up: the caller reports SR_APPG_ABORTED for every output and leaves the kernel, before anything of the model is

@@ -891,7 +891,7 @@ def test_in_place_appends_and_what_follows_them():
 
 def test_grid_append_that_cannot_assemble_falls_back():
     """The one-launch append beyond 512 padded rows is a grid of workgroups that wait for each other; where the grid cannot
-    become resident as a whole, its barrier is given up after ~10 ms, nothing of the model is written, and the append is done
+    become resident as a whole, its barrier is given up after ~5 ms, nothing of the model is written, and the append is done
     by separate launches (sr_gp_append1_host says SR_EUNSUPPORTED and the Python layer takes sr_gp_append).  Forced here
     with sr_test_grid_append_abort; in place (padded size stays) and into new buffers (padded size grows); the appends
     after it work as before."""
