@@ -40,6 +40,8 @@ METRIC = "one-step reachability evals/sec (batched query states), N=5k train pts
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (v_mfma_f64_16x16x4_f64) dense peak, vendor spec
 FP64_MFMA_MEASURED_TFLOPS = 77.4 # what scripts/mfma_f64_peak.hip reaches on this part (2 waves/SIMD, no operands from memory)
 HBM_PEAK_GBS = 8000.0
+XGMI_LINK_GBS = 153.0            # one xGMI link of an MI355X, per direction (7 links per GPU, point to point): what a ring /
+                                 # chain broadcast between two GPUs is bound by
 
 WORKLOADS = {
     # name: (description, seed, N, n_s, n_u, T per GPU, H, signal variance, prior a = a_scale * I)
@@ -181,6 +183,9 @@ def parse_args(argv=None):
                     "same and send the model through the replication path to itself (object broadcast, tensor broadcasts, "
                     "the packed factor in 64 MB pieces) plus one timed 64 MB broadcast -- so that the RCCL library is loaded and "
                     "has moved bytes on this box before a multi-GPU lease does it for the first time")
+    ap.add_argument("--c4-replicas", action="store_true", help="--workload c4 with N > 1 ranks: every rank updates its own "
+                    "replica (weak scaling, no exchange) instead of sharding the OUTPUTS over the ranks "
+                    "(parallel.fit_outputs_sharded: strong scaling, every factor broadcast once from its owner)")
     ap.add_argument("--dump-shards", default="", help="directory: every rank stores its query seed and the head of its "
                     "outputs of the last step there (shard_rank<r>.npz) -- for tests of the sharded path")
     return ap.parse_args(argv)
@@ -226,6 +231,90 @@ def main(argv=None):
                  nprocs=args.gpus, join=True)
         return
     run(args)
+
+
+def gather_rank_stats(vals, dev, world):
+    """(world, len(vals)) array of every rank's numbers, on every rank (one all_gather of a small fp64 tensor)."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=dev)
+    if world == 1:
+        return mine.cpu().numpy()[None, :]
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return torch.stack(parts).cpu().numpy()
+
+
+def rank_section(per_rank_ms):
+    """The per-rank part of an N > 1 line: a slow rank, a straggling clock or an uneven shard must be readable from the
+    line itself (the scaling run is launched by the driver, nobody watches it)."""
+    per = [float(x) for x in per_rank_ms]
+    return {"ms_per_step": [round(x, 4) for x in per], "ms_per_step_min": min(per), "ms_per_step_max": max(per),
+            "slowest_rank": int(np.argmax(per)), "spread": (max(per) - min(per)) / max(min(per), 1e-12)}
+
+
+def run_model_update_sharded(args, dev, world, rank):
+    """--workload c4 with N > 1 ranks (default): ONE model update with the outputs dealt to the ranks
+    (parallel.fit_outputs_sharded, SURVEY 8(e) / DESIGN 5): rank r factorises outputs r, r + world, ... with no
+    communication, every factor then travels once from its owner as its packed upper triangle.  Strong scaling: the
+    work is fixed (n_out = 2: two ranks have something to factorise, the others only receive).  value = algorithmic
+    TFLOP/s of the whole job over the slowest rank's time, the broadcast included."""
+    import torch
+    import torch.distributed as dist
+    from safe_exploration_amd import workload, parallel
+    N = args.n_train or 50000
+    n_s, n_u = 2, 1
+    prob = workload.make_problem(4, N, n_s, n_u, 16)
+    hyp = workload.hyp_list(prob)
+    gp = None
+    for _ in range(max(args.warmup, 1)):
+        gp = None
+        gp = parallel.fit_outputs_sharded(n_s, n_s, n_u, prob["Z"], prob["Y"], hyp=hyp, device=dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    moved = 0
+    for _ in range(args.steps):
+        gp = None                                          # (the previous full model goes back to the block cache first)
+        gp = parallel.fit_outputs_sharded(n_s, n_s, n_u, prob["Z"], prob["Y"], hyp=hyp, device=dev)
+        moved += parallel.LAST_REPLICATION.get("factor_bytes", 0) + parallel.LAST_REPLICATION.get("other_bytes", 0)
+    torch.cuda.synchronize(dev)
+    local = time.perf_counter() - t0
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = gather_rank_stats([local, elapsed], dev, world)
+    elapsed = float(stats[:, 1].max())
+    idx = np.random.default_rng(0).choice(N, min(N, 1024), replace=False)
+    s2n = prob["noise_var"] + 1e-5 + 1e-8
+    mu, _ = gp.predict(prob["Z"][idx])
+    res_mu = float(np.abs(mu + s2n[None, :] * gp.beta[idx] - prob["Y"][idx]).max())
+    assert res_mu < 1e-7, "posterior identity violated on rank %d: %g" % (rank, res_mu)
+    if rank == 0:
+        flops = n_s * (2.0 / 3.0) * float(N) ** 3
+        per = elapsed / args.steps
+        owners = min(world, n_s)
+        line = {
+            "metric": "GP model update TFLOP/s (blocked fp64 Cholesky + explicit triangular inverse), N=%d train pts" % N,
+            "value": flops / per / 1e12, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * per, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4 pendulum dims n_out=2, N=%d training points, ONE model update with the outputs sharded "
+                                   "over the ranks (parallel.fit_outputs_sharded), every factor broadcast once from its owner as "
+                                   "its packed upper triangle, fp64" % N,
+                       "N": N, "n_out": n_s,
+                       "parallelism": "output-shard x%d of %d ranks (%s world=%d%s)" % (
+                           owners, world, dist.get_backend(), world, ", all ranks on cuda:0" if share_device() else ", one GPU per rank"),
+                       "broadcast_bytes_per_step": moved // max(args.steps, 1),
+                       "max|mu(z)+s2n*alpha-y|": res_mu},
+            "ranks": rank_section(1e3 * stats[:, 0] / args.steps),
+            "roofline": {"kernel": "sr_gemm_tn_kernel", "bound": "mfma", "achieved": flops / per / 1e12 / owners,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / per / 1e12 / owners / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "note": "per factorising GPU (%d of the %d ranks own an output), the broadcast inside the time" % (owners, world)},
+        }
+        print(json.dumps(line), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def run_model_update(args, dev, world, rank):
@@ -336,6 +425,8 @@ def run(args):
                                      ", all ranks on cuda:0" if share_device() else ", one GPU per rank")
 
     if args.workload == "c4":
+        if world > 1 and not args.c4_replicas:
+            return run_model_update_sharded(args, dev, world, rank)
         return run_model_update(args, dev, world, rank)
     desc, seed, N, n_s, n_u, T, H, sf2, a_scale = WORKLOADS[args.workload]
     if args.queries:
@@ -386,7 +477,8 @@ def run(args):
         assert bool((piece == ref).all())
         dry = {"backend": dist.get_backend(), "world": dist.get_world_size(), "replication_s": round(rep_s, 4),
                "replication_bytes": parallel.LAST_REPLICATION.get("factor_bytes", 0) + parallel.LAST_REPLICATION.get("other_bytes", 0),
-               "pieces": parallel.LAST_REPLICATION.get("pieces"), "broadcast_64MB_ms": round(1e3 * bc_s, 4)}
+               "pieces": parallel.LAST_REPLICATION.get("pieces"), "broadcast_64MB_ms": round(1e3 * bc_s, 4),
+               "broadcast_64MB_GBps": (64 << 20) / bc_s / 1e9, "xgmi_link_GBps": XGMI_LINK_GBS}
         backend = "single process; dry run of the %s process group with one rank" % dist.get_backend()
         dist.destroy_process_group()
     if args.var_group:
@@ -418,14 +510,16 @@ def run(args):
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize(dev)
+    local_s = time.perf_counter() - t0   # this rank alone (before the barrier)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gp.prof_enable(False)
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    # every rank's own numbers (its time to its own synchronize, the dominant kernel's hipEvent pairs), so that the line is
+    # computed from the SLOWEST rank and says how far the ranks are apart; `elapsed` = MAX over ranks of the bracketed time
+    stats = gather_rank_stats([elapsed, local_s] + list(gp.prof_get(_lib.K_VAR)) + list(gp.prof_get(_lib.K_KSTAR)), dev, world)
+    elapsed = float(stats[:, 0].max())
+    slowest = int(np.argmax(stats[:, 1]))
     overflow = None
     if args.workload == "c3s":
         # the surveyed parameters leave fp64 inside the horizon (by construction of the chain, not of this build: the
@@ -446,8 +540,8 @@ def run(args):
 
     if rank == 0:
         evals = float(world) * T * H * args.steps
-        var_ms, var_n = gp.prof_get(_lib.K_VAR)
-        ks_ms, ks_n = gp.prof_get(_lib.K_KSTAR)
+        # the roofline objects are those of the SLOWEST rank (rank 0 at N = 1)
+        var_ms, var_n, ks_ms, ks_n = (float(v) for v in stats[slowest, 2:6])
         ell_ms, ell_n = gp.prof_get(_lib.K_ELL)
         fin_ms, fin_n = gp.prof_get(_lib.K_FINAL)
         # algorithmic flops of one sr_var_kernel launch: n_out * N^2 * T  (N^2/2 MACs per query and
@@ -490,7 +584,8 @@ def run(args):
                        "parallelism": "query-shard x%d (%s), one-time broadcast of Z/alpha and the packed upper "
                                       "triangle of U^-1, no data-path collective" % (world, backend),
                        "model_fit_s": round(fit_s, 3), "broadcast_s": round(bcast_s, 3)},
-            "roofline": {"kernel": "sr_var_kernel", "bound": "mfma", "achieved": achieved,
+            "ranks": rank_section(1e3 * stats[:, 1] / args.steps),
+            "roofline": {"kernel": "sr_var_kernel", "bound": "mfma", "rank": slowest, "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "frac_of_measured_ceiling": achieved / FP64_MFMA_MEASURED_TFLOPS,
@@ -522,7 +617,11 @@ def run(args):
             fb = bcast.get("factor_bytes", 0) + bcast.get("other_bytes", 0)
             line["config"].update({"broadcast_bytes": fb, "broadcast_dense_factor_bytes": bcast.get("dense_factor_bytes"),
                                    "broadcast_pieces": bcast.get("pieces"),
-                                   "broadcast_GBps": fb / bcast_s / 1e9 if bcast_s > 0 else None})
+                                   "broadcast_GBps": fb / bcast_s / 1e9 if bcast_s > 0 else None,
+                                   "xgmi_link_GBps": XGMI_LINK_GBS,
+                                   "broadcast_frac_of_xgmi_link": fb / bcast_s / 1e9 / XGMI_LINK_GBS if bcast_s > 0 else None,
+                                   "broadcast_note": "one-time replication (host-side packing and unpacking of the 64 MB pieces "
+                                                     "included); a chain / ring broadcast is bound by ONE xGMI link per hop"})
         if world == 1 and not args.no_cpu_baseline:
             if H == 1:
                 line["cpu_baseline"] = cpu_baseline(prob, l_mu, l_sigma)

@@ -29,6 +29,8 @@ typedef struct sr_gp* sr_gp_t;
 #define SR_EHIP       -2   /* HIP runtime error (no device, OOM, launch)  */
 #define SR_ENOTPD     -3   /* Cholesky breakdown: matrix not positive definite */
 #define SR_ESTATE     -4   /* call order violated (e.g. predict before factorize) */
+#define SR_EBUSY      -6   /* transient: the device could not take the request now (a grid of co-resident workgroups did
+                            * not assemble).  Nothing was changed; retry, or take the entry point the comment names. */
 #define SR_EUNSUPPORTED -5 /* dimension outside compiled range (n_s<=8, n_u<=4, D<=12).  The reference's systems (n_s <= 4,
                             * D <= 5) run in registers, and so does everything up to n_s = 8 with n_u <= 2; the ellipsoid
                             * step with n_s = 8 and n_u = 3, 4 is compiled but spills 164 / 452 B per lane to scratch
@@ -96,6 +98,8 @@ int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void*
  * sr_gp_set_small_path not 0: one workgroup per output up to 512 padded rows, a grid of workgroups with two device-wide
  * barriers beyond -- every workgroup of that grid has to be resident at once, the library keeps it below 7/8 of the CUs);
  * SR_EUNSUPPORTED otherwise, before anything is touched: copy the point to the device and call sr_gp_append.
+ * SR_EBUSY when the grid could not become resident this time (nothing touched; sr_gp_append takes separate launches, and
+ * the library leaves the grid alone for the next 16 one-point appends, doubling with every abort in a row).
  * Beyond 512 padded rows, and while the padded size stays, the point is appended IN PLACE (the model's buffers become views
  * one step further into their allocations; sr_gp_export and every query work on the views; calls that rewrite the model and
  * big batches first copy it back into plain buffers).  sr_gp_append with m = 1 does the same. */
@@ -265,6 +269,13 @@ int sr_gp_set_var_variant(sr_gp_t h, int variant);
 /* blocks of 128 rows per Cholesky panel of sr_gp_factorize (the trailing matrix is read-modify-written once per
  * panel); 0 = chosen by size (default).  Results agree to rounding; a measurement knob. */
 int sr_gp_set_fact_panel(sr_gp_t h, int panel);
+/* sr_gp_factorize between 3 and 128 blocks of 128 rows, a measured prototype (round 6): 1 runs the diagonal-block kernel on
+ * a stream of its own beside the rest of the previous block row, 2 keeps it on the critical stream and moves only the
+ * rest of the rows; the streams hand over through device counters.  0 (default) = one chain of launches: the pipelined
+ * forms are 1.2 - 2.8 times SLOWER on this part (profiles/r06_fact_pipeline.txt).  Same tiles, same order of summation:
+ * identical numbers.  sr_gp_fact_pipelined: did the last update of h run pipelined (1 / 0)? */
+int sr_gp_set_fact_pipeline(sr_gp_t h, int on);
+int sr_gp_fact_pipelined(sr_gp_t h);
 /* latency paths instead of the plain MFMA tiles: one-launch pass for small models (Np <= 512, T <= 1024),
  * HBM-bound streaming of U^-1 for batches of <= 64 queries, 64 x 64 tiles, balanced shares of the k-blocks under few
  * query tiles.  on = 1 (default) all of them, 2 all but the one-launch pass, 0 none; an A/B measurement knob.  Results
@@ -379,8 +390,10 @@ int sr_test_chain_drop(sr_gp_t h, int drop);
 /* diagnostic: the next n launches of the one-launch append of a grid of workgroups (sr_gp_append / sr_gp_append1_host with
  * one point beyond 512 padded rows) wait at their first device-wide barrier for a workgroup that does not exist and give
  * it up after ~5 ms: the deterministic way into the path a grid takes that cannot become resident as a whole (nothing of
- * the model written, the append done by separate launches instead; sr_gp_append1_host answers SR_EUNSUPPORTED). */
+ * the model written, the append done by separate launches instead; sr_gp_append1_host answers SR_EBUSY).
+ * sr_gp_grid_append_aborts: how often that has happened to h so far. */
 int sr_test_grid_append_abort(int n);
+int sr_gp_grid_append_aborts(sr_gp_t h, long* n);
 /* per-kernel hipEvent timing inside the library (adds an event pair per launch while enabled). */
 int sr_prof_enable(sr_gp_t h, int on);
 int sr_prof_reset (sr_gp_t h);

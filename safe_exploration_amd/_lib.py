@@ -13,7 +13,7 @@ import torch  # noqa: F401  MUST precede CDLL below: PyTorch-ROCm bundles its ow
 
 from ._build import LIB_PATH
 
-SR_OK, SR_EINVAL, SR_EHIP, SR_ENOTPD, SR_ESTATE, SR_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+SR_OK, SR_EINVAL, SR_EHIP, SR_ENOTPD, SR_ESTATE, SR_EUNSUPPORTED, SR_EBUSY = 0, -1, -2, -3, -4, -5, -6
 K_GRAM, K_POTRF, K_GEMM, K_KSTAR, K_VAR, K_FINAL, K_ELL, K_TRINV, K_SMALL = range(9)
 KERNEL_NAMES = {K_GRAM: "sr_gram_kernel", K_POTRF: "sr_potrf_diag_kernel", K_GEMM: "sr_gemm_tn_kernel",
                 K_KSTAR: "sr_kstar_kernel", K_VAR: "sr_var_kernel", K_FINAL: "sr_finalize_kernel",
@@ -92,11 +92,14 @@ SIGNATURES = {
     "sr_gp_chain_status": (_I, [_H, _PI]),
     "sr_gp_set_small_path": (_I, [_H, _I]),
     "sr_gp_set_fact_panel": (_I, [_H, _I]),
+    "sr_gp_set_fact_pipeline": (_I, [_H, _I]),
+    "sr_gp_fact_pipelined": (_I, [_H]),
     "sr_test_gemm_tn": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_gemm_tn_upper": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_potrf_diag": (_I, [_I, _P, _L, _P, _P, _L, _P, _I, _P]),
     "sr_test_chain_drop": (_I, [_H, _I]),
     "sr_test_grid_append_abort": (_I, [_I]),
+    "sr_gp_grid_append_aborts": (_I, [_H, _PL]),
     "sr_prof_enable": (_I, [_H, _I]),
     "sr_prof_reset": (_I, [_H]),
     "sr_prof_get": (_I, [_H, _I, _PD, _PL]),

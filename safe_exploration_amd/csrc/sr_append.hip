@@ -2,6 +2,7 @@
 // update_model(x, y, opt_hyp=False, replace_old=False), /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:347-419
 // (the reference refactorises; its row-append sketch: ssm_pytorch/utilities.py:74-117).
 #include "sr_mfma_tile.h"
+#include <atomic>
 #include "sr_pivot_dev.h"
 #include "sr_final_dev.h"
 
@@ -727,9 +728,9 @@ __global__ __launch_bounds__(1024) void sr_append1_grid_kernel(sr_append1g_args 
     }
 }
 
-static int g_test_grid_abort = 0;
+static std::atomic<int> g_test_grid_abort{0};
 // tests: the next n launches of the grid kernel wait for a workgroup that does not exist and give up
-extern "C" int sr_test_grid_append_abort(int n) { g_test_grid_abort = n; return SR_OK; }
+extern "C" int sr_test_grid_append_abort(int n) { g_test_grid_abort.store(n); return SR_OK; }
 
 long sr_append1_grid_ws(int Np0, int n_out) {                 // doubles of scratch: vp (W partials of u12), u12, gpart
     const int ncb = (Np0 + 255) / 256;
@@ -757,7 +758,7 @@ int sr_launch_append1_grid(const double* Wt0, const double* alpha0, const double
     g.vp = ws; g.u12 = ws + (long)n_out * SR_APPEND1G_MAX_W * Np0; g.gpart = g.u12 + (long)n_out * Np0;
     g.cnt = cnt; g.base = base; g.q0 = q0;
     g.extra = 0;
-    if (g_test_grid_abort > 0) { --g_test_grid_abort; g.extra = 1; }
+    if (g_test_grid_abort.load() > 0 && g_test_grid_abort.fetch_sub(1) > 0) g.extra = 1;
     g.inplace = inplace;
     SR_CHECK(!inplace || (Np1 == Np0 && Wt1 == Wt0 + Np0 + 1 && alpha1 == alpha0 + 1 && yT1 == yT0 + 1), SR_EINVAL,
              "append1_grid: in place needs the slid views of the same buffers");

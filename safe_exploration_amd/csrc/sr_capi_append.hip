@@ -43,17 +43,26 @@ __global__ void sr_append_y_kernel(const double* __restrict__ yT0, int Np0, int 
 // The grid kernel's workgroups wait for each other on the device, so two of its launches must never be in flight together
 // (each could hold a part of the CUs and wait for the rest): one at a time per process, from the launch to the stream
 // synchronisation behind it.  (Launches of OTHER processes on the same device are outside this lock.)
-static std::mutex g_grid_append_mutex;
+// Co-residency is a matter of ONE device: a lock per device.
+static std::mutex g_grid_append_mutex[SR_MAX_DEVICES];
+static std::mutex& grid_append_mutex(int device) { return g_grid_append_mutex[(unsigned)device % SR_MAX_DEVICES]; }
 
 // 0: the general route (a chain of launches); 1: one launch, one workgroup per output and share of the rows (small models);
 // 2: one launch of a grid of workgroups with two device-wide barriers (sr_append1_grid_kernel)
-static int append1_route(const sr_gp* h, int m) {
+static int append1_route(const sr_gp* h, int m, bool ignore_hold = false) {
     if (m != 1 || h->small_path == 0) return 0;
     const int Np1 = (int)round_up(h->N + m, SR_NB);
     if (h->Np <= SR_APPEND1_MAX_NP0 && Np1 <= SR_APPEND1_MAX_NP0 + SR_NB) return 1;
     static const bool no_grid = getenv("SR_APPEND_NO_GRID") != nullptr;       // (A/B measurements)
-    if (h->Np <= SR_APPEND1G_MAX_NP0 && h->n_out <= SR_APPEND1_MAX_OUT && !no_grid) return 2;
+    if (h->Np <= SR_APPEND1G_MAX_NP0 && h->n_out <= SR_APPEND1_MAX_OUT && !no_grid && (h->grid_hold == 0 || ignore_hold)) return 2;
     return 0;
+}
+// a grid launch gave its barrier up: leave the route alone for a while (the CUs it wants are held by someone else -- every
+// further attempt costs its ~5 ms time-out again), longer after every abort in a row
+static void grid_append_aborted(sr_gp* h) {
+    ++h->grid_aborts;
+    h->grid_hold = 16 << std::min(h->grid_aborts_row, 10);
+    ++h->grid_aborts_row;
 }
 static bool append1_fused(const sr_gp* h, int m) { return append1_route(h, m) != 0; }
 // workgroups per output of the grid route: all of them must be resident at once (they wait for each other) and one fits a
@@ -86,6 +95,9 @@ static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipSt
                          const double* y_host, bool* aborted) {
     *aborted = false;
     const int N0 = h->N, Np0 = h->Np, D = h->D, n_out = h->n_out;
+    // what the in-place view rests on: a front-padding row to give up, slack left behind the last output, buffers that carry it
+    SR_CHECK(Np0 - N0 >= 1 && h->slide >= 0 && h->slide < SR_SLIDE_STEPS - 1 && h->slack_ok, SR_ESTATE,
+             "append in place: N=%d Np=%d slide=%d slack=%d", N0, Np0, h->slide, h->slack_ok);
     const bool host_new = x_host != nullptr;
     const int W = append1_grid_w(h), nld = n_out * W;
     if (host_new && !h->app_pin) {
@@ -114,7 +126,7 @@ static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipSt
         SR_HIP(hipMemsetAsync(h->appg_cnt, 0, sizeof(double) * SR_APPEND1_MAX_OUT, s));
         h->appg_base = 0; h->appg_q = 0;
     }
-    std::unique_lock<std::mutex> grid_lock(g_grid_append_mutex);
+    std::unique_lock<std::mutex> grid_lock(grid_append_mutex(h->device));
     SR_TRY(sr_launch_append1_grid(h->Wt, h->alpha, h->yT, h->Z, h->ls, h->sf2, h->noise, h->general ? h->kp : nullptr, Znew, Ynew,
                                   h->Wt + Np0 + 1, h->alpha + 1, h->yT + 1, h->Z + (size_t)N0 * D,
                                   host_new ? h->app_pin_dev : ws + o_ld,
@@ -134,9 +146,12 @@ static int append1_slide(sr_gp* h, const double* Znew, const double* Ynew, hipSt
     memcpy(info_h.data(), back.data() + nld, sizeof(int) * n_out);
     if (info_h[0] == SR_APPG_ABORTED) {                           // the grid did not assemble: nothing written
         SR_TRY(grid_append_reset(h, s));
+        grid_append_aborted(h);
         *aborted = true;
-        return SR_EUNSUPPORTED;
+        sr_set_error("one-point append: the grid of workgroups did not become resident (abort %ld of this handle)", h->grid_aborts);
+        return SR_EBUSY;
     }
+    h->grid_aborts_row = 0;
     grid_lock.unlock();
     int bad = 0;
     for (int d = 0; d < n_out; ++d) {
@@ -163,14 +178,17 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         // one point, the padded size stays, the buffers carry their slack: in place
         static const bool no_slide = getenv("SR_APPEND_NO_SLIDE") != nullptr;      // (A/B measurements)
         const int np1 = (int)round_up(h->N + m, SR_NB);
-        if (!no_grid && append1_route(h, m) == 2 && np1 == h->Np && h->slack_ok && h->slide < SR_SLIDE_STEPS - 1 &&
+        const bool held = m == 1 && (h->grid_hold > 0 || h->slide_hold > 0);
+        if (m == 1 && h->slide_hold > 0) --h->slide_hold;       // (a big batch met an odd slide: see tile_route_alignment)
+        if (!no_grid && !held && append1_route(h, m) == 2 && np1 == h->Np && h->slack_ok && h->slide < SR_SLIDE_STEPS - 1 &&
             h->N + 1 <= h->z_cap && h->n_out <= SR_APPEND1_MAX_OUT && !no_slide) {
             bool aborted = false;
             const int rc = append1_slide(h, Znew, Ynew, s, info, x_host, y_host, &aborted);
             if (!aborted) return rc;
-            if (x_host) return rc;               // (the routes of separate launches want the point in device memory: SR_EUNSUPPORTED)
+            if (x_host) return rc;               // (the routes of separate launches want the point in device memory: SR_EBUSY)
             no_grid = true;                      // the grid did not assemble: separate launches
         }
+        if (m == 1 && h->grid_hold > 0) { --h->grid_hold; no_grid = true; }
         SR_TRY(unslide(h));                  // everything below works on plain buffers
     }
     const int N0 = h->N, Np0 = h->Np, off0 = Np0 - N0, D = h->D, n_out = h->n_out;
@@ -249,7 +267,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     if (!z_inplace) SR_AH(hipMemcpyAsync(Z1, h->Z, sizeof(double) * N0 * D, hipMemcpyDeviceToDevice, s));
     // (in place: rows N0 .. N1-1 of Z are not read by anything below -- the model keeps N = N0 until the commit)
     // one point on a small model: the whole append is ONE launch (sr_append1_small_kernel)
-    std::unique_lock<std::mutex> grid_lock(g_grid_append_mutex, std::defer_lock);
+    std::unique_lock<std::mutex> grid_lock(grid_append_mutex(h->device), std::defer_lock);
     if (route == 2) {
         grid_lock.lock();
         // the target holds zeros below the diagonal and its identity padding, or gets them now (as on the general route)
@@ -330,9 +348,11 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
         if (reuse_alt) h->wt_alt_off = -1;
         drop_new();
         if (rr != SR_OK) return rr;
-        if (host_new) { sr_set_error("sr_gp_append1_host: the grid of the one-launch append did not assemble"); return SR_EUNSUPPORTED; }
+        grid_append_aborted(h);
+        if (host_new) { sr_set_error("sr_gp_append1_host: the grid of the one-launch append did not assemble"); return SR_EBUSY; }
         return append_small(h, Znew, Ynew, m, s, info, nullptr, nullptr, true);
     }
+    if (route == 2) h->grid_aborts_row = 0;
     if (grid_lock.owns_lock()) grid_lock.unlock();
     for (int d = 0; d < n_out; ++d) {
         double t = back[fused1 ? d * nwy : d];
@@ -387,11 +407,21 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
     return SR_OK;
 }
 
+extern "C" int sr_gp_grid_append_aborts(sr_gp_t h, long* n) {
+    SR_CHECK(h && n, SR_EINVAL, "sr_gp_grid_append_aborts: NULL argument");
+    *n = h->grid_aborts;
+    return SR_OK;
+}
+
 extern "C" int sr_gp_append1_host(sr_gp_t h, const double* x_host, const double* y_host, void* stream, int* info) {
     SR_CHECK(h != nullptr && x_host && y_host, SR_EINVAL, "sr_gp_append1_host: NULL argument");
     SR_CHECK(h->factorized, SR_ESTATE, "sr_gp_append1_host: model not factorized");
     SR_DEVICE(h->device);
     if (!append1_fused(h, 1) || h->n_out > SR_APPEND1_MAX_OUT) {
+        if (append1_route(h, 1, true) == 2 && h->n_out <= SR_APPEND1_MAX_OUT) {
+            sr_set_error("sr_gp_append1_host: the grid route is resting after an abort (%d appends to go)", h->grid_hold);
+            return SR_EBUSY;                 // (sr_gp_append counts the rest down)
+        }
         sr_set_error("sr_gp_append1_host: no one-launch append for this model (Np=%d, n_out=%d)", h->Np, h->n_out);
         return SR_EUNSUPPORTED;
     }

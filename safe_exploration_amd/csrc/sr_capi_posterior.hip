@@ -179,6 +179,19 @@ static int stream_linearize(sr_gp* h, const double* x, double* mu, double* var, 
 }
 
 // GP posterior of Tc queries x = [xa | xb] into (mu, var, jac) in API layout (jac may be NULL).
+// The tile kernels read U^-1 in 16-byte pieces; after an odd number of in-place one-point appends the view is 8 bytes off
+// and the model goes back to plain buffers first (unslide: a copy of the factor and a device-wide wait -- this call then
+// BLOCKS).  So that a loop of "one append, one big batch" does not pay that every step, the in-place route of the append
+// is held off for the next 64 one-point appends, twice as many after every further forced unslide (reset by a refit).
+static int tile_route_alignment(sr_gp* h) {
+    if (!(h->slide & 1)) return SR_OK;
+    SR_TRY(unslide(h));
+    const int shift = std::min(h->slide_forced, 14);
+    h->slide_hold = 64 << shift;
+    ++h->slide_forced;
+    return SR_OK;
+}
+
 int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const double* xb, long ldb,
                    int nb, double* mu, double* var, double* jac, hipStream_t s) {
     // (ONE query against Np = 384: the one-launch pass is a single workgroup per output that fetches 590 KB of U^-1 on its
@@ -245,7 +258,7 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
         var_part = h->splitk_part;
         nrb = 4 * (h->Np / SR_NB);
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        if (h->slide & 1) SR_TRY(unslide(h));     // (16-byte reads of U^-1: after an odd number of in-place appends the view is 8 bytes off)
+        SR_TRY(tile_route_alignment(h));
         SR_TRY(sr_launch_var_bal(h->Wt, h->Ks, h->splitk_vt, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else if (h->small_path && sr_var64_wanted(h->Np, Tp, h->n_out)) {
         // small model, few tiles: 64 x 64 workgroup tiles shorten the critical path of the tiny grid
@@ -253,11 +266,11 @@ int srh::gp_pass(sr_gp* h, long Tc, const double* xa, long lda, int na, const do
         var_part = h->splitk_part;             // n_out * (Np/64) * Tp <= 2 * 256 * 128 * 16 doubles
         nrb = h->Np / 64;
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        if (h->slide & 1) SR_TRY(unslide(h));     // (16-byte reads of U^-1: after an odd number of in-place appends the view is 8 bytes off)
+        SR_TRY(tile_route_alignment(h));
         SR_TRY(sr_launch_var64(h->Wt, h->Ks, h->splitk_part, h->N, h->Np, Tp, h->n_out, s));
     } else {
         sr_prof_scope ps(&h->prof, SR_K_VAR, s);
-        if (h->slide & 1) SR_TRY(unslide(h));     // (16-byte reads of U^-1: after an odd number of in-place appends the view is 8 bytes off)
+        SR_TRY(tile_route_alignment(h));
         SR_TRY(sr_launch_var(h->Wt, h->Ks, h->var_part, h->N, h->Np, Tp, h->n_out, h->var_group, h->var_variant, s));
     }
     sr_final_args fa;

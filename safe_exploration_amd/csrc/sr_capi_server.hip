@@ -40,9 +40,10 @@ inline unsigned long long mb_check(const unsigned long long* mb) {
     for (int i = 0; i < 7; ++i) c ^= mb_load(mb + i);
     return c;
 }
-// epoch word of the line for this launch, command kept; the check word follows it
+// epoch word of the line for this launch with the command of the request that stands in the line (kept on the host: a
+// launch that was called off has ~0 in this word); the check word follows it
 inline void mb_set_epoch(sr_server& sv, unsigned long long epoch) {
-    mb_store(sv.mb + 5, (epoch << 8) | (mb_load(sv.mb + 5) & 0xffull));
+    mb_store(sv.mb + 5, (epoch << 8) | (sv.cmd & 0xffull));
     mb_store(sv.mb + 7, mb_check(sv.mb));
     std::atomic_thread_fence(std::memory_order_seq_cst);
 }
@@ -223,7 +224,8 @@ extern "C" int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_ord
             const double xv = j < D ? x_host[j] : 0.0;
             memcpy(&w[j], &xv, sizeof(double));
         }
-        w[5] = (sv.epoch << 8) | (second_order == 2 ? SR_SERVER_CMD_PING : (second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST));   // (2: diagnostics)
+        sv.cmd = second_order == 2 ? SR_SERVER_CMD_PING : (second_order ? SR_SERVER_CMD_SECOND : SR_SERVER_CMD_FIRST);   // (2: diagnostics)
+        w[5] = (sv.epoch << 8) | sv.cmd;
         w[6] = seq;
         w[7] = SR_SERVER_CHK;
         for (int i = 0; i < 7; ++i) w[7] ^= w[i];

@@ -4,6 +4,10 @@
 #include "sr_handle.h"
 using namespace srh;
 
+// set when a hand-over of the pipelined chain ran into its time-out once (a foreign stream of the chain's priority on one of
+// its hardware queues): the process stays on the plain chain from then on
+static std::atomic<bool> g_pipe_broken{false};
+
 // ---------------------------------------------------------------------------------------------
 // factorisation: K = U^T U (right-looking, 128-blocks in panels, look-ahead), U^-T / U^-1 by recursive halving
 // with all nodes of a level in one launch, alpha = U^-1 (U^-T y)
@@ -129,7 +133,7 @@ static int make_masked_stream(hipStream_t* st, int ncu, int first_bit, int last_
 // idle stream of the first and its kernels took twice as long in situ (diagonal block 38 -> 75 us, the whole update 4.9 ->
 // 7.6 - 8.9 ms; profiles/r04_factor_bench.txt against r03's).  A set of another key is destroyed when a new one is made,
 // unless an update is running on it at that moment (`busy`).
-struct sr_stream_set { int device, key, busy; hipStream_t fact, bulk, inv; };
+struct sr_stream_set { int device, key, busy; hipStream_t fact, bulk, inv, diag, row; int pipe_ok; };
 static std::mutex g_stream_mutex;
 static std::vector<sr_stream_set> g_stream_sets;
 static void release_fact_streams(sr_gp* h) {           // end of an update: the handle forgets the streams, the set is free
@@ -137,8 +141,30 @@ static void release_fact_streams(sr_gp* h) {           // end of an update: the 
     std::lock_guard<std::mutex> lk(g_stream_mutex);
     for (sr_stream_set& c : g_stream_sets)
         if (c.device == h->device && c.fact == h->fact_stream && c.busy > 0) --c.busy;
-    h->fact_stream = h->bulk_stream = h->inv_stream = nullptr;
+    h->fact_stream = h->bulk_stream = h->inv_stream = h->diag_stream = h->row_stream = nullptr;
     h->fact_regime = 0;
+}
+
+// Do the three streams run on three different hardware queues?  For every ordered pair: a waiter on one, the signal on
+// the other; a waiter whose signal sits behind it in the same queue gives up after 3 ms and says so.
+static bool own_queues(hipStream_t a, hipStream_t b, hipStream_t c) {
+    unsigned* f = nullptr;
+    if (hipMalloc((void**)&f, 8 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool ok = hipMemset(f, 0, 8 * sizeof(unsigned)) == hipSuccess;
+    hipStream_t st[3] = {a, b, c};
+    unsigned v = 0;
+    for (int i = 0; i < 3 && ok; ++i)
+        for (int j = 0; j < 3 && ok; ++j) {
+            if (i == j) continue;
+            ++v;
+            ok = sr_launch_fact_handover(nullptr, 0, f + 1, v, nullptr, 0, f, 3e-3, st[i]) == SR_OK &&
+                 sr_launch_fact_handover(f + 1, v, nullptr, 0, nullptr, 0, f, 3e-3, st[j]) == SR_OK &&
+                 hipStreamSynchronize(st[i]) == hipSuccess && hipStreamSynchronize(st[j]) == hipSuccess;
+        }
+    unsigned status = 1;
+    if (ok) ok = hipMemcpy(&status, f, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && status == 0;
+    (void)hipFree(f);
+    return ok;
 }
 
 static int ensure_fact_streams(sr_gp* h, int regime) {
@@ -168,12 +194,12 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
             for (size_t i = 0; i < g_stream_sets.size();) {
                 sr_stream_set& c = g_stream_sets[i];
                 if (c.device == h->device && c.busy == 0) {
-                    for (hipStream_t st : {c.fact, c.bulk, c.inv})
+                    for (hipStream_t st : {c.fact, c.bulk, c.inv, c.diag, c.row})
                         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
                     g_stream_sets.erase(g_stream_sets.begin() + i);
                 } else ++i;
             }
-            sr_stream_set c{h->device, key, 0, nullptr, nullptr, nullptr};
+            sr_stream_set c{h->device, key, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             int prio_lo = 0, prio_hi = 0;
             SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
             SR_HIP(hipStreamCreateWithPriority(&c.fact, hipStreamNonBlocking, prio_hi));
@@ -182,6 +208,12 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
             if (regime == 1) {
                 if (can_mask) SR_TRY(make_masked_stream(&c.inv, ncu, reserve, ncu));
                 else SR_HIP(hipStreamCreateWithPriority(&c.inv, hipStreamNonBlocking, prio_lo));
+                // the pipelined chain: two more streams of the chain's priority.  Their kernels WAIT for each other on the
+                // device, so each must sit on a hardware queue of its own (streams of one priority share a small pool of
+                // queues): checked once, here -- a waiter that shares its producer's queue runs into its time-out
+                SR_HIP(hipStreamCreateWithPriority(&c.diag, hipStreamNonBlocking, prio_hi));
+                SR_HIP(hipStreamCreateWithPriority(&c.row, hipStreamNonBlocking, prio_hi));
+                c.pipe_ok = own_queues(c.fact, c.diag, c.row) ? 1 : 0;
             } else {
                 // regime 2: a second bulk stream WITHOUT a mask, for the trailing updates that are long enough to hide a
                 // chain that waits for its CUs (below)
@@ -192,6 +224,7 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
         }
         ++set->busy;
         h->fact_stream = set->fact; h->bulk_stream = set->bulk; h->inv_stream = set->inv;
+        h->diag_stream = set->pipe_ok ? set->diag : nullptr; h->row_stream = set->pipe_ok ? set->row : nullptr;
     }
     if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
     for (int e = 0; e < 2; ++e) {
@@ -241,7 +274,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     hipStream_t s0 = (hipStream_t)stream;
     auto cleanup = [&]() {
         // never return with work in flight on the side streams
-        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream}) if (st) (void)hipStreamSynchronize(st);
+        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream, h->diag_stream, h->row_stream}) if (st) (void)hipStreamSynchronize(st);
         release_fact_streams(h);
         dev_free(scratch);
     };
@@ -283,6 +316,27 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     }
     lap("streams");
     static const bool no_early_inv = getenv("SR_FACT_NO_EARLY_INV") != nullptr;
+    // Pipelined chain (round 6; chain-bound sizes): see the block behind `if (pipe)` below.
+    const bool pipe = own_streams && regime == 1 && h->fact_pipe && !g_pipe_broken.load() && h->diag_stream && h->row_stream &&
+                      nb >= 3;
+    const bool two = h->fact_pipe == 2;
+    hipStream_t sd = nullptr, sr = nullptr;
+    unsigned *fl_status = nullptr, *fl_c = nullptr, *fl_d = nullptr, *fl_r = nullptr;
+    if (pipe) {
+        if (h->fact_flags_nb < nb) {
+            (void)device_sync();
+            dev_free(h->fact_flags);
+            h->fact_flags = nullptr; h->fact_flags_nb = 0;
+            SR_F(dev_alloc(&h->fact_flags, (size_t)(4 + 3 * nb)));
+            SR_F(dev_zero(h->fact_flags, sizeof(unsigned) * (size_t)(4 + 3 * nb)));
+            h->fact_flags_nb = nb; h->fact_epoch = 0;
+        }
+        fl_status = h->fact_flags; fl_c = h->fact_flags + 4; fl_d = fl_c + h->fact_flags_nb; fl_r = fl_d + h->fact_flags_nb;
+        sd = two ? sc : h->diag_stream; sr = h->row_stream;
+        if (!two) SR_FH(hipStreamWaitEvent(sd, h->fact_fork, 0));
+        SR_FH(hipStreamWaitEvent(sr, h->fact_fork, 0));
+    }
+    h->last_fact_pipe = pipe ? 1 : 0;
 
     // Outputs are processed in rounds of n_par as a BATCH: one chain of launches, every kernel works on the n_par
     // problems at once (grid dimension = output; operands `per` resp. NN doubles apart).  Round 2 ran one chain of
@@ -339,6 +393,126 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         std::vector<int> pb;
         for (int p = 0; p < nb; p += P) pb.push_back(p);
         pb.push_back(nb);
+        if (pipe) {
+            // ---- The same factorisation with the block step CUT at its dependencies and dealt to three streams:
+            //   critical (sc):  Sc(k) = the ONE block U[k][k+1] of the block row solve, then Ud(k+1) = the update of the next
+            //                   diagonal block -- all the next diagonal block needs;
+            //   diagonal (sd):  D(k+1), the diagonal-block kernel, as soon as Ud(k+1) is through;
+            //   row (sr):       Sr(k) = the rest of the block row solve, Ur(k+1) = the rest of the next row's update, BESIDE
+            //                   D(k+1) (24 us in which the plain chain ran one workgroup per output and nothing else);
+            //                   at a panel boundary the look-ahead rows and the hand-over to the bulk stream.
+            // Step k of the plain chain was D + S + U one after the other (~55 us alone, ~100 beside the trailing update);
+            // here it is max(D + Sc + Ud + two hand-overs, Sr + Ur).  Hand-overs: counters c[k] (diagonal block k updated),
+            // d[k] (factored), r[k] (row k updated; everything older on the row stream done), published and awaited by
+            // sr_fact_handover_kernel -- 2.7 us each, where an event pair between two hardware queues costs 12 - 13
+            // (scripts/xqueue_handoff.hip, profiles/r06_xqueue_handoff.txt) and lost the overlap in round 2.
+            // Same tiles, same k order as the plain chain: the same numbers.
+            const unsigned ep = ++h->fact_epoch;
+            const double tmo = 2.0;
+            auto hand = [&](hipStream_t st, unsigned* set, const unsigned* w0, const unsigned* w1) {
+                return sr_launch_fact_handover(set, ep, w0, ep, w1, ep, fl_status, tmo, st);
+            };
+            int pi = 0;                                    // panel of block kb
+            bool early_pending = false;
+            for (int kb = 0; kb < nb; ++kb) {
+                while (kb >= pb[pi + 1]) ++pi;
+                const int p0 = pb[pi], p1 = pb[pi + 1];
+                const size_t dg = (size_t)kb * SR_NB * Np + (size_t)kb * SR_NB;
+                const int ncols = Np - (kb + 1) * SR_NB;
+                // ---- diagonal stream: D(kb) once its block is updated (block 0: once the Gram matrix is there)
+                // (two-stream form, fact_pipe == 2: D(kb) stays on the critical stream behind Ud(kb); only the rest of the
+                //  rows runs beside it -- one hardware queue and two hand-overs per step fewer)
+                if (!two) SR_F(hand(sd, kb > 0 ? fl_d + kb - 1 : nullptr, fl_c + kb, nullptr));
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_POTRF, sd);
+                    SR_F(sr_launch_potrf_diag(U, Np, Wt + dg, W + dg, Np, kb, info_dev + d0, sd, 0, &b_diag));
+                }
+                // ---- critical stream: publishes c[kb] (Gram / Ud(kb) are in front of it), waits for D(kb) and row kb
+                if (two) SR_F(hand(sc, fl_d + kb, kb > 0 ? fl_r + kb : nullptr, nullptr));
+                else SR_F(hand(sc, fl_c + kb, fl_d + kb, kb > 0 ? fl_r + kb : nullptr));
+                if (early_pending) {
+                    // every factor row above the middle is final, its diagonal blocks inverted (r[kb] stands for the
+                    // rest of row kb - 1's solve as well): left subtree of the inversion + the root's first product
+                    early_pending = false; early_done = true;
+                    SR_FH(hipEventRecord(h->ev_inv[0], sc));
+                    SR_FH(hipStreamWaitEvent(si, h->ev_inv[0], 0));
+                    for (const sr_gp::inv_level& lv : h->inv_levels) {
+                        sr_prof_scope ps(&h->prof, SR_K_TRINV, si);
+                        if (lv.depth == 0) {
+                            SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, 1, lv.maxM, lv.maxN, lv.tiles, 1.0, 2,
+                                                        si, &b_inv1));
+                        } else if (lv.n_left > 0) {
+                            SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, lv.n_left, lv.maxM, lv.maxN,
+                                                        lv.tiles_left, 1.0, 2, si, &b_inv1));
+                            SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2, lv.n_left, lv.maxM, lv.maxN,
+                                                        lv.tiles_left, -1.0, 3, si, &b_inv2));
+                        }
+                    }
+                    SR_FH(hipEventRecord(h->ev_inv[1], si));
+                }
+                // ---- row stream: publishes r[kb] (Ur(kb) is in front of it), waits for D(kb)
+                SR_F(hand(sr, kb > 0 ? fl_r + kb : nullptr, fl_d + kb, nullptr));
+                if (ncols <= 0) break;                     // last block: factored, nothing to its right
+                const int nxt = kb + 1;                    // the row the updates below make ready
+                const bool boundary = nxt == p1;           // ... is the first of the next panel: look-ahead of the panel [p0, p1)
+                const size_t dg1 = (size_t)nxt * SR_NB * Np + (size_t)nxt * SR_NB;
+                const int right = ncols - SR_NB;           // columns right of block nxt
+                // operands of the update of row nxt: the factor rows [p0, nxt) of this panel at columns >= nxt
+                const double* Ua = W + (size_t)p0 * SR_NB * Np + (size_t)nxt * SR_NB;
+                const int Ku = (nxt - p0) * SR_NB;
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    SR_F(sr_launch_gemm_tn(Wt + dg, Np, U + dg + SR_NB, Np, W + dg + SR_NB, Np, SR_NB, SR_NB, SR_NB, 1.0, 0.0, 0, sc, 1,
+                                           &b_solve));                                   // Sc(kb)
+                }
+                if (two) SR_F(hand(sc, fl_c + nxt, nullptr, nullptr));      // (here c[nxt] says: U[kb][nxt] is there)
+                // the previous trailing update wrote the look-ahead rows too: it has to be through (here and on the row stream)
+                if (boundary && n_bulk > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
+                {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                    SR_F(sr_launch_gemm_tn_upper(Ua, Np, Ua, Np, U + dg1, Np, SR_NB, SR_NB, Ku, -1.0, 1.0, sc, 1, -1, &b_ppp));   // Ud(nxt)
+                }
+                if (right > 0) {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sr);
+                    SR_F(sr_launch_gemm_tn(Wt + dg, Np, U + dg + 2 * SR_NB, Np, W + dg + 2 * SR_NB, Np, SR_NB, right, SR_NB, 1.0, 0.0, 0,
+                                           sr, 1, &b_solve));                            // Sr(kb)
+                }
+                // the updates of row nxt read U[kb][nxt] (Sc): c[nxt] is published behind Ud(nxt), i.e. behind Sc(kb)
+                if (right > 0 || boundary) SR_F(hand(sr, nullptr, fl_c + nxt, nullptr));
+                if (boundary && n_bulk > 0) SR_FH(hipStreamWaitEvent(sr, h->ev_bulk[(n_bulk - 1) & 1], 0));
+                if (right > 0) {
+                    sr_prof_scope ps(&h->prof, SR_K_GEMM, sr);
+                    SR_F(sr_launch_gemm_tn(Ua, Np, Ua + SR_NB, Np, U + dg1 + SR_NB, Np, SR_NB, right, Ku, -1.0, 1.0, 0, sr, 1,
+                                           &b_ppp));                                     // Ur(nxt)
+                }
+                if (boundary) {
+                    const int next_w = pi + 2 < (int)pb.size() ? pb[pi + 2] - p1 : 0;
+                    const int rest = Np - p1 * SR_NB;
+                    const int la = std::min(next_w * SR_NB, rest);
+                    const int bulk = rest - la;
+                    if (la > SR_NB) {                      // the other look-ahead rows (behind Ur(nxt): same stream)
+                        sr_prof_scope ps(&h->prof, SR_K_GEMM, sr);
+                        SR_F(sr_launch_gemm_tn_upper(Ua + SR_NB, Np, Ua + SR_NB, Np, U + dg1 + (size_t)SR_NB * Np + SR_NB, Np, la - SR_NB,
+                                                     rest - SR_NB, Ku, -1.0, 1.0, sr, 1, -1, &b_ppp));
+                    }
+                    if (bulk > 0) {                        // the trailing update behind them, on the bulk stream
+                        SR_FH(hipEventRecord(h->ev_panel[pi & 1], sr));
+                        SR_FH(hipStreamWaitEvent(sb, h->ev_panel[pi & 1], 0));
+                        {
+                            sr_prof_scope ps(&h->prof, SR_K_GEMM, sb);
+                            SR_F(sr_launch_gemm_tn_upper(Ua + la, Np, Ua + la, Np, U + dg1 + (size_t)la * Np + la, Np, bulk, bulk, Ku, -1.0, 1.0,
+                                                         sb, 0, -1, &b_ppp));
+                        }
+                        SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sb));
+                        ++n_bulk;
+                    }
+                    if (early_inv && !early_done && p1 >= root_mid && p1 < nb) early_pending = true;
+                }
+            }
+            // the last hand-over of the critical stream has waited for d[nb-1] and r[nb-1]; the diagonal stream still owes
+            // the publication of d[nb-1]
+            if (!two) SR_F(hand(sd, fl_d + nb - 1, nullptr, nullptr));
+        } else
         for (int pi = 0; pi + 1 < (int)pb.size(); ++pi) {
             const int p0 = pb[pi], p1 = pb[pi + 1];
             const int next_w = pi + 2 < (int)pb.size() ? pb[pi + 2] - p1 : 0;      // blocks of the next panel
@@ -472,9 +646,18 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                 std::chrono::duration<double, std::milli>(t_enq - t_begin).count(),
                 std::chrono::duration<double, std::milli>(t_end - t_begin).count());
     }
+    unsigned pipe_status = 0;
+    if (pipe && hipMemcpy(&pipe_status, fl_status, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) pipe_status = 1;
     cleanup();
 #undef SR_F
 #undef SR_FH
+    if (pipe_status != 0) {
+        // a hand-over gave up: whatever was computed behind it is void.  Once more, on the plain chain.
+        g_pipe_broken.store(true);
+        (void)hipMemset(h->fact_flags, 0, sizeof(unsigned) * (size_t)(4 + 3 * h->fact_flags_nb));
+        h->fact_epoch = 0;
+        return sr_gp_factorize(h, stream, info);
+    }
     int bad = 0;
     for (int d = 0; d < h->n_out; ++d) {
         if (info_h[d] > 0) info_h[d] = std::max(1, info_h[d] - (h->Np - h->N));   // padded -> training index
@@ -489,6 +672,14 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     h->factorized = 1;
     return SR_OK;
 }
+
+extern "C" int sr_gp_set_fact_pipeline(sr_gp_t h, int on) {
+    SR_CHECK(h != nullptr && on >= 0 && on <= 2, SR_EINVAL, "sr_gp_set_fact_pipeline: bad argument");
+    h->fact_pipe = on;
+    return SR_OK;
+}
+
+extern "C" int sr_gp_fact_pipelined(sr_gp_t h) { return h ? h->last_fact_pipe : 0; }
 
 extern "C" int sr_gp_set_fact_panel(sr_gp_t h, int panel) {
     SR_CHECK(h != nullptr && panel >= 0 && panel <= 64, SR_EINVAL, "sr_gp_set_fact_panel: bad argument");

@@ -11,6 +11,7 @@
 #define SR_NB 128          // factor block size == GEMM tile edge; Np is a multiple of it
 #define SR_PANEL 4         // factor blocks per Cholesky panel (deferred trailing update with K = 512)
 #define SR_MAX_NS 8
+#define SR_MAX_DEVICES 64    // per-device tables of the host side (locks)
 #define SR_FACT_SLOTS 8      // outputs factorised concurrently (own streams + scratch each)
 #define SR_MAX_NU 4
 #define SR_MAX_D 12
@@ -145,6 +146,10 @@ int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int
 // bt: batch of blocks (sA: stride of A, sB: of wt_diag, sC: of w_diag; info_dev + b)
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw,
                          int kb, int* info_dev, hipStream_t s, int skip = 0, const sr_batch* bt = nullptr);
+// one-thread hand-over between streams: publish set_flag = set_v (NULL: nothing), then wait for *w0 >= v0 and *w1 >= v1
+// (NULL: no wait); a wait longer than timeout_s sets *status = 1 and passes (sr_factor.hip)
+int sr_launch_fact_handover(unsigned* set_flag, unsigned set_v, const unsigned* w0, unsigned v0, const unsigned* w1,
+                            unsigned v1, unsigned* status, double timeout_s, hipStream_t s);
 int sr_launch_transpose(const double* src, double* dst, int n, hipStream_t s);
 int sr_launch_transpose_rect(const double* src, long lds_, double* dst, long ldd, int rows, int cols,
                              hipStream_t s);

@@ -26,6 +26,8 @@ struct sr_server {
     unsigned long long *mb_dev = nullptr, *reply_dev = nullptr; double* out_dev = nullptr;  // the device's addresses of the same
     hipStream_t stream = nullptr;            // non-blocking stream of its own: nothing else is ever ordered behind the kernel
     unsigned long long next_seq = 1, idle_ticks = 500000, epoch = 0;
+    unsigned long long cmd = 0;              // command of the request in the mailbox (the line's word 5 also carries the epoch and is
+                                             // overwritten when a launch is called off: the host keeps the command)
     long launches = 0, calls = 0;
     int stale = 0;                           // a request was given up (time-out): the next call starts from a fresh launch
     std::mutex mu;                           // one caller at a time: a call, and a quiesce from another thread's entry point
@@ -86,6 +88,14 @@ struct sr_gp {
     // (Wt: slide * (Np + 1) doubles, alpha / yT: slide doubles); every entry point that rewrites the model, and every kernel
     // that wants U^-1 aligned to 16 bytes, calls unslide() first.  slack_ok: the three allocations carry the zeroed slack.
     int slide = 0; int slack_ok = 0;
+    // A tile route of the posterior pass (16-byte reads of U^-1) that meets an odd slide has to unslide: a full copy of the
+    // factor and a device-wide wait.  A loop that alternates one append with one big batch would pay that every step, so such
+    // an unslide keeps the next `slide_hold` one-point appends off the in-place route (64, doubling with every forced
+    // unslide since the last refit: slide_forced).
+    int slide_hold = 0, slide_forced = 0;
+    // Grid route of the one-point append: a grid that cannot become resident gives up after ~5 ms.  After such an abort the
+    // route is left alone for `grid_hold` one-point appends (16, doubling with every further abort in a row, at most 16384).
+    int grid_hold = 0, grid_aborts_row = 0; long grid_aborts = 0;
     double* appg_cnt = nullptr; unsigned appg_base = 0, appg_q = 0;   // (arrivals and barriers of all launches so far)      // barrier counters of the grid append (zero at allocation), their value after the last launch
     void* app_pin = nullptr; double* app_pin_dev = nullptr;   // pinned, mapped: results of sr_gp_append1_host (log det partials, status words)
     double* Wt_alt = nullptr; size_t wt_alt_cap = 0;
@@ -97,6 +107,14 @@ struct sr_gp {
     // CRITICAL (diagonal blocks, panel rows, look-ahead rows, late inversion), BULK (the trailing update behind the
     // look-ahead rows) and INVERSION (the early part of the triangular inversion); the caller's stream waits for them
     hipStream_t fact_stream = nullptr, bulk_stream = nullptr, inv_stream = nullptr;
+    // pipelined chain (round 6, chain-bound sizes): the diagonal blocks on a stream of their own BESIDE the rest of the
+    // previous block row (row stream); the three streams hand over through counters in device memory (sr_fact_handover_kernel)
+    hipStream_t diag_stream = nullptr, row_stream = nullptr;
+    unsigned* fact_flags = nullptr; int fact_flags_nb = 0;   // [status | c[nb] | d[nb] | r[nb]]; zero at allocation, values = epochs
+    unsigned fact_epoch = 0;
+    int fact_pipe = 0;                                    // sr_gp_set_fact_pipeline: 0 = one chain of launches (default: the pipelined
+                                                          // forms measured slower, profiles/r06_fact_pipeline.txt), 1 = three streams, 2 = two
+    int last_fact_pipe = 0;                               // the last update ran pipelined (diagnostics / tests)
     hipEvent_t fact_fork = nullptr, fact_join = nullptr;
     hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_bulk[2] = {nullptr, nullptr};
     hipEvent_t ev_inv[2] = {nullptr, nullptr};            // critical -> inversion stream, back

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import _buffers as B
-from .._lib import lib, check, last_error, SR_EUNSUPPORTED
+from .._lib import lib, check, last_error, SR_EUNSUPPORTED, SR_EBUSY
 from ..state_space_models import StateSpaceModel
 
 _server_call = lib.sr_gp_server_call
@@ -516,6 +516,8 @@ class SimpleGPModel(StateSpaceModel):
                 if rc == SR_EUNSUPPORTED:
                     hd._append1_off_np = hd.Np       # not for this padded size: the general route from now on
                     rc = None
+                elif rc == SR_EBUSY:
+                    rc = None                        # this time only (the grid did not assemble): stage the point
             if rc is not None:
                 check(rc)
             elif xs.shape[0] <= 16:
@@ -571,6 +573,8 @@ class SimpleGPModel(StateSpaceModel):
         self._set_data(handle, Z, Y, noise, dev, s)
         if getattr(self, "_fact_panel", None) is not None:
             check(lib.sr_gp_set_fact_panel(handle.h, self._fact_panel))
+        if getattr(self, "_fact_pipeline", None) is not None:
+            check(lib.sr_gp_set_fact_pipeline(handle.h, self._fact_pipeline))
         info = (ctypes.c_int * self.n_s_out)()
         check(lib.sr_gp_factorize(handle.h, s, info))
         self._handle = handle
@@ -1052,6 +1056,18 @@ class SimpleGPModel(StateSpaceModel):
         self._fact_panel = int(panel)
         if self._handle is not None:
             check(lib.sr_gp_set_fact_panel(self._handle.h, int(panel)))
+
+    def set_fact_pipeline(self, on):
+        """model updates of 3 .. 128 blocks of 128 rows: diagonal blocks beside the previous block row (default) or one
+        chain of launches (sr_gp_set_fact_pipeline); identical numbers either way.  Works before training too."""
+        self._fact_pipeline = int(on)
+        if self._handle is not None:
+            check(lib.sr_gp_set_fact_pipeline(self._handle.h, self._fact_pipeline))
+
+    def fact_pipelined(self):
+        """did the last model update run pipelined? (sr_gp_fact_pipelined)"""
+        self._need_trained()
+        return bool(lib.sr_gp_fact_pipelined(self._handle.h))
 
     def get_forward_model_casadi(self, linearize_mu=True):
         """state_space_models.py:140-166.  The evaluator calls the model once per IPOPT callback and blocks: the resident

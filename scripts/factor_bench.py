@@ -3,6 +3,7 @@
 with the per-kernel split of the library's own hipEvent pairs and the posterior identity as a sanity check.
 
 usage (GPU box):  python scripts/factor_bench.py [N ...]      (default 1000 2000 5000 10000)
+SR_PANELS=0,2,4 picks the panel widths (0 = by size), SR_PIPE=1,0 the chain forms (1 = pipelined, round 6; 0 = one chain).
 """
 import json
 import os
@@ -19,13 +20,15 @@ from safe_exploration_amd import SimpleGPModel, workload, _lib  # noqa: E402
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [1000, 2000, 5000, 10000]
     panels = [int(p) for p in os.environ.get("SR_PANELS", "0,1,2,4").split(",")]
+    pipes = [int(p) for p in os.environ.get("SR_PIPE", "1").split(",")]
     n_s, n_u = int(os.environ.get("SR_NOUT", "2")), 1
     out = []
     for N in sizes:
         prob = workload.make_problem(4, N, n_s, n_u, 16)
-        for P in panels:
+        for P, pipe in [(P, q) for P in panels for q in pipes]:
             gp = SimpleGPModel(n_s, n_s, n_u, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob), device="cuda:0")
             gp.set_fact_panel(P)
+            gp.set_fact_pipeline(pipe)
             # Warm state and the MEDIAN of single refits.  (Round 3 timed five refits right after two warm-up calls on a model
             # created a moment before: at N = 5000 the table said 9.0 - 11.8 ms where `bench.py --workload c4 --n-train 5000`
             # -- three warm-up steps, twenty timed -- measures 5.0: the first refits of a new handle still touch fresh
@@ -55,7 +58,7 @@ def main():
             mu, var = gp.predict(prob["Z"][idx])
             res = float(np.abs(mu + s2n[None, :] * gp.beta[idx] - prob["Y"][idx]).max())
             flops = n_s * (2.0 / 3.0) * float(N) ** 3
-            rec = {"N": N, "n_out": n_s, "panel": P, "refit_ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 2),
+            rec = {"N": N, "n_out": n_s, "panel": P, "pipelined": int(gp.fact_pipelined()), "refit_ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 2),
                    "kernel_ms[total,launches]": split, "max|mu+s2n*alpha-y|": res}
             print(json.dumps(rec), flush=True)
             out.append(rec)

@@ -19,6 +19,8 @@ def run(N, n_out=2, panel=0):
     prob = workload.make_problem(4, N, n_out, 1, 16)
     gp = SimpleGPModel(n_out, n_out, 1, kern_types=["rbf"] * n_out, hyp=workload.hyp_list(prob), device="cuda:0")
     gp.set_fact_panel(panel)
+    if os.environ.get("SR_PIPE"):
+        gp.set_fact_pipeline(int(os.environ["SR_PIPE"]))        # 0: one chain, 1 / 2: the pipelined forms of round 6
     for _ in range(3):
         gp.train(prob["Z"], prob["Y"], opt_hyp=False)
         torch.cuda.synchronize()

@@ -107,6 +107,40 @@ def test_potrf_diag_block_matches_numpy(seed, cond):
         assert np.array_equal(B.to_numpy(tA), np.eye(128))
 
 
+@pytest.mark.parametrize("N,n_s,panel", [(300, 2, 0), (900, 2, 0), (1500, 4, 0), (2100, 2, 2), (2100, 2, 4), (3300, 1, 0)])
+def test_pipelined_model_update_equals_the_plain_chain(N, n_s, panel):
+    """Round 6: the block step of the Cholesky cut at its dependencies and dealt to three streams that hand over through
+    device counters (sr_capi_update.hip, `if (pipe)`) runs the SAME tiles in the same k order as the one chain of launches:
+    alpha and U^-1 must come out bit for bit, at panel boundaries that fall everywhere (sizes with 3 .. 26 blocks, panels
+    of 2, 3, 4), repeatedly on one handle (the counters carry epochs), and the library must say that it did run pipelined."""
+    import torch
+    from safe_exploration_amd import workload, SimpleGPModel
+    prob = workload.make_problem(40 + N, N, n_s, 1, 4)
+    out = {}
+    for pipe in (1, 0, 2, 1):
+        gp = SimpleGPModel(n_s, n_s, 1, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob))
+        gp.set_fact_panel(panel)
+        gp.set_fact_pipeline(pipe)
+        for rep in range(3 if pipe else 1):
+            gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+            assert gp.fact_pipelined() == bool(pipe) or N <= 256, (N, pipe)      # (fewer than 3 blocks: nothing to pipeline)
+            alpha, wt = gp.export_state()
+            got = (alpha.cpu().numpy().copy(), wt.cpu().numpy().copy())
+            if "ref" in out:
+                assert np.array_equal(got[0], out["ref"][0]), (N, pipe, rep)
+                assert np.array_equal(got[1], out["ref"][1]), (N, pipe, rep)
+            else:
+                out["ref"] = got
+        del gp
+    torch.cuda.synchronize()
+    # and the posterior identity at the training inputs (the chain did factor THIS matrix)
+    gp = SimpleGPModel(n_s, n_s, 1, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob))
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+    s2n = prob["noise_var"] + 1e-5 + 1e-8
+    mu, _ = gp.predict(prob["Z"][:256])
+    assert np.abs(mu + s2n[None, :] * gp.beta[:256] - prob["Y"][:256]).max() < 1e-9
+
+
 # ------------------------------------------------------------------ GP fit + predict
 @pytest.mark.parametrize("name,n_s,n_u", [("gp_pend.npz", 2, 1), ("gp_cart.npz", 4, 1)])
 def test_predict_matches_golden_and_oracle(name, n_s, n_u):
