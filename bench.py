@@ -398,6 +398,9 @@ def run_model_update(args, dev, world, rank):
 
 
 def run(args):
+    if args.var_variant not in (-1, 4) or os.environ.get("SR_FACT_FREE_RATIO"):
+        # A/B forms and measurement switches exist in the lab build only (make -C safe_exploration_amd/csrc lab)
+        os.environ.setdefault("SAFEREACH_LIB", os.path.join(ROOT, "scripts", "_bin", "libsafereach_lab.so"))
     import torch
     import torch.distributed as dist
     from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload, parallel

@@ -263,8 +263,9 @@ int sr_gp_set_chunk(sr_gp_t h, long chunk);
 int sr_gp_set_var_group(sr_gp_t h, int group);
 /* main loop of the variance kernel: 1 = the loop of rounds 1 - 4 (LDS-DMA tiles, workgroup barrier on top of every
  * k-tile), 3 = the pipelined loop of round 5 (barrier under the MFMA stream; same results as 1 bit for bit), 4 = 3 with
- * the structural zeros of the diagonal blocks of U^-1 left out (default; same numbers summed in another order: equal
- * to 1e-13).  A measurement knob; other values are SR_EINVAL. */
+ * the structural zeros of the diagonal blocks of U^-1 left out (same numbers summed in another order: equal to 1e-13),
+ * 5 = 4 with the row blocks (nrb - 1 - p, p) of a query tile in ONE workgroup (equal work per workgroup; bit for bit 4).
+ * A measurement knob; other values are SR_EINVAL. */
 int sr_gp_set_var_variant(sr_gp_t h, int variant);
 /* blocks of 128 rows per Cholesky panel of sr_gp_factorize (the trailing matrix is read-modify-written once per
  * panel); 0 = chosen by size (default).  Results agree to rounding; a measurement knob. */

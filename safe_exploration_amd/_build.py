@@ -4,7 +4,9 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libsafereach.so")
+# SAFEREACH_LIB (measurement scripts only): another build of the same C-ABI, e.g. scripts/_bin/libsafereach_lab.so (`make lab`:
+# the A/B kernel variants and the environment switches of the sweeps compiled in)
+LIB_PATH = os.environ.get("SAFEREACH_LIB") or os.path.join(PKG_DIR, "libsafereach.so")
 
 
 def build(force=False, verbose=False):

@@ -53,7 +53,7 @@ static int append1_route(const sr_gp* h, int m, bool ignore_hold = false) {
     if (m != 1 || h->small_path == 0) return 0;
     const int Np1 = (int)round_up(h->N + m, SR_NB);
     if (h->Np <= SR_APPEND1_MAX_NP0 && Np1 <= SR_APPEND1_MAX_NP0 + SR_NB) return 1;
-    static const bool no_grid = getenv("SR_APPEND_NO_GRID") != nullptr;       // (A/B measurements)
+    static const bool no_grid = sr_lab_on("SR_APPEND_NO_GRID");       // (lab build: A/B measurements)
     if (h->Np <= SR_APPEND1G_MAX_NP0 && h->n_out <= SR_APPEND1_MAX_OUT && !no_grid && (h->grid_hold == 0 || ignore_hold)) return 2;
     return 0;
 }
@@ -176,7 +176,7 @@ static int append_small(sr_gp* h, const double* Znew, const double* Ynew, int m,
                         const double* x_host = nullptr, const double* y_host = nullptr, bool no_grid = false) {
     {
         // one point, the padded size stays, the buffers carry their slack: in place
-        static const bool no_slide = getenv("SR_APPEND_NO_SLIDE") != nullptr;      // (A/B measurements)
+        static const bool no_slide = sr_lab_on("SR_APPEND_NO_SLIDE");      // (lab build: A/B measurements)
         const int np1 = (int)round_up(h->N + m, SR_NB);
         const bool held = m == 1 && (h->grid_hold > 0 || h->slide_hold > 0);
         if (m == 1 && h->slide_hold > 0) --h->slide_hold;       // (a big batch met an odd slide: see tile_route_alignment)

@@ -134,10 +134,10 @@ void srh::dev_free(void* p) {
                 size_t mem_free = 0, mem_total = 0;
                 sr_dev_guard guard(b.device);
                 (void)hipMemGetInfo(&mem_free, &mem_total);
-                const char* env = getenv("SR_BLOCK_CACHE_MB");
+                const char* env = getenv("SR_BLOCK_CACHE_MB");          // (0: every release goes to the driver)
                 cap = env ? ((size_t)atol(env) << 20) + 1 : std::min(mem_total / 8, (size_t)8 << 30);   // (+ 1: "asked" marker)
             }
-            static const bool no_cache = getenv("SR_NO_BLOCK_CACHE") != nullptr;      // diagnostics: every release goes to the driver
+            const bool no_cache = cap <= 1;
             // (a block that fell back to its exact size when memory was short would never match a request again)
             if (b.bytes > cap / 2 || b.bytes != sr_size_class(b.bytes) || no_cache) {
                 sr_dev_guard guard(b.device);
@@ -498,7 +498,10 @@ extern "C" int sr_gp_set_small_path(sr_gp_t h, int on) {
 }
 
 extern "C" int sr_gp_set_var_variant(sr_gp_t h, int variant) {
-    SR_CHECK(h != nullptr && (variant == 1 || variant == 3 || variant == 4), SR_EINVAL, "sr_gp_set_var_variant: 1, 3 or 4");
+    SR_CHECK(h != nullptr && (variant == 1 || variant == 3 || variant == 4 || variant == 5), SR_EINVAL, "sr_gp_set_var_variant: 1, 3, 4 or 5");
+#ifndef SR_LAB
+    if (variant != 4) { sr_set_error("sr_gp_set_var_variant: variant %d exists in the lab build only (make lab)", variant); return SR_EUNSUPPORTED; }
+#endif
     h->var_variant = variant;
     return SR_OK;
 }

@@ -243,7 +243,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_TRY(server_quiesce(h));
     SR_TRY(unslide(h));
     const auto t_begin = std::chrono::steady_clock::now();
-    static const bool trace_laps = getenv("SR_FACT_TRACE") != nullptr;
+    static const bool trace_laps = sr_lab_on("SR_FACT_TRACE");
     auto lap = [&](const char* what) { if (trace_laps) fprintf(stderr, "  %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };
     SR_TRY(ensure_wt(h));
     lap("wt");
@@ -264,7 +264,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         size_t mem_free = 0;
         (void)hipMemGetInfo(&mem_free, &h->mem_total);
     }
-    static const size_t par_cap_env = getenv("SR_FACT_PAR_GB") ? (size_t)atol(getenv("SR_FACT_PAR_GB")) << 30 : 0;
+    static const size_t par_cap_env = (size_t)sr_lab_env("SR_FACT_PAR_GB", 0) << 30;
     const size_t par_bytes = par_cap_env ? par_cap_env : std::max<size_t>(SR_FACT_PAR_BYTES, h->mem_total / 3);
     int n_par = (int)std::min<size_t>((size_t)std::min(h->n_out, SR_FACT_SLOTS),
                                       std::max<size_t>(1, par_bytes / (per * sizeof(double))));
@@ -315,7 +315,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));
     }
     lap("streams");
-    static const bool no_early_inv = getenv("SR_FACT_NO_EARLY_INV") != nullptr;
+    static const bool no_early_inv = sr_lab_on("SR_FACT_NO_EARLY_INV");
     // Pipelined chain (round 6; chain-bound sizes): see the block behind `if (pipe)` below.
     const bool pipe = own_streams && regime == 1 && h->fact_pipe && !g_pipe_broken.load() && h->diag_stream && h->row_stream &&
                       nb >= 3;
@@ -592,7 +592,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                 if (regime == 2 && si != nullptr) {
                     const double t_bulk = (double)nd * (double)bulk * (double)bulk * (double)Kp / 65e12;      // s
                     const double t_chain = (double)next_w * 1.8e-3;
-                    static const double free_ratio = getenv("SR_FACT_FREE_RATIO") ? atof(getenv("SR_FACT_FREE_RATIO")) : SR_FACT_FREE_RATIO;
+                    static const double free_ratio = sr_lab_envf("SR_FACT_FREE_RATIO", SR_FACT_FREE_RATIO);
                     if (free_ratio > 0.0 && t_bulk > free_ratio * t_chain) sbp = si;
                 }
                 if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
@@ -632,7 +632,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         SR_FH(hipEventRecord(h->fact_join, sc));
         SR_FH(hipStreamWaitEvent(s0, h->fact_join, 0));
     }
-    static const bool trace = getenv("SR_FACT_TRACE") != nullptr;
+    static const bool trace = sr_lab_on("SR_FACT_TRACE");
     const auto t_enq = std::chrono::steady_clock::now();
     std::vector<int> info_h(h->n_out, 0);
     SR_FH(hipMemcpyAsync(info_h.data(), info_dev, sizeof(int) * h->n_out, hipMemcpyDeviceToHost, s0));

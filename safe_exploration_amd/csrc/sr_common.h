@@ -19,6 +19,19 @@
 
 void sr_set_error(const char* fmt, ...);
 
+// Measurement switches exist in the LAB build only (make lab: scripts/_bin/libsafereach_lab.so, -DSR_LAB; the scripts that
+// sweep them load it through SAFEREACH_LIB).  In the product every one of them is its default, at compile time: the
+// library reads no environment variable except the three allocator diagnostics of sr_capi_handle.hip.
+#include <cstdlib>
+#ifdef SR_LAB
+static inline const char* sr_lab_str(const char* name) { return getenv(name); }
+#else
+static inline constexpr const char* sr_lab_str(const char*) { return nullptr; }
+#endif
+static inline long sr_lab_env(const char* name, long dflt) { const char* v = sr_lab_str(name); return v ? atol(v) : dflt; }
+static inline double sr_lab_envf(const char* name, double dflt) { const char* v = sr_lab_str(name); return v ? atof(v) : dflt; }
+static inline bool sr_lab_on(const char* name) { return sr_lab_str(name) != nullptr; }
+
 #define SR_HIP(call)                                                                  \
     do {                                                                              \
         hipError_t e_ = (call);                                                       \
@@ -377,8 +390,8 @@ static inline bool sr_var_splitk_wanted(int Np, long Tp, int n_out) {
 // 1024 workgroups -- shares that do not line up with the residency of the chip -- lose 15 - 30 %.  Half of a 512-way launch's
 // time goes to twice the partial products (128 KB each, written and read again by the reduce pass).
 static inline long sr_var_bal_wgs(long U) {
-    static const long forced = getenv("SR_BAL_WGS") ? atol(getenv("SR_BAL_WGS")) : 0;     // (measurements)
-    static const long thr = getenv("SR_BAL_THR") ? atol(getenv("SR_BAL_THR")) : 8192;
+    static const long forced = sr_lab_env("SR_BAL_WGS", 0);     // (lab build: scripts/bal_ab.py)
+    static const long thr = sr_lab_env("SR_BAL_THR", 8192);
     if (forced > 0) return U < forced ? U : forced;
     return U >= thr ? 512 : (U >= 256 ? 256 : U);
 }

@@ -617,8 +617,12 @@ __global__ __launch_bounds__(64) void sr_fact_handover_kernel(unsigned* set_flag
         const unsigned v = i ? v1 : v0;
         if (!w) continue;
         // counters only grow (the epoch of the update is the value waited for); signed difference: wrap-safe
+        unsigned spins = 0;
         while ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
-            __builtin_amdgcn_s_sleep(1);
+            // a polite poller: ~0.4 us between looks (single-workgroup kernels land on the same first CUs as this wave; a
+            // tight loop competes with them for instruction issue)
+            __builtin_amdgcn_s_sleep(16);
+            if ((++spins & 63) != 0) continue;
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
             if (wall_clock64() - t0 > timeout) {
                 __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

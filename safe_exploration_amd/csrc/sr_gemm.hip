@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_kernel(
 // One fp64 MFMA holds its SIMD for 64 cycles: a 128 x 128 tile with K = 128 is 14 us of one CU, whatever else
 // happens.  Products of few tiles are therefore latency-bound (the block row and the look-ahead row of the
 // Cholesky sit on its critical path) or balance-bound (triangular k ranges); they take the 64 x 64 tile.
-static long sr_env_long(const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; }
+static long sr_env_long(const char* name, long dflt) { return sr_lab_env(name, dflt); }     // (lab build: scripts/refit_ab.py)
 static inline bool sr_use_tile64(long tiles128, int K = 0) {
     static const long thr = sr_env_long("SR_T64_THR", 1024);           // (measurements)
     // ... unless K is long: then a grid that occupies the chip at least once is throughput-bound and the 64-tile's 8 flop

@@ -10,6 +10,7 @@
 // shapes:   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:546-596
 #include "sr_mfma_tile.h"
 #include "sr_final_dev.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // K1: one thread per (query, output); training inputs staged through LDS in tiles of 256 rows,
@@ -19,18 +20,23 @@
 #define SR_ZT 256
 // QPT queries per thread (t, t + 256, ..): the workgroup's stores of a row are one contiguous run of QPT x 2 KiB, the
 // LDS reads of the training row are shared by QPT kernel evaluations, and QPT independent exp chains interleave.
-template <int DT, int QPT>
+// ADJ (round 6, QPT == 2 only): the two queries of a thread are NEIGHBOURS (t, t + 1) and a row of K* leaves as one 16-byte
+// store per lane (1 KiB contiguous per wavefront) instead of two 8-byte stores 2 KiB apart; ADJ == 2: non-temporal (what the
+// big batches use).
+template <int DT, int QPT, int ADJ = 0>
 __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
     __shared__ double zs[SR_ZT * DT];
     __shared__ double al[SR_ZT];
+    static_assert(ADJ == 0 || QPT == 2, "adjacent queries come in pairs");
+    constexpr int QS = ADJ ? 1 : 256;                     // distance of a thread's queries
     const int d = blockIdx.y, sp = blockIdx.z;
-    const long tb = (long)blockIdx.x * 256 * QPT + threadIdx.x;
+    const long tb = (long)blockIdx.x * 256 * QPT + (ADJ ? 2 * threadIdx.x : threadIdx.x);
     const long tpad = a.Tw ? a.Tw : a.Tp;
     bool live[QPT], inpad[QPT], any = false;
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
-        live[q] = tb + 256 * q < a.T;
-        inpad[q] = tb + 256 * q < tpad;
+        live[q] = tb + QS * q < a.T;
+        inpad[q] = tb + QS * q < tpad;
         any |= inpad[q];
     }
 
@@ -39,7 +45,7 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
     for (int j = 0; j < DT; ++j) inv_l[j] = (j < a.D) ? 1.0 / a.ls[d * a.D + j] : 0.0;
 #pragma unroll
     for (int q = 0; q < QPT; ++q) {
-        const long t = tb + 256 * q;
+        const long t = tb + QS * q;
         mu[q] = 0.0;
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
@@ -76,12 +82,13 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
             for (int r = 0; r < rpad; ++r)
 #pragma unroll
                 for (int q = 0; q < QPT; ++q)
-                    if (inpad[q]) ks_col[(long)(i0 + r) * a.Tp + 256 * q] = 0.0;
+                    if (inpad[q]) ks_col[(long)(i0 + r) * a.Tp + QS * q] = 0.0;
             for (int r = rpad; r < nrow; ++r) {
                 double z[DT];
 #pragma unroll
                 for (int j = 0; j < DT; ++j) z[j] = zs[r * DT + j];
                 const double alr = al[r];
+                double kq[QPT];
 #pragma unroll
                 for (int q = 0; q < QPT; ++q) {
                     double diff[DT];
@@ -92,11 +99,18 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
                         r2 = fma(diff[j], diff[j], r2);
                     }
                     const double k = live[q] ? sf2 * exp(-0.5 * r2) : 0.0;
-                    if (inpad[q]) ks_col[(long)(i0 + r) * a.Tp + 256 * q] = k;
+                    kq[q] = k;
+                    if (!ADJ && inpad[q]) ks_col[(long)(i0 + r) * a.Tp + 256 * q] = k;
                     const double w = k * alr;
                     mu[q] += w;
 #pragma unroll
                     for (int j = 0; j < DT; ++j) g[q][j] = fma(-w, diff[j], g[q][j]);
+                }
+                if (ADJ) {                        // (tpad is a multiple of 128: a pair is inside the padded range or outside)
+                    typedef double sr_d2 __attribute__((ext_vector_type(2)));
+                    sr_d2* dst = reinterpret_cast<sr_d2*>(ks_col + (long)(i0 + r) * a.Tp);
+                    const sr_d2 v = {kq[0], kq[QPT - 1]};
+                    if (inpad[0]) { if (ADJ == 2) __builtin_nontemporal_store(v, dst); else *dst = v; }
                 }
             }
         }
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(256) void sr_kstar_kernel(sr_kstar_args a) {
 #pragma unroll
     for (int q = 0; q < QPT; ++q)
         if (inpad[q]) {
-            const long t = tb + 256 * q;
+            const long t = tb + QS * q;
             a.mu_part[((long)sp * a.n_out + d) * a.Tp + t] = mu[q];
 #pragma unroll
             for (int j = 0; j < DT; ++j)
@@ -230,8 +244,11 @@ int sr_launch_kstar(const sr_kstar_args& a, hipStream_t s) {
     if (a.D <= 5 && (a.Tw ? a.Tw : a.Tp) >= 8192) {
         const long tpad = a.Tw ? a.Tw : a.Tp;
         dim3 g2((unsigned)((tpad + 511) / 512), a.n_out, a.nsplit);
-        if (a.D <= 3) hipLaunchKernelGGL((sr_kstar_kernel<3, 2>), g2, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((sr_kstar_kernel<5, 2>), g2, dim3(256), 0, s, a);
+        // round 6: the two queries of a thread are neighbours and a row of K* leaves as ONE non-temporal 16-byte store per lane
+        // (same box, 65536 queries at N = 5000: 1.49 ms with two 8-byte stores 2 KiB apart, 1.47 with plain 16-byte stores,
+        // 1.28 non-temporal -- the 5.2 GB pass through the caches once; profiles/r06_headline_sweeps.txt)
+        if (a.D <= 3) hipLaunchKernelGGL((sr_kstar_kernel<3, 2, 2>), g2, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((sr_kstar_kernel<5, 2, 2>), g2, dim3(256), 0, s, a);
         SR_HIP(hipGetLastError());
         return SR_OK;
     }
@@ -261,55 +278,66 @@ __global__ __launch_bounds__(256, 2) void sr_var_kernel(const double* __restrict
                                                         double* __restrict__ part, int Np, long Tp,
                                                         int nrb, int ntq, int group, int k_beg) {
     __shared__ double smem[srt::SMEM_DOUBLES];
-    const long per_d = (long)nrb * ntq;
+    // VARIANT 5 (round 6): a workgroup takes the PAIR of row blocks (nrb - 1 - p, p) of its query tile, one after the other.
+    // Every pair contracts over (nrb + 1) * 128 rows in all, so all workgroups of the launch last the same: the 512 that are
+    // resident together start together, walk k together and are replaced together.  With single tiles (variants 1 - 4) a
+    // row of 64 equal workgroups is replaced as a whole while the seven other resident rows are somewhere else in k: the
+    // K* tiles of a query tile are then fetched once per row (L2 hit rate 0.58 at C2': the hits are the U^-1 tiles shared
+    // by the eight query tiles of a row on an XCD).  Same tiles, same arithmetic per tile: same bits.
+    constexpr bool PAIR = VARIANT == 5;
+    const int nrow = PAIR ? (nrb + 1) / 2 : nrb;          // work items per query tile
     const int ngrp = (ntq + group - 1) / group;
-    const long per_d_padded = (long)ngrp * nrb * group;
+    const long per_d_padded = (long)ngrp * nrow * group;
     const long b = blockIdx.x;
     const int d = (int)(b / per_d_padded);
     long rem = b % per_d_padded;
-    const int xg = (int)(rem / ((long)nrb * group));
-    rem = rem % ((long)nrb * group);
-    const int rb = nrb - 1 - (int)(rem / group);
+    const int xg = (int)(rem / ((long)nrow * group));
+    rem = rem % ((long)nrow * group);
+    const int item = (int)(rem / group);
     const int x = xg * group + (int)(rem % group);
     if (x >= ntq) return;
-    (void)per_d;
-
-    const double* A = Wt + (long)d * Np * Np + (long)rb * srt::BM;
     const double* B = Ks + (long)d * Np * Tp + (long)x * srt::BN;
-
-    srt::Acc acc;
-    acc.zero();
-    // VARIANT 4 leaves out the structural zeros of the diagonal block (row tiles interleaved over the two wavefront rows;
-    // the epilogue below sums over all rows of the block, so the row assignment does not show).
-    // VARIANT 3 / 4: the pipelined loop of round 5 (barrier under the MFMA stream), without / with the diagonal-block walk
-    if (VARIANT == 4) srt::mainloop_tn_pipe<true>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
-    else if (VARIANT == 3) srt::mainloop_tn_pipe<false>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
-    else srt::mainloop_tn_glds<16>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);      // (1: the loop of rounds 1 - 4)
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    double s[4];
+
+#pragma unroll 1
+    for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+        const int rb = PAIR ? (pass == 0 ? nrb - 1 - item : item) : nrb - 1 - item;
+        if (PAIR && pass == 1 && rb == nrb - 1 - item) break;            // odd number of row blocks: the middle one is alone
+        const double* A = Wt + (long)d * Np * Np + (long)rb * srt::BM;
+        srt::Acc acc;
+        acc.zero();
+        // VARIANT 4 / 5 leave out the structural zeros of the diagonal block (row tiles interleaved over the two wavefront
+        // rows; the epilogue below sums over all rows of the block, so the row assignment does not show).
+        // VARIANT 3 / 4 / 5: the pipelined loop of round 5 (barrier under the MFMA stream)
+        if (VARIANT >= 4) srt::mainloop_tn_pipe<true>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+        else if (VARIANT == 3) srt::mainloop_tn_pipe<false>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);
+        else srt::mainloop_tn_glds<16>(A, Np, B, Tp, k_beg, (rb + 1) * srt::BM, smem, acc);      // (1: the loop of rounds 1 - 4)
+
+        double s[4];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        double v = 0.0;
+        for (int ni = 0; ni < 4; ++ni) {
+            double v = 0.0;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v = fma(acc.v[mi][ni][r], acc.v[mi][ni][r], v);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        s[ni] = v;
-    }
-    // mainloop_tn ended with a barrier: smem is free.  red[wm][128]
-    double* red = smem;
-    if (lane < 16) {
+                for (int r = 0; r < 4; ++r) v = fma(acc.v[mi][ni][r], acc.v[mi][ni][r], v);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            s[ni] = v;
+        }
+        // the main loop ended with a barrier: smem is free.  red[wm][128]
+        double* red = smem;
+        if (lane < 16) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) red[wm * 128 + wn * 64 + ni * 16 + lane] = s[ni];
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        const double v = red[threadIdx.x] + red[128 + threadIdx.x];
-        part[((long)d * nrb + rb) * Tp + (long)x * srt::BN + threadIdx.x] = v;
+            for (int ni = 0; ni < 4; ++ni) red[wm * 128 + wn * 64 + ni * 16 + lane] = s[ni];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const double v = red[threadIdx.x] + red[128 + threadIdx.x];
+            part[((long)d * nrb + rb) * Tp + (long)x * srt::BN + threadIdx.x] = v;
+        }
+        if (PAIR) __syncthreads();                                       // `red` is read: the next tile's DMA may land
     }
 }
 
@@ -322,17 +350,23 @@ int sr_launch_var(const double* Wt, const double* Ks, double* part, int N, int N
     if (group < 1) group = 1;
     if (group > ntq) group = ntq;
     const int ngrp = (ntq + group - 1) / group;
-    const long blocks = (long)n_out * ngrp * nrb * group;
+    const long blocks = (long)n_out * ngrp * (variant == 5 ? (nrb + 1) / 2 : nrb) * group;
     SR_CHECK(blocks < 2147483647L, SR_EINVAL, "var: grid too large (%ld blocks)", blocks);
-    if (variant == 4)
-        hipLaunchKernelGGL(sr_var_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
-                           nrb, ntq, group, k_beg);
-    else if (variant == 3)
-        hipLaunchKernelGGL(sr_var_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
-                           nrb, ntq, group, k_beg);
-    else
-        hipLaunchKernelGGL(sr_var_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp,
-                           nrb, ntq, group, k_beg);
+#ifdef SR_LAB
+    // the A/B forms (sr_gp_set_var_variant): 1 the loop of rounds 1 - 4, 3 the pipelined loop without the diagonal-block walk,
+    // 5 pairs of row blocks per workgroup (round 6: profiles/r06_headline_sweeps.txt)
+    if (variant == 5) {
+        hipLaunchKernelGGL(sr_var_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp, nrb, ntq, group, k_beg);
+    } else if (variant == 3) {
+        hipLaunchKernelGGL(sr_var_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp, nrb, ntq, group, k_beg);
+    } else if (variant == 1) {
+        hipLaunchKernelGGL(sr_var_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp, nrb, ntq, group, k_beg);
+    } else
+#endif
+    {
+        (void)variant;
+        hipLaunchKernelGGL(sr_var_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, Wt, Ks, part, Np, Tp, nrb, ntq, group, k_beg);
+    }
     SR_HIP(hipGetLastError());
     return SR_OK;
 }

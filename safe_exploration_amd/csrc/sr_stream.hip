@@ -780,7 +780,7 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     a.npairs = a.ncb * (a.ncb + 1);
     const int nc = max(sr_stream_width(a.ncols), a.width_min);
     SR_CHECK(a.ncols >= 1 && a.ncols <= 128, SR_EINVAL, "stream: %d columns", a.ncols);
-    static const int probe_env = getenv("SR_ST1_PROBE") ? atoi(getenv("SR_ST1_PROBE")) : 0;
+    static const int probe_env = (int)sr_lab_env("SR_ST1_PROBE", 0);      // (lab build: scripts/t1_probe.py)
     a.probe = probe_env;
     dim3 grid(a.npairs, a.n_out);
     if (nc <= 4) {

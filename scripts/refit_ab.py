@@ -4,6 +4,8 @@ are read at the first call, so one process per setting.  GPU box: SR_T64_JOBS_TH
 import os, sys, time, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: F401  (the switches exist in the lab build only)
 from safe_exploration_amd import SimpleGPModel, workload
 out = []
 for N in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1000,2000,5000,10000").split(",")]:

@@ -6,6 +6,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: F401  (the switches exist in the lab build only)
 from safe_exploration_amd import SimpleGPModel, workload, _buffers as B
 from _timing import timeit
 for N in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1000,2000,3000,5000").split(",")]:

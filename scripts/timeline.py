@@ -13,6 +13,9 @@ import sys
 
 
 def run(N, n_out=2, panel=0):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if any(k.startswith(("SR_FACT_", "SR_T64_")) for k in os.environ):
+        import _lab  # noqa: F401  (the switches exist in the lab build only)
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from safe_exploration_amd import SimpleGPModel, workload

@@ -446,8 +446,28 @@ def test_full_size_properties():
 
 def test_var_kernel_variants_agree_bitwise():
     """The pipelined main loop of round 5 (variant 3) is the arithmetic of the loop of rounds 1 - 4 (variant 1) in the same
-    order: equal bit for bit.  Variant 4 (default) leaves out the structural zeros of the diagonal blocks and deals the rows
-    of a block to the wavefronts differently: same numbers, another order of summation."""
+    order: equal bit for bit.  Variant 4 (the product's) leaves out the structural zeros of the diagonal blocks and deals
+    the rows of a block to the wavefronts differently: same numbers, another order of summation.  Variant 5 (round 6)
+    runs the tiles of 4 two per workgroup: bit for bit 4.
+    The A/B forms live in the LAB build (scripts/_bin/libsafereach_lab.so, `make lab`): the test runs itself once more in
+    a process that loads that library; the product answers SR_EUNSUPPORTED for them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lab = os.path.join(root, "scripts", "_bin", "libsafereach_lab.so")
+    if os.environ.get("SAFEREACH_LIB") != lab:
+        probe = hip_model(*[orc.make_synthetic(5, 40, 2, 1, 4)[k] for k in ("Z", "Y", "lengthscale", "signal_var", "noise_var")], 2, 1)
+        with pytest.raises(NotImplementedError):
+            probe.set_var_variant(1)
+        probe.set_var_variant(4)
+        if not os.path.exists(lab):
+            pytest.skip("lab build missing (make -C safe_exploration_amd/csrc lab)")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                            "test_var_kernel_variants_agree_bitwise"], env=dict(os.environ, SAFEREACH_LIB=lab), cwd=root,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        return
     syn = orc.make_synthetic(91, 700, 2, 1, 3000)
     gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
     x = np.hstack((syn["p"], syn["k_ff"]))
@@ -461,6 +481,9 @@ def test_var_kernel_variants_agree_bitwise():
     mu2, var2 = gp.predict(x)
     np.testing.assert_array_equal(mu0, mu2)
     np.testing.assert_allclose(var2, var0, rtol=0, atol=1e-13)
+    gp.set_var_variant(5)                                  # (round 6) pairs of row blocks per workgroup: the tiles of variant 4
+    _, var5 = gp.predict(x)
+    np.testing.assert_array_equal(var5, var2)
     # every count of k-tiles modulo the pair structure of the pipelined loop, with and without a diagonal-block walk
     # (front padding 0 .. 127 rows moves the first k-tile; row block 0 of a padded model has fewer than eight k-tiles)
     for N in (1, 17, 33, 100, 128, 129, 145, 161, 250, 257, 300, 383, 400):
@@ -474,6 +497,9 @@ def test_var_kernel_variants_agree_bitwise():
         _, v3 = g2.predict(x2)
         g2.set_var_variant(4)
         _, v4 = g2.predict(x2)
+        g2.set_var_variant(5)
+        _, v5 = g2.predict(x2)
+        np.testing.assert_array_equal(v4, v5, err_msg="N=%d" % N)
         np.testing.assert_array_equal(v1, v3, err_msg="N=%d" % N)
         np.testing.assert_allclose(v4, v3, rtol=0, atol=1e-13, err_msg="N=%d" % N)
     om = oracle_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"])
