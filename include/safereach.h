@@ -80,29 +80,21 @@ int sr_gp_set_data_general(sr_gp_t h, const double* Z, const double* Y, const do
  * Synchronises the stream before returning. */
 int sr_gp_factorize(sr_gp_t h, void* stream, int* info);
 
-/* Condition on m <= 128 ADDITIONAL training points (same hyper-parameters) without refactorising:
- * block row append of the triangular factor, O(N^2 m).  Znew m x D, Ynew m x n_out.
+/* Condition on m <= 128 ADDITIONAL training points (same hyper-parameters) without refactorising: block row append of
+ * the triangular factor, O(N^2 m).  Znew m x D, Ynew m x n_out; info [host, n_out] like sr_gp_factorize.
  * replaces: update_model(x, y, opt_hyp=False, replace_old=False)  ssm_gpy/gaussian_process.py:347-419
  * (the reference refactorises; its own row-append sketch is ssm_pytorch/utilities.py:74-117).
- * info [host, n_out] like sr_gp_factorize.  On success N grows by m and Np may grow.
- * m <= 16 takes matrix-vector shaped passes (U12 through the streaming prediction kernels, every step one launch over all
- * outputs; 0.29 ms for one point, 0.57 ms for 16 at N = 5000), one point on a model of <= 512 padded rows is ONE launch
- * (54 us per call at N = 50), larger m the same algebra on 64 x 64 MFMA tiles; either way alpha is updated from the old
- * model's mean at the new points and no buffer of the factor's size is allocated while the padded size stays the same.
- * m <= 16 also leaves log det of the grown model on the host (sr_gp_logdet_cached). */
+ * On success N grows by m and Np may grow; no buffer of the factor's size is allocated while Np stays.  m <= 16 also leaves
+ * log det of the grown model on the host (sr_gp_logdet_cached).  Blocks the host.  Routes by m: docs/HISTORY.md. */
 int sr_gp_append(sr_gp_t h, const double* Znew, const double* Ynew, int m, void* stream, int* info);
-/* ONE new point given in HOST memory (x_host: D doubles, y_host: n_out doubles; any host memory): what the reference's
- * exploration loop does after every step (exploration_runner.py:186-188 -> update_model(x, y, replace_old=False)).  The
- * point travels in the kernel arguments and the status words / log det come back through a pinned block the kernel
- * writes: no copy command in either direction.  Only where a one-launch append applies (<= 8192 padded rows, n_out <= 16,
- * sr_gp_set_small_path not 0: one workgroup per output up to 512 padded rows, a grid of workgroups with two device-wide
- * barriers beyond -- every workgroup of that grid has to be resident at once, the library keeps it below 7/8 of the CUs);
- * SR_EUNSUPPORTED otherwise, before anything is touched: copy the point to the device and call sr_gp_append.
- * SR_EBUSY when the grid could not become resident this time (nothing touched; sr_gp_append takes separate launches, and
- * the library leaves the grid alone for the next 16 one-point appends, doubling with every abort in a row).
- * Beyond 512 padded rows, and while the padded size stays, the point is appended IN PLACE (the model's buffers become views
- * one step further into their allocations; sr_gp_export and every query work on the views; calls that rewrite the model and
- * big batches first copy it back into plain buffers).  sr_gp_append with m = 1 does the same. */
+/* ONE new point given in HOST memory (x_host: D doubles, y_host: n_out doubles; any host memory): the reference's
+ * exploration loop after every step (exploration_runner.py:186-188 -> update_model(x, y, replace_old=False)).
+ * The point travels in the kernel arguments, status and log det come back through a pinned block: no copy command.
+ * Only where a one-launch append applies (<= 8192 padded rows, n_out <= 16, small path on).
+ * SR_EUNSUPPORTED otherwise and SR_EBUSY when the grid of co-resident workgroups could not assemble this time -- either
+ * way nothing was touched: copy the point to the device and call sr_gp_append.
+ * Beyond 512 padded rows, while Np stays, the point is appended IN PLACE (the model's buffers become views one step further
+ * into their allocations; calls that rewrite the model, and big batches after an odd number of steps, copy it back first). */
 int sr_gp_append1_host(sr_gp_t h, const double* x_host, const double* y_host, void* stream, int* info);
 
 /* padded leading dimension Np (multiple of 128) of the factor matrices.  The Np - N padding rows and
@@ -159,15 +151,12 @@ int sr_gp_linearize(sr_gp_t h, const double* x, double* mu, double* var, double*
 int sr_gp_set_input_transform(sr_gp_t h, const double* Tz, int n_x_in, void* stream);
 
 /* ---- one-step reachability, batched over T queries ------------------------------------------
- * replaces: gp_reachability.onestep_reachability  gp_reachability.py:19-156
- *   (+ utils.compute_remainder_overapproximations utils.py:108-144,
- *      utils_ellipsoid.ellipsoid_from_rectangle / sum_two_ellipsoids utils_ellipsoid.py:63-94,197-233)
- * p T x n_s ; q T x n_s x n_s or NULL (point branch) ; k_ff T x n_u ; k_fb T x n_u x n_s (required
- * iff q != NULL) ; a n_s x n_s ; b n_s x n_u ; l_mu, l_sigma n_s.
- * -> p_out T x n_s ; q_out T x n_s x n_s ; var_out T x n_s or NULL.
- * n_bad: device int or NULL; atomically incremented once per query whose box half-widths were not
- * all > 0 -- the condition on which the reference raises AssertionError
- * (utils_ellipsoid.py:226-228).  The caller zeroes it. */
+ * replaces: gp_reachability.onestep_reachability  gp_reachability.py:19-156  (+ utils.py:108-144,
+ *   utils_ellipsoid.py:63-94,197-233)
+ * p T x n_s ; q T x n_s x n_s or NULL (point branch) ; k_ff T x n_u ; k_fb T x n_u x n_s (required iff q != NULL) ;
+ * a n_s x n_s ; b n_s x n_u ; l_mu, l_sigma n_s.  -> p_out T x n_s ; q_out T x n_s x n_s ; var_out T x n_s or NULL.
+ * n_bad: device int or NULL, atomically incremented once per query whose box half-widths were not all > 0 -- where the
+ * reference raises AssertionError (utils_ellipsoid.py:226-228).  The caller zeroes it. */
 int sr_onestep_reach(sr_gp_t h, long T, const double* p, const double* q, const double* k_ff,
                      const double* k_fb, const double* a, const double* b, const double* l_mu,
                      const double* l_sigma, double c_safety, double* p_out, double* q_out,
@@ -322,47 +311,24 @@ int sr_host_block_is_device_visible(int device, const void* host_block);
 /* hipStreamSynchronize(stream) with `device` current, for a host layer that holds the raw stream handle (the handle 0 --
  * the null stream, PyTorch's default -- names the stream of whichever device is current: hence the device). */
 int sr_stream_synchronize(int device, void* stream);
-/* One blocking single query as ONE command: the D coordinates x_host (host memory, read at call time) travel in the
- * kernel arguments, the results go straight to the pinned host block
- *   out_host = [mu n | var n | jac_mu n x D]                      (second_order == 0)
- *              [... | jac_var n x D | hess_mu n x D x D]          (second_order != 0)
- * and the last workgroup stores seq to *flag_host (pinned; wait with sr_wait_flag).  Where the one-launch posterior applies
- * (ARD-RBF, Np <= 384; Np = 512 for second order) that is one launch; on larger models (from 512 padded rows; any kernel
- * family) the streamed route takes it over: x_host must then be PINNED, device-visible memory too -- the kernels read the
- * query from it -- and the workgroup that runs the final stage writes results and sequence number (N = 1000: 32 -> 26 us per
- * blocking call, N = 5000: 56 -> 49).  SR_EUNSUPPORTED with an input transform, with the size dispatch switched off, or
- * where a block is not device-visible: use sr_gp_predict / sr_gp_linearize.  replaces SimpleGPModel.__call__ (ssm_gpy/gaussian_process.py:135-144) and
- * linearize_predict(jacobians=True) as CasadiSSMEvaluator drives them (state_space_models.py:271-303, 384-417). */
+/* One blocking single query as ONE command.  replaces SimpleGPModel.__call__ (ssm_gpy/gaussian_process.py:135-144) and
+ * linearize_predict(jacobians=True) as CasadiSSMEvaluator drives them (state_space_models.py:271-303, 384-417).
+ * x_host (D doubles, read at call time) travels in the kernel arguments; the results go to the pinned block
+ *   out_host = [mu n | var n | jac_mu n x D]   (+ [jac_var n x D | hess_mu n x D x D] with second_order != 0)
+ * and the last workgroup stores seq to *flag_host (pinned; wait with sr_wait_flag).
+ * From 512 padded rows on the streamed kernels read the query from x_host: it must then be pinned, device-visible too.
+ * SR_EUNSUPPORTED with an input transform, with the size dispatch switched off, or where a block is not device-visible:
+ * use sr_gp_predict / sr_gp_linearize. */
 int sr_gp_call1(sr_gp_t h, const double* x_host, int second_order, double* out_host,
                 unsigned long long* flag_host, unsigned long long seq, void* stream);
-/* Resident single-query server: the latency path of the MPC loop -- CasadiSSMEvaluator.eval / JacFun.eval
- * (state_space_models.py:278-303, 384-417) call SimpleGPModel.__call__ / linearize_predict(jacobians=True)
- * (ssm_gpy/gaussian_process.py:135-144) once per IPOPT iteration and block.  sr_gp_server_start launches workgroups that
- * STAY on the device and poll a mailbox in pinned host memory (one workgroup per output up to 128 padded rows, Np / 64
- * per output from 256 on: every one keeps its strips of U^-1 in registers); sr_gp_server_call posts the query x_host
- * (D doubles, any host memory), waits for the answer and copies it to out_host (any host memory):
- *   [mu n | var n | jac_mu n x D]                              second_order == 0
- *   [... | jac_var n x D | hess_mu n x D x D]                  second_order != 0
- * No launch, copy command or completion interrupt per query: one PCIe read to see the request, one posted write to
- * answer it.  The kernel leaves after idle_timeout_s without a request (a hipDeviceSynchronize elsewhere in the process
- * waits at most that long) and sr_gp_server_call launches it again; every entry point that writes the model, and every
- * persistent multi-step launch on the device, takes it off the device first (it stays armed).  Models of at most 512
- * padded rows with D <= 5, every kernel identifier (ARD-RBF: one workgroup per output at 128 rows; mat52 / lin_rbf /
- * lin_mat52 -- the general family of sr_gp_set_data_general -- in Np / 64 parts at every size); x_host is in the GP's
- * input space, as for sr_gp_predict (an input transform set with sr_gp_set_input_transform concerns the reachability
- * entry points only and leaves the server resident).  SR_EUNSUPPORTED otherwise and from sr_gp_server_call when no
- * server is armed: use sr_gp_call1 / sr_gp_predict / sr_gp_linearize.
- * Host memory model: the request is ONE 64-byte mailbox line [x0 .. x4 | (epoch << 8) | command | sequence number | check
- * word]; the host writes payload, check word and sequence number (last) with ordinary stores separated by release
- * fences and spins on the reply words with volatile loads + an acquire fence.  The device takes a request only when the
- * eight words of its fetch xor to the check constant, so neither the atomicity of the 64-byte PCIe read nor the host's
- * store order is relied upon for CORRECTNESS: a half-written line is fetched again.  On x86-64 (TSO) the fences cost
- * nothing and a request is seen with the first fetch after its sequence number; a weaker host memory model only adds
- * re-fetches.  The spin loops use the pause hint on x86 and std::this_thread::yield elsewhere.
- * Calls on one handle are serialised inside the library (one mailbox), so two host threads may evaluate the same model
- * with buffers of their own; the model itself must not be written meanwhile, as everywhere.  A request that is not
- * answered within timeout_s is given up with SR_ESTATE: its sequence number is retired and the launch called off, the
- * next call starts a fresh one (a device kept busy by other work for longer than timeout_s is the expected cause). */
+/* Resident single-query server (the MPC loop's latency path).  replaces the blocking model evaluation inside
+ * CasadiSSMEvaluator.eval / JacFun.eval / BackFun.eval (state_space_models.py:278-303, 384-417, 534-562).
+ * _start launches workgroups that STAY on the device and poll a mailbox line in pinned host memory; _call posts x_host
+ * (D doubles, any host memory; GP input space), waits and copies the answer to out_host (layout of sr_gp_call1).
+ * Every kernel identifier, Np <= 512, D <= 5; SR_EUNSUPPORTED otherwise and from _call when no server is armed.
+ * The kernel leaves after idle_timeout_s without a request and _call launches it again; model updates take it off the
+ * device first (it stays armed).  No answer within timeout_s: SR_ESTATE, the next call starts a fresh launch.
+ * Threads, device-wide synchronisation, mailbox protocol: INTEGRATION.md 2.3 and csrc/sr_capi_server.hip. */
 int sr_gp_server_start(sr_gp_t h, double idle_timeout_s);
 int sr_gp_server_stop(sr_gp_t h);
 int sr_gp_server_call(sr_gp_t h, const double* x_host, int second_order, double* out_host, double timeout_s);
