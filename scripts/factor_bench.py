@@ -14,6 +14,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if any(k.startswith(("SR_FACT_", "SR_T64_")) for k in os.environ):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _lab  # noqa: F401,E402  (the switches exist in the lab build only)
 from safe_exploration_amd import SimpleGPModel, workload, _lib  # noqa: E402
 
 
