@@ -237,9 +237,10 @@ def gather_rank_stats(vals, dev, world):
     """(world, len(vals)) array of every rank's numbers, on every rank (one all_gather of a small fp64 tensor)."""
     import torch
     import torch.distributed as dist
-    mine = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=dev)
     if world == 1:
-        return mine.cpu().numpy()[None, :]
+        return np.array([[float(v) for v in vals]])
+    # (gloo gathers host tensors only; nccl = RCCL device tensors only)
+    mine = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     return torch.stack(parts).cpu().numpy()
@@ -249,7 +250,7 @@ def rank_section(per_rank_ms):
     """The per-rank part of an N > 1 line: a slow rank, a straggling clock or an uneven shard must be readable from the
     line itself (the scaling run is launched by the driver, nobody watches it)."""
     per = [float(x) for x in per_rank_ms]
-    return {"ms_per_step": [round(x, 4) for x in per], "ms_per_step_min": min(per), "ms_per_step_max": max(per),
+    return {"ms_per_step": per, "ms_per_step_min": min(per), "ms_per_step_max": max(per),
             "slowest_rank": int(np.argmax(per)), "spread": (max(per) - min(per)) / max(min(per), 1e-12)}
 
 

@@ -93,6 +93,41 @@ def _run_bench(argv, env_extra=None, timeout=1500):
     return json.loads(lines[0])
 
 
+def _check_rank_fields(line, world):
+    """an N > 1 line must diagnose itself -- every rank's own ms_per_step with min / max / slowest rank,
+    the roofline objects computed from the SLOWEST rank, and the one-time broadcast against the xGMI per-link figure."""
+    rk = line["ranks"]
+    assert len(rk["ms_per_step"]) == world and all(v > 0 for v in rk["ms_per_step"])
+    assert rk["ms_per_step_min"] == min(rk["ms_per_step"]) and rk["ms_per_step_max"] == max(rk["ms_per_step"])
+    assert 0 <= rk["slowest_rank"] < world and rk["ms_per_step"][rk["slowest_rank"]] == rk["ms_per_step_max"]
+    assert rk["spread"] >= 0
+    # the bracketed time (barrier on both sides, MAX over ranks) is never shorter than the slowest rank's own
+    assert line["ms_per_step"] >= rk["ms_per_step_max"] * (1 - 1e-9)
+    assert line["roofline"]["rank"] == rk["slowest_rank"]
+    cfg = line["config"]
+    assert cfg["xgmi_link_GBps"] == 153.0
+    assert abs(cfg["broadcast_frac_of_xgmi_link"] - cfg["broadcast_GBps"] / 153.0) < 1e-12
+
+
+def test_bench_model_update_with_the_outputs_sharded_over_two_ranks(lib_built):
+    """``bench.py --workload c4 --gpus 2``: ONE model update with the two outputs dealt to two ranks
+    (parallel.fit_outputs_sharded), every factor broadcast once from its owner as its packed upper triangle -- on the one
+    device of this box over gloo, at N = 3000.  Strong scaling: the line says so, counts the flops of the whole job once,
+    carries every rank's own time and has checked the posterior identity on every rank."""
+    N = 3000
+    line = _run_bench(["--gpus", "2", "--workload", "c4", "--n-train", str(N), "--steps", "2", "--warmup", "1"],
+                      {"SR_DIST_BACKEND": "gloo", "SR_SHARE_DEVICE": "1"})
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["unit"] == "TFLOP/s"
+    assert "output-shard x2 of 2 ranks" in line["config"]["parallelism"] and "gloo" in line["config"]["parallelism"]
+    flops = 2 * (2.0 / 3.0) * float(N) ** 3
+    assert abs(line["value"] - flops / (line["ms_per_step"] * 1e-3) / 1e12) < 1e-9 * line["value"]
+    packed = N * (N + 1) // 2 * 8
+    assert line["config"]["broadcast_bytes_per_step"] == 2 * packed + 2 * N * 8
+    rk = line["ranks"]
+    assert len(rk["ms_per_step"]) == 2 and rk["ms_per_step_max"] <= line["ms_per_step"] * (1 + 1e-9)
+    assert line["config"]["max|mu(z)+s2n*alpha-y|"] < 1e-9
+
+
 def test_bench_two_ranks_c5_on_one_gpu(lib_built, tmp_path):
     """bench.py's N > 1 branch, executed: two self-spawned ranks share cuda:0 over gloo (SR_DIST_BACKEND /
     SR_SHARE_DEVICE; RCCL refuses two ranks on one device), workload c5 (N = 5000, 131072 queries per rank in two
@@ -114,6 +149,7 @@ def test_bench_two_ranks_c5_on_one_gpu(lib_built, tmp_path):
     assert line["config"]["broadcast_GBps"] > 0
     assert np.isfinite(line["value"]) and line["value"] > 0
     assert abs(line["value"] - 2 * T * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    _check_rank_fields(line, 2)
     # rank 1's shard against a single-process evaluation
     from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload
     d1 = np.load(os.path.join(str(tmp_path), "shard_rank1.npz"))
@@ -161,6 +197,7 @@ def test_bench_eight_ranks_c5_on_one_gpu(lib_built, tmp_path):
     assert np.isfinite(line["value"]) and line["value"] > 0
     assert abs(line["value"] - world * T / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     assert "cpu_baseline" not in line                      # rank 0 at N = 1 only
+    _check_rank_fields(line, world)
     # every rank wrote its shard; all seeds differ; the last rank's rows equal a single-process evaluation
     from safe_exploration_amd import SimpleGPModel, gp_reachability as reach, workload
     shards = [np.load(os.path.join(str(tmp_path), "shard_rank%d.npz" % r)) for r in range(world)]
@@ -207,6 +244,7 @@ def test_bench_eight_ranks_under_torchrun_default_workload(lib_built, tmp_path):
     assert line["config"]["queries_per_gpu_per_step"] == 65536 and "world=8" in line["config"]["parallelism"]
     assert abs(line["value"] - 8 * 65536 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     assert sorted(os.listdir(str(tmp_path))) == ["shard_rank%d.npz" % r for r in range(8)]
+    _check_rank_fields(line, 8)
 
 
 def test_bench_dry_run_of_the_rccl_process_group_with_one_rank(lib_built):
@@ -221,5 +259,7 @@ def test_bench_dry_run_of_the_rccl_process_group_with_one_rank(lib_built):
     N, n_out = 2000, 2
     assert d["replication_bytes"] == (n_out * N * (N + 1) // 2 + N * 3 + N * n_out + n_out * N) * 8
     assert d["pieces"] >= 2 and d["broadcast_64MB_ms"] > 0
+    assert d["broadcast_64MB_GBps"] > 0 and d["xgmi_link_GBps"] == 153.0
     assert "nccl" in line["config"]["parallelism"]
+    assert line["ranks"]["ms_per_step"] and line["ranks"]["slowest_rank"] == 0 and line["roofline"]["rank"] == 0
     assert np.isfinite(line["value"]) and line["value"] > 0
