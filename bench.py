@@ -521,7 +521,8 @@ def run(args):
     gp.prof_enable(False)
     # every rank's own numbers (its time to its own synchronize, the dominant kernel's hipEvent pairs), so that the line is
     # computed from the SLOWEST rank and says how far the ranks are apart; `elapsed` = MAX over ranks of the bracketed time
-    stats = gather_rank_stats([elapsed, local_s] + list(gp.prof_get(_lib.K_VAR)) + list(gp.prof_get(_lib.K_KSTAR)), dev, world)
+    stats = gather_rank_stats([elapsed, local_s] + list(gp.prof_get(_lib.K_VAR)) + list(gp.prof_get(_lib.K_KSTAR))
+                              + list(gp.prof_get(_lib.K_ELL)) + list(gp.prof_get(_lib.K_FINAL)), dev, world)
     elapsed = float(stats[:, 0].max())
     slowest = int(np.argmax(stats[:, 1]))
     overflow = None
@@ -545,9 +546,7 @@ def run(args):
     if rank == 0:
         evals = float(world) * T * H * args.steps
         # the roofline objects are those of the SLOWEST rank (rank 0 at N = 1)
-        var_ms, var_n, ks_ms, ks_n = (float(v) for v in stats[slowest, 2:6])
-        ell_ms, ell_n = gp.prof_get(_lib.K_ELL)
-        fin_ms, fin_n = gp.prof_get(_lib.K_FINAL)
+        var_ms, var_n, ks_ms, ks_n, ell_ms, ell_n, fin_ms, fin_n = (float(v) for v in stats[slowest, 2:10])
         # algorithmic flops of one sr_var_kernel launch: n_out * N^2 * T  (N^2/2 MACs per query and
         # output through the triangular factor) -- true N, not the padded one
         # (a launch covers whatever share of the queries the library gave it -- one chunk of <= 65536: the launches of
@@ -610,6 +609,12 @@ def run(args):
             "kernel_ms_per_step": {"sr_kstar_kernel": ks_ms / args.steps, "sr_var_kernel": var_ms / args.steps,
                                    "sr_finalize_kernel": fin_ms / args.steps,
                                    "sr_ellipsoid_kernel": ell_ms / args.steps},
+            # how busy the GPU is INSIDE the timed region (hipEvent pairs of the four kernels of a step over the wall time of
+            # the region): the process as a whole spends most of its wall time in the model fit and the CPU baseline, so a
+            # utilisation sampler that looks at it a few times mostly sees an idle device
+            "timed_region": {"wall_s": elapsed, "kernel_s": (ks_ms + var_ms + fin_ms + ell_ms) * 1e-3,
+                             "gpu_busy_frac": (ks_ms + var_ms + fin_ms + ell_ms) * 1e-3 / elapsed,
+                             "rank": slowest},
         }
         if dry is not None:
             line["config"]["dry_nccl"] = dry

@@ -273,20 +273,28 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
     {
         const double* src = a.Vp + ((long)d * a.npairs + cb * (cb + 1)) * TQ * SR_ST_COLS + tid;
         double v[TQ];
+        // same association as the stand-alone reduce kernel (even chunks, odd chunks, ascending).  Round 6: the loads of ALL
+        // columns and of up to 40 chunks are in flight together -- this reduction sits on the tail of the launch (the last
+        // arriver of the longest column block runs it while the chip waits), and it is a chain of dependent round trips,
+        // not of bytes: batches of 8 chunks per column were 5 round trips at N = 5000 for one column and 20 for four.
+        constexpr int CB = (TQ == 1) ? 40 : 10;              // chunks per batch (TQ x CB loads in flight)
+        double v0[TQ], v1[TQ];
 #pragma unroll
-        for (int t = 0; t < TQ; ++t) {
-            // same association as the stand-alone reduce kernel (even chunks, odd chunks), 8 loads in flight
-            double v0 = 0.0, v1 = 0.0;
-            for (int c = 0; c < nch; c += 8) {
-                double x[8];
+        for (int t = 0; t < TQ; ++t) { v0[t] = 0.0; v1[t] = 0.0; }
+        for (int c = 0; c < nch; c += CB) {
+            double x[CB][TQ];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    x[u] = (c + u < nch) ? sr_ld<true>(src + ((long)(c + u) * TQ + t) * SR_ST_COLS) : 0.0;
+            for (int u = 0; u < CB; ++u)
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) { v0 += x[u]; v1 += x[u + 1]; }
-            }
-            v[t] = v0 + v1;
+                for (int t = 0; t < TQ; ++t)
+                    x[u][t] = (c + u < nch) ? sr_ld<true>(src + ((long)(c + u) * TQ + t) * SR_ST_COLS) : 0.0;
+#pragma unroll
+            for (int u = 0; u < CB; u += 2)
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) { v0[t] += x[u][t]; v1[t] += x[u + 1][t]; }
         }
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) v[t] = v0[t] + v1[t];
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
             const double q = sr_block_sum(v[t] * ((a.dot0 && t != 0) ? v[0] : v[t]), sh);
