@@ -183,7 +183,8 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
     // reserve 32 / 64: N = 3500 2.79 / 2.80, N = 5000 5.14 / 4.99, N = 6500 8.79 / 8.74, N = 7500 12.17 / 12.45, N = 10000 25.1 / 26.7 ms)
     const int nblk = h->Np / SR_NB;
     const int reserve = sr_fact_reserved_cus(regime, nblk);
-    const int key = regime * 1000 + reserve;
+    const bool want_pipe = regime == 1 && h->fact_pipe != 0;      // (the prototype's two extra streams only where it is asked for)
+    const int key = regime * 1000 + reserve + (want_pipe ? 500 : 0);
     {
         std::lock_guard<std::mutex> lk(g_stream_mutex);
         sr_stream_set* set = nullptr;
@@ -211,9 +212,11 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
                 // the pipelined chain: two more streams of the chain's priority.  Their kernels WAIT for each other on the
                 // device, so each must sit on a hardware queue of its own (streams of one priority share a small pool of
                 // queues): checked once, here -- a waiter that shares its producer's queue runs into its time-out
-                SR_HIP(hipStreamCreateWithPriority(&c.diag, hipStreamNonBlocking, prio_hi));
-                SR_HIP(hipStreamCreateWithPriority(&c.row, hipStreamNonBlocking, prio_hi));
-                c.pipe_ok = own_queues(c.fact, c.diag, c.row) ? 1 : 0;
+                if (want_pipe) {
+                    SR_HIP(hipStreamCreateWithPriority(&c.diag, hipStreamNonBlocking, prio_hi));
+                    SR_HIP(hipStreamCreateWithPriority(&c.row, hipStreamNonBlocking, prio_hi));
+                    c.pipe_ok = own_queues(c.fact, c.diag, c.row) ? 1 : 0;
+                }
             } else {
                 // regime 2: a second bulk stream WITHOUT a mask, for the trailing updates that are long enough to hide a
                 // chain that waits for its CUs (below)

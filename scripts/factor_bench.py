@@ -3,7 +3,7 @@
 with the per-kernel split of the library's own hipEvent pairs and the posterior identity as a sanity check.
 
 usage (GPU box):  python scripts/factor_bench.py [N ...]      (default 1000 2000 5000 10000)
-SR_PANELS=0,2,4 picks the panel widths (0 = by size), SR_PIPE=1,0 the chain forms (1 = pipelined, round 6; 0 = one chain).
+SR_PANELS=0,2,4 picks the panel widths (0 = by size), SR_PIPE=0,1,2 the chain forms (0 = one chain of launches, the default; 1 / 2 = the pipelined prototypes of round 6).
 """
 import json
 import os
@@ -23,7 +23,7 @@ from safe_exploration_amd import SimpleGPModel, workload, _lib  # noqa: E402
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [1000, 2000, 5000, 10000]
     panels = [int(p) for p in os.environ.get("SR_PANELS", "0,1,2,4").split(",")]
-    pipes = [int(p) for p in os.environ.get("SR_PIPE", "1").split(",")]
+    pipes = [int(p) for p in os.environ.get("SR_PIPE", "0").split(",")]
     n_s, n_u = int(os.environ.get("SR_NOUT", "2")), 1
     out = []
     for N in sizes:
