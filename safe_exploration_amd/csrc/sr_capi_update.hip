@@ -182,7 +182,8 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
     // behind the trailing update's workgroups (50 instead of 12 us each) and the trailing update has the slack (measured,
     // reserve 32 / 64: N = 3500 2.79 / 2.80, N = 5000 5.14 / 4.99, N = 6500 8.79 / 8.74, N = 7500 12.17 / 12.45, N = 10000 25.1 / 26.7 ms)
     const int nblk = h->Np / SR_NB;
-    const int reserve = sr_fact_reserved_cus(regime, nblk);
+    static const int reserve_lab = (int)sr_lab_env("SR_FACT_RESERVE", 0);       // (lab build: CUs the bulk streams leave free)
+    const int reserve = reserve_lab > 0 ? reserve_lab : sr_fact_reserved_cus(regime, nblk);
     const bool want_pipe = regime == 1 && h->fact_pipe != 0;      // (the prototype's two extra streams only where it is asked for)
     const int key = regime * 1000 + reserve + (want_pipe ? 500 : 0);
     {
