@@ -952,9 +952,11 @@ def test_in_place_appends_and_what_follows_them():
 def test_grid_append_that_cannot_assemble_falls_back():
     """The one-launch append beyond 512 padded rows is a grid of workgroups that wait for each other; where the grid cannot
     become resident as a whole, its barrier is given up after ~5 ms, nothing of the model is written, and the append is done
-    by separate launches (sr_gp_append1_host says SR_EUNSUPPORTED and the Python layer takes sr_gp_append).  Forced here
-    with sr_test_grid_append_abort; in place (padded size stays) and into new buffers (padded size grows); the appends
-    after it work as before."""
+    by separate launches (sr_gp_append1_host says SR_EBUSY -- transient, nothing touched -- and the Python layer stages the
+    point for sr_gp_append).  Forced here with sr_test_grid_append_abort; in place (padded size stays) and into new buffers
+    (padded size grows); the appends after it work as before.  Round 6: after an abort the library leaves the grid alone for
+    the next 16 one-point appends (every further attempt would cost its ~5 ms time-out again) and counts the aborts."""
+    import ctypes
     from safe_exploration_amd._lib import lib
     syn = orc.make_synthetic(78, 780, 2, 1, 8)
     Z, Y = syn["Z"], syn["Y"]
@@ -963,11 +965,14 @@ def test_grid_append_that_cannot_assemble_falls_back():
     for n0 in (700, 768):                                       # 768: the padded size grows with the next point
         gp = ref(n0)
         gp.append_limit = 10 ** 9
-        assert lib.sr_test_grid_append_abort(2) == 0            # host route gives up, then the device-pointer route too
+        assert lib.sr_test_grid_append_abort(2) == 0            # the host route gives up; the staged call then rests the grid
         gp.update_model(Z[n0:n0 + 1], Y[n0:n0 + 1], opt_hyp=False, replace_old=False)
         assert lib.sr_test_grid_append_abort(0) == 0
+        n_ab = ctypes.c_long(-1)
+        assert lib.sr_gp_grid_append_aborts(gp._handle.h, ctypes.byref(n_ab)) == 0 and n_ab.value == 1
         for i in range(n0 + 1, n0 + 4):
             gp.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)
+        assert lib.sr_gp_grid_append_aborts(gp._handle.h, ctypes.byref(n_ab)) == 0 and n_ab.value == 1
         full = ref(n0 + 4)
         for u, v in zip(gp.export_state(), full.export_state()):
             np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-6, atol=1e-9 * float(v.abs().max()))
@@ -975,6 +980,32 @@ def test_grid_append_that_cannot_assemble_falls_back():
         m2, v2 = full.predict(x)
         np.testing.assert_allclose(m1, m2, rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(v1, v2, rtol=0, atol=1e-10)
+
+
+def test_appends_alternating_with_big_batches():
+    """a tile route of the posterior pass reads U^-1 in 16-byte pieces and, after an ODD number of in-place
+    one-point appends, first copies the model back into plain buffers (a device-wide wait).  A loop of "one append, one big
+    batch" used to pay that every step; now such an unslide keeps the next 64 one-point appends off the in-place route.  The
+    numbers must not care: twelve such steps on a model beyond 512 padded rows against a refit, the big batch and a single
+    query after every append."""
+    syn = orc.make_synthetic(79, 720, 2, 1, 1500)
+    Z, Y = syn["Z"], syn["Y"]
+    ref = lambda n: hip_model(Z[:n], Y[:n], syn["lengthscale"], syn["signal_var"], syn["noise_var"], 2, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    n0 = 700
+    gp = ref(n0)
+    gp.append_limit = 10 ** 9
+    for i in range(n0, n0 + 12):
+        gp.update_model(Z[i:i + 1], Y[i:i + 1], opt_hyp=False, replace_old=False)
+        m_big, v_big = gp.predict(x)                          # 1500 queries: the MFMA tiles
+        m_one, v_one = gp.predict(x[:1])                      # the streamed single-query kernel on whatever view is current
+        np.testing.assert_allclose(m_one, m_big[:1], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(v_one, v_big[:1], rtol=0, atol=1e-10)
+        if i in (n0, n0 + 5, n0 + 11):
+            full = ref(i + 1)
+            m2, v2 = full.predict(x)
+            np.testing.assert_allclose(m_big, m2, rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(v_big, v2, rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize("kt", ["rbf", "lin_mat52"])
