@@ -34,7 +34,7 @@ typedef struct sr_gp* sr_gp_t;
 #define SR_EUNSUPPORTED -5 /* dimension outside compiled range (n_s<=8, n_u<=4, D<=12).  The reference's systems (n_s <= 4,
                             * D <= 5) run in registers, and so does everything up to n_s = 8 with n_u <= 2; the ellipsoid
                             * step with n_s = 8 and n_u = 3, 4 is compiled but spills 164 / 452 B per lane to scratch
-                            * (profiles/r03_kernel_resources.txt): correct, tested, and several times slower per query
+                            * (profiles/archive/r03_kernel_resources.txt): correct, tested, and several times slower per query
                             * than the small instantiations */
 
 /* kernel ids for sr_prof_get() */

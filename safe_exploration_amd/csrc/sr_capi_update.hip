@@ -131,7 +131,7 @@ static int make_masked_stream(hipStream_t* st, int ncu, int first_bit, int last_
 // then a 5000-point one (reserve 64) in the same process: two priority streams and four CU-masked ones -- and the streams
 // of one priority share a small pool of hardware queues: the critical chain of the second model then shared a queue with an
 // idle stream of the first and its kernels took twice as long in situ (diagonal block 38 -> 75 us, the whole update 4.9 ->
-// 7.6 - 8.9 ms; profiles/r04_factor_bench.txt against r03's).  A set of another key is destroyed when a new one is made,
+// 7.6 - 8.9 ms; profiles/archive/r04_factor_bench.txt against r03's).  A set of another key is destroyed when a new one is made,
 // unless an update is running on it at that moment (`busy`).
 struct sr_stream_set { int device, key, busy; hipStream_t fact, bulk, inv, diag, row; int pipe_ok; };
 static std::mutex g_stream_mutex;

@@ -479,7 +479,7 @@ static int launch_chain_su(const sr_chain_args& a, hipStream_t s) {
 
 // the systems of the reference's experiments (pendulum 2 + 1, cart-pole 4 + 1) and their neighbours; anything else
 // runs the per-step launches
-// Every instantiation is scratch-free (profiles/r03_kernel_resources.txt: 147 .. 254 VGPRs, no spills) since the
+// Every instantiation is scratch-free (profiles/archive/r03_kernel_resources.txt: 147 .. 254 VGPRs, no spills) since the
 // ellipsoid step moved to the group's tail workgroup: the posterior workgroups hold their U^-1 fragments (36 .. 132
 // registers of the 256 per lane) without the live ranges of sr_ellipsoid_one beside them, and the tail workgroup holds no
 // fragments.  (Round 2 / early round 3: one body did both -- up to 328 B of scratch per lane, and the dispatcher had

@@ -384,7 +384,7 @@ static inline bool sr_var_splitk_wanted(int Np, long Tp, int n_out) {
     return nrb > 2 && wgs <= 1024;
 }
 // workgroups of the balanced launch: one per CU, two from 8192 cells on.  Round 5, with the pipelined main loop (G = 256
-// against 512, n_out = 2, profiles/r05_bal_ab.txt): N = 5000 T = 128 (U = 1640) 142 / 148 us, T = 256 (3280) 235 / 250, T = 512
+// against 512, n_out = 2, profiles/archive/r05_bal_ab.txt): N = 5000 T = 128 (U = 1640) 142 / 148 us, T = 256 (3280) 235 / 250, T = 512
 // (6560) 426 / 425, T = 1024 (13120) 801 / 795; N = 4000 T = 512 (4224) 291 / 306, T = 1024 (8448) 525 / 535; N = 3000 T = 1024
 // 321 / 329 -- the threshold of round 3 (2304 cells, old loop) sent T = 256 at N = 5000 to 512 workgroups; 384, 768 or
 // 1024 workgroups -- shares that do not line up with the residency of the chip -- lose 15 - 30 %.  Half of a 512-way launch's
@@ -406,7 +406,7 @@ static inline int sr_var_small_groups_max(int Np, int n_out) {
 }
 // blocks per Cholesky panel by the number of 128-blocks (measurements: sr_capi_update.hip, pick_fact_panel)
 // (round 5, with the pipelined GEMM loops: at N = 50000 panels of 12 .. 24 blocks 69.0 - 69.2 TF, 32: 68.5, 48 -- round 4's choice --
-//  67.8, 64: 66.5 on one box, profiles/r05_c4_panels.txt; N = 10000 / 20000 / 30000 keep 8 / 8 / 24)
+//  67.8, 64: 66.5 on one box, profiles/archive/r05_c4_panels.txt; N = 10000 / 20000 / 30000 keep 8 / 8 / 24)
 static inline int sr_fact_panel(int nb) { return nb <= 28 ? 2 : (nb <= 44 ? 3 : (nb <= 64 ? 4 : (nb <= 200 ? 8 : 24))); }
 // CUs the bulk streams of the model update leave to the critical chain (regime 1: one per shader engine, two for 36 < nb
 // <= 52; regime 2: one per XCD for the diagonal blocks)

@@ -184,7 +184,7 @@ __device__ __forceinline__ void sr_ellipsoid_one(const sr_ell_args& a, long t) {
         for (int j = 0; j < NS; ++j) q[i][j] = a.q[t * a.ldq + i * NS + j];
 
     // remainder radius first: lambda_max(Q (I + K^T K)) needs Q, L, Q L and M at once -- computed before H Q H^T exists,
-    // the step stays in registers up to n_s = 7 (n_s = 8: see profiles/r03_kernel_resources.txt)   (:125-137, utils.py:129-142)
+    // the step stays in registers up to n_s = 7 (n_s = 8: see profiles/archive/r03_kernel_resources.txt)   (:125-137, utils.py:129-142)
     // (the feedback matrix is fetched twice -- here and for H below -- rather than held across the eigenvalue iteration)
     double r2 = 0.0;
     if (a.mode == 0) {

@@ -246,13 +246,13 @@ int sr_launch_potrf_corner16(double* A, long lda, double* wt_diag, long ldw, int
 // Synchronisation: ONE LDS-only workgroup barrier per panel (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would
 // also wait for the global stores in flight, which nobody reads back) and a tile count in LDS that tells the workers when
 // the panel row is complete.
-// History (profiles/r05_diag_kernel.txt has the cycle counts): 88 us (round 1) -> 62 (sub-block inverses on a spare
+// History (profiles/archive/r05_diag_kernel.txt has the cycle counts): 88 us (round 1) -> 62 (sub-block inverses on a spare
 // wavefront) -> 43 (one sweep) -> 30 (round 3: pivots by v_readlane, two barriers per panel) -> 23 (this form: pivot
 // chain written for the smallest fp64 instruction count, one barrier, loads of the upper triangle only and in flight
 // together, wavefront 0 starting on the first tile while the other 15 load).  What is left: wavefront 0's 4.8k cycles per
 // panel (3.1k of them the 16 pivots) and, in the first four panels, the 35 .. 26 trailing tiles, whose 16 LDS operations
 // per tile keep the LDS busier than the pivots keep wavefront 0 (tiles resident in worker registers halve that traffic but
-// measured slower: 24.5 us, profiles/r05_diag_kernel.txt).
+// measured slower: 24.5 us, profiles/archive/r05_diag_kernel.txt).
 // ------------------------------------------------------------------------------------------------
 #define SR_PD_TLD 33      // pivot stage: 16 rows of [U_pp (16 columns) | T_p = U_pp^-T (16 columns)], padded
 

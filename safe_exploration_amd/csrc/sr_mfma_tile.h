@@ -118,7 +118,7 @@ __device__ __forceinline__ void mainloop_tn_glds(const double* __restrict__ A, l
 
 // ------------------------------------------------------------------------------------------------------------------
 // Round 5: the same contract with the k-tile boundary crossed UNDER the MFMA stream (scripts/mfma_pipe_tile.hip,
-// profiles/r05_mfma_pipe_tile.txt: 69.7 TF for the skeleton of mainloop_tn_glds, 77.8 TF for this one on the same box).
+// profiles/archive/r05_mfma_pipe_tile.txt: 69.7 TF for the skeleton of mainloop_tn_glds, 77.8 TF for this one on the same box).
 // What the old loop lost: after its barrier at the top of a k-tile a wavefront issued its DMA burst, then its first
 // fragment reads, waited for them, and only then its first MFMA; and hipcc's s_waitcnt pass, which stops counting LDS
 // reads in order once a global_load_lds builtin is in the loop, waited lgkmcnt(0) before EVERY block of 16 MFMAs, i.e. for
@@ -275,7 +275,7 @@ __device__ __forceinline__ void mainloop_tn_pipe(const double* __restrict__ A, l
 #undef SRT_TILE
 }
 
-// Round 3, measured and NOT kept (scripts/mfma_lds_tile.hip, profiles/r03_mfma_lds_tile.txt): where the 9 % between this
+// Round 3, measured and NOT kept (scripts/mfma_lds_tile.hip, profiles/archive/r03_mfma_lds_tile.txt): where the 9 % between this
 // loop (70.5 TF inside sr_var_kernel) and the matrix pipe (77.5 TF) go.  An LDS-fed loop of the same fragment reads and
 // MFMAs runs at 77.0 - 77.7 TF for EVERY wavefront tile from 32 x 32 to 96 x 64 at two wavefronts per SIMD: the LDS -> VGPR
 // traffic costs nothing, so a 96 x 64 wavefront tile has nothing to win (and its 41 KB stages would leave one workgroup per

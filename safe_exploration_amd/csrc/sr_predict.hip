@@ -475,7 +475,7 @@ int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int
 // K2b: few query tiles (<= 1024 plain workgroups on a model of more than two row blocks), BALANCED ("stream-K" shares).
 // (K2k -- every tile cut into chunks of 1 / 2 / 4 / 8 k-blocks, rounds 1 - 4 -- lost to this kernel everywhere once the main
 //  loop was the pipelined one, also below 256 cells where it used to be the default: 46 against 60 us at N = 512, T = 1100;
-//  removed in round 5, profiles/r05_bal_ab.txt.)  The work of the launch is the list of
+//  removed in round 5, profiles/archive/r05_bal_ab.txt.)  The work of the launch is the list of
 // k-blocks (128 k-rows of one 128 x 128 output tile), tiles ordered (output, query tile, row block DEScending: heavy tiles
 // first), blocks ascending inside a tile; workgroup g of G takes the contiguous share [g U / G, (g + 1) U / G) of its U
 // entries -- the same number of MFMAs for everybody, whatever the triangular k range of a tile (K2k cuts every tile into
@@ -489,7 +489,7 @@ int sr_launch_var64(const double* Wt, const double* Ks, double* part, int N, int
 //  the tail of the launch: N = 5000, T = 128 / 256: 192 / 297 us against 168 / 287 of K2k; with the second launch instead
 //  158 / 257, and it is faster everywhere else too -- N = 2000 T = 256 / 512: 96 / 136 -> 83 / 118 us, N = 3000 T = 512:
 //  207 -> 198, N = 4000 T = 128 / 512: 167 / 441 -> 120 / 323, N = 5000 T = 512 / 1024: 483 / 896 -> 451 / 844;
-//  profiles/r03_streamk.txt.)
+//  profiles/archive/r03_streamk.txt.)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ long sr_sk_bound(long g, long U, long G) { return (g * U) / G; }
 __device__ __forceinline__ long sr_sk_owner(long u, long U, long G) {        // the g with bound(g) <= u < bound(g + 1)
