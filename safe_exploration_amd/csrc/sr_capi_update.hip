@@ -246,6 +246,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     SR_DEVICE(h->device);
     SR_TRY(server_quiesce(h));
     SR_TRY(unslide(h));
+    h->slide_hold = 0; h->slide_forced = 0;          // (a refit starts the in-place appends' hold-off afresh: sr_capi_posterior.hip)
     const auto t_begin = std::chrono::steady_clock::now();
     static const bool trace_laps = sr_lab_on("SR_FACT_TRACE");
     auto lap = [&](const char* what) { if (trace_laps) fprintf(stderr, "  %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count()); };

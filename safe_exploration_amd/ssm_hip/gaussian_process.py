@@ -1058,8 +1058,9 @@ class SimpleGPModel(StateSpaceModel):
             check(lib.sr_gp_set_fact_panel(self._handle.h, int(panel)))
 
     def set_fact_pipeline(self, on):
-        """model updates of 3 .. 128 blocks of 128 rows: diagonal blocks beside the previous block row (default) or one
-        chain of launches (sr_gp_set_fact_pipeline); identical numbers either way.  Works before training too."""
+        """model updates of 3 .. 128 blocks of 128 rows: 0 (default) one chain of launches; 1 / 2 the pipelined prototypes of
+        round 6 (diagonal blocks beside the previous block row: measured slower); identical numbers either way
+        (sr_gp_set_fact_pipeline).  Works before training too."""
         self._fact_pipeline = int(on)
         if self._handle is not None:
             check(lib.sr_gp_set_fact_pipeline(self._handle.h, self._fact_pipeline))
