@@ -135,6 +135,24 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
     a.fa.mu_part = h->mu_part; a.fa.jac_part = h->jac_part; a.fa.var_part = h->var_part; a.fa.sf2 = h->sf2;
     a.fa.ls = h->ls; a.fa.kxx = h->general ? h->kxx : nullptr; a.fa.mu = mu; a.fa.var = var; a.fa.jac = jac;
     a.fa.n_out = h->n_out; a.fa.D = h->D; a.fa.nsplit = nsplit; a.fa.nrb = ncb; a.fa.T = Tc; a.fa.Tp = Tp;
+    // ONE query evaluated in the kernel: the polling finaliser and its self-validating slots (sr_stream1_kernel) where they
+    // fit its LDS; their pattern is "empty" from the allocation on, the finaliser leaves it behind again
+    static const bool st1_poll = sr_lab_env("SR_ST1_POLL", 1) != 0;           // (lab build: A/B against the two ticket levels)
+    const long nslot = sr_st1_slots(ncb, h->n_out, h->D);
+    if (fused && Tc == 1 && !fused_mfma && nslot <= SR_ST1_SLOTS_MAX && 2 * ncb <= 64 && st1_poll) {
+        if (h->stream_slots_cap < nslot) {
+            (void)hipStreamSynchronize(s);
+            dev_free(h->stream_slots);
+            h->stream_slots = nullptr; h->stream_slots_cap = 0;
+            SR_TRY(dev_alloc(&h->stream_slots, (size_t)SR_ST1_SLOTS_MAX));
+            h->stream_slots_cap = SR_ST1_SLOTS_MAX;
+            double empty;
+            const unsigned long long bits = SR_ST1_EMPTY;
+            memcpy(&empty, &bits, sizeof(double));
+            SR_TRY(sr_launch_fill(h->stream_slots, (size_t)SR_ST1_SLOTS_MAX, empty, s));
+        }
+        a.slots = h->stream_slots;
+    }
     h->last_streamed = 0;
     sr_prof_scope ps(&h->prof, SR_K_VAR, s);
     return sr_launch_stream(a, fused ? 1 : 0, s);

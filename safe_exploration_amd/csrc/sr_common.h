@@ -510,7 +510,14 @@ struct sr_stream_args {
     // sequence number into pinned host memory after its outputs (which then live in pinned host memory too)
     unsigned long long* host_flag; unsigned long long host_seq;
     int probe = 0;                   // measurements only (SR_ST1_PROBE): 1 = sr_stream1_kernel stops after its streaming part
+    // polling finaliser of the one-column kernel (round 6): dedicated, self-validating slots (SR_ST1_EMPTY until written):
+    // [d][cb] column-block norms, then [j][d][1 + D] the N-split partial sums of mean and mean-Jacobian; NULL = tickets
+    double* slots = nullptr;
 };
+#define SR_ST1_SLOTS_MAX 1536        /* doubles of LDS the finaliser gathers the slots in */
+__host__ __device__ static inline long sr_st1_slots(int ncb, int n_out, int D) { return (long)n_out * ncb * (1 + 2 * (1 + D)); }
+// bit pattern no arithmetic produces (a signalling NaN with a payload): "not written yet"
+#define SR_ST1_EMPTY 0x7FF4C0FFEE5AFE01ull
 long sr_stream_vp_doubles(int Np, int n_out, int ncols);
 int sr_stream_tickets(int Np, int n_out);
 int sr_stream_width(int ncols);

@@ -63,6 +63,7 @@ struct sr_gp {
     size_t lin_cap = 0;                                                 // doubles behind lin_v
     double* stream_vp = nullptr; long stream_vp_cap = 0;   // fused small-batch path: partial sums (grow-only)
     unsigned* stream_tickets = nullptr;
+    double* stream_slots = nullptr; long stream_slots_cap = 0;    // self-validating hand-over slots of the T = 1 kernel's polling finaliser
     double* splitk_vt = nullptr; long splitk_cap = 0;   // partial products of the balanced few-query-tile route (grow-only)
     // log det(K + noise) per output as of the last <= 16-row append (read back with its status words): the blocking read of
     // sr_gp_logdet costs the exploration loop 30 us per step

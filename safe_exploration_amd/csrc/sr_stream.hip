@@ -215,7 +215,9 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
                     sr_st_agent(a.lin_part_w + ((long)d * a.nblk + j) * NACC + tid, sum);
                 } else {
                     const int t = tid / (1 + DT), c = tid % (1 + DT);
-                    if (t < a.ncols) {
+                    if (TQ == 1 && SRC == 1 && a.slots) {       // polling finaliser: the chunk's slot [j][d][1 + D]
+                        if (c <= a.D) sr_st_agent(a.slots + (long)a.n_out * a.ncb + ((long)j * a.n_out + d) * (1 + a.D) + c, sum);
+                    } else if (t < a.ncols) {
                         if (c == 0) sr_st_agent(a.mu_part_w + ((long)j * a.n_out + d) * a.Tp + t, sum);
                         else if (c - 1 < a.D) sr_st_agent(a.jac_part_w + (((long)j * a.n_out + d) * a.D + (c - 1)) * a.Tp + t, sum);
                     }
@@ -266,11 +268,18 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
     for (int t = 0; t < TQ; ++t) sr_st_agent(out + t * SR_ST_COLS + tid, acc[t]);
 
     if (a.probe == 1) return;
+    // Polling finaliser (round 6; one ARD-RBF query, a.slots): the LAST workgroup of the grid in dispatch order -- everybody
+    // else is resident or gone when it starts -- stays behind and gathers the self-validating slots: no second ticket
+    // (store -> drain -> atomic -> loads were four dependent round trips behind the last column block: 5.7 of the 38 us of
+    // the call at N = 5000).
+    const bool poll = TQ == 1 && SRC == 1 && a.slots != nullptr;
+    const bool finaliser = poll && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;
     // ---- last workgroup of this column block: add the chunks, square (or multiply with column 0), reduce
     const int nch = 2 * cb + 2;
-    if (!sr_ticket_last(a.tickets + d * a.ncb + cb, (unsigned)nch, &s_flag)) return;
+    const bool last1 = sr_ticket_last(a.tickets + d * a.ncb + cb, (unsigned)nch, &s_flag);
+    if (!last1 && !finaliser) return;
     if (a.probe == 2) return;
-    {
+    if (last1) {
         const double* src = a.Vp + ((long)d * a.npairs + cb * (cb + 1)) * TQ * SR_ST_COLS + tid;
         double v[TQ];
         // same association as the stand-alone reduce kernel (even chunks, odd chunks, ascending).  Round 6: the loads of ALL
@@ -298,8 +307,73 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
             const double q = sr_block_sum(v[t] * ((a.dot0 && t != 0) ? v[0] : v[t]), sh);
-            if (tid == 0) sr_st_agent(a.part + ((long)d * a.ncb + cb) * a.Tp + t, q);
+            if (tid == 0) {
+                if (poll) sr_st_agent(a.slots + (long)d * a.ncb + cb, q);
+                else sr_st_agent(a.part + ((long)d * a.ncb + cb) * a.Tp + t, q);
+            }
         }
+    }
+    if (TQ == 1 && SRC == 1 && poll) {
+        if (!finaliser) return;
+        // ---- gather: every thread polls its share of the slots until none of them is empty (one load round trip per
+        // look; everything the final stage needs arrives with the look that succeeds), keeps them in LDS, empties them
+        // again for the next call
+        __shared__ double slot_s[SR_ST1_SLOTS_MAX];
+        const int nslot = (int)sr_st1_slots(a.ncb, a.n_out, a.D);
+        constexpr int PER = SR_ST1_SLOTS_MAX / SR_ST1_THREADS;
+        double val[PER];
+        for (int it = 0; it < 4000000; ++it) {
+            int missing = 0;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int i = tid + SR_ST1_THREADS * u;
+                val[u] = (i < nslot) ? sr_ld<true>(a.slots + i) : 0.0;
+                missing |= (i < nslot && (unsigned long long)__double_as_longlong(val[u]) == SR_ST1_EMPTY);
+            }
+            if (!__syncthreads_or(missing)) break;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + SR_ST1_THREADS * u;
+            if (i < nslot) {
+                slot_s[i] = val[u];
+                a.slots[i] = __longlong_as_double((long long)SR_ST1_EMPTY);
+            }
+        }
+        __syncthreads();
+        // ---- final stage from LDS, one wavefront per output: the loads and butterflies of sr_final_query_wave (few partial
+        // sums: lane l holds partial l of every quantity), so the result is the ticket route's to the last bit
+        const int lane = tid & 63;
+        const int nsplit = 2 * a.ncb;
+        for (int dd = tid >> 6; dd < a.n_out; dd += SR_ST1_THREADS / 64) {
+            const double* ms = slot_s + (long)a.n_out * a.ncb + (long)dd * (1 + a.D);
+            const int mstride = a.n_out * (1 + a.D);
+            double m = 0.0, q = 0.0;
+            for (int l = lane; l < nsplit; l += 64) m += ms[(long)l * mstride];          // (nsplit <= 64: one term per lane)
+            for (int l = lane; l < a.ncb; l += 64) q += slot_s[(long)dd * a.ncb + l];
+            m = sr_wave_sum(m);
+            q = sr_wave_sum(q);
+            double v = a.fa.sf2[dd] - q;
+            if (!(v > SR_VAR_CLIP)) v = SR_VAR_CLIP;
+            if (lane == 0) {
+                a.fa.mu[dd] = m;
+                a.fa.var[dd] = v;
+            }
+            if (a.fa.jac) {
+                for (int c = 0; c < a.D; ++c) {
+                    double g = 0.0;
+                    for (int l = lane; l < nsplit; l += 64) g += ms[(long)l * mstride + 1 + c];
+                    g = sr_wave_sum(g);
+                    if (lane == 0) a.fa.jac[(long)dd * a.D + c] = g;
+                }
+            }
+        }
+        if (a.host_flag) {                                   // (as sr_stream_final)
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
     }
     // ---- last column block of the call: final stage
     if (!sr_ticket_last(a.tickets + a.n_out * a.ncb, (unsigned)(a.n_out * a.ncb), &s_flag)) return;
