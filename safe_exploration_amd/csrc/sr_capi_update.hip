@@ -37,16 +37,13 @@ static int ensure_inv_jobs(sr_gp* h) {
     }
     std::vector<sr_gemm_job> jobs;
     h->inv_levels.clear();
-    const int root_mid = nb / 2;
+    std::sort(nodes.begin(), nodes.end(), [](const Node& a, const Node& b) { return a.lo < b.lo; });
     for (int depth = max_depth; depth >= 0; --depth) {
         sr_gp::inv_level lv{};
         lv.depth = depth;
         std::vector<sr_gemm_job> j1, j2;
-        for (int side = 0; side < 2; ++side)
-        for (const Node& r : nodes) {
+        for (const Node& r : nodes) {                             // (ascending lo: the jobs the Cholesky has passed are a prefix)
             if (r.depth != depth) continue;
-            const bool left = depth > 0 && r.hi <= root_mid;          // inside the root's left half
-            if (left != (side == 0)) continue;
             const int mid = (r.lo + r.hi) / 2;
             const int n1 = (mid - r.lo) * SR_NB, n2 = (r.hi - mid) * SR_NB;
             const long o11 = (long)r.lo * SR_NB * Np + (long)r.lo * SR_NB;
@@ -57,8 +54,9 @@ static int ensure_inv_jobs(sr_gp* h) {
             j2.push_back({o22, o21, o21, o12, n2, n1, n2, 0});    // W21 = -Wt22^T Y ; Wt12 = W21^T
             lv.maxM = std::max(lv.maxM, n2);
             lv.maxN = std::max(lv.maxN, n1);
-            lv.tiles += (long)(n2 / SR_NB) * (n1 / SR_NB);
-            if (left) { ++lv.n_left; lv.tiles_left += (long)(n2 / SR_NB) * (n1 / SR_NB); }
+            const long tl = (long)(n2 / SR_NB) * (n1 / SR_NB);
+            lv.tiles += tl;
+            lv.hi.push_back(r.hi); lv.mid.push_back(mid); lv.tl.push_back(tl);
         }
         lv.count = (int)j1.size();
         if (lv.count == 0) continue;
@@ -377,6 +375,50 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         const int root_mid = nb / 2;
         const bool early_inv = regime == 1 && si != nullptr && nb >= 8 && !no_early_inv;
         bool early_done = false;
+        // Staged inversion (round 6: more than one stage).  A node [lo, hi) of the halving tree needs nothing the Cholesky
+        // still writes once the chain has passed hi (both products), its FIRST product once the chain has passed its middle.
+        // Stages are launched on the inversion stream when the chain passes the middles of the rightmost spine of the tree
+        // -- nb / 2 (round 3: the root's left subtree and first product), then 3 nb / 4, 7 nb / 8, .. -- children before
+        // parents; what is left runs behind the chain.  inv_done[l]: jobs of level l that are complete (a prefix: ascending
+        // block ranges); inv_p1[l]: the first product of the job behind them is launched too.
+        std::vector<int> inv_done(h->inv_levels.size(), 0), inv_p1(h->inv_levels.size(), 0);
+        auto inv_stage = [&](int X, hipStream_t st, bool all) -> int {
+            for (size_t li = 0; li < h->inv_levels.size(); ++li) {       // deepest level first
+                const sr_gp::inv_level& lv = h->inv_levels[li];
+                const int a = inv_done[li];
+                int b = a;
+                while (b < lv.count && (all || lv.hi[b] <= X)) ++b;
+                const int a1 = a + inv_p1[li];                           // first job whose first product is still to come
+                const bool half = b < lv.count && lv.mid[b] <= X && !(b == a && inv_p1[li]);   // job b: left child complete
+                const int b1 = half ? b + 1 : ((b == a && inv_p1[li]) ? a1 : b);
+                sr_prof_scope ps(&h->prof, SR_K_TRINV, st);
+                if (b1 > a1) {
+                    long tl = 0;
+                    for (int j = a1; j < b1; ++j) tl += lv.tl[j];
+                    const int rc1 = sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1 + a1, b1 - a1, lv.maxM, lv.maxN, tl,
+                                                           1.0, 2, st, &b_inv1);
+                    if (rc1 != SR_OK) return rc1;
+                }
+                if (b > a) {
+                    long tl = 0;
+                    for (int j = a; j < b; ++j) tl += lv.tl[j];
+                    const int rc2 = sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2 + a, b - a, lv.maxM, lv.maxN, tl, -1.0, 3,
+                                                           st, &b_inv2);
+                    if (rc2 != SR_OK) return rc2;
+                }
+                if (b > a) inv_p1[li] = half ? 1 : 0;
+                else if (half) inv_p1[li] = 1;
+                inv_done[li] = b;
+            }
+            return SR_OK;
+        };
+        int inv_trigger = root_mid;                       // next point of the chain at which a stage is launched
+        // further stages while at least this many blocks remain -- up to 24 blocks only: beyond, whatever runs beside the chain
+        // costs it more than the shorter tail saves (same box, stages / one stage: N = 2000 1.142 / 1.156 ms, 3000 1.85 / 1.88,
+        // 5000 4.70 / 4.41, 10000 24.0 / 23.7; profiles/r06_fact_pipeline.txt)
+        static const int inv_rest_lab = (int)sr_lab_env("SR_FACT_INV_REST", 0);      // (lab build: 1000 = one stage everywhere)
+        const int inv_min_rest = inv_rest_lab > 0 ? inv_rest_lab : (nb <= 24 ? 3 : 1000);
+        (void)root_mid;
         {
             sr_prof_scope ps(&h->prof, SR_K_GRAM, sc);
             if (h->general)
@@ -436,24 +478,14 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                 if (two) SR_F(hand(sc, fl_d + kb, kb > 0 ? fl_r + kb : nullptr, nullptr));
                 else SR_F(hand(sc, fl_c + kb, fl_d + kb, kb > 0 ? fl_r + kb : nullptr));
                 if (early_pending) {
-                    // every factor row above the middle is final, its diagonal blocks inverted (r[kb] stands for the
-                    // rest of row kb - 1's solve as well): left subtree of the inversion + the root's first product
+                    // every factor row above kb is final, its diagonal blocks inverted (r[kb] stands for the rest of row
+                    // kb - 1's solve as well): the stage of the inversion that lies above it
                     early_pending = false; early_done = true;
                     SR_FH(hipEventRecord(h->ev_inv[0], sc));
                     SR_FH(hipStreamWaitEvent(si, h->ev_inv[0], 0));
-                    for (const sr_gp::inv_level& lv : h->inv_levels) {
-                        sr_prof_scope ps(&h->prof, SR_K_TRINV, si);
-                        if (lv.depth == 0) {
-                            SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, 1, lv.maxM, lv.maxN, lv.tiles, 1.0, 2,
-                                                        si, &b_inv1));
-                        } else if (lv.n_left > 0) {
-                            SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, lv.n_left, lv.maxM, lv.maxN,
-                                                        lv.tiles_left, 1.0, 2, si, &b_inv1));
-                            SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2, lv.n_left, lv.maxM, lv.maxN,
-                                                        lv.tiles_left, -1.0, 3, si, &b_inv2));
-                        }
-                    }
+                    SR_F(inv_stage(kb, si, false));
                     SR_FH(hipEventRecord(h->ev_inv[1], si));
+                    inv_trigger = nb + 1;                              // (the prototype keeps to one stage)
                 }
                 // ---- row stream: publishes r[kb] (Ur(kb) is in front of it), waits for D(kb)
                 SR_F(hand(sr, kb > 0 ? fl_r + kb : nullptr, fl_d + kb, nullptr));
@@ -511,7 +543,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                         SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sb));
                         ++n_bulk;
                     }
-                    if (early_inv && !early_done && p1 >= root_mid && p1 < nb) early_pending = true;
+                    if (early_inv && !early_done && p1 >= inv_trigger && p1 < nb) early_pending = true;
                 }
             }
             // the last hand-over of the critical stream has waited for d[nb-1] and r[nb-1]; the diagonal stream still owes
@@ -550,24 +582,18 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                     SR_F(sr_launch_gemm_tn(Wt + dg, Np, Arow, Np, Urow, Np, SR_NB, ncols, SR_NB, 1.0, 0.0, 0, sc, 1, &b_solve));
                 }
             }
-            if (early_inv && !early_done && p1 >= root_mid && p1 < nb) {
-                // every factor row above the middle is final (and its diagonal block inverted): left subtree + root product 1
+            if (early_inv && p1 >= inv_trigger && p1 < nb) {
+                // every factor row above p1 is final (and its diagonal block inverted): what of the inversion lies above it
+                if (early_done) SR_FH(hipStreamWaitEvent(si, h->ev_inv[1], 0));      // (stages in order; same stream anyway)
                 early_done = true;
                 SR_FH(hipEventRecord(h->ev_inv[0], sc));
                 SR_FH(hipStreamWaitEvent(si, h->ev_inv[0], 0));
-                for (const sr_gp::inv_level& lv : h->inv_levels) {
-                    sr_prof_scope ps(&h->prof, SR_K_TRINV, si);
-                    if (lv.depth == 0) {
-                        SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, 1, lv.maxM, lv.maxN, lv.tiles, 1.0, 2,
-                                                    si, &b_inv1));
-                    } else if (lv.n_left > 0) {
-                        SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1, lv.n_left, lv.maxM, lv.maxN,
-                                                    lv.tiles_left, 1.0, 2, si, &b_inv1));
-                        SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2, lv.n_left, lv.maxM, lv.maxN,
-                                                    lv.tiles_left, -1.0, 3, si, &b_inv2));
-                    }
-                }
+                SR_F(inv_stage(p1, si, false));
                 SR_FH(hipEventRecord(h->ev_inv[1], si));
+                while (inv_trigger <= p1) {
+                    const int nxt_t = (inv_trigger + nb) / 2;
+                    inv_trigger = (nb - nxt_t >= inv_min_rest && nxt_t > inv_trigger) ? nxt_t : nb + 1;
+                }
             }
             const int rest = Np - p1 * SR_NB;
             if (rest <= 0) continue;
@@ -617,18 +643,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         // --- W = U^-T (lower) and Wt = U^-1 (upper) by recursive halving of the block range, level by level
         // (ensure_inv_jobs).  The diagonal blocks of W / Wt were written by sr_potrf_diag_kernel.
         if (early_done) SR_FH(hipStreamWaitEvent(sc, h->ev_inv[1], 0));
-        for (const sr_gp::inv_level& lv : h->inv_levels) {
-            sr_prof_scope ps(&h->prof, SR_K_TRINV, sc);
-            const int skip = early_done ? lv.n_left : 0;          // jobs of the left subtree already ran
-            const int cnt = lv.count - skip;
-            const long tiles = lv.tiles - (early_done ? lv.tiles_left : 0);
-            if (cnt > 0 && !(early_done && lv.depth == 0))
-                SR_F(sr_launch_gemm_tn_jobs(W, W, U, nullptr, Np, h->inv_jobs + lv.off1 + skip, cnt, lv.maxM, lv.maxN, tiles, 1.0, 2,
-                                            sc, &b_inv1));
-            if (cnt > 0)
-                SR_F(sr_launch_gemm_tn_jobs(Wt, U, W, Wt, Np, h->inv_jobs + lv.off2 + skip, cnt, lv.maxM, lv.maxN, tiles, -1.0, 3,
-                                            sc, &b_inv2));
-        }
+        SR_F(inv_stage(nb, sc, true));                    // whatever the stages have left
         // alpha = Wt (W y)   (v behind W in the scratch)
         SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d0 * Np, W + NN, Np, 1, sc, nd, sP, Np, sP));
         SR_F(sr_launch_trmv(Wt, Np, W + NN, h->alpha + (size_t)d0 * Np, Np, 0, sc, nd, sN, sP, Np));

@@ -126,7 +126,9 @@ struct sr_gp {
     int* fact_info = nullptr;                            // status words of the factorisation (64 ints)
     size_t mem_total = 0;                                // device memory (cached)
     sr_gemm_job* inv_jobs = nullptr; int inv_jobs_np = 0;
-    struct inv_level { int off1, off2, count, maxM, maxN; long tiles; int depth, n_left; long tiles_left; };   // jobs of the root's left subtree first
+    // jobs of a level in ascending order of their block range [lo, hi); per job: where it ends, where its left child ends
+    // (blocks), its 128-tiles -- the inversion is launched in stages as the Cholesky passes those points (sr_capi_update.hip)
+    struct inv_level { int off1, off2, count, maxM, maxN; long tiles; int depth; std::vector<int> hi, mid; std::vector<long> tl; };
     std::vector<inv_level> inv_levels;
     sr_prof prof;
 };
