@@ -479,6 +479,11 @@ def run(args):
         torch.cuda.synchronize(dev)
         bc_s = (time.perf_counter() - t0) / 5
         assert bool((piece == ref).all())
+        # the collective the N > 1 line takes its per-rank numbers from (gather_rank_stats): device tensors through RCCL
+        probe = torch.arange(10, dtype=torch.float64, device=dev)
+        got = [torch.empty_like(probe)]
+        dist.all_gather(got, probe)
+        assert bool((got[0] == probe).all())
         dry = {"backend": dist.get_backend(), "world": dist.get_world_size(), "replication_s": round(rep_s, 4),
                "replication_bytes": parallel.LAST_REPLICATION.get("factor_bytes", 0) + parallel.LAST_REPLICATION.get("other_bytes", 0),
                "pieces": parallel.LAST_REPLICATION.get("pieces"), "broadcast_64MB_ms": round(1e3 * bc_s, 4),
