@@ -439,3 +439,22 @@ def test_only_the_documented_kernels_use_scratch():
                "void sr_gp_small_general_kernel<512, 8>"}
     spilled = {r["kernel"] for r in rows if int(r.get("ScratchSize", 0)) > 0}
     assert spilled <= allowed, sorted(spilled - allowed)
+
+
+def test_bench_rank_section_and_single_rank_gather():
+    """The self-diagnosis of an N > 1 bench line, host side: min / max / slowest / spread of the ranks' own
+    times, and the one-rank form of the gather (no process group needed)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rk = bench.rank_section([45.1, 45.9, 44.8, 45.0])
+    assert rk["ms_per_step"] == [45.1, 45.9, 44.8, 45.0]
+    assert rk["ms_per_step_min"] == 44.8 and rk["ms_per_step_max"] == 45.9 and rk["slowest_rank"] == 1
+    assert abs(rk["spread"] - (45.9 - 44.8) / 44.8) < 1e-15
+    one = bench.gather_rank_stats([1.5, 2, 3.25], "cpu", 1)
+    assert one.shape == (1, 3) and list(one[0]) == [1.5, 2.0, 3.25]
+    assert bench.XGMI_LINK_GBS == 153.0
+    args = bench.parse_args(["--workload", "c4", "--gpus", "2"])
+    assert args.c4_replicas is False and bench.parse_args(["--c4-replicas"]).c4_replicas is True
