@@ -222,7 +222,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     (void)device_sync();
     dev_free(h->Z); dev_free(yT_alloc_of(h)); dev_free(h->ls); dev_free(h->sf2); dev_free(h->noise);
     dev_free(alpha_alloc_of(h)); dev_free(wt_alloc_of(h)); dev_free(h->kp); dev_free(h->lin_v); dev_free(h->lin_g); dev_free(h->small_vp); dev_free(h->splitk_vt); dev_free(h->splitk_part);
-    dev_free(h->stream_vp); dev_free(h->stream_tickets); dev_free(h->stream_slots);
+    dev_free(h->stream_vp); dev_free(h->stream_tickets); dev_free(h->stream_slots); dev_free(h->stream_tab);
     dev_free(h->Tz); dev_free(h->tz_x); dev_free(h->tz_jac);
     dev_free(h->chain_xch); dev_free(h->chain_tickets); dev_free(h->chain_done); dev_free(h->call_ticket);
     if (h->chain_status_host) (void)hipHostFree(h->chain_status_host);

@@ -87,6 +87,38 @@ static int stream_buffers(sr_gp* h, int ncols, hipStream_t s) {
     return SR_OK;
 }
 
+// work items of the run kernel for this model and column count: planned on the host once per (padded size, width), the table
+// kept on the device (sr_stream_items)
+static int stream_items(sr_gp* h, sr_stream_args& a, int ncols, int width_min, hipStream_t s) {
+    const int nc = std::max(sr_stream_width(ncols), width_min);
+    if (nc <= 4) return SR_OK;
+    const long key = ((long)h->Np * 256 + nc) * 64 + h->n_out;
+    if (h->stream_tab_key != key) {
+        if (h->ncu == 0) {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+            h->ncu = cus;
+        }
+        std::vector<int> tab;
+        int n = 0;
+        const int kr = sr_stream_items(h->Np, h->n_out, nc, h->ncu, tab, &n);
+        if (kr > 0) {
+            if ((long)tab.size() > h->stream_tab_cap) {
+                (void)hipStreamSynchronize(s);
+                dev_free(h->stream_tab);
+                h->stream_tab = nullptr; h->stream_tab_cap = 0;
+                SR_TRY(dev_alloc(&h->stream_tab, tab.size()));
+                h->stream_tab_cap = (long)tab.size();
+            }
+            SR_HIP(hipStreamSynchronize(s));                      // (a launch that still reads the old table)
+            SR_HIP(hipMemcpy(h->stream_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        h->stream_tab_key = key; h->stream_tab_kr = kr; h->stream_tab_n = n;
+    }
+    a.item_tab = h->stream_tab; a.kr = h->stream_tab_kr; a.nitems = h->stream_tab_n;
+    return SR_OK;
+}
+
 static void stream_common(const sr_gp* h, sr_stream_args& a, int ncols, long Tp) {
     a.Wt = h->Wt; a.Ks = h->Ks; a.Vp = h->stream_vp; a.part = h->var_part; a.tickets = h->stream_tickets;
     a.N = h->N; a.Np = h->Np; a.D = h->D; a.n_out = h->n_out; a.k_lo = h->Np - h->N; a.ncols = ncols; a.ncols_pad = ncols;
@@ -153,6 +185,7 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
         }
         a.slots = h->stream_slots;
     }
+    SR_TRY(stream_items(h, a, (int)Tc, a.width_min, s));
     h->last_streamed = 0;
     sr_prof_scope ps(&h->prof, SR_K_VAR, s);
     return sr_launch_stream(a, fused ? 1 : 0, s);
@@ -191,6 +224,7 @@ static int stream_linearize(sr_gp* h, const double* x, double* mu, double* var, 
     a.nblk = fused ? 2 * ncb : nblk256;
     a.lin_dt = h->D <= 3 ? 3 : (h->D <= 5 ? 5 : (h->D <= 8 ? 8 : 12));
     a.lmu = mu; a.lvar = var; a.ljac_mu = jac_mu;
+    SR_TRY(stream_items(h, a, ncols, 0, s));
     h->last_streamed = 0;
     sr_prof_scope ps(&h->prof, SR_K_VAR, s);
     return sr_launch_stream(a, fused ? 2 : 0, s);

@@ -513,6 +513,8 @@ struct sr_stream_args {
     // polling finaliser of the one-column kernel (round 6): dedicated, self-validating slots (SR_ST1_EMPTY until written):
     // [d][cb] column-block norms, then [j][d][1 + D] the N-split partial sums of mean and mean-Jacobian; NULL = tickets
     double* slots = nullptr;
+    // work items of the run kernel (sr_stream_items): device table [column block, run, slot] x nitems, rows per run
+    const int* item_tab = nullptr; int kr = 0, nitems = 0;
 };
 #define SR_ST1_SLOTS_MAX 1536        /* doubles of LDS the finaliser gathers the slots in */
 __host__ __device__ static inline long sr_st1_slots(int ncb, int n_out, int D) { return (long)n_out * ncb * (1 + 2 * (1 + D)); }
@@ -522,6 +524,10 @@ long sr_stream_vp_doubles(int Np, int n_out, int ncols);
 int sr_stream_tickets(int Np, int n_out);
 int sr_stream_width(int ncols);
 void sr_stream_plan(int Np, int n_out, int nc, int* g, int* kc);
+#ifdef __cplusplus
+#include <vector>
+int sr_stream_items(int Np, int n_out, int nc, int n_cu, std::vector<int>& tab, int* nitems);   // rows per run (0: no run kernel)
+#endif
 int sr_launch_stream(sr_stream_args a, int src, hipStream_t s);
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s);
 int sr_lin_nacc(int D);

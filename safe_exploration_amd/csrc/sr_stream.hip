@@ -24,6 +24,8 @@
 // zeroed at allocation and reset by the last arriver.
 #include "sr_mfma_tile.h"
 #include "sr_final_dev.h"
+#include <algorithm>
+#include <vector>
 
 #define SR_ST_ROWS 128
 #define SR_ST_COLS 256
@@ -567,14 +569,15 @@ __global__ __launch_bounds__(256) void sr_stream_reduce1_kernel(sr_stream_args a
 // Vp[(d, work item)][column][256].
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ int sr_st_items_of(int cb, int kc) { return (2 * cb + 2 + kc - 1) / kc; }
-__device__ __forceinline__ void sr_item_decode(int p, int kc, int& cb, int& J) {
-    cb = 0;
-    for (int n = sr_st_items_of(0, kc); p >= n; n = sr_st_items_of(cb, kc)) { p -= n; ++cb; }
-    J = p;
-}
+// work items of column block cb when an item is a run of `kr` rows (round 6: kr a multiple of the kernel's LDS stage, not of
+// the 128-row chunk; the last item of a column block is shorter)
+__host__ __device__ __forceinline__ int sr_st_items_rows(int cb, int kr) { return ((2 * cb + 2) * SR_ST_ROWS + kr - 1) / kr; }
 
+// Work items come from a TABLE (round 6): entry p = (column block, run J of a.kr rows, slot of the partial result), longest
+// runs first -- the launch is one workgroup per CU and as long as its longest resident sequence; with runs of whole chunks in
+// column-block order, N = 5000 / T = 64 was 220 workgroups of up to 8 LDS stages on 256 CUs (1680 stages: 6.6 per CU).
 template <int G>
-__global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, int KC) {
+__global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) {
     constexpr int NC = 16 * G;
     constexpr int LDK = (G == 1) ? 16 : NC + 16;
     constexpr int SUB = (G <= 2) ? 128 : (G == 4 ? 64 : 32);      // K* rows per LDS stage
@@ -583,11 +586,9 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
     constexpr int PF = SUB * NC / 1024;                           // K* doubles a thread moves per stage
     static_assert(BPS == 2 && BPS * UB * 4 == SUB && PF * 1024 == SUB * NC, "stage geometry");
     __shared__ double ks[2][SUB * LDK];
-    const int d = blockIdx.y, p = blockIdx.x;
-    int cb, J;
-    sr_item_decode(p, KC, cb, J);
-    const int j_hi = min(J * KC + KC, 2 * cb + 2);
-    const int k0 = J * KC * SR_ST_ROWS, k1 = min(j_hi * SR_ST_ROWS, a.Np);
+    const int d = blockIdx.y;
+    const int cb = a.item_tab[3 * blockIdx.x], J = a.item_tab[3 * blockIdx.x + 1], p = a.item_tab[3 * blockIdx.x + 2];
+    const int k0 = J * a.kr, k1 = min(min(k0 + a.kr, (2 * cb + 2) * SR_ST_ROWS), a.Np);
     const int nsub = (k1 - k0 + SUB - 1) / SUB;
     if (k0 >= a.Np) {
         // an EMPTY run (the chunk beyond Np of an odd padded size) reports zeros and is gone.  (Not a branch around the
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a, 
 // stage on the spot.  (Round 2: one workgroup of 256 threads per (column block, output, column) + a ticket per query:
 // 20 x n_out x T workgroups of two dependent round trips each -- 19 / 26 / 38 us for T = 16 / 32 / 64 at N = 5000,
 // whatever the amount of partial sums.)  Linearize mode: the last workgroup of the grid (ticket) runs the final stage.
-__global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a, int nc, int KC, int nitems) {
+__global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a, int nc, int KR, int nitems) {
     __shared__ double sh[4 * 120];
     __shared__ double red[8];
     __shared__ int s_flag;
@@ -727,9 +728,9 @@ __global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a,
     }
     // first work item of this thread's first column block
     int p0 = 0;
-    for (int c = 0; c < sub; ++c) p0 += sr_st_items_of(c, KC);
+    for (int c = 0; c < sub; ++c) p0 += sr_st_items_rows(c, KR);
     double acc = 0.0;
-    if (!dot && sr_st_items_of(a.ncb - 1, KC) <= 12) {
+    if (!dot && sr_st_items_rows(a.ncb - 1, KR) <= 12) {
         // at most 12 work items per column block (N = 5000: KC = 4, 1 .. 10): the items of FIVE column blocks are
         // requested together -- the reduction is a chain of dependent round trips, not of bytes
         for (int cb = sub; cb < a.ncb; cb += 10) {
@@ -738,10 +739,10 @@ __global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a,
 #pragma unroll
             for (int b = 0; b < 5; ++b) {
                 const int cbb = cb + 2 * b;
-                const int nch = cbb < a.ncb ? sr_st_items_of(cbb, KC) : 0;
+                const int nch = cbb < a.ncb ? sr_st_items_rows(cbb, KR) : 0;
 #pragma unroll
                 for (int u = 0; u < 12; ++u) x[b][u] = (u < nch) ? base[(long)(pp + u) * cs + (long)t * SR_ST_COLS] : 0.0;
-                for (int c = cbb; c < cbb + 2 && c < a.ncb; ++c) pp += sr_st_items_of(c, KC);
+                for (int c = cbb; c < cbb + 2 && c < a.ncb; ++c) pp += sr_st_items_rows(c, KR);
             }
             p0 = pp;
 #pragma unroll
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a,
         }
     } else {
         for (int cb = sub; cb < a.ncb; cb += 2) {
-            const int nch = sr_st_items_of(cb, KC);
+            const int nch = sr_st_items_rows(cb, KR);
             double v = 0.0, v0 = 0.0;
             for (int c = 0; c < nch; c += 12) {               // (plain loads: Vp comes from the previous launch)
                 double x[12], y[12];
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(512) void sr_stream_reduce_kernel(sr_stream_args a,
                 for (int u = 0; u < 12; ++u) { v += x[u]; v0 += y[u]; }
             }
             acc = fma(v, dot ? v0 : v, acc);
-            for (int c = cb; c < cb + 2 && c < a.ncb; ++c) p0 += sr_st_items_of(c, KC);
+            for (int c = cb; c < cb + 2 && c < a.ncb; ++c) p0 += sr_st_items_rows(c, KR);
         }
     }
     // sum over the workgroup in a fixed order: wavefront butterflies, then the 16 wavefront sums
@@ -856,6 +857,79 @@ void sr_stream_plan(int Np, int n_out, int nc, int* g_out, int* kc_out) {
     *g_out = g; *kc_out = kc;
 }
 
+
+// Work items of the run kernel (kc > 1 in sr_stream_plan) for nc columns: the run length kr (rows; a multiple of the kernel's LDS
+// stage, at least a chunk) that gives the shortest launch, and the table [column block, run, slot] x items, longest runs first.
+// "Shortest": the workgroups are dealt to the CUs in grid order (x fastest, then output, then column group), one per CU, each to
+// the CU that is free first; a run costs its rows plus ~32 rows' worth of prologue and epilogue.  (Round 5 took runs of whole
+// chunks in column-block order, as long as >= 200 workgroups remained: N = 5000, T = 64: 220 workgroups of up to 512 rows =
+// 8 stages on the longest CU where 1680 stages over 256 CUs are 6.6.)
+int sr_stream_items(int Np, int n_out, int nc, int n_cu, std::vector<int>& tab, int* nitems_out) {
+    int g, kc;
+    sr_stream_plan(Np, n_out, nc, &g, &kc);
+    tab.clear();
+    *nitems_out = 0;
+    if (kc <= 1) return 0;
+    const int ncb = (Np + SR_ST_COLS - 1) / SR_ST_COLS;
+    const int gz = nc / (16 * g);
+    const int sub = (g <= 2) ? 128 : (g == 4 ? 64 : 32);          // rows per LDS stage (sr_stream_mfma_kernel)
+    const int cus = n_cu > 0 ? n_cu : 256;
+    static const int forced = (int)sr_lab_env("SR_ST_KR", 0);     // (lab build: rows per run, 0 = planned; -1 = round 5's runs)
+    auto build = [&](int kr, std::vector<int>& out) {             // entries sorted by length, longest first (stable)
+        std::vector<std::pair<int, int>> ord;                      // (rows, index)
+        std::vector<int> raw;
+        int slot = 0;
+        for (int cb = 0; cb < ncb; ++cb) {
+            const int n = sr_st_items_rows(cb, kr), top = std::min((2 * cb + 2) * SR_ST_ROWS, Np);
+            for (int J = 0; J < n; ++J, ++slot) {
+                const int rows = std::max(0, std::min(J * kr + kr, top) - J * kr);
+                ord.push_back({rows, (int)raw.size() / 3});
+                raw.push_back(cb); raw.push_back(J); raw.push_back(slot);
+            }
+        }
+        std::stable_sort(ord.begin(), ord.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+        out.clear();
+        for (const auto& e : ord) { out.push_back(raw[3 * e.second]); out.push_back(raw[3 * e.second + 1]); out.push_back(raw[3 * e.second + 2]); }
+        return ord;
+    };
+    auto makespan = [&](const std::vector<std::pair<int, int>>& ord) {
+        std::vector<long> cu(cus, 0);
+        long worst = 0;
+        for (int z = 0; z < gz * n_out; ++z)
+            for (const auto& e : ord) {
+                auto it = std::min_element(cu.begin(), cu.end());
+                *it += e.first + 32;
+                worst = std::max(worst, *it);
+            }
+        return worst;
+    };
+    int best_kr = kc * SR_ST_ROWS;
+    if (forced > 0) best_kr = (forced + sub - 1) / sub * sub;
+    else if (forced == 0) {
+        // ONE round where there is one (every workgroup resident from the start): a workgroup that has to wait for a CU measured
+        // far worse than its length says (N = 5000, T = 64: 258 workgroups of <= 448 rows 112 us, 220 of <= 512 rows 102)
+        long best = -1, best1 = -1;
+        int kr1 = 0;
+        for (int kr = std::max(SR_ST_ROWS, 2 * sub); kr <= 32 * SR_ST_ROWS; kr += sub) {
+            std::vector<int> t;
+            const auto ord = build(kr, t);
+            const long m = makespan(ord);
+            if (best < 0 || m < best) { best = m; best_kr = kr; }
+            if ((long)ord.size() * gz * n_out <= cus && (best1 < 0 || m < best1)) { best1 = m; kr1 = kr; }
+        }
+        if (kr1 > 0) best_kr = kr1;
+    }
+    const auto ord = build(best_kr, tab);
+    if (forced < 0) {                                              // round 5: column-block order (no sorting)
+        tab.clear();
+        int slot = 0;
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int J = 0; J < sr_st_items_rows(cb, best_kr); ++J, ++slot) { tab.push_back(cb); tab.push_back(J); tab.push_back(slot); }
+    }
+    *nitems_out = (int)ord.size();
+    return best_kr;
+}
+
 // src: 0 columns from a.Ks, 1 ARD-RBF predict columns evaluated in the kernel, 2 ARD-RBF linearize columns
 int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     a.ncb = (a.Np + SR_ST_COLS - 1) / SR_ST_COLS;
@@ -882,7 +956,6 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     int g, kc;
     sr_stream_plan(a.Np, a.n_out, nc, &g, &kc);
     grid.z = nc / (16 * g);
-    auto items = [&](int kc_) { long n = 0; for (int cb = 0; cb < a.ncb; ++cb) n += sr_st_items_of(cb, kc_); return n; };
     SR_CHECK(src == 0 || kc == 1, SR_EINVAL, "stream: columns evaluated in the kernel only for one-chunk work items (runs of %d)", kc);
     if (kc == 1) {
         // (columns evaluated in the kernel: 16 or 32 per workgroup only -- every column block re-evaluates the chunk's rows,
@@ -903,16 +976,17 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
         SR_HIP(hipGetLastError());
         return SR_OK;
     }
-    const int nitems = (int)items(kc);
+    SR_CHECK(a.item_tab != nullptr && a.kr >= SR_ST_ROWS && a.nitems > 0, SR_EINVAL, "stream: no work-item table (sr_stream_items)");
+    const int nitems = a.nitems;
     grid.x = nitems;
     switch (g) {
-        case 1: hipLaunchKernelGGL(sr_stream_mfma_kernel<1>, grid, dim3(1024), 0, s, a, kc); break;
-        case 2: hipLaunchKernelGGL(sr_stream_mfma_kernel<2>, grid, dim3(1024), 0, s, a, kc); break;
-        case 4: hipLaunchKernelGGL(sr_stream_mfma_kernel<4>, grid, dim3(1024), 0, s, a, kc); break;
-        default: hipLaunchKernelGGL(sr_stream_mfma_kernel<8>, grid, dim3(1024), 0, s, a, kc); break;
+        case 1: hipLaunchKernelGGL(sr_stream_mfma_kernel<1>, grid, dim3(1024), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(sr_stream_mfma_kernel<2>, grid, dim3(1024), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(sr_stream_mfma_kernel<4>, grid, dim3(1024), 0, s, a); break;
+        default: hipLaunchKernelGGL(sr_stream_mfma_kernel<8>, grid, dim3(1024), 0, s, a); break;
     }
     SR_HIP(hipGetLastError());
-    hipLaunchKernelGGL(sr_stream_reduce_kernel, dim3(a.ncols, a.n_out), dim3(512), 0, s, a, nc, kc, nitems);
+    hipLaunchKernelGGL(sr_stream_reduce_kernel, dim3(a.ncols, a.n_out), dim3(512), 0, s, a, nc, a.kr, nitems);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
