@@ -89,10 +89,10 @@ static int stream_buffers(sr_gp* h, int ncols, hipStream_t s) {
 
 // work items of the run kernel for this model and column count: planned on the host once per (padded size, width), the table
 // kept on the device (sr_stream_items)
-static int stream_items(sr_gp* h, sr_stream_args& a, int ncols, int width_min, hipStream_t s) {
+static int stream_items(sr_gp* h, sr_stream_args& a, int ncols, int width_min, bool can_fuse, hipStream_t s) {
     const int nc = std::max(sr_stream_width(ncols), width_min);
     if (nc <= 4) return SR_OK;
-    const long key = ((long)h->Np * 256 + nc) * 64 + h->n_out;
+    const long key = (((long)h->Np * 256 + nc) * 64 + h->n_out) * 2 + (can_fuse ? 1 : 0);
     if (h->stream_tab_key != key) {
         if (h->ncu == 0) {
             int cus = 0;
@@ -101,7 +101,7 @@ static int stream_items(sr_gp* h, sr_stream_args& a, int ncols, int width_min, h
         }
         std::vector<int> tab;
         int n = 0;
-        const int kr = sr_stream_items(h->Np, h->n_out, nc, h->ncu, tab, &n);
+        const int kr = sr_stream_items(h->Np, h->n_out, nc, h->ncu, can_fuse, tab, &n);
         if (kr > 0) {
             if ((long)tab.size() > h->stream_tab_cap) {
                 (void)hipStreamSynchronize(s);
@@ -143,7 +143,7 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
     bool fused_mfma = false;
     if (!h->general && h->D <= SR_STREAM_FUSED_MAX_D && (Tc > 4 || mfma_small) && h->small_path != 0) {
         int g = 0, kc = 0;
-        sr_stream_plan(h->Np, h->n_out, std::max(sr_stream_width((int)Tc), mfma_small ? 16 : 0), &g, &kc);
+        sr_stream_plan(h->Np, h->n_out, std::max(sr_stream_width((int)Tc), mfma_small ? 16 : 0), &g, &kc, true);
         fused_mfma = kc == 1 && (g == 1 || (g == 2 && ncb <= SR_STREAM_FUSED32_MAX_NCB));
     }
     const bool fused = (!h->general && h->D <= SR_STREAM_FUSED_MAX_D && Tc <= 4 && !mfma_small) || fused_mfma;
@@ -185,7 +185,7 @@ static int stream_predict(sr_gp* h, long Tc, const double* xa, long lda, int na,
         }
         a.slots = h->stream_slots;
     }
-    SR_TRY(stream_items(h, a, (int)Tc, a.width_min, s));
+    SR_TRY(stream_items(h, a, (int)Tc, a.width_min, fused, s));
     h->last_streamed = 0;
     sr_prof_scope ps(&h->prof, SR_K_VAR, s);
     return sr_launch_stream(a, fused ? 1 : 0, s);
@@ -224,7 +224,7 @@ static int stream_linearize(sr_gp* h, const double* x, double* mu, double* var, 
     a.nblk = fused ? 2 * ncb : nblk256;
     a.lin_dt = h->D <= 3 ? 3 : (h->D <= 5 ? 5 : (h->D <= 8 ? 8 : 12));
     a.lmu = mu; a.lvar = var; a.ljac_mu = jac_mu;
-    SR_TRY(stream_items(h, a, ncols, 0, s));
+    SR_TRY(stream_items(h, a, ncols, 0, false, s));
     h->last_streamed = 0;
     sr_prof_scope ps(&h->prof, SR_K_VAR, s);
     return sr_launch_stream(a, fused ? 2 : 0, s);

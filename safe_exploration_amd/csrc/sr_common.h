@@ -523,10 +523,11 @@ __host__ __device__ static inline long sr_st1_slots(int ncb, int n_out, int D) {
 long sr_stream_vp_doubles(int Np, int n_out, int ncols);
 int sr_stream_tickets(int Np, int n_out);
 int sr_stream_width(int ncols);
-void sr_stream_plan(int Np, int n_out, int nc, int* g, int* kc);
+// can_fuse: the caller can have the kernel evaluate its own K* rows (ARD-RBF, D <= 5): one-chunk items then reach further
+void sr_stream_plan(int Np, int n_out, int nc, int* g, int* kc, bool can_fuse = false);
 #ifdef __cplusplus
 #include <vector>
-int sr_stream_items(int Np, int n_out, int nc, int n_cu, std::vector<int>& tab, int* nitems);   // rows per run (0: no run kernel)
+int sr_stream_items(int Np, int n_out, int nc, int n_cu, bool can_fuse, std::vector<int>& tab, int* nitems);   // rows per run (0: no run kernel)
 #endif
 int sr_launch_stream(sr_stream_args a, int src, hipStream_t s);
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s);

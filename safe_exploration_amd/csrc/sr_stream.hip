@@ -840,7 +840,7 @@ int sr_stream_width(int ncols) {
 }
 
 // The plan of the MFMA route for nc (16 .. 128) columns: g = groups of 16 columns per workgroup, kc = k-chunks per work item.
-void sr_stream_plan(int Np, int n_out, int nc, int* g_out, int* kc_out) {
+void sr_stream_plan(int Np, int n_out, int nc, int* g_out, int* kc_out, bool can_fuse) {
     const int ncb = (Np + SR_ST_COLS - 1) / SR_ST_COLS;
     const long npairs = (long)ncb * (ncb + 1);
     // columns per workgroup: as many as possible (U^-1 is then read once for all of them) while the grid still
@@ -852,8 +852,14 @@ void sr_stream_plan(int Np, int n_out, int nc, int* g_out, int* kc_out) {
     // columns, whole call: runs of 1 / 2 / 3 / 4 chunks 79 / 70 / 81 / 66, 169 / 138 / 166 / 125, 288 / 245 / 300 / 218 us)
     auto items = [&](int kc) { long n = 0; for (int cb = 0; cb < ncb; ++cb) n += sr_st_items_of(cb, kc); return n; };
     int kc = 1;
+    static const long min_items = sr_lab_env("SR_ST_MIN_ITEMS", 200);       // (lab build: 1000000 = one-chunk work items everywhere)
     for (int c : {2, 3, 4, 6, 8})
-        if (items(c) * n_out * gz >= 200) kc = c;
+        if (items(c) * n_out * gz >= min_items) kc = c;
+    // 16 columns: one-chunk work items that evaluate their rows of K* themselves (no K* pass in front) stay ahead of the run
+    // kernel up to ~7000 rows (round 6 scan, same box, T = 8 / 16, one-chunk against runs: N = 3400 32 / 35 against 45 / 45 us,
+    // 4200 43 / 48 against 52 / 52, 5000 53 / 60 against 63 / 62, 7000 108 / 115 against 113 / 113; with 32 columns the two are
+    // level up to 3800 rows and the runs win beyond: profiles/r06_stream_items.txt)
+    if (can_fuse && nc == 16 && ncb <= 28 && min_items == 200) kc = 1;
     *g_out = g; *kc_out = kc;
 }
 
@@ -864,9 +870,9 @@ void sr_stream_plan(int Np, int n_out, int nc, int* g_out, int* kc_out) {
 // the CU that is free first; a run costs its rows plus ~32 rows' worth of prologue and epilogue.  (Round 5 took runs of whole
 // chunks in column-block order, as long as >= 200 workgroups remained: N = 5000, T = 64: 220 workgroups of up to 512 rows =
 // 8 stages on the longest CU where 1680 stages over 256 CUs are 6.6.)
-int sr_stream_items(int Np, int n_out, int nc, int n_cu, std::vector<int>& tab, int* nitems_out) {
+int sr_stream_items(int Np, int n_out, int nc, int n_cu, bool can_fuse, std::vector<int>& tab, int* nitems_out) {
     int g, kc;
-    sr_stream_plan(Np, n_out, nc, &g, &kc);
+    sr_stream_plan(Np, n_out, nc, &g, &kc, can_fuse);
     tab.clear();
     *nitems_out = 0;
     if (kc <= 1) return 0;
@@ -954,7 +960,7 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     SR_CHECK(src == 0 || (src == 1 && a.D <= 5), SR_EINVAL, "stream: src %d with %d columns, D = %d", src, a.ncols, a.D);
     a.ncols_pad = a.ncols;
     int g, kc;
-    sr_stream_plan(a.Np, a.n_out, nc, &g, &kc);
+    sr_stream_plan(a.Np, a.n_out, nc, &g, &kc, src == 1);
     grid.z = nc / (16 * g);
     SR_CHECK(src == 0 || kc == 1, SR_EINVAL, "stream: columns evaluated in the kernel only for one-chunk work items (runs of %d)", kc);
     if (kc == 1) {
