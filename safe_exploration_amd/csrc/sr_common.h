@@ -515,6 +515,7 @@ struct sr_stream_args {
     double* slots = nullptr;
     // work items of the run kernel (sr_stream_items): device table [column block, run, slot] x nitems, rows per run
     const int* item_tab = nullptr; int kr = 0, nitems = 0;
+    int epi = 1;                     // partial products of the MFMA kernels: 1 one 32-byte run per lane; lab build: 0 8-byte pieces (round 5), 2 non-temporal
 };
 #define SR_ST1_SLOTS_MAX 1536        /* doubles of LDS the finaliser gathers the slots in */
 __host__ __device__ static inline long sr_st1_slots(int ncb, int n_out, int D) { return (long)n_out * ncb * (1 + 2 * (1 + D)); }

@@ -382,6 +382,30 @@ __global__ __launch_bounds__(SR_ST1_THREADS) void sr_stream1_kernel(sr_stream_ar
     sr_stream_final(a, sh);
 }
 
+// Partial product of an MFMA work item: Vp[item][query][256 columns].  The accumulator of v_mfma_f64_16x16x4 holds, in lane
+// (lk, ln), rows lk + 4 r (r = 0 .. 3) of query ln.  Round 6: the A-fragment lanes load the strip's columns PERMUTED (MFMA row
+// m <-> column 4 (m % 4) + m / 4: the same 128-byte line, another lane), so that a lane's four rows are the neighbouring
+// columns 4 lk .. 4 lk + 3 and leave as ONE 32-byte run: the four lanes of a query fill a whole 128-byte line per store.
+// (N = 5000, T = 64: 102.5 -> 99.3 us, N = 3000: 74.2 -> 68.9, T = 32 45 from 48; non-temporal on top: no difference --
+// profiles/r06_stream_items.txt)
+__device__ __forceinline__ int sr_st_strip_col(int ln, int epi) { return epi ? 4 * (ln & 3) + (ln >> 2) : ln; }
+template <int G>
+__device__ __forceinline__ void sr_st_store_partial(double* out, const d4_t (&acc)[G], int wave, int lk, int ln, bool live, int epi) {
+    if (epi == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long)(16 * g + ln) * SR_ST_COLS + 16 * wave + lk + 4 * r] = live ? acc[g][r] : 0.0;
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        d4_t* dst = reinterpret_cast<d4_t*>(out + (long)(16 * g + ln) * SR_ST_COLS + 16 * wave + 4 * lk);
+        const d4_t v = live ? acc[g] : d4_t{0.0, 0.0, 0.0, 0.0};
+        if (epi == 2) __builtin_nontemporal_store(v, dst); else *dst = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ONE 128-row k-chunk per workgroup (models whose grid would not cover the chip with longer runs: N < ~4000; there
 // this form is faster than the run kernel below with KC = 1 -- N = 3000, T = 32: 26.0 + 14.6 against 33.3 + 17.0 us for
@@ -486,7 +510,7 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma1_kernel(sr_stream_args a)
         //  four rows past U^-1 of the last output)
         const int u_end = (i0 + 15 < k0) ? 0 : min(min(32, (a.Np - k0) / 4), (i0 + 15 - k0) / 4 + 1);
         int u = max(0, (a.k_lo - k0) / 4);
-        const double* w = a.Wt + (long)d * a.Np * a.Np + (long)(k0 + lk) * a.Np + i0 + ln;
+        const double* w = a.Wt + (long)d * a.Np * a.Np + (long)(k0 + lk) * a.Np + i0 + sr_st_strip_col(ln, a.epi);
         constexpr int UB = (G <= 2) ? 16 : 8;            // A-fragments in flight per batch
         for (; u + UB <= u_end; u += UB) {
             double af[UB];
@@ -505,12 +529,9 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma1_kernel(sr_stream_args a)
                 acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, ks[(4 * u + lk) * LDK + 16 * g + ln], acc[g], 0, 0, 0);
         }
     }
-    // acc[g][r] = V[column i0 + lk + 4r][query 16 g + ln]
+    // acc[g][r] = V[column i0 + 4 lk + r][query 16 g + ln]   (sr_st_store_partial)
     double* out = a.Vp + (((long)d * a.npairs + p) * (NC * gridDim.z) + c0) * SR_ST_COLS;
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(long)(16 * g + ln) * SR_ST_COLS + 16 * wave + lk + 4 * r] = acc[g][r];
+    sr_st_store_partial<G>(out, acc, wave, lk, ln, true, a.epi);
 }
 
 // part[d][cb][t] = sum_{i in column block cb} V_t[i] (dot0 ? V_0[i] : V_t[i]),  V_t = sum_chunks Vp;
@@ -576,6 +597,20 @@ __host__ __device__ __forceinline__ int sr_st_items_rows(int cb, int kr) { retur
 // Work items come from a TABLE (round 6): entry p = (column block, run J of a.kr rows, slot of the partial result), longest
 // runs first -- the launch is one workgroup per CU and as long as its longest resident sequence; with runs of whole chunks in
 // column-block order, N = 5000 / T = 64 was 220 workgroups of up to 8 LDS stages on 256 CUs (1680 stages: 6.6 per CU).
+#ifdef SR_LAB
+// lab build: per-workgroup time stamps of the run kernel (100 MHz wall clock): start, first stage staged, loop done, end, stages
+__device__ unsigned long long sr_lab_st_trace[8 * 4096];
+extern "C" int sr_lab_stream_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sr_lab_st_trace), sizeof(unsigned long long) * (size_t)std::min(n, 8 * 4096));
+}
+#define SR_LAB_STAMP(i_) do { if (threadIdx.x == 0) { const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (wg_ < 4096) sr_lab_st_trace[8 * wg_ + (i_)] = wall_clock64(); } } while (0)
+#define SR_LAB_NOTE(i_, v_) do { if (threadIdx.x == 0) { const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (wg_ < 4096) sr_lab_st_trace[8 * wg_ + (i_)] = (unsigned long long)(v_); } } while (0)
+#else
+#define SR_LAB_STAMP(i_) do {} while (0)
+#define SR_LAB_NOTE(i_, v_) do {} while (0)
+#endif
 template <int G>
 __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) {
     constexpr int NC = 16 * G;
@@ -590,6 +625,9 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
     const int cb = a.item_tab[3 * blockIdx.x], J = a.item_tab[3 * blockIdx.x + 1], p = a.item_tab[3 * blockIdx.x + 2];
     const int k0 = J * a.kr, k1 = min(min(k0 + a.kr, (2 * cb + 2) * SR_ST_ROWS), a.Np);
     const int nsub = (k1 - k0 + SUB - 1) / SUB;
+    SR_LAB_STAMP(0);
+    SR_LAB_NOTE(4, nsub);
+    SR_LAB_NOTE(5, __smid());
     if (k0 >= a.Np) {
         // an EMPTY run (the chunk beyond Np of an odd padded size) reports zeros and is gone.  (Not a branch around the
         // prologue below: with one, the G = 2 kernel went from 112 VGPRs to 128 + 76 B of scratch, T = 32 at N = 5000 75 ->
@@ -632,7 +670,7 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
     // rows in front of k_lo meet K* == 0.  (A per-wavefront range -- skipping the batches below the diagonal -- made the
     // compiler wait for every single load: 116 against 71 us at N = 5000, T = 16.  What it would save is half of the
     // two diagonal chunks of a column block: 5 % of the MFMAs at N = 5000.)
-    const double* w = a.Wt + (long)d * a.Np * a.Np + (long)(k0 + lk) * a.Np + i0 + ln;
+    const double* w = a.Wt + (long)d * a.Np * a.Np + (long)(k0 + lk) * a.Np + i0 + sr_st_strip_col(ln, a.epi);
     d4_t acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = d4_t{0.0, 0.0, 0.0, 0.0};
@@ -643,6 +681,7 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
     for (int q = 0; q < UB; ++q) A0[q] = w[(long)(4 * q) * a.Np];
     ks_put(0, pf);
     __syncthreads();
+    SR_LAB_STAMP(1);
     // One stage = 2 UB k-steps of 4 rows: A-fragment of the step (A0: first half, A1: second half, each requested half a
     // stage ahead, ONE load per step), G B-fragments out of the LDS stage, G MFMAs.  The B-fragments run PD steps ahead of
     // their MFMAs in a ring of registers: read, wait, multiply in turn -- as the compiler arranges it -- ties every pair of
@@ -684,13 +723,15 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
         if (more) ks_put((sub + 1) & 1, pf);                  // (that buffer was last read in stage sub - 1)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    // acc[g][r] = V[column i0 + lk + 4r][query 16 g + ln]; strips beyond the matrix (last column block) report zeros
+    // acc[g][r] = V[column i0 + 4 lk + r][query 16 g + ln] (sr_st_store_partial); strips beyond the matrix (last column block) report zeros
+    SR_LAB_STAMP(2);
     const bool live = cb * SR_ST_COLS + 16 * wave < a.Np;
     double* out = a.Vp + (((long)d * gridDim.x + p) * (NC * gridDim.z) + c0) * SR_ST_COLS;
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(long)(16 * g + ln) * SR_ST_COLS + 16 * wave + lk + 4 * r] = live ? acc[g][r] : 0.0;
+    sr_st_store_partial<G>(out, acc, wave, lk, ln, live, a.epi);
+#ifdef SR_LAB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SR_LAB_STAMP(3);
+#endif
 }
 
 // Reduction + final stage of the MFMA kernel's partial results, ONE workgroup of 512 threads per (column t, output d) and
@@ -944,6 +985,8 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
     SR_CHECK(a.ncols >= 1 && a.ncols <= 128, SR_EINVAL, "stream: %d columns", a.ncols);
     static const int probe_env = (int)sr_lab_env("SR_ST1_PROBE", 0);      // (lab build: scripts/t1_probe.py)
     a.probe = probe_env;
+    static const int epi_env = (int)sr_lab_env("SR_ST_EPI", 1);           // (lab build: A/B of the partial-product stores)
+    a.epi = epi_env;
     dim3 grid(a.npairs, a.n_out);
     if (nc <= 4) {
         SR_CHECK(src == 0 || (a.D <= 5 && (src == 1 || a.D + 1 <= 4)), SR_EINVAL, "stream: src %d with D = %d", src, a.D);
