@@ -273,7 +273,7 @@ int sr_launch_gemm_tn_upper(const double* A, long lda, const double* B, long ldb
 template <class TL>
 __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_jobs_kernel(
     const double* __restrict__ Ab, const double* __restrict__ Bb, double* Cb, double* CTb, long ld,
-    const sr_gemm_job* __restrict__ jobs, double alpha, int mode, int njobs, sr_batch bt) {
+    const sr_gemm_job* __restrict__ jobs, double alpha, int mode, int njobs, int stf, int sts, sr_batch bt) {
     __shared__ double smem[TL::SMEM];
     const int bz = (int)blockIdx.z / njobs;               // batch member, job
     const sr_gemm_job jb = jobs[(int)blockIdx.z - bz * njobs];
@@ -282,8 +282,26 @@ __global__ __launch_bounds__(256, TL::WPS) void sr_gemm_tn_jobs_kernel(
     const int tm = jb.M / TL::T;
     // heavy tiles first, so that the tail of the grid consists of the SHORT k ranges: the slow grid index (y) walks
     // the dimension that sets the k range -- mode 2: n ascending (k starts at n0), mode 3: m descending (k ends at m0 + T)
-    const int mt = (mode == 2) ? (int)blockIdx.x : tm - 1 - (int)blockIdx.y;
-    const int nt = (mode == 2) ? (int)blockIdx.y : (int)blockIdx.x;
+    int mt, nt;
+    if (stf == 0) {
+        mt = (mode == 2) ? (int)blockIdx.x : tm - 1 - (int)blockIdx.y;
+        nt = (mode == 2) ? (int)blockIdx.y : (int)blockIdx.x;
+    } else {
+        // XCD-aware super-tiles (grids many times the chip; linear grid.x, a multiple of 8 x 64), as in
+        // sr_gemm_tn_upper_kernel: workgroup b runs on XCD b % 8, which takes the super-tiles s = x, x + 8, .. of 8 x 8 tiles,
+        // 64 consecutive workgroups of its own sequence each -- the 64 its 32 CUs hold at a time share 8 operand rows of A
+        // and 8 of B and start at (nearly) the same k.  Super-tiles in the order of the plain grid: `stf` of them along the
+        // fast dimension, `sts` along the one that sets the k range (heavy first).
+        const long b = blockIdx.x;
+        const int xcd = (int)(b & 7);
+        const long l = b >> 3;
+        const long st = (l >> 6) * 8 + xcd;
+        const int w = (int)(l & 63);
+        const int ss = (int)(st / stf), sf = (int)(st - (long)ss * stf);
+        if (ss >= sts) return;
+        if (mode == 2) { mt = sf * 8 + (w & 7); nt = ss * 8 + (w >> 3); }
+        else           { mt = tm - 1 - (ss * 8 + (w >> 3)); nt = sf * 8 + (w & 7); }
+    }
     if (nt * TL::T >= jb.N || mt >= tm || mt < 0) return;
     const int m0 = mt * TL::T;
     const int n0 = nt * TL::T;
@@ -337,13 +355,27 @@ int sr_launch_gemm_tn_jobs(const double* Ab, const double* Bb, double* Cb, doubl
     SR_CHECK(njobs > 0 && (long)njobs * bt.n <= 65535 && maxM % srt::BM == 0 && maxN % srt::BN == 0 && (mode == 2 || mode == 3),
              SR_EINVAL, "gemm_tn_jobs: njobs=%d maxM=%d maxN=%d mode=%d", njobs, maxM, maxN, mode);
     const int T = sr_use_tile64_jobs(tiles128 * bt.n) ? 64 : 128;
-    const dim3 grid = (mode == 2) ? dim3(maxM / T, maxN / T, njobs * bt.n) : dim3(maxN / T, maxM / T, njobs * bt.n);
+    dim3 grid = (mode == 2) ? dim3(maxM / T, maxN / T, njobs * bt.n) : dim3(maxN / T, maxM / T, njobs * bt.n);
+    // super-tiles pay once a job's grid is MANY times the chip -- the root of a big inversion (N = 50000: 195 x 196 tiles,
+    // the whole update 2.507 -> 2.469 s on one box, 2.478 -> 2.429 on another); the order of the plain grid otherwise: a
+    // workgroup goes to XCD b % 8, an XCD takes whole super-tiles, and with few of them per XCD the shares differ -- from 8192
+    // tiles on (the second level at N = 50000, 98 x 98, the root at N = 30000) 2.469 -> 2.482 s and 557 -> 561 ms, from 4096
+    // N = 20000 (root 78 x 79) 173.3 -> 176.8 ms, from 1024 N = 10000 23.7 -> 26.3 ms (profiles/r06_jobs_supertiles.txt)
+    static const long st_thr = sr_lab_env("SR_JOBS_ST_THR", 16384);      // (lab build: A/B)
+    int stf = 0, sts = 0;
+    if (T == 128 && (long)grid.x * grid.y >= st_thr) {
+        stf = ((int)grid.x + 7) / 8; sts = ((int)grid.y + 7) / 8;
+        const long nst = (long)stf * sts;
+        const long blocks = ((nst + 7) / 8) * 8 * 64;
+        SR_CHECK(blocks < 2147483647L, SR_EINVAL, "gemm_tn_jobs: grid too large");
+        grid = dim3((unsigned)blocks, 1, njobs * bt.n);
+    }
     if (T == 64)
         hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile64>, grid, dim3(256), 0, s, Ab, Bb, Cb, CTb, ld, jobs_dev, alpha,
-                           mode, njobs, bt);
+                           mode, njobs, stf, sts, bt);
     else
         hipLaunchKernelGGL(sr_gemm_tn_jobs_kernel<sr_tile128>, grid, dim3(256), 0, s, Ab, Bb, Cb, CTb, ld, jobs_dev,
-                           alpha, mode, njobs, bt);
+                           alpha, mode, njobs, stf, sts, bt);
     SR_HIP(hipGetLastError());
     return SR_OK;
 }
