@@ -100,8 +100,8 @@ static int stream_items(sr_gp* h, sr_stream_args& a, int ncols, int width_min, b
             h->ncu = cus;
         }
         std::vector<int> tab;
-        int n = 0;
-        const int kr = sr_stream_items(h->Np, h->n_out, nc, h->ncu, can_fuse, tab, &n);
+        int n = 0, nwg = 0;
+        const int kr = sr_stream_items(h->Np, h->n_out, nc, h->ncu, can_fuse, tab, &n, &nwg);
         if (kr > 0) {
             if ((long)tab.size() > h->stream_tab_cap) {
                 (void)hipStreamSynchronize(s);
@@ -113,9 +113,9 @@ static int stream_items(sr_gp* h, sr_stream_args& a, int ncols, int width_min, b
             SR_HIP(hipStreamSynchronize(s));                      // (a launch that still reads the old table)
             SR_HIP(hipMemcpy(h->stream_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
         }
-        h->stream_tab_key = key; h->stream_tab_kr = kr; h->stream_tab_n = n;
+        h->stream_tab_key = key; h->stream_tab_kr = kr; h->stream_tab_n = n; h->stream_tab_nwg = nwg;
     }
-    a.item_tab = h->stream_tab; a.kr = h->stream_tab_kr; a.nitems = h->stream_tab_n;
+    a.item_tab = h->stream_tab; a.kr = h->stream_tab_kr; a.nitems = h->stream_tab_n; a.nwg = h->stream_tab_nwg;
     return SR_OK;
 }
 

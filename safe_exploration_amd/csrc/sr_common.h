@@ -514,7 +514,8 @@ struct sr_stream_args {
     // [d][cb] column-block norms, then [j][d][1 + D] the N-split partial sums of mean and mean-Jacobian; NULL = tickets
     double* slots = nullptr;
     // work items of the run kernel (sr_stream_items): device table [column block, run, slot] x nitems, rows per run
-    const int* item_tab = nullptr; int kr = 0, nitems = 0;
+    // followed by the workgroups' first entries (nwg + 1): a workgroup runs entries [first[w], first[w + 1])
+    const int* item_tab = nullptr; int kr = 0, nitems = 0, nwg = 0;
     int epi = 1;                     // partial products of the MFMA kernels: 1 one 32-byte run per lane; lab build: 0 8-byte pieces (round 5), 2 non-temporal
 };
 #define SR_ST1_SLOTS_MAX 1536        /* doubles of LDS the finaliser gathers the slots in */
@@ -528,7 +529,7 @@ int sr_stream_width(int ncols);
 void sr_stream_plan(int Np, int n_out, int nc, int* g, int* kc, bool can_fuse = false);
 #ifdef __cplusplus
 #include <vector>
-int sr_stream_items(int Np, int n_out, int nc, int n_cu, bool can_fuse, std::vector<int>& tab, int* nitems);   // rows per run (0: no run kernel)
+int sr_stream_items(int Np, int n_out, int nc, int n_cu, bool can_fuse, std::vector<int>& tab, int* nitems, int* nwg);   // rows per run (0: no run kernel)
 #endif
 int sr_launch_stream(sr_stream_args a, int src, hipStream_t s);
 int sr_launch_linearize(const sr_lin_args& a, hipStream_t s);

@@ -63,7 +63,7 @@ struct sr_gp {
     size_t lin_cap = 0;                                                 // doubles behind lin_v
     double* stream_vp = nullptr; long stream_vp_cap = 0;   // fused small-batch path: partial sums (grow-only)
     unsigned* stream_tickets = nullptr;
-    int* stream_tab = nullptr; long stream_tab_cap = 0; long stream_tab_key = -1; int stream_tab_kr = 0, stream_tab_n = 0;   // work items of the run kernel
+    int* stream_tab = nullptr; long stream_tab_cap = 0; long stream_tab_key = -1; int stream_tab_kr = 0, stream_tab_n = 0, stream_tab_nwg = 0;   // work items of the run kernel (+ workgroups they are dealt to)
     double* stream_slots = nullptr; long stream_slots_cap = 0;    // self-validating hand-over slots of the T = 1 kernel's polling finaliser
     double* splitk_vt = nullptr; long splitk_cap = 0;   // partial products of the balanced few-query-tile route (grow-only)
     // log det(K + noise) per output as of the last <= 16-row append (read back with its status words): the blocking read of

@@ -611,7 +611,7 @@ extern "C" int sr_lab_stream_trace(unsigned long long* out, int n) {
 #define SR_LAB_STAMP(i_) do {} while (0)
 #define SR_LAB_NOTE(i_, v_) do {} while (0)
 #endif
-template <int G>
+template <int G, bool MULTI = false>
 __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) {
     constexpr int NC = 16 * G;
     constexpr int LDK = (G == 1) ? 16 : NC + 16;
@@ -622,7 +622,19 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
     static_assert(BPS == 2 && BPS * UB * 4 == SUB && PF * 1024 == SUB * NC, "stage geometry");
     __shared__ double ks[2][SUB * LDK];
     const int d = blockIdx.y;
-    const int cb = a.item_tab[3 * blockIdx.x], J = a.item_tab[3 * blockIdx.x + 1], p = a.item_tab[3 * blockIdx.x + 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane >> 4, ln = lane & 15;
+    const int c0 = blockIdx.z * NC;                      // first column of this workgroup (grid.z: column blocks)
+    // The workgroup's work items, one after the other (round 6, second half: a launch with a few more items than CUs -- N = 5000,
+    // T = 64: 258 runs of <= 7 stages -- gives two short ones to the same workgroup instead of taking longer runs: sr_stream_items)
+    // (MULTI is a variant of its own: with the loop the compiler keeps the strips' addresses in registers across the items --
+    //  98 -> 122 VGPRs at G = 4, spills at G = 2 and G = 8 -- so the one-item form stays exactly the kernel it was)
+    const int* wg_tab = a.item_tab + 3 * a.nitems;
+    const int it0 = MULTI ? wg_tab[blockIdx.x] : (int)blockIdx.x, it1 = MULTI ? wg_tab[blockIdx.x + 1] : (int)blockIdx.x + 1;
+#pragma unroll 1
+    for (int it = it0; it < it1; ++it) {
+    const int cb = a.item_tab[3 * it], J = a.item_tab[3 * it + 1], p = a.item_tab[3 * it + 2];
     const int k0 = J * a.kr, k1 = min(min(k0 + a.kr, (2 * cb + 2) * SR_ST_ROWS), a.Np);
     const int nsub = (k1 - k0 + SUB - 1) / SUB;
     SR_LAB_STAMP(0);
@@ -632,14 +644,10 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
         // an EMPTY run (the chunk beyond Np of an odd padded size) reports zeros and is gone.  (Not a branch around the
         // prologue below: with one, the G = 2 kernel went from 112 VGPRs to 128 + 76 B of scratch, T = 32 at N = 5000 75 ->
         // 101 us; a run that starts at row 0 instead cost the same registers.)
-        double* out = a.Vp + (((long)d * gridDim.x + p) * (NC * gridDim.z) + blockIdx.z * NC) * SR_ST_COLS;
+        double* out = a.Vp + (((long)d * a.nitems + p) * (NC * gridDim.z) + blockIdx.z * NC) * SR_ST_COLS;
         for (int e = threadIdx.x; e < NC * SR_ST_COLS; e += 1024) out[e] = 0.0;
-        return;
+        continue;
     }
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lk = lane >> 4, ln = lane & 15;
-    const int c0 = blockIdx.z * NC;                      // first column of this workgroup (grid.z: column blocks)
     const double* ksrc = a.Ks + (long)d * a.Np * a.Tp + (long)k0 * a.Tp + c0;
 
     // K* rows of stage `sub` that this thread moves (element e = tid + 1024 m: row e / NC, column e % NC)
@@ -726,12 +734,13 @@ __global__ __launch_bounds__(1024) void sr_stream_mfma_kernel(sr_stream_args a) 
     // acc[g][r] = V[column i0 + 4 lk + r][query 16 g + ln] (sr_st_store_partial); strips beyond the matrix (last column block) report zeros
     SR_LAB_STAMP(2);
     const bool live = cb * SR_ST_COLS + 16 * wave < a.Np;
-    double* out = a.Vp + (((long)d * gridDim.x + p) * (NC * gridDim.z) + c0) * SR_ST_COLS;
+    double* out = a.Vp + (((long)d * a.nitems + p) * (NC * gridDim.z) + c0) * SR_ST_COLS;
     sr_st_store_partial<G>(out, acc, wave, lk, ln, live, a.epi);
 #ifdef SR_LAB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SR_LAB_STAMP(3);
 #endif
+    }
 }
 
 // Reduction + final stage of the MFMA kernel's partial results, ONE workgroup of 512 threads per (column t, output d) and
@@ -911,69 +920,89 @@ void sr_stream_plan(int Np, int n_out, int nc, int* g_out, int* kc_out, bool can
 // the CU that is free first; a run costs its rows plus ~32 rows' worth of prologue and epilogue.  (Round 5 took runs of whole
 // chunks in column-block order, as long as >= 200 workgroups remained: N = 5000, T = 64: 220 workgroups of up to 512 rows =
 // 8 stages on the longest CU where 1680 stages over 256 CUs are 6.6.)
-int sr_stream_items(int Np, int n_out, int nc, int n_cu, bool can_fuse, std::vector<int>& tab, int* nitems_out) {
+int sr_stream_items(int Np, int n_out, int nc, int n_cu, bool can_fuse, std::vector<int>& tab, int* nitems_out, int* nwg_out) {
     int g, kc;
     sr_stream_plan(Np, n_out, nc, &g, &kc, can_fuse);
     tab.clear();
-    *nitems_out = 0;
+    *nitems_out = 0; *nwg_out = 0;
     if (kc <= 1) return 0;
     const int ncb = (Np + SR_ST_COLS - 1) / SR_ST_COLS;
     const int gz = nc / (16 * g);
     const int sub = (g <= 2) ? 128 : (g == 4 ? 64 : 32);          // rows per LDS stage (sr_stream_mfma_kernel)
     const int cus = n_cu > 0 ? n_cu : 256;
     static const int forced = (int)sr_lab_env("SR_ST_KR", 0);     // (lab build: rows per run, 0 = planned; -1 = round 5's runs)
-    auto build = [&](int kr, std::vector<int>& out) {             // entries sorted by length, longest first (stable)
-        std::vector<std::pair<int, int>> ord;                      // (rows, index)
-        std::vector<int> raw;
+    // several items per workgroup only with 64 columns per workgroup (g = 4: the MFMA-bound width; the narrower ones are bound by
+    // the stream and their kernels would spill with the loop over the items)
+    static const int no_pack_lab = (int)sr_lab_env("SR_ST_NO_PACK", 0);   // (lab build: 1 = one work item per workgroup everywhere)
+    const bool no_pack = no_pack_lab != 0 || g != 4;
+    struct item { int rows, cb, J, slot; };
+    auto build = [&](int kr) {                                    // items sorted by length, longest first (stable)
+        std::vector<item> v;
         int slot = 0;
         for (int cb = 0; cb < ncb; ++cb) {
             const int n = sr_st_items_rows(cb, kr), top = std::min((2 * cb + 2) * SR_ST_ROWS, Np);
-            for (int J = 0; J < n; ++J, ++slot) {
-                const int rows = std::max(0, std::min(J * kr + kr, top) - J * kr);
-                ord.push_back({rows, (int)raw.size() / 3});
-                raw.push_back(cb); raw.push_back(J); raw.push_back(slot);
-            }
+            for (int J = 0; J < n; ++J, ++slot) v.push_back({std::max(0, std::min(J * kr + kr, top) - J * kr), cb, J, slot});
         }
-        std::stable_sort(ord.begin(), ord.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
-        out.clear();
-        for (const auto& e : ord) { out.push_back(raw[3 * e.second]); out.push_back(raw[3 * e.second + 1]); out.push_back(raw[3 * e.second + 2]); }
-        return ord;
+        std::stable_sort(v.begin(), v.end(), [](const item& x, const item& y) { return x.rows > y.rows; });
+        return v;
     };
-    auto makespan = [&](const std::vector<std::pair<int, int>>& ord) {
-        std::vector<long> cu(cus, 0);
+    // The launch is ONE round: at most one workgroup per CU (a workgroup that has to wait for a CU measured far worse than its
+    // length says -- N = 5000, T = 64: 258 workgroups of <= 448 rows 112 us, 220 of <= 512 rows 102).  W workgroups per (output,
+    // column group); with more items than that, the items are dealt longest first to the workgroup that is shortest so far, and a
+    // workgroup runs its items one after the other.  An item costs its rows plus ~32 rows' worth of prologue and epilogue (96 behind
+    // another item).
+    const int W = std::max(1, cus / (n_out * gz));
+    auto pack = [&](const std::vector<item>& v, std::vector<std::vector<int>>& bins) {
+        const int nb = no_pack ? (int)v.size() : std::min((int)v.size(), W);
+        bins.assign(nb, {});
+        std::vector<long> load(nb, 0);
+        for (int i = 0; i < (int)v.size(); ++i) {
+            const int b = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            // (a further item of a workgroup costs more than the first: its prologue starts cold behind the stores of the item in
+            //  front.  With 32 rows for every item and ties going to the shortest runs the plan of N = 5400 was 125 workgroups of
+            //  two 4-stage items each -- 125 - 140 us against 113 with one 9-stage item: profiles/r06_stream_pack.txt)
+            load[b] += v[i].rows + (bins[b].empty() ? 32 : 96);
+            bins[b].push_back(i);
+        }
         long worst = 0;
-        for (int z = 0; z < gz * n_out; ++z)
-            for (const auto& e : ord) {
-                auto it = std::min_element(cu.begin(), cu.end());
-                *it += e.first + 32;
-                worst = std::max(worst, *it);
-            }
+        if (no_pack) {                                           // the old estimate: dealt in grid order to the CU that is free first
+            std::vector<long> cu(cus, 0);
+            for (int z = 0; z < gz * n_out; ++z)
+                for (const item& e : v) { auto it = std::min_element(cu.begin(), cu.end()); *it += e.rows + 32; worst = std::max(worst, *it); }
+            if ((long)v.size() * gz * n_out > cus) worst += 1000000;      // (more than one round: last resort)
+        } else
+            worst = *std::max_element(load.begin(), load.end());
         return worst;
     };
     int best_kr = kc * SR_ST_ROWS;
     if (forced > 0) best_kr = (forced + sub - 1) / sub * sub;
     else if (forced == 0) {
-        // ONE round where there is one (every workgroup resident from the start): a workgroup that has to wait for a CU measured
-        // far worse than its length says (N = 5000, T = 64: 258 workgroups of <= 448 rows 112 us, 220 of <= 512 rows 102)
-        long best = -1, best1 = -1;
-        int kr1 = 0;
+        long best = -1;
         for (int kr = std::max(SR_ST_ROWS, 2 * sub); kr <= 32 * SR_ST_ROWS; kr += sub) {
-            std::vector<int> t;
-            const auto ord = build(kr, t);
-            const long m = makespan(ord);
-            if (best < 0 || m < best) { best = m; best_kr = kr; }
-            if ((long)ord.size() * gz * n_out <= cus && (best1 < 0 || m < best1)) { best1 = m; kr1 = kr; }
+            std::vector<std::vector<int>> bins;
+            const long m = pack(build(kr), bins);
+            if (best < 0 || m < best || (!no_pack && m == best)) { best = m; best_kr = kr; }     // (ties: the longer runs when packing)
         }
-        if (kr1 > 0) best_kr = kr1;
     }
-    const auto ord = build(best_kr, tab);
-    if (forced < 0) {                                              // round 5: column-block order (no sorting)
-        tab.clear();
-        int slot = 0;
-        for (int cb = 0; cb < ncb; ++cb)
-            for (int J = 0; J < sr_st_items_rows(cb, best_kr); ++J, ++slot) { tab.push_back(cb); tab.push_back(J); tab.push_back(slot); }
+    const std::vector<item> v = build(best_kr);
+    std::vector<std::vector<int>> bins;
+    if (forced < 0) {                                              // round 5: column-block order (no sorting), one item each
+        bins.clear();
+        std::vector<int> order(v.size());
+        for (size_t i = 0; i < v.size(); ++i) order[v[i].slot] = (int)i;
+        for (size_t sidx = 0; sidx < v.size(); ++sidx) bins.push_back({order[sidx]});
+    } else
+        (void)pack(v, bins);
+    // table: [column block, run, slot] x items in workgroup order, then the workgroups' first entries (nwg + 1)
+    std::vector<int> first;
+    for (const auto& b : bins) {
+        first.push_back((int)tab.size() / 3);
+        for (int i : b) { tab.push_back(v[i].cb); tab.push_back(v[i].J); tab.push_back(v[i].slot); }
     }
-    *nitems_out = (int)ord.size();
+    first.push_back((int)tab.size() / 3);
+    tab.insert(tab.end(), first.begin(), first.end());
+    *nitems_out = (int)v.size();
+    *nwg_out = (int)bins.size();
     return best_kr;
 }
 
@@ -1025,13 +1054,17 @@ int sr_launch_stream(sr_stream_args a, int src, hipStream_t s) {
         SR_HIP(hipGetLastError());
         return SR_OK;
     }
-    SR_CHECK(a.item_tab != nullptr && a.kr >= SR_ST_ROWS && a.nitems > 0, SR_EINVAL, "stream: no work-item table (sr_stream_items)");
+    SR_CHECK(a.item_tab != nullptr && a.kr >= SR_ST_ROWS && a.nitems > 0 && a.nwg > 0 && a.nwg <= a.nitems &&
+             (a.nwg == a.nitems || g == 4), SR_EINVAL, "stream: no work-item table (sr_stream_items)");
     const int nitems = a.nitems;
-    grid.x = nitems;
+    grid.x = a.nwg;
     switch (g) {
         case 1: hipLaunchKernelGGL(sr_stream_mfma_kernel<1>, grid, dim3(1024), 0, s, a); break;
         case 2: hipLaunchKernelGGL(sr_stream_mfma_kernel<2>, grid, dim3(1024), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(sr_stream_mfma_kernel<4>, grid, dim3(1024), 0, s, a); break;
+        case 4:
+            if (a.nwg < nitems) hipLaunchKernelGGL((sr_stream_mfma_kernel<4, true>), grid, dim3(1024), 0, s, a);
+            else hipLaunchKernelGGL(sr_stream_mfma_kernel<4>, grid, dim3(1024), 0, s, a);
+            break;
         default: hipLaunchKernelGGL(sr_stream_mfma_kernel<8>, grid, dim3(1024), 0, s, a); break;
     }
     SR_HIP(hipGetLastError());
