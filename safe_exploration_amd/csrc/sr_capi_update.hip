@@ -165,6 +165,16 @@ static bool own_queues(hipStream_t a, hipStream_t b, hipStream_t c) {
     return ok;
 }
 
+static int ensure_fact_events(sr_gp* h) {
+    if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
+    for (int e = 0; e < 2; ++e) {
+        if (!h->ev_panel[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_panel[e], hipEventDisableTiming));
+        if (!h->ev_bulk[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_bulk[e], hipEventDisableTiming));
+        if (!h->ev_inv[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_inv[e], hipEventDisableTiming));
+    }
+    return SR_OK;
+}
+
 static int ensure_fact_streams(sr_gp* h, int regime) {
     if (h->ncu == 0) {
         int cus = 0;
@@ -228,12 +238,7 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
         h->fact_stream = set->fact; h->bulk_stream = set->bulk; h->inv_stream = set->inv;
         h->diag_stream = set->pipe_ok ? set->diag : nullptr; h->row_stream = set->pipe_ok ? set->row : nullptr;
     }
-    if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
-    for (int e = 0; e < 2; ++e) {
-        if (!h->ev_panel[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_panel[e], hipEventDisableTiming));
-        if (!h->ev_bulk[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_bulk[e], hipEventDisableTiming));
-        if (!h->ev_inv[e]) SR_HIP(hipEventCreateWithFlags(&h->ev_inv[e], hipEventDisableTiming));
-    }
+    SR_TRY(ensure_fact_events(h));
     h->fact_regime = key;
     return SR_OK;
 }
@@ -308,14 +313,20 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     const int regime = nb <= SR_FACT_CHAIN_MAX_NB ? 1 : 2;
     // One or two blocks (the reference's own model sizes): a handful of kernels with nothing to run beside each other, on the
     // caller's stream -- the hand-over to the critical stream and back cost 25 of the 85 us of such an update.
-    const bool own_streams = !(nb <= 2 && P >= nb);       // (one panel: no trailing update, none of the events below is touched)
+    static const int all_on_caller_nb = (int)sr_lab_env("SR_FACT_ALL_ON_CALLER", 0);      // (lab build: A/B)
+    const bool own_streams = !(nb <= 2 && P >= nb) && !(nb <= all_on_caller_nb && !h->fact_pipe);       // (one panel: no trailing update, none of the events below is touched)
+
     hipStream_t sc = s0, sb = s0, si = nullptr;
+    // (lab build: up to this many blocks the chain stays on the CALLER's stream -- no fork to a priority stream and no join back,
+    //  ~25 + 12 us of event hand-overs per update; the trailing updates and the inversion's stage keep their side streams)
+    static const int chain_on_caller_nb = (int)sr_lab_env("SR_FACT_CHAIN_ON_CALLER", 0);
+    const bool chain_on_caller = own_streams && nb <= chain_on_caller_nb && !h->fact_pipe;
     if (own_streams) {
         if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
-        SR_FH(hipEventRecord(h->fact_fork, s0));
+        if (!chain_on_caller) SR_FH(hipEventRecord(h->fact_fork, s0));
         SR_F(ensure_fact_streams(h, regime));
-        sc = h->fact_stream; sb = h->bulk_stream; si = h->inv_stream;
-        SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));
+        sc = chain_on_caller ? s0 : h->fact_stream; sb = h->bulk_stream; si = h->inv_stream;
+        if (!chain_on_caller) SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));
     }
     lap("streams");
     static const bool no_early_inv = sr_lab_on("SR_FACT_NO_EARLY_INV");
@@ -606,9 +617,10 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             // together, its workgroups fill the CUs first and the look-ahead (on the critical path) takes 60 - 70 us
             // instead of 20; regime 2: when the panel's rows are final
             const bool bulk_after_la = (regime == 1);
-            if (bulk > 0 && !bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
+            const bool side = sb != sc;                   // (everything on one stream: no events)
+            if (bulk > 0 && !bulk_after_la && side) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
             // the previous bulk update wrote the look-ahead rows too: it has to be through
-            if (n_bulk > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
+            if (n_bulk > 0 && side) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
             {
                 sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
                 SR_F(sr_launch_gemm_tn_upper(Upan, Np, Upan, Np, Cnext, Np, la, rest, Kp, -1.0, 1.0, sc, 1, -1, &b_ppp));
@@ -626,8 +638,8 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                     static const double free_ratio = sr_lab_envf("SR_FACT_FREE_RATIO", SR_FACT_FREE_RATIO);
                     if (free_ratio > 0.0 && t_bulk > free_ratio * t_chain) sbp = si;
                 }
-                if (bulk_after_la) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
-                SR_FH(hipStreamWaitEvent(sbp, h->ev_panel[pi & 1], 0));
+                if (bulk_after_la && side) SR_FH(hipEventRecord(h->ev_panel[pi & 1], sc));
+                if (side) SR_FH(hipStreamWaitEvent(sbp, h->ev_panel[pi & 1], 0));
                 // (two bulk streams: the previous trailing update may have run on the other one)
                 if (regime == 2 && n_bulk > 0) SR_FH(hipStreamWaitEvent(sbp, h->ev_bulk[(n_bulk - 1) & 1], 0));
                 {
@@ -635,11 +647,11 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
                     SR_F(sr_launch_gemm_tn_upper(Upan + la, Np, Upan + la, Np, Cnext + (size_t)la * Np + la, Np,
                                                  bulk, bulk, Kp, -1.0, 1.0, sbp, 0, -1, &b_ppp));
                 }
-                SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sbp));
+                if (side) SR_FH(hipEventRecord(h->ev_bulk[n_bulk & 1], sbp));
                 ++n_bulk;
             }
         }
-        if (n_bulk > 0) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
+        if (n_bulk > 0 && sb != sc) SR_FH(hipStreamWaitEvent(sc, h->ev_bulk[(n_bulk - 1) & 1], 0));
         // --- W = U^-T (lower) and Wt = U^-1 (upper) by recursive halving of the block range, level by level
         // (ensure_inv_jobs).  The diagonal blocks of W / Wt were written by sr_potrf_diag_kernel.
         if (early_done) SR_FH(hipStreamWaitEvent(sc, h->ev_inv[1], 0));
@@ -648,7 +660,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d0 * Np, W + NN, Np, 1, sc, nd, sP, Np, sP));
         SR_F(sr_launch_trmv(Wt, Np, W + NN, h->alpha + (size_t)d0 * Np, Np, 0, sc, nd, sN, sP, Np));
     }
-    if (own_streams) {
+    if (own_streams && !chain_on_caller) {
         SR_FH(hipEventRecord(h->fact_join, sc));
         SR_FH(hipStreamWaitEvent(s0, h->fact_join, 0));
     }

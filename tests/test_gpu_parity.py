@@ -609,6 +609,32 @@ def test_small_batch_streaming_path_matches_mfma_path(N, T):
     np.testing.assert_allclose(var_s, rvar, rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("N,T,n_s", [(4200, 64, 2), (5000, 48, 2), (5800, 33, 2), (3000, 64, 3), (6500, 64, 3)])
+def test_streamed_runs_dealt_to_one_workgroup_per_cu(N, T, n_s):
+    """33 .. 64 queries beyond 512 rows: the streamed MFMA kernel's work items are runs of U^-1 rows; when a launch has more
+    runs than CUs (N = 5000, two outputs: 258 runs of <= 7 LDS stages) a workgroup takes several, one after the other
+    (sr_stream_mfma_kernel<4, true>, planned by sr_stream_items).  Same partial results in the same slots as with one run per
+    workgroup: the posterior must agree with the plain MFMA tiles (validated against the oracle at these sizes elsewhere) and
+    repeat bit for bit."""
+    syn = orc.make_synthetic(7 * N + T, N, n_s, 1, T)
+    gp = hip_model(syn["Z"], syn["Y"], syn["lengthscale"], syn["signal_var"], syn["noise_var"], n_s, 1)
+    x = np.hstack((syn["p"], syn["k_ff"]))
+    gp.set_small_path(True)
+    mu_s, var_s = gp.predict(x)
+    mu_2, var_2 = gp.predict(x)
+    np.testing.assert_array_equal(mu_s, mu_2)
+    np.testing.assert_array_equal(var_s, var_2)
+    mu_h, var_h = gp.predict(x[: T // 2 + 1])                 # another width class, other runs: same numbers to rounding
+    gp.set_small_path(False)
+    mu_m, var_m = gp.predict(x)
+    # (the two routes split the sums over the training points differently: SURVEY 8(d)'s 1e-12 sigma_f |alpha|_1)
+    scale = float(np.sqrt(np.max(syn["signal_var"])) * np.abs(gp.beta).sum(0).max())
+    np.testing.assert_allclose(mu_s, mu_m, rtol=1e-11, atol=1e-12 * scale)
+    np.testing.assert_allclose(var_s, var_m, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(var_h, var_m[: T // 2 + 1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mu_h, mu_m[: T // 2 + 1], rtol=1e-11, atol=1e-12 * scale)
+
+
 @pytest.mark.parametrize("N,T", [(1300, 17), (1300, 300), (2500, 129), (2000, 500), (3100, 1000), (1900, 257), (4100, 130),
                                  (600, 700), (300, 1100), (450, 1400), (512, 2600)])
 def test_splitk_path_matches_plain_path(N, T):
