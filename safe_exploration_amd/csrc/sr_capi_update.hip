@@ -313,20 +313,23 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     const int regime = nb <= SR_FACT_CHAIN_MAX_NB ? 1 : 2;
     // One or two blocks (the reference's own model sizes): a handful of kernels with nothing to run beside each other, on the
     // caller's stream -- the hand-over to the critical stream and back cost 25 of the 85 us of such an update.
-    static const int all_on_caller_nb = (int)sr_lab_env("SR_FACT_ALL_ON_CALLER", 0);      // (lab build: A/B)
-    const bool own_streams = !(nb <= 2 && P >= nb) && !(nb <= all_on_caller_nb && !h->fact_pipe);       // (one panel: no trailing update, none of the events below is touched)
+    // Up to SR_FACT_ONE_STREAM_MAX_NB (15) blocks the WHOLE update stays on the caller's stream (round 6): no fork to the priority
+    // stream and no join back (~25 + 12 us of event hand-overs), no side streams for the trailing updates and the inversion's
+    // stages, no events -- at these sizes running them beside the chain hides less than the hand-overs cost: N = 300 0.28 -> 0.24 ms,
+    // 600 0.43 -> 0.36, 1000 0.59 -> 0.53, 1500 0.85 -> 0.80, 1800 1.07 -> 1.04; level at 16 blocks, 6 % slower at 20
+    // (profiles/r06_small_update_streams.txt).  (Only the chain on the caller's stream and the rest beside it: slower from 5
+    // blocks on -- the CU-masked side streams synchronise with a caller that is the device's null stream.)
+    static const int one_stream_lab = (int)sr_lab_env("SR_FACT_ALL_ON_CALLER", -1);      // (lab build: A/B)
+    const int one_stream_nb = one_stream_lab >= 0 ? one_stream_lab : SR_FACT_ONE_STREAM_MAX_NB;
+    const bool own_streams = !(nb <= 2 && P >= nb) && !(nb <= one_stream_nb && h->fact_pipe <= 0);
 
     hipStream_t sc = s0, sb = s0, si = nullptr;
-    // (lab build: up to this many blocks the chain stays on the CALLER's stream -- no fork to a priority stream and no join back,
-    //  ~25 + 12 us of event hand-overs per update; the trailing updates and the inversion's stage keep their side streams)
-    static const int chain_on_caller_nb = (int)sr_lab_env("SR_FACT_CHAIN_ON_CALLER", 0);
-    const bool chain_on_caller = own_streams && nb <= chain_on_caller_nb && !h->fact_pipe;
     if (own_streams) {
         if (!h->fact_fork) SR_FH(hipEventCreateWithFlags(&h->fact_fork, hipEventDisableTiming));
-        if (!chain_on_caller) SR_FH(hipEventRecord(h->fact_fork, s0));
+        SR_FH(hipEventRecord(h->fact_fork, s0));
         SR_F(ensure_fact_streams(h, regime));
-        sc = chain_on_caller ? s0 : h->fact_stream; sb = h->bulk_stream; si = h->inv_stream;
-        if (!chain_on_caller) SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));
+        sc = h->fact_stream; sb = h->bulk_stream; si = h->inv_stream;
+        SR_FH(hipStreamWaitEvent(sc, h->fact_fork, 0));
     }
     lap("streams");
     static const bool no_early_inv = sr_lab_on("SR_FACT_NO_EARLY_INV");
@@ -660,7 +663,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         SR_F(sr_launch_trmv(W, Np, h->yT + (size_t)d0 * Np, W + NN, Np, 1, sc, nd, sP, Np, sP));
         SR_F(sr_launch_trmv(Wt, Np, W + NN, h->alpha + (size_t)d0 * Np, Np, 0, sc, nd, sN, sP, Np));
     }
-    if (own_streams && !chain_on_caller) {
+    if (own_streams) {
         SR_FH(hipEventRecord(h->fact_join, sc));
         SR_FH(hipStreamWaitEvent(s0, h->fact_join, 0));
     }

@@ -336,6 +336,7 @@ int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* pa
 //                                            rollouts 203 against 253 us, 4096 in six launches 608 / 722, r03_chain_bench); one-step
 //                                            through it for n_s <= 2 (24.5 -> 21.5 us; n_s >= 3: 25 -> 35 us)
 //  model update (sr_capi_update.hip)         panels of sr_fact_panel(nb) blocks (r03_factor_bench and the comment there); streams:
+//                                            up to SR_FACT_ONE_STREAM_MAX_NB (15) blocks the caller's stream only (r06_small_update_streams),
 //                                            regime 1 up to SR_FACT_CHAIN_MAX_NB (128) blocks -- bulk stream without 32 CUs (64 for
 //                                            36 < nb <= 52: N = 5000 5.14 -> 4.99 ms) --, regime 2 beyond (8 CUs for the diagonal
 //                                            blocks; a trailing update SR_FACT_FREE_RATIO (2) times longer than the next chain takes
@@ -350,6 +351,7 @@ int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* pa
 #define SR_STREAM_FUSED_MAX_D 5      /* one-launch streamed predict (T <= 4) evaluates its own K* columns up to this D */
 #define SR_LIN_FUSED_MAX_D 3         /* one-launch streamed linearize up to this D */
 #define SR_FACT_CHAIN_MAX_NB 128     /* model update: up to here the chain of diagonal blocks bounds it (stream regime 1) */
+#define SR_FACT_ONE_STREAM_MAX_NB 15 /* model update: up to here every launch stays on the caller's stream (no side streams, no events) */
 #define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch of one workgroup per output up to this padded size (the grown model: <= 640) */
 #define SR_APPEND1G_MAX_NP0 8192     /* +1 point in ONE launch of a grid of workgroups up to this padded size (K* row in LDS) */
 #define SR_APPEND1G_MAX_W 128        /* workgroups per output of that grid */
