@@ -2,11 +2,14 @@
 // updates -> explicit U^-1 -> alpha), its stream set, and the diagnostics that read the factor (marginal likelihood,
 // log determinant, explicit K^-1, GEMM / diagonal-block test hooks).
 #include "sr_handle.h"
+#include "sr_flow.h"
 using namespace srh;
 
 // set when a hand-over of the pipelined chain ran into its time-out once (a foreign stream of the chain's priority on one of
 // its hardware queues): the process stays on the plain chain from then on
 static std::atomic<bool> g_pipe_broken{false};
+// ... or a wait of the tile-flow Cholesky did (its diagonal-block workgroups not resident, or on the workers' hardware queue)
+static std::atomic<bool> g_flow_broken{false};
 
 // ---------------------------------------------------------------------------------------------
 // factorisation: K = U^T U (right-looking, 128-blocks in panels, look-ahead), U^-T / U^-1 by recursive halving
@@ -165,6 +168,41 @@ static bool own_queues(hipStream_t a, hipStream_t b, hipStream_t c) {
     return ok;
 }
 
+// Stream of the resident diagonal-block workgroups of the tile-flow Cholesky: one per device for the life of the process,
+// non-blocking (the caller's stream may be the null stream) and of the lowest priority (another pool of hardware queues than
+// the update's priority stream).  Its kernel WAITS for the workers on the device, so the two must not share a hardware queue:
+// checked once per (device, worker stream) with a pair of hand-overs in either order.
+struct sr_flow_stream { hipStream_t srv = nullptr; hipStream_t checked_with = nullptr; bool checked = false, ok = false; };
+static sr_flow_stream g_flow_streams[64];
+static int flow_server_stream(int device, hipStream_t worker, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_stream_mutex);
+    SR_CHECK(device >= 0 && device < 64, SR_EINVAL, "device index %d", device);
+    sr_flow_stream& f = g_flow_streams[device];
+    if (!f.srv) {
+        int prio_lo = 0, prio_hi = 0;
+        SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        SR_HIP(hipStreamCreateWithPriority(&f.srv, hipStreamNonBlocking, prio_lo));
+    }
+    if (!f.checked || f.checked_with != worker) {
+        unsigned* w = nullptr;
+        bool ok = hipMalloc((void**)&w, 8 * sizeof(unsigned)) == hipSuccess && hipMemset(w, 0, 8 * sizeof(unsigned)) == hipSuccess;
+        hipStream_t st[2] = {f.srv, worker};
+        for (int i = 0; i < 2 && ok; ++i) {
+            const unsigned v = (unsigned)(i + 1);
+            ok = sr_launch_fact_handover(nullptr, 0, w + 1, v, nullptr, 0, w, 3e-3, st[i]) == SR_OK &&
+                 sr_launch_fact_handover(w + 1, v, nullptr, 0, nullptr, 0, w, 3e-3, st[1 - i]) == SR_OK &&
+                 hipStreamSynchronize(st[i]) == hipSuccess && hipStreamSynchronize(st[1 - i]) == hipSuccess;
+        }
+        unsigned status = 1;
+        if (ok) ok = hipMemcpy(&status, w, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && status == 0;
+        if (w) (void)hipFree(w);
+        (void)hipGetLastError();
+        f.checked = true; f.checked_with = worker; f.ok = ok;
+    }
+    *out = f.ok ? f.srv : nullptr;
+    return SR_OK;
+}
+
 static int ensure_fact_events(sr_gp* h) {
     if (!h->fact_join) SR_HIP(hipEventCreateWithFlags(&h->fact_join, hipEventDisableTiming));
     for (int e = 0; e < 2; ++e) {
@@ -192,7 +230,7 @@ static int ensure_fact_streams(sr_gp* h, int regime) {
     const int nblk = h->Np / SR_NB;
     static const int reserve_lab = (int)sr_lab_env("SR_FACT_RESERVE", 0);       // (lab build: CUs the bulk streams leave free)
     const int reserve = reserve_lab > 0 ? reserve_lab : sr_fact_reserved_cus(regime, nblk);
-    const bool want_pipe = regime == 1 && h->fact_pipe != 0;      // (the prototype's two extra streams only where it is asked for)
+    const bool want_pipe = regime == 1 && (h->fact_pipe == 1 || h->fact_pipe == 2);      // (the prototype's two extra streams only where it is asked for)
     const int key = regime * 1000 + reserve + (want_pipe ? 500 : 0);
     {
         std::lock_guard<std::mutex> lk(g_stream_mutex);
@@ -280,9 +318,10 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     double* scratch = nullptr;                           // owned here only when it is not kept in the handle
     int rc = SR_OK;
     hipStream_t s0 = (hipStream_t)stream;
+    hipStream_t srv = nullptr;                           // tile flow: the stream of the resident diagonal-block workgroups
     auto cleanup = [&]() {
         // never return with work in flight on the side streams
-        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream, h->diag_stream, h->row_stream}) if (st) (void)hipStreamSynchronize(st);
+        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream, h->diag_stream, h->row_stream, srv}) if (st) (void)hipStreamSynchronize(st);
         release_fact_streams(h);
         dev_free(scratch);
     };
@@ -321,7 +360,17 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     // blocks on -- the CU-masked side streams synchronise with a caller that is the device's null stream.)
     static const int one_stream_lab = (int)sr_lab_env("SR_FACT_ALL_ON_CALLER", -1);      // (lab build: A/B)
     const int one_stream_nb = one_stream_lab >= 0 ? one_stream_lab : SR_FACT_ONE_STREAM_MAX_NB;
-    const bool own_streams = !(nb <= 2 && P >= nb) && !(nb <= one_stream_nb && h->fact_pipe <= 0);
+    // Tile flow (round 6; sr_flow.hip): the whole Cholesky as ONE resident kernel of GEMM workgroups on the caller's stream plus
+    // one resident diagonal-block workgroup per output on a stream of its own; the inversion behind it, on the caller's stream.
+    // One batch of outputs only (the counters are zeroed once per update).
+    static const int flow_lab = (int)sr_lab_env("SR_FACT_FLOW", -1);                     // (lab build: 1 = wherever it can run)
+    const bool want_flow = h->fact_pipe == 3 || (h->fact_pipe == 0 && (flow_lab == 1 || (nb >= SR_FLOW_MIN_NB && nb <= SR_FLOW_MAX_NB)));
+    bool flow = want_flow && regime == 1 && nb >= 3 && n_par >= h->n_out && !g_flow_broken.load();
+    if (flow) {
+        SR_F(flow_server_stream(h->device, s0, &srv));
+        if (!srv) flow = false;
+    }
+    const bool own_streams = !flow && !(nb <= 2 && P >= nb) && !(nb <= one_stream_nb && h->fact_pipe <= 0);
 
     hipStream_t sc = s0, sb = s0, si = nullptr;
     if (own_streams) {
@@ -334,7 +383,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     lap("streams");
     static const bool no_early_inv = sr_lab_on("SR_FACT_NO_EARLY_INV");
     // Pipelined chain (round 6; chain-bound sizes): see the block behind `if (pipe)` below.
-    const bool pipe = own_streams && regime == 1 && h->fact_pipe && !g_pipe_broken.load() && h->diag_stream && h->row_stream &&
+    const bool pipe = own_streams && regime == 1 && (h->fact_pipe == 1 || h->fact_pipe == 2) && !g_pipe_broken.load() && h->diag_stream && h->row_stream &&
                       nb >= 3;
     const bool two = h->fact_pipe == 2;
     hipStream_t sd = nullptr, sr = nullptr;
@@ -353,7 +402,22 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         if (!two) SR_FH(hipStreamWaitEvent(sd, h->fact_fork, 0));
         SR_FH(hipStreamWaitEvent(sr, h->fact_fork, 0));
     }
-    h->last_fact_pipe = pipe ? 1 : 0;
+    h->last_fact_pipe = pipe ? 1 : (flow ? 4 : 0);
+    unsigned flow_ep = 0;
+    static const int flow_band_lab = (int)sr_lab_env("SR_FLOW_BAND", -1), flow_acq = (int)sr_lab_env("SR_FLOW_ACQ", 0);
+    const int flow_band = flow_band_lab >= 0 ? flow_band_lab : SR_FLOW_BAND;
+    if (flow) {
+        const long words = SR_FLOW_HDR + (long)h->n_out * sr_flow_words(nb);
+        if (h->flow_words < words) {
+            (void)device_sync();
+            dev_free(h->flow_flags);
+            h->flow_flags = nullptr; h->flow_words = 0;
+            SR_F(dev_alloc(&h->flow_flags, (size_t)words));
+            SR_F(dev_zero(h->flow_flags, sizeof(unsigned) * (size_t)words));
+            h->flow_words = words; h->flow_epoch = 0;
+        }
+        flow_ep = ++h->flow_epoch;
+    }
 
     // Outputs are processed in rounds of n_par as a BATCH: one chain of launches, every kernel works on the n_par
     // problems at once (grid dimension = output; operands `per` resp. NN doubles apart).  Round 2 ran one chain of
@@ -433,6 +497,15 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         static const int inv_rest_lab = (int)sr_lab_env("SR_FACT_INV_REST", 0);      // (lab build: 1000 = one stage everywhere)
         const int inv_min_rest = inv_rest_lab > 0 ? inv_rest_lab : (nb <= 24 ? 3 : 1000);
         (void)root_mid;
+        if (flow) {
+            // the diagonal-block workgroups first -- they must be resident when the workers fill the chip; the caller's stream
+            // is drained so that they do not wait for their go longer than the Gram kernel takes
+            SR_FH(hipStreamSynchronize(s0));
+            SR_F(sr_launch_flow_diag_server(U, Np, Wt, W, Np, nb, info_dev + d0, h->flow_flags, flow_ep, SR_FLOW_TIMEOUT_S,
+                                            SR_FLOW_TIMEOUT_S, srv, &b_diag));
+            SR_FH(hipMemsetAsync(h->flow_flags + SR_FLOW_STATUS, 0,
+                                 sizeof(unsigned) * (size_t)(SR_FLOW_HDR - SR_FLOW_STATUS + (long)h->n_out * sr_flow_words(nb)), sc));
+        }
         {
             sr_prof_scope ps(&h->prof, SR_K_GRAM, sc);
             if (h->general)
@@ -454,7 +527,21 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         std::vector<int> pb;
         for (int p = 0; p < nb; p += P) pb.push_back(p);
         pb.push_back(nb);
-        if (pipe) {
+        if (flow) {
+            long total = 0;
+            for (int i = 0; i < nb; ++i) total += sr_flow_nacc(nb, i, flow_band) + sr_flow_ntr(nb, i, flow_band);
+            const sr_flow_params fp{U, W, Wt, sP, sN, Np, nb, nd, flow_band, total, h->flow_flags, flow_ep,
+                                    (unsigned long long)(SR_FLOW_TIMEOUT_S * 1e8), flow_acq};
+            if (h->ncu == 0) {
+                int cus = 0;
+                SR_FH(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+                h->ncu = cus;
+            }
+            // two workgroups per CU (72 KB of LDS each), none on the CUs the diagonal-block workgroups hold
+            const long wgs = std::min<long>(total * nd, 2L * std::max(1, h->ncu - nd));
+            sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+            SR_F(sr_launch_flow_workers(fp, (int)wgs, sc));
+        } else if (pipe) {
             // ---- The same factorisation with the block step CUT at its dependencies and dealt to three streams:
             //   critical (sc):  Sc(k) = the ONE block U[k][k+1] of the block row solve, then Ud(k+1) = the update of the next
             //                   diagonal block -- all the next diagonal block needs;
@@ -683,14 +770,20 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     }
     unsigned pipe_status = 0;
     if (pipe && hipMemcpy(&pipe_status, fl_status, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) pipe_status = 1;
+    if (flow && hipMemcpy(&pipe_status, h->flow_flags + SR_FLOW_STATUS, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess)
+        pipe_status = 1;
     cleanup();
 #undef SR_F
 #undef SR_FH
     if (pipe_status != 0) {
         // a hand-over gave up: whatever was computed behind it is void.  Once more, on the plain chain.
-        g_pipe_broken.store(true);
-        (void)hipMemset(h->fact_flags, 0, sizeof(unsigned) * (size_t)(4 + 3 * h->fact_flags_nb));
-        h->fact_epoch = 0;
+        if (flow) {
+            g_flow_broken.store(true);
+        } else {
+            g_pipe_broken.store(true);
+            (void)hipMemset(h->fact_flags, 0, sizeof(unsigned) * (size_t)(4 + 3 * h->fact_flags_nb));
+            h->fact_epoch = 0;
+        }
         return sr_gp_factorize(h, stream, info);
     }
     int bad = 0;
@@ -709,7 +802,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
 }
 
 extern "C" int sr_gp_set_fact_pipeline(sr_gp_t h, int on) {
-    SR_CHECK(h != nullptr && on >= 0 && on <= 2, SR_EINVAL, "sr_gp_set_fact_pipeline: bad argument");
+    SR_CHECK(h != nullptr && on >= -1 && on <= 3, SR_EINVAL, "sr_gp_set_fact_pipeline: bad argument");
     h->fact_pipe = on;
     return SR_OK;
 }

@@ -5,6 +5,7 @@
 // replaces (numerically) what GPy computes for SimpleGPModel.train / update_model:
 //   /root/reference/safe_exploration/ssm_gpy/gaussian_process.py:238-275, 398-419
 #include "sr_mfma_tile.h"
+#include "sr_flow.h"
 #include "sr_pivot_dev.h"
 // ------------------------------------------------------------------------------------------------
 // Gram matrix K[i][j] = sf2 exp(-0.5 |(z_i - z_j)/l|^2) + noise (i==j); identity on the padding.
@@ -367,23 +368,15 @@ __device__ __forceinline__ void sr_pd_wait(int* cnt, int target) {
     asm volatile("" ::: "memory");
 }
 
-__global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
-                                                                         double* wt_diag, double* w_diag,
-                                                                         long ldw, int kb, int* info, int skip,
-                                                                         sr_batch bt) {
-    // skip (sr_test_potrf_diag; 0 in production): 64 = leave A untouched (back-to-back timing on one input)
-    __shared__ double S[SR_NB * SR_PD_LD];
-    __shared__ double Xb[2][16 * SR_PD_TLD];
-    __shared__ int fail, done;
-    A += (long)blockIdx.x * bt.sA; wt_diag += (long)blockIdx.x * bt.sB; w_diag += (long)blockIdx.x * bt.sC;
-    info += blockIdx.x;
+// The block at Ag (leading dimension lda; k0 = its first row, for the breakdown report) -> U_kk in place, U_kk^-1 to wt_diag,
+// U_kk^-T to w_diag (leading dimension ldw).  S, Xb, fail, done: the workgroup's LDS.  Shared by the launched kernel (one block
+// per launch) and the resident workgroup of the tile-flow Cholesky below.
+__device__ __forceinline__ void sr_pd_block(double* Ag, long lda, double* wt_diag, double* w_diag, long ldw, long k0,
+                                            int* info, bool storeA, double* S, double (*Xb)[16 * SR_PD_TLD], int& fail,
+                                            int& done) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane >> 4, ln = lane & 15;
-    const long k0 = (long)kb * SR_NB;
-    const bool storeA = !(skip & 64);
-    double* Ag = A + k0 * lda + k0;
-    __builtin_amdgcn_s_setprio(3);
     if (tid == 0) { fail = 0; done = 0; }
     // wavefront -> role: 0 the pivots; 1 .. 6 a tile of the panel row each, then trailing-update jobs; 4, 8, 12 (the SIMD
     // of wavefront 0: fp64 MFMA and fp64 VALU share its DP pipe, MFMA jobs there stall the pivot chain) stores only
@@ -585,6 +578,97 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
             w_diag[(long)r * ldw + c] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double* A, long lda,
+                                                                         double* wt_diag, double* w_diag,
+                                                                         long ldw, int kb, int* info, int skip,
+                                                                         sr_batch bt) {
+    // skip (sr_test_potrf_diag; 0 in production): 64 = leave A untouched (back-to-back timing on one input)
+    __shared__ double S[SR_NB * SR_PD_LD];
+    __shared__ double Xb[2][16 * SR_PD_TLD];
+    __shared__ int fail, done;
+    A += (long)blockIdx.x * bt.sA; wt_diag += (long)blockIdx.x * bt.sB; w_diag += (long)blockIdx.x * bt.sC;
+    info += blockIdx.x;
+    const long k0 = (long)kb * SR_NB;
+    __builtin_amdgcn_s_setprio(3);
+    sr_pd_block(A + k0 * lda + k0, lda, wt_diag, w_diag, ldw, k0, info, !(skip & 64), S, Xb, fail, done);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RESIDENT form: the diagonal blocks of the tile-flow Cholesky (round 6; sr_flow.hip has the picture, sr_flow.h the counters).
+// ONE workgroup per output is launched in front of everything else, keeps its CU for the whole factorisation and factors
+// block after block: it waits until the three upper 64 x 64 tiles of block kb have taken their last update (ac[kb][2 kb] >= 1,
+// ac[kb][2 kb + 1] >= 2; block 0: until the Gram matrix is there, SR_FLOW_GO), factors and inverts, and publishes dd[kb] = 1,
+// which the block-row solves of the worker kernel wait for.  What comes in is read behind an agent-scope acquire, what goes
+// out leaves in front of an agent-scope release (the L2s of the XCDs are not coherent with each other).  A wait beyond its
+// time-out, or a raised status word, ends the workgroup (the host then repeats the update by launches).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_flow_diag_server_kernel(double* A, long lda, double* Wt, double* W,
+                                                                               long ldw, int nb, int* info, sr_batch bt,
+                                                                               unsigned* flags, unsigned epoch,
+                                                                               unsigned long long timeout_go,
+                                                                               unsigned long long timeout) {
+    __shared__ double S[SR_NB * SR_PD_LD];
+    __shared__ double Xb[2][16 * SR_PD_TLD];
+    __shared__ int fail, done, go;
+    const int d = blockIdx.x;
+    A += (long)d * bt.sA; Wt += (long)d * bt.sB; W += (long)d * bt.sC;
+    info += d;
+    unsigned* dd = flags + SR_FLOW_HDR + (long)d * sr_flow_words(nb);
+    const unsigned* ac = dd + nb;
+    const int nt = 2 * nb;
+    unsigned* status = flags + SR_FLOW_STATUS;
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + SR_FLOW_ALIVE + d, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+    for (int kb = 0; kb < nb; ++kb) {
+        if (threadIdx.x == 0) {
+            int ok = 1;
+            const unsigned long long t0 = wall_clock64();
+            unsigned spins = 0;
+            if (kb == 0) {
+                // (the status word may still hold the previous run's value until the memset in front of this run's Gram
+                //  kernel has run: not looked at here, and a time-out just leaves)
+                while (__hip_atomic_load(flags + SR_FLOW_GO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if ((++spins & 63) == 0 && wall_clock64() - t0 > timeout_go) { ok = 0; break; }
+                }
+            } else {
+                const unsigned* a0 = ac + (long)kb * nt + 2 * kb;
+                while (__hip_atomic_load(a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1u ||
+                       __hip_atomic_load(a0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63) != 0) continue;
+                    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                    if (wall_clock64() - t0 > timeout) {
+                        __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            go = ok;
+        }
+        __syncthreads();
+        if (!go) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const long k0 = (long)kb * SR_NB;
+        const long dg = k0 * ldw + k0;
+        sr_pd_block(A + k0 * lda + k0, lda, Wt + dg, W + dg, ldw, k0, info, true, S, Xb, fail, done);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every thread: its stores are out before the word below
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(dd + kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int sr_launch_flow_diag_server(double* A, long lda, double* Wt, double* W, long ldw, int nb, int* info_dev, unsigned* flags,
+                               unsigned epoch, double timeout_go_s, double timeout_s, hipStream_t s, const sr_batch* btp) {
+    const sr_batch bt = btp ? *btp : sr_batch{};
+    hipLaunchKernelGGL(sr_flow_diag_server_kernel, dim3(bt.n), dim3(SR_PD_THREADS), 0, s, A, lda, Wt, W, ldw, nb, info_dev, bt,
+                       flags, epoch, (unsigned long long)(timeout_go_s * 1e8), (unsigned long long)(timeout_s * 1e8));
+    SR_HIP(hipGetLastError());
+    return SR_OK;
 }
 
 int sr_launch_potrf_diag(double* A, long lda, double* wt_diag, double* w_diag, long ldw, int kb,

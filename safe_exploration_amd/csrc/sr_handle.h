@@ -114,8 +114,11 @@ struct sr_gp {
     hipStream_t diag_stream = nullptr, row_stream = nullptr;
     unsigned* fact_flags = nullptr; int fact_flags_nb = 0;   // [status | c[nb] | d[nb] | r[nb]]; zero at allocation, values = epochs
     unsigned fact_epoch = 0;
+    // tile-flow Cholesky (round 6; sr_flow.h): its counters, their capacity in words, the epoch of the last run
+    unsigned* flow_flags = nullptr; long flow_words = 0; unsigned flow_epoch = 0;
     int fact_pipe = 0;                                    // sr_gp_set_fact_pipeline: 0 = one chain of launches (default: the pipelined
-                                                          // forms measured slower, profiles/r06_fact_pipeline.txt), 1 = three streams, 2 = two
+                                                          // forms measured slower, profiles/r06_fact_pipeline.txt), 1 = three streams, 2 = two,
+                                                          // 3 = tile-flow Cholesky (one resident kernel), -1 = never the tile flow
     int last_fact_pipe = 0;                               // the last update ran pipelined (diagnostics / tests)
     hipEvent_t fact_fork = nullptr, fact_join = nullptr;
     hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_bulk[2] = {nullptr, nullptr};

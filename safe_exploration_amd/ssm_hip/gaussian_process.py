@@ -1070,6 +1070,12 @@ class SimpleGPModel(StateSpaceModel):
         self._need_trained()
         return bool(lib.sr_gp_fact_pipelined(self._handle.h))
 
+    def fact_route(self):
+        """how the last model update ran: 0 one chain of launches, 1 pipelined prototype, 4 tile-flow Cholesky (one resident
+        kernel, ``set_fact_pipeline(3)``)"""
+        self._need_trained()
+        return int(lib.sr_gp_fact_pipelined(self._handle.h))
+
     def get_forward_model_casadi(self, linearize_mu=True):
         """state_space_models.py:140-166.  The evaluator calls the model once per IPOPT callback and blocks: the resident
         single-query server is armed for it (``start_server``; SR_NO_SERVER=1 in the environment keeps the launched

@@ -3,7 +3,7 @@
 with the per-kernel split of the library's own hipEvent pairs and the posterior identity as a sanity check.
 
 usage (GPU box):  python scripts/factor_bench.py [N ...]      (default 1000 2000 5000 10000)
-SR_PANELS=0,2,4 picks the panel widths (0 = by size), SR_PIPE=0,1,2 the chain forms (0 = one chain of launches, the default; 1 / 2 = the pipelined prototypes of round 6).
+SR_PANELS=0,2,4 picks the panel widths (0 = by size), SR_PIPE=0,1,2,3 the chain forms (0 = by size, -1 = one chain of launches; 1 / 2 = the pipelined prototypes of round 6, 3 = the tile-flow Cholesky).
 """
 import json
 import os
@@ -61,7 +61,7 @@ def main():
             mu, var = gp.predict(prob["Z"][idx])
             res = float(np.abs(mu + s2n[None, :] * gp.beta[idx] - prob["Y"][idx]).max())
             flops = n_s * (2.0 / 3.0) * float(N) ** 3
-            rec = {"N": N, "n_out": n_s, "panel": P, "pipelined": int(gp.fact_pipelined()), "refit_ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 2),
+            rec = {"N": N, "n_out": n_s, "panel": P, "route": gp.fact_route(), "refit_ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 2),
                    "kernel_ms[total,launches]": split, "max|mu+s2n*alpha-y|": res}
             print(json.dumps(rec), flush=True)
             out.append(rec)
