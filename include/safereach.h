@@ -263,9 +263,17 @@ int sr_gp_set_fact_panel(sr_gp_t h, int panel);
  * a stream of its own beside the rest of the previous block row, 2 keeps it on the critical stream and moves only the
  * rest of the rows; the streams hand over through device counters.  0 (default) = one chain of launches: the pipelined
  * forms are 1.2 - 2.8 times SLOWER on this part (profiles/r06_fact_pipeline.txt).  Same tiles, same order of summation:
- * identical numbers.  sr_gp_fact_pipelined: did the last update of h run pipelined (1 / 0)? */
+ * identical numbers.  3 = the tile-flow Cholesky (csrc/sr_flow.hip: the whole factorisation as ONE resident kernel of tile
+ * tasks plus a resident diagonal-block workgroup per output, dependencies through device counters; results agree with the
+ * launched form to rounding); -1 = never the tile flow.  sr_gp_fact_pipelined: how the last update of h ran -- 0 one chain
+ * of launches, 1 pipelined prototype, 4 tile flow. */
 int sr_gp_set_fact_pipeline(sr_gp_t h, int on);
 int sr_gp_fact_pipelined(sr_gp_t h);
+/* diagnostics of the last tile-flow update (SR_ESTATE if it was none): out[0..23] = per kind of task (look-ahead update,
+ * bulk update, diagonal tiles, near updates, near solves, far blocks) [count, ticks inside, ticks of those waiting, 0] at
+ * 100 MHz; then per output the ticks from the start to each diagonal block.  Returns the words written (cap too small:
+ * SR_EINVAL). */
+int sr_gp_flow_stats(sr_gp_t h, unsigned* out, int cap);
 /* latency paths instead of the plain MFMA tiles: one-launch pass for small models (Np <= 512, T <= 1024),
  * HBM-bound streaming of U^-1 for batches of <= 64 queries, 64 x 64 tiles, balanced shares of the k-blocks under few
  * query tiles.  on = 1 (default) all of them, 2 all but the one-launch pass, 0 none; an A/B measurement knob.  Results
@@ -354,6 +362,10 @@ int sr_test_potrf_diag(int device, double* A, long lda, double* wt, double* w, l
  * group of rollouts waits for partners that never come: the deterministic way into the time-out path (the tests check
  * that it is reported -- sr_gp_chain_status -- and not silent).  0 restores normal launches. */
 int sr_test_chain_drop(sr_gp_t h, int drop);
+/* host only: the task plan of the tile-flow Cholesky (csrc/sr_flow.h) for nb block rows -- segs[4 i + 0..3] = first critical
+ * task, far task, panel update, position in the one order of block row i (i = 0 .. nb: one behind the last); totals[0..3] =
+ * critical tasks, far tasks, panel updates, positions per output. */
+int sr_test_flow_plan(int nb, int band, int panel, int* segs, long* totals);
 /* diagnostic: the next n launches of the one-launch append of a grid of workgroups (sr_gp_append / sr_gp_append1_host with
  * one point beyond 512 padded rows) wait at their first device-wide barrier for a workgroup that does not exist and give
  * it up after ~5 ms: the deterministic way into the path a grid takes that cannot become resident as a whole (nothing of

@@ -228,7 +228,7 @@ extern "C" int sr_gp_destroy(sr_gp_t h) {
     if (h->chain_status_host) (void)hipHostFree(h->chain_status_host);
     dev_free(h->yT_alt); dev_free(h->alpha_alt);
     free_ws(h);
-    dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->appg_cnt); dev_free(h->Wt_alt); dev_free(h->fact_flags); dev_free(h->flow_flags);
+    dev_free(h->fact_ws); dev_free(h->app_ws); dev_free(h->appg_cnt); dev_free(h->Wt_alt); dev_free(h->fact_flags); dev_free(h->flow_flags); if (h->flow_segs) (void)hipFree(h->flow_segs);
     if (h->app_pin) (void)hipHostFree(h->app_pin);
     for (hipEvent_t e : {h->fact_join, h->ev_panel[0], h->ev_panel[1], h->ev_bulk[0], h->ev_bulk[1], h->ev_inv[0], h->ev_inv[1]})
         if (e) (void)hipEventDestroy(e);

@@ -172,9 +172,9 @@ static bool own_queues(hipStream_t a, hipStream_t b, hipStream_t c) {
 // non-blocking (the caller's stream may be the null stream) and of the lowest priority (another pool of hardware queues than
 // the update's priority stream).  Its kernel WAITS for the workers on the device, so the two must not share a hardware queue:
 // checked once per (device, worker stream) with a pair of hand-overs in either order.
-struct sr_flow_stream { hipStream_t srv = nullptr; hipStream_t checked_with = nullptr; bool checked = false, ok = false; };
+struct sr_flow_stream { hipStream_t srv = nullptr, inv = nullptr; hipStream_t checked_with = nullptr; bool checked = false, ok = false; };
 static sr_flow_stream g_flow_streams[64];
-static int flow_server_stream(int device, hipStream_t worker, hipStream_t* out) {
+static int flow_server_stream(int device, hipStream_t worker, hipStream_t* out, hipStream_t* inv_out) {
     std::lock_guard<std::mutex> lk(g_stream_mutex);
     SR_CHECK(device >= 0 && device < 64, SR_EINVAL, "device index %d", device);
     sr_flow_stream& f = g_flow_streams[device];
@@ -182,6 +182,10 @@ static int flow_server_stream(int device, hipStream_t worker, hipStream_t* out) 
         int prio_lo = 0, prio_hi = 0;
         SR_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         SR_HIP(hipStreamCreateWithPriority(&f.srv, hipStreamNonBlocking, prio_lo));
+        // ... and the stream of the inversion's stages that run beside the flow (each behind a gate kernel that waits on the
+        // device; everything on it is launched AFTER the diagonal-block workgroups and the workers, so a hardware queue it
+        // shares with either only costs the overlap)
+        SR_HIP(hipStreamCreateWithPriority(&f.inv, hipStreamNonBlocking, prio_lo));
     }
     if (!f.checked || f.checked_with != worker) {
         unsigned* w = nullptr;
@@ -200,6 +204,7 @@ static int flow_server_stream(int device, hipStream_t worker, hipStream_t* out) 
         f.checked = true; f.checked_with = worker; f.ok = ok;
     }
     *out = f.ok ? f.srv : nullptr;
+    *inv_out = f.ok ? f.inv : nullptr;
     return SR_OK;
 }
 
@@ -318,10 +323,10 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     double* scratch = nullptr;                           // owned here only when it is not kept in the handle
     int rc = SR_OK;
     hipStream_t s0 = (hipStream_t)stream;
-    hipStream_t srv = nullptr;                           // tile flow: the stream of the resident diagonal-block workgroups
+    hipStream_t srv = nullptr, finv = nullptr;           // tile flow: the streams of the resident diagonal-block workgroups / of the inversion beside it
     auto cleanup = [&]() {
         // never return with work in flight on the side streams
-        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream, h->diag_stream, h->row_stream, srv}) if (st) (void)hipStreamSynchronize(st);
+        for (hipStream_t st : {h->fact_stream, h->bulk_stream, h->inv_stream, h->diag_stream, h->row_stream, srv, finv}) if (st) (void)hipStreamSynchronize(st);
         release_fact_streams(h);
         dev_free(scratch);
     };
@@ -367,8 +372,8 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     const bool want_flow = h->fact_pipe == 3 || (h->fact_pipe == 0 && (flow_lab == 1 || (nb >= SR_FLOW_MIN_NB && nb <= SR_FLOW_MAX_NB)));
     bool flow = want_flow && regime == 1 && nb >= 3 && n_par >= h->n_out && !g_flow_broken.load();
     if (flow) {
-        SR_F(flow_server_stream(h->device, s0, &srv));
-        if (!srv) flow = false;
+        SR_F(flow_server_stream(h->device, s0, &srv, &finv));
+        if (!srv) { flow = false; finv = nullptr; }
     }
     const bool own_streams = !flow && !(nb <= 2 && P >= nb) && !(nb <= one_stream_nb && h->fact_pipe <= 0);
 
@@ -406,6 +411,8 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     unsigned flow_ep = 0;
     static const int flow_band_lab = (int)sr_lab_env("SR_FLOW_BAND", -1), flow_acq = (int)sr_lab_env("SR_FLOW_ACQ", 0);
     const int flow_band = flow_band_lab >= 0 ? flow_band_lab : SR_FLOW_BAND;
+    static const int flow_panel_lab = (int)sr_lab_env("SR_FLOW_PANEL", 0);
+    const int flow_panel = flow_panel_lab > 0 ? flow_panel_lab : (h->fact_panel > 0 ? h->fact_panel : sr_flow_panel(nb));
     if (flow) {
         const long words = SR_FLOW_HDR + (long)h->n_out * sr_flow_words(nb);
         if (h->flow_words < words) {
@@ -417,6 +424,16 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             h->flow_words = words; h->flow_epoch = 0;
         }
         flow_ep = ++h->flow_epoch;
+        if (!h->flow_segs || h->flow_segs_key[0] != nb || h->flow_segs_key[1] != flow_band || h->flow_segs_key[2] != flow_panel) {
+            std::vector<sr_flow_seg> segs((size_t)nb + 1);
+            h->flow_total = sr_flow_plan(nb, flow_band, flow_panel, segs.data(), &h->flow_total_far, &h->flow_total_upd, &h->flow_total_m);
+            (void)device_sync();
+            if (h->flow_segs) (void)hipFree(h->flow_segs);
+            h->flow_segs = nullptr;
+            SR_FH(hipMalloc(&h->flow_segs, sizeof(sr_flow_seg) * ((size_t)nb + 1)));
+            SR_FH(hipMemcpy(h->flow_segs, segs.data(), sizeof(sr_flow_seg) * ((size_t)nb + 1), hipMemcpyHostToDevice));
+            h->flow_segs_key[0] = nb; h->flow_segs_key[1] = flow_band; h->flow_segs_key[2] = flow_panel;
+        }
     }
 
     // Outputs are processed in rounds of n_par as a BATCH: one chain of launches, every kernel works on the n_par
@@ -501,7 +518,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             // the diagonal-block workgroups first -- they must be resident when the workers fill the chip; the caller's stream
             // is drained so that they do not wait for their go longer than the Gram kernel takes
             SR_FH(hipStreamSynchronize(s0));
-            SR_F(sr_launch_flow_diag_server(U, Np, Wt, W, Np, nb, info_dev + d0, h->flow_flags, flow_ep, SR_FLOW_TIMEOUT_S,
+            SR_F(sr_launch_flow_diag_server(U, Np, Wt, W, Np, nb, flow_panel, info_dev + d0, h->flow_flags, flow_ep, SR_FLOW_TIMEOUT_S,
                                             SR_FLOW_TIMEOUT_S, srv, &b_diag));
             SR_FH(hipMemsetAsync(h->flow_flags + SR_FLOW_STATUS, 0,
                                  sizeof(unsigned) * (size_t)(SR_FLOW_HDR - SR_FLOW_STATUS + (long)h->n_out * sr_flow_words(nb)), sc));
@@ -528,19 +545,39 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
         for (int p = 0; p < nb; p += P) pb.push_back(p);
         pb.push_back(nb);
         if (flow) {
-            long total = 0;
-            for (int i = 0; i < nb; ++i) total += sr_flow_nacc(nb, i, flow_band) + sr_flow_ntr(nb, i, flow_band);
-            const sr_flow_params fp{U, W, Wt, sP, sN, Np, nb, nd, flow_band, total, h->flow_flags, flow_ep,
-                                    (unsigned long long)(SR_FLOW_TIMEOUT_S * 1e8), flow_acq};
+            const long total = h->flow_total;
+            static const int flow_keep_lab = (int)sr_lab_env("SR_FLOW_KEEP", -1), flow_exit_lab = (int)sr_lab_env("SR_FLOW_EXIT_PCT", -1);
+            const int flow_keep = flow_keep_lab >= 0 ? flow_keep_lab : SR_FLOW_KEEP_WGS;
+            const int flow_exit_row = (finv && nb >= 8) ? nb * (flow_exit_lab >= 0 ? flow_exit_lab : SR_FLOW_EXIT_PCT) / 100 : nb;
+            const sr_flow_params fp{U, W, Wt, sP, sN, Np, nb, nd, flow_band, flow_panel, total, h->flow_total_far, h->flow_total_upd, h->flow_total_m, flow_keep, flow_exit_row, (const sr_flow_seg*)h->flow_segs,
+                                    h->flow_flags, flow_ep, (unsigned long long)(SR_FLOW_TIMEOUT_S * 1e8), flow_acq};
             if (h->ncu == 0) {
                 int cus = 0;
                 SR_FH(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
                 h->ncu = cus;
             }
             // two workgroups per CU (72 KB of LDS each), none on the CUs the diagonal-block workgroups hold
-            const long wgs = std::min<long>(total * nd, 2L * std::max(1, h->ncu - nd));
-            sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
-            SR_F(sr_launch_flow_workers(fp, (int)wgs, sc));
+            const long wgs = std::min<long>((total + h->flow_total_far + h->flow_total_upd) * nd, 2L * std::max(1, h->ncu - nd));
+            {
+                sr_prof_scope ps(&h->prof, SR_K_GEMM, sc);
+                SR_F(sr_launch_flow_workers(fp, (int)wgs, sc));
+            }
+            // the inversion's stages beside the flow: what lies above block row X needs nothing the Cholesky still writes once
+            // the chain has passed X (inv_stage) -- at X = nb / 2, then halfway to the end again while three blocks remain;
+            // each stage behind a gate kernel that waits for the flow's counters on the device
+            static const bool flow_no_inv = sr_lab_on("SR_FLOW_NO_EARLY_INV");
+            if (finv && nb >= 8 && !flow_no_inv) {
+                SR_F(ensure_fact_events(h));
+                for (int X = nb / 2; X < nb;) {
+                    SR_F(sr_launch_flow_gate(h->flow_flags, flow_ep, nd, nb, X, SR_FLOW_TIMEOUT_S, finv));
+                    SR_F(inv_stage(X, finv, false));
+                    const int nxt = (X + nb) / 2;
+                    if (nb - nxt < 3 || nxt <= X) break;
+                    X = nxt;
+                }
+                SR_FH(hipEventRecord(h->ev_inv[1], finv));
+                early_done = true;
+            }
         } else if (pipe) {
             // ---- The same factorisation with the block step CUT at its dependencies and dealt to three streams:
             //   critical (sc):  Sc(k) = the ONE block U[k][k+1] of the block row solve, then Ud(k+1) = the update of the next
@@ -808,6 +845,30 @@ extern "C" int sr_gp_set_fact_pipeline(sr_gp_t h, int on) {
 }
 
 extern "C" int sr_gp_fact_pipelined(sr_gp_t h) { return h ? h->last_fact_pipe : 0; }
+
+extern "C" int sr_test_flow_plan(int nb, int band, int panel, int* segs, long* totals) {
+    SR_CHECK(nb >= 1 && nb <= 4096 && band >= 0 && panel >= 1 && segs && totals, SR_EINVAL, "sr_test_flow_plan: bad argument");
+    std::vector<sr_flow_seg> sg((size_t)nb + 1);
+    totals[0] = sr_flow_plan(nb, band, panel, sg.data(), &totals[1], &totals[2], &totals[3]);
+    for (int i = 0; i <= nb; ++i) {
+        segs[4 * i + 0] = sg[i].start_c; segs[4 * i + 1] = sg[i].start_f; segs[4 * i + 2] = sg[i].start_b; segs[4 * i + 3] = sg[i].start_m;
+    }
+    return SR_OK;
+}
+
+extern "C" int sr_gp_flow_stats(sr_gp_t h, unsigned* out, int cap) {
+    SR_CHECK(h != nullptr && out != nullptr, SR_EINVAL, "sr_gp_flow_stats: NULL argument");
+    SR_CHECK(h->last_fact_pipe == 4 && h->flow_flags, SR_ESTATE, "sr_gp_flow_stats: the last model update was not a tile flow");
+    SR_DEVICE(h->device);
+    const int nb = h->Np / SR_NB;
+    const int need = 24 + h->n_out * nb;
+    SR_CHECK(cap >= need, SR_EINVAL, "sr_gp_flow_stats: %d words needed", need);
+    SR_HIP(hipMemcpy(out, h->flow_flags + SR_FLOW_STATS, 24 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (int d = 0; d < h->n_out; ++d)
+        SR_HIP(hipMemcpy(out + 24 + d * nb, h->flow_flags + SR_FLOW_HDR + (long)d * sr_flow_words(nb) + nb + 9L * nb * nb,
+                         nb * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return need;
+}
 
 extern "C" int sr_gp_set_fact_panel(sr_gp_t h, int panel) {
     SR_CHECK(h != nullptr && panel >= 0 && panel <= 64, SR_EINVAL, "sr_gp_set_fact_panel: bad argument");

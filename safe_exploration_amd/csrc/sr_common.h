@@ -354,7 +354,10 @@ int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* pa
 #define SR_FLOW_MIN_NB 1000           /* model update: tile-flow Cholesky (sr_flow.hip) from this many blocks ... */
 #define SR_FLOW_MAX_NB 0              /* ... up to this many (empty range: opt-in through sr_gp_set_fact_pipeline(h, 3)) */
 #define SR_FLOW_BAND 2                /* blocks right of the diagonal block that go in 64 x 64 tiles */
-#define SR_FLOW_TIMEOUT_S 0.05        /* a wait of the tile flow that lasts longer gives up (the host repeats the update by launches) */
+static inline int sr_flow_panel(int nb) { return nb <= 12 ? 2 : (nb <= 28 ? 3 : 4); }   /* block rows per panel of the tile flow */
+#define SR_FLOW_KEEP_WGS 128          /* tile flow: workgroups that stay to the end ... */
+#define SR_FLOW_EXIT_PCT 50           /* ... the others leave after a row task past this percentage of the block rows */
+#define SR_FLOW_TIMEOUT_S 0.25        /* a wait of the tile flow that lasts longer gives up (the host repeats the update by launches) */
 #define SR_FACT_ONE_STREAM_MAX_NB 15 /* model update: up to here every launch stays on the caller's stream (no side streams, no events) */
 #define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch of one workgroup per output up to this padded size (the grown model: <= 640) */
 #define SR_APPEND1G_MAX_NP0 8192     /* +1 point in ONE launch of a grid of workgroups up to this padded size (K* row in LDS) */

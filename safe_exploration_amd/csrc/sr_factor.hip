@@ -599,13 +599,13 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_potrf_diag_kernel(double*
 // RESIDENT form: the diagonal blocks of the tile-flow Cholesky (round 6; sr_flow.hip has the picture, sr_flow.h the counters).
 // ONE workgroup per output is launched in front of everything else, keeps its CU for the whole factorisation and factors
 // block after block: it waits until the three upper 64 x 64 tiles of block kb have taken their last update (ac[kb][2 kb] >= 1,
-// ac[kb][2 kb + 1] >= 2; block 0: until the Gram matrix is there, SR_FLOW_GO), factors and inverts, and publishes dd[kb] = 1,
+// ac[kb][2 kb + 1] >= 2; first row of a panel: ap[kb][kb]; block 0: until the Gram matrix is there, SR_FLOW_GO), factors and inverts, and publishes dd[kb] = 1,
 // which the block-row solves of the worker kernel wait for.  What comes in is read behind an agent-scope acquire, what goes
 // out leaves in front of an agent-scope release (the L2s of the XCDs are not coherent with each other).  A wait beyond its
 // time-out, or a raised status word, ends the workgroup (the host then repeats the update by launches).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_flow_diag_server_kernel(double* A, long lda, double* Wt, double* W,
-                                                                               long ldw, int nb, int* info, sr_batch bt,
+                                                                               long ldw, int nb, int panel, int* info, sr_batch bt,
                                                                                unsigned* flags, unsigned epoch,
                                                                                unsigned long long timeout_go,
                                                                                unsigned long long timeout) {
@@ -618,6 +618,9 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_flow_diag_server_kernel(d
     unsigned* dd = flags + SR_FLOW_HDR + (long)d * sr_flow_words(nb);
     const unsigned* ac = dd + nb;
     const int nt = 2 * nb;
+    const unsigned* ap = ac + 2L * nb * nt;
+    unsigned* tk = dd + nb + 9L * nb * nb;
+    unsigned long long t_go = 0;
     unsigned* status = flags + SR_FLOW_STATUS;
     __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) __hip_atomic_store(flags + SR_FLOW_ALIVE + d, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -634,10 +637,16 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_flow_diag_server_kernel(d
                     __builtin_amdgcn_s_sleep(4);
                     if ((++spins & 63) == 0 && wall_clock64() - t0 > timeout_go) { ok = 0; break; }
                 }
+                t_go = wall_clock64();
             } else {
-                const unsigned* a0 = ac + (long)kb * nt + 2 * kb;
-                while (__hip_atomic_load(a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1u ||
-                       __hip_atomic_load(a0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+                // first row of a panel: the block is what the updates by the panels in front left (ap counts them); otherwise
+                // its three upper tiles have taken the panel's rows above it
+                const bool first = false && kb % panel == 0;   // (every block's band is updated in 64-tiles now: sr_flow.hip)
+                const unsigned* a0 = first ? ap + (long)kb * nb + kb : ac + (long)kb * nt + 2 * kb;
+                const unsigned* a1 = first ? a0 : a0 + 1;
+                const unsigned v0 = first ? (unsigned)(kb / panel) : 1u, v1 = first ? v0 : 2u;
+                while (__hip_atomic_load(a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v0 ||
+                       __hip_atomic_load(a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v1) {
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 63) != 0) continue;
                     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
@@ -654,18 +663,27 @@ __global__ __launch_bounds__(SR_PD_THREADS, 1) void sr_flow_diag_server_kernel(d
         if (!go) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const long k0 = (long)kb * SR_NB;
-        const long dg = k0 * ldw + k0;
-        sr_pd_block(A + k0 * lda + k0, lda, Wt + dg, W + dg, ldw, k0, info, true, S, Xb, fail, done);
+        // (the leading dimensions are made opaque per block: otherwise every per-lane address of the block routine is computed
+        //  once in front of the loop and kept -- 128 VGPRs at 16 wavefronts, 84 bytes of scratch per lane)
+        long lda_i = lda, ldw_i = ldw;
+        double *A_i = A, *Wt_i = Wt, *W_i = W;
+        asm volatile("" : "+s"(lda_i), "+s"(ldw_i), "+s"(A_i), "+s"(Wt_i), "+s"(W_i));
+        const long dg = k0 * ldw_i + k0;
+        sr_pd_block(A_i + k0 * lda_i + k0, lda_i, Wt_i + dg, W_i + dg, ldw_i, k0, info, true, S, Xb, fail, done);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every thread: its stores are out before the word below
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(dd + kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(dd + kb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tk[kb] = (unsigned)(wall_clock64() - t_go);
+        }
     }
 }
 
-int sr_launch_flow_diag_server(double* A, long lda, double* Wt, double* W, long ldw, int nb, int* info_dev, unsigned* flags,
-                               unsigned epoch, double timeout_go_s, double timeout_s, hipStream_t s, const sr_batch* btp) {
+int sr_launch_flow_diag_server(double* A, long lda, double* Wt, double* W, long ldw, int nb, int panel, int* info_dev,
+                               unsigned* flags, unsigned epoch, double timeout_go_s, double timeout_s, hipStream_t s,
+                               const sr_batch* btp) {
     const sr_batch bt = btp ? *btp : sr_batch{};
-    hipLaunchKernelGGL(sr_flow_diag_server_kernel, dim3(bt.n), dim3(SR_PD_THREADS), 0, s, A, lda, Wt, W, ldw, nb, info_dev, bt,
+    hipLaunchKernelGGL(sr_flow_diag_server_kernel, dim3(bt.n), dim3(SR_PD_THREADS), 0, s, A, lda, Wt, W, ldw, nb, panel, info_dev, bt,
                        flags, epoch, (unsigned long long)(timeout_go_s * 1e8), (unsigned long long)(timeout_s * 1e8));
     SR_HIP(hipGetLastError());
     return SR_OK;

@@ -116,6 +116,7 @@ struct sr_gp {
     unsigned fact_epoch = 0;
     // tile-flow Cholesky (round 6; sr_flow.h): its counters, their capacity in words, the epoch of the last run
     unsigned* flow_flags = nullptr; long flow_words = 0; unsigned flow_epoch = 0;
+    void* flow_segs = nullptr; int flow_segs_key[3] = {0, 0, 0}; long flow_total = 0, flow_total_far = 0, flow_total_upd = 0, flow_total_m = 0;   // task plan on the device for (nb, band, panel)
     int fact_pipe = 0;                                    // sr_gp_set_fact_pipeline: 0 = one chain of launches (default: the pipelined
                                                           // forms measured slower, profiles/r06_fact_pipeline.txt), 1 = three streams, 2 = two,
                                                           // 3 = tile-flow Cholesky (one resident kernel), -1 = never the tile flow

@@ -147,11 +147,19 @@ struct Frag { double a[4], b[4]; };
 
 // one LDS-DMA instruction: 1 KiB tile row from gbase (SGPR pair) + voff (bytes, per lane) to LDS byte address lds0 + IMM
 // (M0 is a reserved register: the compiler loads it in front of each of its own uses and keeps nothing in it)
+// (COH, a template parameter of the loops below: the loads are agent-scope, sc1 -- for operands that other workgroups, on
+//  other XCDs, have rewritten since this XCD's L2 may last have seen them: the tile-flow Cholesky, sr_flow.hip)
 #define SRT_DMA1(lds0_, IMM_, voff_, gbase_)                                                        \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                    \
-                 :: "s"((lds0_) + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory")
+    do {                                                                                            \
+        if constexpr (COH)                                                                          \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1"            \
+                         :: "s"((lds0_) + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory");     \
+        else                                                                                        \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                \
+                         :: "s"((lds0_) + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory");     \
+    } while (0)
 
-template <bool DIAG = false>
+template <bool DIAG = false, bool COH = false>
 __device__ __forceinline__ void mainloop_tn_pipe(const double* __restrict__ A, long lda,
                                                  const double* __restrict__ B, long ldb,
                                                  int k_beg, int k_end, double* smem, Acc& acc) {
@@ -404,6 +412,7 @@ __device__ __forceinline__ void mainloop_tn(const double* __restrict__ A, long l
 // so that the stage is a compile-time constant.  Same order of accumulation as mainloop_tn: identical bits.
 struct Frag { double a[2], b[2]; };
 
+template <bool COH = false>
 __device__ __forceinline__ void mainloop_tn_pipe(const double* __restrict__ A, long lda, const double* __restrict__ B,
                                                  long ldb, int k_beg, int k_end, double* smem, Acc& acc) {
     if (k_beg >= k_end) return;
@@ -428,8 +437,14 @@ __device__ __forceinline__ void mainloop_tn_pipe(const double* __restrict__ A, l
     const int fa = fo + wm * 32, fb = fo + wn * 32;
 
 #define S64_DMA1(IMM_, voff_, gbase_)                                                               \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                    \
-                 :: "s"(lds0 + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory")
+    do {                                                                                            \
+        if constexpr (COH)                                                                          \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1"            \
+                         :: "s"(lds0 + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory");        \
+        else                                                                                        \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                \
+                         :: "s"(lds0 + (unsigned)(IMM_)), "v"(voff_), "s"(gbase_) : "memory");        \
+    } while (0)
     // instruction q (0 .. 3) of the DMA of the tile at (ga, gb) into stage st: A pair w, B pair w, A pair w + 4, B pair w + 4
 #define S64_DMAQ(st, q)                                                                             \
     do {                                                                                            \

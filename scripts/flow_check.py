@@ -7,6 +7,9 @@ import time
 import numpy as np
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if any(k.startswith("SR_FLOW_") and k not in ("SR_FLOW_STATS", "SR_FLOW_ONLY") for k in os.environ):
+    import _lab  # noqa: F401,E402  (SR_FLOW_PANEL / _BAND / _LOOK / _ACQ exist in the lab build only)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from safe_exploration_amd import SimpleGPModel, workload  # noqa: E402
 
@@ -32,6 +35,11 @@ def main():
     n_s, n_u = int(os.environ.get("SR_NOUT", "2")), 1
     for N in sizes:
         prob = workload.make_problem(4, N, n_s, n_u, 16)
+        if os.environ.get("SR_FLOW_ONLY"):
+            gp1, b1, w1, ms1 = fit(prob, n_s, n_u, 3, 7)
+            print(f"N={N} route {gp1.fact_route()} flow {ms1:.3f} ms  " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("SR_FLOW_")), flush=True)
+            del gp1, w1
+            continue
         gp0, b0, w0, ms0 = fit(prob, n_s, n_u, -1, 7)
         r0 = gp0.fact_route()
         del gp0
@@ -43,6 +51,21 @@ def main():
         res = float(np.abs(mu + s2n[None, :] * gp1.beta[idx] - prob["Y"][idx]).max())
         db = float(np.abs(b1 - b0).max() / np.abs(b0).max())
         dw = float((w1 - w0).abs().max() / w0.abs().max())
+        if os.environ.get("SR_FLOW_STATS"):
+            import ctypes
+            from safe_exploration_amd import _lib
+            nb = gp1._handle.Np // 128
+            buf = (ctypes.c_uint * (24 + n_s * nb))()
+            n = _lib.lib.sr_gp_flow_stats(gp1._handle.h, buf, len(buf))
+            if n > 0:
+                names = ["upd next panel", "upd behind", "diag tiles", "near upd", "near solve", "far block"]
+                for k, nm in enumerate(names):
+                    c, t, w = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2]
+                    if c:
+                        print(f"   {nm:15s} {c:6d} tasks  {t / c / 100:8.1f} us each  of which waiting {w / c / 100:8.1f}", flush=True)
+                tk = [buf[24 + k] / 100.0 for k in range(nb)]
+                print("   diagonal block done at us:", " ".join(f"{x:.0f}" for x in tk), flush=True)
+                print("   steps us:", " ".join(f"{b - a:.0f}" for a, b in zip([0.0] + tk[:-1], tk)), flush=True)
         print(f"N={N} routes {r0}/{r1}  launches {ms0:.3f} ms  flow {ms1:.3f} ms  rel|d alpha| {db:.2e}  rel|d U^-1| {dw:.2e}  "
               f"residual {res:.2e}", flush=True)
         del gp1, w0, w1

@@ -141,6 +141,89 @@ def test_pipelined_model_update_equals_the_plain_chain(N, n_s, panel):
     assert np.abs(mu + s2n[None, :] * gp.beta[:256] - prob["Y"][:256]).max() < 1e-9
 
 
+@pytest.mark.parametrize("N,n_s,panel", [(300, 2, 0), (500, 2, 0), (900, 2, 2), (1500, 4, 0), (2100, 2, 2), (2100, 3, 5), (2500, 2, 64),
+                                         (3300, 1, 0)])
+def test_tile_flow_model_update_agrees_with_the_chain_of_launches(N, n_s, panel):
+    """Round 6: the whole Cholesky as ONE resident kernel of tile tasks plus a resident diagonal-block workgroup per output,
+    dependencies through device counters (csrc/sr_flow.hip; opt-in: set_fact_pipeline(3)).  It sums in another order than the
+    chain of launches (left-looking band, panels of its own), so alpha and U^-1 agree to rounding, not bit for bit -- but every
+    tile has ONE order of summation whatever the workgroups' timing: repeated updates on one handle (the counters carry epochs)
+    and a second handle must reproduce the first bit for bit, which a stale read of a tile another XCD rewrote would not.
+    Panels of 2 / 3 / 5 blocks and none (64 > the number of block rows: everything left-looking), 1 - 4 outputs, 3 .. 26 blocks; below 3 blocks the
+    knob is accepted and the chain of launches runs."""
+    import torch
+    from safe_exploration_amd import workload, SimpleGPModel
+    prob = workload.make_problem(70 + N, N, n_s, 1, 4)
+    ref = SimpleGPModel(n_s, n_s, 1, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob))
+    ref.set_fact_pipeline(-1)
+    ref.train(prob["Z"], prob["Y"], opt_hyp=False)
+    assert ref.fact_route() == 0
+    a0, w0 = ref.export_state()
+    a0, w0 = a0.cpu().numpy().copy(), w0.cpu().numpy().copy()
+    del ref
+    first = None
+    for handle in range(2):
+        gp = SimpleGPModel(n_s, n_s, 1, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob))
+        gp.set_fact_panel(panel)
+        gp.set_fact_pipeline(3)
+        for rep in range(3 if handle == 0 else 1):
+            gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+            assert gp.fact_route() == (4 if N > 256 else 0), (N, gp.fact_route())
+            alpha, wt = gp.export_state()
+            got = (alpha.cpu().numpy().copy(), wt.cpu().numpy().copy())
+            if first is None:
+                first = got
+                assert np.abs(got[0] - a0).max() <= 1e-9 * np.abs(a0).max()
+                assert np.abs(got[1] - w0).max() <= 1e-10 * np.abs(w0).max()
+            else:
+                assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1]), (N, handle, rep)
+        if handle == 0:
+            # the posterior identity at the training inputs (the flow did factor THIS matrix)
+            s2n = prob["noise_var"] + 1e-5 + 1e-8
+            mu, _ = gp.predict(prob["Z"][:256])
+            assert np.abs(mu + s2n[None, :] * gp.beta[:256] - prob["Y"][:256]).max() < 1e-9
+            if N > 256:
+                # its diagnostics: every task of the plan was counted once
+                import ctypes
+                from safe_exploration_amd import _lib
+                nb = gp._handle.Np // 128
+                buf = (ctypes.c_uint * (24 + n_s * nb))()
+                assert _lib.lib.sr_gp_flow_stats(gp._handle.h, buf, len(buf)) == len(buf)
+                sg, tot = (ctypes.c_int * (4 * (nb + 1)))(), (ctypes.c_long * 4)()
+                p_eff = panel if panel > 0 else (2 if nb <= 12 else (3 if nb <= 28 else 4))
+                assert _lib.lib.sr_test_flow_plan(nb, 2, p_eff, sg, tot) == 0
+                assert sum(buf[4 * k] for k in range(6)) == tot[3] * n_s
+                ticks = [buf[24 + k] for k in range(nb)]
+                assert all(b > a for a, b in zip(ticks, ticks[1:]))
+        del gp
+    torch.cuda.synchronize()
+
+
+def test_tile_flow_reports_a_matrix_that_is_not_positive_definite():
+    """A breakdown inside the resident diagonal-block workgroup (a NaN among the training inputs: the pivot of its row is not
+    positive) is reported like the launched kernel's -- LinAlgError naming the same pivot --, nothing hangs, and the handle
+    takes a good model afterwards, by the tile flow again."""
+    from safe_exploration_amd import workload, SimpleGPModel
+    N, n_s = 900, 2
+    prob = workload.make_problem(7, N, n_s, 1, 4)
+    Z = prob["Z"].copy()
+    Z[300, 0] = np.nan
+    res = {}
+    for knob in (-1, 3):
+        gp = SimpleGPModel(n_s, n_s, 1, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob))
+        gp.set_fact_pipeline(knob)
+        with pytest.raises(np.linalg.LinAlgError) as exc:
+            gp.train(Z, prob["Y"], opt_hyp=False)
+        res[knob] = str(exc.value).split("breakdown:")[-1]
+        gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+        assert gp.fact_route() == (4 if knob == 3 else 0)
+        mu, _ = gp.predict(prob["Z"][:64])
+        s2n = prob["noise_var"] + 1e-5 + 1e-8
+        assert np.abs(mu + s2n[None, :] * gp.beta[:64] - prob["Y"][:64]).max() < 1e-9
+        del gp
+    assert res[-1] == res[3], res
+
+
 # ------------------------------------------------------------------ GP fit + predict
 @pytest.mark.parametrize("name,n_s,n_u", [("gp_pend.npz", 2, 1), ("gp_cart.npz", 4, 1)])
 def test_predict_matches_golden_and_oracle(name, n_s, n_u):

@@ -436,7 +436,11 @@ def test_only_the_documented_kernels_use_scratch():
     assert len(rows) > 200
     allowed = {"void sr_ellipsoid_kernel<8, 3>", "void sr_ellipsoid_kernel<8, 4>",
                "void sr_gp_small_general_kernel<256, 8>", "void sr_gp_small_general_kernel<384, 8>",
-               "void sr_gp_small_general_kernel<512, 8>"}
+               "void sr_gp_small_general_kernel<512, 8>",
+               # the opt-in tile-flow Cholesky (csrc/sr_flow.hip): both tile sizes in one resident kernel, 32 bytes per lane;
+               # its resident diagonal-block workgroup (the launched kernel's block routine inside a loop over the blocks, at
+               # 128 VGPRs for 16 wavefronts): 44 bytes per lane
+               "sr_flow_worker_kernel", "sr_flow_diag_server_kernel"}
     spilled = {r["kernel"] for r in rows if int(r.get("ScratchSize", 0)) > 0}
     assert spilled <= allowed, sorted(spilled - allowed)
 
@@ -458,3 +462,130 @@ def test_bench_rank_section_and_single_rank_gather():
     assert bench.XGMI_LINK_GBS == 153.0
     args = bench.parse_args(["--workload", "c4", "--gpus", "2"])
     assert args.c4_replicas is False and bench.parse_args(["--c4-replicas"]).c4_replicas is True
+
+
+def _flow_tasks(nb, band, P, segs):
+    """the tile-flow Cholesky's task order as csrc/sr_flow.hip decodes it (fl_decode and the position -> task step of the
+    worker kernel), in Python: a list of (kind, ...) tuples in the order the positions are handed out"""
+    near = lambda i: min(nb - 1 - i, band)                                           # noqa: E731
+    upd_rows = lambda q, bi: max(0, nb - bi - band - 1) if bi < (q + 2) * P else nb - bi   # noqa: E731
+
+    def critical(qi):
+        s = max(i for i in range(nb) if segs[i][0] <= qi)
+        e = qi - segs[s][0]
+        n_sol = 4 * near(s)
+        if e < n_sol:
+            return ("solve64", s, s + 1 + (e >> 2), (e >> 1) & 1, e & 1)
+        e -= n_sol
+        i = s + 1
+        p = i // P
+        k_lo, apt = ((p - 1) * P, p - 1) if p >= 1 else (0, 0)
+        if e < 3:
+            return ("upd64", i, i, 1 if e == 2 else 0, 0 if e == 0 else 1, k_lo, apt)
+        e -= 3
+        return ("upd64", i, i + 1 + (e >> 2), (e >> 1) & 1, e & 1, k_lo, apt)
+
+    def far(qi):
+        i = max(r for r in range(nb) if segs[r][1] <= qi and (segs[r + 1][1] > qi or segs[r + 1][1] == segs[r][1] and False))
+        return ("far", i, i + 1 + near(i) + (qi - segs[i][1]), (i // P) * P, i // P)
+
+    def update(qi):
+        q, base = 0, 0
+        while True:
+            cnt = sum(upd_rows(q, bi) for bi in range((q + 1) * P, nb))
+            if qi < base + cnt:
+                break
+            base += cnt
+            q += 1
+        idx, bi = qi - base, (q + 1) * P
+        while idx >= upd_rows(q, bi):
+            idx -= upd_rows(q, bi)
+            bi += 1
+        return ("UPD", q, bi, (bi + band + 1 if bi < (q + 2) * P else bi) + idx)
+
+    out = []
+    for i in range(nb):
+        nbk, nc, nf = segs[i + 1][2] - segs[i][2], segs[i + 1][0] - segs[i][0], segs[i + 1][1] - segs[i][1]
+        n_sol = 4 * near(i)
+        out += [update(segs[i][2] + e) for e in range(nbk)]
+        out += [critical(segs[i][0] + e) for e in range(n_sol)]
+        out += [far(segs[i][1] + e) for e in range(nf)]
+        out += [critical(segs[i][0] + e) for e in range(n_sol, nc)]
+    return out
+
+
+@pytest.mark.parametrize("nb,band,panel", [(3, 2, 2), (5, 3, 4), (7, 2, 2), (16, 2, 3), (23, 1, 3), (40, 2, 4), (12, 2, 100), (9, 0, 2)])
+def test_tile_flow_plan_covers_every_block_once_and_orders_dependencies(lib_built, nb, band, panel):
+    """The task plan of the tile-flow Cholesky (csrc/sr_flow.h, sr_flow_plan; the decoding mirrored above).  Every tile of the
+    factor is produced exactly once, every block takes every panel in front of it exactly once (by a UPD task, or left-looking
+    inside its band task), and whatever a task waits for stands IN FRONT of it in the one order the positions are handed out
+    in -- which is what makes the resident kernel deadlock-free for any number of resident workgroups."""
+    import ctypes
+    from safe_exploration_amd import _lib
+    sg = (ctypes.c_int * (4 * (nb + 1)))()
+    tot = (ctypes.c_long * 4)()
+    assert _lib.lib.sr_test_flow_plan(nb, band, panel, sg, tot) == 0
+    segs = [tuple(sg[4 * i:4 * i + 4]) for i in range(nb + 1)]
+    assert [s[3] for s in segs] == sorted(s[3] for s in segs) and segs[nb][3] == tot[3] == tot[0] + tot[1] + tot[2]
+    tasks = _flow_tasks(nb, band, panel, segs)
+    assert len(tasks) == tot[3] and len(set(tasks)) == len(tasks)
+    pos = {t: k for k, t in enumerate(tasks)}
+    P = panel
+    near = lambda i: min(nb - 1 - i, band)                                           # noqa: E731
+    # -- coverage: factor tiles
+    solved64 = {(t[1], t[2], t[3], t[4]) for t in tasks if t[0] == "solve64"}
+    assert solved64 == {(i, j, rh, ch) for i in range(nb) for j in range(i + 1, i + 1 + near(i)) for rh in (0, 1) for ch in (0, 1)}
+    assert {(t[1], t[2]) for t in tasks if t[0] == "far"} == {(i, j) for i in range(nb) for j in range(i + 1 + near(i), nb)}
+    upd64 = {(t[1], t[2], t[3], t[4]) for t in tasks if t[0] == "upd64"}
+    want64 = {(i, i, rh, ch) for i in range(1, nb) for rh, ch in ((0, 0), (0, 1), (1, 1))}
+    want64 |= {(i, j, rh, ch) for i in range(1, nb) for j in range(i + 1, i + 1 + near(i)) for rh in (0, 1) for ch in (0, 1)}
+    assert upd64 == want64
+    # -- coverage: every block (i, j) takes the factor rows 0 .. i - 1 exactly once
+    upd = {(t[1], t[2], t[3]) for t in tasks if t[0] == "UPD"}
+    for i in range(nb):
+        for j in range(i, nb):
+            band_block = j - i <= band
+            got = []
+            for q in range(nb):
+                if (q, i, j) in upd:
+                    got += list(range(q * P, (q + 1) * P))
+            if band_block and i >= 1:
+                k_lo = next(t[5] for t in tasks if t[0] == "upd64" and t[1] == i and t[2] == j)
+                got += list(range(k_lo, i))
+            elif not band_block:
+                got += list(range((i // P) * P, i))
+            assert sorted(got) == list(range(i)), (i, j, got)
+    # -- order: what a task waits for is in front of it
+    def tr_pos(k, c64):                 # who makes the factor's block row k final at 64-column c64
+        j, ch = divmod(c64, 2)
+        if j - k <= band:
+            return max(pos[("solve64", k, j, rh, ch)] for rh in (0, 1))
+        return pos[next(t for t in tasks if t[0] == "far" and t[1] == k and t[2] == j)]
+    diag_pos = lambda i: max(pos[t] for t in tasks if t[0] == "upd64" and t[1] == i and t[2] == i) if i else -1   # noqa: E731
+    for t, k in pos.items():
+        if t[0] == "UPD":
+            q, bi, bj = t[1:]
+            if q > 0:
+                assert pos[("UPD", q - 1, bi, bj)] < k
+            for kk in range(q * P, (q + 1) * P):
+                for c in (2 * bi, 2 * bi + 1, 2 * bj, 2 * bj + 1):
+                    assert tr_pos(kk, c) < k, (t, kk, c)
+        elif t[0] == "upd64":
+            i, j, rh, ch, k_lo, apt = t[1:]
+            if apt > 0:
+                assert pos[("UPD", apt - 1, i, j)] < k
+            for kk in range(k_lo, i):
+                assert tr_pos(kk, 2 * i + rh) < k and tr_pos(kk, 2 * j + ch) < k, (t, kk)
+        elif t[0] == "solve64":
+            i, j, rh, ch = t[1:]
+            assert diag_pos(i) < k
+            if i > 0:
+                assert all(pos[next(u for u in tasks if u[0] == "upd64" and u[1:5] == (i, j, r2, ch))] < k for r2 in (0, 1))
+        else:
+            i, j, k_lo, apt = t[1:]
+            assert diag_pos(i) < k
+            if apt > 0:
+                assert pos[("UPD", apt - 1, i, j)] < k
+            for kk in range(k_lo, i):
+                for c in (2 * i, 2 * i + 1, 2 * j, 2 * j + 1):
+                    assert tr_pos(kk, c) < k, (t, kk, c)
