@@ -44,6 +44,7 @@ struct sr_flow_params {
     int Np, nb, n_out, band, panel;
     long total, total_far, total_upd;   // tasks per output: critical, far blocks, panel updates
     long total_m;                // tasks per output in the one order
+    int prio;                    // issue priorities for far blocks / next-panel updates (1) or for the band only (0)
     int keep, exit_row;          // workgroups with blockIdx >= keep leave after a row task of block row >= exit_row
     const sr_flow_seg* segs;     // nb + 1 segments
     unsigned* flags;

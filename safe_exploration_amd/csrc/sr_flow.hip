@@ -422,7 +422,13 @@ __global__ __launch_bounds__(256, 2) void sr_flow_worker_kernel(sr_flow_params P
         unsigned* apw = ap + (long)T.i * nb + T.j;
         const long r0 = (long)T.i * SR_NB + T.moff;
         bool ok;
-        if (T.kind == 2 || (T.kind == 4 && T.j == T.i + 1)) __builtin_amdgcn_s_setprio(2);      // between two diagonal blocks
+        // Issue priority on a CU shared with another workgroup: the band (between two diagonal blocks) first, then whatever the
+        // NEXT block row waits for column by column -- a far block's update + solve is a link of a chain over the rows of its
+        // column, and at the matrix pipe's half rate (beside a UPD task) that link is longer than a block step -- then the UPD
+        // tasks of the next panel's rows, last the bulk.  (lab: SR_FLOW_PRIO=0 only the band)
+        if (T.kind >= 2 && T.kind <= 4) __builtin_amdgcn_s_setprio(3);
+        else if (T.kind == 5 && P.prio) __builtin_amdgcn_s_setprio(2);
+        else if (T.kind == 0 && P.prio) __builtin_amdgcn_s_setprio(1);
         if (T.op == 0) {
             ok = fl_accum<fl_tile64>(cx, U, W, Np, r0, T.n0, T.k_lo, T.k_hi, tr, nt, apw, T.apt, smem);
             if (ok) fl_publish1(ac + (long)T.i * nt + (T.n0 >> 6));

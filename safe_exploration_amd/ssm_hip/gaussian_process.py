@@ -1059,8 +1059,9 @@ class SimpleGPModel(StateSpaceModel):
 
     def set_fact_pipeline(self, on):
         """model updates of 3 .. 128 blocks of 128 rows: 0 (default) one chain of launches; 1 / 2 the pipelined prototypes of
-        round 6 (diagonal blocks beside the previous block row: measured slower); identical numbers either way
-        (sr_gp_set_fact_pipeline).  Works before training too."""
+        round 6 (diagonal blocks beside the previous block row: measured slower; identical numbers); 3 the
+        tile-flow Cholesky (one resident kernel of tile tasks, csrc/sr_flow.hip: at parity, results to rounding); -1 never the
+        tile flow (sr_gp_set_fact_pipeline).  Works before training too."""
         self._fact_pipeline = int(on)
         if self._handle is not None:
             check(lib.sr_gp_set_fact_pipeline(self._handle.h, self._fact_pipeline))

@@ -46,6 +46,8 @@ fi
 # the 16-pivot chain of the diagonal-block kernel and the fp64 MFMA issue rate in isolation (built by scripts/build_bins.sh)
 if [ -x scripts/_bin/pivot ]; then ./scripts/_bin/pivot > "$EV/${TAG}_pivot_chain.txt" 2>>"$EV/.err"; fi
 if [ -x scripts/_bin/mfma_issue ]; then ./scripts/_bin/mfma_issue > "$EV/${TAG}_mfma_issue.txt" 2>>"$EV/.err"; fi
+# the opt-in tile-flow Cholesky beside the chain of launches (same box), its lab sweep and its own diagnostics
+{ bash scripts/flow_cmp.sh; SR_FLOW_STATS=1 timeout 200 python scripts/flow_check.py 2000 5000; } > "$EV/${TAG}_flow_cmp.txt" 2>>"$EV/.err"
 timeout 300 python scripts/refit_ab.py 500,1000,2000,5000,10000 > "$EV/${TAG}_refit_sizes.txt" 2>>"$EV/.err"
 timeout 300 python scripts/numpy_latency.py > "$EV/${TAG}_numpy_latency.txt" 2>>"$EV/.err"
 timeout 300 python scripts/exploration_step.py > "$EV/${TAG}_exploration_step.txt" 2>>"$EV/.err"
