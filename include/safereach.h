@@ -366,6 +366,10 @@ int sr_test_chain_drop(sr_gp_t h, int drop);
  * task, far task, panel update, position in the one order of block row i (i = 0 .. nb: one behind the last); totals[0..3] =
  * critical tasks, far tasks, panel updates, positions per output. */
 int sr_test_flow_plan(int nb, int band, int panel, int* segs, long* totals);
+/* n > 0: the next n tile-flow model updates of this process fail ON THE DEVICE (their diagonal-block workgroups never get
+ * their go: every wait runs into its time-out, the status word is raised) -- sr_gp_factorize must then repeat the update by
+ * launches and stay on launches; n = 0: forget that (the tile flow may run again). */
+int sr_test_flow_fail(int n);
 /* diagnostic: the next n launches of the one-launch append of a grid of workgroups (sr_gp_append / sr_gp_append1_host with
  * one point beyond 512 padded rows) wait at their first device-wide barrier for a workgroup that does not exist and give
  * it up after ~5 ms: the deterministic way into the path a grid takes that cannot become resident as a whole (nothing of

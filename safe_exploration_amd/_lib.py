@@ -96,6 +96,7 @@ SIGNATURES = {
     "sr_gp_fact_pipelined": (_I, [_H]),
     "sr_gp_flow_stats": (_I, [_H, ctypes.POINTER(ctypes.c_uint), _I]),
     "sr_test_flow_plan": (_I, [_I, _I, _I, _PI, _PL]),
+    "sr_test_flow_fail": (_I, [_I]),
     "sr_test_gemm_tn": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_gemm_tn_upper": (_I, [_I, _P, _L, _P, _L, _P, _L, _I, _I, _I, _D, _D, _I, _P]),
     "sr_test_potrf_diag": (_I, [_I, _P, _L, _P, _P, _L, _P, _I, _P]),

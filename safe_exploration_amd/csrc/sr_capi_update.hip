@@ -10,6 +10,7 @@ using namespace srh;
 static std::atomic<bool> g_pipe_broken{false};
 // ... or a wait of the tile-flow Cholesky did (its diagonal-block workgroups not resident, or on the workers' hardware queue)
 static std::atomic<bool> g_flow_broken{false};
+static std::atomic<int> g_test_flow_fail{0};          // sr_test_flow_fail: the next tile flows' diagonal-block workgroups never get their go
 
 // ---------------------------------------------------------------------------------------------
 // factorisation: K = U^T U (right-looking, 128-blocks in panels, look-ahead), U^-T / U^-1 by recursive halving
@@ -518,7 +519,11 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             // the diagonal-block workgroups first -- they must be resident when the workers fill the chip; the caller's stream
             // is drained so that they do not wait for their go longer than the Gram kernel takes
             SR_FH(hipStreamSynchronize(s0));
-            SR_F(sr_launch_flow_diag_server(U, Np, Wt, W, Np, nb, flow_panel, info_dev + d0, h->flow_flags, flow_ep, SR_FLOW_TIMEOUT_S,
+            // (test hook: an epoch nobody publishes -- they leave after their time-out, the workers' waits run into theirs, the
+            //  status word is raised and the update is repeated by launches)
+            const unsigned srv_ep = g_test_flow_fail.load() > 0 ? flow_ep + 0x40000000u : flow_ep;
+            if (g_test_flow_fail.load() > 0) --g_test_flow_fail;
+            SR_F(sr_launch_flow_diag_server(U, Np, Wt, W, Np, nb, flow_panel, info_dev + d0, h->flow_flags, srv_ep, SR_FLOW_TIMEOUT_S,
                                             SR_FLOW_TIMEOUT_S, srv, &b_diag));
             SR_FH(hipMemsetAsync(h->flow_flags + SR_FLOW_STATUS, 0,
                                  sizeof(unsigned) * (size_t)(SR_FLOW_HDR - SR_FLOW_STATUS + (long)h->n_out * sr_flow_words(nb)), sc));
@@ -846,6 +851,15 @@ extern "C" int sr_gp_set_fact_pipeline(sr_gp_t h, int on) {
 }
 
 extern "C" int sr_gp_fact_pipelined(sr_gp_t h) { return h ? h->last_fact_pipe : 0; }
+
+extern "C" int sr_test_flow_fail(int n) {
+    // n > 0: the next n tile-flow updates of this process fail on the device (see sr_gp_factorize); n = 0: forget that one did
+    // (a failed flow keeps the process on the chain of launches from then on)
+    SR_CHECK(n >= 0, SR_EINVAL, "sr_test_flow_fail: bad argument");
+    g_test_flow_fail.store(n);
+    if (n == 0) g_flow_broken.store(false);
+    return SR_OK;
+}
 
 extern "C" int sr_test_flow_plan(int nb, int band, int panel, int* segs, long* totals) {
     SR_CHECK(nb >= 1 && nb <= 4096 && band >= 0 && panel >= 1 && segs && totals, SR_EINVAL, "sr_test_flow_plan: bad argument");

@@ -354,7 +354,7 @@ int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* pa
 #define SR_FLOW_MIN_NB 1000           /* model update: tile-flow Cholesky (sr_flow.hip) from this many blocks ... */
 #define SR_FLOW_MAX_NB 0              /* ... up to this many (empty range: opt-in through sr_gp_set_fact_pipeline(h, 3)) */
 #define SR_FLOW_BAND 2                /* blocks right of the diagonal block that go in 64 x 64 tiles */
-static inline int sr_flow_panel(int nb) { return nb <= 12 ? 2 : (nb <= 28 ? 3 : 4); }   /* block rows per panel of the tile flow */
+static inline int sr_flow_panel(int nb) { return nb <= 12 ? 2 : (nb <= 28 ? 3 : (nb <= 36 ? 4 : (nb <= 44 ? 6 : 8))); }   /* block rows per panel of the tile flow */
 #define SR_FLOW_KEEP_WGS 128          /* tile flow: workgroups that stay to the end ... */
 #define SR_FLOW_EXIT_PCT 50           /* ... the others leave after a row task past this percentage of the block rows */
 #define SR_FLOW_TIMEOUT_S 0.25        /* a wait of the tile flow that lasts longer gives up (the host repeats the update by launches) */

@@ -190,13 +190,45 @@ def test_tile_flow_model_update_agrees_with_the_chain_of_launches(N, n_s, panel)
                 buf = (ctypes.c_uint * (24 + n_s * nb))()
                 assert _lib.lib.sr_gp_flow_stats(gp._handle.h, buf, len(buf)) == len(buf)
                 sg, tot = (ctypes.c_int * (4 * (nb + 1)))(), (ctypes.c_long * 4)()
-                p_eff = panel if panel > 0 else (2 if nb <= 12 else (3 if nb <= 28 else 4))
+                p_eff = panel if panel > 0 else (2 if nb <= 12 else (3 if nb <= 28 else (4 if nb <= 36 else (6 if nb <= 44 else 8))))
                 assert _lib.lib.sr_test_flow_plan(nb, 2, p_eff, sg, tot) == 0
                 assert sum(buf[4 * k] for k in range(6)) == tot[3] * n_s
                 ticks = [buf[24 + k] for k in range(nb)]
                 assert all(b > a for a, b in zip(ticks, ticks[1:]))
         del gp
     torch.cuda.synchronize()
+
+
+def test_tile_flow_that_fails_on_the_device_is_repeated_by_launches():
+    """Every wait of the tile flow has a time-out (0.25 s), and a wait that runs into it raises a status word that makes
+    everybody leave: the resident kernels END, whatever happened.  The update is then repeated by launches -- the caller gets
+    the right model, late -- and the process stays on launches (sr_test_flow_fail: the diagonal-block workgroups are given an
+    epoch nobody publishes)."""
+    import time
+    from safe_exploration_amd import workload, SimpleGPModel, _lib
+    N, n_s = 900, 2
+    prob = workload.make_problem(11, N, n_s, 1, 4)
+    s2n = prob["noise_var"] + 1e-5 + 1e-8
+    gp = SimpleGPModel(n_s, n_s, 1, kern_types=["rbf"] * n_s, hyp=workload.hyp_list(prob))
+    gp.set_fact_pipeline(3)
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+    assert gp.fact_route() == 4
+    try:
+        assert _lib.lib.sr_test_flow_fail(1) == 0
+        t0 = time.perf_counter()
+        gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+        took = time.perf_counter() - t0
+        assert gp.fact_route() == 0 and took < 5.0, (gp.fact_route(), took)
+        mu, _ = gp.predict(prob["Z"][:128])
+        assert np.abs(mu + s2n[None, :] * gp.beta[:128] - prob["Y"][:128]).max() < 1e-9
+        gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+        assert gp.fact_route() == 0          # once failed: launches from then on
+    finally:
+        assert _lib.lib.sr_test_flow_fail(0) == 0
+    gp.train(prob["Z"], prob["Y"], opt_hyp=False)
+    assert gp.fact_route() == 4
+    mu, _ = gp.predict(prob["Z"][:128])
+    assert np.abs(mu + s2n[None, :] * gp.beta[:128] - prob["Y"][:128]).max() < 1e-9
 
 
 def test_tile_flow_reports_a_matrix_that_is_not_positive_definite():
