@@ -554,7 +554,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             static const int flow_prio = (int)sr_lab_env("SR_FLOW_PRIO", 1);
             static const int flow_keep_lab = (int)sr_lab_env("SR_FLOW_KEEP", -1), flow_exit_lab = (int)sr_lab_env("SR_FLOW_EXIT_PCT", -1);
             const int flow_keep = flow_keep_lab >= 0 ? flow_keep_lab : SR_FLOW_KEEP_WGS;
-            const int flow_exit_row = (finv && nb >= 8) ? nb * (flow_exit_lab >= 0 ? flow_exit_lab : SR_FLOW_EXIT_PCT) / 100 : nb;
+            const int flow_exit_row = (finv && nb >= 8) ? nb * (flow_exit_lab >= 0 ? flow_exit_lab : (nb <= 64 ? SR_FLOW_EXIT_PCT : SR_FLOW_EXIT_PCT_BIG)) / 100 : nb;
             const sr_flow_params fp{U, W, Wt, sP, sN, Np, nb, nd, flow_band, flow_panel, total, h->flow_total_far, h->flow_total_upd, h->flow_total_m, flow_prio, flow_keep, flow_exit_row, (const sr_flow_seg*)h->flow_segs,
                                     h->flow_flags, flow_ep, (unsigned long long)(SR_FLOW_TIMEOUT_S * 1e8), flow_acq};
             if (h->ncu == 0) {

@@ -357,6 +357,7 @@ int sr_launch_var_bal(const double* Wt, const double* Ks, double* Vt, double* pa
 static inline int sr_flow_panel(int nb) { return nb <= 12 ? 2 : (nb <= 28 ? 3 : (nb <= 36 ? 4 : (nb <= 44 ? 6 : 8))); }   /* block rows per panel of the tile flow */
 #define SR_FLOW_KEEP_WGS 128          /* tile flow: workgroups that stay to the end ... */
 #define SR_FLOW_EXIT_PCT 50           /* ... the others leave after a row task past this percentage of the block rows */
+#define SR_FLOW_EXIT_PCT_BIG 65       /* ... beyond 64 block rows (GEMM-bound for longer; N = 14000: 61.0 -> 59.4 ms, profiles/r06_flow.txt) */
 #define SR_FLOW_TIMEOUT_S 0.25        /* a wait of the tile flow that lasts longer gives up (the host repeats the update by launches) */
 #define SR_FACT_ONE_STREAM_MAX_NB 15 /* model update: up to here every launch stays on the caller's stream (no side streams, no events) */
 #define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch of one workgroup per output up to this padded size (the grown model: <= 640) */
