@@ -259,14 +259,12 @@ int sr_gp_set_var_variant(sr_gp_t h, int variant);
 /* blocks of 128 rows per Cholesky panel of sr_gp_factorize (the trailing matrix is read-modify-written once per
  * panel); 0 = chosen by size (default).  Results agree to rounding; a measurement knob. */
 int sr_gp_set_fact_panel(sr_gp_t h, int panel);
-/* sr_gp_factorize between 3 and 128 blocks of 128 rows, a measured prototype (round 6): 1 runs the diagonal-block kernel on
- * a stream of its own beside the rest of the previous block row, 2 keeps it on the critical stream and moves only the
- * rest of the rows; the streams hand over through device counters.  0 (default) = one chain of launches: the pipelined
- * forms are 1.2 - 2.8 times SLOWER on this part (profiles/r06_fact_pipeline.txt).  Same tiles, same order of summation:
- * identical numbers.  3 = the tile-flow Cholesky (csrc/sr_flow.hip: the whole factorisation as ONE resident kernel of tile
- * tasks plus a resident diagonal-block workgroup per output, dependencies through device counters; results agree with the
- * launched form to rounding); -1 = never the tile flow.  sr_gp_fact_pipelined: how the last update of h ran -- 0 one chain
- * of launches, 1 pipelined prototype, 4 tile flow. */
+/* How sr_gp_factorize runs between 3 and 128 blocks of 128 rows.  0 (default) = one chain of launches.  1 / 2 = the pipelined
+ * prototypes of round 6 (diagonal blocks on a stream of their own / only the rest of the rows moved; identical numbers,
+ * 1.2 - 2.8 times slower: profiles/r06_fact_pipeline.txt).  3 = the tile-flow Cholesky (csrc/sr_flow.hip: ONE resident
+ * kernel of tile tasks plus a resident diagonal-block workgroup per output, device counters for dependencies; results to
+ * rounding, time within 1 - 3 % of the launched form from N = 5000 on: profiles/r06_flow.txt).  -1 = never the tile flow.
+ * sr_gp_fact_pipelined: how the last update of h ran -- 0 chain of launches, 1 pipelined prototype, 4 tile flow. */
 int sr_gp_set_fact_pipeline(sr_gp_t h, int on);
 int sr_gp_fact_pipelined(sr_gp_t h);
 /* diagnostics of the last tile-flow update (SR_ESTATE if it was none): out[0..23] = per kind of task (look-ahead update,
