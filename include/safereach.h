@@ -263,7 +263,7 @@ int sr_gp_set_fact_panel(sr_gp_t h, int panel);
  * prototypes of round 6 (diagonal blocks on a stream of their own / only the rest of the rows moved; identical numbers,
  * 1.2 - 2.8 times slower: profiles/r06_fact_pipeline.txt).  3 = the tile-flow Cholesky (csrc/sr_flow.hip: ONE resident
  * kernel of tile tasks plus a resident diagonal-block workgroup per output, device counters for dependencies; results to
- * rounding, time within 1 - 3 % of the launched form from N = 5000 on: profiles/r06_flow.txt).  -1 = never the tile flow.
+ * rounding, time within 2 % of the launched form from N = 6000 on, behind below: profiles/r06_flow.txt).  -1 = never the tile flow.
  * sr_gp_fact_pipelined: how the last update of h ran -- 0 chain of launches, 1 pipelined prototype, 4 tile flow. */
 int sr_gp_set_fact_pipeline(sr_gp_t h, int on);
 int sr_gp_fact_pipelined(sr_gp_t h);

@@ -410,6 +410,11 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     }
     h->last_fact_pipe = pipe ? 1 : (flow ? 4 : 0);
     unsigned flow_ep = 0;
+    // a wait of the tile flow that lasts longer gives up.  It grows with the size of the update: the FIRST update on fresh
+    // scratch memory of many gigabytes can stand still for seconds (page-table work inside the first kernels: 4.0 - 4.8 s for
+    // the first update at N = 50000 against 2.67), and a wait that gives up keeps the process on launches from then on
+    // (one of ten updates at N = 14000 did, once, with the fixed quarter of a second)
+    const double flow_timeout_s = SR_FLOW_TIMEOUT_S + 1e-12 * (double)h->n_out * (double)Np * (double)Np * (double)Np;
     static const int flow_band_lab = (int)sr_lab_env("SR_FLOW_BAND", -1), flow_acq = (int)sr_lab_env("SR_FLOW_ACQ", 0);
     const int flow_band = flow_band_lab >= 0 ? flow_band_lab : SR_FLOW_BAND;
     static const int flow_panel_lab = (int)sr_lab_env("SR_FLOW_PANEL", 0);
@@ -523,8 +528,8 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             //  status word is raised and the update is repeated by launches)
             const unsigned srv_ep = g_test_flow_fail.load() > 0 ? flow_ep + 0x40000000u : flow_ep;
             if (g_test_flow_fail.load() > 0) --g_test_flow_fail;
-            SR_F(sr_launch_flow_diag_server(U, Np, Wt, W, Np, nb, flow_panel, info_dev + d0, h->flow_flags, srv_ep, SR_FLOW_TIMEOUT_S,
-                                            SR_FLOW_TIMEOUT_S, srv, &b_diag));
+            SR_F(sr_launch_flow_diag_server(U, Np, Wt, W, Np, nb, flow_panel, info_dev + d0, h->flow_flags, srv_ep, flow_timeout_s,
+                                            flow_timeout_s, srv, &b_diag));
             SR_FH(hipMemsetAsync(h->flow_flags + SR_FLOW_STATUS, 0,
                                  sizeof(unsigned) * (size_t)(SR_FLOW_HDR - SR_FLOW_STATUS + (long)h->n_out * sr_flow_words(nb)), sc));
         }
@@ -556,7 +561,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             const int flow_keep = flow_keep_lab >= 0 ? flow_keep_lab : SR_FLOW_KEEP_WGS;
             const int flow_exit_row = (finv && nb >= 8) ? nb * (flow_exit_lab >= 0 ? flow_exit_lab : (nb <= 64 ? SR_FLOW_EXIT_PCT : SR_FLOW_EXIT_PCT_BIG)) / 100 : nb;
             const sr_flow_params fp{U, W, Wt, sP, sN, Np, nb, nd, flow_band, flow_panel, total, h->flow_total_far, h->flow_total_upd, h->flow_total_m, flow_prio, flow_keep, flow_exit_row, (const sr_flow_seg*)h->flow_segs,
-                                    h->flow_flags, flow_ep, (unsigned long long)(SR_FLOW_TIMEOUT_S * 1e8), flow_acq};
+                                    h->flow_flags, flow_ep, (unsigned long long)(flow_timeout_s * 1e8), flow_acq};
             if (h->ncu == 0) {
                 int cus = 0;
                 SR_FH(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
@@ -575,7 +580,7 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
             if (finv && nb >= 8 && !flow_no_inv) {
                 SR_F(ensure_fact_events(h));
                 for (int X = nb / 2; X < nb;) {
-                    SR_F(sr_launch_flow_gate(h->flow_flags, flow_ep, nd, nb, X, SR_FLOW_TIMEOUT_S, finv));
+                    SR_F(sr_launch_flow_gate(h->flow_flags, flow_ep, nd, nb, X, flow_timeout_s, finv));
                     SR_F(inv_stage(X, finv, false));
                     const int nxt = (X + nb) / 2;
                     if (nb - nxt < 3 || nxt <= X) break;

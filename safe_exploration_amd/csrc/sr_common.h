@@ -358,7 +358,7 @@ static inline int sr_flow_panel(int nb) { return nb <= 12 ? 2 : (nb <= 28 ? 3 : 
 #define SR_FLOW_KEEP_WGS 128          /* tile flow: workgroups that stay to the end ... */
 #define SR_FLOW_EXIT_PCT 50           /* ... the others leave after a row task past this percentage of the block rows */
 #define SR_FLOW_EXIT_PCT_BIG 65       /* ... beyond 64 block rows (GEMM-bound for longer; N = 14000: 61.0 -> 59.4 ms, profiles/r06_flow.txt) */
-#define SR_FLOW_TIMEOUT_S 0.25        /* a wait of the tile flow that lasts longer gives up (the host repeats the update by launches) */
+#define SR_FLOW_TIMEOUT_S 0.25        /* a wait of the tile flow that lasts longer (+ 1 ps per output and Np^3: sr_capi_update.hip) gives up (the host repeats the update by launches) */
 #define SR_FACT_ONE_STREAM_MAX_NB 15 /* model update: up to here every launch stays on the caller's stream (no side streams, no events) */
 #define SR_APPEND1_MAX_NP0 512       /* +1 point in ONE launch of one workgroup per output up to this padded size (the grown model: <= 640) */
 #define SR_APPEND1G_MAX_NP0 8192     /* +1 point in ONE launch of a grid of workgroups up to this padded size (K* row in LDS) */
