@@ -366,7 +366,8 @@ int sr_test_chain_drop(sr_gp_t h, int drop);
 int sr_test_flow_plan(int nb, int band, int panel, int* segs, long* totals);
 /* n > 0: the next n tile-flow model updates of this process fail ON THE DEVICE (their diagonal-block workgroups never get
  * their go: every wait runs into its time-out, the status word is raised) -- sr_gp_factorize must then repeat the update by
- * launches and stay on launches; n = 0: forget that (the tile flow may run again). */
+ * launches, and the process' next 16 (then 32, .. 4096) would-be tile flows run by launches too; n = 0: forget that (the tile
+ * flow runs again at once). */
 int sr_test_flow_fail(int n);
 /* diagnostic: the next n launches of the one-launch append of a grid of workgroups (sr_gp_append / sr_gp_append1_host with
  * one point beyond 512 padded rows) wait at their first device-wide barrier for a workgroup that does not exist and give

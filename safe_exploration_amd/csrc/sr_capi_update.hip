@@ -9,7 +9,11 @@ using namespace srh;
 // its hardware queues): the process stays on the plain chain from then on
 static std::atomic<bool> g_pipe_broken{false};
 // ... or a wait of the tile-flow Cholesky did (its diagonal-block workgroups not resident, or on the workers' hardware queue)
-static std::atomic<bool> g_flow_broken{false};
+// A flow that failed rests: the next g_flow_rest updates that would be tile flows run by launches, then it is tried again; every
+// further failure doubles the rest (16, 32, .. 4096 updates).  (Not "never again": the one spurious time-out seen -- a first update
+// on fresh scratch of many gigabytes -- would have kept its process on launches for good.)
+static std::atomic<long> g_flow_rest{0};
+static std::atomic<long> g_flow_rest_len{16};
 static std::atomic<int> g_test_flow_fail{0};          // sr_test_flow_fail: the next tile flows' diagonal-block workgroups never get their go
 
 // ---------------------------------------------------------------------------------------------
@@ -371,7 +375,8 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     // One batch of outputs only (the counters are zeroed once per update).
     static const int flow_lab = (int)sr_lab_env("SR_FACT_FLOW", -1);                     // (lab build: 1 = wherever it can run)
     const bool want_flow = h->fact_pipe == 3 || (h->fact_pipe == 0 && (flow_lab == 1 || (nb >= SR_FLOW_MIN_NB && nb <= SR_FLOW_MAX_NB)));
-    bool flow = want_flow && regime == 1 && nb >= 3 && n_par >= h->n_out && !g_flow_broken.load();
+    bool flow = want_flow && regime == 1 && nb >= 3 && n_par >= h->n_out;
+    if (flow && g_flow_rest.load() > 0) { --g_flow_rest; flow = false; }
     if (flow) {
         SR_F(flow_server_stream(h->device, s0, &srv, &finv));
         if (!srv) { flow = false; finv = nullptr; }
@@ -828,7 +833,9 @@ extern "C" int sr_gp_factorize(sr_gp_t h, void* stream, int* info) {
     if (pipe_status != 0) {
         // a hand-over gave up: whatever was computed behind it is void.  Once more, on the plain chain.
         if (flow) {
-            g_flow_broken.store(true);
+            const long len = g_flow_rest_len.load();
+            g_flow_rest.store(len);
+            g_flow_rest_len.store(std::min<long>(4096, 2 * len));
         } else {
             g_pipe_broken.store(true);
             (void)hipMemset(h->fact_flags, 0, sizeof(unsigned) * (size_t)(4 + 3 * h->fact_flags_nb));
@@ -861,10 +868,10 @@ extern "C" int sr_gp_fact_pipelined(sr_gp_t h) { return h ? h->last_fact_pipe : 
 
 extern "C" int sr_test_flow_fail(int n) {
     // n > 0: the next n tile-flow updates of this process fail on the device (see sr_gp_factorize); n = 0: forget that one did
-    // (a failed flow keeps the process on the chain of launches from then on)
+    // (a failed flow rests for 16, 32, .. updates of the process)
     SR_CHECK(n >= 0, SR_EINVAL, "sr_test_flow_fail: bad argument");
     g_test_flow_fail.store(n);
-    if (n == 0) g_flow_broken.store(false);
+    if (n == 0) { g_flow_rest.store(0); g_flow_rest_len.store(16); }
     return SR_OK;
 }
 
